@@ -1,0 +1,124 @@
+"""Synthetic genome-chunk generator for the blast-phase benchmarks and parity tests.
+
+Stands in for the evolver / chr20 / whole-genome inputs that BASELINE.json's configs name
+(/root/reference/examples/evolverMammals.txt:3-7 are URLs; there is no network).  The recipe
+follows SURVEY.md section 8(d) "Config 2": an iid ancestor, a query derived from it by substitutions
+(transitions twice as likely as each transversion), geometric-length indels, one inversion, one
+replaced segment, soft-masked runs and two N runs.  numpy's PCG64 replaces the xoshiro generator
+named there; the bytes are what both the oracle and the HIP path consume, so only determinism
+for a given (numpy version, seed) matters.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[_a] = _b
+
+
+def random_sequence(n: int, rng: np.random.Generator, p=(0.3, 0.2, 0.2, 0.3)) -> np.ndarray:
+    return _BASES[rng.choice(4, size=n, p=p)]
+
+
+def revcomp(seq: np.ndarray) -> np.ndarray:
+    return _COMP[seq[::-1]]
+
+
+def mutate(seq: np.ndarray, rng: np.random.Generator, sub_rate: float, indel_rate: float,
+           indel_mean: float = 3.0, indel_max: int = 50) -> np.ndarray:
+    """Substitutions (transition : each transversion = 2 : 1 : 1) then indel events."""
+    n = len(seq)
+    out = seq.copy()
+    # substitutions
+    hit = rng.random(n) < sub_rate
+    idx = np.nonzero(hit)[0]
+    if len(idx):
+        code = np.searchsorted(_BASES, out[idx])          # A0 C1 G2 T3
+        kind = rng.choice(3, size=len(idx), p=(0.5, 0.25, 0.25))
+        # transition: xor 2 ; transversions: xor 1 / xor 3
+        xor = np.array([2, 1, 3])[kind]
+        out[idx] = _BASES[code ^ xor]
+    if indel_rate <= 0:
+        return out
+    # indels: walk event positions
+    ev = np.nonzero(rng.random(n) < indel_rate)[0]
+    pieces = []
+    last = 0
+    for pos in ev:
+        if pos < last:
+            continue
+        ln = int(min(indel_max, rng.geometric(1.0 / indel_mean)))
+        pieces.append(out[last:pos])
+        if rng.random() < 0.5:                            # deletion
+            last = min(n, pos + ln)
+        else:                                             # insertion
+            pieces.append(random_sequence(ln, rng))
+            last = pos
+    pieces.append(out[last:])
+    return np.concatenate(pieces)
+
+
+def soft_mask(seq: np.ndarray, rng: np.random.Generator, frac: float, mean_run: int = 300) -> np.ndarray:
+    out = seq.copy()
+    n = len(out)
+    if frac <= 0 or n == 0:
+        return out
+    n_runs = max(1, int(frac * n / mean_run))
+    starts = rng.integers(0, n, size=n_runs)
+    lens = rng.geometric(1.0 / mean_run, size=n_runs)
+    for s, l in zip(starts, lens):
+        out[s:s + l] |= 0x20
+    return out
+
+
+def n_runs(seq: np.ndarray, rng: np.random.Generator, count: int, length: int) -> np.ndarray:
+    out = seq.copy()
+    for _ in range(count):
+        if len(out) <= length:
+            break
+        s = int(rng.integers(0, len(out) - length))
+        out[s:s + length] = ord("N")
+    return out
+
+
+def make_pair(n: int, seed: int, sub_rate=0.15, indel_rate=0.01, mask_frac=0.2,
+              inversion=True, replaced=True, nruns=2, homologous=True):
+    """Returns (target_bytes, query_bytes) uppercase/lowercase ASCII numpy arrays.
+    homologous=False gives the 'pure-random' pair (seed/ungapped throughput isolation)."""
+    rng = np.random.default_rng(seed)
+    anc = random_sequence(n, rng)
+    target = anc.copy()
+    if homologous:
+        q = anc.copy()
+        if inversion and n >= 20:
+            a = int(0.4 * n); b = a + max(1, n // 20)
+            q[a:b] = revcomp(q[a:b])
+        if replaced and n >= 10:
+            a = int(0.7 * n); b = a + max(1, n // 10)
+            q[a:b] = random_sequence(b - a, rng)
+        query = mutate(q, rng, sub_rate, indel_rate)
+    else:
+        query = random_sequence(n, rng)
+    target = soft_mask(target, rng, mask_frac)
+    query = soft_mask(query, rng, mask_frac)
+    if nruns:
+        target = n_runs(target, rng, nruns, min(500, max(1, n // 200)))
+        query = n_runs(query, rng, nruns, min(500, max(1, n // 200)))
+    return target, query
+
+
+def fasta_bytes(records) -> bytes:
+    """records: iterable of (name, uint8 array).  60 columns per line like faffy/sonLib writers."""
+    out = []
+    for name, seq in records:
+        out.append(b">" + name.encode() + b"\n")
+        s = seq.tobytes()
+        out.extend(s[i:i + 60] + b"\n" for i in range(0, len(s), 60))
+    return b"".join(out)
+
+
+def write_fasta(path: str, records) -> None:
+    with open(path, "wb") as f:
+        f.write(fasta_bytes(records))

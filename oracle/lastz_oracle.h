@@ -1,0 +1,118 @@
+/*
+ * lastz_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, single-threaded restatement of the lastz seeded gapped aligner
+ * that Cactus's blast phase shells out to
+ *   (/root/reference/src/cactus/paf/local_alignment.py:29-97 `run_lastz`,
+ *    command line built at :60-68, parameter sets at
+ *    /root/reference/src/cactus/cactus_progressive_config.xml:130-137).
+ *
+ * The arithmetic itself lives in the third-party `lastz` submodule
+ * (/root/reference/.gitmodules:25-27), whose directory is EMPTY in the
+ * reference tree, and in no other file of the reference.  This oracle therefore
+ * restates lastz's published algorithm as fixed in SURVEY.md Appendix A.10
+ * ("normative pseudo-code").
+ *
+ * *** PARITY UNPINNED ***: the reference holds no golden vector, known-answer
+ * test or fixture for this path at PAF/cigar level, and no
+ * lastz binary can be built or run here.  The only pins that exist are the
+ * parameter strings (api/tests/cactusParamsTest.c:16-17) and the structural
+ * PAF contract enforced by caf (caf/impl/pinchIterator.c:59-121); both are
+ * checked in tests/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * use this code.  The product (cactus_amd/csrc) never links or calls it.
+ */
+#ifndef LASTZ_ORACLE_H
+#define LASTZ_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- parameters (lastz command-line options used by Cactus) ------------- */
+typedef struct olz_params {
+    int32_t step;          /* --step=N          (default 1)                     */
+    int32_t transitions;   /* 1 = 12of19 with one transition, 0 = --notransition */
+    int32_t xdrop;         /* ungapped x-drop   (default 10*sub[A][A] = 910)    */
+    int32_t ydrop;         /* --ydrop=N         (default O+300E = 9400)         */
+    int32_t hspthresh;     /* --hspthresh=N  K  (default 3000)                  */
+    int32_t gappedthresh;  /* --gappedthresh=N L (default = K)                  */
+    int32_t gap_open;      /* O = 400                                           */
+    int32_t gap_extend;    /* E = 30                                            */
+    int32_t entropy;       /* 1 = entropy-adjusted HSP filter (default)         */
+    int32_t queryhspbest;  /* --queryhspbest=N (0 = unlimited)                  */
+    int32_t ambiguous_n;   /* 1 = --ambiguous=iupac,100,100 (N scores -100)     */
+    int32_t gapped;        /* 1 = gapped stage on; 0 = --ungapped / --nogapped  */
+} olz_params;
+
+void olz_params_default(olz_params *p);
+
+/* ---- sequences ---------------------------------------------------------- */
+/* code byte: bits 0..2 = base (0..3 = A,C,G,T ; 4 = N/other), bit 3 = lowercase
+ * (soft-masked); 0xFF = separator between contigs of a concatenated set.     */
+#define OLZ_SEP 0xFFu
+
+typedef struct olz_seqset {
+    int32_t   n_contigs;
+    char    **names;      /* nameparse=darkspace: header up to first blank     */
+    int64_t  *starts;     /* start of contig in the concatenation              */
+    int64_t  *lens;
+    int64_t   total;      /* concatenated length incl. one separator between   */
+    uint8_t  *codes;      /* total+1 bytes (trailing separator)                */
+} olz_seqset;
+
+olz_seqset *olz_seqset_from_fasta_mem(const char *buf, size_t len);
+olz_seqset *olz_seqset_from_fasta_file(const char *path);
+void        olz_seqset_free(olz_seqset *s);
+
+/* ---- stage records (shared layout with the product's debug exports) ----- */
+typedef struct olz_hsp {
+    int32_t t_start, q_start, len, score;   /* concatenated coords; q on the strand searched */
+    int32_t seed_t_end, seed_q_end;         /* the seed hit that produced it   */
+    int32_t cnt[4];                         /* identical A,C,G,T columns       */
+    int32_t strand;                         /* 0 '+', 1 '-'                    */
+    int32_t q_contig;                       /* query contig index              */
+} olz_hsp;
+
+typedef struct olz_aln {
+    int32_t strand, q_contig, t_contig;
+    int32_t t_lo, t_hi, q_lo, q_hi;         /* concatenated, strand coords     */
+    int32_t score;
+    int32_t dmin, dmax;
+    int32_t anchor_t, anchor_q;
+    int64_t ops_off, n_ops;                 /* into olz_result.ops             */
+} olz_aln;
+
+typedef struct olz_counters {
+    int64_t seed_lookups, seed_hits, hits_extended, ungapped_cols;
+    int64_t hsps_pre_entropy, hsps, anchors, anchors_skipped;
+    int64_t dp_sides, dp_cells, dp_rows, alignments;
+    double  t_index, t_seed, t_gapped, t_total;    /* seconds (CPU wall)       */
+} olz_counters;
+
+typedef struct olz_result {
+    char     *paf;      size_t paf_len;
+    olz_hsp  *hsps;     int64_t n_hsps;     /* after entropy + queryhspbest, found order */
+    olz_aln  *alns;     int64_t n_alns;     /* output order                     */
+    uint32_t *ops;      int64_t n_ops;      /* (len<<2)|op ; op 0 '=',1 'X',2 'I',3 'D' */
+    olz_counters c;
+} olz_result;
+
+int  olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *p, olz_result **out);
+void olz_result_free(olz_result *r);
+
+/* seed index export (stage parity): offsets[2^24+1], positions[offsets[2^24]] */
+int  olz_build_index(const olz_seqset *T, int32_t step, uint32_t **offsets, uint32_t **positions);
+void olz_free(void *p);
+
+/* substitution score between two code bytes (case-insensitive) */
+int32_t olz_score(uint8_t a, uint8_t b, int ambiguous_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
