@@ -1,0 +1,277 @@
+// mb_capi.cpp -- the C ABI declared in include/miblast.h (extern "C", plain pointers, no exceptions
+// escape).  There is deliberately no CPU path: without a gfx950 device every compute entry point
+// returns MIBLAST_ENODEV.
+#include "mb_pipeline.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <unistd.h>
+
+namespace mb {
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+}  // namespace mb
+
+struct miblast_ctx { mb::Ctx c; };
+struct miblast_seqset { mb::SeqSet s; };
+struct miblast_result { mb::Result r; };
+
+namespace {
+
+template <typename F>
+int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const mb::HipFailure &e) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "HIP call did not succeed: %s -> %s (%s:%d)", e.what, hipGetErrorString(e.code), e.file, e.line);
+        mb::set_error(buf);
+        return e.code == hipErrorNoDevice || e.code == hipErrorInvalidDevice ? MIBLAST_ENODEV : MIBLAST_EHIP;
+    } catch (const std::bad_alloc &) {
+        mb::set_error("out of host memory");
+        return MIBLAST_ELIMIT;
+    } catch (const std::exception &e) {
+        mb::set_error(std::string("internal: ") + e.what());
+        return MIBLAST_EHIP;
+    }
+}
+
+bool parse_int(const char *s, long &v) {
+    if (!s || !*s) return false;
+    char *end = nullptr;
+    v = strtol(s, &end, 10);
+    return end && *end == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void miblast_params_default(miblast_params *p) {
+    p->step = 1; p->transitions = 1; p->xdrop = 910; p->ydrop = 9400; p->hspthresh = 3000; p->gappedthresh = -1;
+    p->gap_open = 400; p->gap_extend = 30; p->entropy = 1; p->queryhspbest = 0; p->ambiguous_n = 1; p->gapped = 1;
+}
+
+int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const char *files[2], int *num_gpu, int *num_threads) {
+    miblast_params_default(p);
+    int nf = 0, ng = 1, nt = 1;
+    files[0] = files[1] = nullptr;
+    auto bad = [&](const char *a, const char *why) {
+        mb::set_error(std::string(why) + ": " + a);
+        return MIBLAST_EINVAL;
+    };
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (a[0] != '-') {
+            if (nf >= 2) return bad(a, "more than two sequence files");
+            files[nf++] = a;
+            continue;
+        }
+        const char *eq = strchr(a, '=');
+        std::string key = eq ? std::string(a, (size_t)(eq - a)) : std::string(a);
+        const char *val = eq ? eq + 1 : nullptr;
+        long v = 0;
+        auto need_int = [&](int32_t &dst, long lo) -> int {
+            if (!parse_int(val, v) || v < lo) return bad(a, "bad value for option");
+            dst = (int32_t)v;
+            return 0;
+        };
+        int rc = 0;
+        if (key == "--step") rc = need_int(p->step, 1);
+        else if (key == "--ydrop") rc = need_int(p->ydrop, 0);
+        else if (key == "--xdrop") rc = need_int(p->xdrop, 0);
+        else if (key == "--hspthresh") rc = need_int(p->hspthresh, 0);
+        else if (key == "--gappedthresh") rc = need_int(p->gappedthresh, 0);
+        else if (key == "--queryhspbest") rc = need_int(p->queryhspbest, 0);
+        else if (key == "--notransition" && !val) p->transitions = 0;
+        else if (key == "--transition" && !val) p->transitions = 1;
+        else if (key == "--noentropy" && !val) p->entropy = 0;
+        else if (key == "--entropy" && !val) p->entropy = 1;
+        else if ((key == "--ungapped" || key == "--nogapped") && !val) p->gapped = 0;
+        else if (key == "--gapped" && !val) p->gapped = 1;
+        else if (key == "--ambiguous") {
+            // Cactus always passes iupac,100,100 (cactus_progressive_config.xml:131-145)
+            if (!val || (strcmp(val, "iupac,100,100") && strcmp(val, "iupac") && strcmp(val, "n,100,100") && strcmp(val, "n")))
+                return bad(a, "unsupported --ambiguous form");
+            p->ambiguous_n = 1;
+        } else if (key == "--format") {
+            if (!val || strcmp(val, "paf:wfmash")) return bad(a, "only --format=paf:wfmash is implemented");
+        } else if (key == "--num_gpu") {                       // run_kegalign form: "--num_gpu N" (local_alignment.py:58)
+            if (val) { if (!parse_int(val, v) || v < 1) return bad(a, "bad value for option"); }
+            else { if (i + 1 >= argc || !parse_int(argv[++i], v) || v < 1) return bad(a, "bad value for option"); }
+            ng = (int)v;
+        } else if (key == "--num_threads") {
+            if (val) { if (!parse_int(val, v) || v < 0) return bad(a, "bad value for option"); }
+            else { if (i + 1 >= argc || !parse_int(argv[++i], v) || v < 0) return bad(a, "bad value for option"); }
+            nt = (int)v;
+        } else return bad(a, "unknown option");
+        if (rc) return rc;
+    }
+    if (nf != 2) { mb::set_error("expected a target and a query sequence file"); return MIBLAST_EINVAL; }
+    if (num_gpu) *num_gpu = ng;
+    if (num_threads) *num_threads = nt;
+    return MIBLAST_OK;
+}
+
+int miblast_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int miblast_ctx_create(int device, miblast_ctx **out) {
+    if (!out) return MIBLAST_EINVAL;
+    *out = nullptr;
+    return guarded([&]() -> int {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            mb::set_error("no HIP device visible: libmiblast has no CPU path");
+            return MIBLAST_ENODEV;
+        }
+        if (device < 0 || device >= n) { mb::set_error("device ordinal out of range"); return MIBLAST_ENODEV; }
+        hipDeviceProp_t prop;
+        MB_HIP(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("MIBLAST_ALLOW_ANY_ARCH")) {
+            mb::set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+            return MIBLAST_ENODEV;
+        }
+        MB_HIP(hipSetDevice(device));
+        miblast_ctx *c = new miblast_ctx();
+        c->c.device = device;
+        MB_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
+        MB_HIP(hipEventCreate(&c->c.ev0)); MB_HIP(hipEventCreate(&c->c.ev1)); MB_HIP(hipEventCreate(&c->c.ev2));
+        MB_HIP(hipEventCreate(&c->c.ev3)); MB_HIP(hipEventCreate(&c->c.ev4));
+        *out = c;
+        return MIBLAST_OK;
+    });
+}
+
+void miblast_ctx_destroy(miblast_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->c.device);
+    if (c->c.ev0) (void)hipEventDestroy(c->c.ev0);
+    if (c->c.ev1) (void)hipEventDestroy(c->c.ev1);
+    if (c->c.ev2) (void)hipEventDestroy(c->c.ev2);
+    if (c->c.ev3) (void)hipEventDestroy(c->c.ev3);
+    if (c->c.ev4) (void)hipEventDestroy(c->c.ev4);
+    if (c->c.stream) (void)hipStreamDestroy(c->c.stream);
+    delete c;
+}
+
+int miblast_seqset_from_fasta_mem(miblast_ctx *ctx, const char *buf, size_t len, miblast_seqset **out) {
+    if (!ctx || !out || (!buf && len)) return MIBLAST_EINVAL;
+    *out = nullptr;
+    return guarded([&]() -> int {
+        miblast_seqset *s = new miblast_seqset();
+        mb::parse_fasta(buf, len, s->s);
+        try { mb::upload_seqset(s->s, ctx->c.device); } catch (...) { mb::release_seqset(s->s); delete s; throw; }
+        *out = s;
+        return MIBLAST_OK;
+    });
+}
+
+int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_seqset **out) {
+    if (!ctx || !out || !path) return MIBLAST_EINVAL;
+    *out = nullptr;
+    // accept lastz's trailing [actions] on the file name (local_alignment.py:60-62)
+    std::string file(path);
+    size_t br = file.find('[');
+    if (br != std::string::npos) file.resize(br);
+    std::ifstream f(file, std::ios::binary);
+    if (!f) { mb::set_error("cannot open " + file); return MIBLAST_EIO; }
+    std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return miblast_seqset_from_fasta_mem(ctx, data.data(), data.size(), out);
+}
+
+void miblast_seqset_free(miblast_seqset *s) {
+    if (!s) return;
+    if (s->s.device >= 0) (void)hipSetDevice(s->s.device);
+    mb::release_seqset(s->s);
+    delete s;
+}
+
+int32_t miblast_seqset_n_contigs(const miblast_seqset *s) { return s ? (int32_t)s->s.names.size() : 0; }
+int64_t miblast_seqset_total(const miblast_seqset *s) { return s ? s->s.total : 0; }
+const char *miblast_seqset_name(const miblast_seqset *s, int32_t i) {
+    return (s && i >= 0 && (size_t)i < s->s.names.size()) ? s->s.names[(size_t)i].c_str() : nullptr;
+}
+int64_t miblast_seqset_start(const miblast_seqset *s, int32_t i) {
+    return (s && i >= 0 && (size_t)i < s->s.starts.size()) ? s->s.starts[(size_t)i] : -1;
+}
+int64_t miblast_seqset_len(const miblast_seqset *s, int32_t i) {
+    return (s && i >= 0 && (size_t)i < s->s.lens.size()) ? s->s.lens[(size_t)i] : -1;
+}
+
+int miblast_align(miblast_ctx *ctx, const miblast_seqset *target, const miblast_seqset *query, const miblast_params *p,
+                  miblast_result **out) {
+    if (!ctx || !target || !query || !p || !out) return MIBLAST_EINVAL;
+    *out = nullptr;
+    return guarded([&]() -> int {
+        miblast_result *r = new miblast_result();
+        int rc;
+        try { rc = mb::align(ctx->c, target->s, query->s, *p, r->r); } catch (...) { delete r; throw; }
+        if (rc != MIBLAST_OK) { delete r; return rc; }
+        *out = r;
+        return MIBLAST_OK;
+    });
+}
+
+void miblast_result_free(miblast_result *r) { delete r; }
+
+const char *miblast_result_paf(const miblast_result *r, size_t *len) {
+    if (len) *len = r ? r->r.paf.size() : 0;
+    return r ? r->r.paf.c_str() : nullptr;
+}
+const miblast_stats *miblast_result_stats(const miblast_result *r) { return r ? &r->r.stats : nullptr; }
+const miblast_hsp *miblast_result_hsps(const miblast_result *r, int64_t *n) {
+    if (n) *n = r ? (int64_t)r->r.hsps.size() : 0;
+    return r ? r->r.hsps.data() : nullptr;
+}
+const miblast_aln *miblast_result_alns(const miblast_result *r, int64_t *n) {
+    if (n) *n = r ? (int64_t)r->r.alns.size() : 0;
+    return r ? r->r.alns.data() : nullptr;
+}
+const uint32_t *miblast_result_ops(const miblast_result *r, int64_t *n) {
+    if (n) *n = r ? (int64_t)r->r.ops.size() : 0;
+    return r ? r->r.ops.data() : nullptr;
+}
+
+int miblast_align_files(miblast_ctx *ctx, const char *target_fa, const char *query_fa, const miblast_params *p, int out_fd,
+                        miblast_stats *stats) {
+    if (!ctx || !target_fa || !query_fa || !p) return MIBLAST_EINVAL;
+    miblast_seqset *t = nullptr, *q = nullptr;
+    miblast_result *r = nullptr;
+    int rc = miblast_seqset_from_fasta_file(ctx, target_fa, &t);
+    if (rc == MIBLAST_OK) rc = miblast_seqset_from_fasta_file(ctx, query_fa, &q);
+    if (rc == MIBLAST_OK) rc = miblast_align(ctx, t, q, p, &r);
+    if (rc == MIBLAST_OK) {
+        size_t len = 0, done = 0;
+        const char *paf = miblast_result_paf(r, &len);
+        while (done < len) {
+            ssize_t w = write(out_fd, paf + done, len - done);
+            if (w <= 0) { mb::set_error("cannot write PAF output"); rc = MIBLAST_EIO; break; }
+            done += (size_t)w;
+        }
+        if (stats) *stats = *miblast_result_stats(r);
+    }
+    miblast_result_free(r);
+    miblast_seqset_free(q);
+    miblast_seqset_free(t);
+    return rc;
+}
+
+int miblast_build_index(miblast_ctx *ctx, const miblast_seqset *target, int32_t step, uint32_t **offsets, uint32_t **positions) {
+    if (!ctx || !target || !offsets || !positions || step < 1) return MIBLAST_EINVAL;
+    return guarded([&]() -> int { return mb::export_index(ctx->c, target->s, step, offsets, positions); });
+}
+
+void miblast_free(void *p) { free(p); }
+
+const char *miblast_last_error(void) { return mb::g_last_error.c_str(); }
+const char *miblast_version(void) { return "miblast 0.1 (gfx950)"; }
+
+}  // extern "C"

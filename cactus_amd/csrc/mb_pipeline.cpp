@@ -1,0 +1,619 @@
+// mb_pipeline.cpp -- host orchestration of one blast job (= one `lastz target query` process of
+// /root/reference/src/cactus/paf/local_alignment.py:65-73) on one MI355X.
+//
+//   index build  ->  per strand: seed count / batch / fill / sort / ungapped  ->  HSP filters (host,
+//   entropy in IEEE double like lastz)  ->  anchors  ->  score-ordered gapped extension with
+//   speculative batches of Y-drop DPs  ->  PAF text.
+//
+// The sequential rules of SURVEY.md A.10 that look order dependent are kept exact:
+//   * diagonal suppression: hits are sorted by (diagonal, q) and each diagonal run is walked in order;
+//   * "anchor covered by an earlier alignment": DPs are independent of each other, so they are run
+//     speculatively in score-ranked batches and a host pass commits them strictly in anchor order.
+#include "mb_pipeline.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+namespace mb {
+
+namespace {
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void ensure(size_t count) { if (count > n) alloc(count + count / 4); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+// host substitution score (HOXD70 + N = -100)
+inline int host_score(unsigned a, unsigned b) {
+    static const int M[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
+    unsigned x = a & 7u, y = b & 7u;
+    return (x > 3u || y > 3u) ? -100 : M[x][y];
+}
+
+inline uint32_t host_word(const uint8_t *c, int64_t p) {
+    static const int care[kSeedWeight] = {0, 1, 2, 4, 7, 8, 11, 13, 15, 16, 17, 18};
+    uint32_t w = 0;
+    for (int k = 0; k < kSeedWeight; k++) w = (w << 2) | (c[p + care[k]] & 3u);
+    return w;
+}
+
+// rank of the word variant that produced a seed hit: 0 exact, 1+k transition at care position k.
+// Needed only to order HSPs the way the sequential search finds them (--queryhspbest ties).
+inline int variant_rank(const uint8_t *tc, const uint8_t *qc, int64_t t_end, int64_t q_end) {
+    uint32_t dx = host_word(tc, t_end - kSeedSpan) ^ host_word(qc, q_end - kSeedSpan);
+    if (!dx) return 0;
+    for (int k = 0; k < kSeedWeight; k++) if (dx == (2u << (2 * (kSeedWeight - 1 - k)))) return 1 + k;
+    return 99;
+}
+
+struct Anchor { int32_t t, q, score; };
+
+struct Cached {                // result of one anchor's two one-sided DPs
+    bool accepted = false;
+    int32_t score = 0, t_lo = 0, t_hi = 0, q_lo = 0, q_hi = 0, dmin = 0, dmax = 0;
+    int64_t cells = 0, rows = 0;
+    std::vector<uint8_t> raw_r, raw_l;   // walk-back op bytes of the right / left DP (until merged)
+    std::vector<uint32_t> ops;           // merged run-length ops, forward order
+};
+
+struct Unit {                  // one (query contig, strand): anchors are committed strictly in order
+    int strand = 0, q_contig = 0;
+    std::vector<Anchor> anchors;
+    size_t next = 0;           // first anchor not yet committed
+    std::unordered_map<size_t, Cached> cache;
+    std::vector<miblast_aln> kept;          // ops_off indexes unit_ops
+    std::vector<uint32_t> unit_ops;
+    size_t batch = 0;
+};
+
+bool covered(const Unit &u, const Anchor &a) {
+    int32_t d = a.t - a.q;
+    for (const miblast_aln &A : u.kept)
+        if (a.t >= A.t_lo && a.t < A.t_hi && a.q >= A.q_lo && a.q < A.q_hi && d >= A.dmin && d <= A.dmax) return true;
+    return false;
+}
+
+long env_long(const char *name, long dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atol(v) : dflt;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------------
+void upload_seqset(SeqSet &s, int device) {
+    MB_HIP(hipSetDevice(device));
+    s.device = device;
+    MB_HIP(hipMalloc((void **)&s.d_buf, s.codes.size()));
+    MB_HIP(hipMemcpy(s.d_buf, s.codes.data(), s.codes.size(), hipMemcpyHostToDevice));
+    size_t nc = std::max<size_t>(1, s.starts.size());
+    MB_HIP(hipMalloc((void **)&s.d_starts, nc * sizeof(int64_t)));
+    MB_HIP(hipMalloc((void **)&s.d_lens, nc * sizeof(int64_t)));
+    if (!s.starts.empty()) {
+        MB_HIP(hipMemcpy(s.d_starts, s.starts.data(), s.starts.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        MB_HIP(hipMemcpy(s.d_lens, s.lens.data(), s.lens.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+}
+
+void release_seqset(SeqSet &s) {
+    if (s.d_buf) (void)hipFree(s.d_buf);
+    if (s.d_starts) (void)hipFree(s.d_starts);
+    if (s.d_lens) (void)hipFree(s.d_lens);
+    s.d_buf = nullptr; s.d_starts = nullptr; s.d_lens = nullptr;
+}
+
+// --------------------------------------------------------------------------------------------------
+struct Index {
+    DevBuf<uint32_t> offsets;      // 2^24 + 1
+    DevBuf<uint32_t> positions;
+    uint32_t n_positions = 0;
+};
+
+static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
+    hipStream_t s = ctx.stream;
+    int64_t n_slots = (T.total + step - 1) / step;
+    DevBuf<uint32_t> words((size_t)std::max<int64_t>(1, n_slots));
+    DevBuf<uint32_t> counts((size_t)kBuckets + 1);
+    ix.offsets.alloc((size_t)kBuckets + 1);
+    ix.positions.alloc((size_t)std::max<int64_t>(1, n_slots));
+    int64_t nblk = ((int64_t)kBuckets + 1 + 2047) / 2048;
+    DevBuf<unsigned long long> bsum((size_t)nblk + 2);
+    MB_HIP(hipMemsetAsync(counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
+    launch_index_words(T.dev(), T.total, step, words.p, n_slots, counts.p, s);
+    launch_scan_u32(counts.p, ix.offsets.p, (int64_t)kBuckets + 1, bsum.p, s);
+    MB_HIP(hipMemsetAsync(counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
+    launch_index_scatter(words.p, n_slots, step, ix.offsets.p, counts.p, ix.positions.p, s);
+    MB_HIP(hipMemcpyAsync(&ix.n_positions, ix.offsets.p + kBuckets, 4, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipStreamSynchronize(s));
+}
+
+int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions) {
+    MB_HIP(hipSetDevice(ctx.device));
+    Index ix;
+    build_index(ctx, T, step, ix);
+    uint32_t *off = (uint32_t *)malloc(((size_t)kBuckets + 1) * 4);
+    uint32_t *pos = (uint32_t *)malloc(((size_t)ix.n_positions + 1) * 4);
+    MB_HIP(hipMemcpy(off, ix.offsets.p, ((size_t)kBuckets + 1) * 4, hipMemcpyDeviceToHost));
+    if (ix.n_positions) MB_HIP(hipMemcpy(pos, ix.positions.p, (size_t)ix.n_positions * 4, hipMemcpyDeviceToHost));
+    // the device scatter fills a bucket in arrival order; the exported table is canonical (ascending)
+    for (uint32_t b = 0; b < kBuckets; b++)
+        if (off[b + 1] - off[b] > 1) std::sort(pos + off[b], pos + off[b + 1]);
+    *offsets = off; *positions = pos;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+struct GappedScratch {
+    DevBuf<DpProb> probs;
+    DevBuf<DpOut> outs;
+    DevBuf<int32_t> grows;
+    DevBuf<uint8_t> trace;
+    DevBuf<uint64_t> rowoff;
+    DevBuf<uint32_t> rowly;
+    DevBuf<uint8_t> ops;
+};
+
+static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, bool trace, bool global_rows, const DpProb *probs, DpOut *outs,
+                            int n, const uint8_t *tc, const uint8_t *qf, const uint8_t *qr, const miblast_params &p,
+                            GappedScratch &g) {
+    MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+    launch_ydrop(trace, global_rows, probs, outs, n, tc, qf, qr, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.trace.p,
+                 g.rowoff.p, g.rowly.p, ctx.stream);
+    MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+    MB_HIP(hipEventSynchronize(ctx.ev1));
+    float ms = 0;
+    MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+    st.t_dp_kernel_ms += ms;
+    st.dp_kernel_launches++;
+}
+
+int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin, Result &res) {
+    MB_HIP(hipSetDevice(ctx.device));
+    hipStream_t s = ctx.stream;
+    miblast_params p = pin;
+    if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
+    if (p.step < 1) p.step = 1;
+    if (T.device != ctx.device || Q.device != ctx.device) { set_error("sequence set lives on another device"); return MIBLAST_EINVAL; }
+    if (T.total + Q.total + 4 >= (int64_t)0x7fffffff) {
+        set_error("target+query longer than 2^31-1 bases: chunk the input (Cactus chunkSize is 30 Mb)");
+        return MIBLAST_ELIMIT;
+    }
+    miblast_stats &st = res.stats;
+    memset(&st, 0, sizeof st);
+    const double t_begin = now_s();
+    const int nvar = p.transitions ? 1 + kSeedWeight : 1;
+    const int64_t qtot = Q.total, ttot = T.total;
+
+    // ---- seed position table ------------------------------------------------------------------
+    Index ix;
+    build_index(ctx, T, p.step, ix);
+    st.t_index = now_s() - t_begin;
+
+    // ---- '-' strand of the query -----------------------------------------------------------------
+    DevBuf<uint8_t> d_rc((size_t)qtot + 2);
+    MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2, s));
+    launch_revcomp(Q.dev(), d_rc.p + 1, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
+    std::vector<uint8_t> h_rc((size_t)qtot + 2);
+    MB_HIP(hipMemcpyAsync(h_rc.data(), d_rc.p, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipStreamSynchronize(s));
+    const uint8_t *tc_h = T.host();
+    const uint8_t *qc_h[2] = {Q.host(), h_rc.data() + 1};
+    const uint8_t *qc_d[2] = {Q.dev(), d_rc.p + 1};
+
+    // ---- seed search + ungapped extension, per strand ----------------------------------------------
+    const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
+    const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
+    DevBuf<int32_t> extent((size_t)(ttot + qtot + 2));
+    DevBuf<uint32_t> qcnt((size_t)std::max<int64_t>(1, qtot));
+    int64_t n_qblk = (qtot + 2047) / 2048;
+    DevBuf<unsigned long long> qbsum((size_t)n_qblk + 2), scan_scratch((size_t)n_qblk + 2);
+    DevBuf<uint32_t> hit_off;
+    DevBuf<unsigned long long> keys_a, keys_b;
+    DevBuf<char> sort_temp;
+    DevBuf<DevHsp> d_hsps;
+    DevBuf<UngappedCounters> d_ctr(1);
+    DevBuf<unsigned long long> d_nvalid(1);
+    std::vector<unsigned long long> h_qbsum((size_t)n_qblk + 2);
+    std::vector<miblast_hsp> strand_hsps[2];
+
+    for (int strand = 0; strand < 2 && qtot >= kSeedSpan && ttot >= kSeedSpan; strand++) {
+        const double t0 = now_s();
+        MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
+        launch_seed_count(qc_d[strand], qtot, ix.offsets.p, p.transitions, qcnt.p, s);
+        launch_block_sums(qcnt.p, qtot, qbsum.p, s);
+        MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));
+        std::vector<DevHsp> found;
+        int64_t b0 = 0;
+        while (b0 < n_qblk) {
+            // greedy batch of whole 2048-position blocks with at most hit_cap hits
+            int64_t b1 = b0;
+            unsigned long long nh = 0;
+            while (b1 < n_qblk && (b1 == b0 || nh + h_qbsum[(size_t)b1] <= (unsigned long long)hit_cap)) nh += h_qbsum[(size_t)b1++];
+            const int64_t q0 = b0 * 2048, q1 = std::min(qtot, b1 * 2048);
+            b0 = b1;
+            if (nh == 0) continue;
+            if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one 2048-base query block (unmasked repeat?)"); return MIBLAST_ELIMIT; }
+            st.seed_hits += (int64_t)nh;
+            st.seed_batches++;
+            hit_off.ensure((size_t)(q1 - q0));
+            keys_a.ensure((size_t)nh); keys_b.ensure((size_t)nh);
+            d_hsps.ensure((size_t)nh);
+            size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
+            sort_temp.ensure(tb + 16);
+            MB_HIP(hipEventRecord(ctx.ev0, s));
+            launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
+            launch_seed_fill(qc_d[strand], q0, q1, qtot, ix.offsets.p, ix.positions.p, p.transitions, hit_off.p, keys_a.p, s);
+            MB_HIP(hipEventRecord(ctx.ev1, s));
+            sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, sort_bits, s);
+            MB_HIP(hipEventRecord(ctx.ev2, s));
+            MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
+            MB_HIP(hipEventRecord(ctx.ev3, s));
+            launch_ungapped(keys_b.p, (int64_t)nh, T.dev(), qc_d[strand], qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
+                            (int64_t)d_hsps.n, d_ctr.p, s);
+            MB_HIP(hipEventRecord(ctx.ev4, s));
+            UngappedCounters hc;
+            MB_HIP(hipMemcpyAsync(&hc, d_ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
+            MB_HIP(hipStreamSynchronize(s));
+            float ms;
+            MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1)); st.t_seedfill_ms += ms;
+            MB_HIP(hipEventElapsedTime(&ms, ctx.ev1, ctx.ev2)); st.t_sort_ms += ms;
+            MB_HIP(hipEventElapsedTime(&ms, ctx.ev3, ctx.ev4)); st.t_ungapped_kernel_ms += ms; st.ungapped_kernel_launches++;
+            st.hits_extended += (int64_t)hc.extended;
+            st.ungapped_cols += (int64_t)hc.cols;
+            if (hc.hsps > d_hsps.n) { set_error("HSP buffer overflow"); return MIBLAST_ELIMIT; }
+            size_t base = found.size();
+            found.resize(base + (size_t)hc.hsps);
+            if (hc.hsps) MB_HIP(hipMemcpy(found.data() + base, d_hsps.p, (size_t)hc.hsps * sizeof(DevHsp), hipMemcpyDeviceToHost));
+        }
+        // number of seed word lookups = valid query windows x variants (counter only)
+        {
+            int64_t run = 0, valid = 0;
+            const uint8_t *qc = qc_h[strand];
+            for (int64_t i = 0; i < qtot; i++) { run = qc[i] < 4 ? run + 1 : 0; valid += run >= kSeedSpan; }
+            st.seed_lookups += valid * nvar;
+        }
+        st.hsps_pre_entropy += (int64_t)found.size();
+        // order HSPs the way the sequential search discovers them: q ascending, word variant, target descending
+        struct Key { int32_t q_end, rank, neg_t; size_t idx; };
+        std::vector<Key> order(found.size());
+        for (size_t k = 0; k < found.size(); k++)
+            order[k] = Key{found[k].seed_q_end, variant_rank(tc_h, qc_h[strand], found[k].seed_t_end, found[k].seed_q_end),
+                           -found[k].seed_t_end, k};
+        std::sort(order.begin(), order.end(), [](const Key &a, const Key &b) {
+            if (a.q_end != b.q_end) return a.q_end < b.q_end;
+            if (a.rank != b.rank) return a.rank < b.rank;
+            return a.neg_t < b.neg_t;
+        });
+        // entropy filter in IEEE double on the host, like lastz (hard part H4)
+        std::vector<miblast_hsp> &hs = strand_hsps[strand];
+        for (const Key &k : order) {
+            const DevHsp &d = found[k.idx];
+            bool keep = true;
+            if (p.entropy) {
+                int64_t n = (int64_t)d.cnt[0] + d.cnt[1] + d.cnt[2] + d.cnt[3];
+                if (n == 0) keep = false;
+                else {
+                    double H = 0.0;
+                    for (int c = 0; c < 4; c++)
+                        if (d.cnt[c] > 0) { double pr = (double)d.cnt[c] / (double)n; H -= pr * std::log(pr); }
+                    H /= std::log(4.0);
+                    keep = (double)d.score * H >= (double)p.hspthresh;
+                }
+            }
+            if (!keep) continue;
+            miblast_hsp h;
+            h.t_start = d.t_start; h.q_start = d.q_start; h.len = d.len; h.score = d.score;
+            h.seed_t_end = d.seed_t_end; h.seed_q_end = d.seed_q_end;
+            for (int c = 0; c < 4; c++) h.cnt[c] = d.cnt[c];
+            h.strand = strand;
+            h.q_contig = Q.contig_of(d.q_start);
+            hs.push_back(h);
+        }
+        // --queryhspbest=N per query contig and strand: N best scores, ties to the earlier found
+        if (p.queryhspbest > 0) {
+            std::vector<miblast_hsp> kept;
+            for (int qc_i = 0; qc_i < (int)Q.starts.size(); qc_i++) {
+                std::vector<size_t> idx;
+                for (size_t k = 0; k < hs.size(); k++) if (hs[k].q_contig == qc_i) idx.push_back(k);
+                if ((int64_t)idx.size() > p.queryhspbest) {
+                    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return hs[a].score > hs[b].score; });
+                    idx.resize((size_t)p.queryhspbest);
+                    std::sort(idx.begin(), idx.end());
+                }
+                for (size_t k : idx) kept.push_back(hs[k]);
+            }
+            hs.swap(kept);
+        }
+        st.hsps += (int64_t)hs.size();
+        st.t_seed += now_s() - t0;
+    }
+    for (int strand = 0; strand < 2; strand++) res.hsps.insert(res.hsps.end(), strand_hsps[strand].begin(), strand_hsps[strand].end());
+
+    // ---- gapped extension ----------------------------------------------------------------------------
+    const double t_g0 = now_s();
+    std::vector<Unit> units;
+    if (p.gapped) {
+        for (int strand = 0; strand < 2; strand++) {
+            std::vector<std::vector<Anchor>> per((size_t)Q.starts.size());
+            const uint8_t *qc = qc_h[strand];
+            for (const miblast_hsp &h : strand_hsps[strand]) {
+                // anchor = middle of the best-scoring 31-column window (first on ties); SURVEY A.6
+                int off;
+                if (h.len <= 31) off = h.len / 2;
+                else {
+                    int64_t sum = 0;
+                    for (int k = 0; k < 31; k++) sum += host_score(tc_h[h.t_start + k], qc[h.q_start + k]);
+                    int64_t bestsum = sum; int bestc = 0;
+                    for (int c = 1; c + 31 <= h.len; c++) {
+                        sum += host_score(tc_h[h.t_start + c + 30], qc[h.q_start + c + 30]);
+                        sum -= host_score(tc_h[h.t_start + c - 1], qc[h.q_start + c - 1]);
+                        if (sum > bestsum) { bestsum = sum; bestc = c; }
+                    }
+                    off = bestc + 15;
+                }
+                per[(size_t)h.q_contig].push_back(Anchor{h.t_start + off, h.q_start + off, h.score});
+            }
+            for (size_t qc_i = 0; qc_i < per.size(); qc_i++) {
+                if (per[qc_i].empty()) continue;
+                Unit u;
+                u.strand = strand; u.q_contig = (int)qc_i;
+                u.anchors.swap(per[qc_i]);
+                std::sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
+                    if (a.score != b.score) return a.score > b.score;
+                    if (a.t != b.t) return a.t < b.t;
+                    return a.q < b.q;
+                });
+                st.anchors += (int64_t)u.anchors.size();
+                u.batch = (size_t)env_long("MIBLAST_GAPPED_BATCH0", 32);
+                units.push_back(std::move(u));
+            }
+        }
+    }
+    const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 8192);
+    const int64_t trace_budget = env_long("MIBLAST_TRACE_BUDGET_MB", 8192) << 20;
+    GappedScratch g;
+    struct Pending { size_t unit, anchor; };
+    while (true) {
+        // commit what can be committed, then nominate the next speculative batch of every unit
+        std::vector<Pending> pend;
+        for (size_t ui = 0; ui < units.size(); ui++) {
+            Unit &u = units[ui];
+            while (u.next < u.anchors.size()) {
+                const Anchor &a = u.anchors[u.next];
+                if (covered(u, a)) { st.anchors_skipped++; u.cache.erase(u.next); u.next++; continue; }
+                auto it = u.cache.find(u.next);
+                if (it == u.cache.end()) break;
+                Cached &c = it->second;
+                st.dp_sides += 2; st.dp_cells += c.cells; st.dp_rows += c.rows;
+                if (c.accepted) {
+                    miblast_aln A;
+                    memset(&A, 0, sizeof A);
+                    A.strand = u.strand; A.q_contig = u.q_contig; A.t_contig = T.contig_of(a.t);
+                    A.t_lo = c.t_lo; A.t_hi = c.t_hi; A.q_lo = c.q_lo; A.q_hi = c.q_hi;
+                    A.score = c.score; A.dmin = c.dmin; A.dmax = c.dmax; A.anchor_t = a.t; A.anchor_q = a.q;
+                    A.ops_off = (int64_t)u.unit_ops.size(); A.n_ops = (int64_t)c.ops.size();
+                    u.unit_ops.insert(u.unit_ops.end(), c.ops.begin(), c.ops.end());
+                    u.kept.push_back(A);
+                }
+                u.cache.erase(it);
+                u.next++;
+            }
+            size_t taken = 0;
+            for (size_t k = u.next; k < u.anchors.size() && taken < u.batch; k++) {
+                if (u.cache.count(k)) continue;
+                if (covered(u, u.anchors[k])) continue;
+                pend.push_back(Pending{ui, k});
+                taken++;
+            }
+            u.batch = std::min(batch_max, u.batch * 2);
+        }
+        if (pend.empty()) break;
+        st.gapped_rounds++;
+
+        // ---- score pass: two one-sided DPs per anchor -----------------------------------------------
+        const int np = (int)pend.size() * 2;
+        std::vector<DpProb> probs((size_t)np);
+        for (size_t k = 0; k < pend.size(); k++) {
+            const Unit &u = units[pend[k].unit];
+            const Anchor &a = u.anchors[pend[k].anchor];
+            int tcg = T.contig_of(a.t);
+            int64_t tlo = T.starts[(size_t)tcg], thi = tlo + T.lens[(size_t)tcg];
+            int64_t qlo = Q.starts[(size_t)u.q_contig], qhi = qlo + Q.lens[(size_t)u.q_contig];
+            DpProb &r = probs[2 * k], &l = probs[2 * k + 1];
+            memset(&r, 0, sizeof r); memset(&l, 0, sizeof l);
+            r.t0 = a.t; r.q0 = a.q; r.dir = +1; r.na = (int32_t)(thi - a.t); r.nb = (int32_t)(qhi - a.q); r.strand = u.strand; r.stop_row = 0x7fffffff;
+            l.t0 = a.t; l.q0 = a.q; l.dir = -1; l.na = (int32_t)(a.t - tlo); l.nb = (int32_t)(a.q - qlo); l.strand = u.strand; l.stop_row = 0x7fffffff;
+        }
+        g.probs.ensure((size_t)np); g.outs.ensure((size_t)np);
+        MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
+        run_ydrop_timed(ctx, st, false, false, g.probs.p, g.outs.p, np, T.dev(), qc_d[0], qc_d[1], p, g);
+        std::vector<DpOut> outs((size_t)np);
+        MB_HIP(hipMemcpy(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost));
+        // rows wider than the LDS ring: rerun those sides with the ring in HBM
+        std::vector<int> wide;
+        for (int k = 0; k < np; k++) if (outs[(size_t)k].overflow) wide.push_back(k);
+        for (size_t w0 = 0; w0 < wide.size(); w0 += 64) {
+            size_t w1 = std::min(wide.size(), w0 + 64);
+            std::vector<DpProb> wp;
+            for (size_t k = w0; k < w1; k++) wp.push_back(probs[(size_t)wide[k]]);
+            DevBuf<DpProb> dwp(wp.size()); DevBuf<DpOut> dwo(wp.size());
+            g.grows.ensure(wp.size() * 2 * (size_t)kGlobalRowCap);
+            MB_HIP(hipMemcpy(dwp.p, wp.data(), wp.size() * sizeof(DpProb), hipMemcpyHostToDevice));
+            run_ydrop_timed(ctx, st, false, true, dwp.p, dwo.p, (int)wp.size(), T.dev(), qc_d[0], qc_d[1], p, g);
+            std::vector<DpOut> wo(wp.size());
+            MB_HIP(hipMemcpy(wo.data(), dwo.p, wp.size() * sizeof(DpOut), hipMemcpyDeviceToHost));
+            for (size_t k = w0; k < w1; k++) {
+                if (wo[k - w0].overflow) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
+                outs[(size_t)wide[k]] = wo[k - w0];
+                outs[(size_t)wide[k]].overflow = 2;       // remember: needs the HBM ring in the trace pass too
+            }
+        }
+        for (int k = 0; k < np; k++) { st.dp_sides_run++; st.dp_cells_run += outs[(size_t)k].cells; }
+
+        // ---- trace pass + traceback for anchors reaching --gappedthresh ------------------------------
+        std::vector<size_t> acc;                        // indices into pend
+        for (size_t k = 0; k < pend.size(); k++) {
+            Unit &u = units[pend[k].unit];
+            Cached c;
+            const DpOut &R = outs[2 * k], &L = outs[2 * k + 1];
+            const Anchor &a = u.anchors[pend[k].anchor];
+            c.score = R.best + L.best;
+            c.cells = R.cells + L.cells; c.rows = (int64_t)R.rows + L.rows;
+            c.t_lo = a.t - L.bj; c.t_hi = a.t + R.bj; c.q_lo = a.q - L.bi; c.q_hi = a.q + R.bi;
+            c.accepted = c.score >= p.gappedthresh;
+            if (c.accepted) acc.push_back(k);
+            u.cache.emplace(pend[k].anchor, std::move(c));
+        }
+        size_t a0 = 0;
+        while (a0 < acc.size()) {
+            // chunk of accepted anchors whose traces fit the budget
+            size_t a1 = a0; int64_t bytes = 0;
+            while (a1 < acc.size()) {
+                const DpOut &R = outs[2 * acc[a1]], &L = outs[2 * acc[a1] + 1];
+                int64_t need = R.cells_to_bi + L.cells_to_bi;
+                if (a1 > a0 && bytes + need > trace_budget) break;
+                bytes += need; a1++;
+            }
+            for (int pass = 0; pass < 2; pass++) {      // pass 0: LDS-ring sides, pass 1: HBM-ring sides
+                std::vector<DpProb> tp; std::vector<std::pair<size_t, int>> who;   // (acc index, side)
+                uint64_t toff = 0, roff = 0, ooff = 0;
+                for (size_t k = a0; k < a1; k++)
+                    for (int side = 0; side < 2; side++) {
+                        const DpOut &o = outs[2 * acc[k] + side];
+                        if ((o.overflow == 2) != (pass == 1)) continue;
+                        DpProb pr = probs[2 * acc[k] + side];
+                        pr.stop_row = o.bi; pr.trace_off = toff; pr.row_off = roff; pr.ops_off = ooff;
+                        toff += (uint64_t)o.cells_to_bi; roff += (uint64_t)o.bi + 1; ooff += (uint64_t)o.bi + (uint64_t)o.bj + 1;
+                        tp.push_back(pr); who.emplace_back(k, side);
+                    }
+                if (tp.empty()) continue;
+                const size_t per_launch = pass == 1 ? 64 : tp.size();
+                g.trace.ensure((size_t)toff + 64); g.rowoff.ensure((size_t)roff + 1); g.rowly.ensure((size_t)roff + 1); g.ops.ensure((size_t)ooff + 1);
+                g.probs.ensure(tp.size()); g.outs.ensure(tp.size());
+                MB_HIP(hipMemcpy(g.probs.p, tp.data(), tp.size() * sizeof(DpProb), hipMemcpyHostToDevice));
+                if (pass == 1) g.grows.ensure(std::min(per_launch, tp.size()) * 2 * (size_t)kGlobalRowCap);
+                for (size_t l0 = 0; l0 < tp.size(); l0 += per_launch) {
+                    size_t l1 = std::min(tp.size(), l0 + per_launch);
+                    run_ydrop_timed(ctx, st, true, pass == 1, g.probs.p + l0, g.outs.p + l0, (int)(l1 - l0), T.dev(), qc_d[0], qc_d[1], p, g);
+                }
+                launch_traceback(g.probs.p, g.outs.p, (int)tp.size(), g.trace.p, g.rowoff.p, g.rowly.p, g.ops.p, s);
+                std::vector<DpOut> to(tp.size());
+                std::vector<uint8_t> hops((size_t)ooff + 1);
+                MB_HIP(hipMemcpyAsync(to.data(), g.outs.p, tp.size() * sizeof(DpOut), hipMemcpyDeviceToHost, s));
+                MB_HIP(hipMemcpyAsync(hops.data(), g.ops.p, (size_t)ooff, hipMemcpyDeviceToHost, s));
+                MB_HIP(hipStreamSynchronize(s));
+                for (size_t k = 0; k < tp.size(); k++) {
+                    st.dp_sides_run++; st.dp_cells_run += to[k].cells;
+                    Unit &u = units[pend[acc[who[k].first]].unit];
+                    Cached &c = u.cache[pend[acc[who[k].first]].anchor];
+                    std::vector<uint8_t> &raw = who[k].second == 0 ? c.raw_r : c.raw_l;
+                    raw.assign(hops.begin() + (ptrdiff_t)tp[k].ops_off, hops.begin() + (ptrdiff_t)tp[k].ops_off + to[k].n_ops);
+                }
+            }
+            // merge the two sides of every accepted anchor of this chunk into a run-length '=XID' string
+            for (size_t k = a0; k < a1; k++) {
+                Unit &u = units[pend[acc[k]].unit];
+                Cached &c = u.cache[pend[acc[k]].anchor];
+                std::vector<uint8_t> Rops, Lops;
+                Rops.swap(c.raw_r); Lops.swap(c.raw_l);
+                c.ops.clear();
+                const uint8_t *qc = qc_h[u.strand];
+                int64_t tt = c.t_lo, qq = c.q_lo;
+                int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
+                uint32_t cur_op = 0, cur_len = 0;
+                const size_t ncol = Lops.size() + Rops.size();
+                for (size_t col = 0; col < ncol; col++) {
+                    uint8_t o = col < Lops.size() ? Lops[col] : Rops[Rops.size() - 1 - (col - Lops.size())];
+                    uint32_t op;
+                    if (o == 0) {
+                        unsigned x = tc_h[tt] & 7u, y = qc[qq] & 7u;
+                        op = (x < 4u && x == y) ? 0u : 1u;
+                        int32_t d = (int32_t)(tt - qq);
+                        dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+                        tt++; qq++;
+                    } else if (o == 2) { op = 2; qq++; }
+                    else { op = 3; tt++; }
+                    if (cur_len && op == cur_op) cur_len++;
+                    else { if (cur_len) c.ops.push_back((cur_len << 2) | cur_op); cur_op = op; cur_len = 1; }
+                }
+                if (cur_len) c.ops.push_back((cur_len << 2) | cur_op);
+                c.dmin = dmin; c.dmax = dmax;
+                if (tt != c.t_hi || qq != c.q_hi) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
+            }
+            a0 = a1;
+        }
+    }
+    st.t_gapped = now_s() - t_g0;
+
+    // ---- output: per query contig, '+' then '-', commit order ------------------------------
+    for (int qc_i = 0; qc_i < (int)Q.starts.size(); qc_i++)
+        for (int strand = 0; strand < 2; strand++)
+            for (Unit &u : units) {
+                if (u.q_contig != qc_i || u.strand != strand) continue;
+                for (miblast_aln A : u.kept) {
+                    int64_t off = (int64_t)res.ops.size();
+                    res.ops.insert(res.ops.end(), u.unit_ops.begin() + A.ops_off, u.unit_ops.begin() + A.ops_off + A.n_ops);
+                    A.ops_off = off;
+                    res.alns.push_back(A);
+                }
+            }
+    st.alignments = (int64_t)res.alns.size();
+    char line[640];
+    for (const miblast_aln &A : res.alns) {
+        int64_t qst = Q.starts[(size_t)A.q_contig], qlen = Q.lens[(size_t)A.q_contig];
+        int64_t tst = T.starts[(size_t)A.t_contig], tlen = T.lens[(size_t)A.t_contig];
+        int64_t qs = A.q_lo - qst, qe = A.q_hi - qst;
+        if (A.strand) { int64_t s2 = qlen - qe, e2 = qlen - qs; qs = s2; qe = e2; }
+        int64_t nmatch = 0, alen = 0;
+        for (int64_t k = 0; k < A.n_ops; k++) {
+            uint32_t o = res.ops[(size_t)(A.ops_off + k)];
+            alen += o >> 2;
+            if ((o & 3u) == 0) nmatch += o >> 2;
+        }
+        int n = snprintf(line, sizeof line, "%s\t%lld\t%lld\t%lld\t%c\t%s\t%lld\t%lld\t%lld\t%lld\t%lld\t255\tAS:i:%d\tcg:Z:",
+                         Q.names[(size_t)A.q_contig].c_str(), (long long)qlen, (long long)qs, (long long)qe, A.strand ? '-' : '+',
+                         T.names[(size_t)A.t_contig].c_str(), (long long)tlen, (long long)(A.t_lo - tst), (long long)(A.t_hi - tst),
+                         (long long)nmatch, (long long)alen, A.score);
+        if (n >= (int)sizeof line) {             // very long names: format in a string instead
+            std::string big((size_t)n + 1, '\0');
+            snprintf(&big[0], big.size(), "%s\t%lld\t%lld\t%lld\t%c\t%s\t%lld\t%lld\t%lld\t%lld\t%lld\t255\tAS:i:%d\tcg:Z:",
+                     Q.names[(size_t)A.q_contig].c_str(), (long long)qlen, (long long)qs, (long long)qe, A.strand ? '-' : '+',
+                     T.names[(size_t)A.t_contig].c_str(), (long long)tlen, (long long)(A.t_lo - tst), (long long)(A.t_hi - tst),
+                     (long long)nmatch, (long long)alen, A.score);
+            res.paf.append(big.c_str(), (size_t)n);
+        } else res.paf.append(line, (size_t)n);
+        for (int64_t k = 0; k < A.n_ops; k++) {
+            uint32_t o = res.ops[(size_t)(A.ops_off + k)];
+            n = snprintf(line, sizeof line, "%u%c", o >> 2, "=XID"[o & 3u]);
+            res.paf.append(line, (size_t)n);
+        }
+        res.paf.push_back('\n');
+    }
+    st.t_total = now_s() - t_begin;
+    return MIBLAST_OK;
+}
+
+}  // namespace mb

@@ -1,0 +1,27 @@
+// mb_pipeline.h -- host-side objects behind the opaque handles of include/miblast.h
+#pragma once
+
+#include "mb_common.h"
+
+namespace mb {
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
+};
+
+struct Result {
+    std::string paf;
+    std::vector<miblast_hsp> hsps;
+    std::vector<miblast_aln> alns;
+    std::vector<uint32_t> ops;
+    miblast_stats stats{};
+};
+
+void upload_seqset(SeqSet &s, int device);
+void release_seqset(SeqSet &s);
+int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &p, Result &res);
+int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions);
+
+}  // namespace mb

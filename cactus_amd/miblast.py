@@ -1,0 +1,240 @@
+"""ctypes binding of libmiblast.so (include/miblast.h) -- the in-process form of the lastz /
+run_kegalign replacement.  This is product code: it never imports anything from oracle/ and it
+raises if the HIP library or a gfx950 device is missing (there is no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiblast.so")
+
+
+class MiblastError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """miblast_params; defaults = lastz defaults."""
+    _fields_ = [(n, C.c_int32) for n in ("step", "transitions", "xdrop", "ydrop", "hspthresh", "gappedthresh", "gap_open",
+                                          "gap_extend", "entropy", "queryhspbest", "ambiguous_n", "gapped")]
+
+    def __repr__(self):
+        return "Params(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_) + ")"
+
+
+class Hsp(C.Structure):
+    _fields_ = [("t_start", C.c_int32), ("q_start", C.c_int32), ("len", C.c_int32), ("score", C.c_int32),
+                ("seed_t_end", C.c_int32), ("seed_q_end", C.c_int32), ("cnt", C.c_int32 * 4), ("strand", C.c_int32),
+                ("q_contig", C.c_int32)]
+
+
+class Aln(C.Structure):
+    _fields_ = [("strand", C.c_int32), ("q_contig", C.c_int32), ("t_contig", C.c_int32), ("t_lo", C.c_int32),
+                ("t_hi", C.c_int32), ("q_lo", C.c_int32), ("q_hi", C.c_int32), ("score", C.c_int32), ("dmin", C.c_int32),
+                ("dmax", C.c_int32), ("anchor_t", C.c_int32), ("anchor_q", C.c_int32), ("ops_off", C.c_int64),
+                ("n_ops", C.c_int64)]
+
+
+class Stats(C.Structure):
+    _fields_ = ([(n, C.c_int64) for n in ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps_pre_entropy",
+                                           "hsps", "anchors", "anchors_skipped", "dp_sides", "dp_cells", "dp_rows", "alignments")]
+                + [(n, C.c_double) for n in ("t_index", "t_seed", "t_gapped", "t_total")]
+                + [("dp_sides_run", C.c_int64), ("dp_cells_run", C.c_int64), ("gapped_rounds", C.c_int64),
+                   ("seed_batches", C.c_int64), ("t_dp_kernel_ms", C.c_double), ("dp_kernel_launches", C.c_int64),
+                   ("t_ungapped_kernel_ms", C.c_double), ("ungapped_kernel_launches", C.c_int64), ("t_sort_ms", C.c_double),
+                   ("t_seedfill_ms", C.c_double)])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libmiblast.so; raises MiblastError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MiblastError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C cactus_amd/csrc`")
+    lib = C.CDLL(LIB_PATH)
+    vp, cp, i32, i64 = C.c_void_p, C.c_char_p, C.c_int32, C.c_int64
+    P = C.POINTER
+    sig = {
+        "miblast_params_default": (None, [P(Params)]),
+        "miblast_params_from_argv": (C.c_int, [C.c_int, P(cp), P(Params), P(cp), P(C.c_int), P(C.c_int)]),
+        "miblast_device_count": (C.c_int, []),
+        "miblast_ctx_create": (C.c_int, [C.c_int, P(vp)]),
+        "miblast_ctx_destroy": (None, [vp]),
+        "miblast_seqset_from_fasta_file": (C.c_int, [vp, cp, P(vp)]),
+        "miblast_seqset_from_fasta_mem": (C.c_int, [vp, cp, C.c_size_t, P(vp)]),
+        "miblast_seqset_free": (None, [vp]),
+        "miblast_seqset_n_contigs": (i32, [vp]),
+        "miblast_seqset_total": (i64, [vp]),
+        "miblast_seqset_name": (cp, [vp, i32]),
+        "miblast_seqset_start": (i64, [vp, i32]),
+        "miblast_seqset_len": (i64, [vp, i32]),
+        "miblast_align": (C.c_int, [vp, vp, vp, P(Params), P(vp)]),
+        "miblast_result_free": (None, [vp]),
+        "miblast_result_paf": (vp, [vp, P(C.c_size_t)]),
+        "miblast_result_stats": (P(Stats), [vp]),
+        "miblast_result_hsps": (P(Hsp), [vp, P(i64)]),
+        "miblast_result_alns": (P(Aln), [vp, P(i64)]),
+        "miblast_result_ops": (P(C.c_uint32), [vp, P(i64)]),
+        "miblast_align_files": (C.c_int, [vp, cp, cp, P(Params), C.c_int, P(Stats)]),
+        "miblast_build_index": (C.c_int, [vp, vp, i32, P(P(C.c_uint32)), P(P(C.c_uint32))]),
+        "miblast_free": (None, [vp]),
+        "miblast_last_error": (cp, []),
+        "miblast_version": (cp, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)           # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_ctx_create",
+                    "miblast_ctx_destroy", "miblast_seqset_from_fasta_file", "miblast_seqset_from_fasta_mem",
+                    "miblast_seqset_free", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
+                    "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_result_free",
+                    "miblast_result_paf", "miblast_result_stats", "miblast_result_hsps", "miblast_result_alns",
+                    "miblast_result_ops", "miblast_align_files", "miblast_build_index", "miblast_free",
+                    "miblast_last_error", "miblast_version")
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise MiblastError(f"miblast rc={rc}: {load().miblast_last_error().decode()}")
+
+
+def default_params(**over) -> Params:
+    p = Params()
+    load().miblast_params_default(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def params_from_args(args) -> Params:
+    """Parses lastz-style option strings (no file names), e.g. the <lastzArguments> sets."""
+    argv = [b"lastz", b"T.fa", b"Q.fa"] + [a.encode() for a in args if a]
+    arr = (C.c_char_p * len(argv))(*argv)
+    p = Params()
+    files = (C.c_char_p * 2)()
+    ng, nt = C.c_int(), C.c_int()
+    _check(load().miblast_params_from_argv(len(argv), arr, C.byref(p), files, C.byref(ng), C.byref(nt)))
+    return p
+
+
+def device_count() -> int:
+    return load().miblast_device_count()
+
+
+@dataclass
+class AlignResult:
+    paf: bytes
+    stats: dict
+    hsps: list
+    alns: list
+    ops: list
+
+
+class SeqSet:
+    def __init__(self, ctx: "Context", handle):
+        self._ctx, self._h = ctx, handle
+
+    @property
+    def total(self) -> int:
+        return load().miblast_seqset_total(self._h)
+
+    @property
+    def contigs(self):
+        lib = load()
+        return [(lib.miblast_seqset_name(self._h, i).decode(), lib.miblast_seqset_start(self._h, i), lib.miblast_seqset_len(self._h, i))
+                for i in range(lib.miblast_seqset_n_contigs(self._h))]
+
+    def close(self):
+        if self._h:
+            load().miblast_seqset_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One MI355X.  Raises MiblastError when no gfx950 device is visible."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _check(load().miblast_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def seqset_from_fasta_bytes(self, data: bytes) -> SeqSet:
+        h = C.c_void_p()
+        _check(load().miblast_seqset_from_fasta_mem(self._h, data, len(data), C.byref(h)))
+        return SeqSet(self, h)
+
+    def seqset_from_fasta_file(self, path: str) -> SeqSet:
+        h = C.c_void_p()
+        _check(load().miblast_seqset_from_fasta_file(self._h, path.encode(), C.byref(h)))
+        return SeqSet(self, h)
+
+    def align(self, target: SeqSet, query: SeqSet, params: Params, details: bool = True) -> AlignResult:
+        lib = load()
+        r = C.c_void_p()
+        _check(lib.miblast_align(self._h, target._h, query._h, C.byref(params), C.byref(r)))
+        try:
+            n = C.c_size_t()
+            ptr = lib.miblast_result_paf(r, C.byref(n))
+            paf = C.string_at(ptr, n.value) if n.value else b""
+            stats = lib.miblast_result_stats(r).contents.as_dict()
+            hsps = alns = ops = []
+            if details:
+                k = C.c_int64()
+                hp = lib.miblast_result_hsps(r, C.byref(k))
+                hsps = [(h.strand, h.q_contig, h.t_start, h.q_start, h.len, h.score, h.seed_t_end, h.seed_q_end, tuple(h.cnt))
+                        for h in (hp[i] for i in range(k.value))]
+                ap = lib.miblast_result_alns(r, C.byref(k))
+                alns = [(a.strand, a.q_contig, a.t_contig, a.t_lo, a.t_hi, a.q_lo, a.q_hi, a.score, a.dmin, a.dmax,
+                         a.anchor_t, a.anchor_q, a.n_ops) for a in (ap[i] for i in range(k.value))]
+                op = lib.miblast_result_ops(r, C.byref(k))
+                ops = [op[i] for i in range(k.value)] if k.value < 5_000_000 else []
+            return AlignResult(paf, stats, hsps, alns, ops)
+        finally:
+            lib.miblast_result_free(r)
+
+    def build_index(self, target: SeqSet, step: int):
+        """Returns (offsets, positions) as numpy arrays (seed position table, CSR over 2^24 words)."""
+        import numpy as np
+        lib = load()
+        off, pos = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        _check(lib.miblast_build_index(self._h, target._h, step, C.byref(off), C.byref(pos)))
+        try:
+            o = np.ctypeslib.as_array(off, shape=((1 << 24) + 1,)).copy()
+            p = np.ctypeslib.as_array(pos, shape=(max(1, int(o[-1])),)).copy()[: int(o[-1])]
+        finally:
+            lib.miblast_free(off)
+            lib.miblast_free(pos)
+        return o, p
+
+    def close(self):
+        if self._h:
+            load().miblast_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,151 @@
+/*
+ * miblast.h -- C ABI of libmiblast.so, the MI355X-native replacement for the external
+ * `lastz` / `run_kegalign` executables that Cactus's blast phase shells out to.
+ *
+ * The reference has NO FFI for this path: the boundary is a subprocess command line built by
+ *   run_lastz                /root/reference/src/cactus/paf/local_alignment.py:29-97
+ *     argv                   local_alignment.py:60-68   (lastz A.fa[multiple][nameparse=darkspace] B.fa[...] --format=paf:wfmash <opts>)
+ *     GPU argv               local_alignment.py:54-58   (run_kegalign A.fa B.fa --format=paf:wfmash <opts> --num_gpu G --num_threads C)
+ *     process launch         /root/reference/src/cactus/shared/common.py:732-994 (cactus_call: stdout -> file, exit code, stderr)
+ * Each entry point below names the piece of that interface it replaces.  The same code is also
+ * linked into bin/lastz and bin/run_kegalign (cactus_amd/csrc/mb_lastz_main.cpp) so that the
+ * unmodified run_lastz job works with CACTUS_BINARIES_MODE=local; INTEGRATION.md shows the
+ * ctypes binding a maintainer would add for in-process use.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * MIBLAST_E* code and never throws, aborts or writes to stderr; miblast_last_error() returns a
+ * thread-local message.  Callers own the buffers they pass in; buffers returned by the library
+ * stay valid until the owning handle is freed.
+ */
+#ifndef MIBLAST_H
+#define MIBLAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIBLAST_OK         0
+#define MIBLAST_EINVAL    (-1)   /* bad argument / unknown option (lastz: exit != 0, common.py:962-988) */
+#define MIBLAST_EIO       (-2)   /* cannot read input / write output                                    */
+#define MIBLAST_ENODEV    (-3)   /* no usable gfx950 device: the library has NO CPU fallback             */
+#define MIBLAST_EHIP      (-4)   /* a HIP runtime call returned non-success                               */
+#define MIBLAST_ELIMIT    (-5)   /* input exceeds an implementation limit               */
+
+/* ---- alignment parameters = the lastz options Cactus passes ------------------------------
+ * (cactus_progressive_config.xml:130-146 <lastzArguments>/<kegalignArguments>; lastz defaults
+ * per SURVEY.md A.2).  Same field order as the oracle's olz_params on purpose: tests memcpy. */
+typedef struct miblast_params {
+    int32_t step;          /* --step=N                                   default 1    */
+    int32_t transitions;   /* 0 = --notransition                         default 1    */
+    int32_t xdrop;         /* ungapped x-drop                            default 910  */
+    int32_t ydrop;         /* --ydrop=N                                  default 9400 */
+    int32_t hspthresh;     /* --hspthresh=N                              default 3000 */
+    int32_t gappedthresh;  /* --gappedthresh=N (-1: same as hspthresh)   default -1   */
+    int32_t gap_open;      /* 400                                                     */
+    int32_t gap_extend;    /* 30                                                      */
+    int32_t entropy;       /* entropy-adjusted HSP filter                default 1    */
+    int32_t queryhspbest;  /* --queryhspbest=N, 0 = unlimited            default 0    */
+    int32_t ambiguous_n;   /* --ambiguous=iupac,100,100                  default 1    */
+    int32_t gapped;        /* 0 = --ungapped / --nogapped                default 1    */
+} miblast_params;
+
+void miblast_params_default(miblast_params *p);
+
+/* Replaces lastz's own option parser for the argv run_lastz builds (local_alignment.py:60-68).
+ * argv[0] is ignored.  On return files[0]/files[1] point INTO argv (target, query) with any
+ * trailing [actions] left in place; num_gpu / num_threads receive --num_gpu / --num_threads
+ * (local_alignment.py:58) or 1 / 1.  Unknown option -> MIBLAST_EINVAL.                        */
+int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const char *files[2],
+                             int *num_gpu, int *num_threads);
+
+/* ---- device context ---------------------------------------------------------------------- */
+typedef struct miblast_ctx miblast_ctx;
+
+/* Replaces `count_nvidia_gpus` (/root/reference/src/cactus/shared/configWrapper.py:307).      */
+int miblast_device_count(void);
+/* One context per process per GPU (ordinal after HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES). */
+int miblast_ctx_create(int device, miblast_ctx **ctx);
+void miblast_ctx_destroy(miblast_ctx *ctx);
+
+/* ---- sequence sets ------------------------------------------------------------------------
+ * A FASTA file as lastz loads it with [multiple][nameparse=darkspace] (local_alignment.py:60-62):
+ * all records concatenated with one separator, names cut at the first blank.  The set is encoded
+ * on the host and made resident in HBM at creation, so miblast_align() starts from device memory. */
+typedef struct miblast_seqset miblast_seqset;
+
+int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_seqset **out);
+int miblast_seqset_from_fasta_mem(miblast_ctx *ctx, const char *buf, size_t len, miblast_seqset **out);
+void miblast_seqset_free(miblast_seqset *s);
+int32_t miblast_seqset_n_contigs(const miblast_seqset *s);
+int64_t miblast_seqset_total(const miblast_seqset *s);           /* concatenated length */
+const char *miblast_seqset_name(const miblast_seqset *s, int32_t i);
+int64_t miblast_seqset_start(const miblast_seqset *s, int32_t i);
+int64_t miblast_seqset_len(const miblast_seqset *s, int32_t i);
+
+/* ---- results ------------------------------------------------------------------------------- */
+typedef struct miblast_hsp {            /* an ungapped HSP that passed --hspthresh (+entropy, +queryhspbest) */
+    int32_t t_start, q_start, len, score;   /* concatenated coordinates; q on the strand searched */
+    int32_t seed_t_end, seed_q_end;
+    int32_t cnt[4];                         /* identical A,C,G,T columns (entropy input)          */
+    int32_t strand;                         /* 0 '+', 1 '-'                                        */
+    int32_t q_contig;
+} miblast_hsp;
+
+typedef struct miblast_aln {            /* one output alignment = one PAF line                    */
+    int32_t strand, q_contig, t_contig;
+    int32_t t_lo, t_hi, q_lo, q_hi;         /* concatenated, strand coordinates, half-open         */
+    int32_t score;
+    int32_t dmin, dmax;                     /* diagonal band of its aligned columns                */
+    int32_t anchor_t, anchor_q;
+    int64_t ops_off, n_ops;                 /* into miblast_result_ops()                           */
+} miblast_aln;
+
+typedef struct miblast_stats {          /* counters defined by SURVEY.md section 8(d); seconds are GPU-side wall time */
+    int64_t seed_lookups, seed_hits, hits_extended, ungapped_cols;
+    int64_t hsps_pre_entropy, hsps, anchors, anchors_skipped;
+    int64_t dp_sides, dp_cells, dp_rows, alignments;
+    double  t_index, t_seed, t_gapped, t_total;
+    /* implementation-side extras (not part of the oracle's counter set) */
+    int64_t dp_sides_run, dp_cells_run;     /* incl. speculative / re-run work                    */
+    int64_t gapped_rounds, seed_batches;
+    double  t_dp_kernel_ms;  int64_t dp_kernel_launches;     /* HIP-event time of k_ydrop launches  */
+    double  t_ungapped_kernel_ms; int64_t ungapped_kernel_launches;
+    double  t_sort_ms, t_seedfill_ms;
+} miblast_stats;
+
+typedef struct miblast_result miblast_result;
+
+/* The blast job itself: replaces one `lastz target query --format=paf:wfmash <opts>` process
+ * (local_alignment.py:65-73).  Output order and bytes follow SURVEY.md Appendix B / A.8.       */
+int miblast_align(miblast_ctx *ctx, const miblast_seqset *target, const miblast_seqset *query,
+                  const miblast_params *p, miblast_result **out);
+void miblast_result_free(miblast_result *r);
+/* PAF text that the reference reads from the process's stdout (common.py:875-878).            */
+const char *miblast_result_paf(const miblast_result *r, size_t *len);
+const miblast_stats *miblast_result_stats(const miblast_result *r);
+const miblast_hsp *miblast_result_hsps(const miblast_result *r, int64_t *n);
+const miblast_aln *miblast_result_alns(const miblast_result *r, int64_t *n);
+const uint32_t *miblast_result_ops(const miblast_result *r, int64_t *n);   /* (len<<2)|op, op 0 '=',1 'X',2 'I',3 'D' */
+
+/* File-level convenience = what bin/lastz does: load both FASTA files, align, write PAF to fd.
+ * Replaces the whole cactus_call(lastz ...) invocation (local_alignment.py:72).                */
+int miblast_align_files(miblast_ctx *ctx, const char *target_fa, const char *query_fa,
+                        const miblast_params *p, int out_fd, miblast_stats *stats);
+
+/* Stage export for parity tests: the target seed position table (lastz pos_table)
+ * as CSR.  offsets has 2^24+1 entries; positions are ascending inside a bucket.  Caller frees
+ * both with miblast_free().                                                                    */
+int miblast_build_index(miblast_ctx *ctx, const miblast_seqset *target, int32_t step,
+                        uint32_t **offsets, uint32_t **positions);
+void miblast_free(void *p);
+
+const char *miblast_last_error(void);
+const char *miblast_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
