@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- blast-phase throughput of the MI355X-native lastz replacement.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): one 1 Mb x 1 Mb synthetic chunk pair
+per GPU (ancestor + mutated copy: 15 % substitutions, 1 % indels, one inversion, one replaced
+segment, 20 % soft-masked, two N runs), lastz "default" parameter set of
+cactus_progressive_config.xml:136.  A step = one full blast job (index build, seed search both
+strands, ungapped extension, gapped Y-drop extension, PAF) with both sequence sets already
+resident in HBM.  N>1: one process per GPU, each with its own chunk pair (weak scaling, no
+data-path collective); the only exchange is the gather of the final PAF bytes to rank 0 over RCCL,
+inside the timed region.
+
+Prints ONE JSON line on rank 0.  metric value = dp_cells (the oracle-defined counter: cells of
+committed anchors only, speculative work NOT counted) per second, whole job.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DEFAULT_ARGS = "--step=1 --ambiguous=iupac,100,100 --ydrop=4000 --hspthresh=2200 --gappedthresh=2400 --queryhspbest=100000"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1_000_000, help="bases per chunk (config 2: 1 Mb)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--random-pair", action="store_true", help="pure-random pair (seed/ungapped isolation)")
+    ap.add_argument("--cpu-sample", type=int, default=250_000, help="chunk size for the CPU-oracle baseline leg (0 = skip)")
+    ap.add_argument("--lastz-args", default=DEFAULT_ARGS)
+    a = ap.parse_args()
+
+    import torch
+    from cactus_amd import gen, miblast
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libmiblast has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    pm = miblast.params_from_args(a.lastz_args.split())
+    ctx = miblast.Context(local_rank)
+    # each rank aligns its own chunk pair (chunk-pair sharding)
+    t, q = gen.make_pair(a.size, a.seed + rank, homologous=not a.random_pair)
+    T = ctx.seqset_from_fasta_bytes(gen.fasta_bytes([(f"id=simT{rank}|chr1", t)]))
+    Q = ctx.seqset_from_fasta_bytes(gen.fasta_bytes([(f"id=simQ{rank}|chr1", q)]))
+
+    from cactus_amd.multigpu import gather_bytes
+
+    def gather_paf(paf: bytes):
+        """final hit list -> rank 0 (RCCL over xGMI)"""
+        return gather_bytes(paf, dist, rank, world, torch.device("cuda", local_rank))
+
+    def step():
+        r = ctx.align(T, Q, pm, details=False)
+        pafs = gather_paf(r.paf)
+        return r, pafs
+
+    for _ in range(a.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    agg = None
+    for _ in range(a.steps):
+        r, pafs = step()
+        if agg is None:
+            agg = {k: 0 for k in r.stats}
+        for k, v in r.stats.items():
+            agg[k] += v
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    keys = ["dp_cells", "seed_hits", "seed_lookups", "ungapped_cols", "alignments", "dp_cells_run", "t_dp_kernel_ms",
+            "dp_kernel_launches", "t_index", "t_seed", "t_gapped", "t_total", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms"]
+    vec = torch.tensor([float(agg[k]) for k in keys] + [elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    if dist is not None:
+        tmax = vec[-1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax.item())
+    tot = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
+
+    if rank == 0:
+        cells_per_launch = tot["dp_cells_run"] / max(1.0, tot["dp_kernel_launches"])
+        # algorithmic HBM bytes of the Y-drop DP kernel (SURVEY 8d "Gapped"): <= 1 trace byte written per
+        # cell of the trace pass + 2 * 0.375 B of sequence per row/column touched; dominated by the trace.
+        # We charge 1 B per evaluated cell (upper bound of the algorithmic figure).
+        dp_ms = tot["t_dp_kernel_ms"] / max(1.0, tot["dp_kernel_launches"])
+        achieved = (cells_per_launch * 1.0) / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+        out = {
+            "metric": "gapped X-drop Gcell/s (blast phase, whole job)",
+            "value": tot["dp_cells"] / elapsed / 1e9,
+            "unit": "Gcell/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{a.size} x {a.size} synthetic chunk pair per GPU (SURVEY 8d config 2"
+                                   f"{', pure-random variant' if a.random_pair else ''}), seed {a.seed}+rank",
+                       "lastz_args": a.lastz_args, "chunk_pairs": world, "sharding": "one chunk pair per GPU, RCCL gather of PAF"},
+            "seeds_per_s": tot["seed_hits"] / elapsed,
+            "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
+            "stage_seconds_per_step": {k: tot[k] / a.steps / world for k in ("t_index", "t_seed", "t_gapped", "t_total")},
+            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / a.steps / world, "ungapped": tot["t_ungapped_kernel_ms"] / a.steps / world,
+                                         "sort": tot["t_sort_ms"] / a.steps / world, "seed_fill": tot["t_seedfill_ms"] / a.steps / world},
+            "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3 / world) / 1e9,
+            "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
+            "alignments_per_step": tot["alignments"] / a.steps,
+            "roofline": {"bound": "hbm", "kernel": "k_ydrop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "integer DP is VALU/LDS-latency bound, not HBM bound (SURVEY 8d caveat); see DESIGN.md"},
+        }
+        if a.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(a, pm)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, pm):
+    """CPU oracle (kind "port": the in-repo C restatement, 1 thread like a lastz job) on a bounded
+    sample of the same recipe, timed on this box's host cores."""
+    from cactus_amd import gen
+    from oracle import olz
+    n = min(a.size, a.cpu_sample)
+    t, q = gen.make_pair(n, a.seed, homologous=not a.random_pair)
+    tf, qf = gen.fasta_bytes([("id=simT|chr1", t)]), gen.fasta_bytes([("id=simQ|chr1", q)])
+    po = olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_})
+    t0 = time.perf_counter()
+    o = olz.align(tf, qf, po, details=False)
+    dt = time.perf_counter() - t0
+    c = o["counters"]
+    return {"value": c["dp_cells"] / dt / 1e9, "unit": "Gcell/s", "cores": 1, "kind": "port",
+            "sample": f"{n} x {n} pair of the same recipe, seed {a.seed}; whole job {dt:.2f} s",
+            "seeds_per_s": c["seed_hits"] / dt, "seconds": dt,
+            "stage_seconds": {k: c[k] for k in ("t_index", "t_seed", "t_gapped", "t_total")}}
+
+
+if __name__ == "__main__":
+    main()

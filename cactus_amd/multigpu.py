@@ -1,0 +1,74 @@
+"""Multi-GPU driver of the blast phase: chunk pairs are independent (they are separate Toil jobs in the
+reference, /root/reference/src/cactus/paf/local_alignment.py:395-405), so the path shards with no
+data-path collective.  One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" in the CPU tests); the single exchange is the gather of the final PAF bytes to rank 0
+(SURVEY.md 8e).  Output is assembled in chunk-pair order, so it is byte-identical for any world size."""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+
+def assign_pairs(weights: Sequence[float], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of chunk pairs (weight ~ len(A) * len(B)) to ranks.
+    Deterministic: ties go to the lower pair index, then the lower rank."""
+    order = sorted(range(len(weights)), key=lambda i: (-weights[i], i))
+    load = [0.0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += weights[i]
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def gather_bytes(payload: bytes, dist, rank: int, world_size: int, device) -> Optional[List[bytes]]:
+    """Variable-length gather to rank 0: all_gather of the byte counts, then one padded gather
+    (the 'gatherv' of SURVEY 8e; payload is small next to xGMI bandwidth, so latency matters, not size)."""
+    import torch
+    if world_size == 1:
+        return [payload]
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world_size)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(1, max(sizes))
+    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+    if payload:
+        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    return [bytes(o[:s].cpu().numpy()) for o, s in zip(out, sizes)]
+
+
+def _frame(index: int, paf: bytes) -> bytes:
+    return index.to_bytes(8, "little") + len(paf).to_bytes(8, "little") + paf
+
+
+def _unframe(blob: bytes):
+    pos = 0
+    while pos < len(blob):
+        idx = int.from_bytes(blob[pos:pos + 8], "little")
+        n = int.from_bytes(blob[pos + 8:pos + 16], "little")
+        yield idx, blob[pos + 16:pos + 16 + n]
+        pos += 16 + n
+
+
+def blast_pairs_sharded(pairs: Sequence, weights: Sequence[float], align_fn: Callable[[object], bytes], dist, rank: int,
+                        world_size: int, device) -> Optional[bytes]:
+    """Aligns pairs[i] for the indices this rank owns, gathers the framed PAFs to rank 0 and returns
+    the concatenation in pair order there (None elsewhere)."""
+    mine = assign_pairs(weights, world_size)[rank]
+    blob = b"".join(_frame(i, align_fn(pairs[i])) for i in mine)
+    gathered = gather_bytes(blob, dist, rank, world_size, device)
+    if gathered is None:
+        return None
+    by_index = {}
+    for part in gathered:
+        for idx, paf in _unframe(part):
+            by_index[idx] = paf
+    assert sorted(by_index) == list(range(len(pairs)))
+    return b"".join(by_index[i] for i in range(len(pairs)))

@@ -1,0 +1,74 @@
+"""Data formats either side of the blast job: the `faffy chunk` FASTA
+chunker and the `paffy dechunk` coordinate fix-up that make_chunked_alignments / combine_chunks shell
+out to (/root/reference/src/cactus/paf/local_alignment.py:378-387 and :352).  The paffy submodule is
+empty in the reference tree, so these follow its documented behaviour: a chunk record is named
+`ORIGINAL|SEQLEN|CHUNKSTART`, chunks are chunkSize (+ overlapSize) long and are packed into files of
+about chunkSize bases; dechunk strips the two suffix fields, shifts start/end by CHUNKSTART and restores
+SEQLEN."""
+from __future__ import annotations
+
+import os
+
+
+def _read_fasta(path):
+    name, parts = None, []
+    with open(path) as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    yield name, "".join(parts)
+                name, parts = line[1:].strip(), []
+            else:
+                parts.append(line.strip())
+    if name is not None:
+        yield name, "".join(parts)
+
+
+def fasta_chunk(fasta_path: str, out_dir: str, chunk_size: int, overlap_size: int):
+    """Returns the list of chunk files written (faffy chunk -c chunk_size -o overlap_size --dir out_dir)."""
+    os.makedirs(out_dir, exist_ok=True)
+    files, fh, remaining, idx = [], None, 0, 0
+    for header, seq in _read_fasta(fasta_path):
+        name = header.split()[0] if header.split() else header
+        n = len(seq)
+        for start in range(0, n, chunk_size):
+            piece = seq[start:start + chunk_size + overlap_size]
+            if fh is None or remaining <= 0:
+                if fh is not None:
+                    fh.close()
+                path = os.path.join(out_dir, "chunk_{}.fa".format(idx))
+                idx += 1
+                fh = open(path, "w")
+                files.append(path)
+                remaining = chunk_size
+            fh.write(">{}|{}|{}\n".format(name, n, start))
+            for i in range(0, len(piece), 100):
+                fh.write(piece[i:i + 100] + "\n")
+            remaining -= len(piece)
+    if fh is not None:
+        fh.close()
+    return files
+
+
+def _split_chunk_name(name: str):
+    base, seq_len, start = name.rsplit("|", 2)
+    return base, int(seq_len), int(start)
+
+
+def paf_dechunk_line(line: str, query_only: bool = False) -> str:
+    f = line.rstrip("\n").split("\t")
+    qname, qlen, qoff = _split_chunk_name(f[0])
+    f[0], f[1] = qname, str(qlen)
+    f[2], f[3] = str(int(f[2]) + qoff), str(int(f[3]) + qoff)
+    if not query_only:
+        tname, tlen, toff = _split_chunk_name(f[5])
+        f[5], f[6] = tname, str(tlen)
+        f[7], f[8] = str(int(f[7]) + toff), str(int(f[8]) + toff)
+    return "\t".join(f) + "\n"
+
+
+def paf_dechunk(in_path: str, out_path: str, query_only: bool = False, append: bool = True):
+    with open(in_path) as fin, open(out_path, "a" if append else "w") as fout:
+        for line in fin:
+            if line.strip():
+                fout.write(paf_dechunk_line(line, query_only))

@@ -1,0 +1,165 @@
+"""Host side of the blast phase: the Toil job functions of
+/root/reference/src/cactus/paf/local_alignment.py that sit directly on the hot path, kept with the
+same names, arguments, return values and error behaviour so the parity tests read like the
+reference's callers:
+
+    run_lastz                 :29-97    one chunk-pair job  -> PAF file id
+    make_chunked_alignments   :370-408  chunk both genomes, all-vs-all run_lastz, then combine
+    combine_chunks            :336-356  dechunk + concatenate
+
+What differs, on purpose: the `lastz` / `run_kegalign` found on PATH are the MI355X front ends in
+<repo>/bin (or, with MIBLAST_INPROCESS=1, the same code through the C ABI via ctypes), AMD GPUs are
+requested as 'rocm:N', and faffy/paffy are replaced by cactus_amd.paf.chunking.  Everything after
+combine_chunks (chaining, trimming, cactus_consolidated) is untouched by design.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+from cactus_amd.paf import chunking
+from cactus_amd.shared.common import cactus_call, getOptionalAttrib
+from cactus_amd.shared.configWrapper import accelerator_string
+
+STDERR_KEYWORDS = ['terminate', 'error', 'fail', 'assert', 'signal', 'abort', 'segmentation', 'sigsegv', 'kill']
+
+
+def select_lastz_params(distance, params, gpu):
+    """distance -> lastz option string, exactly the rule of local_alignment.py:44-51: the first of
+    one..five whose divergence bound is >= distance, else "default" (or always default if useDefault)."""
+    lastz_params_node = params.find("blast")
+    lastz_divergence_node = lastz_params_node.find("kegalignArguments" if gpu else "lastzArguments")
+    divergences = params.find("constants").find("divergences")
+    lastz_params = lastz_divergence_node.attrib["default"]
+    if not getOptionalAttrib(divergences, 'useDefault', typeFn=bool, default=False):
+        for i in "one", "two", "three", "four", "five":
+            if distance <= float(divergences.attrib[i]):
+                lastz_params = lastz_divergence_node.attrib[i]
+                break
+    return lastz_params
+
+
+def run_lastz(job, name_A, genome_A, name_B, genome_B, distance, params):
+    work_dir = job.fileStore.getLocalTempDir()
+    alignment_file = os.path.join(work_dir, '{}_{}.paf'.format(name_A, name_B))
+    genome_a_file = os.path.join(work_dir, '{}.fa'.format(name_A))
+    genome_b_file = os.path.join(work_dir, '{}.fa'.format(name_B))
+    job.fileStore.readGlobalFile(genome_A, genome_a_file)
+    job.fileStore.readGlobalFile(genome_B, genome_b_file)
+
+    lastz_params_node = params.find("blast")
+    gpu = getOptionalAttrib(lastz_params_node, 'gpu', typeFn=int, default=0)
+    cpu = getOptionalAttrib(lastz_params_node, 'cpu', typeFn=int, default=None)
+    lastz_params = select_lastz_params(distance, params, gpu)
+    if gpu:
+        lastz_bin = 'run_kegalign'
+        suffix_a, suffix_b = '', ''
+        assert gpu > 0
+        lastz_params += ' --num_gpu {} --num_threads {}'.format(gpu, job.cores)
+    else:
+        lastz_bin = 'lastz'
+        suffix_a = '[multiple][nameparse=darkspace]'
+        suffix_b = '[nameparse=darkspace]'
+
+    lastz_cmd = [lastz_bin,
+                 '{}{}'.format(os.path.basename(genome_a_file), suffix_a),
+                 '{}{}'.format(os.path.basename(genome_b_file), suffix_b),
+                 '--format=paf:wfmash'] + lastz_params.split(' ')
+
+    if os.environ.get("MIBLAST_INPROCESS") == "1":
+        messages = _run_inprocess(lastz_cmd, work_dir, alignment_file)
+    else:
+        messages = cactus_call(parameters=lastz_cmd, outfile=alignment_file, work_dir=work_dir, returnStdErr=True,
+                               gpus=gpu, cpus=cpu, job_memory=job.memory)
+
+    if gpu:
+        # same guard as local_alignment.py:75-83 -- our front end keeps stderr empty on success
+        for line in (messages or "").lower().split("\n"):
+            if not line.startswith("signals delivered"):
+                for keyword in STDERR_KEYWORDS:
+                    if keyword in line and 'signals' not in line:
+                        job.fileStore.logToMaster("KegAlign offending line: " + line)
+                        raise RuntimeError('{} exited 0 but keyword "{}" found in stderr'.format(lastz_cmd, keyword))
+    return job.fileStore.writeGlobalFile(alignment_file)
+
+
+def _run_inprocess(lastz_cmd, work_dir, alignment_file):
+    """The same job through libmiblast's C ABI instead of a subprocess."""
+    import ctypes as C
+    from cactus_amd import miblast
+    lib = miblast.load()
+    argv = [a.encode() for a in lastz_cmd]
+    arr = (C.c_char_p * len(argv))(*argv)
+    p = miblast.Params()
+    files = (C.c_char_p * 2)()
+    ng, nt = C.c_int(), C.c_int()
+    rc = lib.miblast_params_from_argv(len(argv), arr, C.byref(p), files, C.byref(ng), C.byref(nt))
+    if rc != 0:
+        raise RuntimeError("Command {} exited {}: stderr={}".format(lastz_cmd, 2, lib.miblast_last_error().decode()))
+    ctx = miblast.Context(0)
+    try:
+        fd = os.open(alignment_file, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            rc = lib.miblast_align_files(ctx._h, os.path.join(work_dir, files[0].decode()).encode(),
+                                         os.path.join(work_dir, files[1].decode()).encode(), C.byref(p), fd, None)
+        finally:
+            os.close(fd)
+        if rc != 0:
+            raise RuntimeError("Command {} exited {}: stderr={}".format(lastz_cmd, 1, lib.miblast_last_error().decode()))
+    finally:
+        ctx.close()
+    return ""
+
+
+def combine_chunks(job, chunked_alignment_files, batch_size):
+    if len(chunked_alignment_files) >= 2 * batch_size:
+        batch_results = []
+        for chunk_idx in range(math.ceil(len(chunked_alignment_files) / batch_size)):
+            batch = chunked_alignment_files[chunk_idx * batch_size: chunk_idx * batch_size + batch_size]
+            batch_results.append(job.addChildJobFn(combine_chunks, batch, batch_size).rv())
+        return job.addFollowOnJobFn(merge_combined_chunks, batch_results).rv()
+    alignment_file = job.fileStore.getLocalTempFile()
+    for chunk in chunked_alignment_files:
+        chunking.paf_dechunk(job.fileStore.readGlobalFile(chunk), alignment_file, append=True)
+        job.fileStore.deleteGlobalFile(chunk)
+    return job.fileStore.writeGlobalFile(alignment_file)
+
+
+def merge_combined_chunks(job, combined_chunks):
+    output_path = job.fileStore.getLocalTempFile()
+    with open(output_path, 'a') as output_file:
+        for chunk in combined_chunks:
+            with open(job.fileStore.readGlobalFile(chunk, mutable=True), 'r') as chunk_file:
+                output_file.write(chunk_file.read())
+            job.fileStore.deleteGlobalFile(chunk)
+    return job.fileStore.writeGlobalFile(output_path)
+
+
+def make_chunked_alignments(job, event_a, genome_a, event_b, genome_b, distance, params):
+    lastz_params_node = params.find("blast")
+    gpu = getOptionalAttrib(lastz_params_node, 'gpu', typeFn=int, default=0)
+    lastz_cores = getOptionalAttrib(lastz_params_node, 'cpu', typeFn=int, default=None)
+    lastz_memory = getOptionalAttrib(lastz_params_node, 'lastz_memory', typeFn=int, default=None)
+    chunk_attr = 'bigChunkSize' if gpu else 'chunkSize'
+
+    def make_chunks(genome):
+        output_chunks_dir = job.fileStore.getLocalTempDir()
+        chunk_files = chunking.fasta_chunk(job.fileStore.readGlobalFile(genome), output_chunks_dir,
+                                           int(params.find("blast").attrib[chunk_attr]),
+                                           int(params.find("blast").attrib["overlapSize"]))
+        return [job.fileStore.writeGlobalFile(chunk, cleanup=True) for chunk in chunk_files]
+
+    chunks_a = make_chunks(genome_a)
+    chunks_b = make_chunks(genome_b)
+    accelerators = accelerator_string(gpu)
+    chunked_alignment_files = []
+    for i, chunk_a in enumerate(chunks_a):
+        for j, chunk_b in enumerate(chunks_b):
+            memory = lastz_memory if lastz_memory else max(200000000, 15 * (chunk_a.size + chunk_b.size))
+            chunked_alignment_files.append(job.addChildJobFn(run_lastz, '{}_{}'.format(event_a, i), chunk_a,
+                                                             '{}_{}'.format(event_b, j), chunk_b, distance, params,
+                                                             cores=lastz_cores,
+                                                             disk=max(4 * (chunk_a.size + chunk_b.size), memory),
+                                                             memory=memory, accelerators=accelerators).rv())
+    dechunk_batch_size = getOptionalAttrib(lastz_params_node, 'dechunkBatchSize', typeFn=int, default=int(1e9))
+    return job.addFollowOnJobFn(combine_chunks, chunked_alignment_files, dechunk_batch_size).rv()

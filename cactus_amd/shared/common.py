@@ -1,0 +1,59 @@
+"""Process boundary of the blast path: the local-binaries slice of cactus_call
+(/root/reference/src/cactus/shared/common.py:732-994) and getOptionalAttrib (:226), with the same
+argument names, stdout->outfile behaviour and RuntimeError-on-non-zero-exit convention
+(:962-988).  Docker / singularity modes, memory accounting and realtime logging are out of
+scope (orchestration, unchanged).  The MI355X front ends live in <repo>/bin and
+are put first on PATH, which is how CACTUS_BINARIES_MODE=local finds `lastz` (:793-795)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+BIN_DIR = os.path.join(REPO_ROOT, "bin")
+
+
+def getOptionalAttrib(node, attribName, typeFn=None, default=None, errorIfNotPresent=False):
+    """Same contract as common.py:226: typed attribute lookup with default; bool('0') is False."""
+    if node is not None and attribName in node.attrib:
+        if typeFn is not None:
+            if typeFn == bool:
+                aname = node.attrib[attribName].lower()
+                if aname == "false":
+                    return False
+                if aname == "true":
+                    return True
+                return bool(int(node.attrib[attribName]))
+            return typeFn(node.attrib[attribName])
+        return node.attrib[attribName]
+    if errorIfNotPresent:
+        raise RuntimeError("Could not find attribute %s in %s node" % (attribName, node))
+    return default
+
+
+def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpus=None, cpus=None, job_memory=None,
+                outappend=False, check_output=False, env=None):
+    """Runs one command locally.  stdout goes to `outfile` (or is returned when check_output), stderr is
+    captured; non-zero exit raises RuntimeError carrying the command line and stderr."""
+    assert parameters and isinstance(parameters[0], str), "pipelines are not needed on the blast path"
+    call_env = dict(os.environ if env is None else env)
+    call_env["PATH"] = BIN_DIR + os.pathsep + call_env.get("PATH", "")
+    stdout = subprocess.PIPE if check_output else None
+    fh = None
+    if outfile is not None:
+        fh = open(outfile, "ab" if outappend else "wb")
+        stdout = fh
+    try:
+        proc = subprocess.Popen(parameters, stdout=stdout, stderr=subprocess.PIPE, cwd=work_dir, env=call_env)
+        out, err = proc.communicate()
+    finally:
+        if fh is not None:
+            fh.close()
+    err_text = err.decode(errors="replace") if err else ""
+    if proc.returncode != 0:
+        raise RuntimeError("Command {} exited {}: stderr={}".format(parameters, proc.returncode, err_text))
+    if check_output:
+        return out.decode()
+    if returnStdErr:
+        return err_text
+    return None

@@ -1,0 +1,113 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/miblast.h
+declares, parses the reference's argv forms, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from cactus_amd import miblast
+from cactus_amd.shared.common import BIN_DIR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_gpu():
+    return miblast.device_count() == 0
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "miblast.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(miblast_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = miblast.load()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert declared == set(miblast.EXPORTED_SYMBOLS)
+    assert b"gfx950" in lib.miblast_version()
+
+
+def test_struct_layouts_match_header():
+    # 12 x int32 params ; stats = 12 int64 + 4 double + extras
+    assert C.sizeof(miblast.Params) == 48
+    assert C.sizeof(miblast.Hsp) == 48 and C.sizeof(miblast.Aln) == 64
+    assert C.sizeof(miblast.Stats) == 12 * 8 + 4 * 8 + 4 * 8 + 8 + 8 + 8 + 8 + 8 + 8
+
+
+def test_default_params_are_lastz_defaults():
+    p = miblast.default_params()
+    assert (p.step, p.transitions, p.xdrop, p.ydrop, p.hspthresh, p.gappedthresh, p.gap_open, p.gap_extend, p.entropy,
+            p.queryhspbest, p.ambiguous_n, p.gapped) == (1, 1, 910, 9400, 3000, -1, 400, 30, 1, 0, 1, 1)
+
+
+def _argv(args):
+    lib = miblast.load()
+    argv = [a.encode() for a in args]
+    arr = (C.c_char_p * len(argv))(*argv)
+    p = miblast.Params()
+    files = (C.c_char_p * 2)()
+    ng, nt = C.c_int(-1), C.c_int(-1)
+    rc = lib.miblast_params_from_argv(len(argv), arr, C.byref(p), files, C.byref(ng), C.byref(nt))
+    return rc, p, [f.decode() if f else None for f in files], ng.value, nt.value, lib.miblast_last_error().decode()
+
+
+def test_argv_of_run_lastz_cpu_form():
+    # local_alignment.py:60-68
+    rc, p, files, ng, nt, _ = _argv(["lastz", "A_0.fa[multiple][nameparse=darkspace]", "B_1.fa[nameparse=darkspace]", "--format=paf:wfmash",
+                                     "--step=3", "--ambiguous=iupac,100,100", "--ydrop=3500", "--hspthresh=2600", "--gappedthresh=2800",
+                                     "--queryhspbest=100000"])
+    assert rc == 0 and files == ["A_0.fa[multiple][nameparse=darkspace]", "B_1.fa[nameparse=darkspace]"]
+    assert (p.step, p.ydrop, p.hspthresh, p.gappedthresh, p.queryhspbest, ng, nt) == (3, 3500, 2600, 2800, 100000, 1, 1)
+
+
+def test_argv_of_run_lastz_gpu_form():
+    # local_alignment.py:54-58: "--num_gpu N --num_threads C" appended as separate tokens
+    rc, p, files, ng, nt, _ = _argv(["run_kegalign", "A.fa", "B.fa", "--format=paf:wfmash", "--step=2", "--ambiguous=iupac,100,100",
+                                     "--ydrop=3000", "--notransition", "--num_gpu", "8", "--num_threads", "32"])
+    assert rc == 0 and files == ["A.fa", "B.fa"] and (p.step, p.transitions, ng, nt) == (2, 0, 8, 32)
+
+
+@pytest.mark.parametrize("bad", [["--bogus"], ["--step=0"], ["--step=x"], ["--format=maf"], ["--ambiguous=weird"], ["extra.fa"],
+                                 ["--num_gpu"], ["--ydrop"]])
+def test_argv_rejects_what_it_does_not_implement(bad):
+    rc, _, _, _, _, msg = _argv(["lastz", "A.fa", "B.fa"] + bad)
+    assert rc == -1 and msg
+
+
+def test_argv_needs_two_files():
+    assert _argv(["lastz", "A.fa"])[0] == -1
+
+
+def test_no_device_means_loud_refusal_not_cpu_fallback():
+    if not _no_gpu():
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(miblast.MiblastError) as e:
+        miblast.Context(0)
+    assert "no CPU path" in str(e.value)
+
+
+def test_front_end_binaries_exist_and_refuse_without_gpu(tmp_path):
+    for name in ("lastz", "run_kegalign"):
+        exe = os.path.join(BIN_DIR, name)
+        assert os.access(exe, os.X_OK), exe
+        p = subprocess.run([exe, "A.fa", "B.fa", "--format=paf:wfmash", "--nonsense"], capture_output=True, cwd=tmp_path)
+        assert p.returncode == 2 and p.stdout == b"" and b"unknown option" in p.stderr
+    if _no_gpu():
+        (tmp_path / "A.fa").write_text(">a\nACGT\n")
+        p = subprocess.run([os.path.join(BIN_DIR, "lastz"), "A.fa", "A.fa", "--format=paf:wfmash"], capture_output=True, cwd=tmp_path)
+        assert p.returncode == 3 and p.stdout == b""
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under cactus_amd/ may import, link or exec it."""
+    pkg = os.path.join(ROOT, "cactus_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "lastz_oracle" not in text and "olz_" not in text, os.path.join(base, f)
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(base, f)
+    out = subprocess.run(["ldd", os.path.join(pkg, "libmiblast.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out

@@ -1,0 +1,125 @@
+"""CPU tests of the host logic around the hot path: parameter selection by distance, the process
+boundary (cactus_call), the local Toil stand-in, chunk / dechunk formats, the PAF validator and the
+synthetic generator."""
+import os
+
+import numpy as np
+import pytest
+
+from cactus_amd import gen, pafcheck
+from cactus_amd.paf import chunking
+from cactus_amd.paf.local_alignment import select_lastz_params, combine_chunks
+from cactus_amd.shared import configWrapper
+from cactus_amd.shared.common import cactus_call, getOptionalAttrib
+from cactus_amd.shared.localjob import FileID, LocalFileStore, LocalJob
+
+
+def test_distance_selects_the_reference_parameter_sets():
+    # local_alignment.py:44-51 with divergences one..five = 0.05..0.25 (cactus_progressive_config.xml:10-13)
+    cfg = configWrapper.load_config()
+    la = cfg.find("blast").find("lastzArguments").attrib
+    ka = cfg.find("blast").find("kegalignArguments").attrib
+    for d, key in [(0.0, "one"), (0.05, "one"), (0.0501, "two"), (0.1, "two"), (0.15, "three"), (0.176, "four"), (0.2, "four"),
+                   (0.25, "five"), (0.2501, "default"), (3.0, "default")]:
+        assert select_lastz_params(d, cfg, 0) == la[key]
+        assert select_lastz_params(d, cfg, 2) == ka[key]
+    cfg.find("constants").find("divergences").attrib["useDefault"] = "1"
+    assert select_lastz_params(0.01, cfg, 0) == la["default"]
+    assert "--queryhspbest" not in ka["default"]          # cactus_progressive_config.xml:138
+
+
+def test_get_optional_attrib():
+    cfg = configWrapper.load_config()
+    b = cfg.find("blast")
+    assert getOptionalAttrib(b, "gpu", typeFn=int, default=5) == 0
+    assert getOptionalAttrib(b, "cpu", typeFn=int, default=None) is None
+    assert getOptionalAttrib(b, "chunkSize", typeFn=int) == 30000000
+    with pytest.raises(RuntimeError):
+        getOptionalAttrib(b, "nope", errorIfNotPresent=True)
+
+
+def test_cactus_call_contract(tmp_path):
+    out = tmp_path / "o.txt"
+    assert cactus_call(["sh", "-c", "echo hi; echo warn >&2"], outfile=str(out)) is None
+    assert out.read_text() == "hi\n"
+    assert cactus_call(["sh", "-c", "echo hi; echo warn >&2"], outfile=str(out), returnStdErr=True, outappend=True) == "warn\n"
+    assert out.read_text() == "hi\nhi\n"
+    assert cactus_call(["sh", "-c", "echo x"], check_output=True) == "x\n"
+    with pytest.raises(RuntimeError) as e:
+        cactus_call(["sh", "-c", "echo boom >&2; exit 7"])
+    assert "exited 7" in str(e.value) and "boom" in str(e.value)
+
+
+def test_chunk_then_dechunk_round_trip(tmp_path):
+    rng = np.random.default_rng(3)
+    recs = [("id=E|chrA", gen.random_sequence(2500, rng)), ("id=E|chrB desc", gen.random_sequence(700, rng)),
+            ("id=E|chrC", gen.random_sequence(1000, rng))]
+    fa = tmp_path / "g.fa"
+    gen.write_fasta(str(fa), recs)
+    files = chunking.fasta_chunk(str(fa), str(tmp_path / "chunks"), 1000, 100)
+    seen = {}
+    for f in files:
+        for name, seq in pafcheck.read_fasta(f).items():
+            base, n, start = name.rsplit("|", 2)
+            assert len(seq) <= 1100
+            seen.setdefault(base, []).append((int(start), seq, int(n)))
+    full = {name.split()[0]: s.tobytes().decode() for name, s in recs}
+    for base, parts in seen.items():
+        for start, seq, n in parts:
+            assert n == len(full[base]) and full[base][start:start + len(seq)] == seq
+        assert sorted(s for s, _, _ in parts) == list(range(0, len(full[base]), 1000))
+    line = "id=E|chrA|2500|1000\t1100\t10\t60\t-\tid=F|x|9000|3000\t1100\t5\t55\t50\t50\t255\tAS:i:4550\tcg:Z:50=\n"
+    f = chunking.paf_dechunk_line(line).split("\t")
+    assert f[:9] == ["id=E|chrA", "2500", "1010", "1060", "-", "id=F|x", "9000", "3005", "3055"]
+    f = chunking.paf_dechunk_line(line, query_only=True).split("\t")
+    assert f[0] == "id=E|chrA" and f[5] == "id=F|x|9000|3000" and f[7] == "5"
+
+
+def test_combine_chunks_batches_and_dechunks(tmp_path):
+    fs = LocalFileStore(str(tmp_path))
+    job = LocalJob(fs)
+    ids = []
+    for k in range(5):
+        p = tmp_path / ("c%d.paf" % k)
+        p.write_text("q|100|%d\t50\t0\t10\t+\tt|200|0\t200\t0\t10\t10\t10\t255\tAS:i:910\tcg:Z:10=\n" % (k * 10))
+        ids.append(fs.writeGlobalFile(str(p)))
+    out = combine_chunks(job, ids, 2)          # 5 >= 2*2 -> batched path
+    lines = open(str(out)).read().splitlines()
+    assert len(lines) == 5 and [l.split("\t")[2] for l in lines] == ["0", "10", "20", "30", "40"]
+    assert all(l.split("\t")[0] == "q" and l.split("\t")[1] == "100" for l in lines)
+
+
+def test_local_job_shim(tmp_path):
+    job = LocalJob(LocalFileStore(str(tmp_path)))
+    p = tmp_path / "x"
+    p.write_text("abc")
+    fid = job.fileStore.writeGlobalFile(str(p))
+    assert isinstance(fid, FileID) and fid.size == 3
+    dst = tmp_path / "y"
+    assert job.fileStore.readGlobalFile(fid, str(dst)) == str(dst) and dst.read_text() == "abc"
+    assert job.addChildJobFn(lambda j, a: a + 1, 41).rv() == 42
+
+
+def test_paf_validator_rejects_broken_records():
+    good = "q\t100\t0\t20\t+\tt\t100\t5\t25\t20\t20\t255\tAS:i:1820\tcg:Z:20=\n"
+    pafcheck.check_paf(good)
+    for bad in (good.replace("cg:Z:20=", "cg:Z:19="), good.replace("\t20\t20\t255", "\t19\t20\t255"),
+                good.replace("cg:Z:20=", "cg:Z:10=10="), good.replace("cg:Z:20=", "cg:Z:10=0X10=")):
+        with pytest.raises(AssertionError):
+            pafcheck.check_paf(bad)
+    minus = "q\t100\t10\t30\t-\tt\t100\t5\t27\t20\t22\t255\tAS:i:1\tcg:Z:10=2D10=\n"
+    pafcheck.check_paf(minus)
+
+
+def test_generator_is_deterministic_and_has_the_advertised_features():
+    a = gen.make_pair(50000, 42)
+    b = gen.make_pair(50000, 42)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    t, q = a
+    assert abs(np.mean(t > 96) - 0.2) < 0.08 and (t == ord("N")).sum() >= 250 and len(q) != len(t)
+    r = gen.make_pair(1000, 1, homologous=False)
+    assert len(r[0]) == len(r[1]) == 1000
+
+
+def test_accelerator_string_is_rocm():
+    assert configWrapper.accelerator_string(0) is None and configWrapper.accelerator_string(4) == "rocm:4"

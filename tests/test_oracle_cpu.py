@@ -1,0 +1,158 @@
+"""CPU tests of the oracle itself (test infrastructure): hand-derived known answers, agreement with the
+independent pure-Python restatement of SURVEY.md A.10, the committed golden fixtures, and the
+reference's only pins for this path (parameter strings, PAF validity contract)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pyref
+from cactus_amd import gen, pafcheck
+from cases import CASES, CASE_IDS
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fa(name, s):
+    return (">%s\n%s\n" % (name, s)).encode()
+
+
+def _rand(n, seed):
+    return gen.random_sequence(n, np.random.default_rng(seed)).tobytes().decode()
+
+
+def _match_score(s):
+    return sum(91 if c in "AT" else 100 for c in s)
+
+
+def test_known_answer_identical(olz):
+    s = _rand(400, 1)
+    r = olz.align(_fa("t", s), _fa("q", s), olz.default_params())
+    assert r["paf"].decode() == "q\t400\t0\t400\t+\tt\t400\t0\t400\t400\t400\t255\tAS:i:%d\tcg:Z:400=\n" % _match_score(s)
+
+
+def test_known_answer_single_substitution(olz):
+    s = _rand(400, 2)
+    q = s[:200] + {"A": "C", "C": "A", "G": "T", "T": "G"}[s[200]] + s[201:]
+    r = olz.align(_fa("t", s), _fa("q", q), olz.default_params())
+    f = r["paf"].decode().split("\t")
+    assert f[-1].strip() == "cg:Z:200=1X199="
+    assert int(f[-2][5:]) == _match_score(s) - _match_score(s[200]) + pafcheck.sub_score(s[200], q[200])
+
+
+def test_known_answer_deletion_and_insertion(olz):
+    s = _rand(600, 3)
+    q = s[:300] + s[307:]                    # 7 target-only bases -> one D of length 7 (placement may shift inside ties)
+    r = olz.align(_fa("t", s), _fa("q", q), olz.default_params())
+    rec = pafcheck.parse_line(r["paf"].decode().splitlines()[0])
+    assert (rec["tstart"], rec["tend"], rec["qstart"], rec["qend"]) == (0, 600, 0, 593)
+    assert rec["cigar"].count("D") == 1 and "7D" in rec["cigar"] and "I" not in rec["cigar"]
+    assert rec["score"] == _match_score(s) - _match_score(s[300:307]) - (400 + 7 * 30)
+    r2 = olz.align(_fa("t", q), _fa("q", s), olz.default_params())
+    rec2 = pafcheck.parse_line(r2["paf"].decode().splitlines()[0])
+    assert "7I" in rec2["cigar"] and rec2["score"] == rec["score"]
+
+
+def test_known_answer_reverse_strand(olz):
+    s = _rand(500, 4)
+    r = olz.align(_fa("t", s), _fa("q", pyref.revcomp(s)), olz.default_params())
+    assert r["paf"].decode() == "q\t500\t0\t500\t-\tt\t500\t0\t500\t500\t500\t255\tAS:i:%d\tcg:Z:500=\n" % _match_score(s)
+
+
+def test_soft_masked_bases_do_not_seed_but_score(olz):
+    s = _rand(300, 5)
+    assert olz.align(_fa("t", s.lower()), _fa("q", s), olz.default_params())["paf"] == b""
+    t = s[:100].lower() + s[100:]            # seeds in the uppercase part, extension runs through the masked part
+    r = olz.align(_fa("t", t), _fa("q", s), olz.default_params())
+    assert r["paf"].decode().split("\t")[-1].strip() == "cg:Z:300="
+
+
+def test_n_scores_minus_100_and_never_seeds(olz):
+    assert olz.load().olz_score(4, 4, 1) == -100 and olz.load().olz_score(4, 0, 1) == -100 and olz.load().olz_score(0, 12, 1) == -100
+    s = _rand(400, 6)
+    q = s[:200] + "N" + s[201:]
+    r = olz.align(_fa("t", s), _fa("q", q), olz.default_params())
+    rec = pafcheck.parse_line(r["paf"].decode().splitlines()[0])
+    assert rec["cigar"] == "200=1X199=" and rec["score"] == _match_score(s) - _match_score(s[200]) - 100
+
+
+def test_hoxd70_matrix(olz):
+    lib = olz.load()
+    want = [[91, -114, -31, -123], [-114, 100, -125, -31], [-31, -125, 100, -114], [-123, -31, -114, 91]]
+    for a in range(4):
+        for b in range(4):
+            assert lib.olz_score(a, b, 1) == want[a][b]
+            assert lib.olz_score(a | 8, b, 1) == want[a][b]      # case-insensitive
+
+
+@pytest.mark.parametrize("seed,n,sub,indel,kw", [
+    (11, 700, 0.06, 0.004, {}), (12, 900, 0.10, 0.01, {"step": 2}), (13, 600, 0.03, 0.0, {"transitions": False}),
+    (14, 800, 0.12, 0.01, {"K": 2200, "L": 2400, "ydrop": 4000}), (15, 500, 0.05, 0.02, {"ydrop": 1500}),
+    (16, 1000, 0.08, 0.006, {"K": 2600, "L": 2800, "ydrop": 3500, "step": 3}), (17, 400, 0.0, 0.0, {"entropy": False}),
+])
+def test_c_oracle_agrees_with_python_restatement(olz, seed, n, sub, indel, kw):
+    rng = np.random.default_rng(seed)
+    t = gen.random_sequence(n, rng)
+    q = gen.mutate(t, rng, sub, indel)
+    if seed % 2:
+        q = gen.revcomp(q)
+    q = gen.soft_mask(q, rng, 0.1, 40)
+    T, Q = t.tobytes().decode(), q.tobytes().decode()
+    want, ctr = pyref.align(T, Q, **kw)
+    p = olz.default_params(step=kw.get("step", 1), transitions=int(kw.get("transitions", True)), ydrop=kw.get("ydrop", 9400),
+                           hspthresh=kw.get("K", 3000), gappedthresh=kw.get("L", -1), entropy=int(kw.get("entropy", True)))
+    r = olz.align(_fa("t", T), _fa("q", Q), p)
+    got = []
+    for line in r["paf"].decode().splitlines():
+        rec = pafcheck.parse_line(line)
+        got.append((0 if rec["strand"] == "+" else 1, rec["tstart"], rec["tend"], rec["qstart"], rec["qend"], rec["score"],
+                    rec["nmatch"], rec["alnlen"], rec["cigar"]))
+    assert got == want
+    for k in ("seed_hits", "hits_extended", "hsps", "dp_cells"):
+        assert r["counters"][k] == ctr[k], k
+    assert len(want) >= 1
+
+
+@pytest.mark.parametrize("name,tf,qf,args", CASES, ids=CASE_IDS)
+def test_oracle_output_is_valid_paf_and_matches_golden(olz, name, tf, qf, args):
+    """Every parity case: the oracle's PAF passes the caf walk + score re-derivation, and equals the committed
+    golden digest (tests/golden/golden.json, made by tests/golden/make_golden.py from this same oracle: a
+    regression pin -- the reference has no PAF-level vectors)."""
+    import hashlib
+    from cactus_amd import miblast
+    pm = miblast.params_from_args(args)
+    r = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}))
+    if r["paf"]:
+        n = pafcheck.check_paf(r["paf"].decode(), pafcheck.read_fasta(tf), pafcheck.read_fasta(qf))
+        assert n == r["counters"]["alignments"]
+    gold = json.load(open(os.path.join(GOLDEN, "golden.json")))[name]
+    assert hashlib.sha256(r["paf"]).hexdigest() == gold["paf_sha256"]
+    for k, v in gold["counters"].items():
+        assert r["counters"][k] == v, k
+
+
+def test_golden_small_fixture_files(olz):
+    """Two tiny committed input/output fixtures (FASTA + PAF text) that can be read by eye."""
+    for stem in ("tiny_plus", "tiny_minus_gap"):
+        tf = open(os.path.join(GOLDEN, stem + ".target.fa"), "rb").read()
+        qf = open(os.path.join(GOLDEN, stem + ".query.fa"), "rb").read()
+        want = open(os.path.join(GOLDEN, stem + ".paf"), "rb").read()
+        assert olz.align(tf, qf, olz.default_params(hspthresh=2200, gappedthresh=2400, ydrop=4000))["paf"] == want
+
+
+def test_reference_parameter_pins():
+    """The only pin the reference holds on this path: the literal default lastz option string
+    (/root/reference/api/tests/cactusParamsTest.c:16-17) -- and the six sets of the config parse cleanly."""
+    from cactus_amd import miblast
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    la = cfg.find("blast").find("lastzArguments").attrib
+    assert la["default"] == "--step=1 --ambiguous=iupac,100,100 --ydrop=4000 --hspthresh=2200 --gappedthresh=2400 --queryhspbest=100000"
+    p = miblast.params_from_args(la["default"].split())
+    assert (p.step, p.ydrop, p.hspthresh, p.gappedthresh, p.queryhspbest, p.transitions) == (1, 4000, 2200, 2400, 100000, 1)
+    p1 = miblast.params_from_args(la["one"].split())
+    assert (p1.step, p1.ydrop, p1.hspthresh, p1.gappedthresh, p1.transitions) == (2, 3000, 3000, -1, 0)
+    for node in ("lastzArguments", "kegalignArguments"):
+        for k, v in cfg.find("blast").find(node).attrib.items():
+            miblast.params_from_args(v.split())
