@@ -238,7 +238,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     std::vector<unsigned long long> h_qbsum((size_t)n_qblk + 2);
     std::vector<miblast_hsp> strand_hsps[2];
 
-    for (int strand = 0; strand < 2 && qtot >= kSeedSpan && ttot >= kSeedSpan; strand++) {
+    for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
         const double t0 = now_s();
         MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
         launch_seed_count(qc_d[strand], qtot, ix.offsets.p, p.transitions, qcnt.p, s);

@@ -206,10 +206,12 @@ class Context:
                 hsps = [(h.strand, h.q_contig, h.t_start, h.q_start, h.len, h.score, h.seed_t_end, h.seed_q_end, tuple(h.cnt))
                         for h in (hp[i] for i in range(k.value))]
                 ap = lib.miblast_result_alns(r, C.byref(k))
+                raw = [ap[i] for i in range(k.value)]
                 alns = [(a.strand, a.q_contig, a.t_contig, a.t_lo, a.t_hi, a.q_lo, a.q_hi, a.score, a.dmin, a.dmax,
-                         a.anchor_t, a.anchor_q, a.n_ops) for a in (ap[i] for i in range(k.value))]
+                         a.anchor_t, a.anchor_q, a.n_ops) for a in raw]
                 op = lib.miblast_result_ops(r, C.byref(k))
-                ops = [op[i] for i in range(k.value)] if k.value < 5_000_000 else []
+                # run-length ops per alignment ((len<<2)|op), in output order
+                ops = [[op[a.ops_off + j] for j in range(a.n_ops)] for a in raw] if k.value < 5_000_000 else []
             return AlignResult(paf, stats, hsps, alns, ops)
         finally:
             lib.miblast_result_free(r)

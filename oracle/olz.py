@@ -95,9 +95,10 @@ def align(target_fasta: bytes, query_fasta: bytes, params: Params, details: bool
     if details:
         out["hsps"] = [(h.strand, h.q_contig, h.t_start, h.q_start, h.len, h.score, h.seed_t_end, h.seed_q_end, tuple(h.cnt))
                        for h in (R.hsps[i] for i in range(R.n_hsps))]
+        raw = [R.alns[i] for i in range(R.n_alns)]
         out["alns"] = [(a.strand, a.q_contig, a.t_contig, a.t_lo, a.t_hi, a.q_lo, a.q_hi, a.score, a.dmin, a.dmax,
-                        a.anchor_t, a.anchor_q, a.n_ops) for a in (R.alns[i] for i in range(R.n_alns))]
-        out["ops"] = [R.ops[i] for i in range(R.n_ops)] if R.n_ops < 5_000_000 else []
+                        a.anchor_t, a.anchor_q, a.n_ops) for a in raw]
+        out["ops"] = [[R.ops[a.ops_off + j] for j in range(a.n_ops)] for a in raw] if R.n_ops < 5_000_000 else []
     lib.olz_result_free(r)
     lib.olz_seqset_free(T)
     lib.olz_seqset_free(Q)
