@@ -23,5 +23,5 @@ def short(n):
 with open(out, "w") as f:
     f.write("kernel,calls,total_us,avg_us,pct\n")
     for n, calls, tot, avg, pct in rows:
-        f.write('"%s",%d,%.1f,%.2f,%.3f\n' % (short(n), calls, tot / 1e3, avg / 1e3, pct))
+        f.write('"%s",%d,%.1f,%.2f,%.3f\n' % (short(n), calls, tot, avg, pct))
 print(open(out).read())
