@@ -142,6 +142,7 @@ int miblast_ctx_create(int device, miblast_ctx **out) {
         MB_HIP(hipSetDevice(device));
         miblast_ctx *c = new miblast_ctx();
         c->c.device = device;
+        c->c.ws = mb::workspace_create();
         MB_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
         MB_HIP(hipEventCreate(&c->c.ev0)); MB_HIP(hipEventCreate(&c->c.ev1)); MB_HIP(hipEventCreate(&c->c.ev2));
         MB_HIP(hipEventCreate(&c->c.ev3)); MB_HIP(hipEventCreate(&c->c.ev4));
@@ -159,6 +160,7 @@ void miblast_ctx_destroy(miblast_ctx *c) {
     if (c->c.ev3) (void)hipEventDestroy(c->c.ev3);
     if (c->c.ev4) (void)hipEventDestroy(c->c.ev4);
     if (c->c.stream) (void)hipStreamDestroy(c->c.stream);
+    mb::workspace_destroy(c->c.ws);
     delete c;
 }
 

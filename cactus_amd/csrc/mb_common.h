@@ -30,19 +30,18 @@ struct DpProb {                               // one one-sided Y-drop DP (SURVEY
     int32_t na, nb;                           // columns (target) / rows (query) available
     int32_t dir;                              // +1 forward from (t0,q0); -1 backward from (t0-1,q0-1)
     int32_t strand;                           // selects the query code array
-    int32_t stop_row;                         // trace pass: last row to evaluate (= bi of the score pass)
-    int32_t pad;
-    uint64_t trace_off;                       // trace pass: byte offset of this side's trace cells
-    uint64_t row_off;                         // trace pass: index of this side's first row-table entry
+    int32_t pad0, pad1;
+    uint64_t row_off;                         // index of this side's first row-chunk directory entry
     uint64_t ops_off;                         // traceback: byte offset of this side's op string
 };
 
 struct DpOut {
     int32_t best, bi, bj, rows;
     int64_t cells;                            // cells evaluated (oracle counter dp_cells)
-    int64_t cells_to_bi;                      // cells in rows 0..bi (trace bytes the trace pass needs)
-    int32_t overflow;                         // row wider than the LDS ring: rerun with global rows
+    int64_t cells_to_bi;                      // unused (kept for layout stability)
+    int32_t overflow;                         // 1: row wider than the LDS ring (rerun with HBM rows); 3: trace arena exhausted
     int32_t n_ops;                            // traceback: number of ops written
+    long long prof[6];                        // MIBLAST_DP_PROFILE: shader clocks per phase of the row loop
 };
 
 struct UngappedCounters {
@@ -96,11 +95,11 @@ void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qto
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, const uint8_t *tcodes, const uint8_t *qcodes,
                      int64_t qtot, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, hipStream_t s);
-void launch_ydrop(bool trace, bool global_rows, const DpProb *probs, DpOut *outs, int n, const uint8_t *tc,
-                  const uint8_t *qf, const uint8_t *qr, int O, int E, int Y, int32_t *grows, uint8_t *tracebuf,
-                  uint64_t *rowoff, uint32_t *rowly, hipStream_t s);
-void launch_traceback(const DpProb *probs, DpOut *outs, int n, const uint8_t *tracebuf, const uint64_t *rowoff,
-                      const uint32_t *rowly, uint8_t *ops, hipStream_t s);
+void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const uint8_t *tc, const uint8_t *qf,
+                  const uint8_t *qr, int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
+                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s);
+void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
+                      const unsigned long long *rowdir, uint8_t *ops, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int end_bit,
                hipStream_t s);

@@ -11,6 +11,7 @@
 // (see DESIGN.md "Why the row sweep is exact").
 #include "mb_common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -346,205 +347,388 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, const uint8
 }
 
 // ------------------------------------------------------------------------------------------------
-// One-sided Y-drop DP (A.7 / A.10 ONE_SIDED).  One wave64 per problem; rows are swept sequentially,
-// 64 columns per segment.  The horizontal-gap recurrence becomes a max-plus prefix scan over the
-// row; the running `best` that the y-drop test uses becomes a prefix max.  C and D of the previous
-// row live in a ring indexed by column (LDS, or HBM for the rare row wider than the LDS ring) and
-// are overwritten in place segment by segment (the diagonal input of the next segment's first
-// lane is carried in a register).
-__device__ __forceinline__ int wave_incl_max(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v = max(v, t); }
+// One-sided Y-drop DP (A.7 / A.10 ONE_SIDED), single pass with trace.
+//
+// One wave64 per problem.  Rows are swept sequentially (the y-drop rule prunes against the running
+// best in ROW-MAJOR order, so row i+1 needs all of row i); inside a row the columns are evaluated
+// 64 per segment, G segments per group with independent instruction streams:
+//   * vertical gap D and the diagonal come from the previous row's C/D, kept in an LDS ring indexed
+//     by column and overwritten in place;
+//   * the horizontal gap I is a max-plus prefix scan over the row, the running best a prefix max --
+//     both done with DPP row_shr / row_bcast steps (no LDS traffic), segment carries through SGPRs;
+//   * target bases are staged in an LDS byte ring ahead of the window, query bases 64 rows at a time
+//     in a register (v_readlane per row), so no global load sits on the row-to-row critical path;
+//   * one trace byte per evaluated cell goes to 64 KiB blocks bump-allocated from an HBM arena, with a
+//     16-byte (offset, LY) record per row in 4096-row chunks found through a per-problem directory.
+constexpr int kNeg2 = -(1 << 30);            // below every real score: fill value for shifted-in lanes
+constexpr int kRowChunk = 4096;              // rows per row-info chunk (16 B each = one 64 KiB arena block)
+
+__device__ __forceinline__ int dpp_shr1(int v, int fill) {            // lane l <- lane l-1, lane 0 <- fill
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_scan_max(int v) {                  // inclusive prefix max over the wave
+    constexpr int kId = -2147483647 - 1;                                        // identity of max: lets the DPP fold into v_max
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x111, 0xf, 0xf, false));    // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x112, 0xf, 0xf, false));    // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x114, 0xf, 0xf, false));    // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x118, 0xf, 0xf, false));    // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x142, 0xa, 0xf, false));    // row_bcast:15 -> rows 1,3
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x143, 0xc, 0xf, false));    // row_bcast:31 -> rows 2,3
     return v;
 }
 
-template <bool TRACE>
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }          // pin a wave-uniform value to an SGPR
+
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)(unsigned)v);
+}
+
+struct RowInfo { unsigned long long off; uint32_t ly; uint32_t pad; };
+
+// per-row packed score table: byte k = HOXD70[k][bq] + 128 for k = A,C,G,T (N handled separately)
+__device__ __forceinline__ uint32_t row_score_lut(unsigned bq) {
+    const unsigned b = bq & 7u;
+    constexpr uint32_t LA = (91 + 128) | ((-114 + 128) << 8) | ((-31 + 128) << 16) | ((unsigned)(-123 + 128) << 24);
+    constexpr uint32_t LC = (-114 + 128) | ((100 + 128) << 8) | ((-125 + 128) << 16) | ((unsigned)(-31 + 128) << 24);
+    constexpr uint32_t LG = (-31 + 128) | ((-125 + 128) << 8) | ((100 + 128) << 16) | ((unsigned)(-114 + 128) << 24);
+    constexpr uint32_t LT = (-123 + 128) | ((-31 + 128) << 8) | ((-114 + 128) << 16) | ((unsigned)(91 + 128) << 24);
+    constexpr uint32_t LN = 28u | (28u << 8) | (28u << 16) | (28u << 24);            // -100 + 128
+    return b == 0u ? LA : b == 1u ? LC : b == 2u ? LG : b == 3u ? LT : LN;
+}
+__device__ __forceinline__ int lut_score(uint32_t lut, unsigned at) {
+    const unsigned a = at & 7u;
+    const int v = (int)((lut >> ((a & 3u) * 8u)) & 0xFFu) - 128;
+    return (a & 4u) ? -100 : v;
+}
+
+constexpr int kYdWaves = 4;                  // one wave per SIMD of the CU
+constexpr int kYdThreads = 64 * kYdWaves;
+constexpr int kBig = 1 << 20;
+
+struct YdShared {                            // LDS of one DP problem (LDS-ring variant: 16 + 2 + 2 KiB + exchange)
+    int2 scan[kYdThreads];                   // per-thread inclusive scans {X = M + rel, M}; read at uniform slots 63,127,191,255
+    int4 xb[kYdWaves];                       // per-wave {first break, first alive, last alive, best candidate} (pass-relative columns)
+    int iv_last, cp_last;                    // last column of a pass, for the next pass of a wide row
+    unsigned long long blk, chunk; int fail; // arena allocations made by thread 0
+};
+
+// One workgroup (4 waves) per problem; a row is evaluated 256 columns per pass, wave w taking columns
+// base+64w .. base+64w+63.  Two barriers per pass:
+//   B1  after the wave-local DPP scans: the other waves' scan totals are read from LDS.  Two scans run
+//       side by side: X = M + rel for the horizontal gap, and M itself for the running best -- the prefix
+//       max of C equals the prefix max of M because every horizontal-gap value is strictly below an M
+//       further left, so the y-drop test needs no scan after I is known;
+//   B2  after the y-drop test: each wave publishes {first break, first alive, last alive, best candidate};
+//       all waves reduce the four records identically, so no third barrier is needed.
+// C/D of the previous row live in an LDS ring of int2 indexed by column, overwritten in place.
+template <bool GLOBAL, bool PROF>
 __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const uint8_t *__restrict__ tc,
-                                           const uint8_t *__restrict__ qc, int O, int E, int Y, int *Crow, int *Drow,
-                                           int cap, uint8_t *__restrict__ trace, uint64_t *__restrict__ rowoff,
-                                           uint32_t *__restrict__ rowly) {
-    const int lane = threadIdx.x & 63;
+                                           const uint8_t *__restrict__ qc, const int O, const int E, const int Y,
+                                           int2 *CD, uint8_t *Tb, const int cap, YdShared *sh,
+                                           uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
+                                           unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
+                                           unsigned long long *__restrict__ rowdir) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = uni(tid >> 6);
     const int mask = cap - 1;
     const int na = pr.na, nb = pr.nb, dir = pr.dir;
     const int64_t t0 = pr.t0, q0 = pr.q0;
-    // row 0
+    const long long clk0 = clock64();
+    long long pf[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
+#define MB_TICK(k) do { if (PROF) { long long _n = clock64(); pf[k] += _n - pt; pt = _n; } } while (0)
+    const int OE = O + E;
+    const int grow = (Y >= O ? (Y - O) / E : 0) + 2;          // a row can outgrow the previous window by at most this
+    int overflow = 0;
     int R0 = 0;
     if (Y >= O) { R0 = (Y - O) / E; if (R0 > na) R0 = na; }
-    int overflow = 0;
-    if (R0 + 2 > cap) overflow = 1;
+    if (R0 + 1 + grow + 2 * kYdThreads + 64 > cap) overflow = 1;
+    // ---- trace arena bookkeeping (identical in every wave; thread 0 does the atomics) ----
+    unsigned long long blk_off = 0, chunk_off = 0;
+    unsigned blk_used = 0;
     if (!overflow) {
-        for (int j = lane; j <= R0; j += 64) {
-            Crow[j & mask] = (j == 0) ? 0 : -(O + j * E);
-            Drow[j & mask] = kNeg;
-            if (TRACE) trace[pr.trace_off + j] = (j == 0) ? 3 : (uint8_t)(2 | (j >= 2 ? 8 : 0));
+        if (tid == 0) {
+            unsigned long long o1 = atomicAdd(arena_next, 2ull * blk_bytes);
+            sh->blk = o1; sh->chunk = o1 + blk_bytes; sh->fail = (o1 + 2ull * blk_bytes > arena_bytes);
         }
-        if (TRACE && lane == 0) { rowoff[pr.row_off] = 0; rowly[pr.row_off] = 0; }
+        __syncthreads();
+        blk_off = uni64(sh->blk); chunk_off = uni64(sh->chunk);
+        if (uni(sh->fail)) overflow = 3;
+        __syncthreads();
     }
-    int LY = 0, RY = R0 + 1;
-    int best = 0, bi = 0, bj = 0;
-    long long cells = R0 + 1, cells_to_bi = R0 + 1;
-    int rows = 1;
-    const int last_row = TRACE ? min(nb, pr.stop_row) : nb;
-    for (int i = 1; i <= last_row && !overflow; i++) {
-        const unsigned bq = qc[dir > 0 ? q0 + i - 1 : q0 - i];
-        if (TRACE && lane == 0) { rowoff[pr.row_off + i] = (uint64_t)cells; rowly[pr.row_off + i] = (uint32_t)LY; }
-        int carry_cp = kNeg;          // Cprev[base-1]
-        int carry_x = kNeg;           // prefix max of M_k + (k-LY)*E over earlier segments
-        int carry_iv = kNeg;          // Iv of column base-1
-        int row_best = best;
-        int first_alive = -1, last_alive = -1;
-        bool done = false;
-        for (int base = LY; !done; base += 64) {
-            if (base + 64 - LY + 1 > cap) { overflow = 1; break; }
-            const int j = base + lane;
-            const bool active = j <= na;
-            const bool inwin = j < RY;
-            __builtin_amdgcn_wave_barrier();
-            int cp = inwin ? Crow[j & mask] : kNeg;
-            int dp = inwin ? Drow[j & mask] : kNeg;
-            int cpl = __shfl_up(cp, 1);
-            if (lane == 0) cpl = carry_cp;
-            carry_cp = __shfl(cp, 63);
-            unsigned at = 4u;
-            if (active && j >= 1) at = tc[dir > 0 ? t0 + j - 1 : t0 - j];
-            int diag = cpl + sub_score(at, bq);
-            int dext_v = dp - E, dopn_v = cp - O - E;
-            int Dv = max(dext_v, dopn_v);
-            int Dext = dext_v >= dopn_v;
-            int M = max(diag, Dv);
-            int rel = (j - LY) * E;
-            int X = M + rel;
-            int pin = wave_incl_max(X, lane);
-            int pex = __shfl_up(pin, 1);
-            if (lane == 0) pex = carry_x; else pex = max(pex, carry_x);
-            carry_x = max(carry_x, __shfl(pin, 63));
-            int Iv = pex - O - rel;
-            int iv_left = __shfl_up(Iv, 1);
-            if (lane == 0) iv_left = carry_iv;
-            carry_iv = __shfl(Iv, 63);
-            int Iext = (Iv == iv_left - E);
-            int Cv; int src;
-            if (diag >= Dv && diag >= Iv) { Cv = diag; src = 0; }
-            else if (Dv >= Iv) { Cv = Dv; src = 1; }
-            else { Cv = Iv; src = 2; }
-            int cact = active ? Cv : kNeg;
-            int pb = wave_incl_max(cact, lane);
-            int best_at = max(row_best, pb);
-            bool alive = active && (Cv >= best_at - Y);
-            unsigned long long brk = __ballot((j >= RY && !alive) || !active);
-            bool valid = active;
-            if (brk) {
-                int fb = __ffsll((long long)brk) - 1;
-                valid = active && lane <= fb;
-                alive = alive && lane <= fb;
-                done = true;
-            }
-            unsigned long long vmask = __ballot(valid);
-            unsigned long long amask = __ballot(alive);
-            cells += __popcll(vmask);
-            // best update: strict >, first column attaining the row maximum (row-major first)
-            int cand = valid ? Cv : kNeg;
-            int segmax = cand;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) segmax = max(segmax, __shfl_xor(segmax, o));
-            if (segmax > row_best) {
-                unsigned long long w = __ballot(valid && Cv == segmax);
-                bj = base + __ffsll((long long)w) - 1;
-                bi = i;
-                row_best = segmax;
-            }
-            if (valid) {
-                Crow[j & mask] = alive ? Cv : kNeg;
-                Drow[j & mask] = Dv;
-                if (TRACE) trace[pr.trace_off + (uint64_t)(cells - __popcll(vmask)) + (j - base)] =
-                    (uint8_t)(src | (Dext << 2) | (Iext << 3));
-            }
-            if (amask) {
-                if (first_alive < 0) first_alive = base + __ffsll((long long)amask) - 1;
-                last_alive = base + 63 - __clzll((long long)amask);
+    // row records {offset, LY} are buffered 64 rows at a time in wave 0 (lane = row & 63)
+    unsigned rb_lo = 0, rb_hi = 0, rb_ly = 0;
+    auto flush_rows = [&](int last_row) {      // rows (last_row & ~63) .. last_row
+        if (wv == 0) {
+            const int r = (last_row & ~63) + lane;
+            if (r <= last_row) {
+                RowInfo ri; ri.off = ((unsigned long long)rb_hi << 32) | rb_lo; ri.ly = rb_ly; ri.pad = 0;
+                ((RowInfo *)(arena + chunk_off))[r & (kRowChunk - 1)] = ri;
             }
         }
-        if (overflow) break;
+    };
+    // ---- row 0: C = -(O + jE) while within ydrop of 0, every cell reached by a horizontal gap from the origin
+    if (!overflow) {
+        uint8_t *tr = arena + blk_off;
+        for (int j = tid; j <= R0; j += kYdThreads) {
+            CD[j & mask] = make_int2((j == 0) ? 0 : -(O + j * E), kNeg);
+            tr[j] = (j == 0) ? 3 : (uint8_t)(2 | (j >= 2 ? 8 : 0));
+        }
+        if (tid == 0) rowdir[pr.row_off] = chunk_off;
+        if (lane == 0) { rb_lo = (unsigned)blk_off; rb_hi = (unsigned)(blk_off >> 32); rb_ly = 0; }
+        blk_used = (unsigned)(R0 + 1);
+    }
+    int LY = 0, RY = R0 + 1, best = 0, bi = 0, bj = 0;
+    long long cells = R0 + 1;
+    int rows = 1;
+    int t_hi = 0;                                                       // highest target column staged in Tb
+    int qblk0 = 1;                                                      // first row of the block held in qv
+    auto load_q = [&](int r0) -> unsigned {
+        const int r = r0 + lane;
+        return (r >= 1 && r <= nb) ? (unsigned)qc[dir > 0 ? q0 + r - 1 : q0 - r] : 4u;
+    };
+    unsigned qv = load_q(1), qnext = load_q(65);
+    const int tidE = tid * E;
+    __syncthreads();
+    int i = 1;
+    for (; i <= nb && !overflow; i++) {
+        if (PROF) pt = clock64();
+        if (i - qblk0 >= 64) { qblk0 += 64; qv = qnext; qnext = load_q(qblk0 + 64); }
+        const uint32_t lut = row_score_lut((unsigned)__builtin_amdgcn_readlane((int)qv, i - qblk0));
+        // the row can reach at most column RY + grow; everything it may touch must be staged and fit the ring
+        const int reach = min(na, RY + grow);
+        if (reach - LY + 2 * kYdThreads + 64 > cap) { overflow = 1; break; }
+        const int need = reach - LY + 1;
+        const bool new_blk = blk_used + (unsigned)need > blk_bytes;
+        const bool new_chunk = (i & (kRowChunk - 1)) == 0;
+        if ((i & 63) == 0) flush_rows(i - 1);
+        if (new_blk || new_chunk) {
+            __syncthreads();                                             // everyone is past the previous use of sh->blk/chunk
+            if (tid == 0) {
+                const unsigned nblk = (new_blk ? 1u : 0u) + (new_chunk ? 1u : 0u);
+                unsigned long long o1 = atomicAdd(arena_next, (unsigned long long)nblk * blk_bytes);
+                sh->fail = (o1 + (unsigned long long)nblk * blk_bytes > arena_bytes);
+                if (new_blk) { sh->blk = o1; o1 += blk_bytes; }
+                if (new_chunk) sh->chunk = o1;
+            }
+            __syncthreads();
+            if (uni(sh->fail)) { overflow = 3; break; }
+            if (new_blk) { blk_off = uni64(sh->blk); blk_used = 0; }
+            if (new_chunk) { chunk_off = uni64(sh->chunk); if (tid == 0) rowdir[pr.row_off + (unsigned)(i / kRowChunk)] = chunk_off; }
+        }
+        if (!GLOBAL && t_hi < min(na, reach + kYdThreads)) {
+            // stage target columns ahead of the window, 256 at a time (visible to all waves after the barrier)
+            while (t_hi < min(na, reach + kYdThreads)) {
+                const int j = t_hi + 1 + tid;
+                if (j <= na) Tb[j & mask] = tc[dir > 0 ? t0 + j - 1 : t0 - j];
+                t_hi += kYdThreads;
+            }
+            __syncthreads();
+        }
+        if (lane == (i & 63)) { const unsigned long long ro = blk_off + blk_used; rb_lo = (unsigned)ro; rb_hi = (unsigned)(ro >> 32); rb_ly = (unsigned)LY; }
+        MB_TICK(0);
+        int carry_x = kNeg2, carry_m = best, carry_iv = kNeg, carry_cp = kNeg;   // pass-level carries (wave-uniform)
+        int row_best = best, first_alive = -1, last_alive = -1, nrow = 0;
+        bool done = false;
+        for (int base = LY; !done; base += kYdThreads) {
+            const int j = base + tid;
+            const int idx = j & mask;
+            const int2 cd = CD[idx];
+            int cpl = CD[(j - 1) & mask].x;
+            const unsigned t = GLOBAL ? (unsigned)tc[dir > 0 ? t0 + max(j, 1) - 1 : t0 - max(j, 1)] : (unsigned)Tb[idx];
+            const bool inwin = j < RY;
+            const int cp = inwin ? cd.x : kNeg;
+            const int dp = inwin ? cd.y : kNeg;
+            cpl = (j - 1 >= LY && j - 1 < RY) ? cpl : kNeg;
+            if (base != LY && tid == 0) cpl = carry_cp;                   // column base-1 was overwritten by the previous pass
+            const unsigned at = (j <= na && j >= 1) ? t : 4u;
+            const int diag = cpl + lut_score(lut, at);
+            const int de = dp - E, dn = cp - OE;
+            const int Dv = max(de, dn);
+            const int dext = de >= dn ? 4 : 0;
+            const int M = max(diag, Dv);
+            const int rel = tidE + uni((base - LY) * E);
+            const int PX = dpp_scan_max(M + rel);
+            const int PM = dpp_scan_max(j <= na ? M : kNeg);
+            sh->scan[tid] = make_int2(PX, PM);
+            MB_TICK(1);
+            __syncthreads();                                            // ---- B1
+            MB_TICK(2);
+            const int2 t0s = sh->scan[63], t1s = sh->scan[127], t2s = sh->scan[191], t3s = sh->scan[255];
+            const int x62 = sh->scan[(64 * wv + 254) & 255].x;            // lane 62 of the previous wave (unused for wave 0)
+            const int cx = max(max(carry_x, wv > 0 ? t0s.x : kNeg2), max(wv > 1 ? t1s.x : kNeg2, wv > 2 ? t2s.x : kNeg2));
+            const int cxm1 = max(carry_x, max(wv > 1 ? t0s.x : kNeg2, wv > 2 ? t1s.x : kNeg2));   // carry into the previous wave
+            const int cm = max(max(carry_m, wv > 0 ? t0s.y : kNeg2), max(wv > 1 ? t1s.y : kNeg2, wv > 2 ? t2s.y : kNeg2));
+            const int allm = max(max(carry_m, t0s.y), max(max(t1s.y, t2s.y), t3s.y));
+            const int allx = max(max(carry_x, t0s.x), max(max(t1s.x, t2s.x), t3s.x));
+            const int ivl0 = wv == 0 ? carry_iv : max(cxm1, x62) - O - (rel - tidE + (64 * wv - 1) * E);
+            const int pex = max(dpp_shr1(PX, kNeg2), cx);
+            const int Iv = pex - O - rel;
+            const int ivl = dpp_shr1(Iv, ivl0);
+            const int iext = (Iv == ivl - E) ? 8 : 0;
+            const int gmax = max(Dv, Iv);
+            const int Cv = max(diag, gmax);
+            const int src = diag >= gmax ? 0 : (Dv >= Iv ? 1 : 2);       // tie preference diag > D > I
+            const int best_at = max(PM, cm);                             // running best, row-major, incl. this cell
+            const bool alive = (j <= na) & (Cv >= best_at - Y);
+            const unsigned long long am = __ballot(alive);
+            const unsigned long long bm = __ballot(((j >= RY) & !alive) | (j > na));
+            const unsigned long long wm = __ballot((j <= na) & (Cv == allm));
+            // C/D of columns past the break are never read again, so the ring can be written before validity is known
+            CD[idx] = make_int2(alive ? Cv : kNeg, Dv);
+            {
+                const int w64 = 64 * wv;
+                int4 rec;
+                rec.x = bm ? w64 + (int)__ffsll((long long)bm) - 1 : kBig;
+                rec.y = am ? w64 + (int)__ffsll((long long)am) - 1 : kBig;
+                rec.z = am ? w64 + 63 - (int)__clzll((long long)am) : -1;
+                rec.w = wm ? w64 + (int)__ffsll((long long)wm) - 1 : kBig;
+                sh->xb[wv] = rec;
+            }
+            if (tid == kYdThreads - 1) { sh->iv_last = Iv; sh->cp_last = cp; }   // last column of the pass, for the next pass
+            MB_TICK(3);
+            __syncthreads();                                            // ---- B2
+            MB_TICK(4);
+            const int4 r0 = sh->xb[0], r1 = sh->xb[1], r2 = sh->xb[2], r3 = sh->xb[3];
+            const int pbrk = uni(min(min(r0.x, r1.x), min(r2.x, r3.x)));
+            const int fa = uni(min(min(r0.y, r1.y), min(r2.y, r3.y)));
+            const int la = uni(max(max(r0.z, r1.z), max(r2.z, r3.z)));
+            const int cand = uni(min(min(r0.w, r1.w), min(r2.w, r3.w)));
+            // no alive cell lies behind the first break (cells there are only reachable through the dead break cell)
+            int nvalid = kYdThreads;
+            if (pbrk < kYdThreads) { nvalid = pbrk + ((base + pbrk) <= na ? 1 : 0); done = true; }
+            if (fa < kBig && first_alive < 0) first_alive = base + fa;
+            if (la >= 0) last_alive = base + la;
+            if (uni(allm) > row_best) { row_best = uni(allm); bi = i; bj = base + cand; }
+            if (tid < nvalid) arena[blk_off + blk_used + (unsigned)(nrow + tid)] = (uint8_t)(src | dext | iext);
+            nrow += nvalid;
+            if (!done) { carry_x = uni(allx); carry_m = uni(allm); carry_iv = uni(sh->iv_last); carry_cp = uni(sh->cp_last); }
+            MB_TICK(5);
+        }
+        blk_used += (unsigned)nrow;
+        cells += nrow;
         rows++;
         best = row_best;
-        if (bi == i) cells_to_bi = cells;
-        if (first_alive < 0) break;
+        if (first_alive < 0) { i++; break; }
         LY = first_alive;
         RY = last_alive + 1;
     }
-    if (lane == 0) {
+    if (!overflow) flush_rows(i - 1);
+    if (tid == 0) {
         out->best = best; out->bi = bi; out->bj = bj; out->rows = rows;
-        out->cells = cells; out->cells_to_bi = cells_to_bi; out->overflow = overflow; out->n_ops = 0;
+        out->cells = cells; out->cells_to_bi = clock64() - clk0; out->overflow = overflow; out->n_ops = 0;
+        if (PROF) for (int k = 0; k < 6; k++) out->prof[k] = pf[k];
     }
 }
 
-template <bool TRACE, bool GLOBAL_ROWS>
-__global__ __launch_bounds__(64) void k_ydrop(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
-                                              const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qf,
-                                              const uint8_t *__restrict__ qr, int O, int E, int Y, int32_t *grows,
-                                              uint8_t *__restrict__ trace, uint64_t *__restrict__ rowoff,
-                                              uint32_t *__restrict__ rowly) {
+template <bool GLOBAL_ROWS, bool PROF>
+__global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
+                                                      const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qf,
+                                                      const uint8_t *__restrict__ qr, int O, int E, int Y, int32_t *grows,
+                                                      uint8_t *__restrict__ arena, unsigned long long arena_bytes,
+                                                      unsigned long long *__restrict__ arena_next, unsigned blk_bytes,
+                                                      unsigned long long *__restrict__ rowdir) {
     int pi = blockIdx.x;
     if (pi >= n) return;
     DpProb pr = probs[pi];
     const uint8_t *qc = pr.strand ? qr : qf;
+    __shared__ YdShared sh;
     if (GLOBAL_ROWS) {
-        int *C = grows + (size_t)pi * 2 * kGlobalRowCap;
-        ydrop_body<TRACE>(pr, &outs[pi], tc, qc, O, E, Y, C, C + kGlobalRowCap, kGlobalRowCap, trace, rowoff, rowly);
+        int2 *CD = (int2 *)(grows + (size_t)pi * 2 * kGlobalRowCap);
+        ydrop_body<true, PROF>(pr, &outs[pi], tc, qc, O, E, Y, CD, nullptr, kGlobalRowCap, &sh, arena, arena_bytes, arena_next,
+                               blk_bytes, rowdir);
     } else {
-        __shared__ int sC[kLdsRowCap];
-        __shared__ int sD[kLdsRowCap];
-        ydrop_body<TRACE>(pr, &outs[pi], tc, qc, O, E, Y, sC, sD, kLdsRowCap, trace, rowoff, rowly);
+        __shared__ int2 sCD[kLdsRowCap];
+        __shared__ uint8_t sT[kLdsRowCap];
+        ydrop_body<false, PROF>(pr, &outs[pi], tc, qc, O, E, Y, sCD, sT, kLdsRowCap, &sh, arena, arena_bytes, arena_next,
+                                blk_bytes, rowdir);
     }
 }
 
-void launch_ydrop(bool trace, bool global_rows, const DpProb *probs, DpOut *outs, int n, const uint8_t *tc,
-                  const uint8_t *qf, const uint8_t *qr, int O, int E, int Y, int32_t *grows, uint8_t *tracebuf,
-                  uint64_t *rowoff, uint32_t *rowly, hipStream_t s) {
+void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const uint8_t *tc, const uint8_t *qf,
+                  const uint8_t *qr, int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
+                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s) {
     if (n <= 0) return;
-    dim3 g((unsigned)n), b(64);
-    if (trace) {
-        if (global_rows) hipLaunchKernelGGL((k_ydrop<true, true>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, tracebuf, rowoff, rowly);
-        else hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, tracebuf, rowoff, rowly);
-    } else {
-        if (global_rows) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, tracebuf, rowoff, rowly);
-        else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, tracebuf, rowoff, rowly);
-    }
+    dim3 g((unsigned)n), b(kYdThreads);
+    static const bool prof = getenv("MIBLAST_DP_PROFILE") != nullptr;
+    if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
+    else if (prof) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
+    else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
 }
 
 // ------------------------------------------------------------------------------------------------
-// traceback: one thread per DP side; emits one op byte per alignment column in walk-back order
-// (0 aligned pair, 2 query-only, 3 target-only).
-__global__ void k_traceback(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
-                            const uint8_t *__restrict__ trace, const uint64_t *__restrict__ rowoff,
-                            const uint32_t *__restrict__ rowly, uint8_t *__restrict__ ops) {
-    int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= n) return;
-    DpProb pr = probs[pi];
+// traceback: one wave per DP side.  The walk itself is wave-uniform (state in SGPRs); the memory latency is
+// taken off the chain by fetching, for 64 rows at a time, each row's (offset, LY) record and the 8 trace
+// bytes around the column a gap-free path would visit (lane l <-> row i-l, columns j-l-3 .. j-l+4).
+// Ops are emitted one byte per alignment column in walk-back order (0 pair, 2 query-only, 3 target-only),
+// 64 at a time.
+__global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ probs, DpOut *__restrict__ outs,
+                                                  const int *__restrict__ which, int n, const uint8_t *__restrict__ arena,
+                                                  const unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ ops) {
+    const int slot = blockIdx.x;
+    if (slot >= n) return;
+    const int pi = which[slot];
+    const DpProb pr = probs[pi];
+    const int lane = threadIdx.x & 63;
     int i = outs[pi].bi, j = outs[pi].bj, state = 0;
     uint8_t *o = ops + pr.ops_off;
     int n_ops = 0;
+    unsigned opbuf = 0;
     while (i > 0 || j > 0) {
-        uint8_t tb = trace[pr.trace_off + rowoff[pr.row_off + i] + (uint64_t)(j - (int)rowly[pr.row_off + i])];
-        if (state == 0) {
-            int src = tb & 3;
-            if (src == 0) { o[n_ops++] = 0; i--; j--; }
-            else if (src == 1) state = 1;
-            else if (src == 2) state = 2;
-            else break;
-        } else if (state == 1) {
-            o[n_ops++] = 2; if (!(tb & 4)) state = 0; i--;
-        } else {
-            o[n_ops++] = 3; if (!(tb & 8)) state = 0; j--;
+        // fetch block: rows i .. i-63
+        const int i0 = i, j0 = j;
+        const int r = i0 - lane;
+        unsigned long long win = 0; int wly = 0, wc0 = 0;
+        if (r >= 0) {
+            const RowInfo ri = ((const RowInfo *)(arena + rowdir[pr.row_off + (unsigned)(r / kRowChunk)]))[r & (kRowChunk - 1)];
+            wly = (int)ri.ly;
+            wc0 = j0 - lane - 3;                               // column of byte 0 of the window
+            const uint8_t *rowp = arena + ri.off;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = wc0 + k;
+                unsigned b = 0;
+                if (c >= wly) b = rowp[c - wly];              // bytes right of the stored row are never consulted
+                win |= (unsigned long long)b << (8 * k);
+            }
+        }
+        const unsigned wlo = (unsigned)win, whi = (unsigned)(win >> 32);
+        // uniform walk inside the block
+        while (i > 0 || j > 0) {
+            const int l = i0 - i;
+            if (l >= 64) break;
+            const int c0 = j0 - l - 3;
+            const int k = j - c0;
+            if (k < 0 || k >= 8) break;                        // drifted out of the prefetched window: refetch
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wlo, l), hi = (unsigned)__builtin_amdgcn_readlane((int)whi, l);
+            const unsigned tb = ((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4)))) & 0xFFu;
+            int op = -1;
+            if (state == 0) {
+                const unsigned src = tb & 3u;
+                if (src == 0u) { op = 0; i--; j--; }
+                else if (src == 1u) state = 1;
+                else if (src == 2u) state = 2;
+                else { i = 0; j = 0; }
+            } else if (state == 1) {
+                op = 2; if (!(tb & 4u)) state = 0; i--;
+            } else {
+                op = 3; if (!(tb & 8u)) state = 0; j--;
+            }
+            if (op >= 0) {
+                if (lane == (n_ops & 63)) opbuf = (unsigned)op;
+                n_ops++;
+                if ((n_ops & 63) == 0) o[n_ops - 64 + lane] = (uint8_t)opbuf;
+            }
         }
     }
-    outs[pi].n_ops = n_ops;
+    if ((n_ops & 63) && lane < (n_ops & 63)) o[(n_ops & ~63) + lane] = (uint8_t)opbuf;
+    if (lane == 0) outs[pi].n_ops = n_ops;
 }
 
-void launch_traceback(const DpProb *probs, DpOut *outs, int n, const uint8_t *tracebuf, const uint64_t *rowoff,
-                      const uint32_t *rowly, uint8_t *ops, hipStream_t s) {
+void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
+                      const unsigned long long *rowdir, uint8_t *ops, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_traceback, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, probs, outs, n, tracebuf, rowoff, rowly, ops);
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, probs, outs, which, n, arena, rowdir, ops);
 }
 
 }  // namespace mb

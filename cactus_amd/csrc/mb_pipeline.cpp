@@ -74,7 +74,6 @@ struct Cached {                // result of one anchor's two one-sided DPs
     bool accepted = false;
     int32_t score = 0, t_lo = 0, t_hi = 0, q_lo = 0, q_hi = 0, dmin = 0, dmax = 0;
     int64_t cells = 0, rows = 0;
-    std::vector<uint8_t> raw_r, raw_l;   // walk-back op bytes of the right / left DP (until merged)
     std::vector<uint32_t> ops;           // merged run-length ops, forward order
 };
 
@@ -85,13 +84,22 @@ struct Unit {                  // one (query contig, strand): anchors are commit
     std::unordered_map<size_t, Cached> cache;
     std::vector<miblast_aln> kept;          // ops_off indexes unit_ops
     std::vector<uint32_t> unit_ops;
-    size_t batch = 0;
 };
 
 bool covered(const Unit &u, const Anchor &a) {
     int32_t d = a.t - a.q;
     for (const miblast_aln &A : u.kept)
         if (a.t >= A.t_lo && a.t < A.t_hi && a.q >= A.q_lo && a.q < A.q_hi && d >= A.dmin && d <= A.dmax) return true;
+    return false;
+}
+
+// heuristic only (never affects results): would `a` be covered if the not-yet-committed accepted results were kept?
+bool tentatively_covered(const Unit &u, const Anchor &a) {
+    int32_t d = a.t - a.q;
+    for (const auto &kv : u.cache) {
+        const Cached &c = kv.second;
+        if (c.accepted && a.t >= c.t_lo && a.t < c.t_hi && a.q >= c.q_lo && a.q < c.q_hi && d >= c.dmin && d <= c.dmax) return true;
+    }
     return false;
 }
 
@@ -124,28 +132,52 @@ void release_seqset(SeqSet &s) {
     s.d_buf = nullptr; s.d_starts = nullptr; s.d_lens = nullptr;
 }
 
+
 // --------------------------------------------------------------------------------------------------
-struct Index {
-    DevBuf<uint32_t> offsets;      // 2^24 + 1
-    DevBuf<uint32_t> positions;
-    uint32_t n_positions = 0;
+struct Workspace {                      // device buffers that persist across miblast_align() calls of one context
+    // seed position table
+    DevBuf<uint32_t> words, counts, offsets, positions;
+    DevBuf<unsigned long long> bsum;
+    // seed search / ungapped
+    DevBuf<uint8_t> rc;
+    DevBuf<int32_t> extent;
+    DevBuf<uint32_t> qcnt, hit_off;
+    DevBuf<unsigned long long> qbsum, scan_scratch, keys_a, keys_b;
+    DevBuf<char> sort_temp;
+    DevBuf<DevHsp> hsps;
+    DevBuf<UngappedCounters> ctr;
+    // gapped
+    DevBuf<DpProb> probs;
+    DevBuf<DpOut> outs;
+    DevBuf<int32_t> grows;
+    DevBuf<uint8_t> arena;
+    DevBuf<unsigned long long> arena_next;
+    DevBuf<unsigned long long> rowdir;
+    DevBuf<uint8_t> ops;
+    DevBuf<int> which;
 };
+
+Workspace *workspace_create() { return new Workspace(); }
+void workspace_destroy(Workspace *w) { delete w; }
+
+struct Index { uint32_t n_positions = 0; };
 
 static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     hipStream_t s = ctx.stream;
+    Workspace &w = *ctx.ws;
     int64_t n_slots = (T.total + step - 1) / step;
-    DevBuf<uint32_t> words((size_t)std::max<int64_t>(1, n_slots));
-    DevBuf<uint32_t> counts((size_t)kBuckets + 1);
-    ix.offsets.alloc((size_t)kBuckets + 1);
-    ix.positions.alloc((size_t)std::max<int64_t>(1, n_slots));
+    w.words.ensure((size_t)std::max<int64_t>(1, n_slots));
+    w.counts.ensure((size_t)kBuckets + 1);
+    w.offsets.ensure((size_t)kBuckets + 1);
+    w.positions.ensure((size_t)std::max<int64_t>(1, n_slots));
     int64_t nblk = ((int64_t)kBuckets + 1 + 2047) / 2048;
-    DevBuf<unsigned long long> bsum((size_t)nblk + 2);
-    MB_HIP(hipMemsetAsync(counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
-    launch_index_words(T.dev(), T.total, step, words.p, n_slots, counts.p, s);
-    launch_scan_u32(counts.p, ix.offsets.p, (int64_t)kBuckets + 1, bsum.p, s);
-    MB_HIP(hipMemsetAsync(counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
-    launch_index_scatter(words.p, n_slots, step, ix.offsets.p, counts.p, ix.positions.p, s);
-    MB_HIP(hipMemcpyAsync(&ix.n_positions, ix.offsets.p + kBuckets, 4, hipMemcpyDeviceToHost, s));
+    w.bsum.ensure((size_t)nblk + 2);
+    MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
+    launch_index_words(T.dev(), T.total, step, w.words.p, n_slots, w.counts.p, s);
+    launch_scan_u32(w.counts.p, w.offsets.p, (int64_t)kBuckets + 1, w.bsum.p, s);
+    MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
+    launch_index_scatter(w.words.p, n_slots, step, w.offsets.p, w.counts.p, w.positions.p, s);
+    MB_HIP(hipMemcpyAsync(&ix.n_positions, w.offsets.p + kBuckets, 4, hipMemcpyDeviceToHost, s));
     MB_HIP(hipStreamSynchronize(s));
 }
 
@@ -153,10 +185,11 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
     MB_HIP(hipSetDevice(ctx.device));
     Index ix;
     build_index(ctx, T, step, ix);
+    Workspace &w = *ctx.ws;
     uint32_t *off = (uint32_t *)malloc(((size_t)kBuckets + 1) * 4);
     uint32_t *pos = (uint32_t *)malloc(((size_t)ix.n_positions + 1) * 4);
-    MB_HIP(hipMemcpy(off, ix.offsets.p, ((size_t)kBuckets + 1) * 4, hipMemcpyDeviceToHost));
-    if (ix.n_positions) MB_HIP(hipMemcpy(pos, ix.positions.p, (size_t)ix.n_positions * 4, hipMemcpyDeviceToHost));
+    MB_HIP(hipMemcpy(off, w.offsets.p, ((size_t)kBuckets + 1) * 4, hipMemcpyDeviceToHost));
+    if (ix.n_positions) MB_HIP(hipMemcpy(pos, w.positions.p, (size_t)ix.n_positions * 4, hipMemcpyDeviceToHost));
     // the device scatter fills a bucket in arrival order; the exported table is canonical (ascending)
     for (uint32_t b = 0; b < kBuckets; b++)
         if (off[b + 1] - off[b] > 1) std::sort(pos + off[b], pos + off[b + 1]);
@@ -164,23 +197,13 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
     return 0;
 }
 
-// --------------------------------------------------------------------------------------------------
-struct GappedScratch {
-    DevBuf<DpProb> probs;
-    DevBuf<DpOut> outs;
-    DevBuf<int32_t> grows;
-    DevBuf<uint8_t> trace;
-    DevBuf<uint64_t> rowoff;
-    DevBuf<uint32_t> rowly;
-    DevBuf<uint8_t> ops;
-};
-
-static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, bool trace, bool global_rows, const DpProb *probs, DpOut *outs,
-                            int n, const uint8_t *tc, const uint8_t *qf, const uint8_t *qr, const miblast_params &p,
-                            GappedScratch &g) {
+static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, bool global_rows, const DpProb *probs, DpOut *outs, int n,
+                            const uint8_t *tc, const uint8_t *qf, const uint8_t *qr, const miblast_params &p,
+                            unsigned blk_bytes) {
+    Workspace &g = *ctx.ws;
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
-    launch_ydrop(trace, global_rows, probs, outs, n, tc, qf, qr, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.trace.p,
-                 g.rowoff.p, g.rowly.p, ctx.stream);
+    launch_ydrop(global_rows, probs, outs, n, tc, qf, qr, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
+                 (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, ctx.stream);
     MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     MB_HIP(hipEventSynchronize(ctx.ev1));
     float ms = 0;
@@ -207,12 +230,14 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     const int64_t qtot = Q.total, ttot = T.total;
 
     // ---- seed position table ------------------------------------------------------------------
+    Workspace &w = *ctx.ws;
     Index ix;
     build_index(ctx, T, p.step, ix);
     st.t_index = now_s() - t_begin;
 
     // ---- '-' strand of the query -----------------------------------------------------------------
-    DevBuf<uint8_t> d_rc((size_t)qtot + 2);
+    DevBuf<uint8_t> &d_rc = w.rc;
+    d_rc.ensure((size_t)qtot + 2);
     MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2, s));
     launch_revcomp(Q.dev(), d_rc.p + 1, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
     std::vector<uint8_t> h_rc((size_t)qtot + 2);
@@ -225,23 +250,24 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     // ---- seed search + ungapped extension, per strand ----------------------------------------------
     const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
     const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
-    DevBuf<int32_t> extent((size_t)(ttot + qtot + 2));
-    DevBuf<uint32_t> qcnt((size_t)std::max<int64_t>(1, qtot));
+    DevBuf<int32_t> &extent = w.extent;
+    extent.ensure((size_t)(ttot + qtot + 2));
+    DevBuf<uint32_t> &qcnt = w.qcnt, &hit_off = w.hit_off;
+    qcnt.ensure((size_t)std::max<int64_t>(1, qtot));
     int64_t n_qblk = (qtot + 2047) / 2048;
-    DevBuf<unsigned long long> qbsum((size_t)n_qblk + 2), scan_scratch((size_t)n_qblk + 2);
-    DevBuf<uint32_t> hit_off;
-    DevBuf<unsigned long long> keys_a, keys_b;
-    DevBuf<char> sort_temp;
-    DevBuf<DevHsp> d_hsps;
-    DevBuf<UngappedCounters> d_ctr(1);
-    DevBuf<unsigned long long> d_nvalid(1);
+    DevBuf<unsigned long long> &qbsum = w.qbsum, &scan_scratch = w.scan_scratch, &keys_a = w.keys_a, &keys_b = w.keys_b;
+    qbsum.ensure((size_t)n_qblk + 2); scan_scratch.ensure((size_t)n_qblk + 2);
+    DevBuf<char> &sort_temp = w.sort_temp;
+    DevBuf<DevHsp> &d_hsps = w.hsps;
+    DevBuf<UngappedCounters> &d_ctr = w.ctr;
+    d_ctr.ensure(1);
     std::vector<unsigned long long> h_qbsum((size_t)n_qblk + 2);
     std::vector<miblast_hsp> strand_hsps[2];
 
     for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
         const double t0 = now_s();
         MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
-        launch_seed_count(qc_d[strand], qtot, ix.offsets.p, p.transitions, qcnt.p, s);
+        launch_seed_count(qc_d[strand], qtot, w.offsets.p, p.transitions, qcnt.p, s);
         launch_block_sums(qcnt.p, qtot, qbsum.p, s);
         MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
         MB_HIP(hipStreamSynchronize(s));
@@ -265,7 +291,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev0, s));
             launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
-            launch_seed_fill(qc_d[strand], q0, q1, qtot, ix.offsets.p, ix.positions.p, p.transitions, hit_off.p, keys_a.p, s);
+            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
             MB_HIP(hipEventRecord(ctx.ev1, s));
             sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, sort_bits, s);
             MB_HIP(hipEventRecord(ctx.ev2, s));
@@ -387,18 +413,26 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                     return a.q < b.q;
                 });
                 st.anchors += (int64_t)u.anchors.size();
-                u.batch = (size_t)env_long("MIBLAST_GAPPED_BATCH0", 32);
                 units.push_back(std::move(u));
             }
         }
     }
-    const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 8192);
-    const int64_t trace_budget = env_long("MIBLAST_TRACE_BUDGET_MB", 8192) << 20;
-    GappedScratch g;
+    const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 4096);
+    const long shadow_q0 = env_long("MIBLAST_SHADOW_Q", 1 << 16);        // spatial thinning of speculative anchors
+    const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
+    const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
+    const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
+    Workspace &g = *ctx.ws;
+    if (!units.empty()) {
+        size_t want = (size_t)env_long("MIBLAST_ARENA_MB", 2048) << 20;
+        if (g.arena.n < want) g.arena.alloc(want);
+        g.arena_next.ensure(1);
+    }
     struct Pending { size_t unit, anchor; };
-    while (true) {
+    for (int round = 0;; round++) {
         // commit what can be committed, then nominate the next speculative batch of every unit
         std::vector<Pending> pend;
+        const long shadow_q = std::max(64l, shadow_q0 >> (2 * std::min(round, 15)));
         for (size_t ui = 0; ui < units.size(); ui++) {
             Unit &u = units[ui];
             while (u.next < u.anchors.size()) {
@@ -421,21 +455,34 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 u.cache.erase(it);
                 u.next++;
             }
-            size_t taken = 0;
-            for (size_t k = u.next; k < u.anchors.size() && taken < u.batch; k++) {
+            // Nomination is a pure scheduling heuristic: results never depend on it because anchors are
+            // committed strictly in order above.  The first unresolved anchor is always nominated (progress);
+            // the others are thinned: skip what an uncommitted accepted result would cover, and keep at most
+            // one new anchor per (diagonal band, query neighbourhood) -- the neighbourhood shrinks 4x per round,
+            // so long alignments are found first from a few probes and the gaps are filled in later rounds.
+            std::vector<Anchor> taken;
+            for (size_t k = u.next; k < u.anchors.size() && taken.size() < batch_max; k++) {
                 if (u.cache.count(k)) continue;
-                if (covered(u, u.anchors[k])) continue;
+                const Anchor &a = u.anchors[k];
+                if (covered(u, a)) continue;
+                if (k != u.next) {
+                    if (tentatively_covered(u, a)) continue;
+                    bool shadowed = false;
+                    for (const Anchor &b : taken)
+                        if (std::labs((long)(a.t - a.q) - (long)(b.t - b.q)) <= shadow_d && std::labs((long)a.q - (long)b.q) <= shadow_q) { shadowed = true; break; }
+                    if (shadowed) continue;
+                }
+                taken.push_back(a);
                 pend.push_back(Pending{ui, k});
-                taken++;
             }
-            u.batch = std::min(batch_max, u.batch * 2);
         }
         if (pend.empty()) break;
         st.gapped_rounds++;
 
-        // ---- score pass: two one-sided DPs per anchor -----------------------------------------------
+        // ---- two one-sided DPs per nominated anchor, trace stored in the arena --------------------------
         const int np = (int)pend.size() * 2;
         std::vector<DpProb> probs((size_t)np);
+        uint64_t dir_entries = 0;
         for (size_t k = 0; k < pend.size(); k++) {
             const Unit &u = units[pend[k].unit];
             const Anchor &a = u.anchors[pend[k].anchor];
@@ -444,37 +491,66 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             int64_t qlo = Q.starts[(size_t)u.q_contig], qhi = qlo + Q.lens[(size_t)u.q_contig];
             DpProb &r = probs[2 * k], &l = probs[2 * k + 1];
             memset(&r, 0, sizeof r); memset(&l, 0, sizeof l);
-            r.t0 = a.t; r.q0 = a.q; r.dir = +1; r.na = (int32_t)(thi - a.t); r.nb = (int32_t)(qhi - a.q); r.strand = u.strand; r.stop_row = 0x7fffffff;
-            l.t0 = a.t; l.q0 = a.q; l.dir = -1; l.na = (int32_t)(a.t - tlo); l.nb = (int32_t)(a.q - qlo); l.strand = u.strand; l.stop_row = 0x7fffffff;
+            r.t0 = a.t; r.q0 = a.q; r.dir = +1; r.na = (int32_t)(thi - a.t); r.nb = (int32_t)(qhi - a.q); r.strand = u.strand;
+            l.t0 = a.t; l.q0 = a.q; l.dir = -1; l.na = (int32_t)(a.t - tlo); l.nb = (int32_t)(a.q - qlo); l.strand = u.strand;
+            r.row_off = dir_entries; dir_entries += (uint64_t)(r.nb / 4096) + 2;
+            l.row_off = dir_entries; dir_entries += (uint64_t)(l.nb / 4096) + 2;
         }
-        g.probs.ensure((size_t)np); g.outs.ensure((size_t)np);
-        MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
-        run_ydrop_timed(ctx, st, false, false, g.probs.p, g.outs.p, np, T.dev(), qc_d[0], qc_d[1], p, g);
+        g.probs.ensure((size_t)np); g.outs.ensure((size_t)np); g.rowdir.ensure((size_t)dir_entries + 1);
         std::vector<DpOut> outs((size_t)np);
-        MB_HIP(hipMemcpy(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost));
-        // rows wider than the LDS ring: rerun those sides with the ring in HBM
-        std::vector<int> wide;
-        for (int k = 0; k < np; k++) if (outs[(size_t)k].overflow) wide.push_back(k);
-        for (size_t w0 = 0; w0 < wide.size(); w0 += 64) {
-            size_t w1 = std::min(wide.size(), w0 + 64);
-            std::vector<DpProb> wp;
-            for (size_t k = w0; k < w1; k++) wp.push_back(probs[(size_t)wide[k]]);
-            DevBuf<DpProb> dwp(wp.size()); DevBuf<DpOut> dwo(wp.size());
-            g.grows.ensure(wp.size() * 2 * (size_t)kGlobalRowCap);
-            MB_HIP(hipMemcpy(dwp.p, wp.data(), wp.size() * sizeof(DpProb), hipMemcpyHostToDevice));
-            run_ydrop_timed(ctx, st, false, true, dwp.p, dwo.p, (int)wp.size(), T.dev(), qc_d[0], qc_d[1], p, g);
-            std::vector<DpOut> wo(wp.size());
-            MB_HIP(hipMemcpy(wo.data(), dwo.p, wp.size() * sizeof(DpOut), hipMemcpyDeviceToHost));
-            for (size_t k = w0; k < w1; k++) {
-                if (wo[k - w0].overflow) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
-                outs[(size_t)wide[k]] = wo[k - w0];
-                outs[(size_t)wide[k]].overflow = 2;       // remember: needs the HBM ring in the trace pass too
+        while (true) {                                   // retried with a larger arena if the trace does not fit
+            MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
+            MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
+            run_ydrop_timed(ctx, st, false, g.probs.p, g.outs.p, np, T.dev(), qc_d[0], qc_d[1], p, kBlk);
+            MB_HIP(hipMemcpy(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost));
+            // rows wider than the LDS ring: rerun those sides with the C/D ring in HBM (arena keeps filling)
+            std::vector<int> wide;
+            for (int k = 0; k < np; k++) if (outs[(size_t)k].overflow == 1) wide.push_back(k);
+            bool arena_full = false;
+            for (int k = 0; k < np; k++) arena_full |= outs[(size_t)k].overflow == 3;
+            for (size_t w0 = 0; w0 < wide.size() && !arena_full; w0 += 32) {
+                size_t w1 = std::min(wide.size(), w0 + 32);
+                std::vector<DpProb> wp;
+                for (size_t k = w0; k < w1; k++) wp.push_back(probs[(size_t)wide[k]]);
+                DevBuf<DpProb> dwp(wp.size()); DevBuf<DpOut> dwo(wp.size());
+                g.grows.ensure(wp.size() * 2 * (size_t)kGlobalRowCap);
+                MB_HIP(hipMemcpy(dwp.p, wp.data(), wp.size() * sizeof(DpProb), hipMemcpyHostToDevice));
+                run_ydrop_timed(ctx, st, true, dwp.p, dwo.p, (int)wp.size(), T.dev(), qc_d[0], qc_d[1], p, kBlkWide);
+                std::vector<DpOut> wo(wp.size());
+                MB_HIP(hipMemcpy(wo.data(), dwo.p, wp.size() * sizeof(DpOut), hipMemcpyDeviceToHost));
+                for (size_t k = w0; k < w1; k++) {
+                    if (wo[k - w0].overflow == 1) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
+                    if (wo[k - w0].overflow == 3) arena_full = true;
+                    outs[(size_t)wide[k]] = wo[k - w0];
+                    MB_HIP(hipMemcpy(g.outs.p + wide[k], &wo[k - w0], sizeof(DpOut), hipMemcpyHostToDevice));
+                }
             }
+            for (int k = 0; k < np; k++) { st.dp_sides_run++; st.dp_cells_run += outs[(size_t)k].cells; }
+            if (debug) {
+                int maxrows = 0; long long cells = 0, clk = 0;
+                for (int k = 0; k < np; k++) { if (outs[(size_t)k].rows > maxrows) { maxrows = outs[(size_t)k].rows; clk = outs[(size_t)k].cells_to_bi; } cells += outs[(size_t)k].cells; }
+                fprintf(stderr, "[miblast] round %d: %d sides, max rows %d (%lld shader clocks = %.0f per row), cells %lld, dp kernel total %.2f ms so far, shadow_q %ld\n",
+                        round, np, maxrows, clk, (double)clk / std::max(1, maxrows), cells, st.t_dp_kernel_ms, shadow_q);
+                for (int k = 0; k < np; k++) if (outs[(size_t)k].rows == maxrows && outs[(size_t)k].prof[1]) {
+                    const DpOut &o = outs[(size_t)k];
+                    fprintf(stderr, "[miblast]   per row: setup %.0f | load+scan %.0f | B1 %.0f | Iv/C/alive %.0f | B2 %.0f | replay+store %.0f\n",
+                            (double)o.prof[0] / maxrows, (double)o.prof[1] / maxrows, (double)o.prof[2] / maxrows, (double)o.prof[3] / maxrows,
+                            (double)o.prof[4] / maxrows, (double)o.prof[5] / maxrows);
+                    break;
+                }
+            }
+            if (!arena_full) break;
+            size_t bigger = g.arena.n * 2;
+            size_t free_b = 0, total_b = 0;
+            MB_HIP(hipMemGetInfo(&free_b, &total_b));
+            if (bigger > free_b + g.arena.n - (1ull << 30)) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
+            g.arena.alloc(bigger);
         }
-        for (int k = 0; k < np; k++) { st.dp_sides_run++; st.dp_cells_run += outs[(size_t)k].cells; }
 
-        // ---- trace pass + traceback for anchors reaching --gappedthresh ------------------------------
+        // ---- traceback of every anchor reaching --gappedthresh ------------------------------------------
         std::vector<size_t> acc;                        // indices into pend
+        std::vector<int> which;
+        uint64_t ooff = 0;
         for (size_t k = 0; k < pend.size(); k++) {
             Unit &u = units[pend[k].unit];
             Cached c;
@@ -484,69 +560,39 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             c.cells = R.cells + L.cells; c.rows = (int64_t)R.rows + L.rows;
             c.t_lo = a.t - L.bj; c.t_hi = a.t + R.bj; c.q_lo = a.q - L.bi; c.q_hi = a.q + R.bi;
             c.accepted = c.score >= p.gappedthresh;
-            if (c.accepted) acc.push_back(k);
+            c.dmin = 0x7fffffff; c.dmax = -0x7fffffff - 1;          // set by the merge below; until then covers nothing
+            if (c.accepted) {
+                acc.push_back(k);
+                for (int side = 0; side < 2; side++) {
+                    which.push_back((int)(2 * k) + side);
+                    probs[2 * k + side].ops_off = ooff;
+                    ooff += (((uint64_t)outs[2 * k + side].bi + (uint64_t)outs[2 * k + side].bj) | 63u) + 1;
+                }
+            }
             u.cache.emplace(pend[k].anchor, std::move(c));
         }
-        size_t a0 = 0;
-        while (a0 < acc.size()) {
-            // chunk of accepted anchors whose traces fit the budget
-            size_t a1 = a0; int64_t bytes = 0;
-            while (a1 < acc.size()) {
-                const DpOut &R = outs[2 * acc[a1]], &L = outs[2 * acc[a1] + 1];
-                int64_t need = R.cells_to_bi + L.cells_to_bi;
-                if (a1 > a0 && bytes + need > trace_budget) break;
-                bytes += need; a1++;
-            }
-            for (int pass = 0; pass < 2; pass++) {      // pass 0: LDS-ring sides, pass 1: HBM-ring sides
-                std::vector<DpProb> tp; std::vector<std::pair<size_t, int>> who;   // (acc index, side)
-                uint64_t toff = 0, roff = 0, ooff = 0;
-                for (size_t k = a0; k < a1; k++)
-                    for (int side = 0; side < 2; side++) {
-                        const DpOut &o = outs[2 * acc[k] + side];
-                        if ((o.overflow == 2) != (pass == 1)) continue;
-                        DpProb pr = probs[2 * acc[k] + side];
-                        pr.stop_row = o.bi; pr.trace_off = toff; pr.row_off = roff; pr.ops_off = ooff;
-                        toff += (uint64_t)o.cells_to_bi; roff += (uint64_t)o.bi + 1; ooff += (uint64_t)o.bi + (uint64_t)o.bj + 1;
-                        tp.push_back(pr); who.emplace_back(k, side);
-                    }
-                if (tp.empty()) continue;
-                const size_t per_launch = pass == 1 ? 64 : tp.size();
-                g.trace.ensure((size_t)toff + 64); g.rowoff.ensure((size_t)roff + 1); g.rowly.ensure((size_t)roff + 1); g.ops.ensure((size_t)ooff + 1);
-                g.probs.ensure(tp.size()); g.outs.ensure(tp.size());
-                MB_HIP(hipMemcpy(g.probs.p, tp.data(), tp.size() * sizeof(DpProb), hipMemcpyHostToDevice));
-                if (pass == 1) g.grows.ensure(std::min(per_launch, tp.size()) * 2 * (size_t)kGlobalRowCap);
-                for (size_t l0 = 0; l0 < tp.size(); l0 += per_launch) {
-                    size_t l1 = std::min(tp.size(), l0 + per_launch);
-                    run_ydrop_timed(ctx, st, true, pass == 1, g.probs.p + l0, g.outs.p + l0, (int)(l1 - l0), T.dev(), qc_d[0], qc_d[1], p, g);
-                }
-                launch_traceback(g.probs.p, g.outs.p, (int)tp.size(), g.trace.p, g.rowoff.p, g.rowly.p, g.ops.p, s);
-                std::vector<DpOut> to(tp.size());
-                std::vector<uint8_t> hops((size_t)ooff + 1);
-                MB_HIP(hipMemcpyAsync(to.data(), g.outs.p, tp.size() * sizeof(DpOut), hipMemcpyDeviceToHost, s));
-                MB_HIP(hipMemcpyAsync(hops.data(), g.ops.p, (size_t)ooff, hipMemcpyDeviceToHost, s));
-                MB_HIP(hipStreamSynchronize(s));
-                for (size_t k = 0; k < tp.size(); k++) {
-                    st.dp_sides_run++; st.dp_cells_run += to[k].cells;
-                    Unit &u = units[pend[acc[who[k].first]].unit];
-                    Cached &c = u.cache[pend[acc[who[k].first]].anchor];
-                    std::vector<uint8_t> &raw = who[k].second == 0 ? c.raw_r : c.raw_l;
-                    raw.assign(hops.begin() + (ptrdiff_t)tp[k].ops_off, hops.begin() + (ptrdiff_t)tp[k].ops_off + to[k].n_ops);
-                }
-            }
-            // merge the two sides of every accepted anchor of this chunk into a run-length '=XID' string
-            for (size_t k = a0; k < a1; k++) {
-                Unit &u = units[pend[acc[k]].unit];
-                Cached &c = u.cache[pend[acc[k]].anchor];
-                std::vector<uint8_t> Rops, Lops;
-                Rops.swap(c.raw_r); Lops.swap(c.raw_l);
-                c.ops.clear();
+        if (!acc.empty()) {
+            g.which.ensure(which.size()); g.ops.ensure((size_t)ooff + 64);
+            MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
+            MB_HIP(hipMemcpyAsync(g.which.p, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            launch_traceback(g.probs.p, g.outs.p, g.which.p, (int)which.size(), g.arena.p, g.rowdir.p, g.ops.p, s);
+            std::vector<uint8_t> hops((size_t)ooff + 1);
+            MB_HIP(hipMemcpyAsync(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost, s));
+            MB_HIP(hipMemcpyAsync(hops.data(), g.ops.p, (size_t)ooff, hipMemcpyDeviceToHost, s));
+            MB_HIP(hipStreamSynchronize(s));
+            // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
+            // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
+            for (size_t k : acc) {
+                Unit &u = units[pend[k].unit];
+                Cached &c = u.cache[pend[k].anchor];
+                const uint8_t *Rops = hops.data() + probs[2 * k].ops_off, *Lops = hops.data() + probs[2 * k + 1].ops_off;
+                const size_t nR = (size_t)outs[2 * k].n_ops, nL = (size_t)outs[2 * k + 1].n_ops;
                 const uint8_t *qc = qc_h[u.strand];
                 int64_t tt = c.t_lo, qq = c.q_lo;
                 int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
                 uint32_t cur_op = 0, cur_len = 0;
-                const size_t ncol = Lops.size() + Rops.size();
-                for (size_t col = 0; col < ncol; col++) {
-                    uint8_t o = col < Lops.size() ? Lops[col] : Rops[Rops.size() - 1 - (col - Lops.size())];
+                for (size_t col = 0; col < nL + nR; col++) {
+                    uint8_t o = col < nL ? Lops[col] : Rops[nR - 1 - (col - nL)];
                     uint32_t op;
                     if (o == 0) {
                         unsigned x = tc_h[tt] & 7u, y = qc[qq] & 7u;
@@ -563,7 +609,6 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 c.dmin = dmin; c.dmax = dmax;
                 if (tt != c.t_hi || qq != c.q_hi) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
             }
-            a0 = a1;
         }
     }
     st.t_gapped = now_s() - t_g0;

@@ -5,8 +5,13 @@
 
 namespace mb {
 
+struct Workspace;
+Workspace *workspace_create();
+void workspace_destroy(Workspace *w);
+
 struct Ctx {
     int device = 0;
+    Workspace *ws = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
 };

@@ -1,6 +1,6 @@
 """first GPU bring-up: product vs oracle on a few synthetic pairs"""
-import sys, time, json
-sys.path.insert(0, '.')
+import sys, time, json, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cactus_amd import gen, miblast
 from oracle import olz
 

@@ -48,15 +48,16 @@ def test_seed_index_matches_oracle(gpu_ctx, olz, step):
 
 
 def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
-    """Speculative batch size and seed-hit batch capacity must not change a single byte."""
+    """Speculation policy (batch size, spatial thinning), seed-hit batch capacity and trace-arena size (forces the
+    grow-and-retry path) must not change a single byte."""
     from cases import pair, DEFAULT
     tf, qf = pair(60000, 33)
     pm = _params(DEFAULT)
     T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
     base = gpu_ctx.align(T, Q, pm)
     assert base.paf.count(b"\n") >= 3
-    for env in ({"MIBLAST_GAPPED_BATCH0": "1", "MIBLAST_GAPPED_BATCH_MAX": "1"}, {"MIBLAST_GAPPED_BATCH0": "1000"},
-                {"MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_TRACE_BUDGET_MB": "1"}):
+    for env in ({"MIBLAST_GAPPED_BATCH_MAX": "1"}, {"MIBLAST_SHADOW_Q": "0", "MIBLAST_SHADOW_D": "0"},
+                {"MIBLAST_SHADOW_Q": "100000000"}, {"MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_ARENA_MB": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         again = gpu_ctx.align(T, Q, pm)
