@@ -32,7 +32,7 @@ struct DpProb {                               // one one-sided Y-drop DP (SURVEY
     int32_t strand;                           // selects the query code array
     int32_t pad0, pad1;
     uint64_t row_off;                         // index of this side's first row-chunk directory entry
-    uint64_t ops_off;                         // traceback: byte offset of this side's op string
+    uint64_t ops_off;                         // traceback: index of this side's first run-length op (u32)
 };
 
 struct DpOut {
@@ -99,7 +99,7 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
                   const uint8_t *qr, int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s);
 void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
-                      const unsigned long long *rowdir, uint8_t *ops, hipStream_t s);
+                      const unsigned long long *rowdir, uint32_t *ops, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int end_bit,
                hipStream_t s);

@@ -657,76 +657,79 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// traceback: one wave per DP side.  The walk itself is wave-uniform (state in SGPRs); the memory latency is
-// taken off the chain by fetching, for 64 rows at a time, each row's (offset, LY) record and the 8 trace
-// bytes around the column a gap-free path would visit (lane l <-> row i-l, columns j-l-3 .. j-l+4).
-// Ops are emitted one byte per alignment column in walk-back order (0 pair, 2 query-only, 3 target-only),
-// 64 at a time.
+// traceback: one wave per DP side.  Memory latency is taken off the chain by fetching, for 64 rows at a time,
+// each row's (offset, LY) record and the 8 trace bytes around the column a gap-free path would visit (lane l
+// <-> row i-l, columns j-l-3 .. j-l+4).  Inside a block, whole runs of diagonal steps are recognised with one
+// ballot (all lanes test "src == diag" at the current drift); only gap cells are stepped one at a time.
+// Output: run-length ops (len << 2 | op) in walk-back order; op 0 aligned pair, 2 query-only, 3 target-only.
 __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ probs, DpOut *__restrict__ outs,
                                                   const int *__restrict__ which, int n, const uint8_t *__restrict__ arena,
-                                                  const unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ ops) {
+                                                  const unsigned long long *__restrict__ rowdir, uint32_t *__restrict__ ops) {
     const int slot = blockIdx.x;
     if (slot >= n) return;
     const int pi = which[slot];
     const DpProb pr = probs[pi];
     const int lane = threadIdx.x & 63;
-    int i = outs[pi].bi, j = outs[pi].bj, state = 0;
-    uint8_t *o = ops + pr.ops_off;
-    int n_ops = 0;
-    unsigned opbuf = 0;
+    int i = uni(outs[pi].bi), j = uni(outs[pi].bj), state = 0;
+    uint32_t *o = ops + pr.ops_off;
+    int n_runs = 0, cur_op = -1, cur_len = 0;
+    auto emit = [&](int op, int len) {
+        if (op == cur_op) cur_len += len;
+        else {
+            if (cur_len > 0 && lane == 0) o[n_runs] = ((uint32_t)cur_len << 2) | (uint32_t)cur_op;
+            n_runs += cur_len > 0 ? 1 : 0;
+            cur_op = op; cur_len = len;
+        }
+    };
     while (i > 0 || j > 0) {
         // fetch block: rows i .. i-63
+        i = uni(i); j = uni(j);
         const int i0 = i, j0 = j;
         const int r = i0 - lane;
-        unsigned long long win = 0; int wly = 0, wc0 = 0;
+        unsigned long long win = 0;
         if (r >= 0) {
             const RowInfo ri = ((const RowInfo *)(arena + rowdir[pr.row_off + (unsigned)(r / kRowChunk)]))[r & (kRowChunk - 1)];
-            wly = (int)ri.ly;
-            wc0 = j0 - lane - 3;                               // column of byte 0 of the window
+            const int wly = (int)ri.ly;
+            const int wc0 = j0 - lane - 3;                     // column of byte 0 of the window
             const uint8_t *rowp = arena + ri.off;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int c = wc0 + k;
-                unsigned b = 0;
-                if (c >= wly) b = rowp[c - wly];              // bytes right of the stored row are never consulted
+                unsigned b = 0xFFu;                             // never a diagonal source: stops runs left of the row
+                if (c >= wly) b = rowp[c - wly];               // bytes right of the stored row are never consulted
                 win |= (unsigned long long)b << (8 * k);
             }
-        }
-        const unsigned wlo = (unsigned)win, whi = (unsigned)(win >> 32);
-        // uniform walk inside the block
-        while (i > 0 || j > 0) {
-            const int l = i0 - i;
-            if (l >= 64) break;
-            const int c0 = j0 - l - 3;
-            const int k = j - c0;
+        } else win = ~0ull;
+        int l = 0;
+        while ((i > 0 || j > 0) && l < 64) {
+            i = uni(i); j = uni(j); state = uni(state); l = uni(l);
+            const int k = j - (j0 - l - 3);                    // byte of the window that holds column j of row i
             if (k < 0 || k >= 8) break;                        // drifted out of the prefetched window: refetch
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wlo, l), hi = (unsigned)__builtin_amdgcn_readlane((int)whi, l);
-            const unsigned tb = ((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4)))) & 0xFFu;
-            int op = -1;
             if (state == 0) {
-                const unsigned src = tb & 3u;
-                if (src == 0u) { op = 0; i--; j--; }
-                else if (src == 1u) state = 1;
+                // how many consecutive rows, starting at lane l, continue diagonally at this drift?
+                const unsigned tbl = (unsigned)(win >> (8 * k)) & 0xFFu;
+                const unsigned long long stop = __ballot(lane >= l && (tbl & 3u) != 0u);
+                const int run = stop ? (int)__ffsll((long long)stop) - 1 - l : 64 - l;
+                if (run > 0) { emit(0, run); i -= run; j -= run; l += run; continue; }
+                const unsigned src = (unsigned)__builtin_amdgcn_readlane((int)tbl, l) & 3u;
+                if (src == 1u) state = 1;
                 else if (src == 2u) state = 2;
                 else { i = 0; j = 0; }
-            } else if (state == 1) {
-                op = 2; if (!(tb & 4u)) state = 0; i--;
             } else {
-                op = 3; if (!(tb & 8u)) state = 0; j--;
-            }
-            if (op >= 0) {
-                if (lane == (n_ops & 63)) opbuf = (unsigned)op;
-                n_ops++;
-                if ((n_ops & 63) == 0) o[n_ops - 64 + lane] = (uint8_t)opbuf;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)win, l);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(win >> 32), l);
+                const unsigned tb = ((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4)))) & 0xFFu;
+                if (state == 1) { emit(2, 1); if (!(tb & 4u)) state = 0; i--; l++; }
+                else { emit(3, 1); if (!(tb & 8u)) state = 0; j--; }
             }
         }
     }
-    if ((n_ops & 63) && lane < (n_ops & 63)) o[(n_ops & ~63) + lane] = (uint8_t)opbuf;
-    if (lane == 0) outs[pi].n_ops = n_ops;
+    emit(-2, 0);                                                // flush the last run
+    if (lane == 0) outs[pi].n_ops = n_runs;
 }
 
 void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
-                      const unsigned long long *rowdir, uint8_t *ops, hipStream_t s) {
+                      const unsigned long long *rowdir, uint32_t *ops, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, probs, outs, which, n, arena, rowdir, ops);
 }

@@ -153,7 +153,7 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<uint8_t> arena;
     DevBuf<unsigned long long> arena_next;
     DevBuf<unsigned long long> rowdir;
-    DevBuf<uint8_t> ops;
+    DevBuf<uint32_t> ops;
     DevBuf<int> which;
 };
 
@@ -566,7 +566,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 for (int side = 0; side < 2; side++) {
                     which.push_back((int)(2 * k) + side);
                     probs[2 * k + side].ops_off = ooff;
-                    ooff += (((uint64_t)outs[2 * k + side].bi + (uint64_t)outs[2 * k + side].bj) | 63u) + 1;
+                    ooff += (uint64_t)outs[2 * k + side].bi + (uint64_t)outs[2 * k + side].bj + 2;      // worst case: every column its own run
                 }
             }
             u.cache.emplace(pend[k].anchor, std::move(c));
@@ -576,34 +576,37 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
             MB_HIP(hipMemcpyAsync(g.which.p, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, s));
             launch_traceback(g.probs.p, g.outs.p, g.which.p, (int)which.size(), g.arena.p, g.rowdir.p, g.ops.p, s);
-            std::vector<uint8_t> hops((size_t)ooff + 1);
+            std::vector<uint32_t> hops((size_t)ooff + 1);
             MB_HIP(hipMemcpyAsync(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost, s));
-            MB_HIP(hipMemcpyAsync(hops.data(), g.ops.p, (size_t)ooff, hipMemcpyDeviceToHost, s));
+            MB_HIP(hipMemcpyAsync(hops.data(), g.ops.p, (size_t)ooff * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
             // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
             // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
             for (size_t k : acc) {
                 Unit &u = units[pend[k].unit];
                 Cached &c = u.cache[pend[k].anchor];
-                const uint8_t *Rops = hops.data() + probs[2 * k].ops_off, *Lops = hops.data() + probs[2 * k + 1].ops_off;
+                const uint32_t *Rops = hops.data() + probs[2 * k].ops_off, *Lops = hops.data() + probs[2 * k + 1].ops_off;
                 const size_t nR = (size_t)outs[2 * k].n_ops, nL = (size_t)outs[2 * k + 1].n_ops;
                 const uint8_t *qc = qc_h[u.strand];
                 int64_t tt = c.t_lo, qq = c.q_lo;
                 int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
                 uint32_t cur_op = 0, cur_len = 0;
-                for (size_t col = 0; col < nL + nR; col++) {
-                    uint8_t o = col < nL ? Lops[col] : Rops[nR - 1 - (col - nL)];
-                    uint32_t op;
+                auto push = [&](uint32_t op, uint32_t len) {
+                    if (cur_len && op == cur_op) cur_len += len;
+                    else { if (cur_len) c.ops.push_back((cur_len << 2) | cur_op); cur_op = op; cur_len = len; }
+                };
+                for (size_t run = 0; run < nL + nR; run++) {
+                    const uint32_t e = run < nL ? Lops[run] : Rops[nR - 1 - (run - nL)];
+                    const uint32_t o = e & 3u, len = e >> 2;
                     if (o == 0) {
-                        unsigned x = tc_h[tt] & 7u, y = qc[qq] & 7u;
-                        op = (x < 4u && x == y) ? 0u : 1u;
-                        int32_t d = (int32_t)(tt - qq);
+                        const int32_t d = (int32_t)(tt - qq);
                         dmin = std::min(dmin, d); dmax = std::max(dmax, d);
-                        tt++; qq++;
-                    } else if (o == 2) { op = 2; qq++; }
-                    else { op = 3; tt++; }
-                    if (cur_len && op == cur_op) cur_len++;
-                    else { if (cur_len) c.ops.push_back((cur_len << 2) | cur_op); cur_op = op; cur_len = 1; }
+                        for (uint32_t m = 0; m < len; m++, tt++, qq++) {
+                            unsigned x = tc_h[tt] & 7u, y = qc[qq] & 7u;
+                            push((x < 4u && x == y) ? 0u : 1u, 1);
+                        }
+                    } else if (o == 2) { push(2, len); qq += len; }
+                    else { push(3, len); tt += len; }
                 }
                 if (cur_len) c.ops.push_back((cur_len << 2) | cur_op);
                 c.dmin = dmin; c.dmax = dmax;
