@@ -17,6 +17,7 @@ constexpr int kSeedWeight = 12;
 constexpr uint32_t kBuckets = 1u << 24;
 constexpr uint8_t kSep = 0xFF;                // contig separator in code arrays
 constexpr int32_t kNeg = -(1 << 29);
+constexpr int kDevPad = 16;                   // separator bytes around device code arrays (8-byte loads may overrun)
 
 // ---- device-side records ---------------------------------------------------------------------
 struct DevHsp {                               // written by k_ungapped for every HSP with score >= K
@@ -55,11 +56,11 @@ struct SeqSet {
     int64_t total = 0;                        // concatenated length (one separator between contigs)
     std::vector<uint8_t> codes;               // [SEP] codes[0..total) [SEP]  -> codes.data()+1 is position 0
     int device = -1;
-    uint8_t *d_buf = nullptr;                 // device copy of `codes` (same padding)
+    uint8_t *d_buf = nullptr;                 // device copy of `codes`, kDevPad separator bytes on both sides
     int64_t *d_starts = nullptr;              // contig starts / lens on the device (revcomp kernel)
     int64_t *d_lens = nullptr;
     const uint8_t *host() const { return codes.data() + 1; }
-    const uint8_t *dev() const { return d_buf + 1; }
+    const uint8_t *dev() const { return d_buf + kDevPad; }
     int contig_of(int64_t pos) const;
 };
 

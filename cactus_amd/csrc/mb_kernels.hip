@@ -11,6 +11,7 @@
 // (see DESIGN.md "Why the row sweep is exact").
 #include "mb_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -266,74 +267,96 @@ void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned l
 // ungapped x-drop extension with exact per-diagonal suppression (A.4, A.5).
 // keys are sorted by (diagonal, q_end); the thread owning the first hit of a diagonal run walks
 // the run in q order carrying extent[d], exactly the sequential rule "skip iff q_end <= extent[d]".
-__global__ void k_ungapped(const unsigned long long *__restrict__ keys, int64_t n_hits, const uint8_t *__restrict__ tc,
-                           const uint8_t *__restrict__ qc, int64_t qtot, int32_t *__restrict__ extent, int xdrop, int K,
-                           DevHsp *__restrict__ hsps, int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ unsigned long long load8(const uint8_t *p) {
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);                       // unaligned global_load_dwordx2
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__restrict__ keys, int64_t n_hits,
+                                                  const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, int64_t qtot,
+                                                  int32_t *__restrict__ extent, int xdrop, int K, DevHsp *__restrict__ hsps,
+                                                  int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     unsigned long long n_ext = 0, n_cols = 0;
-    if (i < n_hits) {
+    // grid-stride over hits: counters stay in registers and cost one atomic per resident wave, not per 64 hits
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += (int64_t)gridDim.x * blockDim.x) {
         unsigned long long key = keys[i];
-        uint32_t dq = (uint32_t)(key >> 32);
-        bool head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != dq);
-        if (head) {
-            int32_t ext = extent[dq];
-            int64_t k = i;
-            while (true) {
-                int32_t q_end = (int32_t)(uint32_t)key;
-                if (q_end > ext) {
-                    int64_t t_end = (int64_t)dq - qtot + q_end;
-                    // left: covers the seed, then beyond; separators (0xFF) bound every contig on both sides
-                    int run = 0, bestL = 0, bl = 0;
-                    for (int kk = 1;; kk++) {
-                        unsigned a = tc[t_end - kk], b = qc[q_end - kk];
-                        if (a == kSep || b == kSep) break;
-                        run += sub_score(a, b);
-                        n_cols++;
-                        if (run > bestL) { bestL = run; bl = kk; }
-                        else if (run < bestL - xdrop) break;
-                    }
-                    run = 0;
-                    int bestR = 0, br = 0;
-                    for (int kk = 0;; kk++) {
-                        unsigned a = tc[t_end + kk], b = qc[q_end + kk];
-                        if (a == kSep || b == kSep) break;
-                        run += sub_score(a, b);
-                        n_cols++;
-                        if (run > bestR) { bestR = run; br = kk + 1; }
-                        else if (run < bestR - xdrop) break;
-                    }
-                    n_ext++;
-                    ext = q_end + br;
-                    int score = bestL + bestR;
-                    if (score >= K) {
-                        unsigned long long slot = atomicAdd(&ctr->hsps, 1ull);
-                        if ((int64_t)slot < hsp_cap) {
-                            DevHsp h;
-                            h.t_start = (int32_t)(t_end - bl);
-                            h.q_start = q_end - bl;
-                            h.len = bl + br;
-                            h.score = score;
-                            h.seed_t_end = (int32_t)t_end;
-                            h.seed_q_end = q_end;
-                            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                            for (int kk = 0; kk < h.len; kk++) {
-                                unsigned a = tc[h.t_start + kk] & 7u, b = qc[h.q_start + kk] & 7u;
-                                if (a == b) { c0 += (a == 0u); c1 += (a == 1u); c2 += (a == 2u); c3 += (a == 3u); }
-                            }
-                            h.cnt[0] = c0; h.cnt[1] = c1; h.cnt[2] = c2; h.cnt[3] = c3;
-                            hsps[slot] = h;
+        const uint32_t dq = (uint32_t)(key >> 32);
+        const bool head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != dq);
+        if (!head) continue;
+        int32_t ext = extent[dq];
+        int64_t k = i;
+        while (true) {
+            const int32_t q_end = (int32_t)(uint32_t)key;
+            if (q_end > ext) {
+                const int64_t t_end = (int64_t)dq - qtot + q_end;
+                // Both directions read 8 bases per (unaligned) 64-bit load: a lane walks its own diagonal, so a
+                // byte load per column would make the L1 tag pipeline (one lane per clock) the bottleneck.
+                // Separators (0xFF) bound every contig on both sides; buffers carry 16 pad bytes.
+                int run = 0, bestL = 0, bl = 0;
+                {
+                    bool stop = false;
+                    for (int c = 0; !stop; c++) {                          // left: covers the seed, then beyond
+                        const unsigned long long a8 = load8(tc + t_end - 8 * (c + 1)), b8 = load8(qc + q_end - 8 * (c + 1));
+#pragma unroll
+                        for (int m = 7; m >= 0; m--) {
+                            const unsigned a = (unsigned)(a8 >> (8 * m)) & 0xFFu, b = (unsigned)(b8 >> (8 * m)) & 0xFFu;
+                            if (a == kSep || b == kSep) { stop = true; break; }
+                            run += sub_score(a, b);
+                            n_cols++;
+                            const int kk = 8 * c + (8 - m);
+                            if (run > bestL) { bestL = run; bl = kk; }
+                            else if (run < bestL - xdrop) { stop = true; break; }
                         }
                     }
                 }
-                k++;
-                if (k >= n_hits) break;
-                key = keys[k];
-                if ((uint32_t)(key >> 32) != dq) break;
+                run = 0;
+                int bestR = 0, br = 0;
+                {
+                    bool stop = false;
+                    for (int c = 0; !stop; c++) {
+                        const unsigned long long a8 = load8(tc + t_end + 8 * c), b8 = load8(qc + q_end + 8 * c);
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            const unsigned a = (unsigned)(a8 >> (8 * m)) & 0xFFu, b = (unsigned)(b8 >> (8 * m)) & 0xFFu;
+                            if (a == kSep || b == kSep) { stop = true; break; }
+                            run += sub_score(a, b);
+                            n_cols++;
+                            if (run > bestR) { bestR = run; br = 8 * c + m + 1; }
+                            else if (run < bestR - xdrop) { stop = true; break; }
+                        }
+                    }
+                }
+                n_ext++;
+                ext = q_end + br;
+                const int score = bestL + bestR;
+                if (score >= K) {
+                    const unsigned long long slot = atomicAdd(&ctr->hsps, 1ull);
+                    if ((int64_t)slot < hsp_cap) {
+                        DevHsp h;
+                        h.t_start = (int32_t)(t_end - bl);
+                        h.q_start = q_end - bl;
+                        h.len = bl + br;
+                        h.score = score;
+                        h.seed_t_end = (int32_t)t_end;
+                        h.seed_q_end = q_end;
+                        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                        for (int kk = 0; kk < h.len; kk++) {
+                            const unsigned a = tc[h.t_start + kk] & 7u, b = qc[h.q_start + kk] & 7u;
+                            if (a == b) { c0 += (a == 0u); c1 += (a == 1u); c2 += (a == 2u); c3 += (a == 3u); }
+                        }
+                        h.cnt[0] = c0; h.cnt[1] = c1; h.cnt[2] = c2; h.cnt[3] = c3;
+                        hsps[slot] = h;
+                    }
+                }
             }
-            extent[dq] = ext;
+            k++;
+            if (k >= n_hits) break;
+            key = keys[k];
+            if ((uint32_t)(key >> 32) != dq) break;
         }
+        extent[dq] = ext;
     }
-    // one atomic per wave for the counters
     for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_cols += __shfl_down(n_cols, o); }
     if ((threadIdx.x & 63) == 0 && (n_ext | n_cols)) { atomicAdd(&ctr->extended, n_ext); atomicAdd(&ctr->cols, n_cols); }
 }
@@ -342,7 +365,8 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, const uint8
                      int64_t qtot, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, hipStream_t s) {
     if (n_hits <= 0) return;
-    hipLaunchKernelGGL(k_ungapped, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, s, keys, n_hits, tcodes, qcodes,
+    const int64_t blocks = std::min<int64_t>((n_hits + 255) / 256, 256 * 8);     // 8 resident blocks per CU
+    hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, tcodes, qcodes,
                        qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
 }
 

@@ -114,8 +114,9 @@ long env_long(const char *name, long dflt) {
 void upload_seqset(SeqSet &s, int device) {
     MB_HIP(hipSetDevice(device));
     s.device = device;
-    MB_HIP(hipMalloc((void **)&s.d_buf, s.codes.size()));
-    MB_HIP(hipMemcpy(s.d_buf, s.codes.data(), s.codes.size(), hipMemcpyHostToDevice));
+    MB_HIP(hipMalloc((void **)&s.d_buf, (size_t)s.total + 2 * kDevPad));
+    MB_HIP(hipMemset(s.d_buf, 0xFF, (size_t)s.total + 2 * kDevPad));
+    if (s.total) MB_HIP(hipMemcpy(s.d_buf + kDevPad, s.codes.data() + 1, (size_t)s.total, hipMemcpyHostToDevice));
     size_t nc = std::max<size_t>(1, s.starts.size());
     MB_HIP(hipMalloc((void **)&s.d_starts, nc * sizeof(int64_t)));
     MB_HIP(hipMalloc((void **)&s.d_lens, nc * sizeof(int64_t)));
@@ -237,15 +238,15 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
 
     // ---- '-' strand of the query -----------------------------------------------------------------
     DevBuf<uint8_t> &d_rc = w.rc;
-    d_rc.ensure((size_t)qtot + 2);
-    MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2, s));
-    launch_revcomp(Q.dev(), d_rc.p + 1, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
+    d_rc.ensure((size_t)qtot + 2 * kDevPad);
+    MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
+    launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
     std::vector<uint8_t> h_rc((size_t)qtot + 2);
-    MB_HIP(hipMemcpyAsync(h_rc.data(), d_rc.p, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipMemcpyAsync(h_rc.data(), d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
     MB_HIP(hipStreamSynchronize(s));
     const uint8_t *tc_h = T.host();
     const uint8_t *qc_h[2] = {Q.host(), h_rc.data() + 1};
-    const uint8_t *qc_d[2] = {Q.dev(), d_rc.p + 1};
+    const uint8_t *qc_d[2] = {Q.dev(), d_rc.p + kDevPad};
 
     // ---- seed search + ungapped extension, per strand ----------------------------------------------
     const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
