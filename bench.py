@@ -91,7 +91,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    keys = ["dp_cells", "seed_hits", "seed_lookups", "ungapped_cols", "alignments", "dp_cells_run", "t_dp_kernel_ms",
+    keys = ["dp_cells", "seed_hits", "seed_lookups", "ungapped_cols", "alignments", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms",
             "dp_kernel_launches", "t_index", "t_seed", "t_gapped", "t_total", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms"]
     vec = torch.tensor([float(agg[k]) for k in keys] + [elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
     if dist is not None:
@@ -102,12 +102,25 @@ def main():
     tot = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
 
     if rank == 0:
-        cells_per_launch = tot["dp_cells_run"] / max(1.0, tot["dp_kernel_launches"])
-        # algorithmic HBM bytes of the Y-drop DP kernel (SURVEY 8d "Gapped"): <= 1 trace byte written per
-        # cell of the trace pass + 2 * 0.375 B of sequence per row/column touched; dominated by the trace.
-        # We charge 1 B per evaluated cell (upper bound of the algorithmic figure).
-        dp_ms = tot["t_dp_kernel_ms"] / max(1.0, tot["dp_kernel_launches"])
-        achieved = (cells_per_launch * 1.0) / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+        launches = max(1.0, tot["dp_kernel_launches"])
+        cells_per_launch = tot["dp_cells_run"] / launches
+        rows_per_launch = tot["dp_rows_run"] / launches
+        # Algorithmic HBM bytes of one k_ydrop launch (SURVEY 8d "Gapped"): one trace byte
+        # written per evaluated cell + one 16-byte {offset, LY} record per row + ~2 sequence bytes read per row
+        # (one query base, ~one new target column).  The launch duration is measured inside libmiblast with HIP
+        # events on its own stream.
+        algo_bytes = cells_per_launch * 1.0 + rows_per_launch * (16.0 + 2.0)
+        dp_ms = tot["t_dp_kernel_ms"] / launches
+        achieved = algo_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+        traffic, traffic_note = None, "no committed PMC summary"
+        pmc_path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+        if os.path.exists(pmc_path) and not a.random_pair and a.size == 1_000_000 and a.lastz_args == DEFAULT_ARGS:
+            k = json.load(open(pmc_path))["kernels"].get("mb::k_ydrop<false, false>")
+            if k:
+                pmc_bytes = k["fetch_bytes_corrected_per_call"] + k["write_size_bytes_per_call"]
+                traffic = pmc_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None
+                traffic_note = ("PMC bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, "
+                                "profiles/r01_hbm_traffic_pmc.json: %.1f MB) / this run's launch duration" % (pmc_bytes / 1e6))
         out = {
             "metric": "gapped X-drop Gcell/s (blast phase, whole job)",
             "value": tot["dp_cells"] / elapsed / 1e9,
@@ -128,8 +141,10 @@ def main():
             "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
             "alignments_per_step": tot["alignments"] / a.steps,
             "roofline": {"bound": "hbm", "kernel": "k_ydrop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "integer DP is VALU/LDS-latency bound, not HBM bound (SURVEY 8d caveat); see DESIGN.md"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": dp_ms, "launches_per_step": launches / a.steps / world,
+                         "traffic_note": traffic_note,
+                         "note": "the row-sweep integer DP is bound by per-row latency, not by HBM (SURVEY 8d caveat, DESIGN.md section 5)"},
         }
         if a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(a, pm)

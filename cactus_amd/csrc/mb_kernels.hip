@@ -512,13 +512,14 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
         return (r >= 1 && r <= nb) ? (unsigned)qc[dir > 0 ? q0 + r - 1 : q0 - r] : 4u;
     };
     unsigned qv = load_q(1), qnext = load_q(65);
+    const uint32_t lutv = row_score_lut((unsigned)min(lane, 4));     // lane k holds the packed score row of query base k
     const int tidE = tid * E;
     __syncthreads();
     int i = 1;
     for (; i <= nb && !overflow; i++) {
         if (PROF) pt = clock64();
         if (i - qblk0 >= 64) { qblk0 += 64; qv = qnext; qnext = load_q(qblk0 + 64); }
-        const uint32_t lut = row_score_lut((unsigned)__builtin_amdgcn_readlane((int)qv, i - qblk0));
+        const uint32_t lut = (uint32_t)__builtin_amdgcn_readlane((int)lutv, min(__builtin_amdgcn_readlane((int)qv, i - qblk0) & 7, 4));
         // the row can reach at most column RY + grow; everything it may touch must be staged and fit the ring
         const int reach = min(na, RY + grow);
         if (reach - LY + 2 * kYdThreads + 64 > cap) { overflow = 1; break; }

@@ -526,7 +526,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                     MB_HIP(hipMemcpy(g.outs.p + wide[k], &wo[k - w0], sizeof(DpOut), hipMemcpyHostToDevice));
                 }
             }
-            for (int k = 0; k < np; k++) { st.dp_sides_run++; st.dp_cells_run += outs[(size_t)k].cells; }
+            for (int k = 0; k < np; k++) { st.dp_sides_run++; st.dp_cells_run += outs[(size_t)k].cells; st.dp_rows_run += outs[(size_t)k].rows; }
             if (debug) {
                 int maxrows = 0; long long cells = 0, clk = 0;
                 for (int k = 0; k < np; k++) { if (outs[(size_t)k].rows > maxrows) { maxrows = outs[(size_t)k].rows; clk = outs[(size_t)k].cells_to_bi; } cells += outs[(size_t)k].cells; }

@@ -122,3 +122,34 @@ def fasta_bytes(records) -> bytes:
 def write_fasta(path: str, records) -> None:
     with open(path, "wb") as f:
         f.write(fasta_bytes(records))
+
+
+def make_tree_genomes(ancestor_len: int, seed: int, tree=None):
+    """Synthetic stand-in for the evolver data sets (their FASTA files are URLs,
+    /root/reference/examples/evolverMammals.txt:3-7; no network): leaves evolved from one ancestor along the
+    branch lengths of the evolverMammals guide tree (/root/reference/examples/evolverMammals.txt:1).
+    Returns {leaf_name: uint8 array}.  Per-branch substitution rate = branch length (capped), indel rate = 1/15 of it."""
+    if tree is None:
+        # ((simHuman_chr6:0.144018,(simMouse_chr6:0.084509,simRat_chr6:0.091589):0.271974):0.020593,
+        #  (simCow_chr6:0.18908,simDog_chr6:0.16303):0.032898);
+        tree = ("root", [("hmr", 0.020593, [("simHuman_chr6", 0.144018, []),
+                                            ("mr", 0.271974, [("simMouse_chr6", 0.084509, []), ("simRat_chr6", 0.091589, [])])]),
+                         ("cd", 0.032898, [("simCow_chr6", 0.18908, []), ("simDog_chr6", 0.16303, [])])])
+    rng = np.random.default_rng(seed)
+    root_seq = random_sequence(ancestor_len, rng)
+    out = {}
+
+    def walk(node_children, seq):
+        for name, blen, kids in node_children:
+            child = mutate(seq, rng, min(0.6, blen), min(0.04, blen / 15.0))
+            n = len(child)
+            if n > 2000:                                   # one inversion and one large deletion per branch
+                a = int(rng.integers(0, n - n // 20)); child[a:a + n // 20] = revcomp(child[a:a + n // 20])
+                d = int(rng.integers(0, n - n // 40)); child = np.concatenate([child[:d], child[d + n // 40:]])
+            if kids:
+                walk(kids, child)
+            else:
+                out[name] = soft_mask(child, rng, 0.15)
+
+    walk(tree[1], root_seq)
+    return out

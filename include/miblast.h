@@ -114,6 +114,7 @@ typedef struct miblast_stats {          /* counters defined by SURVEY.md section
     double  t_dp_kernel_ms;  int64_t dp_kernel_launches;     /* HIP-event time of k_ydrop launches  */
     double  t_ungapped_kernel_ms; int64_t ungapped_kernel_launches;
     double  t_sort_ms, t_seedfill_ms;
+    int64_t dp_rows_run;                    /* DP rows evaluated incl. speculative work                */
 } miblast_stats;
 
 typedef struct miblast_result miblast_result;

@@ -151,3 +151,29 @@ def test_run_lastz_job_interface(gpu_ctx, olz, tmp_path, monkeypatch):
                 monkeypatch.setenv("MIBLAST_INPROCESS", inproc)
                 fid = run_lastz(job, "A_0", FileID.of(str(a)), "B_0", FileID.of(str(b)), distance, cfg)
                 assert open(str(fid), "rb").read() == want, (gpu, distance, inproc)
+
+
+def test_evolver_like_blast_phase_cigar_diff(gpu_ctx, olz):
+    """BASELINE config 3 stand-in (evolverMammals is a set of URLs): five leaves evolved on the evolverMammals guide
+    tree from a 120 kb ancestor; every ingroup pair is run through the job interface's parameter selection (mouse-rat
+    at distance 0.176 -> set "four", the others -> "default") and the PAF is diffed byte-for-byte against the oracle."""
+    from cactus_amd import gen, miblast
+    from cactus_amd.paf.local_alignment import select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    leaves = gen.make_tree_genomes(120_000, 2001)
+    fa = {k: gen.fasta_bytes([("id=%s|%s" % (k, k), v)]) for k, v in leaves.items()}
+    sets = {k: gpu_ctx.seqset_from_fasta_bytes(v) for k, v in fa.items()}
+    pairs = [("simMouse_chr6", "simRat_chr6", 0.176098), ("simHuman_chr6", "simMouse_chr6", 0.500501),
+             ("simCow_chr6", "simDog_chr6", 0.35211), ("simHuman_chr6", "simDog_chr6", 0.360539),
+             ("simRat_chr6", "simCow_chr6", 0.606134)]
+    total = 0
+    for a, b, dist in pairs:
+        args = select_lastz_params(dist, cfg, 0).split(" ")
+        pm = miblast.params_from_args(args)
+        got = gpu_ctx.align(sets[a], sets[b], pm, details=False)
+        want = olz.align(fa[a], fa[b], olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}), details=False)
+        assert got.paf == want["paf"], (a, b)
+        assert got.stats["dp_cells"] == want["counters"]["dp_cells"] and got.stats["seed_hits"] == want["counters"]["seed_hits"]
+        total += got.paf.count(b"\n")
+    assert total >= 2 * len(pairs)
