@@ -273,80 +273,96 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *p) {
     return v;
 }
 
+// Heads of the diagonal runs of the sorted hit keys, compacted so that the extension kernel gets one run per lane
+// (hit counts per diagonal vary with the batch geometry; without this most lanes of k_ungapped would idle).
+// One atomic per 1024-key block; the order of the head list is irrelevant (runs are independent).
+__global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits,
+                                                    unsigned *__restrict__ heads, unsigned *__restrict__ n_heads) {
+    __shared__ unsigned wave_cnt[16];
+    __shared__ unsigned block_base;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool head = false;
+    if (i < n_hits) head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != (uint32_t)(keys[i] >> 32));
+    const unsigned long long m = __ballot(head);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[w] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int k = 0; k < 16; k++) { unsigned c = wave_cnt[k]; wave_cnt[k] = tot; tot += c; }
+        block_base = tot ? atomicAdd(n_heads, tot) : 0u;
+    }
+    __syncthreads();
+    if (head) heads[block_base + wave_cnt[w] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+}
+
+// one x-drop direction, 8 columns per load, branch-free inside a chunk (every per-lane condition is a select)
+template <int DIR>
+__device__ __forceinline__ void xdrop_dir(const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp, const int xdrop,
+                                          int &best_out, int &pos_out, unsigned long long &ncols) {
+    int run = 0, best = 0, bpos = 0;
+    bool live = true;
+    for (int c = 0; live; c++) {
+        const unsigned long long a8 = DIR > 0 ? load8(tp + 8 * c) : load8(tp - 8 * (c + 1));
+        const unsigned long long b8 = DIR > 0 ? load8(qp + 8 * c) : load8(qp - 8 * (c + 1));
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int sh = DIR > 0 ? 8 * m : 8 * (7 - m);
+            const unsigned a = (unsigned)(a8 >> sh) & 0xFFu, b = (unsigned)(b8 >> sh) & 0xFFu;
+            live = live & (a != kSep) & (b != kSep);
+            run = live ? run + sub_score(a, b) : run;
+            ncols += live ? 1u : 0u;
+            const bool upd = live & (run > best);
+            best = upd ? run : best;
+            bpos = upd ? 8 * c + m + 1 : bpos;
+            live = live & (upd | (run >= best - xdrop));
+        }
+    }
+    best_out = best; pos_out = bpos;
+}
+
 __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__restrict__ keys, int64_t n_hits,
+                                                  const unsigned *__restrict__ heads, const unsigned *__restrict__ n_heads_p,
                                                   const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, int64_t qtot,
                                                   int32_t *__restrict__ extent, int xdrop, int K, DevHsp *__restrict__ hsps,
                                                   int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     unsigned long long n_ext = 0, n_cols = 0;
-    // grid-stride over hits: counters stay in registers and cost one atomic per resident wave, not per 64 hits
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += (int64_t)gridDim.x * blockDim.x) {
-        unsigned long long key = keys[i];
+    const unsigned n_heads = *n_heads_p;
+    // grid-stride over diagonal runs: counters stay in registers and cost one atomic per resident wave
+    for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heads; h += gridDim.x * blockDim.x) {
+        int64_t k = heads[h];
+        unsigned long long key = keys[k];
         const uint32_t dq = (uint32_t)(key >> 32);
-        const bool head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != dq);
-        if (!head) continue;
         int32_t ext = extent[dq];
-        int64_t k = i;
         while (true) {
             const int32_t q_end = (int32_t)(uint32_t)key;
             if (q_end > ext) {
                 const int64_t t_end = (int64_t)dq - qtot + q_end;
-                // Both directions read 8 bases per (unaligned) 64-bit load: a lane walks its own diagonal, so a
-                // byte load per column would make the L1 tag pipeline (one lane per clock) the bottleneck.
-                // Separators (0xFF) bound every contig on both sides; buffers carry 16 pad bytes.
-                int run = 0, bestL = 0, bl = 0;
-                {
-                    bool stop = false;
-                    for (int c = 0; !stop; c++) {                          // left: covers the seed, then beyond
-                        const unsigned long long a8 = load8(tc + t_end - 8 * (c + 1)), b8 = load8(qc + q_end - 8 * (c + 1));
-#pragma unroll
-                        for (int m = 7; m >= 0; m--) {
-                            const unsigned a = (unsigned)(a8 >> (8 * m)) & 0xFFu, b = (unsigned)(b8 >> (8 * m)) & 0xFFu;
-                            if (a == kSep || b == kSep) { stop = true; break; }
-                            run += sub_score(a, b);
-                            n_cols++;
-                            const int kk = 8 * c + (8 - m);
-                            if (run > bestL) { bestL = run; bl = kk; }
-                            else if (run < bestL - xdrop) { stop = true; break; }
-                        }
-                    }
-                }
-                run = 0;
-                int bestR = 0, br = 0;
-                {
-                    bool stop = false;
-                    for (int c = 0; !stop; c++) {
-                        const unsigned long long a8 = load8(tc + t_end + 8 * c), b8 = load8(qc + q_end + 8 * c);
-#pragma unroll
-                        for (int m = 0; m < 8; m++) {
-                            const unsigned a = (unsigned)(a8 >> (8 * m)) & 0xFFu, b = (unsigned)(b8 >> (8 * m)) & 0xFFu;
-                            if (a == kSep || b == kSep) { stop = true; break; }
-                            run += sub_score(a, b);
-                            n_cols++;
-                            if (run > bestR) { bestR = run; br = 8 * c + m + 1; }
-                            else if (run < bestR - xdrop) { stop = true; break; }
-                        }
-                    }
-                }
+                // Separators (0xFF) bound every contig on both sides; device buffers carry 16 pad bytes, so the
+                // 8-byte loads may overrun harmlessly.  Left covers the seed, then beyond; right starts at the seed end.
+                int bestL, bl, bestR, br;
+                xdrop_dir<-1>(tc + t_end, qc + q_end, xdrop, bestL, bl, n_cols);
+                xdrop_dir<+1>(tc + t_end, qc + q_end, xdrop, bestR, br, n_cols);
                 n_ext++;
                 ext = q_end + br;
                 const int score = bestL + bestR;
                 if (score >= K) {
                     const unsigned long long slot = atomicAdd(&ctr->hsps, 1ull);
                     if ((int64_t)slot < hsp_cap) {
-                        DevHsp h;
-                        h.t_start = (int32_t)(t_end - bl);
-                        h.q_start = q_end - bl;
-                        h.len = bl + br;
-                        h.score = score;
-                        h.seed_t_end = (int32_t)t_end;
-                        h.seed_q_end = q_end;
+                        DevHsp hs;
+                        hs.t_start = (int32_t)(t_end - bl);
+                        hs.q_start = q_end - bl;
+                        hs.len = bl + br;
+                        hs.score = score;
+                        hs.seed_t_end = (int32_t)t_end;
+                        hs.seed_q_end = q_end;
                         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                        for (int kk = 0; kk < h.len; kk++) {
-                            const unsigned a = tc[h.t_start + kk] & 7u, b = qc[h.q_start + kk] & 7u;
+                        for (int kk = 0; kk < hs.len; kk++) {
+                            const unsigned a = tc[hs.t_start + kk] & 7u, b = qc[hs.q_start + kk] & 7u;
                             if (a == b) { c0 += (a == 0u); c1 += (a == 1u); c2 += (a == 2u); c3 += (a == 3u); }
                         }
-                        h.cnt[0] = c0; h.cnt[1] = c1; h.cnt[2] = c2; h.cnt[3] = c3;
-                        hsps[slot] = h;
+                        hs.cnt[0] = c0; hs.cnt[1] = c1; hs.cnt[2] = c2; hs.cnt[3] = c3;
+                        hsps[slot] = hs;
                     }
                 }
             }
@@ -361,12 +377,14 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
     if ((threadIdx.x & 63) == 0 && (n_ext | n_cols)) { atomicAdd(&ctr->extended, n_ext); atomicAdd(&ctr->cols, n_cols); }
 }
 
-void launch_ungapped(const unsigned long long *keys, int64_t n_hits, const uint8_t *tcodes, const uint8_t *qcodes,
-                     int64_t qtot, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
+void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
+                     const uint8_t *qcodes, int64_t qtot, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, hipStream_t s) {
     if (n_hits <= 0) return;
+    (void)hipMemsetAsync(n_heads, 0, sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, heads, n_heads);
     const int64_t blocks = std::min<int64_t>((n_hits + 255) / 256, 256 * 8);     // 8 resident blocks per CU
-    hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, tcodes, qcodes,
+    hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
                        qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
 }
 

@@ -147,6 +147,7 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<char> sort_temp;
     DevBuf<DevHsp> hsps;
     DevBuf<UngappedCounters> ctr;
+    DevBuf<unsigned> heads, n_heads;
     // gapped
     DevBuf<DpProb> probs;
     DevBuf<DpOut> outs;
@@ -288,6 +289,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             hit_off.ensure((size_t)(q1 - q0));
             keys_a.ensure((size_t)nh); keys_b.ensure((size_t)nh);
             d_hsps.ensure((size_t)nh);
+            w.heads.ensure((size_t)nh); w.n_heads.ensure(1);
             size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev0, s));
@@ -298,7 +300,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
-            launch_ungapped(keys_b.p, (int64_t)nh, T.dev(), qc_d[strand], qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
+            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, s);
             MB_HIP(hipEventRecord(ctx.ev4, s));
             UngappedCounters hc;
