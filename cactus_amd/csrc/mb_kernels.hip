@@ -724,14 +724,24 @@ __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ pro
             cur_op = op; cur_len = len;
         }
     };
+    // row records of the NEXT block are requested while the current block is walked (they do not depend on the walk)
+    auto load_ri = [&](int r) -> RowInfo {
+        RowInfo ri; ri.off = 0; ri.ly = 0; ri.pad = 0;
+        if (r >= 0) ri = ((const RowInfo *)(arena + rowdir[pr.row_off + (unsigned)(r / kRowChunk)]))[r & (kRowChunk - 1)];
+        return ri;
+    };
+    int pre_i0 = i;
+    RowInfo ri_pre = load_ri(i - lane);
     while (i > 0 || j > 0) {
         // fetch block: rows i .. i-63
         i = uni(i); j = uni(j);
         const int i0 = i, j0 = j;
         const int r = i0 - lane;
+        const RowInfo ri = (i0 == pre_i0) ? ri_pre : load_ri(r);
+        pre_i0 = i0 - 64;
+        ri_pre = load_ri(pre_i0 - lane);
         unsigned long long win = 0;
         if (r >= 0) {
-            const RowInfo ri = ((const RowInfo *)(arena + rowdir[pr.row_off + (unsigned)(r / kRowChunk)]))[r & (kRowChunk - 1)];
             const int wly = (int)ri.ly;
             const int wc0 = j0 - lane - 3;                     // column of byte 0 of the window
             const uint8_t *rowp = arena + ri.off;

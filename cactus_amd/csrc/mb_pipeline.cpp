@@ -574,6 +574,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             }
             u.cache.emplace(pend[k].anchor, std::move(c));
         }
+        const double t_tb0 = now_s();
         if (!acc.empty()) {
             g.which.ensure(which.size()); g.ops.ensure((size_t)ooff + 64);
             MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
@@ -581,8 +582,14 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             launch_traceback(g.probs.p, g.outs.p, g.which.p, (int)which.size(), g.arena.p, g.rowdir.p, g.ops.p, s);
             std::vector<uint32_t> hops((size_t)ooff + 1);
             MB_HIP(hipMemcpyAsync(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost, s));
-            MB_HIP(hipMemcpyAsync(hops.data(), g.ops.p, (size_t)ooff * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
+            for (int pidx : which) {                       // only the run slots each side actually used
+                const size_t nrun = (size_t)outs[(size_t)pidx].n_ops;
+                if (nrun) MB_HIP(hipMemcpyAsync(hops.data() + probs[(size_t)pidx].ops_off, g.ops.p + probs[(size_t)pidx].ops_off, nrun * 4, hipMemcpyDeviceToHost, s));
+            }
+            MB_HIP(hipStreamSynchronize(s));
+            if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, which.size(), (unsigned long long)ooff);
+            const double t_mg0 = now_s();
             // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
             // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
             for (size_t k : acc) {
@@ -615,6 +622,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 c.dmin = dmin; c.dmax = dmax;
                 if (tt != c.t_hi || qq != c.q_hi) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
             }
+            if (debug) fprintf(stderr, "[miblast]   host merge: %.2f ms\n", (now_s() - t_mg0) * 1e3);
         }
     }
     st.t_gapped = now_s() - t_g0;
@@ -632,7 +640,19 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 }
             }
     st.alignments = (int64_t)res.alns.size();
-    char line[640];
+    const double t_out0 = now_s();
+    {
+        size_t reserve = 0;
+        for (const miblast_aln &A : res.alns) reserve += 256 + Q.names[(size_t)A.q_contig].size() + T.names[(size_t)A.t_contig].size() + (size_t)A.n_ops * 9;
+        res.paf.reserve(reserve);
+    }
+    auto put_num = [&](long long v) {                   // decimal formatting without snprintf (hundreds of thousands of cigar ops)
+        char buf[24]; int n = 0;
+        unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+        do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) buf[n++] = '-';
+        while (n) res.paf.push_back(buf[--n]);
+    };
     for (const miblast_aln &A : res.alns) {
         int64_t qst = Q.starts[(size_t)A.q_contig], qlen = Q.lens[(size_t)A.q_contig];
         int64_t tst = T.starts[(size_t)A.t_contig], tlen = T.lens[(size_t)A.t_contig];
@@ -644,25 +664,22 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             alen += o >> 2;
             if ((o & 3u) == 0) nmatch += o >> 2;
         }
-        int n = snprintf(line, sizeof line, "%s\t%lld\t%lld\t%lld\t%c\t%s\t%lld\t%lld\t%lld\t%lld\t%lld\t255\tAS:i:%d\tcg:Z:",
-                         Q.names[(size_t)A.q_contig].c_str(), (long long)qlen, (long long)qs, (long long)qe, A.strand ? '-' : '+',
-                         T.names[(size_t)A.t_contig].c_str(), (long long)tlen, (long long)(A.t_lo - tst), (long long)(A.t_hi - tst),
-                         (long long)nmatch, (long long)alen, A.score);
-        if (n >= (int)sizeof line) {             // very long names: format in a string instead
-            std::string big((size_t)n + 1, '\0');
-            snprintf(&big[0], big.size(), "%s\t%lld\t%lld\t%lld\t%c\t%s\t%lld\t%lld\t%lld\t%lld\t%lld\t255\tAS:i:%d\tcg:Z:",
-                     Q.names[(size_t)A.q_contig].c_str(), (long long)qlen, (long long)qs, (long long)qe, A.strand ? '-' : '+',
-                     T.names[(size_t)A.t_contig].c_str(), (long long)tlen, (long long)(A.t_lo - tst), (long long)(A.t_hi - tst),
-                     (long long)nmatch, (long long)alen, A.score);
-            res.paf.append(big.c_str(), (size_t)n);
-        } else res.paf.append(line, (size_t)n);
+        // qname qlen qstart qend strand tname tlen tstart tend nmatch alnlen 255 AS:i:<score> cg:Z:<cigar>  
+        res.paf += Q.names[(size_t)A.q_contig]; res.paf.push_back('\t');
+        put_num(qlen); res.paf.push_back('\t'); put_num(qs); res.paf.push_back('\t'); put_num(qe); res.paf.push_back('\t');
+        res.paf.push_back(A.strand ? '-' : '+'); res.paf.push_back('\t');
+        res.paf += T.names[(size_t)A.t_contig]; res.paf.push_back('\t');
+        put_num(tlen); res.paf.push_back('\t'); put_num(A.t_lo - tst); res.paf.push_back('\t'); put_num(A.t_hi - tst); res.paf.push_back('\t');
+        put_num(nmatch); res.paf.push_back('\t'); put_num(alen);
+        res.paf += "\t255\tAS:i:"; put_num(A.score); res.paf += "\tcg:Z:";
         for (int64_t k = 0; k < A.n_ops; k++) {
             uint32_t o = res.ops[(size_t)(A.ops_off + k)];
-            n = snprintf(line, sizeof line, "%u%c", o >> 2, "=XID"[o & 3u]);
-            res.paf.append(line, (size_t)n);
+            put_num(o >> 2);
+            res.paf.push_back("=XID"[o & 3u]);
         }
         res.paf.push_back('\n');
     }
+    if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast] PAF formatting: %.2f ms; index %.2f ms, seed %.2f ms, gapped %.2f ms\n", (now_s() - t_out0) * 1e3, st.t_index * 1e3, st.t_seed * 1e3, st.t_gapped * 1e3);
     st.t_total = now_s() - t_begin;
     return MIBLAST_OK;
 }

@@ -72,3 +72,32 @@ def blast_pairs_sharded(pairs: Sequence, weights: Sequence[float], align_fn: Cal
             by_index[idx] = paf
     assert sorted(by_index) == list(range(len(pairs)))
     return b"".join(by_index[i] for i in range(len(pairs)))
+
+
+def align_pairs_concurrent(pairs, params, device: int = 0, workers: int = 4):
+    """Several chunk pairs of ONE GPU in flight at once (the reference schedules many single-threaded lastz jobs per
+    node, /root/reference/src/cactus/paf/local_alignment.py:399-405).  A single pair cannot fill an MI355X -- its gapped
+    stage is a handful of long, row-sequential DPs -- so independent pairs are overlapped from `workers` host threads,
+    each with its own miblast context (own HIP stream and workspace; the library is re-entrant per context and ctypes
+    releases the GIL during calls).  pairs: list of (target_fasta_bytes, query_fasta_bytes); returns PAF bytes per pair,
+    in input order."""
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+    from cactus_amd import miblast
+    local = threading.local()
+    out = [None] * len(pairs)
+
+    def work(i):
+        if not hasattr(local, "ctx"):
+            local.ctx = miblast.Context(device)
+        tf, qf = pairs[i]
+        T, Q = local.ctx.seqset_from_fasta_bytes(tf), local.ctx.seqset_from_fasta_bytes(qf)
+        try:
+            r = local.ctx.align(T, Q, params, details=False)
+        finally:
+            T.close(); Q.close()
+        out[i] = (r.paf, r.stats)
+
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        list(ex.map(work, range(len(pairs))))
+    return out
