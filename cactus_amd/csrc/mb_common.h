@@ -17,7 +17,7 @@ constexpr int kSeedWeight = 12;
 constexpr uint32_t kBuckets = 1u << 24;
 constexpr uint8_t kSep = 0xFF;                // contig separator in code arrays
 constexpr int32_t kNeg = -(1 << 29);
-constexpr int kDevPad = 16;                   // separator bytes around device code arrays (8-byte loads may overrun)
+constexpr int kDevPad = 128;                  // separator bytes around device code arrays (8-byte loads may overrun)
 
 // ---- device-side records ---------------------------------------------------------------------
 struct DevHsp {                               // written by k_ungapped for every HSP with score >= K

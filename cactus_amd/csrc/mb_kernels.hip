@@ -48,6 +48,30 @@ __device__ __forceinline__ bool window_word(const uint8_t *codes, int64_t p, uin
     return (bad & 0xFCu) == 0;
 }
 
+// ---- wave-level helpers (DPP scans, SGPR pinning) --------------------------------------------------------
+constexpr int kNeg2 = -(1 << 30);            // below every real score: fill value for shifted-in lanes
+constexpr int kRowChunk = 4096;              // rows per row-info chunk (16 B each = one 64 KiB arena block)
+
+__device__ __forceinline__ int dpp_shr1(int v, int fill) {            // lane l <- lane l-1, lane 0 <- fill
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_scan_max(int v) {                  // inclusive prefix max over the wave
+    constexpr int kId = -2147483647 - 1;                                        // identity of max: lets the DPP fold into v_max
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x111, 0xf, 0xf, false));    // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x112, 0xf, 0xf, false));    // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x114, 0xf, 0xf, false));    // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x118, 0xf, 0xf, false));    // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x142, 0xa, 0xf, false));    // row_bcast:15 -> rows 1,3
+    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x143, 0xc, 0xf, false));    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }          // pin a wave-uniform value to an SGPR
+
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)(unsigned)v);
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int64_t *__restrict__ starts,
                           const int64_t *__restrict__ lens, int n_contigs, int64_t total) {
@@ -273,27 +297,37 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *p) {
     return v;
 }
 
-// Heads of the diagonal runs of the sorted hit keys, compacted so that the extension kernel gets one run per lane
-// (hit counts per diagonal vary with the batch geometry; without this most lanes of k_ungapped would idle).
-// One atomic per 1024-key block; the order of the head list is irrelevant (runs are independent).
+// Heads of the diagonal runs of the sorted hit keys, compacted into two lists: runs of at most kLongRun hits go to
+// the lane-per-run kernel, longer ones (busy diagonals of real homology: hundreds to millions of hits, almost all of
+// them suppressed) to the wave-per-run kernel.  One atomic pair per 1024-key block; list order is irrelevant.
+constexpr int kLongRun = 12;
+
 __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits,
-                                                    unsigned *__restrict__ heads, unsigned *__restrict__ n_heads) {
-    __shared__ unsigned wave_cnt[16];
-    __shared__ unsigned block_base;
+                                                    unsigned *__restrict__ heads_short, unsigned *__restrict__ heads_long,
+                                                    unsigned *__restrict__ n_heads /* [0] short, [1] long */) {
+    __shared__ unsigned cnt_s[16], cnt_l[16];
+    __shared__ unsigned base_s, base_l;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool head = false;
-    if (i < n_hits) head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != (uint32_t)(keys[i] >> 32));
-    const unsigned long long m = __ballot(head);
+    bool head = false, is_long = false;
+    if (i < n_hits) {
+        const uint32_t d = (uint32_t)(keys[i] >> 32);
+        head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != d);
+        if (head) is_long = (i + kLongRun < n_hits) && ((uint32_t)(keys[i + kLongRun] >> 32) == d);
+    }
+    const unsigned long long ms = __ballot(head && !is_long), ml = __ballot(head && is_long);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[w] = (unsigned)__popcll(m);
+    if (lane == 0) { cnt_s[w] = (unsigned)__popcll(ms); cnt_l[w] = (unsigned)__popcll(ml); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned tot = 0;
-        for (int k = 0; k < 16; k++) { unsigned c = wave_cnt[k]; wave_cnt[k] = tot; tot += c; }
-        block_base = tot ? atomicAdd(n_heads, tot) : 0u;
+        unsigned ts = 0, tl = 0;
+        for (int k = 0; k < 16; k++) { unsigned c = cnt_s[k]; cnt_s[k] = ts; ts += c; c = cnt_l[k]; cnt_l[k] = tl; tl += c; }
+        base_s = ts ? atomicAdd(&n_heads[0], ts) : 0u;
+        base_l = tl ? atomicAdd(&n_heads[1], tl) : 0u;
     }
     __syncthreads();
-    if (head) heads[block_base + wave_cnt[w] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (head && !is_long) heads_short[base_s + cnt_s[w] + (unsigned)__popcll(ms & below)] = (unsigned)i;
+    if (head && is_long) heads_long[base_l + cnt_l[w] + (unsigned)__popcll(ml & below)] = (unsigned)i;
 }
 
 // one x-drop direction, 8 columns per load, branch-free inside a chunk (every per-lane condition is a select)
@@ -328,8 +362,8 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
                                                   int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     unsigned long long n_ext = 0, n_cols = 0;
     const unsigned n_heads = *n_heads_p;
-    // grid-stride over diagonal runs: counters stay in registers and cost one atomic per resident wave
-    for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heads; h += gridDim.x * blockDim.x) {
+    // one diagonal run per thread (a long HSP must not delay further runs queued behind it in the same lane)
+    for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heads; h = n_heads) {
         int64_t k = heads[h];
         unsigned long long key = keys[k];
         const uint32_t dq = (uint32_t)(key >> 32);
@@ -338,7 +372,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
             const int32_t q_end = (int32_t)(uint32_t)key;
             if (q_end > ext) {
                 const int64_t t_end = (int64_t)dq - qtot + q_end;
-                // Separators (0xFF) bound every contig on both sides; device buffers carry 16 pad bytes, so the
+                // Separators (0xFF) bound every contig on both sides; device buffers carry kDevPad pad bytes, so the
                 // 8-byte loads may overrun harmlessly.  Left covers the seed, then beyond; right starts at the seed end.
                 int bestL, bl, bestR, br;
                 xdrop_dir<-1>(tc + t_end, qc + q_end, xdrop, bestL, bl, n_cols);
@@ -357,9 +391,15 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
                         hs.seed_t_end = (int32_t)t_end;
                         hs.seed_q_end = q_end;
                         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                        for (int kk = 0; kk < hs.len; kk++) {
-                            const unsigned a = tc[hs.t_start + kk] & 7u, b = qc[hs.q_start + kk] & 7u;
-                            if (a == b) { c0 += (a == 0u); c1 += (a == 1u); c2 += (a == 2u); c3 += (a == 3u); }
+                        for (int kk = 0; kk < hs.len; kk += 8) {          // identical-base census, 8 columns per load
+                            const unsigned long long a8 = load8(tc + hs.t_start + kk), b8 = load8(qc + hs.q_start + kk);
+#pragma unroll
+                            for (int m = 0; m < 8; m++) {
+                                const unsigned a = (unsigned)(a8 >> (8 * m)) & 7u, b = (unsigned)(b8 >> (8 * m)) & 7u;
+                                const bool in = kk + m < hs.len;
+                                c0 += (in & (a == b) & (a == 0u)); c1 += (in & (a == b) & (a == 1u));
+                                c2 += (in & (a == b) & (a == 2u)); c3 += (in & (a == b) & (a == 3u));
+                            }
                         }
                         hs.cnt[0] = c0; hs.cnt[1] = c1; hs.cnt[2] = c2; hs.cnt[3] = c3;
                         hsps[slot] = hs;
@@ -377,15 +417,131 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
     if ((threadIdx.x & 63) == 0 && (n_ext | n_cols)) { atomicAdd(&ctr->extended, n_ext); atomicAdd(&ctr->cols, n_cols); }
 }
 
+// ---- wave-per-run variant for busy diagonals --------------------------------------------------------------------
+__device__ __forceinline__ int dpp_scan_add(int v) {                   // inclusive prefix sum over the wave
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// One x-drop direction evaluated by a whole wave, 64 columns per step: running score = prefix sum, "best so far" =
+// exclusive prefix max, the first lane where run < best - xdrop ends the extension (ballot).  Bit-identical to the
+// sequential loop: the stopping column is examined (counted), never a new best, and nothing behind it is looked at.
+template <int DIR>
+__device__ __forceinline__ void xdrop_dir_wave(const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp, const int xdrop,
+                                               const int lane, int &best_out, int &pos_out, unsigned long long &ncols) {
+    constexpr int kMin = -2147483647 - 1;
+    int run_base = 0, best = 0, bpos = 0;
+    for (int base = 0;; base += 64) {
+        const int k = base + lane;
+        const unsigned a = DIR > 0 ? tp[k] : tp[-1 - k], b = DIR > 0 ? qp[k] : qp[-1 - k];
+        const unsigned long long sepm = __ballot((a == kSep) | (b == kSep));
+        const int nvalid = sepm ? (int)__ffsll((long long)sepm) - 1 : 64;
+        const int sc = lane < nvalid ? sub_score(a, b) : 0;
+        const int incl = dpp_scan_add(sc) + run_base;
+        const int pmi = dpp_scan_max(lane < nvalid ? incl : kMin);
+        const int pme = max(best, dpp_shr1(pmi, kMin));                 // best before this column
+        const unsigned long long stopm = __ballot((lane < nvalid) & (incl <= pme) & (incl < pme - xdrop));
+        const int first_stop = stopm ? (int)__ffsll((long long)stopm) - 1 : 64;
+        const int lim = min(nvalid, first_stop + 1);                    // columns examined in this step
+        ncols += (unsigned long long)lim;
+        const int segbest = __builtin_amdgcn_readlane(pmi, 63 < lim - 1 ? 63 : (lim > 0 ? lim - 1 : 0));
+        if (lim > 0 && segbest > best) {
+            const unsigned long long w = __ballot((lane < lim) & (incl == segbest));
+            bpos = base + (int)__ffsll((long long)w);                  // first column attaining it, 1-based length
+            best = segbest;
+        }
+        if (stopm | sepm) break;                                        // x-drop or end of the contig inside this step
+        run_base = __builtin_amdgcn_readlane(incl, 63);
+    }
+    best_out = best; pos_out = bpos;
+}
+
+__global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long *__restrict__ keys, int64_t n_hits,
+                                                       const unsigned *__restrict__ heads, const unsigned *__restrict__ n_heads_p,
+                                                       const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, int64_t qtot,
+                                                       int32_t *__restrict__ extent, int xdrop, int K, DevHsp *__restrict__ hsps,
+                                                       int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n_heads = *n_heads_p;
+    const unsigned h = uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));      // one run per wave
+    if (h >= n_heads) return;
+    unsigned long long n_ext = 0, n_cols = 0;
+    int64_t k0 = heads[h];
+    const uint32_t dq = (uint32_t)(keys[k0] >> 32);
+    int32_t ext = extent[dq];
+    bool run_done = false;
+    while (!run_done) {
+        // 64 hits of the run at a time; all suppressed hits of the block are skipped with one ballot
+        const int64_t k = k0 + lane;
+        unsigned long long key = k < n_hits ? keys[k] : ~0ull;
+        const bool mine = (uint32_t)(key >> 32) == dq;                   // still the same diagonal
+        const unsigned long long inrun = __ballot(mine);
+        const int n_in = inrun == ~0ull ? 64 : (int)__ffsll((long long)~inrun) - 1;
+        int from = 0;
+        while (true) {
+            const unsigned long long todo = __ballot(mine & (lane >= from) & ((int32_t)(uint32_t)key > ext));
+            if (!todo) break;
+            const int l = (int)__ffsll((long long)todo) - 1;            // next hit that is not inside an extended stretch
+            const int32_t q_end = (int32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l);
+            const int64_t t_end = (int64_t)dq - qtot + q_end;
+            int bestL, bl, bestR, br;
+            xdrop_dir_wave<-1>(tc + t_end, qc + q_end, xdrop, lane, bestL, bl, n_cols);
+            xdrop_dir_wave<+1>(tc + t_end, qc + q_end, xdrop, lane, bestR, br, n_cols);
+            n_ext++;
+            ext = q_end + br;
+            const int score = bestL + bestR;
+            if (score >= K) {
+                unsigned long long slot = 0;
+                if (lane == 0) slot = atomicAdd(&ctr->hsps, 1ull);
+                slot = uni64(slot);
+                if ((int64_t)slot < hsp_cap) {
+                    const int t_start = (int)(t_end - bl), q_start = q_end - bl, len = bl + br;
+                    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                    for (int kk = lane; kk < len; kk += 64) {          // identical-base census, one column per lane
+                        const unsigned a = tc[t_start + kk] & 7u, b = qc[q_start + kk] & 7u;
+                        c0 += (a == b) & (a == 0u); c1 += (a == b) & (a == 1u); c2 += (a == b) & (a == 2u); c3 += (a == b) & (a == 3u);
+                    }
+                    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_down(c0, o); c1 += __shfl_down(c1, o); c2 += __shfl_down(c2, o); c3 += __shfl_down(c3, o); }
+                    if (lane == 0) {
+                        DevHsp hs;
+                        hs.t_start = t_start; hs.q_start = q_start; hs.len = len; hs.score = score;
+                        hs.seed_t_end = (int32_t)t_end; hs.seed_q_end = q_end;
+                        hs.cnt[0] = c0; hs.cnt[1] = c1; hs.cnt[2] = c2; hs.cnt[3] = c3;
+                        hsps[slot] = hs;
+                    }
+                }
+            }
+            from = l + 1;
+        }
+        if (n_in < 64) run_done = true;
+        k0 += 64;
+    }
+    if (lane == 0) {
+        extent[dq] = ext;
+        atomicAdd(&ctr->extended, n_ext);
+        atomicAdd(&ctr->cols, n_cols);
+    }
+}
+
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
                      const uint8_t *qcodes, int64_t qtot, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, hipStream_t s) {
     if (n_hits <= 0) return;
-    (void)hipMemsetAsync(n_heads, 0, sizeof(unsigned), s);
-    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, heads, n_heads);
-    const int64_t blocks = std::min<int64_t>((n_hits + 255) / 256, 256 * 8);     // 8 resident blocks per CU
+    // heads: [0, n_hits) short-run heads, [n_hits, n_hits + n_hits/kLongRun + 1) long-run heads; n_heads: two counters
+    unsigned *heads_long = heads + n_hits;
+    (void)hipMemsetAsync(n_heads, 0, 2 * sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, heads, heads_long, n_heads);
+    const int64_t blocks = (n_hits + 255) / 256;                                 // upper bound on the number of short runs
     hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
                        qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+    const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
+    hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + 1,
+                       tcodes, qcodes, qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -402,29 +558,6 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
 //     in a register (v_readlane per row), so no global load sits on the row-to-row critical path;
 //   * one trace byte per evaluated cell goes to 64 KiB blocks bump-allocated from an HBM arena, with a
 //     16-byte (offset, LY) record per row in 4096-row chunks found through a per-problem directory.
-constexpr int kNeg2 = -(1 << 30);            // below every real score: fill value for shifted-in lanes
-constexpr int kRowChunk = 4096;              // rows per row-info chunk (16 B each = one 64 KiB arena block)
-
-__device__ __forceinline__ int dpp_shr1(int v, int fill) {            // lane l <- lane l-1, lane 0 <- fill
-    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int dpp_scan_max(int v) {                  // inclusive prefix max over the wave
-    constexpr int kId = -2147483647 - 1;                                        // identity of max: lets the DPP fold into v_max
-    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x111, 0xf, 0xf, false));    // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x112, 0xf, 0xf, false));    // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x114, 0xf, 0xf, false));    // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x118, 0xf, 0xf, false));    // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x142, 0xa, 0xf, false));    // row_bcast:15 -> rows 1,3
-    v = max(v, __builtin_amdgcn_update_dpp(kId, v, 0x143, 0xc, 0xf, false));    // row_bcast:31 -> rows 2,3
-    return v;
-}
-
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }          // pin a wave-uniform value to an SGPR
-
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
-    return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)(unsigned)v);
-}
-
 struct RowInfo { unsigned long long off; uint32_t ly; uint32_t pad; };
 
 // per-row packed score table: byte k = HOXD70[k][bq] + 128 for k = A,C,G,T (N handled separately)

@@ -289,7 +289,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             hit_off.ensure((size_t)(q1 - q0));
             keys_a.ensure((size_t)nh); keys_b.ensure((size_t)nh);
             d_hsps.ensure((size_t)nh);
-            w.heads.ensure((size_t)nh); w.n_heads.ensure(1);
+            w.heads.ensure((size_t)nh + (size_t)nh / 12 + 8); w.n_heads.ensure(2);
             size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev0, s));
