@@ -422,6 +422,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     }
     const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 4096);
     const long shadow_q0 = env_long("MIBLAST_SHADOW_Q", 1 << 16);        // spatial thinning of speculative anchors
+    const long spec_target = env_long("MIBLAST_SPEC_TARGET", 24);        // anchors per round the thinning aims at
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
@@ -434,8 +435,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     struct Pending { size_t unit, anchor; };
     for (int round = 0;; round++) {
         // commit what can be committed, then nominate the next speculative batch of every unit
-        std::vector<Pending> pend;
-        const long shadow_q = std::max(64l, shadow_q0 >> (2 * std::min(round, 15)));
+        // commit what can be committed
         for (size_t ui = 0; ui < units.size(); ui++) {
             Unit &u = units[ui];
             while (u.next < u.anchors.size()) {
@@ -458,26 +458,40 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 u.cache.erase(it);
                 u.next++;
             }
-            // Nomination is a pure scheduling heuristic: results never depend on it because anchors are
-            // committed strictly in order above.  The first unresolved anchor is always nominated (progress);
-            // the others are thinned: skip what an uncommitted accepted result would cover, and keep at most
-            // one new anchor per (diagonal band, query neighbourhood) -- the neighbourhood shrinks 4x per round,
-            // so long alignments are found first from a few probes and the gaps are filled in later rounds.
-            std::vector<Anchor> taken;
-            for (size_t k = u.next; k < u.anchors.size() && taken.size() < batch_max; k++) {
-                if (u.cache.count(k)) continue;
-                const Anchor &a = u.anchors[k];
-                if (covered(u, a)) continue;
-                if (k != u.next) {
-                    if (tentatively_covered(u, a)) continue;
-                    bool shadowed = false;
-                    for (const Anchor &b : taken)
-                        if (std::labs((long)(a.t - a.q) - (long)(b.t - b.q)) <= shadow_d && std::labs((long)a.q - (long)b.q) <= shadow_q) { shadowed = true; break; }
-                    if (shadowed) continue;
+        }
+        // Nomination of the next speculative batch is a pure scheduling heuristic: results never depend on it because
+        // anchors are committed strictly in order above.  The first unresolved anchor of every unit is always nominated
+        // (progress); the others are thinned: skip what an uncommitted accepted result would cover, and keep at most one
+        // new anchor per (diagonal band, query neighbourhood).  The neighbourhood is the smallest of a 4x ladder that
+        // keeps the batch within `spec_target` anchors, so an idle GPU is filled with probes in the first round (a
+        // single one-sided DP is a row-sequential chain: rounds cost latency, parallel probes cost almost nothing).
+        std::vector<Pending> pend;
+        long shadow_q = shadow_q0;
+        for (int level = 0; level < 6; level++) {
+            std::vector<Pending> cand;
+            const long sq = std::max(64l, shadow_q0 >> (2 * level));
+            for (size_t ui = 0; ui < units.size(); ui++) {
+                Unit &u = units[ui];
+                std::vector<Anchor> taken;
+                for (size_t k = u.next; k < u.anchors.size() && taken.size() < batch_max; k++) {
+                    if (u.cache.count(k)) continue;
+                    const Anchor &a = u.anchors[k];
+                    if (covered(u, a)) continue;
+                    if (k != u.next) {
+                        if (tentatively_covered(u, a)) continue;
+                        bool shadowed = false;
+                        for (const Anchor &b : taken)
+                            if (std::labs((long)(a.t - a.q) - (long)(b.t - b.q)) <= shadow_d && std::labs((long)a.q - (long)b.q) <= sq) { shadowed = true; break; }
+                        if (shadowed) continue;
+                    }
+                    taken.push_back(a);
+                    cand.push_back(Pending{ui, k});
                 }
-                taken.push_back(a);
-                pend.push_back(Pending{ui, k});
             }
+            if (level > 0 && (long)cand.size() > spec_target) break;      // keep the previous (coarser) level
+            pend.swap(cand);
+            shadow_q = sq;
+            if ((long)pend.size() >= spec_target / 2) break;              // full enough
         }
         if (pend.empty()) break;
         st.gapped_rounds++;
