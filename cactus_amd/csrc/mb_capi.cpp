@@ -53,11 +53,13 @@ extern "C" {
 void miblast_params_default(miblast_params *p) {
     p->step = 1; p->transitions = 1; p->xdrop = 910; p->ydrop = 9400; p->hspthresh = 3000; p->gappedthresh = -1;
     p->gap_open = 400; p->gap_extend = 30; p->entropy = 1; p->queryhspbest = 0; p->ambiguous_n = 1; p->gapped = 1;
+    p->format = 0; p->markend = 0; p->queryhsplimit = 0;
 }
 
 int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const char *files[2], int *num_gpu, int *num_threads) {
     miblast_params_default(p);
     int nf = 0, ng = 1, nt = 1;
+    bool querydepth_seen = false;
     files[0] = files[1] = nullptr;
     auto bad = [&](const char *a, const char *why) {
         mb::set_error(std::string(why) + ": " + a);
@@ -98,7 +100,19 @@ int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const cha
                 return bad(a, "unsupported --ambiguous form");
             p->ambiguous_n = 1;
         } else if (key == "--format") {
-            if (!val || strcmp(val, "paf:wfmash")) return bad(a, "only --format=paf:wfmash is implemented");
+            // blast: paf:wfmash (local_alignment.py:68); repeat masker: the six-column general form (cactus_lastzRepeatMask.py:104)
+            if (val && !strcmp(val, "paf:wfmash")) p->format = 0;
+            else if (val && !strcmp(val, "general:name1,zstart1,end1,name2,zstart2+,end2+")) p->format = 1;
+            else return bad(a, "unsupported --format");
+        } else if (key == "--markend" && !val) p->markend = 1;
+        else if (key == "--queryhsplimit") {
+            // only the form Cactus passes: keep,nowarn:N (cactus_progressive_config.xml:36 lastzOpts)
+            if (!val || strncmp(val, "keep,nowarn:", 12) || !parse_int(val + 12, v) || v < 1) return bad(a, "unsupported --queryhsplimit form");
+            p->queryhsplimit = (int32_t)v;
+        } else if (key == "--querydepth") {
+            // "has no effect when --ungapped is passed" (cactus_lastzRepeatMask.py:100); accepted for that case only
+            if (!val || strncmp(val, "keep,nowarn:", 12) || !parse_int(val + 12, v) || v < 1) return bad(a, "unsupported --querydepth form");
+            querydepth_seen = true;
         } else if (key == "--num_gpu") {                       // run_kegalign form: "--num_gpu N" (local_alignment.py:58)
             if (val) { if (!parse_int(val, v) || v < 1) return bad(a, "bad value for option"); }
             else { if (i + 1 >= argc || !parse_int(argv[++i], v) || v < 1) return bad(a, "bad value for option"); }
@@ -111,6 +125,8 @@ int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const cha
         if (rc) return rc;
     }
     if (nf != 2) { mb::set_error("expected a target and a query sequence file"); return MIBLAST_EINVAL; }
+    if (p->format == 1 && p->gapped) { mb::set_error("--format=general:... is implemented for --ungapped only"); return MIBLAST_EINVAL; }
+    if (querydepth_seen && p->gapped) { mb::set_error("--querydepth is only accepted together with --ungapped"); return MIBLAST_EINVAL; }
     if (num_gpu) *num_gpu = ng;
     if (num_threads) *num_threads = nt;
     return MIBLAST_OK;
@@ -182,10 +198,22 @@ int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_s
     // accept lastz's trailing [actions] on the file name (local_alignment.py:60-62)
     std::string file(path);
     size_t br = file.find('[');
-    if (br != std::string::npos) file.resize(br);
+    bool unmask = false;
+    if (br != std::string::npos) {
+        unmask = file.find("unmask", br) != std::string::npos;     // [unmask] / [multiple,unmask] (cactus_lastzRepeatMask.py:88)
+        file.resize(br);
+    }
     std::ifstream f(file, std::ios::binary);
     if (!f) { mb::set_error("cannot open " + file); return MIBLAST_EIO; }
     std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (unmask) {                                                    // lastz [unmask]: soft-masking is removed on load
+        bool header = false;
+        for (char &c : data) {
+            if (c == '>') header = true;
+            else if (c == '\n') header = false;
+            else if (!header && c >= 'a' && c <= 'z') c = (char)(c - 32);
+        }
+    }
     return miblast_seqset_from_fasta_mem(ctx, data.data(), data.size(), out);
 }
 

@@ -361,12 +361,21 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             h.q_contig = Q.contig_of(d.q_start);
             hs.push_back(h);
         }
+        // --queryhsplimit=keep,nowarn:N: the search of a query stops at N HSPs and keeps them, i.e. the first N in found
+        // order per query contig and strand (repeat-masker option set, cactus_progressive_config.xml:36)
+        if (p.queryhsplimit > 0) {
+            std::vector<int64_t> seen(Q.starts.size() + 1, 0);
+            size_t wr = 0;
+            for (size_t k = 0; k < hs.size(); k++)
+                if (seen[(size_t)hs[k].q_contig]++ < p.queryhsplimit) hs[wr++] = hs[k];
+            hs.resize(wr);
+        }
         // --queryhspbest=N per query contig and strand: N best scores, ties to the earlier found
         if (p.queryhspbest > 0) {
+            std::vector<std::vector<size_t>> by_contig(Q.starts.size());
+            for (size_t k = 0; k < hs.size(); k++) by_contig[(size_t)hs[k].q_contig].push_back(k);
             std::vector<miblast_hsp> kept;
-            for (int qc_i = 0; qc_i < (int)Q.starts.size(); qc_i++) {
-                std::vector<size_t> idx;
-                for (size_t k = 0; k < hs.size(); k++) if (hs[k].q_contig == qc_i) idx.push_back(k);
+            for (std::vector<size_t> &idx : by_contig) {
                 if ((int64_t)idx.size() > p.queryhspbest) {
                     std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return hs[a].score > hs[b].score; });
                     idx.resize((size_t)p.queryhspbest);
@@ -693,6 +702,30 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
         }
         res.paf.push_back('\n');
     }
+    if (p.format == 1) {
+        // --format=general:name1,zstart1,end1,name2,zstart2+,end2+ (cactus_lastzRepeatMask.py:104): one line per HSP
+        res.paf += "#name1\tzstart1\tend1\tname2\tzstart2+\tend2+\n";
+        std::vector<size_t> order(res.hsps.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {      // per query contig, '+' then '-', found order
+            if (res.hsps[a].q_contig != res.hsps[b].q_contig) return res.hsps[a].q_contig < res.hsps[b].q_contig;
+            return res.hsps[a].strand < res.hsps[b].strand;
+        });
+        for (size_t k : order) {
+            const miblast_hsp &h = res.hsps[k];
+            const int qc_i = h.q_contig, strand = h.strand;
+            const int tcg = T.contig_of(h.t_start);
+            const int64_t qst = Q.starts[(size_t)qc_i], qlen = Q.lens[(size_t)qc_i];
+            int64_t qs = h.q_start - qst, qe = qs + h.len;
+            if (strand) { int64_t s2 = qlen - qe, e2 = qlen - qs; qs = s2; qe = e2; }
+            res.paf += T.names[(size_t)tcg]; res.paf.push_back('\t');
+            put_num(h.t_start - T.starts[(size_t)tcg]); res.paf.push_back('\t');
+            put_num(h.t_start - T.starts[(size_t)tcg] + h.len); res.paf.push_back('\t');
+            res.paf += Q.names[(size_t)qc_i]; res.paf.push_back('\t');
+            put_num(qs); res.paf.push_back('\t'); put_num(qe); res.paf.push_back('\n');
+        }
+    }
+    if (p.markend) res.paf += "# lastz end-of-file\n";
     if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast] PAF formatting: %.2f ms; index %.2f ms, seed %.2f ms, gapped %.2f ms\n", (now_s() - t_out0) * 1e3, st.t_index * 1e3, st.t_seed * 1e3, st.t_gapped * 1e3);
     st.t_total = now_s() - t_begin;
     return MIBLAST_OK;

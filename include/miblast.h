@@ -50,6 +50,11 @@ typedef struct miblast_params {
     int32_t queryhspbest;  /* --queryhspbest=N, 0 = unlimited            default 0    */
     int32_t ambiguous_n;   /* --ambiguous=iupac,100,100                  default 1    */
     int32_t gapped;        /* 0 = --ungapped / --nogapped                default 1    */
+    /* second call site of the same binary, the lastz repeat masker
+     * (/root/reference/src/cactus/preprocessor/lastzRepeatMasking/cactus_lastzRepeatMask.py:97-105): */
+    int32_t format;        /* 0 = paf:wfmash ; 1 = general:name1,zstart1,end1,name2,zstart2+,end2+ (HSP list, needs gapped=0) */
+    int32_t markend;       /* --markend: terminate the output with "# lastz end-of-file"                  */
+    int32_t queryhsplimit; /* --queryhsplimit=keep,nowarn:N : per query sequence and strand keep only the first N HSPs found; 0 = off */
 } miblast_params;
 
 void miblast_params_default(miblast_params *p);

@@ -46,6 +46,9 @@ void olz_params_default(olz_params *p) {
     p->queryhspbest = 0;
     p->ambiguous_n = 1;
     p->gapped = 1;
+    p->format = 0;
+    p->markend = 0;
+    p->queryhsplimit = 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -504,6 +507,16 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
         free(qok);
         res->c.t_seed += now_s() - t0s;
 
+        /* --queryhsplimit=keep,nowarn:N (cactus_lastzRepeatMask.py:36 lastzOpts): the search of a query stops once it
+         * has N HSPs; what was found until then is kept -- i.e. the first N in found order, per query contig & strand */
+        if (p.queryhsplimit > 0) {
+            int64_t *seen = (int64_t *)calloc((size_t)Q->n_contigs + 1, sizeof(int64_t));
+            int64_t w = 0;
+            for (int64_t k = 0; k < nsh; k++)
+                if (seen[sh[k].q_contig]++ < p.queryhsplimit) sh[w++] = sh[k];
+            nsh = w;
+            free(seen);
+        }
         /* --queryhspbest=N : per query contig & strand keep the N best, ties by found order */
         if (p.queryhspbest > 0) {
             olz_hsp *kept = NULL; int64_t nk = 0, capk = 0;
@@ -636,6 +649,33 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
         }
         sb_put(&paf, "\n", 1);
     }
+    if (p.format == 1) {
+        /* --format=general:name1,zstart1,end1,name2,zstart2+,end2+ (cactus_lastzRepeatMask.py:104): one line per HSP,
+         * target interval then query interval on the '+' strand; per query contig, '+' strand HSPs then '-' strand */
+        const char *hdr = "#name1\tzstart1\tend1\tname2\tzstart2+\tend2+\n";
+        sb_put(&paf, hdr, strlen(hdr));
+        /* hsps[] holds strand 0 then strand 1, each in found order (q ascending => contig ascending): merge the two */
+        int64_t split = 0;
+        while (split < nh && hsps[split].strand == 0) split++;
+        int64_t a = 0, b = split;
+        while (a < split || b < nh) {
+            int take_a;
+            if (a >= split) take_a = 0;
+            else if (b >= nh) take_a = 1;
+            else take_a = hsps[a].q_contig <= hsps[b].q_contig;
+            const olz_hsp *h = take_a ? &hsps[a++] : &hsps[b++];
+            int qc_i = h->q_contig, strand = h->strand;
+            int tcg = contig_of(T, h->t_start);
+            int64_t qst = Q->starts[qc_i], qlen = Q->lens[qc_i];
+            int64_t qs = h->q_start - qst, qe = qs + h->len;
+            if (strand) { int64_t s2 = qlen - qe, e2 = qlen - qs; qs = s2; qe = e2; }
+            int n = snprintf(line, sizeof line, "%s\t%lld\t%lld\t%s\t%lld\t%lld\n", T->names[tcg],
+                             (long long)(h->t_start - T->starts[tcg]), (long long)(h->t_start - T->starts[tcg] + h->len),
+                             Q->names[qc_i], (long long)qs, (long long)qe);
+            sb_put(&paf, line, (size_t)n);
+        }
+    }
+    if (p.markend) sb_put(&paf, "# lastz end-of-file\n", 20);
     if (!paf.s) { paf.s = (char *)calloc(1, 1); }
     free(alns);
     res->alns = ordered; res->n_alns = no;

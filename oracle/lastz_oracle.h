@@ -47,6 +47,10 @@ typedef struct olz_params {
     int32_t queryhspbest;  /* --queryhspbest=N (0 = unlimited)                  */
     int32_t ambiguous_n;   /* 1 = --ambiguous=iupac,100,100 (N scores -100)     */
     int32_t gapped;        /* 1 = gapped stage on; 0 = --ungapped / --nogapped  */
+    /* repeat-masker call site (cactus_lastzRepeatMask.py:97-105) */
+    int32_t format;        /* 0 paf:wfmash ; 1 general:name1,zstart1,end1,name2,zstart2+,end2+ (ungapped HSPs) */
+    int32_t markend;       /* --markend */
+    int32_t queryhsplimit; /* --queryhsplimit=keep,nowarn:N (0 = off): first N HSPs found per query contig and strand */
 } olz_params;
 
 void olz_params_default(olz_params *p);

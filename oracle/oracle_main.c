@@ -37,7 +37,14 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--entropy")) p.entropy = 1;
         else if (!strcmp(a, "--ungapped") || !strcmp(a, "--nogapped")) p.gapped = 0;
         else if (!strncmp(a, "--ambiguous=", 12)) p.ambiguous_n = 1;
-        else if (!strncmp(a, "--format=", 9)) { if (strcmp(a + 9, "paf:wfmash")) { fprintf(stderr, "unsupported format %s\n", a + 9); return 2; } }
+        else if (!strncmp(a, "--format=", 9)) {
+            if (!strcmp(a + 9, "paf:wfmash")) p.format = 0;
+            else if (!strcmp(a + 9, "general:name1,zstart1,end1,name2,zstart2+,end2+")) p.format = 1;
+            else { fprintf(stderr, "unsupported format %s\n", a + 9); return 2; }
+        }
+        else if (!strcmp(a, "--markend")) p.markend = 1;
+        else if (!strncmp(a, "--queryhsplimit=keep,nowarn:", 28)) p.queryhsplimit = atoi(a + 28);
+        else if (!strncmp(a, "--querydepth=keep,nowarn:", 25)) { /* no effect with --ungapped (cactus_lastzRepeatMask.py:100) */ }
         else if (!strcmp(a, "--counters")) counters = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # 12 x int32 params ; stats = 12 int64 + 4 double + extras
-    assert C.sizeof(miblast.Params) == 48
+    assert C.sizeof(miblast.Params) == 60
     assert C.sizeof(miblast.Hsp) == 48 and C.sizeof(miblast.Aln) == 64
     assert C.sizeof(miblast.Stats) == 12 * 8 + 4 * 8 + 4 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
 def test_default_params_are_lastz_defaults():
     p = miblast.default_params()
     assert (p.step, p.transitions, p.xdrop, p.ydrop, p.hspthresh, p.gappedthresh, p.gap_open, p.gap_extend, p.entropy,
-            p.queryhspbest, p.ambiguous_n, p.gapped) == (1, 1, 910, 9400, 3000, -1, 400, 30, 1, 0, 1, 1)
+            p.queryhspbest, p.ambiguous_n, p.gapped, p.format, p.markend, p.queryhsplimit) == (1, 1, 910, 9400, 3000, -1, 400, 30, 1, 0, 1, 1, 0, 0, 0)
 
 
 def _argv(args):

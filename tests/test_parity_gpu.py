@@ -177,3 +177,52 @@ def test_evolver_like_blast_phase_cigar_diff(gpu_ctx, olz):
         assert got.stats["dp_cells"] == want["counters"]["dp_cells"] and got.stats["seed_hits"] == want["counters"]["seed_hits"]
         total += got.paf.count(b"\n")
     assert total >= 2 * len(pairs)
+
+
+def test_repeat_mask_call_site_general_format(gpu_ctx, olz, tmp_path):
+    """the repeat masker's lastz invocation (cactus_lastzRepeatMask.py:97-105) -- query = 200 bp fragments
+    (hundreds of records), --ungapped --queryhsplimit=keep,nowarn:N, general six-column output, --markend -- byte-identical
+    to the oracle, through the library and through bin/lastz; then the whole job masks a planted high-copy repeat."""
+    import subprocess, os
+    import numpy as np
+    from cactus_amd import gen, miblast
+    from cactus_amd.preprocessor.lastz_repeat_mask import LastzRepeatMaskJob, RepeatMaskOptions, fasta_fragments
+    from cactus_amd.shared.common import BIN_DIR
+    from cactus_amd.shared.localjob import LocalFileStore, FileID
+    rng = np.random.default_rng(9)
+    unit = gen.random_sequence(600, rng)
+    parts, truth = [], []
+    pos = 0
+    for k in range(40):
+        flank = gen.random_sequence(int(rng.integers(300, 900)), rng)
+        parts.append(flank); pos += len(flank)
+        if k % 2 == 0:
+            copy = gen.mutate(unit, rng, 0.03, 0.0)
+            truth.append((pos, pos + len(copy))); parts.append(copy); pos += len(copy)
+    genome = np.concatenate(parts)
+    qfa = gen.fasta_bytes([("id=E|chrR", genome)])
+    frags = fasta_fragments(qfa.decode(), 200, 100, "zero").encode()
+    args = "--step=3 --ambiguous=iupac,100,100 --ungapped --queryhsplimit=keep,nowarn:7 --querydepth=keep,nowarn:53 --format=general:name1,zstart1,end1,name2,zstart2+,end2+ --markend".split()
+    pm = miblast.params_from_args(args)
+    assert (pm.gapped, pm.format, pm.markend, pm.queryhsplimit) == (0, 1, 1, 7)
+    T, Q = gpu_ctx.seqset_from_fasta_bytes(qfa), gpu_ctx.seqset_from_fasta_bytes(frags)
+    got = gpu_ctx.align(T, Q, pm)
+    want = olz.align(qfa, frags, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}))
+    assert got.paf == want["paf"] and got.hsps == want["hsps"]
+    assert got.paf.count(b"\n") > 200 and got.paf.endswith(b"# lastz end-of-file\n")
+    (tmp_path / "t.fa").write_bytes(qfa); (tmp_path / "f.fa").write_bytes(frags)
+    p = subprocess.run([os.path.join(BIN_DIR, "lastz"), "t.fa[multiple][nameparse=darkspace]", "f.fa[nameparse=darkspace]"] + args, cwd=tmp_path, capture_output=True)
+    assert p.returncode == 0 and p.stderr == b"" and p.stdout == got.paf
+    # end to end: fragments -> lastz -> covered intervals -> softmask
+    fs = LocalFileStore(str(tmp_path / "js")) if (tmp_path / "js").mkdir() is None else None
+    src = tmp_path / "g.fa"; src.write_bytes(qfa)
+    job = LastzRepeatMaskJob(RepeatMaskOptions(fragment=200, minPeriod=5, eventName="E"), FileID.of(str(src)), [FileID.of(str(src))])
+    masked = open(str(job.run(fs))).read()
+    seq = "".join(masked.splitlines()[1:])
+    assert seq.upper() == genome.tobytes().decode()
+    low = np.array([c.islower() for c in seq])
+    inside = np.mean([low[a + 50:b - 50].mean() for a, b in truth])
+    outside_mask = np.ones(len(seq), bool)
+    for a, b in truth:
+        outside_mask[max(0, a - 30):b + 30] = False
+    assert inside > 0.9 and low[outside_mask].mean() < 0.02
