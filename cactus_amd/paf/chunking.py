@@ -72,3 +72,67 @@ def paf_dechunk(in_path: str, out_path: str, query_only: bool = False, append: b
         for line in fin:
             if line.strip():
                 fout.write(paf_dechunk_line(line, query_only))
+
+
+# ---- outgroup trimming formats (local_alignment.py:421-526) --------------------------------------
+def paf_invert_line(line: str) -> str:
+    """`paffy invert`: swap query and target; I <-> D in the cg cigar; on the '-' strand the op order is reversed
+    (the cigar always runs along the target's forward strand)."""
+    import re
+    f = line.rstrip("\n").split("\t")
+    f[0], f[1], f[2], f[3], f[5], f[6], f[7], f[8] = f[5], f[6], f[7], f[8], f[0], f[1], f[2], f[3]
+    for k in range(12, len(f)):
+        if f[k].startswith("cg:Z:"):
+            ops = re.findall(r"(\d+)([=XIDM])", f[k][5:])
+            swap = {"I": "D", "D": "I"}
+            ops = [(n, swap.get(o, o)) for n, o in ops]
+            if f[4] == "-":
+                ops.reverse()
+            f[k] = "cg:Z:" + "".join(n + o for n, o in ops)
+    return "\t".join(f) + "\n"
+
+
+def paf_to_bed_unaligned(paf_path: str, query_fasta: str, min_size: int):
+    """`paffy to_bed --excludeAligned --binary --minSize N -i paf --queryFastaFile fa` (local_alignment.py:460-466):
+    BED intervals (name, start, end) of QUERY sequence not covered by any alignment, at least min_size long."""
+    import numpy as np
+    cover = {name.split()[0]: np.zeros(len(seq) + 1, dtype=np.int32) for name, seq in _read_fasta(query_fasta)}
+    with open(paf_path) as f:
+        for line in f:
+            if not line.strip():
+                continue
+            t = line.split("\t")
+            c = cover[t[0]]
+            c[int(t[2])] += 1
+            c[int(t[3])] -= 1
+    out = []
+    for name, diff in cover.items():
+        free = np.cumsum(diff[:-1]) == 0
+        edges = np.diff(np.concatenate(([0], free.astype(np.int8), [0])))
+        for s, e in zip(np.nonzero(edges == 1)[0], np.nonzero(edges == -1)[0]):
+            if e - s >= min_size:
+                out.append((name, int(s), int(e)))
+    return out
+
+
+def fasta_extract(bed, fasta_path: str, out_path: str, flank: int):
+    """`faffy extract -i bed fa --flank F` (local_alignment.py:470-475): the BED intervals, widened by `flank` on
+    both sides (overlapping widened intervals are merged), written as records named NAME|SEQLEN|START so that
+    `paffy dechunk --query` (paf_dechunk(..., query_only=True)) restores full-sequence coordinates."""
+    seqs = {name.split()[0]: seq for name, seq in _read_fasta(fasta_path)}
+    by = {}
+    for name, s, e in bed:
+        by.setdefault(name, []).append((max(0, s - flank), min(len(seqs[name]), e + flank)))
+    with open(out_path, "w") as out:
+        for name in seqs:
+            merged = []
+            for s, e in sorted(by.get(name, [])):
+                if merged and s <= merged[-1][1]:
+                    merged[-1] = (merged[-1][0], max(merged[-1][1], e))
+                else:
+                    merged.append((s, e))
+            for s, e in merged:
+                out.write(">{}|{}|{}\n".format(name, len(seqs[name]), s))
+                piece = seqs[name][s:e]
+                for i in range(0, len(piece), 100):
+                    out.write(piece[i:i + 100] + "\n")

@@ -163,3 +163,66 @@ def make_chunked_alignments(job, event_a, genome_a, event_b, genome_b, distance,
                                                              memory=memory, accelerators=accelerators).rv())
     dechunk_batch_size = getOptionalAttrib(lastz_params_node, 'dechunkBatchSize', typeFn=int, default=int(1e9))
     return job.addFollowOnJobFn(combine_chunks, chunked_alignment_files, dechunk_batch_size).rv()
+
+
+# ---- ingroup -> outgroup alignments with progressive trimming (local_alignment.py:411-526) -----------------------------
+def invert_alignments(job, alignment_file):
+    """ Invert the pafs in the alignment_file (paffy invert, :411-418) """
+    src = job.fileStore.readGlobalFile(alignment_file)
+    dst = job.fileStore.getLocalTempFile()
+    with open(src) as fin, open(dst, "w") as fout:
+        for line in fin:
+            if line.strip():
+                fout.write(chunking.paf_invert_line(line))
+    job.fileStore.deleteGlobalFile(alignment_file)
+    return job.fileStore.writeGlobalFile(dst)
+
+
+def make_ingroup_to_outgroup_alignments_0(job, ingroup_event, outgroup_events, event_names_to_sequences, distances, params):
+    alignment_file = job.addChildJobFn(make_ingroup_to_outgroup_alignments_1, ingroup_event, outgroup_events,
+                                       event_names_to_sequences, distances, params).rv()
+    # Invert the final alignment so that the query is the outgroup and the target is the ingroup
+    return job.addFollowOnJobFn(invert_alignments, alignment_file).rv()
+
+
+def make_ingroup_to_outgroup_alignments_1(job, ingroup_event, outgroup_events, event_names_to_sequences, distances, params):
+    """events are plain names here (the reference passes tree nodes and uses .iD); distances is keyed by (ingroup, outgroup)"""
+    outgroup = outgroup_events[0]
+    alignment = job.addChildJobFn(make_chunked_alignments, outgroup, event_names_to_sequences[outgroup],
+                                  ingroup_event, event_names_to_sequences[ingroup_event], distances[ingroup_event, outgroup], params).rv()
+    if len(outgroup_events) > 1:
+        return job.addFollowOnJobFn(make_ingroup_to_outgroup_alignments_2, alignment, ingroup_event, outgroup_events[1:],
+                                    dict(event_names_to_sequences), distances, params).rv()
+    return alignment
+
+
+def make_ingroup_to_outgroup_alignments_2(job, alignments, ingroup_event, outgroup_events, event_names_to_sequences, distances, params):
+    # identify all ingroup sub-sequences that remain unaligned longer than a threshold (:451-475)
+    work_dir = job.fileStore.getLocalTempDir()
+    alignments_file = os.path.join(work_dir, '{}.paf'.format(ingroup_event))
+    job.fileStore.readGlobalFile(alignments, alignments_file)
+    ingroup_seq_file = os.path.join(work_dir, '{}.fa'.format(ingroup_event))
+    job.fileStore.readGlobalFile(event_names_to_sequences[ingroup_event], ingroup_seq_file)
+    bed = chunking.paf_to_bed_unaligned(alignments_file, ingroup_seq_file, int(params.find("blast").attrib['trimMinSize']))
+    seq_file = os.path.join(work_dir, '{}_subseq.fa'.format(ingroup_event))
+    chunking.fasta_extract(bed, ingroup_seq_file, seq_file, int(params.find("blast").attrib['trimFlanking']))
+    # replace the ingroup sequences with remaining sequences and recurse over the remaining outgroups
+    event_names_to_sequences[ingroup_event] = job.fileStore.writeGlobalFile(seq_file)
+    if os.path.getsize(seq_file) == 0:
+        return alignments
+    alignments2 = job.addChildJobFn(make_ingroup_to_outgroup_alignments_1, ingroup_event, outgroup_events,
+                                    event_names_to_sequences, distances, params).rv()
+    return job.addFollowOnJobFn(make_ingroup_to_outgroup_alignments_3, ingroup_event, event_names_to_sequences[ingroup_event],
+                                alignments, alignments2).rv()
+
+
+def make_ingroup_to_outgroup_alignments_3(job, ingroup_event, ingroup_seq_file, alignments, alignments2, has_resources=False):
+    # use paffy dechunk --query to correct the subsequence coordinates of alignments2, then cat (:515-520)
+    a1 = job.fileStore.readGlobalFile(alignments)
+    a2 = job.fileStore.readGlobalFile(alignments2)
+    merged = job.fileStore.getLocalTempFile()
+    with open(merged, "w") as out, open(a1) as f1:
+        out.write(f1.read())
+    chunking.paf_dechunk(a2, merged, query_only=True, append=True)
+    job.fileStore.deleteGlobalFile(ingroup_seq_file)
+    return job.fileStore.writeGlobalFile(merged)

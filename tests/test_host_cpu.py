@@ -123,3 +123,40 @@ def test_generator_is_deterministic_and_has_the_advertised_features():
 
 def test_accelerator_string_is_rocm():
     assert configWrapper.accelerator_string(0) is None and configWrapper.accelerator_string(4) == "rocm:4"
+
+
+def test_paf_invert_and_validity():
+    from cactus_amd.paf.chunking import paf_invert_line
+    plus = "q\t100\t10\t35\t+\tt\t200\t5\t27\t15\t27\t255\tAS:i:1\tcg:Z:10=2D5X3I5=2I\n"
+    inv = paf_invert_line(plus)
+    f = inv.split("\t")
+    assert f[:9] == ["t", "200", "5", "27", "+", "q", "100", "10", "35"] and f[-1].strip() == "cg:Z:10=2I5X3D5=2D"
+    pafcheck.check_paf(inv)
+    minus = "q\t100\t10\t35\t-\tt\t200\t5\t27\t15\t27\t255\tAS:i:1\tcg:Z:10=2D5X3I5=2I\n"
+    pafcheck.check_paf(minus)
+    inv = paf_invert_line(minus)
+    assert inv.split("\t")[-1].strip() == "cg:Z:2D5=3D5X2I10="
+    pafcheck.check_paf(inv)
+    assert paf_invert_line(paf_invert_line(minus)) == minus
+
+
+def test_unaligned_bed_and_extract_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    fa = tmp_path / "in.fa"
+    recs = [("id=I|c1", gen.random_sequence(3000, rng)), ("id=I|c2", gen.random_sequence(800, rng))]
+    gen.write_fasta(str(fa), recs)
+    paf = tmp_path / "a.paf"
+    paf.write_text("id=I|c1\t3000\t500\t1200\t+\tt\t9\t0\t9\t1\t1\t255\n" "id=I|c1\t3000\t1150\t1300\t-\tt\t9\t0\t9\t1\t1\t255\n"
+                   "id=I|c1\t3000\t2950\t3000\t+\tt\t9\t0\t9\t1\t1\t255\n")
+    bed = chunking.paf_to_bed_unaligned(str(paf), str(fa), 100)
+    assert bed == [("id=I|c1", 0, 500), ("id=I|c1", 1300, 2950), ("id=I|c2", 0, 800)]
+    assert chunking.paf_to_bed_unaligned(str(paf), str(fa), 600) == [("id=I|c1", 1300, 2950), ("id=I|c2", 0, 800)]
+    sub = tmp_path / "sub.fa"
+    chunking.fasta_extract(bed, str(fa), str(sub), 100)
+    got = pafcheck.read_fasta(str(sub))
+    full = {n: s.tobytes().decode() for n, s in recs}
+    assert list(got) == ["id=I|c1|3000|0", "id=I|c1|3000|1200", "id=I|c2|800|0"]
+    assert got["id=I|c1|3000|0"] == full["id=I|c1"][0:600] and got["id=I|c1|3000|1200"] == full["id=I|c1"][1200:3000]
+    # an alignment on an extracted piece maps back with dechunk --query
+    line = "id=I|c1|3000|1200\t1800\t10\t60\t+\tt\t9\t0\t9\t50\t50\t255\tAS:i:1\tcg:Z:50=\n"
+    assert chunking.paf_dechunk_line(line, query_only=True).split("\t")[:4] == ["id=I|c1", "3000", "1210", "1260"]

@@ -226,3 +226,42 @@ def test_repeat_mask_call_site_general_format(gpu_ctx, olz, tmp_path):
     for a, b in truth:
         outside_mask[max(0, a - 30):b + 30] = False
     assert inside > 0.9 and low[outside_mask].mean() < 0.02
+
+
+def test_ingroup_to_outgroup_trimming_chain(gpu_ctx, tmp_path):
+    """SURVEY section 8 f4 (local_alignment.py:421-526): align the ingroup to the nearest outgroup, extract what stayed
+    unaligned (>= trimMinSize, + trimFlanking), align only that to the next outgroup, fix coordinates with dechunk --query,
+    invert.  Every record of the final PAF must validate against the FULL sequences, and the second outgroup must
+    only pick up what the first one did not cover."""
+    import numpy as np
+    from cactus_amd import gen, pafcheck
+    from cactus_amd.paf.local_alignment import make_ingroup_to_outgroup_alignments_0
+    from cactus_amd.shared.configWrapper import load_config
+    from cactus_amd.shared.localjob import LocalJob, LocalFileStore, FileID
+    rng = np.random.default_rng(21)
+    anc = gen.random_sequence(60000, rng)
+    ingroup = gen.mutate(anc, rng, 0.03, 0.002)
+    og1 = np.concatenate([gen.mutate(anc[:28000], rng, 0.08, 0.004), gen.random_sequence(5000, rng)])      # shares the left part
+    og2 = np.concatenate([gen.random_sequence(4000, rng), gen.mutate(anc[20000:], rng, 0.08, 0.004)])      # shares the right part (+ overlap)
+    paths = {}
+    for name, seq in (("I", ingroup), ("O1", og1), ("O2", og2)):
+        p = tmp_path / (name + ".fa"); gen.write_fasta(str(p), [("id=%s|chr1" % name, seq)]); paths[name] = p
+    (tmp_path / "js").mkdir()
+    job = LocalJob(LocalFileStore(str(tmp_path / "js")))
+    seqs = {k: FileID.of(str(v)) for k, v in paths.items()}
+    dist = {("I", "O1"): 0.3, ("I", "O2"): 0.3}
+    out = make_ingroup_to_outgroup_alignments_0(job, "I", ["O1", "O2"], dict(seqs), dist, load_config())
+    text = open(str(out)).read()
+    full = {}
+    for v in paths.values():
+        full.update(pafcheck.read_fasta(str(v)))
+    recs = [pafcheck.parse_line(l) for l in text.splitlines()]
+    assert recs and all(r["tname"] == "id=I|chr1" and r["tlen"] == len(ingroup) for r in recs)      # inverted: ingroup is the target
+    n = pafcheck.check_paf(text, full, full)
+    cov = {"id=O1|chr1": np.zeros(len(ingroup), bool), "id=O2|chr1": np.zeros(len(ingroup), bool)}
+    for r in recs:
+        cov[r["qname"]][r["tstart"]:r["tend"]] = True
+    assert cov["id=O1|chr1"][:25000].mean() > 0.9 and cov["id=O1|chr1"][30000:].mean() < 0.01
+    assert cov["id=O2|chr1"][32000:].mean() > 0.9
+    # O2 was only offered what O1 left unaligned (plus 100 bp flanks): no O2 alignment deep inside O1's territory
+    assert cov["id=O2|chr1"][:20000].mean() < 0.01 and (cov["id=O1|chr1"] & cov["id=O2|chr1"]).sum() <= 2 * 100 * n
