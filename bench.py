@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--random-pair", action="store_true", help="pure-random pair (seed/ungapped isolation)")
     ap.add_argument("--cpu-sample", type=int, default=250_000, help="chunk size for the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--lastz-args", default=DEFAULT_ARGS)
+    ap.add_argument("--seed-leg", type=int, default=8_000_000,
+                    help="chunk size of the extra seed-stage leg on a pure-random pair (0 = skip); reported under seed_stage, never in value")
     a = ap.parse_args()
 
     import torch
@@ -146,12 +148,42 @@ def main():
                          "traffic_note": traffic_note,
                          "note": "the row-sweep integer DP is bound by per-row latency, not by HBM (SURVEY 8d caveat, DESIGN.md section 5)"},
         }
+        if a.seed_leg > 0 and not a.random_pair:
+            out["seed_stage"] = seed_stage_leg(a, pm, ctx)
         if a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(a, pm)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def seed_stage_leg(a, pm, ctx):
+    """seeds/s where it means something: the benchmark pair is dominated by a few long gapped extensions, so the seed
+    half of BASELINE.json's metric is measured on the pure-random variant of the recipe (SURVEY 8d "pure-random pair ...
+    to isolate seed/ungapped throughput"), large enough not to be launch bound.  One untimed + one timed job."""
+    from cactus_amd import gen
+    import numpy as np
+    n = a.seed_leg
+    rng = np.random.default_rng(43)
+    t, q = gen.random_sequence(n, rng), gen.random_sequence(n, rng)
+    T = ctx.seqset_from_fasta_bytes(gen.fasta_bytes([("id=randT|chr1", t)]))
+    Q = ctx.seqset_from_fasta_bytes(gen.fasta_bytes([("id=randQ|chr1", q)]))
+    ctx.align(T, Q, pm, details=False)
+    t0 = time.perf_counter()
+    r = ctx.align(T, Q, pm, details=False)
+    dt = time.perf_counter() - t0
+    s = r.stats
+    T.close(); Q.close()
+    hits, look = s["seed_hits"], s["seed_lookups"]
+    # algorithmic HBM bytes of the seed stage: index build 1*T + 4*T + 2*64 MiB; search 1*Q*S + 8 B per lookup
+    # + 4 B per hit read, 8 B per hit written; sort ~ 6 passes x 16 B per hit; ungapped 8 B per hit + 2 B per column
+    algo = (5.0 * n + 2 * 64 * 2**20) + (2.0 * n + 8.0 * look + 12.0 * hits) + 96.0 * hits + (8.0 * hits + 2.0 * s["ungapped_cols"])
+    return {"workload": f"{n} x {n} pure-random pair, seed 43, same lastz options", "seeds_per_s": hits / dt, "seed_lookups_per_s": look / dt,
+            "seconds": dt, "seed_hits": hits, "t_seed_s": s["t_seed"], "t_index_s": s["t_index"],
+            "kernel_ms": {"ungapped": s["t_ungapped_kernel_ms"], "sort": s["t_sort_ms"], "seed_fill": s["t_seedfill_ms"]},
+            "algorithmic_GBps": algo / max(1e-9, s["t_seed"] + s["t_index"]) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
+            "chance_alignments": s["alignments"], "gapped_gcells_per_s_kernel": s["dp_cells_run"] / max(1e-9, s["t_dp_kernel_ms"] * 1e-3) / 1e9}
 
 
 def cpu_baseline(a, pm):
