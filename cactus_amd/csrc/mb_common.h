@@ -39,7 +39,7 @@ struct DpProb {                               // one one-sided Y-drop DP (SURVEY
 struct DpOut {
     int32_t best, bi, bj, rows;
     int64_t cells;                            // cells evaluated (oracle counter dp_cells)
-    int64_t cells_to_bi;                      // unused (kept for layout stability)
+    int64_t clocks;                           // shader clocks spent in the row sweep (diagnostics)
     int32_t overflow;                         // 1: row wider than the LDS ring (rerun with HBM rows); 3: trace arena exhausted
     int32_t n_ops;                            // traceback: number of ops written
     long long prof[6];                        // MIBLAST_DP_PROFILE: shader clocks per phase of the row loop
@@ -83,7 +83,6 @@ void launch_index_words(const uint8_t *codes, int64_t n, int step, uint32_t *wor
                         hipStream_t s);
 void launch_index_scatter(const uint32_t *words, int64_t n_slots, int step, const uint32_t *offsets, uint32_t *cursor,
                           uint32_t *positions, hipStream_t s);
-void launch_sort_buckets(const uint32_t *offsets, uint32_t *positions, hipStream_t s);
 // exclusive scan of n u32 values; out may alias in; block_sums (u64, one per 2048 inputs) is scratch of
 // ceil(n/2048)+1 entries and on return holds the exclusive prefix of the per-block totals, total last.
 void launch_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, unsigned long long *block_sums, hipStream_t s);

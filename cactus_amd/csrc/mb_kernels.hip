@@ -792,7 +792,7 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
     if (!overflow) flush_rows(i - 1);
     if (tid == 0) {
         out->best = best; out->bi = bi; out->bj = bj; out->rows = rows;
-        out->cells = cells; out->cells_to_bi = clock64() - clk0; out->overflow = overflow; out->n_ops = 0;
+        out->cells = cells; out->clocks = clock64() - clk0; out->overflow = overflow; out->n_ops = 0;
         if (PROF) for (int k = 0; k < 6; k++) out->prof[k] = pf[k];
     }
 }

@@ -554,7 +554,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             for (int k = 0; k < np; k++) { st.dp_sides_run++; st.dp_cells_run += outs[(size_t)k].cells; st.dp_rows_run += outs[(size_t)k].rows; }
             if (debug) {
                 int maxrows = 0; long long cells = 0, clk = 0;
-                for (int k = 0; k < np; k++) { if (outs[(size_t)k].rows > maxrows) { maxrows = outs[(size_t)k].rows; clk = outs[(size_t)k].cells_to_bi; } cells += outs[(size_t)k].cells; }
+                for (int k = 0; k < np; k++) { if (outs[(size_t)k].rows > maxrows) { maxrows = outs[(size_t)k].rows; clk = outs[(size_t)k].clocks; } cells += outs[(size_t)k].cells; }
                 fprintf(stderr, "[miblast] round %d: %d sides, max rows %d (%lld shader clocks = %.0f per row), cells %lld, dp kernel total %.2f ms so far, shadow_q %ld\n",
                         round, np, maxrows, clk, (double)clk / std::max(1, maxrows), cells, st.t_dp_kernel_ms, shadow_q);
                 for (int k = 0; k < np; k++) if (outs[(size_t)k].rows == maxrows && outs[(size_t)k].prof[1]) {
