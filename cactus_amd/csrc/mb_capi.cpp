@@ -250,6 +250,26 @@ int miblast_align(miblast_ctx *ctx, const miblast_seqset *target, const miblast_
     });
 }
 
+int miblast_align_pairs(miblast_ctx *ctx, const miblast_seqset *const *targets, const miblast_seqset *const *queries, size_t n_pairs,
+                        const miblast_params *p, miblast_result **results) {
+    if (!ctx || !targets || !queries || !p || !results || n_pairs == 0) return MIBLAST_EINVAL;
+    for (size_t k = 0; k < n_pairs; k++) { results[k] = nullptr; if (!targets[k] || !queries[k]) return MIBLAST_EINVAL; }
+    return guarded([&]() -> int {
+        std::vector<const mb::SeqSet *> ts(n_pairs), qs(n_pairs);
+        std::vector<mb::Result *> rs(n_pairs);
+        std::vector<miblast_result *> owned(n_pairs, nullptr);
+        auto cleanup = [&]() { for (miblast_result *r : owned) delete r; };
+        int rc;
+        try {
+            for (size_t k = 0; k < n_pairs; k++) { owned[k] = new miblast_result(); ts[k] = &targets[k]->s; qs[k] = &queries[k]->s; rs[k] = &owned[k]->r; }
+            rc = mb::align_pairs(ctx->c, ts.data(), qs.data(), n_pairs, *p, rs.data());
+        } catch (...) { cleanup(); throw; }
+        if (rc != MIBLAST_OK) { cleanup(); return rc; }
+        for (size_t k = 0; k < n_pairs; k++) results[k] = owned[k];
+        return MIBLAST_OK;
+    });
+}
+
 void miblast_result_free(miblast_result *r) { delete r; }
 
 const char *miblast_result_paf(const miblast_result *r, size_t *len) {

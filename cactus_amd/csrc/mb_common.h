@@ -31,9 +31,13 @@ struct DpProb {                               // one one-sided Y-drop DP (SURVEY
     int32_t na, nb;                           // columns (target) / rows (query) available
     int32_t dir;                              // +1 forward from (t0,q0); -1 backward from (t0-1,q0-1)
     int32_t strand;                           // selects the query code array
-    int32_t pad0, pad1;
+    int32_t pad0, pad1;                       // pad0 = index of the chunk pair in the PairPtrs table
     uint64_t row_off;                         // index of this side's first row-chunk directory entry
     uint64_t ops_off;                         // traceback: index of this side's first run-length op (u32)
+};
+
+struct PairPtrs {                              // device pointers of one chunk pair's code arrays
+    const uint8_t *tc, *qf, *qr;              // target, query '+', query '-'
 };
 
 struct DpOut {
@@ -95,8 +99,8 @@ void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qto
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
                      const uint8_t *qcodes, int64_t qtot, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, hipStream_t s);
-void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const uint8_t *tc, const uint8_t *qf,
-                  const uint8_t *qr, int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
+void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
+                  int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s);
 void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
                       const unsigned long long *rowdir, uint32_t *ops, hipStream_t s);

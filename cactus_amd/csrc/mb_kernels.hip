@@ -799,15 +799,16 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
 
 template <bool GLOBAL_ROWS, bool PROF>
 __global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
-                                                      const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qf,
-                                                      const uint8_t *__restrict__ qr, int O, int E, int Y, int32_t *grows,
+                                                      const PairPtrs *__restrict__ pairs, int O, int E, int Y, int32_t *grows,
                                                       uint8_t *__restrict__ arena, unsigned long long arena_bytes,
                                                       unsigned long long *__restrict__ arena_next, unsigned blk_bytes,
                                                       unsigned long long *__restrict__ rowdir) {
     int pi = blockIdx.x;
     if (pi >= n) return;
     DpProb pr = probs[pi];
-    const uint8_t *qc = pr.strand ? qr : qf;
+    const PairPtrs pp = pairs[pr.pad0];
+    const uint8_t *tc = pp.tc;
+    const uint8_t *qc = pr.strand ? pp.qr : pp.qf;
     __shared__ YdShared sh;
     if (GLOBAL_ROWS) {
         int2 *CD = (int2 *)(grows + (size_t)pi * 2 * kGlobalRowCap);
@@ -821,15 +822,15 @@ __global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__
     }
 }
 
-void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const uint8_t *tc, const uint8_t *qf,
-                  const uint8_t *qr, int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
+void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
+                  int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s) {
     if (n <= 0) return;
     dim3 g((unsigned)n), b(kYdThreads);
     static const bool prof = getenv("MIBLAST_DP_PROFILE") != nullptr;
-    if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
-    else if (prof) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
-    else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, tc, qf, qr, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
+    if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
+    else if (prof) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
+    else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
 }
 
 // ------------------------------------------------------------------------------------------------

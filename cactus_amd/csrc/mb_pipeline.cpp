@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <unordered_map>
 
 namespace mb {
@@ -77,8 +78,8 @@ struct Cached {                // result of one anchor's two one-sided DPs
     std::vector<uint32_t> ops;           // merged run-length ops, forward order
 };
 
-struct Unit {                  // one (query contig, strand): anchors are committed strictly in order
-    int strand = 0, q_contig = 0;
+struct Unit {                  // one (pair, query contig, strand): anchors are committed strictly in order
+    int pair = 0, strand = 0, q_contig = 0;
     std::vector<Anchor> anchors;
     size_t next = 0;           // first anchor not yet committed
     std::unordered_map<size_t, Cached> cache;
@@ -157,6 +158,7 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<unsigned long long> rowdir;
     DevBuf<uint32_t> ops;
     DevBuf<int> which;
+    DevBuf<PairPtrs> pair_ptrs;
 };
 
 Workspace *workspace_create() { return new Workspace(); }
@@ -200,11 +202,10 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
 }
 
 static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, bool global_rows, const DpProb *probs, DpOut *outs, int n,
-                            const uint8_t *tc, const uint8_t *qf, const uint8_t *qr, const miblast_params &p,
-                            unsigned blk_bytes) {
+                            const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes) {
     Workspace &g = *ctx.ws;
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
-    launch_ydrop(global_rows, probs, outs, n, tc, qf, qr, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
+    launch_ydrop(global_rows, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
                  (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, ctx.stream);
     MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     MB_HIP(hipEventSynchronize(ctx.ev1));
@@ -214,12 +215,24 @@ static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, bool global_rows, const
     st.dp_kernel_launches++;
 }
 
-int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin, Result &res) {
-    MB_HIP(hipSetDevice(ctx.device));
+struct PairJob {                          // one chunk pair of a (possibly batched) call
+    const SeqSet *T = nullptr, *Q = nullptr;
+    Result *res = nullptr;
+    bool use_ws_rc = true;                // pair 0 keeps its '-' strand in the persistent workspace
+    DevBuf<uint8_t> own_rc;
+    std::vector<uint8_t> h_rc;
+    const uint8_t *tc_h = nullptr;
+    const uint8_t *qc_h[2] = {nullptr, nullptr};
+    const uint8_t *qc_d[2] = {nullptr, nullptr};
+    std::vector<miblast_hsp> strand_hsps[2];
+    double t_begin = 0;
+};
+
+// index build + seed search + ungapped extension + HSP filters of one pair (uses the shared seed workspace)
+static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     hipStream_t s = ctx.stream;
-    miblast_params p = pin;
-    if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
-    if (p.step < 1) p.step = 1;
+    const SeqSet &T = *job.T, &Q = *job.Q;
+    Result &res = *job.res;
     if (T.device != ctx.device || Q.device != ctx.device) { set_error("sequence set lives on another device"); return MIBLAST_EINVAL; }
     if (T.total + Q.total + 4 >= (int64_t)0x7fffffff) {
         set_error("target+query longer than 2^31-1 bases: chunk the input (Cactus chunkSize is 30 Mb)");
@@ -228,6 +241,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     miblast_stats &st = res.stats;
     memset(&st, 0, sizeof st);
     const double t_begin = now_s();
+    job.t_begin = t_begin;
     const int nvar = p.transitions ? 1 + kSeedWeight : 1;
     const int64_t qtot = Q.total, ttot = T.total;
 
@@ -238,16 +252,19 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     st.t_index = now_s() - t_begin;
 
     // ---- '-' strand of the query -----------------------------------------------------------------
-    DevBuf<uint8_t> &d_rc = w.rc;
+    DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : job.own_rc;
     d_rc.ensure((size_t)qtot + 2 * kDevPad);
     MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
     launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
-    std::vector<uint8_t> h_rc((size_t)qtot + 2);
+    std::vector<uint8_t> &h_rc = job.h_rc;
+    h_rc.assign((size_t)qtot + 2, 0);
     MB_HIP(hipMemcpyAsync(h_rc.data(), d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
     MB_HIP(hipStreamSynchronize(s));
-    const uint8_t *tc_h = T.host();
-    const uint8_t *qc_h[2] = {Q.host(), h_rc.data() + 1};
-    const uint8_t *qc_d[2] = {Q.dev(), d_rc.p + kDevPad};
+    job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc.data() + 1;
+    job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
+    const uint8_t *tc_h = job.tc_h;
+    const uint8_t *const *qc_h = job.qc_h;
+    const uint8_t *const *qc_d = job.qc_d;
 
     // ---- seed search + ungapped extension, per strand ----------------------------------------------
     const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
@@ -264,7 +281,8 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     DevBuf<UngappedCounters> &d_ctr = w.ctr;
     d_ctr.ensure(1);
     std::vector<unsigned long long> h_qbsum((size_t)n_qblk + 2);
-    std::vector<miblast_hsp> strand_hsps[2];
+    std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
+    strand_hsps[0].clear(); strand_hsps[1].clear();
 
     for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
         const double t0 = now_s();
@@ -390,9 +408,16 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     }
     for (int strand = 0; strand < 2; strand++) res.hsps.insert(res.hsps.end(), strand_hsps[strand].begin(), strand_hsps[strand].end());
 
-    // ---- gapped extension ----------------------------------------------------------------------------
-    const double t_g0 = now_s();
-    std::vector<Unit> units;
+    return MIBLAST_OK;
+}
+
+// anchors of one pair, one unit per (query contig, strand), sorted by (-score, t, q)  
+static void build_units(const miblast_params &p, PairJob &job, int pair, std::vector<Unit> &units) {
+    const SeqSet &Q = *job.Q;
+    miblast_stats &st = job.res->stats;
+    const uint8_t *tc_h = job.tc_h;
+    const uint8_t *const *qc_h = job.qc_h;
+    std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
     if (p.gapped) {
         for (int strand = 0; strand < 2; strand++) {
             std::vector<std::vector<Anchor>> per((size_t)Q.starts.size());
@@ -417,7 +442,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             for (size_t qc_i = 0; qc_i < per.size(); qc_i++) {
                 if (per[qc_i].empty()) continue;
                 Unit u;
-                u.strand = strand; u.q_contig = (int)qc_i;
+                u.pair = pair; u.strand = strand; u.q_contig = (int)qc_i;
                 u.anchors.swap(per[qc_i]);
                 std::sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
                     if (a.score != b.score) return a.score > b.score;
@@ -429,13 +454,23 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             }
         }
     }
+}
+
+// score-ordered gapped extension of every unit of every pair of the batch: all speculative one-sided DPs of a round
+// share one k_ydrop launch, so several chunk pairs fill the GPU together
+static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, std::vector<Unit> &units) {
     const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 4096);
     const long shadow_q0 = env_long("MIBLAST_SHADOW_Q", 1 << 16);        // spatial thinning of speculative anchors
-    const long spec_target = env_long("MIBLAST_SPEC_TARGET", 24);        // anchors per round the thinning aims at
+    const long spec_target = env_long("MIBLAST_SPEC_TARGET", 24) * (long)std::max<size_t>(1, jobs.size());   // anchors per round the thinning aims at
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
     Workspace &g = *ctx.ws;
+    hipStream_t s = ctx.stream;
+    miblast_stats st;                        // launch-level counters shared by all pairs of the batch
+    memset(&st, 0, sizeof st);
+    const double t_g0 = now_s();
+    auto PS = [&](const Unit &u) -> miblast_stats & { return jobs[(size_t)u.pair]->res->stats; };
     if (!units.empty()) {
         size_t want = (size_t)env_long("MIBLAST_ARENA_MB", 2048) << 20;
         if (g.arena.n < want) g.arena.alloc(want);
@@ -449,15 +484,15 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
             Unit &u = units[ui];
             while (u.next < u.anchors.size()) {
                 const Anchor &a = u.anchors[u.next];
-                if (covered(u, a)) { st.anchors_skipped++; u.cache.erase(u.next); u.next++; continue; }
+                if (covered(u, a)) { PS(u).anchors_skipped++; u.cache.erase(u.next); u.next++; continue; }
                 auto it = u.cache.find(u.next);
                 if (it == u.cache.end()) break;
                 Cached &c = it->second;
-                st.dp_sides += 2; st.dp_cells += c.cells; st.dp_rows += c.rows;
+                PS(u).dp_sides += 2; PS(u).dp_cells += c.cells; PS(u).dp_rows += c.rows;
                 if (c.accepted) {
                     miblast_aln A;
                     memset(&A, 0, sizeof A);
-                    A.strand = u.strand; A.q_contig = u.q_contig; A.t_contig = T.contig_of(a.t);
+                    A.strand = u.strand; A.q_contig = u.q_contig; A.t_contig = jobs[(size_t)u.pair]->T->contig_of(a.t);
                     A.t_lo = c.t_lo; A.t_hi = c.t_hi; A.q_lo = c.q_lo; A.q_hi = c.q_hi;
                     A.score = c.score; A.dmin = c.dmin; A.dmax = c.dmax; A.anchor_t = a.t; A.anchor_q = a.q;
                     A.ops_off = (int64_t)u.unit_ops.size(); A.n_ops = (int64_t)c.ops.size();
@@ -512,13 +547,14 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
         for (size_t k = 0; k < pend.size(); k++) {
             const Unit &u = units[pend[k].unit];
             const Anchor &a = u.anchors[pend[k].anchor];
+            const SeqSet &T = *jobs[(size_t)u.pair]->T, &Q = *jobs[(size_t)u.pair]->Q;
             int tcg = T.contig_of(a.t);
             int64_t tlo = T.starts[(size_t)tcg], thi = tlo + T.lens[(size_t)tcg];
             int64_t qlo = Q.starts[(size_t)u.q_contig], qhi = qlo + Q.lens[(size_t)u.q_contig];
             DpProb &r = probs[2 * k], &l = probs[2 * k + 1];
             memset(&r, 0, sizeof r); memset(&l, 0, sizeof l);
-            r.t0 = a.t; r.q0 = a.q; r.dir = +1; r.na = (int32_t)(thi - a.t); r.nb = (int32_t)(qhi - a.q); r.strand = u.strand;
-            l.t0 = a.t; l.q0 = a.q; l.dir = -1; l.na = (int32_t)(a.t - tlo); l.nb = (int32_t)(a.q - qlo); l.strand = u.strand;
+            r.t0 = a.t; r.q0 = a.q; r.dir = +1; r.na = (int32_t)(thi - a.t); r.nb = (int32_t)(qhi - a.q); r.strand = u.strand; r.pad0 = u.pair;
+            l.t0 = a.t; l.q0 = a.q; l.dir = -1; l.na = (int32_t)(a.t - tlo); l.nb = (int32_t)(a.q - qlo); l.strand = u.strand; l.pad0 = u.pair;
             r.row_off = dir_entries; dir_entries += (uint64_t)(r.nb / 4096) + 2;
             l.row_off = dir_entries; dir_entries += (uint64_t)(l.nb / 4096) + 2;
         }
@@ -527,7 +563,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
         while (true) {                                   // retried with a larger arena if the trace does not fit
             MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
-            run_ydrop_timed(ctx, st, false, g.probs.p, g.outs.p, np, T.dev(), qc_d[0], qc_d[1], p, kBlk);
+            run_ydrop_timed(ctx, st, false, g.probs.p, g.outs.p, np, g.pair_ptrs.p, p, kBlk);
             MB_HIP(hipMemcpy(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost));
             // rows wider than the LDS ring: rerun those sides with the C/D ring in HBM (arena keeps filling)
             std::vector<int> wide;
@@ -541,7 +577,7 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 DevBuf<DpProb> dwp(wp.size()); DevBuf<DpOut> dwo(wp.size());
                 g.grows.ensure(wp.size() * 2 * (size_t)kGlobalRowCap);
                 MB_HIP(hipMemcpy(dwp.p, wp.data(), wp.size() * sizeof(DpProb), hipMemcpyHostToDevice));
-                run_ydrop_timed(ctx, st, true, dwp.p, dwo.p, (int)wp.size(), T.dev(), qc_d[0], qc_d[1], p, kBlkWide);
+                run_ydrop_timed(ctx, st, true, dwp.p, dwo.p, (int)wp.size(), g.pair_ptrs.p, p, kBlkWide);
                 std::vector<DpOut> wo(wp.size());
                 MB_HIP(hipMemcpy(wo.data(), dwo.p, wp.size() * sizeof(DpOut), hipMemcpyDeviceToHost));
                 for (size_t k = w0; k < w1; k++) {
@@ -620,7 +656,8 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
                 Cached &c = u.cache[pend[k].anchor];
                 const uint32_t *Rops = hops.data() + probs[2 * k].ops_off, *Lops = hops.data() + probs[2 * k + 1].ops_off;
                 const size_t nR = (size_t)outs[2 * k].n_ops, nL = (size_t)outs[2 * k + 1].n_ops;
-                const uint8_t *qc = qc_h[u.strand];
+                const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
+                const uint8_t *qc = jobs[(size_t)u.pair]->qc_h[u.strand];
                 int64_t tt = c.t_lo, qq = c.q_lo;
                 int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
                 uint32_t cur_op = 0, cur_len = 0;
@@ -649,12 +686,25 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
         }
     }
     st.t_gapped = now_s() - t_g0;
+    for (PairJob *j : jobs) {                // launch-level figures are shared by the pairs that were in flight together
+        miblast_stats &d = j->res->stats;
+        d.t_gapped = st.t_gapped; d.gapped_rounds = st.gapped_rounds; d.dp_sides_run = st.dp_sides_run; d.dp_cells_run = st.dp_cells_run;
+        d.dp_rows_run = st.dp_rows_run; d.t_dp_kernel_ms = st.t_dp_kernel_ms; d.dp_kernel_launches = st.dp_kernel_launches;
+    }
+    return MIBLAST_OK;
 
+}
+
+// PAF (or the general HSP format) of one pair, in the reference's output order
+static void output_phase(const miblast_params &p, PairJob &job, int pair, std::vector<Unit> &units) {
+    const SeqSet &T = *job.T, &Q = *job.Q;
+    Result &res = *job.res;
+    miblast_stats &st = res.stats;
     // ---- output: per query contig, '+' then '-', commit order ------------------------------
     for (int qc_i = 0; qc_i < (int)Q.starts.size(); qc_i++)
         for (int strand = 0; strand < 2; strand++)
             for (Unit &u : units) {
-                if (u.q_contig != qc_i || u.strand != strand) continue;
+                if (u.pair != pair || u.q_contig != qc_i || u.strand != strand) continue;
                 for (miblast_aln A : u.kept) {
                     int64_t off = (int64_t)res.ops.size();
                     res.ops.insert(res.ops.end(), u.unit_ops.begin() + A.ops_off, u.unit_ops.begin() + A.ops_off + A.n_ops);
@@ -727,8 +777,43 @@ int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin,
     }
     if (p.markend) res.paf += "# lastz end-of-file\n";
     if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast] PAF formatting: %.2f ms; index %.2f ms, seed %.2f ms, gapped %.2f ms\n", (now_s() - t_out0) * 1e3, st.t_index * 1e3, st.t_seed * 1e3, st.t_gapped * 1e3);
-    st.t_total = now_s() - t_begin;
+    st.t_total = now_s() - job.t_begin;
+}
+
+int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
+    MB_HIP(hipSetDevice(ctx.device));
+    miblast_params p = pin;
+    if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
+    if (p.step < 1) p.step = 1;
+    std::vector<std::unique_ptr<PairJob>> store;
+    std::vector<PairJob *> jobs;
+    std::vector<Unit> units;
+    for (size_t k = 0; k < n; k++) {
+        store.emplace_back(new PairJob());
+        PairJob &j = *store.back();
+        j.T = Ts[k]; j.Q = Qs[k]; j.res = results[k]; j.use_ws_rc = (k == 0);
+        jobs.push_back(&j);
+        int rc = seed_phase(ctx, p, j);
+        if (rc != MIBLAST_OK) return rc;
+        build_units(p, j, (int)k, units);
+    }
+    // device table of the pairs' sequence pointers (k_ydrop picks its pair through DpProb.pad0)
+    if (!units.empty()) {
+        std::vector<PairPtrs> pp(n);
+        for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }
+        ctx.ws->pair_ptrs.ensure(n);
+        MB_HIP(hipMemcpy(ctx.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), hipMemcpyHostToDevice));
+    }
+    int rc = gapped_phase(ctx, p, jobs, units);
+    if (rc != MIBLAST_OK) return rc;
+    for (size_t k = 0; k < n; k++) output_phase(p, *jobs[k], (int)k, units);
     return MIBLAST_OK;
+}
+
+int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin, Result &res) {
+    const SeqSet *tp = &T, *qp = &Q;
+    Result *rp = &res;
+    return align_pairs(ctx, &tp, &qp, 1, pin, &rp);
 }
 
 }  // namespace mb

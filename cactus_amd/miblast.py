@@ -80,6 +80,7 @@ def load() -> C.CDLL:
         "miblast_seqset_start": (i64, [vp, i32]),
         "miblast_seqset_len": (i64, [vp, i32]),
         "miblast_align": (C.c_int, [vp, vp, vp, P(Params), P(vp)]),
+        "miblast_align_pairs": (C.c_int, [vp, P(vp), P(vp), C.c_size_t, P(Params), P(vp)]),
         "miblast_result_free": (None, [vp]),
         "miblast_result_paf": (vp, [vp, P(C.c_size_t)]),
         "miblast_result_stats": (P(Stats), [vp]),
@@ -102,7 +103,7 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_ctx_create",
                     "miblast_ctx_destroy", "miblast_seqset_from_fasta_file", "miblast_seqset_from_fasta_mem",
                     "miblast_seqset_free", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
-                    "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_result_free",
+                    "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_align_pairs", "miblast_result_free",
                     "miblast_result_paf", "miblast_result_stats", "miblast_result_hsps", "miblast_result_alns",
                     "miblast_result_ops", "miblast_align_files", "miblast_build_index", "miblast_free",
                     "miblast_last_error", "miblast_version")
@@ -215,6 +216,40 @@ class Context:
             return AlignResult(paf, stats, hsps, alns, ops)
         finally:
             lib.miblast_result_free(r)
+
+    def _unpack(self, r, details: bool) -> AlignResult:
+        lib = load()
+        n = C.c_size_t()
+        ptr = lib.miblast_result_paf(r, C.byref(n))
+        paf = C.string_at(ptr, n.value) if n.value else b""
+        stats = lib.miblast_result_stats(r).contents.as_dict()
+        hsps = alns = ops = []
+        if details:
+            k = C.c_int64()
+            hp = lib.miblast_result_hsps(r, C.byref(k))
+            hsps = [(h.strand, h.q_contig, h.t_start, h.q_start, h.len, h.score, h.seed_t_end, h.seed_q_end, tuple(h.cnt))
+                    for h in (hp[i] for i in range(k.value))]
+            ap = lib.miblast_result_alns(r, C.byref(k))
+            raw = [ap[i] for i in range(k.value)]
+            alns = [(a.strand, a.q_contig, a.t_contig, a.t_lo, a.t_hi, a.q_lo, a.q_hi, a.score, a.dmin, a.dmax,
+                     a.anchor_t, a.anchor_q, a.n_ops) for a in raw]
+            op = lib.miblast_result_ops(r, C.byref(k))
+            ops = [[op[a.ops_off + j] for j in range(a.n_ops)] for a in raw] if k.value < 5_000_000 else []
+        return AlignResult(paf, stats, hsps, alns, ops)
+
+    def align_pairs(self, pairs, params: Params, details: bool = False):
+        """pairs: list of (target SeqSet, query SeqSet); one batched call, gapped stages merged on the GPU."""
+        lib = load()
+        n = len(pairs)
+        ts = (C.c_void_p * n)(*[t._h for t, _ in pairs])
+        qs = (C.c_void_p * n)(*[q._h for _, q in pairs])
+        rs = (C.c_void_p * n)()
+        _check(lib.miblast_align_pairs(self._h, ts, qs, n, C.byref(params), rs))
+        try:
+            return [self._unpack(C.c_void_p(rs[i]), details) for i in range(n)]
+        finally:
+            for i in range(n):
+                lib.miblast_result_free(C.c_void_p(rs[i]))
 
     def build_index(self, target: SeqSet, step: int):
         """Returns (offsets, positions) as numpy arrays (seed position table, CSR over 2^24 words)."""

@@ -128,6 +128,12 @@ typedef struct miblast_result miblast_result;
  * (local_alignment.py:65-73).  Output order and bytes follow SURVEY.md Appendix B / A.8.       */
 int miblast_align(miblast_ctx *ctx, const miblast_seqset *target, const miblast_seqset *query,
                   const miblast_params *p, miblast_result **out);
+/* Several chunk pairs of one GPU in one call (the reference runs one lastz process per pair and lets Toil put many of
+ * them on a node, local_alignment.py:395-405).  Seed stages run back to back; the gapped stages are merged, so the
+ * speculative DPs of all pairs share kernel launches and fill the GPU together.  results[i] is byte-identical to what
+ * miblast_align(targets[i], queries[i]) returns.                                                  */
+int miblast_align_pairs(miblast_ctx *ctx, const miblast_seqset *const *targets, const miblast_seqset *const *queries,
+                        size_t n_pairs, const miblast_params *p, miblast_result **results);
 void miblast_result_free(miblast_result *r);
 /* PAF text that the reference reads from the process's stdout (common.py:875-878).            */
 const char *miblast_result_paf(const miblast_result *r, size_t *len);

@@ -265,3 +265,21 @@ def test_ingroup_to_outgroup_trimming_chain(gpu_ctx, tmp_path):
     assert cov["id=O2|chr1"][32000:].mean() > 0.9
     # O2 was only offered what O1 left unaligned (plus 100 bp flanks): no O2 alignment deep inside O1's territory
     assert cov["id=O2|chr1"][:20000].mean() < 0.01 and (cov["id=O1|chr1"] & cov["id=O2|chr1"]).sum() <= 2 * 100 * n
+
+
+def test_batched_pairs_equal_single_calls(gpu_ctx):
+    """miblast_align_pairs: several chunk pairs in one call (merged gapped launches) must return, pair by pair, exactly
+    the bytes and counters of separate miblast_align calls -- including pairs with no alignment and different contig sets."""
+    from cases import CASES, DEFAULT
+    from cactus_amd import miblast
+    pm = miblast.params_from_args(DEFAULT)
+    chosen = [c for c in CASES if c[0] in ("homolog_20k_default", "random_50k", "multi_contig_ragged", "tandem_repeats", "revcomp_query", "empty_query")]
+    sets = [(gpu_ctx.seqset_from_fasta_bytes(c[1]), gpu_ctx.seqset_from_fasta_bytes(c[2])) for c in chosen]
+    single = [gpu_ctx.align(t, q, pm) for t, q in sets]
+    batched = gpu_ctx.align_pairs(sets, pm, details=True)
+    assert len(batched) == len(single)
+    for name, a, b in zip([c[0] for c in chosen], single, batched):
+        assert a.paf == b.paf, name
+        assert a.hsps == b.hsps and a.alns == b.alns and a.ops == b.ops, name
+        for k in ("seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "anchors_skipped", "dp_sides", "dp_cells", "dp_rows", "alignments"):
+            assert a.stats[k] == b.stats[k], (name, k)
