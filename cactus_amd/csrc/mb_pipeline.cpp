@@ -85,24 +85,29 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
     std::unordered_map<size_t, Cached> cache;
     std::vector<miblast_aln> kept;          // ops_off indexes unit_ops
     std::vector<uint32_t> unit_ops;
-};
+    // coverage bookkeeping: anchors indexed by q so that an alignment only visits the anchors inside its q range
+    // (units of a 30 Mb chunk pair hold up to --queryhspbest=100000 anchors and thousands of alignments)
+    std::vector<uint32_t> by_q;             // anchor indices sorted by q
+    std::vector<uint8_t> cov;               // covered by a COMMITTED alignment (the rule of SURVEY A.10 GAPPED)
+    std::vector<uint8_t> tent;              // would be covered by an accepted, not yet committed result (heuristic only)
 
-bool covered(const Unit &u, const Anchor &a) {
-    int32_t d = a.t - a.q;
-    for (const miblast_aln &A : u.kept)
-        if (a.t >= A.t_lo && a.t < A.t_hi && a.q >= A.q_lo && a.q < A.q_hi && d >= A.dmin && d <= A.dmax) return true;
-    return false;
-}
-
-// heuristic only (never affects results): would `a` be covered if the not-yet-committed accepted results were kept?
-bool tentatively_covered(const Unit &u, const Anchor &a) {
-    int32_t d = a.t - a.q;
-    for (const auto &kv : u.cache) {
-        const Cached &c = kv.second;
-        if (c.accepted && a.t >= c.t_lo && a.t < c.t_hi && a.q >= c.q_lo && a.q < c.q_hi && d >= c.dmin && d <= c.dmax) return true;
+    void index_anchors() {
+        by_q.resize(anchors.size());
+        for (size_t k = 0; k < by_q.size(); k++) by_q[k] = (uint32_t)k;
+        std::sort(by_q.begin(), by_q.end(), [&](uint32_t x, uint32_t y) { return anchors[x].q < anchors[y].q; });
+        cov.assign(anchors.size(), 0);
+        tent.assign(anchors.size(), 0);
     }
-    return false;
-}
+    // marks every anchor inside the bounding box and diagonal band of an alignment
+    void mark(std::vector<uint8_t> &flags, int32_t t_lo, int32_t t_hi, int32_t q_lo, int32_t q_hi, int32_t dmin, int32_t dmax) {
+        auto it = std::lower_bound(by_q.begin(), by_q.end(), q_lo, [&](uint32_t x, int32_t q) { return anchors[x].q < q; });
+        for (; it != by_q.end() && anchors[*it].q < q_hi; ++it) {
+            const Anchor &a = anchors[*it];
+            const int32_t d = a.t - a.q;
+            if (a.t >= t_lo && a.t < t_hi && d >= dmin && d <= dmax) flags[*it] = 1;
+        }
+    }
+};
 
 long env_long(const char *name, long dflt) {
     const char *v = getenv(name);
@@ -450,6 +455,7 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                     return a.q < b.q;
                 });
                 st.anchors += (int64_t)u.anchors.size();
+                u.index_anchors();
                 units.push_back(std::move(u));
             }
         }
@@ -484,7 +490,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             Unit &u = units[ui];
             while (u.next < u.anchors.size()) {
                 const Anchor &a = u.anchors[u.next];
-                if (covered(u, a)) { PS(u).anchors_skipped++; u.cache.erase(u.next); u.next++; continue; }
+                if (u.cov[u.next]) { PS(u).anchors_skipped++; u.cache.erase(u.next); u.next++; continue; }
                 auto it = u.cache.find(u.next);
                 if (it == u.cache.end()) break;
                 Cached &c = it->second;
@@ -498,6 +504,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     A.ops_off = (int64_t)u.unit_ops.size(); A.n_ops = (int64_t)c.ops.size();
                     u.unit_ops.insert(u.unit_ops.end(), c.ops.begin(), c.ops.end());
                     u.kept.push_back(A);
+                    u.mark(u.cov, A.t_lo, A.t_hi, A.q_lo, A.q_hi, A.dmin, A.dmax);
                 }
                 u.cache.erase(it);
                 u.next++;
@@ -509,6 +516,13 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // new anchor per (diagonal band, query neighbourhood).  The neighbourhood is the smallest of a 4x ladder that
         // keeps the batch within `spec_target` anchors, so an idle GPU is filled with probes in the first round (a
         // single one-sided DP is a row-sequential chain: rounds cost latency, parallel probes cost almost nothing).
+        for (Unit &u : units) {
+            std::fill(u.tent.begin(), u.tent.end(), 0);
+            for (const auto &kv : u.cache) {
+                const Cached &c = kv.second;
+                if (c.accepted) u.mark(u.tent, c.t_lo, c.t_hi, c.q_lo, c.q_hi, c.dmin, c.dmax);
+            }
+        }
         std::vector<Pending> pend;
         long shadow_q = shadow_q0;
         for (int level = 0; level < 6; level++) {
@@ -516,19 +530,30 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             const long sq = std::max(64l, shadow_q0 >> (2 * level));
             for (size_t ui = 0; ui < units.size(); ui++) {
                 Unit &u = units[ui];
-                std::vector<Anchor> taken;
-                for (size_t k = u.next; k < u.anchors.size() && taken.size() < batch_max; k++) {
-                    if (u.cache.count(k)) continue;
+                // taken anchors are bucketed on a (diagonal band, query neighbourhood) grid: the shadow test looks at 3x3 cells
+                std::unordered_map<long long, std::vector<Anchor>> grid;
+                size_t n_taken = 0;
+                auto cell = [&](const Anchor &a, long dd, long dq) -> long long {
+                    const long gd = ((long)(a.t - a.q) + (1l << 31)) / (shadow_d + 1) + dd, gq = (long)a.q / (sq + 1) + dq;
+                    return (long long)gd * (1ll << 32) + gq;
+                };
+                for (size_t k = u.next; k < u.anchors.size() && n_taken < batch_max; k++) {
+                    if (u.cov[k] || u.cache.count(k)) continue;
                     const Anchor &a = u.anchors[k];
-                    if (covered(u, a)) continue;
                     if (k != u.next) {
-                        if (tentatively_covered(u, a)) continue;
+                        if (u.tent[k]) continue;
                         bool shadowed = false;
-                        for (const Anchor &b : taken)
-                            if (std::labs((long)(a.t - a.q) - (long)(b.t - b.q)) <= shadow_d && std::labs((long)a.q - (long)b.q) <= sq) { shadowed = true; break; }
+                        for (long dd = -1; dd <= 1 && !shadowed; dd++)
+                            for (long dq = -1; dq <= 1 && !shadowed; dq++) {
+                                auto it = grid.find(cell(a, dd, dq));
+                                if (it == grid.end()) continue;
+                                for (const Anchor &b : it->second)
+                                    if (std::labs((long)(a.t - a.q) - (long)(b.t - b.q)) <= shadow_d && std::labs((long)a.q - (long)b.q) <= sq) { shadowed = true; break; }
+                            }
                         if (shadowed) continue;
                     }
-                    taken.push_back(a);
+                    grid[cell(a, 0, 0)].push_back(a);
+                    n_taken++;
                     cand.push_back(Pending{ui, k});
                 }
             }
