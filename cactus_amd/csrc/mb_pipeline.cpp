@@ -478,7 +478,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const double t_g0 = now_s();
     auto PS = [&](const Unit &u) -> miblast_stats & { return jobs[(size_t)u.pair]->res->stats; };
     if (!units.empty()) {
-        size_t want = (size_t)env_long("MIBLAST_ARENA_MB", 2048) << 20;
+        size_t want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
         if (g.arena.n < want) g.arena.alloc(want);
         g.arena_next.ensure(1);
     }
@@ -627,7 +627,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
             }
             if (!arena_full) break;
-            size_t bigger = g.arena.n * 2;
+            size_t bigger = g.arena.n * 4;                 // few retries: every retry repeats the round
             size_t free_b = 0, total_b = 0;
             MB_HIP(hipMemGetInfo(&free_b, &total_b));
             if (bigger > free_b + g.arena.n - (1ull << 30)) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
