@@ -300,7 +300,7 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *p) {
 // Heads of the diagonal runs of the sorted hit keys, compacted into two lists: runs of at most kLongRun hits go to
 // the lane-per-run kernel, longer ones (busy diagonals of real homology: hundreds to millions of hits, almost all of
 // them suppressed) to the wave-per-run kernel.  One atomic pair per 1024-key block; list order is irrelevant.
-constexpr int kLongRun = 12;
+constexpr int kLongRun = 32;                  // equal cost to 12 on random data; 4 is 7x slower (wave-per-run has a fixed cost)
 
 __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits,
                                                     unsigned *__restrict__ heads_short, unsigned *__restrict__ heads_long,
@@ -711,7 +711,8 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
             const int idx = j & mask;
             const int2 cd = CD[idx];
             int cpl = CD[(j - 1) & mask].x;
-            const unsigned t = GLOBAL ? (unsigned)tc[dir > 0 ? t0 + max(j, 1) - 1 : t0 - max(j, 1)] : (unsigned)Tb[idx];
+            const int jc = min(max(j, 1), max(na, 1));                   // lanes past the contig end must not read past the buffer
+            const unsigned t = GLOBAL ? (unsigned)tc[dir > 0 ? t0 + jc - 1 : t0 - jc] : (unsigned)Tb[idx];
             const bool inwin = j < RY;
             const int cp = inwin ? cd.x : kNeg;
             const int dp = inwin ? cd.y : kNeg;
@@ -841,6 +842,7 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
 // Output: run-length ops (len << 2 | op) in walk-back order; op 0 aligned pair, 2 query-only, 3 target-only.
 __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ probs, DpOut *__restrict__ outs,
                                                   const int *__restrict__ which, int n, const uint8_t *__restrict__ arena,
+                                                  const unsigned long long arena_bytes,
                                                   const unsigned long long *__restrict__ rowdir, uint32_t *__restrict__ ops) {
     const int slot = blockIdx.x;
     if (slot >= n) return;
@@ -883,7 +885,9 @@ __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ pro
             for (int k = 0; k < 8; k++) {
                 const int c = wc0 + k;
                 unsigned b = 0xFFu;                             // never a diagonal source: stops runs left of the row
-                if (c >= wly) b = rowp[c - wly];               // bytes right of the stored row are never consulted
+                // bytes right of the stored row are never consulted, but a long gap can put the predicted column far
+                // beyond it: never read past the arena
+                if (c >= wly && ri.off + (unsigned long long)(c - wly) < arena_bytes) b = rowp[c - wly];
                 win |= (unsigned long long)b << (8 * k);
             }
         } else win = ~0ull;
@@ -916,9 +920,9 @@ __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ pro
 }
 
 void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
-                      const unsigned long long *rowdir, uint32_t *ops, hipStream_t s) {
+                      unsigned long long arena_bytes, const unsigned long long *rowdir, uint32_t *ops, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, probs, outs, which, n, arena, rowdir, ops);
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, probs, outs, which, n, arena, arena_bytes, rowdir, ops);
 }
 
 }  // namespace mb

@@ -312,7 +312,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             hit_off.ensure((size_t)(q1 - q0));
             keys_a.ensure((size_t)nh); keys_b.ensure((size_t)nh);
             d_hsps.ensure((size_t)nh);
-            w.heads.ensure((size_t)nh + (size_t)nh / 12 + 8); w.n_heads.ensure(2);
+            w.heads.ensure((size_t)nh + (size_t)nh / 4 + 8); w.n_heads.ensure(2);
             size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev0, s));
@@ -627,10 +627,12 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
             }
             if (!arena_full) break;
-            size_t bigger = g.arena.n * 4;                 // few retries: every retry repeats the round
             size_t free_b = 0, total_b = 0;
             MB_HIP(hipMemGetInfo(&free_b, &total_b));
-            if (bigger > free_b + g.arena.n - (1ull << 30)) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
+            const size_t room = free_b + g.arena.n > (2ull << 30) ? free_b + g.arena.n - (2ull << 30) : 0;   // leave 2 GiB for the rest
+            size_t bigger = std::min(g.arena.n * 4, room);      // few retries: every retry repeats the round
+            if (bigger <= g.arena.n) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
+            g.arena.release();                                  // free first: old + new need not coexist
             g.arena.alloc(bigger);
         }
 
@@ -663,7 +665,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             g.which.ensure(which.size()); g.ops.ensure((size_t)ooff + 64);
             MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
             MB_HIP(hipMemcpyAsync(g.which.p, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, s));
-            launch_traceback(g.probs.p, g.outs.p, g.which.p, (int)which.size(), g.arena.p, g.rowdir.p, g.ops.p, s);
+            launch_traceback(g.probs.p, g.outs.p, g.which.p, (int)which.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, s);
             std::vector<uint32_t> hops((size_t)ooff + 1);
             MB_HIP(hipMemcpyAsync(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));

@@ -283,3 +283,14 @@ def test_batched_pairs_equal_single_calls(gpu_ctx):
         assert a.hsps == b.hsps and a.alns == b.alns and a.ops == b.ops, name
         for k in ("seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "anchors_skipped", "dp_sides", "dp_cells", "dp_rows", "alignments"):
             assert a.stats[k] == b.stats[k], (name, k)
+
+
+def test_randomised_differential_fuzz():
+    """A slice of scripts/gpu_fuzz.py (random structures x random lastz options, GPU vs oracle byte for byte).  The
+    full script found two real bugs during development (x-drop stop exactly at lane 63 of the wave-parallel extension;
+    an out-of-bounds base read past the contig end in the HBM-ring DP variant)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz.py"), "30", "5000"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "30 cases, 0 mismatches" in p.stdout
