@@ -22,14 +22,15 @@ namespace mb {
 // ------------------------------------------------------------------------------------------------
 // substitution score on code bytes: HOXD70, N (code 4) scores -100 against anything (A.2)
 __device__ __forceinline__ int sub_score(unsigned a, unsigned b) {
-    unsigned x = a & 7u, y = b & 7u;
-    if ((x | y) & 4u) return -100;
-    unsigned d = x ^ y;
-    bool at = (x == 0u) || (x == 3u);
-    if (d == 0u) return at ? 91 : 100;
-    if (d == 2u) return -31;
-    if (d == 1u) return -114;
-    return at ? -123 : -125;
+    // branch-free on purpose (the compiler turns an if-chain into exec-mask branches inside the hot loops):
+    // d = x ^ y selects match / transition / the two transversion classes, `at` tells A,T from C,G
+    const unsigned x = a & 7u, y = b & 7u;
+    const unsigned d = (x ^ y) & 3u;
+    const unsigned cg = (x ^ (x >> 1)) & 1u;                   // 1 for C,G ; 0 for A,T
+    // byte k of the table = score(d = k) + 128 :  match, A-C/G-T (-114), transition (-31), A-T / C-G
+    const unsigned lut = cg ? (228u | (14u << 8) | (97u << 16) | (3u << 24)) : (219u | (14u << 8) | (97u << 16) | (5u << 24));
+    const int v = (int)((lut >> (d * 8u)) & 0xFFu) - 128;
+    return ((x | y) & 4u) ? -100 : v;
 }
 
 __device__ __forceinline__ bool window_word(const uint8_t *codes, int64_t p, uint32_t &word) {
