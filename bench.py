@@ -6,8 +6,8 @@ per GPU (ancestor + mutated copy: 15 % substitutions, 1 % indels, one inversion,
 segment, 20 % soft-masked, two N runs), lastz "default" parameter set of
 cactus_progressive_config.xml:136.  A step = one full blast job (index build, seed search both
 strands, ungapped extension, gapped Y-drop extension, PAF) with both sequence sets already
-resident in HBM.  N>1: one process per GPU, each with its own chunk pair (weak scaling, no
-data-path collective); the only exchange is the gather of the final PAF bytes to rank 0 over RCCL,
+resident in HBM.  N>1: one process per GPU, each with its own copy of the chunk pair (weak scaling with the
+per-GPU work held exactly constant, no data-path collective); the only exchange is the gather of the final PAF bytes to rank 0 over RCCL,
 inside the timed region.
 
 Prints ONE JSON line on rank 0.  metric value = dp_cells (the oracle-defined counter: cells of
@@ -67,7 +67,9 @@ def main():
     P = max(1, a.pairs_per_gpu)
     sets = []
     for k in range(P):
-        t, q = gen.make_pair(a.size, a.seed + rank * P + k, homologous=not a.random_pair)
+        # weak scaling with per-GPU work held exactly constant: every rank gets the same P chunk pairs (same seeds), only
+        # the sequence names differ; different seeds would turn the max-over-ranks time into a lottery over the longest DP
+        t, q = gen.make_pair(a.size, a.seed + k, homologous=not a.random_pair)
         sets.append((ctx.seqset_from_fasta_bytes(gen.fasta_bytes([(f"id=simT{rank}_{k}|chr1", t)])),
                      ctx.seqset_from_fasta_bytes(gen.fasta_bytes([(f"id=simQ{rank}_{k}|chr1", q)]))))
     T, Q = sets[0]
@@ -147,7 +149,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{a.size} x {a.size} synthetic chunk pair per GPU (SURVEY 8d config 2"
-                                   f"{', pure-random variant' if a.random_pair else ''}), seed {a.seed}+pair index",
+                                   f"{', pure-random variant' if a.random_pair else ''}), seed {a.seed}+pair index, identical on every rank",
                        "lastz_args": a.lastz_args, "chunk_pairs": world * P, "pairs_per_gpu": P,
                        "sharding": "chunk pairs sharded over GPUs (batched per GPU when pairs_per_gpu > 1), RCCL gather of PAF"},
             "seeds_per_s": tot["seed_hits"] / elapsed,
