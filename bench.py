@@ -50,13 +50,17 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MIBLAST_BENCH_SINGLE_DEVICE"):      # test hook: several ranks on one GPU (use with MIBLAST_BENCH_BACKEND=gloo)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    coll_backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        coll_backend = os.environ.get("MIBLAST_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=coll_backend, device_id=torch.device("cuda", local_rank) if coll_backend == "nccl" else None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libmiblast has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -75,10 +79,11 @@ def main():
     T, Q = sets[0]
 
     from cactus_amd.multigpu import gather_bytes
+    coll_dev = torch.device("cuda", local_rank) if coll_backend != "gloo" else torch.device("cpu")
 
     def gather_paf(paf: bytes):
         """final hit list -> rank 0 (RCCL over xGMI)"""
-        return gather_bytes(paf, dist, rank, world, torch.device("cuda", local_rank))
+        return gather_bytes(paf, dist, rank, world, coll_dev)
 
     def step():
         if P == 1:
@@ -112,7 +117,7 @@ def main():
     elapsed = time.perf_counter() - t0
     keys = ["dp_cells", "seed_hits", "seed_lookups", "ungapped_cols", "alignments", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms",
             "dp_kernel_launches", "t_index", "t_seed", "t_gapped", "t_total", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms"]
-    vec = torch.tensor([float(agg[k]) for k in keys] + [elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    vec = torch.tensor([float(agg[k]) for k in keys] + [elapsed], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         tmax = vec[-1:].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -151,7 +156,8 @@ def main():
             "config": {"workload": f"{a.size} x {a.size} synthetic chunk pair per GPU (SURVEY 8d config 2"
                                    f"{', pure-random variant' if a.random_pair else ''}), seed {a.seed}+pair index, identical on every rank",
                        "lastz_args": a.lastz_args, "chunk_pairs": world * P, "pairs_per_gpu": P,
-                       "sharding": "chunk pairs sharded over GPUs (batched per GPU when pairs_per_gpu > 1), RCCL gather of PAF"},
+                       "sharding": "chunk pairs sharded over GPUs (batched per GPU when pairs_per_gpu > 1), gather of PAF to rank 0",
+                       "collective_backend": coll_backend},
             "seeds_per_s": tot["seed_hits"] / elapsed,
             "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
             "stage_seconds_per_step": {k: tot[k] / a.steps / world for k in ("t_index", "t_seed", "t_gapped", "t_total")},
