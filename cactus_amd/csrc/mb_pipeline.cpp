@@ -17,7 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <unordered_map>
 
 namespace mb {
@@ -108,6 +110,18 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
         }
     }
 };
+
+// independent work items on a few host threads (merging the traces of many alignments is embarrassingly parallel)
+template <typename F>
+void parallel_for(size_t n, F &&f) {
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = std::min<size_t>({n, hw, (size_t)16});
+    if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back([&]() { for (size_t i; (i = next++) < n;) f(i); });
+    for (std::thread &t : th) t.join();
+}
 
 long env_long(const char *name, long dflt) {
     const char *v = getenv(name);
@@ -678,9 +692,13 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             const double t_mg0 = now_s();
             // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
             // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
-            for (size_t k : acc) {
-                Unit &u = units[pend[k].unit];
-                Cached &c = u.cache[pend[k].anchor];
+            std::vector<Cached *> cptr(acc.size());
+            for (size_t x = 0; x < acc.size(); x++) cptr[x] = &units[pend[acc[x]].unit].cache[pend[acc[x]].anchor];   // no map mutation inside the workers
+            std::atomic<int> bad{0};
+            auto merge_one = [&](size_t x) {
+                const size_t k = acc[x];
+                const Unit &u = units[pend[k].unit];
+                Cached &c = *cptr[x];
                 const uint32_t *Rops = hops.data() + probs[2 * k].ops_off, *Lops = hops.data() + probs[2 * k + 1].ops_off;
                 const size_t nR = (size_t)outs[2 * k].n_ops, nL = (size_t)outs[2 * k + 1].n_ops;
                 const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
@@ -707,8 +725,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
                 if (cur_len) c.ops.push_back((cur_len << 2) | cur_op);
                 c.dmin = dmin; c.dmax = dmax;
-                if (tt != c.t_hi || qq != c.q_hi) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
-            }
+                if (tt != c.t_hi || qq != c.q_hi) bad++;
+            };
+            parallel_for(acc.size(), merge_one);
+            if (bad) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
             if (debug) fprintf(stderr, "[miblast]   host merge: %.2f ms\n", (now_s() - t_mg0) * 1e3);
         }
     }
@@ -833,7 +853,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     }
     int rc = gapped_phase(ctx, p, jobs, units);
     if (rc != MIBLAST_OK) return rc;
-    for (size_t k = 0; k < n; k++) output_phase(p, *jobs[k], (int)k, units);
+    parallel_for(n, [&](size_t k) { output_phase(p, *jobs[k], (int)k, units); });
     return MIBLAST_OK;
 }
 
