@@ -104,6 +104,8 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s);
 void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
                       unsigned long long arena_bytes, const unsigned long long *rowdir, uint32_t *ops, hipStream_t s);
+void launch_pack_ops(const DpProb *probs, const int *which, int n, const unsigned long long *coff, const uint32_t *ops,
+                     uint32_t *packed, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int end_bit,
                hipStream_t s);

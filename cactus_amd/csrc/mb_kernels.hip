@@ -926,4 +926,21 @@ void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n,
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, probs, outs, which, n, arena, arena_bytes, rowdir, ops);
 }
 
+// pack the run lists of all sides back to back (each side was given worst-case room, most of it unused)
+__global__ __launch_bounds__(256) void k_pack_ops(const DpProb *__restrict__ probs, const int *__restrict__ which, int n,
+                                                  const unsigned long long *__restrict__ coff,
+                                                  const uint32_t *__restrict__ ops, uint32_t *__restrict__ packed) {
+    const int slot = blockIdx.x;
+    if (slot >= n) return;
+    const uint32_t *src = ops + probs[which[slot]].ops_off;
+    const unsigned long long c0 = coff[slot], cn = coff[slot + 1] - c0;
+    for (unsigned long long x = threadIdx.x; x < cn; x += blockDim.x) packed[c0 + x] = src[x];
+}
+
+void launch_pack_ops(const DpProb *probs, const int *which, int n, const unsigned long long *coff, const uint32_t *ops,
+                     uint32_t *packed, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack_ops, dim3((unsigned)n), dim3(256), 0, s, probs, which, n, coff, ops, packed);
+}
+
 }  // namespace mb

@@ -48,6 +48,24 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// pinned host staging buffer: one large device-to-host copy at link speed, no page faults
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { release(); }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        release();
+        n = count + count / 4;
+        MB_HIP(hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault));
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
 // host substitution score (HOXD70 + N = -100)
 inline int host_score(unsigned a, unsigned b) {
     static const int M[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
@@ -175,7 +193,9 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<uint8_t> arena;
     DevBuf<unsigned long long> arena_next;
     DevBuf<unsigned long long> rowdir;
-    DevBuf<uint32_t> ops;
+    DevBuf<uint32_t> ops, ops_packed;
+    DevBuf<unsigned long long> coff;
+    PinBuf<uint32_t> hops;
     DevBuf<int> which;
     DevBuf<PairPtrs> pair_ptrs;
 };
@@ -680,14 +700,20 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
             MB_HIP(hipMemcpyAsync(g.which.p, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, s));
             launch_traceback(g.probs.p, g.outs.p, g.which.p, (int)which.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, s);
-            std::vector<uint32_t> hops((size_t)ooff + 1);
             MB_HIP(hipMemcpyAsync(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
-            for (int pidx : which) {                       // only the run slots each side actually used
-                const size_t nrun = (size_t)outs[(size_t)pidx].n_ops;
-                if (nrun) MB_HIP(hipMemcpyAsync(hops.data() + probs[(size_t)pidx].ops_off, g.ops.p + probs[(size_t)pidx].ops_off, nrun * 4, hipMemcpyDeviceToHost, s));
-            }
+            // only the run slots each side actually used travel: packed on the device, then one copy into pinned memory
+            std::vector<unsigned long long> coff(which.size() + 1);
+            unsigned long long ctot = 0;
+            for (size_t x = 0; x < which.size(); x++) { coff[x] = ctot; ctot += (unsigned long long)outs[(size_t)which[x]].n_ops; }
+            coff[which.size()] = ctot;
+            g.coff.ensure(coff.size()); g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
+            MB_HIP(hipMemcpyAsync(g.coff.p, coff.data(), coff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+            launch_pack_ops(g.probs.p, g.which.p, (int)which.size(), g.coff.p, g.ops.p, g.ops_packed.p, s);
+            if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
+            for (size_t x = 0; x < which.size(); x++) probs[(size_t)which[x]].ops_off = coff[x];      // host view: packed offsets
+            const uint32_t *hops = g.hops.p;
             if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, which.size(), (unsigned long long)ooff);
             const double t_mg0 = now_s();
             // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
@@ -699,7 +725,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 const size_t k = acc[x];
                 const Unit &u = units[pend[k].unit];
                 Cached &c = *cptr[x];
-                const uint32_t *Rops = hops.data() + probs[2 * k].ops_off, *Lops = hops.data() + probs[2 * k + 1].ops_off;
+                const uint32_t *Rops = hops + probs[2 * k].ops_off, *Lops = hops + probs[2 * k + 1].ops_off;
                 const size_t nR = (size_t)outs[2 * k].n_ops, nL = (size_t)outs[2 * k + 1].n_ops;
                 const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
                 const uint8_t *qc = jobs[(size_t)u.pair]->qc_h[u.strand];
