@@ -31,10 +31,24 @@ struct DpProb {                               // one one-sided Y-drop DP (SURVEY
     int32_t na, nb;                           // columns (target) / rows (query) available
     int32_t dir;                              // +1 forward from (t0,q0); -1 backward from (t0-1,q0-1)
     int32_t strand;                           // selects the query code array
-    int32_t pad0, pad1;                       // pad0 = index of the chunk pair in the PairPtrs table
-    uint64_t row_off;                         // index of this side's first row-chunk directory entry
+    int32_t pad0;                             // index of the chunk pair in the PairPtrs table
+    int32_t row_lo;                           // 0: fresh DP from the origin; > 0: continue after row row_lo from snapshot init_snap
+    uint64_t row_off;                         // index of this piece's first row-chunk directory entry (record 0 <-> row row_lo)
     uint64_t ops_off;                         // traceback: index of this side's first run-length op (u32)
+    int32_t stop_row;                         // > 0: stop after this row if the DP is still alive and write the exit snapshot
+    int32_t snap_row;                         // > 0: write the entry snapshot after this row
+    int32_t init_snap;                        // snapshot to continue from (row_lo > 0)
+    int32_t snap_idx;                         // entry snapshot slot; the exit snapshot is slot snap_idx + 1 (-1: none)
 };
+
+// DP state after a row (relay hand-over and continuation): header + C and D of the window [LY, RY)
+struct SnapHdr {
+    int32_t valid, LY, RY, best, bi, bj, row, rows;
+    int64_t cells;
+    int32_t pad[6];
+};
+constexpr int kSnapCols = 2048;               // = kLdsRowCap: only the LDS-ring variant takes snapshots
+constexpr size_t kSnapBytes = sizeof(SnapHdr) + 2 * (size_t)kSnapCols * sizeof(int32_t);
 
 struct PairPtrs {                              // device pointers of one chunk pair's code arrays
     const uint8_t *tc, *qf, *qr;              // target, query '+', query '-'
@@ -46,7 +60,25 @@ struct DpOut {
     int64_t clocks;                           // shader clocks spent in the row sweep (diagnostics)
     int32_t overflow;                         // 1: row wider than the LDS ring (rerun with HBM rows); 3: trace arena exhausted
     int32_t n_ops;                            // traceback: number of ops written
+    int32_t stopped, pad;                     // 1: stopped at stop_row with live cells (exit snapshot written)
     long long prof[6];                        // MIBLAST_DP_PROFILE: shader clocks per phase of the row loop
+};
+
+// traceback input: a side's trace is spread over the pieces of its validated chain, listed from the piece that holds
+// the best cell back to the head.  Rows <= min_row of a piece belong to the next piece of the list; (dr, dc) convert a
+// cell of this piece into the next piece's local coordinates.
+struct TbPiece {
+    uint64_t row_off;                         // first row-chunk directory entry of the piece
+    int32_t row_lo;                           // record 0 <-> row row_lo
+    int32_t min_row;
+    int32_t dr, dc;
+    int32_t pad[2];
+};
+struct TbSide {
+    int32_t first_piece, n_pieces;
+    int32_t bi, bj;                           // best cell in the first piece's local coordinates
+    uint64_t ops_off;
+    int32_t n_ops, pad;
 };
 
 struct UngappedCounters {
@@ -101,10 +133,10 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
                      UngappedCounters *ctr, hipStream_t s);
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
                   int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
-                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s);
-void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
+                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s);
+void launch_traceback(TbSide *sides, const TbPiece *pieces, int n, const uint8_t *arena,
                       unsigned long long arena_bytes, const unsigned long long *rowdir, uint32_t *ops, hipStream_t s);
-void launch_pack_ops(const DpProb *probs, const int *which, int n, const unsigned long long *coff, const uint32_t *ops,
+void launch_pack_ops(const TbSide *sides, int n, const unsigned long long *coff, const uint32_t *ops,
                      uint32_t *packed, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int end_bit,

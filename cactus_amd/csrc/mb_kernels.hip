@@ -603,11 +603,12 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
                                            int2 *CD, uint8_t *Tb, const int cap, YdShared *sh,
                                            uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                                            unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
-                                           unsigned long long *__restrict__ rowdir) {
+                                           unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = uni(tid >> 6);
     const int mask = cap - 1;
+    const int row_lo = GLOBAL ? 0 : pr.row_lo;                          // row records are indexed by rho = row - row_lo
     const int na = pr.na, nb = pr.nb, dir = pr.dir;
     const int64_t t0 = pr.t0, q0 = pr.q0;
     const long long clk0 = clock64();
@@ -634,7 +635,7 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
     }
     // row records {offset, LY} are buffered 64 rows at a time in wave 0 (lane = row & 63)
     unsigned rb_lo = 0, rb_hi = 0, rb_ly = 0;
-    auto flush_rows = [&](int last_row) {      // rows (last_row & ~63) .. last_row
+    auto flush_rows = [&](int last_row) {      // records (last_row & ~63) .. last_row  (record = row - row_lo)
         if (wv == 0) {
             const int r = (last_row & ~63) + lane;
             if (r <= last_row) {
@@ -643,33 +644,43 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
             }
         }
     };
-    // ---- row 0: C = -(O + jE) while within ydrop of 0, every cell reached by a horizontal gap from the origin
-    if (!overflow) {
+    int LY = 0, RY = R0 + 1, best = 0, bi = 0, bj = 0;
+    long long cells = R0 + 1;
+    int rows = 1;
+    if (!overflow && row_lo == 0) {
+        // ---- row 0: C = -(O + jE) while within ydrop of 0, every cell reached by a horizontal gap from the origin
         uint8_t *tr = arena + blk_off;
         for (int j = tid; j <= R0; j += kYdThreads) {
             CD[j & mask] = make_int2((j == 0) ? 0 : -(O + j * E), kNeg);
             tr[j] = (j == 0) ? 3 : (uint8_t)(2 | (j >= 2 ? 8 : 0));
         }
-        if (tid == 0) rowdir[pr.row_off] = chunk_off;
         if (lane == 0) { rb_lo = (unsigned)blk_off; rb_hi = (unsigned)(blk_off >> 32); rb_ly = 0; }
         blk_used = (unsigned)(R0 + 1);
+    } else if (!overflow) {
+        // ---- continuation: the state after row row_lo comes from a snapshot (record 0 of this piece stays unused)
+        const uint8_t *sp = snaps + (size_t)pr.init_snap * kSnapBytes;
+        const SnapHdr *h = (const SnapHdr *)sp;
+        const int *sC = (const int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
+        LY = uni(h->LY); RY = uni(h->RY); best = uni(h->best); bi = uni(h->bi); bj = uni(h->bj); rows = uni(h->rows);
+        cells = (long long)uni64((unsigned long long)h->cells);
+        for (int j = LY + tid; j < RY; j += kYdThreads) CD[j & mask] = make_int2(sC[j - LY], sD[j - LY]);
     }
-    int LY = 0, RY = R0 + 1, best = 0, bi = 0, bj = 0;
-    long long cells = R0 + 1;
-    int rows = 1;
-    int t_hi = 0;                                                       // highest target column staged in Tb
-    int qblk0 = 1;                                                      // first row of the block held in qv
+    if (!overflow && tid == 0) rowdir[pr.row_off] = chunk_off;
+    int t_hi = max(LY - 1, 0);                                          // highest target column staged in Tb
+    int qblk0 = 1 + (row_lo & ~63);                                     // first row of the block held in qv
     auto load_q = [&](int r0) -> unsigned {
         const int r = r0 + lane;
         return (r >= 1 && r <= nb) ? (unsigned)qc[dir > 0 ? q0 + r - 1 : q0 - r] : 4u;
     };
-    unsigned qv = load_q(1), qnext = load_q(65);
+    unsigned qv = load_q(qblk0), qnext = load_q(qblk0 + 64);
     const uint32_t lutv = row_score_lut((unsigned)min(lane, 4));     // lane k holds the packed score row of query base k
     const int tidE = tid * E;
     __syncthreads();
-    int i = 1;
+    int i = row_lo + 1;
+    int stopped = 0;
     for (; i <= nb && !overflow; i++) {
         if (PROF) pt = clock64();
+        const int rho = i - row_lo;
         if (i - qblk0 >= 64) { qblk0 += 64; qv = qnext; qnext = load_q(qblk0 + 64); }
         const uint32_t lut = (uint32_t)__builtin_amdgcn_readlane((int)lutv, min(__builtin_amdgcn_readlane((int)qv, i - qblk0) & 7, 4));
         // the row can reach at most column RY + grow; everything it may touch must be staged and fit the ring
@@ -677,8 +688,8 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
         if (reach - LY + 2 * kYdThreads + 64 > cap) { overflow = 1; break; }
         const int need = reach - LY + 1;
         const bool new_blk = blk_used + (unsigned)need > blk_bytes;
-        const bool new_chunk = (i & (kRowChunk - 1)) == 0;
-        if ((i & 63) == 0) flush_rows(i - 1);
+        const bool new_chunk = (rho & (kRowChunk - 1)) == 0;
+        if ((rho & 63) == 0) flush_rows(rho - 1);
         if (new_blk || new_chunk) {
             __syncthreads();                                             // everyone is past the previous use of sh->blk/chunk
             if (tid == 0) {
@@ -691,7 +702,7 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
             __syncthreads();
             if (uni(sh->fail)) { overflow = 3; break; }
             if (new_blk) { blk_off = uni64(sh->blk); blk_used = 0; }
-            if (new_chunk) { chunk_off = uni64(sh->chunk); if (tid == 0) rowdir[pr.row_off + (unsigned)(i / kRowChunk)] = chunk_off; }
+            if (new_chunk) { chunk_off = uni64(sh->chunk); if (tid == 0) rowdir[pr.row_off + (unsigned)(rho / kRowChunk)] = chunk_off; }
         }
         if (!GLOBAL && t_hi < min(na, reach + kYdThreads)) {
             // stage target columns ahead of the window, 256 at a time (visible to all waves after the barrier)
@@ -702,7 +713,7 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
             }
             __syncthreads();
         }
-        if (lane == (i & 63)) { const unsigned long long ro = blk_off + blk_used; rb_lo = (unsigned)ro; rb_hi = (unsigned)(ro >> 32); rb_ly = (unsigned)LY; }
+        if (lane == (rho & 63)) { const unsigned long long ro = blk_off + blk_used; rb_lo = (unsigned)ro; rb_hi = (unsigned)(ro >> 32); rb_ly = (unsigned)LY; }
         MB_TICK(0);
         int carry_x = kNeg2, carry_m = best, carry_iv = kNeg, carry_cp = kNeg;   // pass-level carries (wave-uniform)
         int row_best = best, first_alive = -1, last_alive = -1, nrow = 0;
@@ -790,11 +801,23 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
         if (first_alive < 0) { i++; break; }
         LY = first_alive;
         RY = last_alive + 1;
+        if (!GLOBAL && (i == pr.snap_row || i == pr.stop_row)) {
+            // state after row i (the ring writes of the row are visible: they precede the row's last barrier)
+            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : 0)) * kSnapBytes;
+            int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
+            for (int j = LY + tid; j < RY; j += kYdThreads) { const int2 cd = CD[j & mask]; sC[j - LY] = cd.x; sD[j - LY] = cd.y; }
+            if (tid == 0) {
+                SnapHdr *h = (SnapHdr *)sp;
+                h->LY = LY; h->RY = RY; h->best = best; h->bi = bi; h->bj = bj; h->row = i; h->rows = rows; h->cells = cells;
+                h->valid = 1;
+            }
+            if (i == pr.stop_row) { stopped = 1; i++; break; }
+        }
     }
-    if (!overflow) flush_rows(i - 1);
+    if (!overflow) flush_rows(i - 1 - row_lo);
     if (tid == 0) {
         out->best = best; out->bi = bi; out->bj = bj; out->rows = rows;
-        out->cells = cells; out->clocks = clock64() - clk0; out->overflow = overflow; out->n_ops = 0;
+        out->cells = cells; out->clocks = clock64() - clk0; out->overflow = overflow; out->n_ops = 0; out->stopped = stopped;
         if (PROF) for (int k = 0; k < 6; k++) out->prof[k] = pf[k];
     }
 }
@@ -804,7 +827,7 @@ __global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__
                                                       const PairPtrs *__restrict__ pairs, int O, int E, int Y, int32_t *grows,
                                                       uint8_t *__restrict__ arena, unsigned long long arena_bytes,
                                                       unsigned long long *__restrict__ arena_next, unsigned blk_bytes,
-                                                      unsigned long long *__restrict__ rowdir) {
+                                                      unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps) {
     int pi = blockIdx.x;
     if (pi >= n) return;
     DpProb pr = probs[pi];
@@ -815,24 +838,24 @@ __global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__
     if (GLOBAL_ROWS) {
         int2 *CD = (int2 *)(grows + (size_t)pi * 2 * kGlobalRowCap);
         ydrop_body<true, PROF>(pr, &outs[pi], tc, qc, O, E, Y, CD, nullptr, kGlobalRowCap, &sh, arena, arena_bytes, arena_next,
-                               blk_bytes, rowdir);
+                               blk_bytes, rowdir, snaps);
     } else {
         __shared__ int2 sCD[kLdsRowCap];
         __shared__ uint8_t sT[kLdsRowCap];
         ydrop_body<false, PROF>(pr, &outs[pi], tc, qc, O, E, Y, sCD, sT, kLdsRowCap, &sh, arena, arena_bytes, arena_next,
-                                blk_bytes, rowdir);
+                                blk_bytes, rowdir, snaps);
     }
 }
 
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
                   int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
-                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, hipStream_t s) {
+                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s) {
     if (n <= 0) return;
     dim3 g((unsigned)n), b(kYdThreads);
     static const bool prof = getenv("MIBLAST_DP_PROFILE") != nullptr;
-    if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
-    else if (prof) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
-    else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir);
+    if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    else if (prof) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -841,17 +864,17 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
 // <-> row i-l, columns j-l-3 .. j-l+4).  Inside a block, whole runs of diagonal steps are recognised with one
 // ballot (all lanes test "src == diag" at the current drift); only gap cells are stepped one at a time.
 // Output: run-length ops (len << 2 | op) in walk-back order; op 0 aligned pair, 2 query-only, 3 target-only.
-__global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ probs, DpOut *__restrict__ outs,
-                                                  const int *__restrict__ which, int n, const uint8_t *__restrict__ arena,
-                                                  const unsigned long long arena_bytes,
+__global__ __launch_bounds__(64) void k_traceback(TbSide *__restrict__ sides, const TbPiece *__restrict__ pieces, int n,
+                                                  const uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                                                   const unsigned long long *__restrict__ rowdir, uint32_t *__restrict__ ops) {
     const int slot = blockIdx.x;
     if (slot >= n) return;
-    const int pi = which[slot];
-    const DpProb pr = probs[pi];
+    const TbSide sd = sides[slot];
     const int lane = threadIdx.x & 63;
-    int i = uni(outs[pi].bi), j = uni(outs[pi].bj), state = 0;
-    uint32_t *o = ops + pr.ops_off;
+    int pc = uni(sd.first_piece), left = uni(sd.n_pieces);
+    TbPiece P = pieces[pc];
+    int i = uni(sd.bi), j = uni(sd.bj), state = 0;
+    uint32_t *o = ops + sd.ops_off;
     int n_runs = 0, cur_op = -1, cur_len = 0;
     auto emit = [&](int op, int len) {
         if (op == cur_op) cur_len += len;
@@ -861,15 +884,30 @@ __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ pro
             cur_op = op; cur_len = len;
         }
     };
+    // rows at or below `floor` belong to the previous piece of the chain (the head's floor is -1: it owns row 0)
+    int floor = left > 1 ? uni(P.min_row) : -1;
     // row records of the NEXT block are requested while the current block is walked (they do not depend on the walk)
     auto load_ri = [&](int r) -> RowInfo {
         RowInfo ri; ri.off = 0; ri.ly = 0; ri.pad = 0;
-        if (r >= 0) ri = ((const RowInfo *)(arena + rowdir[pr.row_off + (unsigned)(r / kRowChunk)]))[r & (kRowChunk - 1)];
+        if (r > floor) {
+            const int rho = r - P.row_lo;
+            ri = ((const RowInfo *)(arena + rowdir[P.row_off + (unsigned)(rho / kRowChunk)]))[rho & (kRowChunk - 1)];
+        }
         return ri;
     };
     int pre_i0 = i;
     RowInfo ri_pre = load_ri(i - lane);
-    while (i > 0 || j > 0) {
+    while (true) {
+        if (left > 1 && i <= floor) {                               // hand over to the piece that owns the rows below
+            i += P.dr; j += P.dc;
+            pc++; left--;
+            P = pieces[pc];
+            floor = left > 1 ? uni(P.min_row) : -1;
+            pre_i0 = i;
+            ri_pre = load_ri(i - lane);
+            continue;
+        }
+        if (!(i > 0 || j > 0)) break;
         // fetch block: rows i .. i-63
         i = uni(i); j = uni(j);
         const int i0 = i, j0 = j;
@@ -878,7 +916,7 @@ __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ pro
         pre_i0 = i0 - 64;
         ri_pre = load_ri(pre_i0 - lane);
         unsigned long long win = 0;
-        if (r >= 0) {
+        if (r > floor) {
             const int wly = (int)ri.ly;
             const int wc0 = j0 - lane - 3;                     // column of byte 0 of the window
             const uint8_t *rowp = arena + ri.off;
@@ -893,7 +931,7 @@ __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ pro
             }
         } else win = ~0ull;
         int l = 0;
-        while ((i > 0 || j > 0) && l < 64) {
+        while ((i > 0 || j > 0) && l < 64 && i > floor) {
             i = uni(i); j = uni(j); state = uni(state); l = uni(l);
             const int k = j - (j0 - l - 3);                    // byte of the window that holds column j of row i
             if (k < 0 || k >= 8) break;                        // drifted out of the prefetched window: refetch
@@ -917,30 +955,30 @@ __global__ __launch_bounds__(64) void k_traceback(const DpProb *__restrict__ pro
         }
     }
     emit(-2, 0);                                                // flush the last run
-    if (lane == 0) outs[pi].n_ops = n_runs;
+    if (lane == 0) sides[slot].n_ops = n_runs;
 }
 
-void launch_traceback(const DpProb *probs, DpOut *outs, const int *which, int n, const uint8_t *arena,
+void launch_traceback(TbSide *sides, const TbPiece *pieces, int n, const uint8_t *arena,
                       unsigned long long arena_bytes, const unsigned long long *rowdir, uint32_t *ops, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, probs, outs, which, n, arena, arena_bytes, rowdir, ops);
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, sides, pieces, n, arena, arena_bytes, rowdir, ops);
 }
 
 // pack the run lists of all sides back to back (each side was given worst-case room, most of it unused)
-__global__ __launch_bounds__(256) void k_pack_ops(const DpProb *__restrict__ probs, const int *__restrict__ which, int n,
+__global__ __launch_bounds__(256) void k_pack_ops(const TbSide *__restrict__ sides, int n,
                                                   const unsigned long long *__restrict__ coff,
                                                   const uint32_t *__restrict__ ops, uint32_t *__restrict__ packed) {
     const int slot = blockIdx.x;
     if (slot >= n) return;
-    const uint32_t *src = ops + probs[which[slot]].ops_off;
+    const uint32_t *src = ops + sides[slot].ops_off;
     const unsigned long long c0 = coff[slot], cn = coff[slot + 1] - c0;
     for (unsigned long long x = threadIdx.x; x < cn; x += blockDim.x) packed[c0 + x] = src[x];
 }
 
-void launch_pack_ops(const DpProb *probs, const int *which, int n, const unsigned long long *coff, const uint32_t *ops,
+void launch_pack_ops(const TbSide *sides, int n, const unsigned long long *coff, const uint32_t *ops,
                      uint32_t *packed, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_pack_ops, dim3((unsigned)n), dim3(256), 0, s, probs, which, n, coff, ops, packed);
+    hipLaunchKernelGGL(k_pack_ops, dim3((unsigned)n), dim3(256), 0, s, sides, n, coff, ops, packed);
 }
 
 }  // namespace mb

@@ -45,6 +45,13 @@ struct DevBuf {
         if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
     }
     void ensure(size_t count) { if (count > n) alloc(count + count / 4); }
+    void ensure_keep(size_t count) {              // grow without losing the contents
+        if (count <= n) return;
+        T *old = p; const size_t old_n = n;
+        p = nullptr; n = count + count / 2;
+        MB_HIP(hipMalloc((void **)&p, n * sizeof(T)));
+        if (old) { MB_HIP(hipMemcpy(p, old, old_n * sizeof(T), hipMemcpyDeviceToDevice)); (void)hipFree(old); }
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
@@ -196,7 +203,9 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<uint32_t> ops, ops_packed;
     DevBuf<unsigned long long> coff;
     PinBuf<uint32_t> hops;
-    DevBuf<int> which;
+    DevBuf<TbSide> tb_sides;
+    DevBuf<TbPiece> tb_pieces;
+    DevBuf<uint8_t> snaps;
     DevBuf<PairPtrs> pair_ptrs;
 };
 
@@ -245,7 +254,7 @@ static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, bool global_rows, const
     Workspace &g = *ctx.ws;
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     launch_ydrop(global_rows, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
-                 (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, ctx.stream);
+                 (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
     MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     MB_HIP(hipEventSynchronize(ctx.ev1));
     float ms = 0;
@@ -504,6 +513,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long spec_target = env_long("MIBLAST_SPEC_TARGET", 24) * (long)std::max<size_t>(1, jobs.size());   // anchors per round the thinning aims at
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
+    // relay hand-over (see the DP section below): first stop, relay spacing, warm-up rows, diagonal tolerance, relays per side
+    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 4096), relay_s = std::max(256l, env_long("MIBLAST_RELAY_S", 4096));
+    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 1024)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
+    const long relay_max = env_long("MIBLAST_RELAY_MAX", 256);
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
     Workspace &g = *ctx.ws;
     hipStream_t s = ctx.stream;
@@ -599,65 +612,274 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (pend.empty()) break;
         st.gapped_rounds++;
 
-        // ---- two one-sided DPs per nominated anchor, trace stored in the arena --------------------------
-        const int np = (int)pend.size() * 2;
-        std::vector<DpProb> probs((size_t)np);
-        uint64_t dir_entries = 0;
-        for (size_t k = 0; k < pend.size(); k++) {
-            const Unit &u = units[pend[k].unit];
-            const Anchor &a = u.anchors[pend[k].anchor];
-            const SeqSet &T = *jobs[(size_t)u.pair]->T, &Q = *jobs[(size_t)u.pair]->Q;
-            int tcg = T.contig_of(a.t);
-            int64_t tlo = T.starts[(size_t)tcg], thi = tlo + T.lens[(size_t)tcg];
-            int64_t qlo = Q.starts[(size_t)u.q_contig], qhi = qlo + Q.lens[(size_t)u.q_contig];
-            DpProb &r = probs[2 * k], &l = probs[2 * k + 1];
-            memset(&r, 0, sizeof r); memset(&l, 0, sizeof l);
-            r.t0 = a.t; r.q0 = a.q; r.dir = +1; r.na = (int32_t)(thi - a.t); r.nb = (int32_t)(qhi - a.q); r.strand = u.strand; r.pad0 = u.pair;
-            l.t0 = a.t; l.q0 = a.q; l.dir = -1; l.na = (int32_t)(a.t - tlo); l.nb = (int32_t)(a.q - qlo); l.strand = u.strand; l.pad0 = u.pair;
-            r.row_off = dir_entries; dir_entries += (uint64_t)(r.nb / 4096) + 2;
-            l.row_off = dir_entries; dir_entries += (uint64_t)(l.nb / 4096) + 2;
-        }
-        g.probs.ensure((size_t)np); g.outs.ensure((size_t)np); g.rowdir.ensure((size_t)dir_entries + 1);
-        std::vector<DpOut> outs((size_t)np);
+        // ---- the one-sided DPs of the round, trace stored in the arena -----------------------------------
+        // A side (anchor, direction) is evaluated as a chain of PIECES (k_ydrop problems).  A one-sided DP is a
+        // row-sequential chain, so a 250 000-row alignment would keep one workgroup busy for a quarter of a second
+        // while the rest of the GPU idles.  Instead the first piece of a side stops after `relay_s0` rows; a side that
+        // is still alive there is continued from its exit snapshot AND relayed: fresh DPs ("runs") are started at
+        // downstream anchors of the same unit -- the ungapped HSPs a long alignment passes through -- and each stops
+        // `relay_w` rows after the origin of the next one.  All of them run concurrently.  A hand-over is accepted only
+        // if the state of the upstream run after the hand-over row equals the relay's state after the same row: same
+        // window, same running best, and every live C / D value equal up to one constant (values too low to ever
+        // reach the y-drop threshold again are compared as dead).  The recurrence is invariant under adding a
+        // constant, so from that row on both runs compute the same rows and the relay's rows simply ARE the rows of
+        // the sequential DP.  A rejected hand-over costs nothing but time: the upstream run is continued from its
+        // snapshot to the next relay.  Results (score, end cell, trace, cell and row counts) never depend on where
+        // relays start or whether they are accepted.
+        struct Piece { int side, run; int32_t row_lo, min_row, stop_row; int target_run; bool accounted; };
+        struct Run { int32_t dr, dc; std::vector<int> pieces; };
+        struct SideRun {
+            DpProb base;
+            std::vector<Run> runs;
+            std::vector<int> chain;             // validated pieces, head first
+            int cur_run = 0;
+            long long c_off = 0;                // score of the current run's origin in the head's scores
+            long long acc_cells = 0, acc_rows = 0, entry_cells = 0, entry_rows = 0;
+            int gbest = -1, gbi = 0, gbj = 0, best_piece = -1;
+            bool done = false, wide = false, relayed = false, waiting = false;
+        };
+        const int nsides = (int)pend.size() * 2;
+        std::vector<SideRun> sides;
+        std::vector<Piece> pieces;
+        std::vector<DpProb> probs;
+        std::vector<DpOut> outs;
+        std::vector<uint8_t> hsnaps;
+        bool arena_full = false;
+        long n_verify_ok = 0, n_verify_bad = 0, n_subrounds = 0;
+        auto snap_hdr = [&](int slot) -> const SnapHdr * { return (const SnapHdr *)(hsnaps.data() + (size_t)slot * kSnapBytes); };
+        auto snap_C = [&](int slot) -> const int32_t * { return (const int32_t *)(hsnaps.data() + (size_t)slot * kSnapBytes + sizeof(SnapHdr)); };
         while (true) {                                   // retried with a larger arena if the trace does not fit
-            MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
+            sides.assign((size_t)nsides, SideRun());
+            pieces.clear(); probs.clear(); outs.clear(); hsnaps.clear();
+            arena_full = false;
+            uint64_t dir_entries = 0;
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
-            run_ydrop_timed(ctx, st, false, g.probs.p, g.outs.p, np, g.pair_ptrs.p, p, kBlk);
-            MB_HIP(hipMemcpy(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost));
-            // rows wider than the LDS ring: rerun those sides with the C/D ring in HBM (arena keeps filling)
-            std::vector<int> wide;
-            for (int k = 0; k < np; k++) if (outs[(size_t)k].overflow == 1) wide.push_back(k);
-            bool arena_full = false;
-            for (int k = 0; k < np; k++) arena_full |= outs[(size_t)k].overflow == 3;
-            for (size_t w0 = 0; w0 < wide.size() && !arena_full; w0 += 32) {
-                size_t w1 = std::min(wide.size(), w0 + 32);
-                std::vector<DpProb> wp;
-                for (size_t k = w0; k < w1; k++) wp.push_back(probs[(size_t)wide[k]]);
-                DevBuf<DpProb> dwp(wp.size()); DevBuf<DpOut> dwo(wp.size());
-                g.grows.ensure(wp.size() * 2 * (size_t)kGlobalRowCap);
-                MB_HIP(hipMemcpy(dwp.p, wp.data(), wp.size() * sizeof(DpProb), hipMemcpyHostToDevice));
-                run_ydrop_timed(ctx, st, true, dwp.p, dwo.p, (int)wp.size(), g.pair_ptrs.p, p, kBlkWide);
-                std::vector<DpOut> wo(wp.size());
-                MB_HIP(hipMemcpy(wo.data(), dwo.p, wp.size() * sizeof(DpOut), hipMemcpyDeviceToHost));
-                for (size_t k = w0; k < w1; k++) {
-                    if (wo[k - w0].overflow == 1) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
-                    if (wo[k - w0].overflow == 3) arena_full = true;
-                    outs[(size_t)wide[k]] = wo[k - w0];
-                    MB_HIP(hipMemcpy(g.outs.p + wide[k], &wo[k - w0], sizeof(DpOut), hipMemcpyHostToDevice));
+            auto add_piece = [&](int side, int run, const DpProb &proto, int32_t row_lo, int32_t min_row, int32_t stop_row,
+                                 int32_t snap_row, int init_snap, int target_run) -> int {
+                const int id = (int)pieces.size();
+                SideRun &sd = sides[(size_t)side];
+                const Run &rn = sd.runs[(size_t)run];
+                DpProb pr = proto;
+                pr.t0 = proto.t0 + proto.dir * rn.dc; pr.q0 = proto.q0 + proto.dir * rn.dr;
+                pr.na = proto.na - rn.dc; pr.nb = proto.nb - rn.dr;
+                pr.row_lo = row_lo; pr.stop_row = stop_row; pr.snap_row = snap_row; pr.init_snap = init_snap; pr.snap_idx = 2 * id;
+                pr.row_off = dir_entries;
+                const int64_t last = stop_row > 0 ? stop_row : pr.nb;
+                dir_entries += (uint64_t)((last - row_lo) / 4096) + 2;
+                probs.push_back(pr);
+                pieces.push_back(Piece{side, run, row_lo, min_row, stop_row, target_run, false});
+                sd.runs[(size_t)run].pieces.push_back(id);
+                return id;
+            };
+            for (size_t k = 0; k < pend.size(); k++) {
+                const Unit &u = units[pend[k].unit];
+                const Anchor &a = u.anchors[pend[k].anchor];
+                const SeqSet &T = *jobs[(size_t)u.pair]->T, &Q = *jobs[(size_t)u.pair]->Q;
+                int tcg = T.contig_of(a.t);
+                int64_t tlo = T.starts[(size_t)tcg], thi = tlo + T.lens[(size_t)tcg];
+                int64_t qlo = Q.starts[(size_t)u.q_contig], qhi = qlo + Q.lens[(size_t)u.q_contig];
+                for (int sdn = 0; sdn < 2; sdn++) {
+                    DpProb b;
+                    memset(&b, 0, sizeof b);
+                    b.t0 = a.t; b.q0 = a.q; b.strand = u.strand; b.pad0 = u.pair; b.init_snap = -1; b.snap_idx = -1;
+                    if (sdn == 0) { b.dir = +1; b.na = (int32_t)(thi - a.t); b.nb = (int32_t)(qhi - a.q); }
+                    else { b.dir = -1; b.na = (int32_t)(a.t - tlo); b.nb = (int32_t)(a.q - qlo); }
+                    SideRun &sd = sides[2 * k + (size_t)sdn];
+                    sd.base = b;
+                    sd.runs.push_back(Run{0, 0, {}});
+                    const int id = add_piece((int)(2 * k) + sdn, 0, b, 0, -1, (int32_t)relay_s0, 0, -1, -1);
+                    sd.chain.push_back(id);
                 }
             }
-            for (int k = 0; k < np; k++) { st.dp_sides_run++; st.dp_cells_run += outs[(size_t)k].cells; st.dp_rows_run += outs[(size_t)k].rows; }
-            if (debug) {
-                int maxrows = 0; long long cells = 0, clk = 0;
-                for (int k = 0; k < np; k++) { if (outs[(size_t)k].rows > maxrows) { maxrows = outs[(size_t)k].rows; clk = outs[(size_t)k].clocks; } cells += outs[(size_t)k].cells; }
-                fprintf(stderr, "[miblast] round %d: %d sides, max rows %d (%lld shader clocks = %.0f per row), cells %lld, dp kernel total %.2f ms so far, shadow_q %ld\n",
-                        round, np, maxrows, clk, (double)clk / std::max(1, maxrows), cells, st.t_dp_kernel_ms, shadow_q);
-                for (int k = 0; k < np; k++) if (outs[(size_t)k].rows == maxrows && outs[(size_t)k].prof[1]) {
-                    const DpOut &o = outs[(size_t)k];
-                    fprintf(stderr, "[miblast]   per row: setup %.0f | load+scan %.0f | B1 %.0f | Iv/C/alive %.0f | B2 %.0f | replay+store %.0f\n",
-                            (double)o.prof[0] / maxrows, (double)o.prof[1] / maxrows, (double)o.prof[2] / maxrows, (double)o.prof[3] / maxrows,
-                            (double)o.prof[4] / maxrows, (double)o.prof[5] / maxrows);
-                    break;
+            size_t launched = 0;                          // pieces [0, launched) have run
+            while (launched < pieces.size() && !arena_full) {
+                n_subrounds++;
+                const size_t n_new = pieces.size() - launched;
+                g.probs.ensure_keep(pieces.size()); g.outs.ensure_keep(pieces.size()); g.rowdir.ensure_keep((size_t)dir_entries + 1);
+                g.snaps.ensure_keep(pieces.size() * 2 * kSnapBytes);
+                outs.resize(pieces.size()); hsnaps.resize(pieces.size() * 2 * kSnapBytes);
+                MB_HIP(hipMemcpyAsync(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), hipMemcpyHostToDevice, s));
+                MB_HIP(hipMemsetAsync(g.snaps.p + launched * 2 * kSnapBytes, 0, n_new * 2 * kSnapBytes, s));
+                run_ydrop_timed(ctx, st, false, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk);
+                MB_HIP(hipMemcpy(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), hipMemcpyDeviceToHost));
+                bool any_stop = false;
+                for (size_t x = launched; x < pieces.size(); x++) { arena_full |= outs[x].overflow == 3; any_stop |= outs[x].stopped != 0 || probs[x].snap_row > 0; }
+                if (arena_full) break;
+                if (any_stop) MB_HIP(hipMemcpy(hsnaps.data() + launched * 2 * kSnapBytes, g.snaps.p + launched * 2 * kSnapBytes, n_new * 2 * kSnapBytes, hipMemcpyDeviceToHost));
+                for (size_t x = launched; x < pieces.size(); x++) {
+                    st.dp_sides_run++;
+                    const SnapHdr *h0 = probs[x].row_lo > 0 ? snap_hdr(probs[x].init_snap) : nullptr;
+                    st.dp_cells_run += outs[x].cells - (h0 ? h0->cells : 0);
+                    st.dp_rows_run += outs[x].rows - (h0 ? h0->rows : 0);
+                }
+                if (debug) {
+                    int maxrows = 0; long long clk = 0;
+                    for (size_t x = launched; x < pieces.size(); x++) {
+                        const int r = outs[x].rows - (probs[x].row_lo > 0 ? snap_hdr(probs[x].init_snap)->rows : 0);
+                        if (r > maxrows) { maxrows = r; clk = outs[x].clocks; }
+                        if (r > 3 * (relay_s + relay_w) && relay_s0 > 0)
+                            fprintf(stderr, "[miblast]   long piece %zu: side %d run %d (of %zu) row_lo %d stop_row %d rows %d stopped %d dr %d\n", x, pieces[x].side, pieces[x].run,
+                                    sides[(size_t)pieces[x].side].runs.size(), pieces[x].row_lo, pieces[x].stop_row, r, outs[x].stopped, sides[(size_t)pieces[x].side].runs[(size_t)pieces[x].run].dr);
+                    }
+                    fprintf(stderr, "[miblast] round %d.%ld: %zu pieces, max rows %d (%lld shader clocks = %.0f per row), dp kernel total %.2f ms so far, shadow_q %ld\n",
+                            round, n_subrounds, n_new, maxrows, clk, (double)clk / std::max(1, maxrows), st.t_dp_kernel_ms, shadow_q);
+                }
+                launched = pieces.size();
+                // ---- advance every side along its chain; new pieces (continuations, relays) are queued for the next launch
+                for (int si = 0; si < nsides; si++) {
+                    SideRun &sd = sides[(size_t)si];
+                    if (sd.done || sd.wide) continue;
+                    while (true) {
+                        const int tp = sd.runs[(size_t)sd.cur_run].pieces.back();
+                        const int32_t rn_dr = sd.runs[(size_t)sd.cur_run].dr, rn_dc = sd.runs[(size_t)sd.cur_run].dc;   // (sd.runs grows below)
+                        if (tp >= (int)launched) break;                          // queued, not run yet
+                        for (int pc : sd.runs[(size_t)sd.cur_run].pieces) {      // fold the run's finished pieces into the side's result
+                            Piece &pp = pieces[(size_t)pc];
+                            if (pp.accounted) continue;
+                            pp.accounted = true;
+                            const DpOut &o = outs[(size_t)pc];
+                            if (o.overflow == 1) { sd.wide = true; break; }
+                            if ((long long)o.best + sd.c_off > sd.gbest) {
+                                sd.gbest = (int)((long long)o.best + sd.c_off); sd.gbi = o.bi + rn_dr; sd.gbj = o.bj + rn_dc; sd.best_piece = pc;
+                            }
+                        }
+                        if (sd.wide) break;
+                        const DpOut &o = outs[(size_t)tp];
+                        if (!o.stopped) {                                        // natural end of the DP
+                            sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
+                            sd.done = true;
+                            break;
+                        }
+                        const int eslot = 2 * tp + 1;
+                        const SnapHdr *E = snap_hdr(eslot);
+                        const int32_t exit_row = E->row + rn_dr;                 // in the head's rows
+                        if (!sd.relayed) {
+                            // first stop of the side: plant relays on downstream anchors of the unit
+                            sd.relayed = true;
+                            const Unit &u = units[pend[(size_t)si / 2].unit];
+                            const DpProb &b = sd.base;
+                            int32_t ct = b.t0, cq = b.q0;                        // last chain point
+                            const int32_t dirn = b.dir;
+                            // anchors sorted by q: walk in the side's direction
+                            auto lb = std::lower_bound(u.by_q.begin(), u.by_q.end(), b.q0, [&](uint32_t x, int32_t q) { return u.anchors[x].q < q; });
+                            long pos = (long)(lb - u.by_q.begin());
+                            if (dirn < 0) pos--;
+                            int32_t need_dr = (int32_t)std::max<long>(exit_row - relay_w + 64, relay_s);   // entry row must lie beyond the exit row
+                            long best_idx = -1; long best_dev = 0;
+                            for (; pos >= 0 && pos < (long)u.by_q.size(); pos += dirn) {
+                                const Anchor &c = u.anchors[u.by_q[(size_t)pos]];
+                                const int32_t dr = (c.q - b.q0) * dirn, dc = (c.t - b.t0) * dirn;
+                                if (dr < need_dr) continue;
+                                if (dr >= b.nb - relay_w - 64) break;
+                                const bool window_end = dr >= need_dr + relay_s / 2;
+                                if (window_end && best_idx >= 0) {
+                                    const Anchor &w = u.anchors[u.by_q[(size_t)best_idx]];
+                                    const int32_t wdr = (w.q - b.q0) * dirn, wdc = (w.t - b.t0) * dirn;
+                                    sd.runs.push_back(Run{wdr, wdc, {}});
+                                    ct = w.t; cq = w.q;
+                                    need_dr = wdr + (int32_t)relay_s;
+                                    best_idx = -1;
+                                    if ((long)sd.runs.size() > relay_max) break;
+                                    if (dr < need_dr) continue;
+                                }
+                                if (dc <= 0 || dc >= b.na - 64) continue;
+                                const long dev = std::labs((long)(c.t - c.q) - (long)(ct - cq));
+                                if (dev > relay_tol) continue;
+                                if (best_idx < 0 || dev < best_dev) { best_idx = pos; best_dev = dev; }
+                            }
+                            if (best_idx >= 0 && (long)sd.runs.size() <= relay_max) {
+                                const Anchor &w = u.anchors[u.by_q[(size_t)best_idx]];
+                                sd.runs.push_back(Run{(w.q - b.q0) * dirn, (w.t - b.t0) * dirn, {}});
+                            }
+                            if (debug) fprintf(stderr, "[miblast]   side %d (dir %d, nb %d): first stop at row %d, %zu relays, last at row %d\n", si, b.dir, b.nb, exit_row,
+                                               sd.runs.size() - 1, sd.runs.back().dr);
+                            for (size_t r = 1; r < sd.runs.size(); r++) {
+                                const bool last = r + 1 == sd.runs.size();
+                                const int32_t stop = last ? 0 : sd.runs[r + 1].dr + (int32_t)relay_w - sd.runs[r].dr;
+                                add_piece(si, (int)r, b, 0, (int32_t)relay_w, stop, (int32_t)relay_w, -1, last ? -1 : (int)r + 1);
+                            }
+                        }
+                        // try the hand-over the exit row was aimed at
+                        Piece &tpp = pieces[(size_t)tp];
+                        bool handed = false;
+                        if (tpp.target_run > 0) {
+                            const Run &nx = sd.runs[(size_t)tpp.target_run];
+                            const int np0 = nx.pieces.front();
+                            if (np0 >= (int)launched) break;                     // the relay has not run yet
+                            const int nslot = 2 * np0;
+                            const SnapHdr *N = snap_hdr(nslot);
+                            bool ok = N->valid && N->row + nx.dr == exit_row && outs[(size_t)np0].overflow == 0;
+                            if (ok) {
+                                const int32_t shift = nx.dc - rn_dc;                 // E column = N column + shift
+                                const long long c = ((long long)E->best + sd.c_off) - (long long)N->best;   // N score + c = head score
+                                ok = E->LY == N->LY + shift && E->RY == N->RY + shift;
+                                if (ok) {
+                                    const int32_t *EC = snap_C(eslot), *ED = EC + kSnapCols, *NC = snap_C(nslot), *ND = NC + kSnapCols;
+                                    const long long eoff = sd.c_off;
+                                    const long long thr = (long long)E->best + eoff - p.ydrop;     // in head scores
+                                    const int w = E->RY - E->LY;
+                                    for (int x = 0; x < w && ok; x++) {
+                                        const bool ea = EC[x] != kNeg, na_ = NC[x] != kNeg;
+                                        if (ea != na_ || (ea && (long long)EC[x] + eoff != (long long)NC[x] + c)) ok = false;
+                                        const long long ed = (long long)ED[x] + eoff, nd = (long long)ND[x] + c;
+                                        const bool el = ed - p.gap_extend >= thr, nl = nd - p.gap_extend >= thr;   // can this D still matter?
+                                        if (el != nl || (el && ed != nd)) ok = false;
+                                    }
+                                }
+                                if (ok) {
+                                    sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
+                                    sd.entry_cells = N->cells; sd.entry_rows = N->rows;
+                                    sd.c_off = c;
+                                    sd.cur_run = tpp.target_run;
+                                    for (int pc : sd.runs[(size_t)sd.cur_run].pieces) sd.chain.push_back(pc);
+                                    handed = true;
+                                    n_verify_ok++;
+                                } else n_verify_bad++;
+                            } else n_verify_bad++;
+                        }
+                        if (handed) continue;
+                        // continue this run from its exit snapshot, aimed at the next relay further down
+                        int next_t = -1;
+                        for (size_t r = (size_t)std::max(tpp.target_run, sd.cur_run) + 1; r < sd.runs.size(); r++)
+                            if (sd.runs[r].dr + (int32_t)relay_w > exit_row + 64) { next_t = (int)r; break; }
+                        const int32_t stop = next_t > 0 ? sd.runs[(size_t)next_t].dr + (int32_t)relay_w - rn_dr : 0;
+                        const int id = add_piece(si, sd.cur_run, sd.base, E->row, E->row, stop, 0, eslot, next_t);
+                        sd.chain.push_back(id);
+                        break;
+                    }
+                }
+            }
+            if (!arena_full) {
+                // rows wider than the LDS ring: those sides are evaluated in one piece with the C/D ring in HBM
+                std::vector<int> wide;
+                for (int si = 0; si < nsides; si++) if (sides[(size_t)si].wide) wide.push_back(si);
+                for (size_t w0 = 0; w0 < wide.size() && !arena_full; w0 += 32) {
+                    const size_t w1 = std::min(wide.size(), w0 + 32);
+                    const size_t first = pieces.size();
+                    for (size_t k = w0; k < w1; k++) {
+                        SideRun &sd = sides[(size_t)wide[k]];
+                        sd.runs.assign(1, Run{0, 0, {}});
+                        sd.chain.clear(); sd.cur_run = 0; sd.c_off = 0; sd.acc_cells = sd.acc_rows = sd.entry_cells = sd.entry_rows = 0; sd.gbest = -1;
+                        DpProb b = sd.base; b.snap_idx = -1;
+                        const int id = add_piece(wide[k], 0, b, 0, -1, 0, 0, -1, -1);
+                        sd.chain.push_back(id);
+                    }
+                    const size_t n_new = pieces.size() - first;
+                    g.probs.ensure_keep(pieces.size()); g.outs.ensure_keep(pieces.size()); g.rowdir.ensure_keep((size_t)dir_entries + 1);
+                    outs.resize(pieces.size());
+                    g.grows.ensure(n_new * 2 * (size_t)kGlobalRowCap);
+                    MB_HIP(hipMemcpy(g.probs.p + first, probs.data() + first, n_new * sizeof(DpProb), hipMemcpyHostToDevice));
+                    run_ydrop_timed(ctx, st, true, g.probs.p + first, g.outs.p + first, (int)n_new, g.pair_ptrs.p, p, kBlkWide);
+                    MB_HIP(hipMemcpy(outs.data() + first, g.outs.p + first, n_new * sizeof(DpOut), hipMemcpyDeviceToHost));
+                    for (size_t x = first; x < pieces.size(); x++) {
+                        const DpOut &o = outs[x];
+                        if (o.overflow == 1) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
+                        if (o.overflow == 3) { arena_full = true; continue; }
+                        SideRun &sd = sides[(size_t)pieces[x].side];
+                        sd.gbest = o.best; sd.gbi = o.bi; sd.gbj = o.bj; sd.best_piece = (int)x;
+                        sd.acc_cells = o.cells; sd.acc_rows = o.rows; sd.done = true;
+                        st.dp_sides_run++; st.dp_cells_run += o.cells; st.dp_rows_run += o.rows;
+                    }
                 }
             }
             if (!arena_full) break;
@@ -669,52 +891,76 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             g.arena.release();                                  // free first: old + new need not coexist
             g.arena.alloc(bigger);
         }
+        if (debug) fprintf(stderr, "[miblast] round %d: %d sides in %zu pieces, %ld launches, hand-overs %ld accepted / %ld rejected\n",
+                           round, nsides, pieces.size(), n_subrounds, n_verify_ok, n_verify_bad);
 
         // ---- traceback of every anchor reaching --gappedthresh ------------------------------------------
         std::vector<size_t> acc;                        // indices into pend
-        std::vector<int> which;
+        std::vector<TbSide> tbs;
+        std::vector<TbPiece> tbp;
         uint64_t ooff = 0;
         for (size_t k = 0; k < pend.size(); k++) {
             Unit &u = units[pend[k].unit];
             Cached c;
-            const DpOut &R = outs[2 * k], &L = outs[2 * k + 1];
+            const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
             const Anchor &a = u.anchors[pend[k].anchor];
-            c.score = R.best + L.best;
-            c.cells = R.cells + L.cells; c.rows = (int64_t)R.rows + L.rows;
-            c.t_lo = a.t - L.bj; c.t_hi = a.t + R.bj; c.q_lo = a.q - L.bi; c.q_hi = a.q + R.bi;
+            c.score = R.gbest + L.gbest;
+            c.cells = R.acc_cells + L.acc_cells; c.rows = R.acc_rows + L.acc_rows;
+            c.t_lo = a.t - L.gbj; c.t_hi = a.t + R.gbj; c.q_lo = a.q - L.gbi; c.q_hi = a.q + R.gbi;
             c.accepted = c.score >= p.gappedthresh;
             c.dmin = 0x7fffffff; c.dmax = -0x7fffffff - 1;          // set by the merge below; until then covers nothing
             if (c.accepted) {
                 acc.push_back(k);
                 for (int side = 0; side < 2; side++) {
-                    which.push_back((int)(2 * k) + side);
-                    probs[2 * k + side].ops_off = ooff;
-                    ooff += (uint64_t)outs[2 * k + side].bi + (uint64_t)outs[2 * k + side].bj + 2;      // worst case: every column its own run
+                    const SideRun &sd = sides[2 * k + (size_t)side];
+                    TbSide ts;
+                    memset(&ts, 0, sizeof ts);
+                    ts.first_piece = (int32_t)tbp.size();
+                    // the chain from the piece that holds the best cell back to the head
+                    size_t at = 0;
+                    while (at < sd.chain.size() && sd.chain[at] != sd.best_piece) at++;
+                    for (size_t x = at + 1; x-- > 0;) {
+                        const int pc = sd.chain[x];
+                        const Piece &pp = pieces[(size_t)pc];
+                        TbPiece tp;
+                        memset(&tp, 0, sizeof tp);
+                        tp.row_off = probs[(size_t)pc].row_off; tp.row_lo = pp.row_lo; tp.min_row = pp.min_row;
+                        if (x > 0) {
+                            const Run &r0 = sd.runs[(size_t)pp.run], &r1 = sd.runs[(size_t)pieces[(size_t)sd.chain[x - 1]].run];
+                            tp.dr = r0.dr - r1.dr; tp.dc = r0.dc - r1.dc;
+                        }
+                        tbp.push_back(tp);
+                    }
+                    ts.n_pieces = (int32_t)tbp.size() - ts.first_piece;
+                    const Run &rb = sd.runs[(size_t)pieces[(size_t)sd.best_piece].run];
+                    ts.bi = sd.gbi - rb.dr; ts.bj = sd.gbj - rb.dc;
+                    ts.ops_off = ooff;
+                    ooff += (uint64_t)sd.gbi + (uint64_t)sd.gbj + 2;      // worst case: every column its own run
+                    tbs.push_back(ts);
                 }
             }
             u.cache.emplace(pend[k].anchor, std::move(c));
         }
         const double t_tb0 = now_s();
         if (!acc.empty()) {
-            g.which.ensure(which.size()); g.ops.ensure((size_t)ooff + 64);
-            MB_HIP(hipMemcpyAsync(g.probs.p, probs.data(), (size_t)np * sizeof(DpProb), hipMemcpyHostToDevice, s));
-            MB_HIP(hipMemcpyAsync(g.which.p, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, s));
-            launch_traceback(g.probs.p, g.outs.p, g.which.p, (int)which.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, s);
-            MB_HIP(hipMemcpyAsync(outs.data(), g.outs.p, (size_t)np * sizeof(DpOut), hipMemcpyDeviceToHost, s));
+            g.tb_sides.ensure(tbs.size()); g.tb_pieces.ensure(tbp.size()); g.ops.ensure((size_t)ooff + 64);
+            MB_HIP(hipMemcpyAsync(g.tb_sides.p, tbs.data(), tbs.size() * sizeof(TbSide), hipMemcpyHostToDevice, s));
+            MB_HIP(hipMemcpyAsync(g.tb_pieces.p, tbp.data(), tbp.size() * sizeof(TbPiece), hipMemcpyHostToDevice, s));
+            launch_traceback(g.tb_sides.p, g.tb_pieces.p, (int)tbs.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, s);
+            MB_HIP(hipMemcpyAsync(tbs.data(), g.tb_sides.p, tbs.size() * sizeof(TbSide), hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
             // only the run slots each side actually used travel: packed on the device, then one copy into pinned memory
-            std::vector<unsigned long long> coff(which.size() + 1);
+            std::vector<unsigned long long> coff(tbs.size() + 1);
             unsigned long long ctot = 0;
-            for (size_t x = 0; x < which.size(); x++) { coff[x] = ctot; ctot += (unsigned long long)outs[(size_t)which[x]].n_ops; }
-            coff[which.size()] = ctot;
+            for (size_t x = 0; x < tbs.size(); x++) { coff[x] = ctot; ctot += (unsigned long long)tbs[x].n_ops; }
+            coff[tbs.size()] = ctot;
             g.coff.ensure(coff.size()); g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
             MB_HIP(hipMemcpyAsync(g.coff.p, coff.data(), coff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-            launch_pack_ops(g.probs.p, g.which.p, (int)which.size(), g.coff.p, g.ops.p, g.ops_packed.p, s);
+            launch_pack_ops(g.tb_sides.p, (int)tbs.size(), g.coff.p, g.ops.p, g.ops_packed.p, s);
             if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
-            for (size_t x = 0; x < which.size(); x++) probs[(size_t)which[x]].ops_off = coff[x];      // host view: packed offsets
             const uint32_t *hops = g.hops.p;
-            if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, which.size(), (unsigned long long)ooff);
+            if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, tbs.size(), (unsigned long long)ooff);
             const double t_mg0 = now_s();
             // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
             // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
@@ -725,8 +971,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 const size_t k = acc[x];
                 const Unit &u = units[pend[k].unit];
                 Cached &c = *cptr[x];
-                const uint32_t *Rops = hops + probs[2 * k].ops_off, *Lops = hops + probs[2 * k + 1].ops_off;
-                const size_t nR = (size_t)outs[2 * k].n_ops, nL = (size_t)outs[2 * k + 1].n_ops;
+                const uint32_t *Rops = hops + coff[2 * x], *Lops = hops + coff[2 * x + 1];
+                const size_t nR = (size_t)tbs[2 * x].n_ops, nL = (size_t)tbs[2 * x + 1].n_ops;
                 const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
                 const uint8_t *qc = jobs[(size_t)u.pair]->qc_h[u.strand];
                 int64_t tt = c.t_lo, qq = c.q_lo;
@@ -751,7 +997,14 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
                 if (cur_len) c.ops.push_back((cur_len << 2) | cur_op);
                 c.dmin = dmin; c.dmax = dmax;
-                if (tt != c.t_hi || qq != c.q_hi) bad++;
+                if (tt != c.t_hi || qq != c.q_hi) {
+                    if (!bad++ && debug) {
+                        const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
+                        fprintf(stderr, "[miblast] span error: anchor %zu box t %d..%d q %d..%d reached t %lld q %lld; R: best %d at (%d,%d) chain %zu runs %zu best_piece run %d, nR %zu; L: best %d at (%d,%d) chain %zu runs %zu best_piece run %d, nL %zu\n",
+                                k, c.t_lo, c.t_hi, c.q_lo, c.q_hi, (long long)tt, (long long)qq, R.gbest, R.gbi, R.gbj, R.chain.size(), R.runs.size(),
+                                pieces[(size_t)R.best_piece].run, nR, L.gbest, L.gbi, L.gbj, L.chain.size(), L.runs.size(), pieces[(size_t)L.best_piece].run, nL);
+                    }
+                }
             };
             parallel_for(acc.size(), merge_one);
             if (bad) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
