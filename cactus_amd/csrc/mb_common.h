@@ -81,6 +81,14 @@ struct TbSide {
     int32_t n_ops, pad;
 };
 
+// relay hand-over check (k_verify): exit snapshot `eslot` of the upstream piece against entry snapshot `nslot` of the relay
+struct VerifyJob { int32_t eslot, nslot, shift, drow; };     // E column = N column + shift; E row = N row + drow
+struct VerifyOut {
+    int32_t ok, n_rows;
+    int32_t n_best, c;                        // relay's best at its entry row; E score = N score + c
+    int64_t n_cells;
+};
+
 struct UngappedCounters {
     unsigned long long extended, cols, hsps;
 };
@@ -136,6 +144,7 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s);
 void launch_traceback(TbSide *sides, const TbPiece *pieces, int n, const uint8_t *arena,
                       unsigned long long arena_bytes, const unsigned long long *rowdir, uint32_t *ops, hipStream_t s);
+void launch_verify(const VerifyJob *jobs, VerifyOut *res, int n, const uint8_t *snaps, int Y, int E, hipStream_t s);
 void launch_pack_ops(const TbSide *sides, int n, const unsigned long long *coff, const uint32_t *ops,
                      uint32_t *packed, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);

@@ -206,6 +206,8 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<TbSide> tb_sides;
     DevBuf<TbPiece> tb_pieces;
     DevBuf<uint8_t> snaps;
+    DevBuf<VerifyJob> vjobs;
+    DevBuf<VerifyOut> vres;
     DevBuf<PairPtrs> pair_ptrs;
 };
 
@@ -616,60 +618,111 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // A side (anchor, direction) is evaluated as a chain of PIECES (k_ydrop problems).  A one-sided DP is a
         // row-sequential chain, so a 250 000-row alignment would keep one workgroup busy for a quarter of a second
         // while the rest of the GPU idles.  Instead the first piece of a side stops after `relay_s0` rows; a side that
-        // is still alive there is continued from its exit snapshot AND relayed: fresh DPs ("runs") are started at
-        // downstream anchors of the same unit -- the ungapped HSPs a long alignment passes through -- and each stops
-        // `relay_w` rows after the origin of the next one.  All of them run concurrently.  A hand-over is accepted only
-        // if the state of the upstream run after the hand-over row equals the relay's state after the same row: same
-        // window, same running best, and every live C / D value equal up to one constant (values too low to ever
-        // reach the y-drop threshold again are compared as dead).  The recurrence is invariant under adding a
-        // constant, so from that row on both runs compute the same rows and the relay's rows simply ARE the rows of
-        // the sequential DP.  A rejected hand-over costs nothing but time: the upstream run is continued from its
-        // snapshot to the next relay.  Results (score, end cell, trace, cell and row counts) never depend on where
-        // relays start or whether they are accepted.
-        struct Piece { int side, run; int32_t row_lo, min_row, stop_row; int target_run; bool accounted; };
-        struct Run { int32_t dr, dc; std::vector<int> pieces; };
+        // is still alive there is continued from its exit snapshot AND relayed: fresh DPs are started at downstream
+        // anchors of the same unit -- the ungapped HSPs a long alignment passes through -- and each stops `relay_w`
+        // rows after the origin of the next one.  All of them run concurrently.  A hand-over is accepted only if the
+        // state of the upstream piece after the hand-over row equals the relay's state after the same row (k_verify:
+        // same window, every value that can still matter equal up to one constant).  The recurrence is invariant
+        // under adding a constant, so from that row on both compute the same rows and the relay's rows simply ARE the
+        // rows of the sequential DP.  A rejected hand-over costs nothing but time: the upstream piece is continued
+        // from its snapshot to the relay after that.  Relays sit on a lattice of the unit's anchors that does not
+        // depend on the side (next_relay), so every side running through the same alignment shares them.  Results
+        // (score, end cell, trace, cell and row counts) never depend on where relays start or whether they are accepted.
+        struct Piece {
+            int unit; int32_t ot, oq, dir;      // origin (concatenated coordinates) and direction
+            int32_t row_lo, min_row, stop_row;
+            int target_anchor;                  // anchor of the relay the stop row is aimed at (-1: none)
+            int init_piece;                     // continuation: the piece whose exit snapshot it starts from
+            int vjob;                           // index into vres of the hand-over check made after it ran (-1: none)
+        };
         struct SideRun {
             DpProb base;
-            std::vector<Run> runs;
+            int unit = 0;
+            std::vector<int> cur;               // pieces of the current run (one origin), in row order
+            size_t accounted = 0;               // how many of them are folded into the result
             std::vector<int> chain;             // validated pieces, head first
-            int cur_run = 0;
             long long c_off = 0;                // score of the current run's origin in the head's scores
             long long acc_cells = 0, acc_rows = 0, entry_cells = 0, entry_rows = 0;
             int gbest = -1, gbi = 0, gbj = 0, best_piece = -1;
-            bool done = false, wide = false, relayed = false, waiting = false;
+            bool done = false, wide = false;
         };
         const int nsides = (int)pend.size() * 2;
         std::vector<SideRun> sides;
         std::vector<Piece> pieces;
         std::vector<DpProb> probs;
         std::vector<DpOut> outs;
-        std::vector<uint8_t> hsnaps;
+        std::vector<VerifyJob> vjobs;
+        std::vector<VerifyOut> vres;
+        std::unordered_map<unsigned long long, int> relay_piece;       // (unit, anchor, direction) -> its fresh piece
         bool arena_full = false;
         long n_verify_ok = 0, n_verify_bad = 0, n_subrounds = 0;
-        auto snap_hdr = [&](int slot) -> const SnapHdr * { return (const SnapHdr *)(hsnaps.data() + (size_t)slot * kSnapBytes); };
-        auto snap_C = [&](int slot) -> const int32_t * { return (const int32_t *)(hsnaps.data() + (size_t)slot * kSnapBytes + sizeof(SnapHdr)); };
+        auto relay_key = [](int unit, int anchor, int dir) -> unsigned long long {
+            return ((unsigned long long)(unsigned)unit << 34) | ((unsigned long long)(unsigned)anchor << 1) | (dir > 0 ? 1ull : 0ull);
+        };
+        // the relay after the point (t, q) of a unit, walking in direction dir: the best-scoring anchor (= smallest index)
+        // of the first q-bucket of width relay_s at least min_dq rows away whose diagonal lies within relay_tol of
+        // (t - q).  Depends on the unit's anchors only, so chains started from different heads merge.
+        auto next_relay = [&](const Unit &u, const DpProb &b, int32_t t, int32_t q, int32_t min_dq) -> int {
+            const int32_t dirn = b.dir;
+            const long s_from = (long)dirn * q + min_dq;                 // first admissible position in walking order, s = dir * q
+            long bucket = s_from >= 0 ? s_from / relay_s : -((-s_from + relay_s - 1) / relay_s);      // floor
+            for (int tries = 0; tries < 8; tries++, bucket++) {
+                // bucket covers s in [bucket * S, (bucket + 1) * S) with s = dirn * q
+                const long s_lo = std::max(bucket * relay_s, s_from), s_hi = (bucket + 1) * relay_s;
+                const long q_lo = dirn > 0 ? s_lo : -(s_hi - 1), q_hi = dirn > 0 ? s_hi : -s_lo + 1;      // [q_lo, q_hi)
+                auto it = std::lower_bound(u.by_q.begin(), u.by_q.end(), q_lo, [&](uint32_t x, long qq) { return (long)u.anchors[x].q < qq; });
+                long best = -1;
+                for (; it != u.by_q.end() && (long)u.anchors[*it].q < q_hi; ++it) {
+                    const Anchor &c = u.anchors[*it];
+                    const int32_t dr = (c.q - b.q0) * dirn, dc = (c.t - b.t0) * dirn;
+                    if (dr <= 0 || dc <= 0 || dc >= b.na - 64 || dr >= b.nb - (int32_t)relay_w - 64) continue;
+                    if (std::labs((long)(c.t - c.q) - (long)(t - q)) > relay_tol) continue;
+                    if (best < 0 || (long)*it < best) best = (long)*it;
+                }
+                if (best >= 0) return (int)best;
+            }
+            return -1;
+        };
         while (true) {                                   // retried with a larger arena if the trace does not fit
             sides.assign((size_t)nsides, SideRun());
-            pieces.clear(); probs.clear(); outs.clear(); hsnaps.clear();
+            pieces.clear(); probs.clear(); outs.clear(); vjobs.clear(); vres.clear(); relay_piece.clear();
             arena_full = false;
             uint64_t dir_entries = 0;
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
-            auto add_piece = [&](int side, int run, const DpProb &proto, int32_t row_lo, int32_t min_row, int32_t stop_row,
-                                 int32_t snap_row, int init_snap, int target_run) -> int {
+            auto add_piece = [&](int unit, const DpProb &base, int32_t ot, int32_t oq, int32_t row_lo, int32_t min_row, int32_t stop_row,
+                                 int32_t snap_row, int init_piece, int target_anchor) -> int {
                 const int id = (int)pieces.size();
-                SideRun &sd = sides[(size_t)side];
-                const Run &rn = sd.runs[(size_t)run];
-                DpProb pr = proto;
-                pr.t0 = proto.t0 + proto.dir * rn.dc; pr.q0 = proto.q0 + proto.dir * rn.dr;
-                pr.na = proto.na - rn.dc; pr.nb = proto.nb - rn.dr;
-                pr.row_lo = row_lo; pr.stop_row = stop_row; pr.snap_row = snap_row; pr.init_snap = init_snap; pr.snap_idx = 2 * id;
+                DpProb pr = base;
+                const int32_t dr = (oq - base.q0) * base.dir, dc = (ot - base.t0) * base.dir;
+                pr.t0 = ot; pr.q0 = oq; pr.na = base.na - dc; pr.nb = base.nb - dr;
+                pr.row_lo = row_lo; pr.stop_row = stop_row; pr.snap_row = snap_row;
+                pr.init_snap = init_piece >= 0 ? 2 * init_piece + 1 : -1; pr.snap_idx = 2 * id;
                 pr.row_off = dir_entries;
                 const int64_t last = stop_row > 0 ? stop_row : pr.nb;
                 dir_entries += (uint64_t)((last - row_lo) / 4096) + 2;
                 probs.push_back(pr);
-                pieces.push_back(Piece{side, run, row_lo, min_row, stop_row, target_run, false});
-                sd.runs[(size_t)run].pieces.push_back(id);
+                pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target_anchor, init_piece, -1});
+                if (target_anchor >= 0) {
+                    // checked right after the launch: this piece's exit state against the aimed relay's entry state
+                    const Anchor &ta = units[(size_t)unit].anchors[(size_t)target_anchor];
+                    pieces.back().vjob = (int)vjobs.size();
+                    vjobs.push_back(VerifyJob{2 * id + 1, -1, (ta.t - ot) * base.dir, (ta.q - oq) * base.dir});   // nslot set at launch
+                }
                 return id;
+            };
+            // fresh pieces of the relay chain that starts at anchor `a` (created once per unit and direction)
+            auto plant_chain = [&](int unit, const DpProb &base, int a) {
+                const Unit &u = units[(size_t)unit];
+                for (long n = 0; a >= 0 && n < relay_max; n++) {
+                    const unsigned long long key = relay_key(unit, a, base.dir);
+                    if (relay_piece.count(key)) return;                          // the rest of the chain exists already
+                    const Anchor &c = u.anchors[(size_t)a];
+                    int nx = next_relay(u, base, c.t, c.q, (int32_t)(relay_s / 4));
+                    int32_t stop = nx >= 0 ? (u.anchors[(size_t)nx].q - c.q) * base.dir + (int32_t)relay_w : 0;
+                    if (nx >= 0 && n + 1 == relay_max) { nx = -1; stop = (int32_t)(relay_s + relay_w); }   // chain cut: whoever gets here plants the rest
+                    relay_piece[key] = add_piece(unit, base, c.t, c.q, 0, (int32_t)relay_w, stop, (int32_t)relay_w, -1, nx);
+                    a = nx;
+                }
             };
             for (size_t k = 0; k < pend.size(); k++) {
                 const Unit &u = units[pend[k].unit];
@@ -685,166 +738,103 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     if (sdn == 0) { b.dir = +1; b.na = (int32_t)(thi - a.t); b.nb = (int32_t)(qhi - a.q); }
                     else { b.dir = -1; b.na = (int32_t)(a.t - tlo); b.nb = (int32_t)(a.q - qlo); }
                     SideRun &sd = sides[2 * k + (size_t)sdn];
-                    sd.base = b;
-                    sd.runs.push_back(Run{0, 0, {}});
-                    const int id = add_piece((int)(2 * k) + sdn, 0, b, 0, -1, (int32_t)relay_s0, 0, -1, -1);
-                    sd.chain.push_back(id);
+                    sd.base = b; sd.unit = (int)pend[k].unit;
+                    const int id = add_piece(sd.unit, b, b.t0, b.q0, 0, -1, (int32_t)relay_s0, 0, -1, -1);
+                    sd.cur.push_back(id); sd.chain.push_back(id);
                 }
             }
-            size_t launched = 0;                          // pieces [0, launched) have run
+            size_t launched = 0, vlaunched = 0;           // pieces [0, launched) have run, checks [0, vlaunched) are made
             while (launched < pieces.size() && !arena_full) {
                 n_subrounds++;
-                const size_t n_new = pieces.size() - launched;
+                const size_t n_new = pieces.size() - launched, v_new = vjobs.size() - vlaunched;
                 g.probs.ensure_keep(pieces.size()); g.outs.ensure_keep(pieces.size()); g.rowdir.ensure_keep((size_t)dir_entries + 1);
                 g.snaps.ensure_keep(pieces.size() * 2 * kSnapBytes);
-                outs.resize(pieces.size()); hsnaps.resize(pieces.size() * 2 * kSnapBytes);
+                g.vjobs.ensure(v_new + 1); g.vres.ensure(v_new + 1);
+                outs.resize(pieces.size()); vres.resize(vjobs.size());
+                for (size_t x = launched; x < pieces.size(); x++)
+                    if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = 2 * relay_piece.at(relay_key(pieces[x].unit, pieces[x].target_anchor, pieces[x].dir));
                 MB_HIP(hipMemcpyAsync(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), hipMemcpyHostToDevice, s));
-                MB_HIP(hipMemsetAsync(g.snaps.p + launched * 2 * kSnapBytes, 0, n_new * 2 * kSnapBytes, s));
+                if (v_new) MB_HIP(hipMemcpyAsync(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), hipMemcpyHostToDevice, s));
+                MB_HIP(hipMemsetAsync(g.snaps.p + launched * 2 * kSnapBytes, 0, n_new * 2 * kSnapBytes, s));      // valid = 0
                 run_ydrop_timed(ctx, st, false, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk);
-                MB_HIP(hipMemcpy(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), hipMemcpyDeviceToHost));
-                bool any_stop = false;
-                for (size_t x = launched; x < pieces.size(); x++) { arena_full |= outs[x].overflow == 3; any_stop |= outs[x].stopped != 0 || probs[x].snap_row > 0; }
+                launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
+                MB_HIP(hipMemcpyAsync(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), hipMemcpyDeviceToHost, s));
+                if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
+                MB_HIP(hipStreamSynchronize(s));
+                for (size_t x = launched; x < pieces.size(); x++) arena_full |= outs[x].overflow == 3;
                 if (arena_full) break;
-                if (any_stop) MB_HIP(hipMemcpy(hsnaps.data() + launched * 2 * kSnapBytes, g.snaps.p + launched * 2 * kSnapBytes, n_new * 2 * kSnapBytes, hipMemcpyDeviceToHost));
                 for (size_t x = launched; x < pieces.size(); x++) {
                     st.dp_sides_run++;
-                    const SnapHdr *h0 = probs[x].row_lo > 0 ? snap_hdr(probs[x].init_snap) : nullptr;
-                    st.dp_cells_run += outs[x].cells - (h0 ? h0->cells : 0);
-                    st.dp_rows_run += outs[x].rows - (h0 ? h0->rows : 0);
+                    const DpOut *o0 = pieces[x].init_piece >= 0 ? &outs[(size_t)pieces[x].init_piece] : nullptr;
+                    st.dp_cells_run += outs[x].cells - (o0 ? o0->cells : 0);
+                    st.dp_rows_run += outs[x].rows - (o0 ? o0->rows : 0);
                 }
                 if (debug) {
                     int maxrows = 0; long long clk = 0;
                     for (size_t x = launched; x < pieces.size(); x++) {
-                        const int r = outs[x].rows - (probs[x].row_lo > 0 ? snap_hdr(probs[x].init_snap)->rows : 0);
+                        const int r = outs[x].rows - (pieces[x].init_piece >= 0 ? outs[(size_t)pieces[x].init_piece].rows : 0);
                         if (r > maxrows) { maxrows = r; clk = outs[x].clocks; }
-                        if (r > 3 * (relay_s + relay_w) && relay_s0 > 0)
-                            fprintf(stderr, "[miblast]   long piece %zu: side %d run %d (of %zu) row_lo %d stop_row %d rows %d stopped %d dr %d\n", x, pieces[x].side, pieces[x].run,
-                                    sides[(size_t)pieces[x].side].runs.size(), pieces[x].row_lo, pieces[x].stop_row, r, outs[x].stopped, sides[(size_t)pieces[x].side].runs[(size_t)pieces[x].run].dr);
                     }
-                    fprintf(stderr, "[miblast] round %d.%ld: %zu pieces, max rows %d (%lld shader clocks = %.0f per row), dp kernel total %.2f ms so far, shadow_q %ld\n",
-                            round, n_subrounds, n_new, maxrows, clk, (double)clk / std::max(1, maxrows), st.t_dp_kernel_ms, shadow_q);
+                    fprintf(stderr, "[miblast] round %d.%ld: %zu pieces, %zu checks, max rows %d (%lld shader clocks = %.0f per row), dp kernel total %.2f ms so far, shadow_q %ld\n",
+                            round, n_subrounds, n_new, v_new, maxrows, clk, (double)clk / std::max(1, maxrows), st.t_dp_kernel_ms, shadow_q);
                 }
-                launched = pieces.size();
+                launched = pieces.size(); vlaunched = vjobs.size();
                 // ---- advance every side along its chain; new pieces (continuations, relays) are queued for the next launch
                 for (int si = 0; si < nsides; si++) {
                     SideRun &sd = sides[(size_t)si];
-                    if (sd.done || sd.wide) continue;
-                    while (true) {
-                        const int tp = sd.runs[(size_t)sd.cur_run].pieces.back();
-                        const int32_t rn_dr = sd.runs[(size_t)sd.cur_run].dr, rn_dc = sd.runs[(size_t)sd.cur_run].dc;   // (sd.runs grows below)
+                    while (!sd.done && !sd.wide) {
+                        const int tp = sd.cur.back();
                         if (tp >= (int)launched) break;                          // queued, not run yet
-                        for (int pc : sd.runs[(size_t)sd.cur_run].pieces) {      // fold the run's finished pieces into the side's result
-                            Piece &pp = pieces[(size_t)pc];
-                            if (pp.accounted) continue;
-                            pp.accounted = true;
+                        const Piece cp = pieces[(size_t)tp];                     // (copy: `pieces` grows below)
+                        const int32_t dr = (cp.oq - sd.base.q0) * sd.base.dir, dc = (cp.ot - sd.base.t0) * sd.base.dir;
+                        for (; sd.accounted < sd.cur.size(); sd.accounted++) {   // fold the run's finished pieces into the side's result
+                            const int pc = sd.cur[sd.accounted];
                             const DpOut &o = outs[(size_t)pc];
                             if (o.overflow == 1) { sd.wide = true; break; }
                             if ((long long)o.best + sd.c_off > sd.gbest) {
-                                sd.gbest = (int)((long long)o.best + sd.c_off); sd.gbi = o.bi + rn_dr; sd.gbj = o.bj + rn_dc; sd.best_piece = pc;
+                                sd.gbest = (int)((long long)o.best + sd.c_off); sd.gbi = o.bi + dr; sd.gbj = o.bj + dc; sd.best_piece = pc;
                             }
                         }
                         if (sd.wide) break;
-                        const DpOut &o = outs[(size_t)tp];
+                        const DpOut o = outs[(size_t)tp];
                         if (!o.stopped) {                                        // natural end of the DP
                             sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
                             sd.done = true;
                             break;
                         }
-                        const int eslot = 2 * tp + 1;
-                        const SnapHdr *E = snap_hdr(eslot);
-                        const int32_t exit_row = E->row + rn_dr;                 // in the head's rows
-                        if (!sd.relayed) {
-                            // first stop of the side: plant relays on downstream anchors of the unit
-                            sd.relayed = true;
-                            const Unit &u = units[pend[(size_t)si / 2].unit];
-                            const DpProb &b = sd.base;
-                            int32_t ct = b.t0, cq = b.q0;                        // last chain point
-                            const int32_t dirn = b.dir;
-                            // anchors sorted by q: walk in the side's direction
-                            auto lb = std::lower_bound(u.by_q.begin(), u.by_q.end(), b.q0, [&](uint32_t x, int32_t q) { return u.anchors[x].q < q; });
-                            long pos = (long)(lb - u.by_q.begin());
-                            if (dirn < 0) pos--;
-                            int32_t need_dr = (int32_t)std::max<long>(exit_row - relay_w + 64, relay_s);   // entry row must lie beyond the exit row
-                            long best_idx = -1; long best_dev = 0;
-                            for (; pos >= 0 && pos < (long)u.by_q.size(); pos += dirn) {
-                                const Anchor &c = u.anchors[u.by_q[(size_t)pos]];
-                                const int32_t dr = (c.q - b.q0) * dirn, dc = (c.t - b.t0) * dirn;
-                                if (dr < need_dr) continue;
-                                if (dr >= b.nb - relay_w - 64) break;
-                                const bool window_end = dr >= need_dr + relay_s / 2;
-                                if (window_end && best_idx >= 0) {
-                                    const Anchor &w = u.anchors[u.by_q[(size_t)best_idx]];
-                                    const int32_t wdr = (w.q - b.q0) * dirn, wdc = (w.t - b.t0) * dirn;
-                                    sd.runs.push_back(Run{wdr, wdc, {}});
-                                    ct = w.t; cq = w.q;
-                                    need_dr = wdr + (int32_t)relay_s;
-                                    best_idx = -1;
-                                    if ((long)sd.runs.size() > relay_max) break;
-                                    if (dr < need_dr) continue;
-                                }
-                                if (dc <= 0 || dc >= b.na - 64) continue;
-                                const long dev = std::labs((long)(c.t - c.q) - (long)(ct - cq));
-                                if (dev > relay_tol) continue;
-                                if (best_idx < 0 || dev < best_dev) { best_idx = pos; best_dev = dev; }
+                        const Unit &u = units[(size_t)sd.unit];
+                        int aim = cp.target_anchor;                              // the relay this piece stopped for
+                        if (aim >= 0) {
+                            const VerifyOut &v = vres[(size_t)cp.vjob];
+                            if (v.ok) {
+                                const int np0 = relay_piece.at(relay_key(sd.unit, aim, sd.base.dir));
+                                sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
+                                sd.entry_cells = v.n_cells; sd.entry_rows = v.n_rows;
+                                sd.c_off += v.c;
+                                sd.cur.assign(1, np0); sd.accounted = 0;
+                                sd.chain.push_back(np0);
+                                n_verify_ok++;
+                                continue;
                             }
-                            if (best_idx >= 0 && (long)sd.runs.size() <= relay_max) {
-                                const Anchor &w = u.anchors[u.by_q[(size_t)best_idx]];
-                                sd.runs.push_back(Run{(w.q - b.q0) * dirn, (w.t - b.t0) * dirn, {}});
-                            }
-                            if (debug) fprintf(stderr, "[miblast]   side %d (dir %d, nb %d): first stop at row %d, %zu relays, last at row %d\n", si, b.dir, b.nb, exit_row,
-                                               sd.runs.size() - 1, sd.runs.back().dr);
-                            for (size_t r = 1; r < sd.runs.size(); r++) {
-                                const bool last = r + 1 == sd.runs.size();
-                                const int32_t stop = last ? 0 : sd.runs[r + 1].dr + (int32_t)relay_w - sd.runs[r].dr;
-                                add_piece(si, (int)r, b, 0, (int32_t)relay_w, stop, (int32_t)relay_w, -1, last ? -1 : (int)r + 1);
-                            }
+                            n_verify_bad++;
+                            aim = pieces[(size_t)relay_piece.at(relay_key(sd.unit, aim, sd.base.dir))].target_anchor;   // the relay after the rejected one
+                        } else if (relay_s0 > 0) {
+                            // a stop without an aim (the first stop of a side): find the lattice relay beyond the exit row and make
+                            // sure its whole chain is queued
+                            const int32_t exit_row = cp.stop_row + dr;
+                            aim = next_relay(u, sd.base, cp.ot + sd.base.dir * o.bj, cp.oq + sd.base.dir * o.bi, 0);
+                            // the relay's entry row must lie beyond the exit row
+                            while (aim >= 0 && (u.anchors[(size_t)aim].q - sd.base.q0) * sd.base.dir + (int32_t)relay_w <= exit_row + 64)
+                                aim = next_relay(u, sd.base, u.anchors[(size_t)aim].t, u.anchors[(size_t)aim].q, (int32_t)(relay_s / 4));
+                            if (aim >= 0) plant_chain(sd.unit, sd.base, aim);
                         }
-                        // try the hand-over the exit row was aimed at
-                        Piece &tpp = pieces[(size_t)tp];
-                        bool handed = false;
-                        if (tpp.target_run > 0) {
-                            const Run &nx = sd.runs[(size_t)tpp.target_run];
-                            const int np0 = nx.pieces.front();
-                            if (np0 >= (int)launched) break;                     // the relay has not run yet
-                            const int nslot = 2 * np0;
-                            const SnapHdr *N = snap_hdr(nslot);
-                            bool ok = N->valid && N->row + nx.dr == exit_row && outs[(size_t)np0].overflow == 0;
-                            if (ok) {
-                                const int32_t shift = nx.dc - rn_dc;                 // E column = N column + shift
-                                const long long c = ((long long)E->best + sd.c_off) - (long long)N->best;   // N score + c = head score
-                                ok = E->LY == N->LY + shift && E->RY == N->RY + shift;
-                                if (ok) {
-                                    const int32_t *EC = snap_C(eslot), *ED = EC + kSnapCols, *NC = snap_C(nslot), *ND = NC + kSnapCols;
-                                    const long long eoff = sd.c_off;
-                                    const long long thr = (long long)E->best + eoff - p.ydrop;     // in head scores
-                                    const int w = E->RY - E->LY;
-                                    for (int x = 0; x < w && ok; x++) {
-                                        const bool ea = EC[x] != kNeg, na_ = NC[x] != kNeg;
-                                        if (ea != na_ || (ea && (long long)EC[x] + eoff != (long long)NC[x] + c)) ok = false;
-                                        const long long ed = (long long)ED[x] + eoff, nd = (long long)ND[x] + c;
-                                        const bool el = ed - p.gap_extend >= thr, nl = nd - p.gap_extend >= thr;   // can this D still matter?
-                                        if (el != nl || (el && ed != nd)) ok = false;
-                                    }
-                                }
-                                if (ok) {
-                                    sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
-                                    sd.entry_cells = N->cells; sd.entry_rows = N->rows;
-                                    sd.c_off = c;
-                                    sd.cur_run = tpp.target_run;
-                                    for (int pc : sd.runs[(size_t)sd.cur_run].pieces) sd.chain.push_back(pc);
-                                    handed = true;
-                                    n_verify_ok++;
-                                } else n_verify_bad++;
-                            } else n_verify_bad++;
-                        }
-                        if (handed) continue;
-                        // continue this run from its exit snapshot, aimed at the next relay further down
-                        int next_t = -1;
-                        for (size_t r = (size_t)std::max(tpp.target_run, sd.cur_run) + 1; r < sd.runs.size(); r++)
-                            if (sd.runs[r].dr + (int32_t)relay_w > exit_row + 64) { next_t = (int)r; break; }
-                        const int32_t stop = next_t > 0 ? sd.runs[(size_t)next_t].dr + (int32_t)relay_w - rn_dr : 0;
-                        const int id = add_piece(si, sd.cur_run, sd.base, E->row, E->row, stop, 0, eslot, next_t);
-                        sd.chain.push_back(id);
+                        // continue this run from its exit snapshot, aimed at the next relay whose entry row is still ahead
+                        const int32_t exit_local = cp.stop_row;
+                        while (aim >= 0 && (u.anchors[(size_t)aim].q - cp.oq) * sd.base.dir + (int32_t)relay_w <= exit_local + 64)
+                            aim = pieces[(size_t)relay_piece.at(relay_key(sd.unit, aim, sd.base.dir))].target_anchor;
+                        const int32_t stop = aim >= 0 ? (u.anchors[(size_t)aim].q - cp.oq) * sd.base.dir + (int32_t)relay_w : 0;
+                        const int id = add_piece(sd.unit, sd.base, cp.ot, cp.oq, exit_local, exit_local, stop, 0, tp, aim);
+                        sd.cur.push_back(id); sd.chain.push_back(id);
                         break;
                     }
                 }
@@ -856,13 +846,14 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 for (size_t w0 = 0; w0 < wide.size() && !arena_full; w0 += 32) {
                     const size_t w1 = std::min(wide.size(), w0 + 32);
                     const size_t first = pieces.size();
+                    std::vector<int> owner;
                     for (size_t k = w0; k < w1; k++) {
                         SideRun &sd = sides[(size_t)wide[k]];
-                        sd.runs.assign(1, Run{0, 0, {}});
-                        sd.chain.clear(); sd.cur_run = 0; sd.c_off = 0; sd.acc_cells = sd.acc_rows = sd.entry_cells = sd.entry_rows = 0; sd.gbest = -1;
-                        DpProb b = sd.base; b.snap_idx = -1;
-                        const int id = add_piece(wide[k], 0, b, 0, -1, 0, 0, -1, -1);
-                        sd.chain.push_back(id);
+                        sd.chain.clear(); sd.cur.clear(); sd.c_off = 0; sd.acc_cells = sd.acc_rows = sd.entry_cells = sd.entry_rows = 0; sd.gbest = -1;
+                        const int id = add_piece(sd.unit, sd.base, sd.base.t0, sd.base.q0, 0, -1, 0, 0, -1, -1);
+                        probs[(size_t)id].snap_idx = -1;
+                        sd.chain.push_back(id); sd.cur.push_back(id);
+                        owner.push_back(wide[k]);
                     }
                     const size_t n_new = pieces.size() - first;
                     g.probs.ensure_keep(pieces.size()); g.outs.ensure_keep(pieces.size()); g.rowdir.ensure_keep((size_t)dir_entries + 1);
@@ -875,7 +866,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         const DpOut &o = outs[x];
                         if (o.overflow == 1) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
                         if (o.overflow == 3) { arena_full = true; continue; }
-                        SideRun &sd = sides[(size_t)pieces[x].side];
+                        SideRun &sd = sides[(size_t)owner[x - first]];
                         sd.gbest = o.best; sd.gbi = o.bi; sd.gbj = o.bj; sd.best_piece = (int)x;
                         sd.acc_cells = o.cells; sd.acc_rows = o.rows; sd.done = true;
                         st.dp_sides_run++; st.dp_cells_run += o.cells; st.dp_rows_run += o.rows;
@@ -926,14 +917,14 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         memset(&tp, 0, sizeof tp);
                         tp.row_off = probs[(size_t)pc].row_off; tp.row_lo = pp.row_lo; tp.min_row = pp.min_row;
                         if (x > 0) {
-                            const Run &r0 = sd.runs[(size_t)pp.run], &r1 = sd.runs[(size_t)pieces[(size_t)sd.chain[x - 1]].run];
-                            tp.dr = r0.dr - r1.dr; tp.dc = r0.dc - r1.dc;
+                            const Piece &pv = pieces[(size_t)sd.chain[x - 1]];
+                            tp.dr = (pp.oq - pv.oq) * pp.dir; tp.dc = (pp.ot - pv.ot) * pp.dir;
                         }
                         tbp.push_back(tp);
                     }
                     ts.n_pieces = (int32_t)tbp.size() - ts.first_piece;
-                    const Run &rb = sd.runs[(size_t)pieces[(size_t)sd.best_piece].run];
-                    ts.bi = sd.gbi - rb.dr; ts.bj = sd.gbj - rb.dc;
+                    const Piece &pb = pieces[(size_t)sd.best_piece];
+                    ts.bi = sd.gbi - (pb.oq - sd.base.q0) * pb.dir; ts.bj = sd.gbj - (pb.ot - sd.base.t0) * pb.dir;
                     ts.ops_off = ooff;
                     ooff += (uint64_t)sd.gbi + (uint64_t)sd.gbj + 2;      // worst case: every column its own run
                     tbs.push_back(ts);
@@ -1000,9 +991,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 if (tt != c.t_hi || qq != c.q_hi) {
                     if (!bad++ && debug) {
                         const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
-                        fprintf(stderr, "[miblast] span error: anchor %zu box t %d..%d q %d..%d reached t %lld q %lld; R: best %d at (%d,%d) chain %zu runs %zu best_piece run %d, nR %zu; L: best %d at (%d,%d) chain %zu runs %zu best_piece run %d, nL %zu\n",
-                                k, c.t_lo, c.t_hi, c.q_lo, c.q_hi, (long long)tt, (long long)qq, R.gbest, R.gbi, R.gbj, R.chain.size(), R.runs.size(),
-                                pieces[(size_t)R.best_piece].run, nR, L.gbest, L.gbi, L.gbj, L.chain.size(), L.runs.size(), pieces[(size_t)L.best_piece].run, nL);
+                        fprintf(stderr, "[miblast] span error: anchor %zu box t %d..%d q %d..%d reached t %lld q %lld; R: best %d at (%d,%d) chain %zu, nR %zu; L: best %d at (%d,%d) chain %zu, nL %zu\n",
+                                k, c.t_lo, c.t_hi, c.q_lo, c.q_hi, (long long)tt, (long long)qq, R.gbest, R.gbi, R.gbj, R.chain.size(), nR, L.gbest, L.gbi, L.gbj, L.chain.size(), nL);
                     }
                 }
             };
