@@ -516,8 +516,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     // relay hand-over (see the DP section below): first stop, relay spacing, warm-up rows, diagonal tolerance, relays per side
-    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 4096), relay_s = std::max(256l, env_long("MIBLAST_RELAY_S", 4096));
-    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 1024)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
+    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 1024), relay_s = std::max(256l, env_long("MIBLAST_RELAY_S", 2048));
+    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 512)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
     const long relay_max = env_long("MIBLAST_RELAY_MAX", 256);
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
     Workspace &g = *ctx.ws;
