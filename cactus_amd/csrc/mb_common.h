@@ -60,25 +60,33 @@ struct DpOut {
     int64_t clocks;                           // shader clocks spent in the row sweep (diagnostics)
     int32_t overflow;                         // 1: row wider than the LDS ring (rerun with HBM rows); 3: trace arena exhausted
     int32_t n_ops;                            // traceback: number of ops written
-    int32_t stopped, pad;                     // 1: stopped at stop_row with live cells (exit snapshot written)
+    int32_t stopped, exit_j;                  // 1: stopped at stop_row with live cells (exit snapshot written); best column of that row
     long long prof[6];                        // MIBLAST_DP_PROFILE: shader clocks per phase of the row loop
 };
 
-// traceback input: a side's trace is spread over the pieces of its validated chain, listed from the piece that holds
-// the best cell back to the head.  Rows <= min_row of a piece belong to the next piece of the list; (dr, dc) convert a
-// cell of this piece into the next piece's local coordinates.
-struct TbPiece {
+// ---- traceback --------------------------------------------------------------------------
+// A side's path runs through the pieces of its validated chain.  Every piece is walked by its own wave at the same
+// time (k_trace_walk): the piece that holds the best cell from that cell, every other piece from a GUESS, the best
+// cell of its last row.  Paths that differ in their start merge after a few rows, so k_trace_join only walks from the
+// true entry cell of a piece until it meets the guessed walk (same row, column and state = same remainder), then
+// splices that walk's remaining runs.  The result is the run list of the sequential walk.
+struct TbWalk {
     uint64_t row_off;                         // first row-chunk directory entry of the piece
     int32_t row_lo;                           // record 0 <-> row row_lo
-    int32_t min_row;
-    int32_t dr, dc;
+    int32_t floor;                            // rows <= floor belong to the next walker of the side (-1: this is the head)
+    int32_t si, sj;                           // start cell in the piece's coordinates (state: aligned pair)
+    int32_t dr, dc;                           // a cell of this piece + (dr, dc) = the same cell in the next walker's coordinates
+    uint64_t ops_off;                         // run buffer of the walk
+    uint64_t rec_off;                         // one record (3 x u32: column, runs written, pending length << 2 | state) per entered row
+    int32_t n_runs, ei, ej, estate;           // out: runs written; cell and state on reaching the floor
     int32_t pad[2];
 };
+struct TbSeg { uint64_t src; int32_t n_runs, first_sub; };       // n_runs runs from ops[src], the first one shortened by first_sub
 struct TbSide {
-    int32_t first_piece, n_pieces;
-    int32_t bi, bj;                           // best cell in the first piece's local coordinates
-    uint64_t ops_off;
-    int32_t n_ops, pad;
+    int32_t first_walk, n_walks;              // walkers from the best cell's piece back to the head
+    uint64_t jops_off;                        // run buffer of the join walk
+    uint64_t seg_off;                         // segment list of the side (<= 2 * n_walks + 1 entries)
+    int32_t n_segs, pad;
 };
 
 // relay hand-over check (k_verify): exit snapshot `eslot` of the upstream piece against entry snapshot `nslot` of the relay
@@ -142,11 +150,12 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
                   int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s);
-void launch_traceback(TbSide *sides, const TbPiece *pieces, int n, const uint8_t *arena,
-                      unsigned long long arena_bytes, const unsigned long long *rowdir, uint32_t *ops, hipStream_t s);
+void launch_trace_walk(TbWalk *walks, int n, const uint8_t *arena, unsigned long long arena_bytes,
+                       const unsigned long long *rowdir, uint32_t *ops, uint32_t *recs, hipStream_t s);
+void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, const uint8_t *arena, unsigned long long arena_bytes,
+                       const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, hipStream_t s);
+void launch_pack_segs(const TbSeg *segs, const unsigned long long *dst, int n, const uint32_t *ops, uint32_t *packed, hipStream_t s);
 void launch_verify(const VerifyJob *jobs, VerifyOut *res, int n, const uint8_t *snaps, int Y, int E, hipStream_t s);
-void launch_pack_ops(const TbSide *sides, int n, const unsigned long long *coff, const uint32_t *ops,
-                     uint32_t *packed, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int end_bit,
                hipStream_t s);

@@ -586,6 +586,7 @@ struct YdShared {                            // LDS of one DP problem (LDS-ring 
     int4 xb[kYdWaves];                       // per-wave {first break, first alive, last alive, best candidate} (pass-relative columns)
     int iv_last, cp_last;                    // last column of a pass, for the next pass of a wide row
     unsigned long long blk, chunk; int fail; // arena allocations made by thread 0
+    unsigned long long smax;                 // best cell of the exit row (score, column) packed for atomicMax
 };
 
 // One workgroup (4 waves) per problem; a row is evaluated 256 columns per pass, wave w taking columns
@@ -677,7 +678,7 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
     const int tidE = tid * E;
     __syncthreads();
     int i = row_lo + 1;
-    int stopped = 0;
+    int stopped = 0, exit_j = 0;
     for (; i <= nb && !overflow; i++) {
         if (PROF) pt = clock64();
         const int rho = i - row_lo;
@@ -805,7 +806,18 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
             // state after row i (the ring writes of the row are visible: they precede the row's last barrier)
             uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : 0)) * kSnapBytes;
             int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
-            for (int j = LY + tid; j < RY; j += kYdThreads) { const int2 cd = CD[j & mask]; sC[j - LY] = cd.x; sD[j - LY] = cd.y; }
+            if (tid == 0) sh->smax = 0;
+            __syncthreads();
+            unsigned long long mine = 0;
+            for (int j = LY + tid; j < RY; j += kYdThreads) {
+                const int2 cd = CD[j & mask]; sC[j - LY] = cd.x; sD[j - LY] = cd.y;
+                // (score biased to unsigned) << 32 | (inverted column): the maximum is the best score, leftmost on ties
+                const unsigned long long key = ((unsigned long long)(unsigned)(cd.x + (1 << 30)) << 32) | (unsigned)(0x7fffffff - j);
+                mine = key > mine ? key : mine;
+            }
+            atomicMax(&sh->smax, mine);
+            __syncthreads();
+            exit_j = 0x7fffffff - (int)(unsigned)(sh->smax & 0xffffffffull);
             if (tid == 0) {
                 SnapHdr *h = (SnapHdr *)sp;
                 h->LY = LY; h->RY = RY; h->best = best; h->bi = bi; h->bj = bj; h->row = i; h->rows = rows; h->cells = cells;
@@ -817,7 +829,7 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const u
     if (!overflow) flush_rows(i - 1 - row_lo);
     if (tid == 0) {
         out->best = best; out->bi = bi; out->bj = bj; out->rows = rows;
-        out->cells = cells; out->clocks = clock64() - clk0; out->overflow = overflow; out->n_ops = 0; out->stopped = stopped;
+        out->cells = cells; out->clocks = clock64() - clk0; out->overflow = overflow; out->n_ops = 0; out->stopped = stopped; out->exit_j = exit_j;
         if (PROF) for (int k = 0; k < 6; k++) out->prof[k] = pf[k];
     }
 }
@@ -859,34 +871,33 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// traceback: one wave per DP side.  Memory latency is taken off the chain by fetching, for 64 rows at a time,
-// each row's (offset, LY) record and the 8 trace bytes around the column a gap-free path would visit (lane l
-// <-> row i-l, columns j-l-3 .. j-l+4).  Inside a block, whole runs of diagonal steps are recognised with one
-// ballot (all lanes test "src == diag" at the current drift); only gap cells are stepped one at a time.
-// Output: run-length ops (len << 2 | op) in walk-back order; op 0 aligned pair, 2 query-only, 3 target-only.
-__global__ __launch_bounds__(64) void k_traceback(TbSide *__restrict__ sides, const TbPiece *__restrict__ pieces, int n,
-                                                  const uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
-                                                  const unsigned long long *__restrict__ rowdir, uint32_t *__restrict__ ops) {
-    const int slot = blockIdx.x;
-    if (slot >= n) return;
-    const TbSide sd = sides[slot];
-    const int lane = threadIdx.x & 63;
-    int pc = uni(sd.first_piece), left = uni(sd.n_pieces);
-    TbPiece P = pieces[pc];
-    int i = uni(sd.bi), j = uni(sd.bj), state = 0;
-    uint32_t *o = ops + sd.ops_off;
-    int n_runs = 0, cur_op = -1, cur_len = 0;
-    auto emit = [&](int op, int len) {
+// traceback.  walk_piece moves one wave from a cell of a piece down to the piece's floor.  Memory latency is taken
+// off the chain by fetching, for 64 rows at a time, each row's (offset, first column) record and the 8 trace bytes
+// around the column a gap-free path would visit (lane l <-> row i-l, columns j-l-3 .. j-l+4).  Inside a block, whole
+// runs of diagonal steps are recognised with one ballot (all lanes test "src == diag" at the current drift); only gap
+// cells are stepped one at a time.  Output: run-length ops (len << 2 | op) in walk-back order; op 0 aligned pair,
+// 2 query-only, 3 target-only.
+//   MODE 0 (k_trace_walk): every entered row gets a record (column, runs written so far, pending run length, state);
+//   MODE 1 (k_trace_join): every entered row is compared with the record another walk left there; on equality the
+//          walk stops (`joined`): from an identical (row, column, state) both walks are identical.
+struct RunOut {
+    uint32_t *o; int n_runs, cur_op, cur_len;
+    __device__ __forceinline__ void emit(int op, int len, int lane) {
         if (op == cur_op) cur_len += len;
         else {
             if (cur_len > 0 && lane == 0) o[n_runs] = ((uint32_t)cur_len << 2) | (uint32_t)cur_op;
             n_runs += cur_len > 0 ? 1 : 0;
             cur_op = op; cur_len = len;
         }
-    };
-    // rows at or below `floor` belong to the previous piece of the chain (the head's floor is -1: it owns row 0)
-    int floor = left > 1 ? uni(P.min_row) : -1;
-    // row records of the NEXT block are requested while the current block is walked (they do not depend on the walk)
+    }
+};
+
+template <int MODE>
+__device__ __forceinline__ bool walk_piece(const TbWalk &P, int &i, int &j, int &state, RunOut &ro, uint32_t *__restrict__ rec,
+                                           const uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
+                                           const unsigned long long *__restrict__ rowdir) {
+    const int lane = threadIdx.x & 63;
+    const int floor = uni(P.floor), si = uni(P.si);
     auto load_ri = [&](int r) -> RowInfo {
         RowInfo ri; ri.off = 0; ri.ly = 0; ri.pad = 0;
         if (r > floor) {
@@ -895,19 +906,16 @@ __global__ __launch_bounds__(64) void k_traceback(TbSide *__restrict__ sides, co
         }
         return ri;
     };
+    auto rec_at = [&](int r) -> uint32_t * { return rec + 3ull * (unsigned)(si - r); };
+    // the start cell is an entered row too
+    if (MODE == 0) { if (lane == 0) { uint32_t *q = rec_at(i); q[0] = (uint32_t)j; q[1] = 0; q[2] = (uint32_t)state; } }
+    else {
+        const uint32_t *q = rec_at(i);
+        if (i <= si && i > floor && q[0] == (uint32_t)j && (q[2] & 3u) == (uint32_t)state) return true;
+    }
     int pre_i0 = i;
     RowInfo ri_pre = load_ri(i - lane);
-    while (true) {
-        if (left > 1 && i <= floor) {                               // hand over to the piece that owns the rows below
-            i += P.dr; j += P.dc;
-            pc++; left--;
-            P = pieces[pc];
-            floor = left > 1 ? uni(P.min_row) : -1;
-            pre_i0 = i;
-            ri_pre = load_ri(i - lane);
-            continue;
-        }
-        if (!(i > 0 || j > 0)) break;
+    while ((i > 0 || j > 0) && i > floor) {
         // fetch block: rows i .. i-63
         i = uni(i); j = uni(j);
         const int i0 = i, j0 = j;
@@ -916,6 +924,7 @@ __global__ __launch_bounds__(64) void k_traceback(TbSide *__restrict__ sides, co
         pre_i0 = i0 - 64;
         ri_pre = load_ri(pre_i0 - lane);
         unsigned long long win = 0;
+        uint32_t rj = 0xFFFFFFFFu, rs = 0;                    // MODE 1: the other walk's record of this lane's row
         if (r > floor) {
             const int wly = (int)ri.ly;
             const int wc0 = j0 - lane - 3;                     // column of byte 0 of the window
@@ -929,6 +938,7 @@ __global__ __launch_bounds__(64) void k_traceback(TbSide *__restrict__ sides, co
                 if (c >= wly && ri.off + (unsigned long long)(c - wly) < arena_bytes) b = rowp[c - wly];
                 win |= (unsigned long long)b << (8 * k);
             }
+            if (MODE == 1 && r <= si) { const uint32_t *q = rec_at(r); rj = q[0]; rs = q[2] & 3u; }
         } else win = ~0ull;
         int l = 0;
         while ((i > 0 || j > 0) && l < 64 && i > floor) {
@@ -939,8 +949,29 @@ __global__ __launch_bounds__(64) void k_traceback(TbSide *__restrict__ sides, co
                 // how many consecutive rows, starting at lane l, continue diagonally at this drift?
                 const unsigned tbl = (unsigned)(win >> (8 * k)) & 0xFFu;
                 const unsigned long long stop = __ballot(lane >= l && (tbl & 3u) != 0u);
-                const int run = stop ? (int)__ffsll((long long)stop) - 1 - l : 64 - l;
-                if (run > 0) { emit(0, run); i -= run; j -= run; l += run; continue; }
+                int run = stop ? (int)__ffsll((long long)stop) - 1 - l : 64 - l;
+                if (run > 0) {
+                    // rows i-1 .. i-run are entered at columns j-1 .. j-run (lane l+x holds row i-x while l+x < 64)
+                    const int x = lane - l;
+                    const bool entered = x >= 1 && x <= run && (i - x) > floor;
+                    if (MODE == 1) {
+                        const unsigned long long hit = __ballot(entered && rj == (uint32_t)(j - x) && rs == 0u);
+                        if (hit) { const int xs = (int)__ffsll((long long)hit) - 1 - l; ro.emit(0, xs, lane); i -= xs; j -= xs; return true; }
+                        // row i-run may be held by no lane (l + run == 64): it is checked as the start of the next block
+                    } else if (entered) {
+                        const int base = ro.cur_op == 0 ? ro.cur_len : 0;
+                        const int nr = ro.n_runs + ((ro.cur_op != 0 && ro.cur_len > 0) ? 1 : 0);
+                        uint32_t *q = rec_at(i - x);
+                        q[0] = (uint32_t)(j - x); q[1] = (uint32_t)nr; q[2] = ((uint32_t)(base + x) << 2);
+                    }
+                    ro.emit(0, run, lane); i -= run; j -= run; l += run;
+                    if (l == 64 && i > floor) {
+                        // the row just entered starts the next block: handle its record here
+                        if (MODE == 0) { if (lane == 0) { uint32_t *q = rec_at(i); q[0] = (uint32_t)j; q[1] = (uint32_t)ro.n_runs; q[2] = ((uint32_t)ro.cur_len << 2); } }
+                        else if (i <= si) { const uint32_t *q = rec_at(i); if (q[0] == (uint32_t)j && (q[2] & 3u) == 0u) return true; }
+                    }
+                    continue;
+                }
                 const unsigned src = (unsigned)__builtin_amdgcn_readlane((int)tbl, l) & 3u;
                 if (src == 1u) state = 1;
                 else if (src == 2u) state = 2;
@@ -949,19 +980,86 @@ __global__ __launch_bounds__(64) void k_traceback(TbSide *__restrict__ sides, co
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)win, l);
                 const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(win >> 32), l);
                 const unsigned tb = ((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4)))) & 0xFFu;
-                if (state == 1) { emit(2, 1); if (!(tb & 4u)) state = 0; i--; l++; }
-                else { emit(3, 1); if (!(tb & 8u)) state = 0; j--; }
+                if (state == 1) {
+                    ro.emit(2, 1, lane); if (!(tb & 4u)) state = 0; i--; l++;
+                    if (i > floor) {                           // entered row i at column j in `state`
+                        if (MODE == 0) {
+                            if (lane == 0) { uint32_t *q = rec_at(i); q[0] = (uint32_t)j; q[1] = (uint32_t)ro.n_runs; q[2] = ((uint32_t)ro.cur_len << 2) | (uint32_t)state; }
+                        } else if (i <= si) {
+                            const uint32_t *q = rec_at(i);
+                            if (q[0] == (uint32_t)j && (q[2] & 3u) == (uint32_t)state) return true;
+                        }
+                    }
+                }
+                else { ro.emit(3, 1, lane); if (!(tb & 8u)) state = 0; j--; }
             }
         }
     }
-    emit(-2, 0);                                                // flush the last run
-    if (lane == 0) sides[slot].n_ops = n_runs;
+    return false;
 }
 
-void launch_traceback(TbSide *sides, const TbPiece *pieces, int n, const uint8_t *arena,
-                      unsigned long long arena_bytes, const unsigned long long *rowdir, uint32_t *ops, hipStream_t s) {
+__global__ __launch_bounds__(64) void k_trace_walk(TbWalk *__restrict__ walks, int n, const uint8_t *__restrict__ arena,
+                                                   const unsigned long long arena_bytes, const unsigned long long *__restrict__ rowdir,
+                                                   uint32_t *__restrict__ ops, uint32_t *__restrict__ recs) {
+    const int slot = blockIdx.x;
+    if (slot >= n) return;
+    const TbWalk P = walks[slot];
+    const int lane = threadIdx.x & 63;
+    int i = uni(P.si), j = uni(P.sj), state = 0;
+    RunOut ro{ops + P.ops_off, 0, -1, 0};
+    walk_piece<0>(P, i, j, state, ro, recs + P.rec_off, arena, arena_bytes, rowdir);
+    // the pending run stays open in the records (a splice shortens it); it is closed here
+    ro.emit(-2, 0, lane);
+    if (lane == 0) { walks[slot].n_runs = ro.n_runs; walks[slot].ei = i; walks[slot].ej = j; walks[slot].estate = state; }
+}
+
+// one wave per side: stitches the walks of the side's pieces (see TbWalk)
+__global__ __launch_bounds__(64) void k_trace_join(TbSide *__restrict__ sides, int n, const TbWalk *__restrict__ walks,
+                                                   TbSeg *__restrict__ segs, const uint8_t *__restrict__ arena,
+                                                   const unsigned long long arena_bytes, const unsigned long long *__restrict__ rowdir,
+                                                   uint32_t *__restrict__ ops, const uint32_t *__restrict__ recs) {
+    const int slot = blockIdx.x;
+    if (slot >= n) return;
+    const TbSide sd = sides[slot];
+    const int lane = threadIdx.x & 63;
+    TbSeg *sg = segs + sd.seg_off;
+    int n_segs = 0;
+    auto push_seg = [&](unsigned long long src, int n_runs, int first_sub) {
+        if (n_runs <= 0) return;
+        if (lane == 0) { TbSeg t; t.src = src; t.n_runs = n_runs; t.first_sub = first_sub; sg[n_segs] = t; }
+        n_segs++;
+    };
+    const TbWalk W0 = walks[sd.first_walk];
+    push_seg(W0.ops_off, W0.n_runs, 0);
+    int i = uni(W0.ei + W0.dr), j = uni(W0.ej + W0.dc), state = uni(W0.estate);
+    unsigned long long jp = sd.jops_off;                          // next free slot of the join walk's own runs
+    for (int k = 1; k < sd.n_walks; k++) {
+        const TbWalk W = walks[sd.first_walk + k];
+        RunOut ro{ops + jp, 0, -1, 0};
+        const bool joined = walk_piece<1>(W, i, j, state, ro, const_cast<uint32_t *>(recs) + W.rec_off, arena, arena_bytes, rowdir);
+        ro.emit(-2, 0, lane);
+        push_seg(jp, ro.n_runs, 0);
+        jp += (unsigned)ro.n_runs;
+        if (joined) {
+            const uint32_t *q = recs + W.rec_off + 3ull * (unsigned)(W.si - i);
+            const int nr = (int)q[1], sub = (int)(q[2] >> 2);
+            push_seg(W.ops_off + (unsigned)nr, W.n_runs - nr, sub);
+            i = W.ei; j = W.ej; state = W.estate;
+        }
+        i = uni(i + W.dr); j = uni(j + W.dc); state = uni(state);
+    }
+    if (lane == 0) sides[slot].n_segs = n_segs;
+}
+
+void launch_trace_walk(TbWalk *walks, int n, const uint8_t *arena, unsigned long long arena_bytes,
+                       const unsigned long long *rowdir, uint32_t *ops, uint32_t *recs, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, s, sides, pieces, n, arena, arena_bytes, rowdir, ops);
+    hipLaunchKernelGGL(k_trace_walk, dim3((unsigned)n), dim3(64), 0, s, walks, n, arena, arena_bytes, rowdir, ops, recs);
+}
+void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, const uint8_t *arena, unsigned long long arena_bytes,
+                       const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_trace_join, dim3((unsigned)n), dim3(64), 0, s, sides, n, walks, segs, arena, arena_bytes, rowdir, ops, recs);
 }
 
 // relay hand-over check: the upstream piece's state after its exit row against the relay's state after the same row.
@@ -1005,21 +1103,24 @@ void launch_verify(const VerifyJob *jobs, VerifyOut *res, int n, const uint8_t *
     hipLaunchKernelGGL(k_verify, dim3((unsigned)n), dim3(256), 0, s, jobs, res, n, snaps, Y, E);
 }
 
-// pack the run lists of all sides back to back (each side was given worst-case room, most of it unused)
-__global__ __launch_bounds__(256) void k_pack_ops(const TbSide *__restrict__ sides, int n,
-                                                  const unsigned long long *__restrict__ coff,
-                                                  const uint32_t *__restrict__ ops, uint32_t *__restrict__ packed) {
+// the segments of all sides back to back in walk order (each walk was given worst-case room, most of it unused)
+__global__ __launch_bounds__(256) void k_pack_segs(const TbSeg *__restrict__ segs, const unsigned long long *__restrict__ dst, int n,
+                                                   const uint32_t *__restrict__ ops, uint32_t *__restrict__ packed) {
     const int slot = blockIdx.x;
     if (slot >= n) return;
-    const uint32_t *src = ops + sides[slot].ops_off;
-    const unsigned long long c0 = coff[slot], cn = coff[slot + 1] - c0;
-    for (unsigned long long x = threadIdx.x; x < cn; x += blockDim.x) packed[c0 + x] = src[x];
+    const TbSeg sg = segs[slot];
+    const uint32_t *src = ops + sg.src;
+    const unsigned long long d0 = dst[slot];
+    for (int x = threadIdx.x; x < sg.n_runs; x += blockDim.x) {
+        uint32_t v = src[x];
+        if (x == 0) v -= (uint32_t)sg.first_sub << 2;             // spliced in the middle of a run
+        packed[d0 + (unsigned)x] = v;
+    }
 }
 
-void launch_pack_ops(const TbSide *sides, int n, const unsigned long long *coff, const uint32_t *ops,
-                     uint32_t *packed, hipStream_t s) {
+void launch_pack_segs(const TbSeg *segs, const unsigned long long *dst, int n, const uint32_t *ops, uint32_t *packed, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_pack_ops, dim3((unsigned)n), dim3(256), 0, s, sides, n, coff, ops, packed);
+    hipLaunchKernelGGL(k_pack_segs, dim3((unsigned)n), dim3(256), 0, s, segs, dst, n, ops, packed);
 }
 
 }  // namespace mb

@@ -204,7 +204,9 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<unsigned long long> coff;
     PinBuf<uint32_t> hops;
     DevBuf<TbSide> tb_sides;
-    DevBuf<TbPiece> tb_pieces;
+    DevBuf<TbWalk> tb_walks;
+    DevBuf<TbSeg> tb_segs;
+    DevBuf<uint32_t> recs;
     DevBuf<uint8_t> snaps;
     DevBuf<VerifyJob> vjobs;
     DevBuf<VerifyOut> vres;
@@ -888,8 +890,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // ---- traceback of every anchor reaching --gappedthresh ------------------------------------------
         std::vector<size_t> acc;                        // indices into pend
         std::vector<TbSide> tbs;
-        std::vector<TbPiece> tbp;
-        uint64_t ooff = 0;
+        std::vector<TbWalk> tbw;
+        uint64_t ooff = 0, roff = 0, soff = 0;          // run slots, row records (3 x u32 each), segments
         for (size_t k = 0; k < pend.size(); k++) {
             Unit &u = units[pend[k].unit];
             Cached c;
@@ -906,52 +908,73 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     const SideRun &sd = sides[2 * k + (size_t)side];
                     TbSide ts;
                     memset(&ts, 0, sizeof ts);
-                    ts.first_piece = (int32_t)tbp.size();
-                    // the chain from the piece that holds the best cell back to the head
+                    ts.first_walk = (int32_t)tbw.size();
+                    // one walker per piece of the chain, from the piece that holds the best cell back to the head
                     size_t at = 0;
                     while (at < sd.chain.size() && sd.chain[at] != sd.best_piece) at++;
+                    uint64_t side_slots = 0;
                     for (size_t x = at + 1; x-- > 0;) {
                         const int pc = sd.chain[x];
                         const Piece &pp = pieces[(size_t)pc];
-                        TbPiece tp;
-                        memset(&tp, 0, sizeof tp);
-                        tp.row_off = probs[(size_t)pc].row_off; tp.row_lo = pp.row_lo; tp.min_row = pp.min_row;
+                        TbWalk w;
+                        memset(&w, 0, sizeof w);
+                        w.row_off = probs[(size_t)pc].row_off; w.row_lo = pp.row_lo; w.floor = x > 0 ? pp.min_row : -1;
+                        if (x == at) { w.si = sd.gbi - (pp.oq - sd.base.q0) * pp.dir; w.sj = sd.gbj - (pp.ot - sd.base.t0) * pp.dir; }
+                        else { w.si = pp.stop_row; w.sj = outs[(size_t)pc].exit_j; }      // guess: the best cell of the piece's last row
                         if (x > 0) {
                             const Piece &pv = pieces[(size_t)sd.chain[x - 1]];
-                            tp.dr = (pp.oq - pv.oq) * pp.dir; tp.dc = (pp.ot - pv.ot) * pp.dir;
+                            w.dr = (pp.oq - pv.oq) * pp.dir; w.dc = (pp.ot - pv.ot) * pp.dir;
                         }
-                        tbp.push_back(tp);
+                        const uint64_t rows = (uint64_t)(w.si - w.floor);
+                        const uint64_t slots = 2 * rows + 2 * (uint64_t)kLdsRowCap + 8;      // a run per step at worst
+                        w.ops_off = ooff; ooff += slots; side_slots += slots;
+                        w.rec_off = roff; roff += 3 * rows;
+                        tbw.push_back(w);
                     }
-                    ts.n_pieces = (int32_t)tbp.size() - ts.first_piece;
-                    const Piece &pb = pieces[(size_t)sd.best_piece];
-                    ts.bi = sd.gbi - (pb.oq - sd.base.q0) * pb.dir; ts.bj = sd.gbj - (pb.ot - sd.base.t0) * pb.dir;
-                    ts.ops_off = ooff;
-                    ooff += (uint64_t)sd.gbi + (uint64_t)sd.gbj + 2;      // worst case: every column its own run
+                    ts.n_walks = (int32_t)tbw.size() - ts.first_walk;
+                    ts.jops_off = ooff; ooff += side_slots;                  // the join walk can at worst repeat every walk
+                    ts.seg_off = soff; soff += 2 * (uint64_t)ts.n_walks + 1;
                     tbs.push_back(ts);
                 }
             }
             u.cache.emplace(pend[k].anchor, std::move(c));
         }
         const double t_tb0 = now_s();
+        std::vector<unsigned long long> coff;           // first packed run of every side (+ total)
         if (!acc.empty()) {
-            g.tb_sides.ensure(tbs.size()); g.tb_pieces.ensure(tbp.size()); g.ops.ensure((size_t)ooff + 64);
+            g.tb_sides.ensure(tbs.size()); g.tb_walks.ensure(tbw.size()); g.tb_segs.ensure((size_t)soff + 1);
+            g.ops.ensure((size_t)ooff + 64); g.recs.ensure((size_t)roff + 64);
             MB_HIP(hipMemcpyAsync(g.tb_sides.p, tbs.data(), tbs.size() * sizeof(TbSide), hipMemcpyHostToDevice, s));
-            MB_HIP(hipMemcpyAsync(g.tb_pieces.p, tbp.data(), tbp.size() * sizeof(TbPiece), hipMemcpyHostToDevice, s));
-            launch_traceback(g.tb_sides.p, g.tb_pieces.p, (int)tbs.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, s);
+            MB_HIP(hipMemcpyAsync(g.tb_walks.p, tbw.data(), tbw.size() * sizeof(TbWalk), hipMemcpyHostToDevice, s));
+            launch_trace_walk(g.tb_walks.p, (int)tbw.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, s);
+            launch_trace_join(g.tb_sides.p, (int)tbs.size(), g.tb_walks.p, g.tb_segs.p, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p,
+                              g.ops.p, g.recs.p, s);
+            std::vector<TbSeg> segs((size_t)soff + 1);
             MB_HIP(hipMemcpyAsync(tbs.data(), g.tb_sides.p, tbs.size() * sizeof(TbSide), hipMemcpyDeviceToHost, s));
+            MB_HIP(hipMemcpyAsync(segs.data(), g.tb_segs.p, (size_t)soff * sizeof(TbSeg), hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
-            // only the run slots each side actually used travel: packed on the device, then one copy into pinned memory
-            std::vector<unsigned long long> coff(tbs.size() + 1);
+            // only the run slots actually used travel: the segments are packed on the device in walk order, then one copy
+            std::vector<TbSeg> flat;
+            std::vector<unsigned long long> dst;
+            coff.assign(tbs.size() + 1, 0);
             unsigned long long ctot = 0;
-            for (size_t x = 0; x < tbs.size(); x++) { coff[x] = ctot; ctot += (unsigned long long)tbs[x].n_ops; }
+            for (size_t x = 0; x < tbs.size(); x++) {
+                coff[x] = ctot;
+                for (int q = 0; q < tbs[x].n_segs; q++) {
+                    const TbSeg &sg = segs[(size_t)tbs[x].seg_off + (size_t)q];
+                    flat.push_back(sg); dst.push_back(ctot); ctot += (unsigned long long)sg.n_runs;
+                }
+            }
             coff[tbs.size()] = ctot;
-            g.coff.ensure(coff.size()); g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
-            MB_HIP(hipMemcpyAsync(g.coff.p, coff.data(), coff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-            launch_pack_ops(g.tb_sides.p, (int)tbs.size(), g.coff.p, g.ops.p, g.ops_packed.p, s);
+            g.tb_segs.ensure(flat.size() + 1); g.coff.ensure(dst.size() + 1); g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
+            MB_HIP(hipMemcpyAsync(g.tb_segs.p, flat.data(), flat.size() * sizeof(TbSeg), hipMemcpyHostToDevice, s));
+            MB_HIP(hipMemcpyAsync(g.coff.p, dst.data(), dst.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+            launch_pack_segs(g.tb_segs.p, g.coff.p, (int)flat.size(), g.ops.p, g.ops_packed.p, s);
             if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
             const uint32_t *hops = g.hops.p;
             if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, tbs.size(), (unsigned long long)ooff);
+            if (debug) fprintf(stderr, "[miblast]   %zu walkers, %zu segments, %llu runs\n", tbw.size(), flat.size(), ctot);
             const double t_mg0 = now_s();
             // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
             // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
@@ -963,7 +986,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 const Unit &u = units[pend[k].unit];
                 Cached &c = *cptr[x];
                 const uint32_t *Rops = hops + coff[2 * x], *Lops = hops + coff[2 * x + 1];
-                const size_t nR = (size_t)tbs[2 * x].n_ops, nL = (size_t)tbs[2 * x + 1].n_ops;
+                const size_t nR = (size_t)(coff[2 * x + 1] - coff[2 * x]), nL = (size_t)(coff[2 * x + 2] - coff[2 * x + 1]);
                 const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
                 const uint8_t *qc = jobs[(size_t)u.pair]->qc_h[u.strand];
                 int64_t tt = c.t_lo, qq = c.q_lo;
@@ -976,6 +999,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 for (size_t run = 0; run < nL + nR; run++) {
                     const uint32_t e = run < nL ? Lops[run] : Rops[nR - 1 - (run - nL)];
                     const uint32_t o = e & 3u, len = e >> 2;
+                    if (len == 0) continue;                         // a splice that fell on a run boundary
                     if (o == 0) {
                         const int32_t d = (int32_t)(tt - qq);
                         dmin = std::min(dmin, d); dmax = std::max(dmax, d);
