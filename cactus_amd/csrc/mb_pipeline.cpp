@@ -518,9 +518,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     // relay hand-over (see the DP section below): first stop, relay spacing, warm-up rows, diagonal tolerance, relays per side
-    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 1024), relay_s = std::max(256l, env_long("MIBLAST_RELAY_S", 2048));
-    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 512)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
-    const long relay_max = env_long("MIBLAST_RELAY_MAX", 256);
+    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 512), relay_s = std::max(256l, env_long("MIBLAST_RELAY_S", 2048));
+    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 256)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
+    const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096);
+    const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
     Workspace &g = *ctx.ws;
     hipStream_t s = ctx.stream;
@@ -636,6 +637,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             int target_anchor;                  // anchor of the relay the stop row is aimed at (-1: none)
             int init_piece;                     // continuation: the piece whose exit snapshot it starts from
             int vjob;                           // index into vres of the hand-over check made after it ran (-1: none)
+            int cont;                           // the piece that continues this one after a rejected hand-over (-1: none)
         };
         struct SideRun {
             DpProb base;
@@ -673,14 +675,17 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 const long s_lo = std::max(bucket * relay_s, s_from), s_hi = (bucket + 1) * relay_s;
                 const long q_lo = dirn > 0 ? s_lo : -(s_hi - 1), q_hi = dirn > 0 ? s_hi : -s_lo + 1;      // [q_lo, q_hi)
                 auto it = std::lower_bound(u.by_q.begin(), u.by_q.end(), q_lo, [&](uint32_t x, long qq) { return (long)u.anchors[x].q < qq; });
-                long best = -1;
+                // anchors near the start of the bucket are preferred: evenly spaced relays = pieces of even length
+                long best = -1, best_near = -1;
                 for (; it != u.by_q.end() && (long)u.anchors[*it].q < q_hi; ++it) {
                     const Anchor &c = u.anchors[*it];
                     const int32_t dr = (c.q - b.q0) * dirn, dc = (c.t - b.t0) * dirn;
                     if (dr <= 0 || dc <= 0 || dc >= b.na - 64 || dr >= b.nb - (int32_t)relay_w - 64) continue;
                     if (std::labs((long)(c.t - c.q) - (long)(t - q)) > relay_tol) continue;
                     if (best < 0 || (long)*it < best) best = (long)*it;
+                    if ((long)dirn * c.q - bucket * relay_s < relay_s / 4 && (best_near < 0 || (long)*it < best_near)) best_near = (long)*it;
                 }
+                if (best_near >= 0) return (int)best_near;
                 if (best >= 0) return (int)best;
             }
             return -1;
@@ -703,7 +708,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 const int64_t last = stop_row > 0 ? stop_row : pr.nb;
                 dir_entries += (uint64_t)((last - row_lo) / 4096) + 2;
                 probs.push_back(pr);
-                pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target_anchor, init_piece, -1});
+                pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target_anchor, init_piece, -1, -1});
                 if (target_anchor >= 0) {
                     // checked right after the launch: this piece's exit state against the aimed relay's entry state
                     const Anchor &ta = units[(size_t)unit].anchors[(size_t)target_anchor];
@@ -780,14 +785,51 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     fprintf(stderr, "[miblast] round %d.%ld: %zu pieces, %zu checks, max rows %d (%lld shader clocks = %.0f per row), dp kernel total %.2f ms so far, shadow_q %ld\n",
                             round, n_subrounds, n_new, v_new, maxrows, clk, (double)clk / std::max(1, maxrows), st.t_dp_kernel_ms, shadow_q);
                 }
+                const size_t first_new = launched;
                 launched = pieces.size(); vlaunched = vjobs.size();
-                // ---- advance every side along its chain; new pieces (continuations, relays) are queued for the next launch
+                auto accepted = [&](int x) -> bool {
+                    const Piece &px = pieces[(size_t)x];
+                    if (px.vjob < 0 || !vres[(size_t)px.vjob].ok) return false;
+                    return !(relay_force_reject > 0 && x % relay_force_reject == 0);
+                };
+                // the continuation of a stopped piece whose hand-over was rejected (or that stopped without an aim): same
+                // origin, starts from the exit snapshot, aimed at the next relay whose entry row is still ahead
+                auto make_cont = [&](int x) -> int {
+                    if (pieces[(size_t)x].cont >= 0) return pieces[(size_t)x].cont;
+                    const Piece cp = pieces[(size_t)x];                          // (copies: the vectors grow below)
+                    const DpProb cb = probs[(size_t)x];
+                    const Unit &u = units[(size_t)cp.unit];
+                    int aim = cp.target_anchor;
+                    if (aim >= 0) aim = pieces[(size_t)relay_piece.at(relay_key(cp.unit, aim, cp.dir))].target_anchor;   // the relay after the rejected one
+                    else if (relay_s0 > 0) {
+                        // a stop without an aim (first stop of a side, end of a capped chain): the lattice relay beyond the best cell
+                        const DpOut &o = outs[(size_t)x];
+                        aim = next_relay(u, cb, cp.ot + cp.dir * o.bj, cp.oq + cp.dir * o.bi, 0);
+                        while (aim >= 0 && (u.anchors[(size_t)aim].q - cp.oq) * cp.dir + (int32_t)relay_w <= cp.stop_row + 64)
+                            aim = next_relay(u, cb, u.anchors[(size_t)aim].t, u.anchors[(size_t)aim].q, (int32_t)(relay_s / 4));
+                        if (aim >= 0) plant_chain(cp.unit, cb, aim);
+                    }
+                    while (aim >= 0 && (u.anchors[(size_t)aim].q - cp.oq) * cp.dir + (int32_t)relay_w <= cp.stop_row + 64)
+                        aim = pieces[(size_t)relay_piece.at(relay_key(cp.unit, aim, cp.dir))].target_anchor;
+                    const int32_t stop = aim >= 0 ? (u.anchors[(size_t)aim].q - cp.oq) * cp.dir + (int32_t)relay_w : 0;
+                    const int id = add_piece(cp.unit, cb, cp.ot, cp.oq, cp.stop_row, cp.stop_row, stop, 0, x, aim);
+                    pieces[(size_t)x].cont = id;
+                    return id;
+                };
+                // rejected hand-overs are continued at once, whether or not a side has reached them yet: a side then never
+                // waits more than one launch per rejection on its path
+                for (size_t x = first_new; x < launched; x++)
+                    if (outs[x].stopped && outs[x].overflow == 0 && pieces[x].target_anchor >= 0) {
+                        if (accepted((int)x)) n_verify_ok++;
+                        else { n_verify_bad++; make_cont((int)x); }
+                    }
+                // ---- advance every side along its chain
                 for (int si = 0; si < nsides; si++) {
                     SideRun &sd = sides[(size_t)si];
                     while (!sd.done && !sd.wide) {
                         const int tp = sd.cur.back();
                         if (tp >= (int)launched) break;                          // queued, not run yet
-                        const Piece cp = pieces[(size_t)tp];                     // (copy: `pieces` grows below)
+                        const Piece cp = pieces[(size_t)tp];
                         const int32_t dr = (cp.oq - sd.base.q0) * sd.base.dir, dc = (cp.ot - sd.base.t0) * sd.base.dir;
                         for (; sd.accounted < sd.cur.size(); sd.accounted++) {   // fold the run's finished pieces into the side's result
                             const int pc = sd.cur[sd.accounted];
@@ -804,40 +846,19 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                             sd.done = true;
                             break;
                         }
-                        const Unit &u = units[(size_t)sd.unit];
-                        int aim = cp.target_anchor;                              // the relay this piece stopped for
-                        if (aim >= 0) {
+                        if (cp.target_anchor >= 0 && accepted(tp)) {
+                            // the relay's rows are the rows of this DP from its entry row on
                             const VerifyOut &v = vres[(size_t)cp.vjob];
-                            if (v.ok) {
-                                const int np0 = relay_piece.at(relay_key(sd.unit, aim, sd.base.dir));
-                                sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
-                                sd.entry_cells = v.n_cells; sd.entry_rows = v.n_rows;
-                                sd.c_off += v.c;
-                                sd.cur.assign(1, np0); sd.accounted = 0;
-                                sd.chain.push_back(np0);
-                                n_verify_ok++;
-                                continue;
-                            }
-                            n_verify_bad++;
-                            aim = pieces[(size_t)relay_piece.at(relay_key(sd.unit, aim, sd.base.dir))].target_anchor;   // the relay after the rejected one
-                        } else if (relay_s0 > 0) {
-                            // a stop without an aim (the first stop of a side): find the lattice relay beyond the exit row and make
-                            // sure its whole chain is queued
-                            const int32_t exit_row = cp.stop_row + dr;
-                            aim = next_relay(u, sd.base, cp.ot + sd.base.dir * o.bj, cp.oq + sd.base.dir * o.bi, 0);
-                            // the relay's entry row must lie beyond the exit row
-                            while (aim >= 0 && (u.anchors[(size_t)aim].q - sd.base.q0) * sd.base.dir + (int32_t)relay_w <= exit_row + 64)
-                                aim = next_relay(u, sd.base, u.anchors[(size_t)aim].t, u.anchors[(size_t)aim].q, (int32_t)(relay_s / 4));
-                            if (aim >= 0) plant_chain(sd.unit, sd.base, aim);
+                            const int np0 = relay_piece.at(relay_key(cp.unit, cp.target_anchor, cp.dir));
+                            sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
+                            sd.entry_cells = v.n_cells; sd.entry_rows = v.n_rows;
+                            sd.c_off += v.c;
+                            sd.cur.assign(1, np0); sd.accounted = 0;
+                            sd.chain.push_back(np0);
+                            continue;
                         }
-                        // continue this run from its exit snapshot, aimed at the next relay whose entry row is still ahead
-                        const int32_t exit_local = cp.stop_row;
-                        while (aim >= 0 && (u.anchors[(size_t)aim].q - cp.oq) * sd.base.dir + (int32_t)relay_w <= exit_local + 64)
-                            aim = pieces[(size_t)relay_piece.at(relay_key(sd.unit, aim, sd.base.dir))].target_anchor;
-                        const int32_t stop = aim >= 0 ? (u.anchors[(size_t)aim].q - cp.oq) * sd.base.dir + (int32_t)relay_w : 0;
-                        const int id = add_piece(sd.unit, sd.base, cp.ot, cp.oq, exit_local, exit_local, stop, 0, tp, aim);
+                        const int id = make_cont(tp);
                         sd.cur.push_back(id); sd.chain.push_back(id);
-                        break;
                     }
                 }
             }
