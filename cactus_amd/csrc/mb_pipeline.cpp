@@ -905,6 +905,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             g.arena.release();                                  // free first: old + new need not coexist
             g.arena.alloc(bigger);
         }
+        st.relay_accepted += n_verify_ok; st.relay_rejected += n_verify_bad;
         if (debug) fprintf(stderr, "[miblast] round %d: %d sides in %zu pieces, %ld launches, hand-overs %ld accepted / %ld rejected\n",
                            round, nsides, pieces.size(), n_subrounds, n_verify_ok, n_verify_bad);
 
@@ -994,6 +995,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
             const uint32_t *hops = g.hops.p;
+            st.t_traceback_ms += (now_s() - t_tb0) * 1e3;
             if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, tbs.size(), (unsigned long long)ooff);
             if (debug) fprintf(stderr, "[miblast]   %zu walkers, %zu segments, %llu runs\n", tbw.size(), flat.size(), ctot);
             const double t_mg0 = now_s();
@@ -1043,6 +1045,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             };
             parallel_for(acc.size(), merge_one);
             if (bad) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
+            st.t_merge_ms += (now_s() - t_mg0) * 1e3;
             if (debug) fprintf(stderr, "[miblast]   host merge: %.2f ms\n", (now_s() - t_mg0) * 1e3);
         }
     }
@@ -1051,6 +1054,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         miblast_stats &d = j->res->stats;
         d.t_gapped = st.t_gapped; d.gapped_rounds = st.gapped_rounds; d.dp_sides_run = st.dp_sides_run; d.dp_cells_run = st.dp_cells_run;
         d.dp_rows_run = st.dp_rows_run; d.t_dp_kernel_ms = st.t_dp_kernel_ms; d.dp_kernel_launches = st.dp_kernel_launches;
+        d.relay_accepted = st.relay_accepted; d.relay_rejected = st.relay_rejected; d.t_traceback_ms = st.t_traceback_ms; d.t_merge_ms = st.t_merge_ms;
     }
     return MIBLAST_OK;
 

@@ -120,6 +120,8 @@ typedef struct miblast_stats {          /* counters defined by SURVEY.md section
     double  t_ungapped_kernel_ms; int64_t ungapped_kernel_launches;
     double  t_sort_ms, t_seedfill_ms;
     int64_t dp_rows_run;                    /* DP rows evaluated incl. speculative work                */
+    int64_t relay_accepted, relay_rejected; /* hand-overs between concurrently evaluated pieces of long DPs */
+    double  t_traceback_ms, t_merge_ms;     /* host wall time of the traceback (kernels + copies) and of the trace merge  */
 } miblast_stats;
 
 typedef struct miblast_result miblast_result;

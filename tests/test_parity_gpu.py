@@ -69,7 +69,46 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
             assert again.stats[k] == base.stats[k], (env, k)
 
 
-def test_full_size_properties_1mb(gpu_ctx):
+RELAY_CONFIGS = [
+    {"MIBLAST_RELAY_S0": "0"},                                                                  # relays off: one piece per side
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64"},
+    {"MIBLAST_RELAY_S0": "128", "MIBLAST_RELAY_S": "512", "MIBLAST_RELAY_W": "128", "MIBLAST_RELAY_MAX": "3"},      # capped chains are re-planted
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "2"},
+    {"MIBLAST_RELAY_S0": "32", "MIBLAST_RELAY_S": "300", "MIBLAST_RELAY_W": "70", "MIBLAST_RELAY_FORCE_REJECT": "3", "MIBLAST_RELAY_TOL": "40"},
+    {"MIBLAST_RELAY_S0": "512", "MIBLAST_RELAY_S": "2048", "MIBLAST_RELAY_W": "256", "MIBLAST_RELAY_FORCE_REJECT": "5"},
+]
+
+
+@pytest.mark.parametrize("env", RELAY_CONFIGS, ids=lambda e: ",".join(v for v in e.values()))
+def test_relay_handover_matches_oracle(gpu_ctx, olz, monkeypatch, env):
+    """Long one-sided DPs are cut into concurrently evaluated pieces (relays started at downstream anchors, accepted
+    only when the hand-over states match).  Wherever the pieces start, whether hand-overs are
+    accepted, rejected (forced here) or chains re-planted, every byte and counter must equal the sequential oracle."""
+    from cases import DEFAULT
+    from cactus_amd import gen
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for n, seed, sub, indel, args in ((60000, 33, 0.15, 0.01, DEFAULT), (90000, 77, 0.05, 0.02, ["--ydrop=4000", "--hspthresh=2200", "--gappedthresh=2400"]),
+                                      (30000, 5, 0.25, 0.03, DEFAULT)):
+        t, q = gen.make_pair(n, seed, sub_rate=sub, indel_rate=indel)
+        tf, qf = gen.fasta_bytes([("T|c0", t)]), gen.fasta_bytes([("Q|c0", q)])
+        pm = _params(args)
+        T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+        got = gpu_ctx.align(T, Q, pm)
+        want = olz.align(tf, qf, _oracle_params(olz, pm))
+        assert got.paf == want["paf"]
+        assert got.alns == want["alns"] and got.ops == want["ops"]
+        for k in COUNTERS:
+            assert got.stats[k] == want["counters"][k], k
+        if env["MIBLAST_RELAY_S0"] == "0":
+            assert got.stats["relay_accepted"] == 0 and got.stats["relay_rejected"] == 0
+        elif n >= 60000:
+            assert got.stats["relay_accepted"] > 0, "the case must exercise hand-overs"
+            if "MIBLAST_RELAY_FORCE_REJECT" in env:
+                assert got.stats["relay_rejected"] > 0
+
+
+def test_full_size_properties_1mb(gpu_ctx, monkeypatch):
     """BASELINE config 2 at full size (1 Mb x 1 Mb): too slow to diff against the oracle in a unit test, so
     check size-independent properties: every record passes the caf walk (pinchIterator.c:59-121) and its AS
     score re-derives from the sequences; the run is reproducible; aligning the reverse-complemented query
@@ -102,6 +141,14 @@ def test_full_size_properties_1mb(gpu_ctx):
 
     assert canon(r1.paf, False) == canon(rr.paf, True)
     assert r1.stats["dp_cells"] == rr.stats["dp_cells"] and r1.stats["seed_hits"] == rr.stats["seed_hits"]
+    # the relay path (hundreds of concurrently evaluated pieces per long alignment) against the plain sequential DPs
+    assert r1.stats["relay_accepted"] > 100
+    monkeypatch.setenv("MIBLAST_RELAY_S0", "0")
+    seq = gpu_ctx.align(T, Q, pm, details=False)
+    monkeypatch.delenv("MIBLAST_RELAY_S0")
+    assert seq.stats["relay_accepted"] == 0 and seq.paf == r1.paf
+    for k in COUNTERS:
+        assert seq.stats[k] == r1.stats[k], k
 
 
 def test_cli_front_ends_match_library(gpu_ctx, tmp_path):
