@@ -141,7 +141,8 @@ def main():
         traffic, traffic_note = None, "no committed PMC summary"
         pmc_path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
         if os.path.exists(pmc_path) and not a.random_pair and a.size == 1_000_000 and a.lastz_args == DEFAULT_ARGS:
-            k = json.load(open(pmc_path))["kernels"].get("mb::k_ydrop<false, false>")
+            ks = json.load(open(pmc_path))["kernels"]
+            k = next((v for name, v in ks.items() if "k_ydrop<false, false>" in name), None)
             if k:
                 pmc_bytes = k["fetch_bytes_corrected_per_call"] + k["write_size_bytes_per_call"]
                 traffic = pmc_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None

@@ -387,6 +387,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             found.resize(base + (size_t)hc.hsps);
             if (hc.hsps) MB_HIP(hipMemcpy(found.data() + base, d_hsps.p, (size_t)hc.hsps * sizeof(DevHsp), hipMemcpyDeviceToHost));
         }
+        const double t_h0 = now_s();
         // number of seed word lookups = valid query windows x variants (counter only)
         {
             int64_t run = 0, valid = 0;
@@ -457,6 +458,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         }
         st.hsps += (int64_t)hs.size();
         st.t_seed += now_s() - t0;
+        if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast]   strand %d: gpu part %.2f ms, host part %.2f ms\n", strand, (t_h0 - t0) * 1e3, (now_s() - t_h0) * 1e3);
     }
     for (int strand = 0; strand < 2; strand++) res.hsps.insert(res.hsps.end(), strand_hsps[strand].begin(), strand_hsps[strand].end());
 
@@ -1158,9 +1160,12 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         PairJob &j = *store.back();
         j.T = Ts[k]; j.Q = Qs[k]; j.res = results[k]; j.use_ws_rc = (k == 0);
         jobs.push_back(&j);
+        const double t_a = now_s();
         int rc = seed_phase(ctx, p, j);
         if (rc != MIBLAST_OK) return rc;
+        const double t_b = now_s();
         build_units(p, j, (int)k, units);
+        if (env_long("MIBLAST_DEBUG", 0) && n == 1) fprintf(stderr, "[miblast] seed phase %.2f ms, build_units %.2f ms\n", (t_b - t_a) * 1e3, (now_s() - t_b) * 1e3);
     }
     // device table of the pairs' sequence pointers (k_ydrop picks its pair through DpProb.pad0)
     if (!units.empty()) {
@@ -1171,7 +1176,9 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     }
     int rc = gapped_phase(ctx, p, jobs, units);
     if (rc != MIBLAST_OK) return rc;
+    const double t_o = now_s();
     parallel_for(n, [&](size_t k) { output_phase(p, *jobs[k], (int)k, units); });
+    if (env_long("MIBLAST_DEBUG", 0) && n == 1) fprintf(stderr, "[miblast] output phase %.2f ms\n", (now_s() - t_o) * 1e3);
     return MIBLAST_OK;
 }
 
