@@ -18,7 +18,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <future>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -136,16 +140,91 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
     }
 };
 
-// independent work items on a few host threads (merging the traces of many alignments is embarrassingly parallel)
+// independent work items on a few persistent host threads (merging traces, formatting PAF, anchors: all embarrassingly
+// parallel).  The caller takes part; nested calls run inline.
+class Pool {
+    std::vector<std::thread> th;
+    std::mutex m, run_m;
+    std::condition_variable cv, done_cv;
+    const std::function<void(size_t)> *fn = nullptr;
+    size_t n = 0;
+    std::atomic<size_t> next{0};
+    size_t busy = 0;
+    unsigned long long gen = 0;
+    std::atomic<unsigned long long> gen_a{0};
+    std::atomic<int> hot_a{0};                // > 0 while a job is in flight: idle workers spin instead of sleeping
+    std::atomic<bool> stop_a{false};
+    bool stop = false;
+    void worker() {
+        unsigned long long seen = 0;
+        for (;;) {
+            for (;;) {
+                if (gen_a.load(std::memory_order_acquire) != seen || stop_a.load(std::memory_order_relaxed)) break;
+                if (hot_a.load(std::memory_order_relaxed) > 0) { __builtin_ia32_pause(); continue; }
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || gen != seen || hot_a.load(std::memory_order_relaxed) > 0; });
+            }
+            const std::function<void(size_t)> *f;
+            size_t cnt;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (stop) return;
+                if (gen == seen) continue;
+                seen = gen; f = fn; cnt = n;
+                if (!f) continue;                                   // the region is already over
+                busy++;
+            }
+            for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < cnt;) (*f)(i);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--busy == 0) done_cv.notify_all();
+            }
+        }
+    }
+public:
+    Pool() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nt = std::min(15u, hw > 1 ? hw - 1 : 0u);
+        for (unsigned t = 0; t < nt; t++) th.emplace_back([this] { worker(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; stop_a = true; }
+        cv.notify_all();
+        for (std::thread &t : th) t.join();
+    }
+    static Pool &get() { static Pool p; return p; }
+    struct Hot {                              // keeps the workers awake for the duration of a job
+        Hot() { Pool &p = get(); p.hot_a++; p.cv.notify_all(); }
+        ~Hot() { get().hot_a--; }
+    };
+    void run(size_t count, const std::function<void(size_t)> &f) {
+        static thread_local bool inside = false;
+        if (count <= 1 || th.empty() || inside) { for (size_t i = 0; i < count; i++) f(i); return; }
+        std::unique_lock<std::mutex> one(run_m, std::try_to_lock);      // one parallel region at a time; others run inline
+        if (!one.owns_lock()) { for (size_t i = 0; i < count; i++) f(i); return; }
+        inside = true;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fn = &f; n = count; next.store(0, std::memory_order_relaxed); gen++; busy++;
+            gen_a.store(gen, std::memory_order_release);
+        }
+        if (hot_a.load(std::memory_order_relaxed) == 0) cv.notify_all();
+        for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count;) f(i);
+        for (bool first = true;; first = false) {                       // the stragglers finish within microseconds: spin
+            std::unique_lock<std::mutex> lk(m);
+            if (first) --busy;
+            if (busy == 0) { fn = nullptr; n = 0; break; }
+            lk.unlock();
+            __builtin_ia32_pause();
+        }
+        inside = false;
+    }
+};
+
 template <typename F>
 void parallel_for(size_t n, F &&f) {
-    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t nt = std::min<size_t>({n, hw, (size_t)16});
-    if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; t++) th.emplace_back([&]() { for (size_t i; (i = next++) < n;) f(i); });
-    for (std::thread &t : th) t.join();
+    const std::function<void(size_t)> fn = std::ref(f);
+    Pool::get().run(n, fn);
 }
 
 long env_long(const char *name, long dflt) {
@@ -277,125 +356,32 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     const uint8_t *qc_h[2] = {nullptr, nullptr};
     const uint8_t *qc_d[2] = {nullptr, nullptr};
     std::vector<miblast_hsp> strand_hsps[2];
+    std::vector<DevHsp> found[2];         // HSPs as the device found them, per strand
+    struct HostOut { int64_t lookups = 0, pre = 0, kept = 0; double seconds = 0; } host_out[2];
+    bool defer_host = false;              // batched calls run the host half of the seed stage on worker threads
+    std::vector<Unit> units;              // anchors of this pair (merged into the call's unit list in pair order)
     double t_begin = 0;
 };
 
-// index build + seed search + ungapped extension + HSP filters of one pair (uses the shared seed workspace)
-static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
-    hipStream_t s = ctx.stream;
-    const SeqSet &T = *job.T, &Q = *job.Q;
-    Result &res = *job.res;
-    if (T.device != ctx.device || Q.device != ctx.device) { set_error("sequence set lives on another device"); return MIBLAST_EINVAL; }
-    if (T.total + Q.total + 4 >= (int64_t)0x7fffffff) {
-        set_error("target+query longer than 2^31-1 bases: chunk the input (Cactus chunkSize is 30 Mb)");
-        return MIBLAST_ELIMIT;
-    }
-    miblast_stats &st = res.stats;
-    memset(&st, 0, sizeof st);
-    const double t_begin = now_s();
-    job.t_begin = t_begin;
-    const int nvar = p.transitions ? 1 + kSeedWeight : 1;
-    const int64_t qtot = Q.total, ttot = T.total;
-
-    // ---- seed position table ------------------------------------------------------------------
-    Workspace &w = *ctx.ws;
-    Index ix;
-    build_index(ctx, T, p.step, ix);
-    st.t_index = now_s() - t_begin;
-
-    // ---- '-' strand of the query -----------------------------------------------------------------
-    DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : job.own_rc;
-    d_rc.ensure((size_t)qtot + 2 * kDevPad);
-    MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
-    launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
-    std::vector<uint8_t> &h_rc = job.h_rc;
-    h_rc.assign((size_t)qtot + 2, 0);
-    MB_HIP(hipMemcpyAsync(h_rc.data(), d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
-    MB_HIP(hipStreamSynchronize(s));
-    job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc.data() + 1;
-    job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
+// host half of the seed stage of one strand: lookup counter, discovery order, entropy filter, --queryhsplimit/--queryhspbest.
+// Touches only the strand's own fields of the job, so it can run beside the device half of the other strand or pair.
+static void seed_host(const miblast_params &p, PairJob &job, int strand) {
+    const double t_h0 = now_s();
+    const SeqSet &Q = *job.Q;
+    const int64_t qtot = Q.total;
     const uint8_t *tc_h = job.tc_h;
     const uint8_t *const *qc_h = job.qc_h;
-    const uint8_t *const *qc_d = job.qc_d;
-
-    // ---- seed search + ungapped extension, per strand ----------------------------------------------
-    const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
-    const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
-    DevBuf<int32_t> &extent = w.extent;
-    extent.ensure((size_t)(ttot + qtot + 2));
-    DevBuf<uint32_t> &qcnt = w.qcnt, &hit_off = w.hit_off;
-    qcnt.ensure((size_t)std::max<int64_t>(1, qtot));
-    int64_t n_qblk = (qtot + 2047) / 2048;
-    DevBuf<unsigned long long> &qbsum = w.qbsum, &scan_scratch = w.scan_scratch, &keys_a = w.keys_a, &keys_b = w.keys_b;
-    qbsum.ensure((size_t)n_qblk + 2); scan_scratch.ensure((size_t)n_qblk + 2);
-    DevBuf<char> &sort_temp = w.sort_temp;
-    DevBuf<DevHsp> &d_hsps = w.hsps;
-    DevBuf<UngappedCounters> &d_ctr = w.ctr;
-    d_ctr.ensure(1);
-    std::vector<unsigned long long> h_qbsum((size_t)n_qblk + 2);
+    std::vector<DevHsp> &found = job.found[strand];
     std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
-    strand_hsps[0].clear(); strand_hsps[1].clear();
-
-    for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
-        const double t0 = now_s();
-        MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
-        launch_seed_count(qc_d[strand], qtot, w.offsets.p, p.transitions, qcnt.p, s);
-        launch_block_sums(qcnt.p, qtot, qbsum.p, s);
-        MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
-        MB_HIP(hipStreamSynchronize(s));
-        std::vector<DevHsp> found;
-        int64_t b0 = 0;
-        while (b0 < n_qblk) {
-            // greedy batch of whole 2048-position blocks with at most hit_cap hits
-            int64_t b1 = b0;
-            unsigned long long nh = 0;
-            while (b1 < n_qblk && (b1 == b0 || nh + h_qbsum[(size_t)b1] <= (unsigned long long)hit_cap)) nh += h_qbsum[(size_t)b1++];
-            const int64_t q0 = b0 * 2048, q1 = std::min(qtot, b1 * 2048);
-            b0 = b1;
-            if (nh == 0) continue;
-            if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one 2048-base query block (unmasked repeat?)"); return MIBLAST_ELIMIT; }
-            st.seed_hits += (int64_t)nh;
-            st.seed_batches++;
-            hit_off.ensure((size_t)(q1 - q0));
-            keys_a.ensure((size_t)nh); keys_b.ensure((size_t)nh);
-            d_hsps.ensure((size_t)nh);
-            w.heads.ensure((size_t)nh + (size_t)nh / 4 + 8); w.n_heads.ensure(2);
-            size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
-            sort_temp.ensure(tb + 16);
-            MB_HIP(hipEventRecord(ctx.ev0, s));
-            launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
-            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
-            MB_HIP(hipEventRecord(ctx.ev1, s));
-            sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, sort_bits, s);
-            MB_HIP(hipEventRecord(ctx.ev2, s));
-            MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
-            MB_HIP(hipEventRecord(ctx.ev3, s));
-            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
-                            (int64_t)d_hsps.n, d_ctr.p, s);
-            MB_HIP(hipEventRecord(ctx.ev4, s));
-            UngappedCounters hc;
-            MB_HIP(hipMemcpyAsync(&hc, d_ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
-            MB_HIP(hipStreamSynchronize(s));
-            float ms;
-            MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1)); st.t_seedfill_ms += ms;
-            MB_HIP(hipEventElapsedTime(&ms, ctx.ev1, ctx.ev2)); st.t_sort_ms += ms;
-            MB_HIP(hipEventElapsedTime(&ms, ctx.ev3, ctx.ev4)); st.t_ungapped_kernel_ms += ms; st.ungapped_kernel_launches++;
-            st.hits_extended += (int64_t)hc.extended;
-            st.ungapped_cols += (int64_t)hc.cols;
-            if (hc.hsps > d_hsps.n) { set_error("HSP buffer overflow"); return MIBLAST_ELIMIT; }
-            size_t base = found.size();
-            found.resize(base + (size_t)hc.hsps);
-            if (hc.hsps) MB_HIP(hipMemcpy(found.data() + base, d_hsps.p, (size_t)hc.hsps * sizeof(DevHsp), hipMemcpyDeviceToHost));
-        }
-        const double t_h0 = now_s();
+    PairJob::HostOut &out = job.host_out[strand];
         // number of seed word lookups = valid query windows x variants (counter only)
         {
             int64_t run = 0, valid = 0;
             const uint8_t *qc = qc_h[strand];
             for (int64_t i = 0; i < qtot; i++) { run = qc[i] < 4 ? run + 1 : 0; valid += run >= kSeedSpan; }
-            st.seed_lookups += valid * nvar;
+            out.lookups = valid * (p.transitions ? 1 + kSeedWeight : 1);
         }
-        st.hsps_pre_entropy += (int64_t)found.size();
+        out.pre = (int64_t)found.size();
         // order HSPs the way the sequential search discovers them: q ascending, word variant, target descending
         struct Key { int32_t q_end, rank, neg_t; size_t idx; };
         std::vector<Key> order(found.size());
@@ -456,14 +442,139 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             }
             hs.swap(kept);
         }
-        st.hsps += (int64_t)hs.size();
-        st.t_seed += now_s() - t0;
-        if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast]   strand %d: gpu part %.2f ms, host part %.2f ms\n", strand, (t_h0 - t0) * 1e3, (now_s() - t_h0) * 1e3);
-    }
-    for (int strand = 0; strand < 2; strand++) res.hsps.insert(res.hsps.end(), strand_hsps[strand].begin(), strand_hsps[strand].end());
+        out.kept = (int64_t)hs.size();
+        out.seconds = now_s() - t_h0;
+}
 
+// folds the host halves into the pair's result (after both strands are done)
+static void seed_finish(PairJob &job) {
+    miblast_stats &st = job.res->stats;
+    for (int strand = 0; strand < 2; strand++) {
+        const PairJob::HostOut &o = job.host_out[strand];
+        st.seed_lookups += o.lookups; st.hsps_pre_entropy += o.pre; st.hsps += o.kept; st.t_seed += o.seconds;
+        job.res->hsps.insert(job.res->hsps.end(), job.strand_hsps[strand].begin(), job.strand_hsps[strand].end());
+        std::vector<DevHsp>().swap(job.found[strand]);
+    }
+}
+
+// index build + seed search + ungapped extension + HSP filters of one pair (uses the shared seed workspace)
+static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
+    hipStream_t s = ctx.stream;
+    const SeqSet &T = *job.T, &Q = *job.Q;
+    Result &res = *job.res;
+    if (T.device != ctx.device || Q.device != ctx.device) { set_error("sequence set lives on another device"); return MIBLAST_EINVAL; }
+    if (T.total + Q.total + 4 >= (int64_t)0x7fffffff) {
+        set_error("target+query longer than 2^31-1 bases: chunk the input (Cactus chunkSize is 30 Mb)");
+        return MIBLAST_ELIMIT;
+    }
+    miblast_stats &st = res.stats;
+    memset(&st, 0, sizeof st);
+    const double t_begin = now_s();
+    job.t_begin = t_begin;
+    const int64_t qtot = Q.total, ttot = T.total;
+
+    // ---- seed position table ------------------------------------------------------------------
+    Workspace &w = *ctx.ws;
+    Index ix;
+    build_index(ctx, T, p.step, ix);
+    st.t_index = now_s() - t_begin;
+
+    // ---- '-' strand of the query -----------------------------------------------------------------
+    DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : job.own_rc;
+    d_rc.ensure((size_t)qtot + 2 * kDevPad);
+    MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
+    launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
+    std::vector<uint8_t> &h_rc = job.h_rc;
+    h_rc.assign((size_t)qtot + 2, 0);
+    MB_HIP(hipMemcpyAsync(h_rc.data(), d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipStreamSynchronize(s));
+    job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc.data() + 1;
+    job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
+    const uint8_t *const *qc_d = job.qc_d;
+
+    // ---- seed search + ungapped extension, per strand ----------------------------------------------
+    const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
+    const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
+    DevBuf<int32_t> &extent = w.extent;
+    extent.ensure((size_t)(ttot + qtot + 2));
+    DevBuf<uint32_t> &qcnt = w.qcnt, &hit_off = w.hit_off;
+    qcnt.ensure((size_t)std::max<int64_t>(1, qtot));
+    int64_t n_qblk = (qtot + 2047) / 2048;
+    DevBuf<unsigned long long> &qbsum = w.qbsum, &scan_scratch = w.scan_scratch, &keys_a = w.keys_a, &keys_b = w.keys_b;
+    qbsum.ensure((size_t)n_qblk + 2); scan_scratch.ensure((size_t)n_qblk + 2);
+    DevBuf<char> &sort_temp = w.sort_temp;
+    DevBuf<DevHsp> &d_hsps = w.hsps;
+    DevBuf<UngappedCounters> &d_ctr = w.ctr;
+    d_ctr.ensure(1);
+    std::vector<unsigned long long> h_qbsum((size_t)n_qblk + 2);
+    std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
+    strand_hsps[0].clear(); strand_hsps[1].clear();
+
+    std::future<void> host0;
+    for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
+        const double t0 = now_s();
+        MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
+        launch_seed_count(qc_d[strand], qtot, w.offsets.p, p.transitions, qcnt.p, s);
+        launch_block_sums(qcnt.p, qtot, qbsum.p, s);
+        MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));
+        std::vector<DevHsp> found;
+        int64_t b0 = 0;
+        while (b0 < n_qblk) {
+            // greedy batch of whole 2048-position blocks with at most hit_cap hits
+            int64_t b1 = b0;
+            unsigned long long nh = 0;
+            while (b1 < n_qblk && (b1 == b0 || nh + h_qbsum[(size_t)b1] <= (unsigned long long)hit_cap)) nh += h_qbsum[(size_t)b1++];
+            const int64_t q0 = b0 * 2048, q1 = std::min(qtot, b1 * 2048);
+            b0 = b1;
+            if (nh == 0) continue;
+            if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one 2048-base query block (unmasked repeat?)"); return MIBLAST_ELIMIT; }
+            st.seed_hits += (int64_t)nh;
+            st.seed_batches++;
+            hit_off.ensure((size_t)(q1 - q0));
+            keys_a.ensure((size_t)nh); keys_b.ensure((size_t)nh);
+            d_hsps.ensure((size_t)nh);
+            w.heads.ensure((size_t)nh + (size_t)nh / 4 + 8); w.n_heads.ensure(2);
+            size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
+            sort_temp.ensure(tb + 16);
+            MB_HIP(hipEventRecord(ctx.ev0, s));
+            launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
+            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
+            MB_HIP(hipEventRecord(ctx.ev1, s));
+            sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, sort_bits, s);
+            MB_HIP(hipEventRecord(ctx.ev2, s));
+            MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
+            MB_HIP(hipEventRecord(ctx.ev3, s));
+            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
+                            (int64_t)d_hsps.n, d_ctr.p, s);
+            MB_HIP(hipEventRecord(ctx.ev4, s));
+            UngappedCounters hc;
+            MB_HIP(hipMemcpyAsync(&hc, d_ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
+            MB_HIP(hipStreamSynchronize(s));
+            float ms;
+            MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1)); st.t_seedfill_ms += ms;
+            MB_HIP(hipEventElapsedTime(&ms, ctx.ev1, ctx.ev2)); st.t_sort_ms += ms;
+            MB_HIP(hipEventElapsedTime(&ms, ctx.ev3, ctx.ev4)); st.t_ungapped_kernel_ms += ms; st.ungapped_kernel_launches++;
+            st.hits_extended += (int64_t)hc.extended;
+            st.ungapped_cols += (int64_t)hc.cols;
+            if (hc.hsps > d_hsps.n) { set_error("HSP buffer overflow"); return MIBLAST_ELIMIT; }
+            size_t base = found.size();
+            found.resize(base + (size_t)hc.hsps);
+            if (hc.hsps) MB_HIP(hipMemcpy(found.data() + base, d_hsps.p, (size_t)hc.hsps * sizeof(DevHsp), hipMemcpyDeviceToHost));
+        }
+        job.found[strand].swap(found);
+        st.t_seed += now_s() - t0;
+        // the host half of strand '+' (ordering, entropy filter) overlaps the device half of strand '-'
+        if (!job.defer_host && strand == 0) host0 = std::async(std::launch::async, [&p, &job] { seed_host(p, job, 0); });
+    }
+    if (host0.valid()) host0.get();
+    if (!job.defer_host) {
+        if (qtot >= kSeedSpan) seed_host(p, job, 1);
+        seed_finish(job);
+    }
     return MIBLAST_OK;
 }
+
 
 // anchors of one pair, one unit per (query contig, strand), sorted by (-score, t, q)  
 static void build_units(const miblast_params &p, PairJob &job, int pair, std::vector<Unit> &units) {
@@ -476,23 +587,31 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
         for (int strand = 0; strand < 2; strand++) {
             std::vector<std::vector<Anchor>> per((size_t)Q.starts.size());
             const uint8_t *qc = qc_h[strand];
-            for (const miblast_hsp &h : strand_hsps[strand]) {
-                // anchor = middle of the best-scoring 31-column window (first on ties); SURVEY A.6
-                int off;
-                if (h.len <= 31) off = h.len / 2;
-                else {
-                    int64_t sum = 0;
-                    for (int k = 0; k < 31; k++) sum += host_score(tc_h[h.t_start + k], qc[h.q_start + k]);
-                    int64_t bestsum = sum; int bestc = 0;
-                    for (int c = 1; c + 31 <= h.len; c++) {
-                        sum += host_score(tc_h[h.t_start + c + 30], qc[h.q_start + c + 30]);
-                        sum -= host_score(tc_h[h.t_start + c - 1], qc[h.q_start + c - 1]);
-                        if (sum > bestsum) { bestsum = sum; bestc = c; }
+            // anchor = middle of the best-scoring 31-column window (first on ties); SURVEY A.6
+            const std::vector<miblast_hsp> &hs = strand_hsps[strand];
+            std::vector<int> offs(hs.size());
+            const size_t kChunk = 256;
+            parallel_for((hs.size() + kChunk - 1) / kChunk, [&](size_t c) {
+                for (size_t x = c * kChunk; x < std::min(hs.size(), (c + 1) * kChunk); x++) {
+                    const miblast_hsp &h = hs[x];
+                    int off;
+                    if (h.len <= 31) off = h.len / 2;
+                    else {
+                        int64_t sum = 0;
+                        for (int k = 0; k < 31; k++) sum += host_score(tc_h[h.t_start + k], qc[h.q_start + k]);
+                        int64_t bestsum = sum; int bestc = 0;
+                        for (int cc = 1; cc + 31 <= h.len; cc++) {
+                            sum += host_score(tc_h[h.t_start + cc + 30], qc[h.q_start + cc + 30]);
+                            sum -= host_score(tc_h[h.t_start + cc - 1], qc[h.q_start + cc - 1]);
+                            if (sum > bestsum) { bestsum = sum; bestc = cc; }
+                        }
+                        off = bestc + 15;
                     }
-                    off = bestc + 15;
+                    offs[x] = off;
                 }
-                per[(size_t)h.q_contig].push_back(Anchor{h.t_start + off, h.q_start + off, h.score});
-            }
+            });
+            for (size_t x = 0; x < hs.size(); x++)
+                per[(size_t)hs[x].q_contig].push_back(Anchor{hs[x].t_start + offs[x], hs[x].q_start + offs[x], hs[x].score});
             for (size_t qc_i = 0; qc_i < per.size(); qc_i++) {
                 if (per[qc_i].empty()) continue;
                 Unit u;
@@ -1005,47 +1124,96 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
             std::vector<Cached *> cptr(acc.size());
             for (size_t x = 0; x < acc.size(); x++) cptr[x] = &units[pend[acc[x]].unit].cache[pend[acc[x]].anchor];   // no map mutation inside the workers
-            std::atomic<int> bad{0};
-            auto merge_one = [&](size_t x) {
-                const size_t k = acc[x];
-                const Unit &u = units[pend[k].unit];
-                Cached &c = *cptr[x];
+            // A long alignment is merged in chunks of runs on several threads: the (t, q) position of every chunk start is
+            // a cheap prefix over the run lengths; the chunks' run-length strings are stitched afterwards.
+            struct MergeTask { size_t x, r0, r1; int64_t tt, qq; std::vector<uint32_t> ops; int32_t dmin, dmax; };
+            std::vector<MergeTask> tasks;
+            std::vector<std::pair<size_t, size_t>> task_range(acc.size());
+            std::vector<std::pair<int64_t, int64_t>> reached(acc.size());
+            const size_t kRunsPerTask = 2048;
+            auto run_at = [&](size_t x, size_t run) -> uint32_t {
                 const uint32_t *Rops = hops + coff[2 * x], *Lops = hops + coff[2 * x + 1];
                 const size_t nR = (size_t)(coff[2 * x + 1] - coff[2 * x]), nL = (size_t)(coff[2 * x + 2] - coff[2 * x + 1]);
+                return run < nL ? Lops[run] : Rops[nR - 1 - (run - nL)];
+            };
+            for (size_t x = 0; x < acc.size(); x++) {
+                const Cached &c = *cptr[x];
+                const size_t nruns = (size_t)(coff[2 * x + 2] - coff[2 * x]);
+                int64_t tt = c.t_lo, qq = c.q_lo;
+                task_range[x].first = tasks.size();
+                for (size_t r0 = 0; r0 < nruns || r0 == 0; r0 += kRunsPerTask) {
+                    const size_t r1 = std::min(nruns, r0 + kRunsPerTask);
+                    tasks.push_back(MergeTask{x, r0, r1, tt, qq, {}, 0x7fffffff, -0x7fffffff - 1});
+                    for (size_t r = r0; r < r1; r++) {
+                        const uint32_t e = run_at(x, r), o = e & 3u, len = e >> 2;
+                        if (o == 0) { tt += len; qq += len; } else if (o == 2) qq += len; else tt += len;
+                    }
+                    if (r1 >= nruns) break;
+                }
+                task_range[x].second = tasks.size();
+                reached[x] = {tt, qq};
+            }
+            const double t_mg1 = now_s();
+            parallel_for(tasks.size(), [&](size_t ti) {
+                MergeTask &t = tasks[ti];
+                const Unit &u = units[pend[acc[t.x]].unit];
                 const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
                 const uint8_t *qc = jobs[(size_t)u.pair]->qc_h[u.strand];
-                int64_t tt = c.t_lo, qq = c.q_lo;
-                int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
+                int64_t tt = t.tt, qq = t.qq;
                 uint32_t cur_op = 0, cur_len = 0;
+                std::vector<uint32_t> out;                          // thread-local until the end: no false sharing on the task array
+                out.reserve(4 * (t.r1 - t.r0) + 16);
+                int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
                 auto push = [&](uint32_t op, uint32_t len) {
                     if (cur_len && op == cur_op) cur_len += len;
-                    else { if (cur_len) c.ops.push_back((cur_len << 2) | cur_op); cur_op = op; cur_len = len; }
+                    else { if (cur_len) out.push_back((cur_len << 2) | cur_op); cur_op = op; cur_len = len; }
                 };
-                for (size_t run = 0; run < nL + nR; run++) {
-                    const uint32_t e = run < nL ? Lops[run] : Rops[nR - 1 - (run - nL)];
+                for (size_t run = t.r0; run < t.r1; run++) {
+                    const uint32_t e = run_at(t.x, run);
                     const uint32_t o = e & 3u, len = e >> 2;
                     if (len == 0) continue;                         // a splice that fell on a run boundary
                     if (o == 0) {
                         const int32_t d = (int32_t)(tt - qq);
                         dmin = std::min(dmin, d); dmax = std::max(dmax, d);
-                        for (uint32_t m = 0; m < len; m++, tt++, qq++) {
-                            unsigned x = tc_h[tt] & 7u, y = qc[qq] & 7u;
-                            push((x < 4u && x == y) ? 0u : 1u, 1);
+                        const uint8_t *tp = tc_h + tt, *qp = qc + qq;
+                        for (uint32_t m = 0; m < len; m++) {
+                            const unsigned a = tp[m] & 7u, b = qp[m] & 7u;
+                            push((a < 4u && a == b) ? 0u : 1u, 1);
                         }
+                        tt += len; qq += len;
                     } else if (o == 2) { push(2, len); qq += len; }
                     else { push(3, len); tt += len; }
                 }
-                if (cur_len) c.ops.push_back((cur_len << 2) | cur_op);
+                if (cur_len) out.push_back((cur_len << 2) | cur_op);
+                t.ops.swap(out); t.dmin = dmin; t.dmax = dmax;
+            });
+            const double t_mg2 = now_s();
+            if (debug) fprintf(stderr, "[miblast]   merge: prefix %.2f ms, %zu tasks %.2f ms (hw threads %u)\n", (t_mg1 - t_mg0) * 1e3, tasks.size(), (t_mg2 - t_mg1) * 1e3, std::thread::hardware_concurrency());
+            int bad = 0;
+            for (size_t x = 0; x < acc.size(); x++) {
+                Cached &c = *cptr[x];
+                size_t total = 0;
+                for (size_t ti = task_range[x].first; ti < task_range[x].second; ti++) total += tasks[ti].ops.size();
+                c.ops.reserve(total);
+                int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
+                for (size_t ti = task_range[x].first; ti < task_range[x].second; ti++) {
+                    const MergeTask &t = tasks[ti];
+                    dmin = std::min(dmin, t.dmin); dmax = std::max(dmax, t.dmax);
+                    size_t from = 0;
+                    if (!c.ops.empty() && !t.ops.empty() && ((c.ops.back() ^ t.ops[0]) & 3u) == 0) { c.ops.back() += t.ops[0] & ~3u; from = 1; }   // same op across the seam
+                    c.ops.insert(c.ops.end(), t.ops.begin() + (long)from, t.ops.end());
+                }
                 c.dmin = dmin; c.dmax = dmax;
-                if (tt != c.t_hi || qq != c.q_hi) {
+                if (reached[x].first != c.t_hi || reached[x].second != c.q_hi) {
+                    const size_t k = acc[x];
                     if (!bad++ && debug) {
                         const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
-                        fprintf(stderr, "[miblast] span error: anchor %zu box t %d..%d q %d..%d reached t %lld q %lld; R: best %d at (%d,%d) chain %zu, nR %zu; L: best %d at (%d,%d) chain %zu, nL %zu\n",
-                                k, c.t_lo, c.t_hi, c.q_lo, c.q_hi, (long long)tt, (long long)qq, R.gbest, R.gbi, R.gbj, R.chain.size(), nR, L.gbest, L.gbi, L.gbj, L.chain.size(), nL);
+                        fprintf(stderr, "[miblast] span error: anchor %zu box t %d..%d q %d..%d reached t %lld q %lld; R: best %d at (%d,%d) chain %zu; L: best %d at (%d,%d) chain %zu\n",
+                                k, c.t_lo, c.t_hi, c.q_lo, c.q_hi, (long long)reached[x].first, (long long)reached[x].second, R.gbest, R.gbi, R.gbj, R.chain.size(),
+                                L.gbest, L.gbi, L.gbj, L.chain.size());
                     }
                 }
-            };
-            parallel_for(acc.size(), merge_one);
+            }
             if (bad) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
             st.t_merge_ms += (now_s() - t_mg0) * 1e3;
             if (debug) fprintf(stderr, "[miblast]   host merge: %.2f ms\n", (now_s() - t_mg0) * 1e3);
@@ -1093,7 +1261,31 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         if (v < 0) buf[n++] = '-';
         while (n) res.paf.push_back(buf[--n]);
     };
-    for (const miblast_aln &A : res.alns) {
+    // the cigar text of long alignments is formatted in chunks on several threads
+    struct CigarTask { size_t aln; int64_t k0, k1; std::string text; };
+    std::vector<CigarTask> ctasks;
+    std::vector<size_t> cfirst(res.alns.size() + 1, 0);
+    const int64_t kOpsPerTask = 16384;
+    for (size_t x = 0; x < res.alns.size(); x++) {
+        cfirst[x] = ctasks.size();
+        for (int64_t k0 = 0; k0 < res.alns[x].n_ops; k0 += kOpsPerTask) ctasks.push_back(CigarTask{x, k0, std::min(res.alns[x].n_ops, k0 + kOpsPerTask), {}});
+    }
+    cfirst[res.alns.size()] = ctasks.size();
+    parallel_for(ctasks.size(), [&](size_t ti) {
+        CigarTask &t = ctasks[ti];
+        const miblast_aln &A = res.alns[t.aln];
+        t.text.reserve((size_t)(t.k1 - t.k0) * 5);
+        for (int64_t k = t.k0; k < t.k1; k++) {
+            const uint32_t o = res.ops[(size_t)(A.ops_off + k)];
+            char buf[12]; int n = 0;
+            uint32_t u = o >> 2;
+            do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+            while (n) t.text.push_back(buf[--n]);
+            t.text.push_back("=XID"[o & 3u]);
+        }
+    });
+    for (size_t ai = 0; ai < res.alns.size(); ai++) {
+        const miblast_aln &A = res.alns[ai];
         int64_t qst = Q.starts[(size_t)A.q_contig], qlen = Q.lens[(size_t)A.q_contig];
         int64_t tst = T.starts[(size_t)A.t_contig], tlen = T.lens[(size_t)A.t_contig];
         int64_t qs = A.q_lo - qst, qe = A.q_hi - qst;
@@ -1112,11 +1304,7 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         put_num(tlen); res.paf.push_back('\t'); put_num(A.t_lo - tst); res.paf.push_back('\t'); put_num(A.t_hi - tst); res.paf.push_back('\t');
         put_num(nmatch); res.paf.push_back('\t'); put_num(alen);
         res.paf += "\t255\tAS:i:"; put_num(A.score); res.paf += "\tcg:Z:";
-        for (int64_t k = 0; k < A.n_ops; k++) {
-            uint32_t o = res.ops[(size_t)(A.ops_off + k)];
-            put_num(o >> 2);
-            res.paf.push_back("=XID"[o & 3u]);
-        }
+        for (size_t ti = cfirst[ai]; ti < cfirst[ai + 1]; ti++) res.paf += ctasks[ti].text;
         res.paf.push_back('\n');
     }
     if (p.format == 1) {
@@ -1149,23 +1337,42 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
 
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
     MB_HIP(hipSetDevice(ctx.device));
+    Pool::Hot keep_workers_awake;
     miblast_params p = pin;
     if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
     if (p.step < 1) p.step = 1;
     std::vector<std::unique_ptr<PairJob>> store;
     std::vector<PairJob *> jobs;
     std::vector<Unit> units;
+    // Seed stages run back to back on the device; in a batched call the host half of every pair (discovery order, entropy
+    // filter, anchors) runs on worker threads meanwhile.
+    std::vector<std::future<void>> host_tasks;
+    size_t waited = 0;
     for (size_t k = 0; k < n; k++) {
         store.emplace_back(new PairJob());
         PairJob &j = *store.back();
         j.T = Ts[k]; j.Q = Qs[k]; j.res = results[k]; j.use_ws_rc = (k == 0);
+        j.defer_host = n > 1;
         jobs.push_back(&j);
         const double t_a = now_s();
         int rc = seed_phase(ctx, p, j);
-        if (rc != MIBLAST_OK) return rc;
+        if (rc != MIBLAST_OK) { for (auto &f : host_tasks) if (f.valid()) f.wait(); return rc; }
         const double t_b = now_s();
-        build_units(p, j, (int)k, units);
-        if (env_long("MIBLAST_DEBUG", 0) && n == 1) fprintf(stderr, "[miblast] seed phase %.2f ms, build_units %.2f ms\n", (t_b - t_a) * 1e3, (now_s() - t_b) * 1e3);
+        if (j.defer_host) {
+            host_tasks.push_back(std::async(std::launch::async, [&p, &j, k] {
+                seed_host(p, j, 0); seed_host(p, j, 1); seed_finish(j);
+                build_units(p, j, (int)k, j.units);
+            }));
+            while (host_tasks.size() - waited > 24) host_tasks[waited++].get();
+        } else {
+            build_units(p, j, (int)k, j.units);
+            if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast] seed phase %.2f ms, build_units %.2f ms\n", (t_b - t_a) * 1e3, (now_s() - t_b) * 1e3);
+        }
+    }
+    for (; waited < host_tasks.size(); waited++) host_tasks[waited].get();
+    for (size_t k = 0; k < n; k++) {
+        for (Unit &u : jobs[k]->units) units.push_back(std::move(u));
+        jobs[k]->units.clear();
     }
     // device table of the pairs' sequence pointers (k_ydrop picks its pair through DpProb.pad0)
     if (!units.empty()) {
