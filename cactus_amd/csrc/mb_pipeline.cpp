@@ -639,9 +639,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     // relay hand-over (see the DP section below): first stop, relay spacing, warm-up rows, diagonal tolerance, relays per side
-    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 512), relay_s = std::max(256l, env_long("MIBLAST_RELAY_S", 2048));
-    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 256)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
-    const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096);
+    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 256), relay_s_env = env_long("MIBLAST_RELAY_S", 0);
+    long relay_s = std::max(256l, relay_s_env > 0 ? relay_s_env : 1280l);
+    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 192)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
+    const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8));
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
     Workspace &g = *ctx.ws;
@@ -755,7 +756,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         struct Piece {
             int unit; int32_t ot, oq, dir;      // origin (concatenated coordinates) and direction
             int32_t row_lo, min_row, stop_row;
-            int target_anchor;                  // anchor of the relay the stop row is aimed at (-1: none)
+            int target;                         // relay point the stop row is aimed at (index into relay_pts, -1: none)
             int init_piece;                     // continuation: the piece whose exit snapshot it starts from
             int vjob;                           // index into vres of the hand-over check made after it ran (-1: none)
             int cont;                           // the piece that continues this one after a rejected hand-over (-1: none)
@@ -772,53 +773,92 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             bool done = false, wide = false;
         };
         const int nsides = (int)pend.size() * 2;
+        // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
+        // anyway, longer pieces waste less on warm-up overlap.
+        if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 1280;
         std::vector<SideRun> sides;
         std::vector<Piece> pieces;
         std::vector<DpProb> probs;
         std::vector<DpOut> outs;
         std::vector<VerifyJob> vjobs;
         std::vector<VerifyOut> vres;
-        std::unordered_map<unsigned long long, int> relay_piece;       // (unit, anchor, direction) -> its fresh piece
+        struct RelayPt { int unit; int32_t t, q, dir; int piece; };      // origin of a relay; piece = its fresh DP (-1: not queued yet)
+        std::vector<RelayPt> relay_pts;
+        std::unordered_map<unsigned long long, int> relay_id;          // (unit, direction, t, q) -> index into relay_pts
         bool arena_full = false;
         long n_verify_ok = 0, n_verify_bad = 0, n_subrounds = 0;
-        auto relay_key = [](int unit, int anchor, int dir) -> unsigned long long {
-            return ((unsigned long long)(unsigned)unit << 34) | ((unsigned long long)(unsigned)anchor << 1) | (dir > 0 ? 1ull : 0ull);
+        auto relay_at = [&](int unit, int32_t dir, int32_t t, int32_t q) -> int {
+            // (t, q) identify the point inside a unit and direction; units of a batch are told apart by the upper bits
+            const unsigned long long key = ((unsigned long long)(unsigned)unit << 52) ^ ((unsigned long long)(unsigned)t << 21) ^ ((unsigned long long)(unsigned)q << 1) ^ (dir > 0 ? 1ull : 0ull);
+            auto it = relay_id.find(key);
+            if (it != relay_id.end()) {
+                const RelayPt &r = relay_pts[(size_t)it->second];
+                if (r.unit == unit && r.t == t && r.q == q && r.dir == dir) return it->second;
+                // (hash collision of two different points: keep them apart with a linear probe on the key)
+                unsigned long long k2 = key;
+                while (true) {
+                    k2 = k2 * 6364136223846793005ull + 1442695040888963407ull;
+                    auto i2 = relay_id.find(k2);
+                    if (i2 == relay_id.end()) { relay_id[k2] = (int)relay_pts.size(); relay_pts.push_back(RelayPt{unit, t, q, dir, -1}); return (int)relay_pts.size() - 1; }
+                    const RelayPt &r2 = relay_pts[(size_t)i2->second];
+                    if (r2.unit == unit && r2.t == t && r2.q == q && r2.dir == dir) return i2->second;
+                }
+            }
+            relay_id[key] = (int)relay_pts.size();
+            relay_pts.push_back(RelayPt{unit, t, q, dir, -1});
+            return (int)relay_pts.size() - 1;
         };
-        // the relay after the point (t, q) of a unit, walking in direction dir: the best-scoring anchor (= smallest index)
-        // of the first q-bucket of width relay_s at least min_dq rows away whose diagonal lies within relay_tol of
-        // (t - q).  Depends on the unit's anchors only, so chains started from different heads merge.
-        auto next_relay = [&](const Unit &u, const DpProb &b, int32_t t, int32_t q, int32_t min_dq) -> int {
+        // the relay after the point (t, q) of a unit, walking in direction dir: in the first q-bucket of width relay_s at least
+        // min_dq rows away, the best-scoring anchor (= smallest index, preferably near the start of the bucket) whose
+        // diagonal lies within relay_tol of (t - q).  A bucket without such an anchor gets a VIRTUAL relay on the line to
+        // the next anchor further down (any cell near the path works as an origin -- a fresh DP locks onto the path and
+        // its state converges all the same; k_verify decides) so that stretches without seeds (soft-masked repeats)
+        // do not turn into one long piece.  No anchor within relay_gap buckets: the chain ends.
+        // Depends on the unit's anchors and the point only, so chains started from different heads merge.
+        auto next_relay = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq) -> int {
+            const Unit &u = units[(size_t)unit];
             const int32_t dirn = b.dir;
             const long s_from = (long)dirn * q + min_dq;                 // first admissible position in walking order, s = dir * q
-            long bucket = s_from >= 0 ? s_from / relay_s : -((-s_from + relay_s - 1) / relay_s);      // floor
-            for (int tries = 0; tries < 8; tries++, bucket++) {
+            const long bucket0 = s_from >= 0 ? s_from / relay_s : -((-s_from + relay_s - 1) / relay_s);      // floor
+            for (long bucket = bucket0; bucket < bucket0 + relay_gap; bucket++) {
                 // bucket covers s in [bucket * S, (bucket + 1) * S) with s = dirn * q
                 const long s_lo = std::max(bucket * relay_s, s_from), s_hi = (bucket + 1) * relay_s;
                 const long q_lo = dirn > 0 ? s_lo : -(s_hi - 1), q_hi = dirn > 0 ? s_hi : -s_lo + 1;      // [q_lo, q_hi)
                 auto it = std::lower_bound(u.by_q.begin(), u.by_q.end(), q_lo, [&](uint32_t x, long qq) { return (long)u.anchors[x].q < qq; });
-                // anchors near the start of the bucket are preferred: evenly spaced relays = pieces of even length
                 long best = -1, best_near = -1;
                 for (; it != u.by_q.end() && (long)u.anchors[*it].q < q_hi; ++it) {
                     const Anchor &c = u.anchors[*it];
+                    if (u.cov[*it]) continue;                           // inside a committed alignment: not where a new one runs
                     const int32_t dr = (c.q - b.q0) * dirn, dc = (c.t - b.t0) * dirn;
                     if (dr <= 0 || dc <= 0 || dc >= b.na - 64 || dr >= b.nb - (int32_t)relay_w - 64) continue;
                     if (std::labs((long)(c.t - c.q) - (long)(t - q)) > relay_tol) continue;
                     if (best < 0 || (long)*it < best) best = (long)*it;
                     if ((long)dirn * c.q - bucket * relay_s < relay_s / 4 && (best_near < 0 || (long)*it < best_near)) best_near = (long)*it;
                 }
-                if (best_near >= 0) return (int)best_near;
-                if (best >= 0) return (int)best;
+                if (best_near >= 0) best = best_near;
+                if (best < 0) continue;
+                const Anchor &c = u.anchors[(size_t)best];
+                if (bucket == bucket0) return relay_at(unit, dirn, c.t, c.q);
+                // virtual relay at the start of the first bucket, on the straight line from (t, q) to the anchor
+                const long vs = std::max(bucket0 * relay_s, s_from);
+                const int32_t vq = (int32_t)(dirn * vs);
+                const long span = (long)(c.q - q) * dirn, step = (long)(vq - q) * dirn;
+                const long ddiag = (long)(c.t - c.q) - (long)(t - q);
+                const int32_t vt = (int32_t)((long)t + (long)(vq - q) + (span > 0 ? ddiag * step / span : 0));
+                const int32_t dr = (vq - b.q0) * dirn, dc = (vt - b.t0) * dirn;
+                if (step <= 0 || dr <= 0 || dc <= 0 || dc >= b.na - 64 || dr >= b.nb - (int32_t)relay_w - 64) return relay_at(unit, dirn, c.t, c.q);
+                return relay_at(unit, dirn, vt, vq);
             }
             return -1;
         };
         while (true) {                                   // retried with a larger arena if the trace does not fit
             sides.assign((size_t)nsides, SideRun());
-            pieces.clear(); probs.clear(); outs.clear(); vjobs.clear(); vres.clear(); relay_piece.clear();
+            pieces.clear(); probs.clear(); outs.clear(); vjobs.clear(); vres.clear(); relay_pts.clear(); relay_id.clear();
             arena_full = false;
             uint64_t dir_entries = 0;
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
             auto add_piece = [&](int unit, const DpProb &base, int32_t ot, int32_t oq, int32_t row_lo, int32_t min_row, int32_t stop_row,
-                                 int32_t snap_row, int init_piece, int target_anchor) -> int {
+                                 int32_t snap_row, int init_piece, int target) -> int {
                 const int id = (int)pieces.size();
                 DpProb pr = base;
                 const int32_t dr = (oq - base.q0) * base.dir, dc = (ot - base.t0) * base.dir;
@@ -829,10 +869,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 const int64_t last = stop_row > 0 ? stop_row : pr.nb;
                 dir_entries += (uint64_t)((last - row_lo) / 4096) + 2;
                 probs.push_back(pr);
-                pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target_anchor, init_piece, -1, -1});
-                if (target_anchor >= 0) {
+                pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target, init_piece, -1, -1});
+                if (target >= 0) {
                     // checked right after the launch: this piece's exit state against the aimed relay's entry state
-                    const Anchor &ta = units[(size_t)unit].anchors[(size_t)target_anchor];
+                    const RelayPt ta = relay_pts[(size_t)target];
                     pieces.back().vjob = (int)vjobs.size();
                     vjobs.push_back(VerifyJob{2 * id + 1, -1, (ta.t - ot) * base.dir, (ta.q - oq) * base.dir});   // nslot set at launch
                 }
@@ -840,15 +880,14 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             };
             // fresh pieces of the relay chain that starts at anchor `a` (created once per unit and direction)
             auto plant_chain = [&](int unit, const DpProb &base, int a) {
-                const Unit &u = units[(size_t)unit];
                 for (long n = 0; a >= 0 && n < relay_max; n++) {
-                    const unsigned long long key = relay_key(unit, a, base.dir);
-                    if (relay_piece.count(key)) return;                          // the rest of the chain exists already
-                    const Anchor &c = u.anchors[(size_t)a];
-                    int nx = next_relay(u, base, c.t, c.q, (int32_t)(relay_s / 4));
-                    int32_t stop = nx >= 0 ? (u.anchors[(size_t)nx].q - c.q) * base.dir + (int32_t)relay_w : 0;
+                    if (relay_pts[(size_t)a].piece >= 0) return;                 // the rest of the chain exists already
+                    const RelayPt c = relay_pts[(size_t)a];                      // (copy: next_relay may grow the table)
+                    int nx = next_relay(unit, base, c.t, c.q, (int32_t)(relay_s / 4));
+                    int32_t stop = nx >= 0 ? (relay_pts[(size_t)nx].q - c.q) * base.dir + (int32_t)relay_w : 0;
                     if (nx >= 0 && n + 1 == relay_max) { nx = -1; stop = (int32_t)(relay_s + relay_w); }   // chain cut: whoever gets here plants the rest
-                    relay_piece[key] = add_piece(unit, base, c.t, c.q, 0, (int32_t)relay_w, stop, (int32_t)relay_w, -1, nx);
+                    const int id = add_piece(unit, base, c.t, c.q, 0, (int32_t)relay_w, stop, (int32_t)relay_w, -1, nx);
+                    relay_pts[(size_t)a].piece = id;
                     a = nx;
                 }
             };
@@ -880,7 +919,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 g.vjobs.ensure(v_new + 1); g.vres.ensure(v_new + 1);
                 outs.resize(pieces.size()); vres.resize(vjobs.size());
                 for (size_t x = launched; x < pieces.size(); x++)
-                    if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = 2 * relay_piece.at(relay_key(pieces[x].unit, pieces[x].target_anchor, pieces[x].dir));
+                    if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = 2 * relay_pts[(size_t)pieces[x].target].piece;
                 MB_HIP(hipMemcpyAsync(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), hipMemcpyHostToDevice, s));
                 if (v_new) MB_HIP(hipMemcpyAsync(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), hipMemcpyHostToDevice, s));
                 MB_HIP(hipMemsetAsync(g.snaps.p + launched * 2 * kSnapBytes, 0, n_new * 2 * kSnapBytes, s));      // valid = 0
@@ -919,20 +958,21 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     if (pieces[(size_t)x].cont >= 0) return pieces[(size_t)x].cont;
                     const Piece cp = pieces[(size_t)x];                          // (copies: the vectors grow below)
                     const DpProb cb = probs[(size_t)x];
-                    const Unit &u = units[(size_t)cp.unit];
-                    int aim = cp.target_anchor;
-                    if (aim >= 0) aim = pieces[(size_t)relay_piece.at(relay_key(cp.unit, aim, cp.dir))].target_anchor;   // the relay after the rejected one
+                    int aim = cp.target;
+                    auto entry_row = [&](int r) -> int32_t { return (relay_pts[(size_t)r].q - cp.oq) * cp.dir + (int32_t)relay_w; };   // in this piece's rows
+                    if (aim >= 0) aim = pieces[(size_t)relay_pts[(size_t)aim].piece].target;      // the relay after the rejected one
                     else if (relay_s0 > 0) {
                         // a stop without an aim (first stop of a side, end of a capped chain): the lattice relay beyond the best cell
                         const DpOut &o = outs[(size_t)x];
-                        aim = next_relay(u, cb, cp.ot + cp.dir * o.bj, cp.oq + cp.dir * o.bi, 0);
-                        while (aim >= 0 && (u.anchors[(size_t)aim].q - cp.oq) * cp.dir + (int32_t)relay_w <= cp.stop_row + 64)
-                            aim = next_relay(u, cb, u.anchors[(size_t)aim].t, u.anchors[(size_t)aim].q, (int32_t)(relay_s / 4));
+                        aim = next_relay(cp.unit, cb, cp.ot + cp.dir * o.bj, cp.oq + cp.dir * o.bi, 0);
+                        while (aim >= 0 && entry_row(aim) <= cp.stop_row + 64) {
+                            const RelayPt r = relay_pts[(size_t)aim];
+                            aim = next_relay(cp.unit, cb, r.t, r.q, (int32_t)(relay_s / 4));
+                        }
                         if (aim >= 0) plant_chain(cp.unit, cb, aim);
                     }
-                    while (aim >= 0 && (u.anchors[(size_t)aim].q - cp.oq) * cp.dir + (int32_t)relay_w <= cp.stop_row + 64)
-                        aim = pieces[(size_t)relay_piece.at(relay_key(cp.unit, aim, cp.dir))].target_anchor;
-                    const int32_t stop = aim >= 0 ? (u.anchors[(size_t)aim].q - cp.oq) * cp.dir + (int32_t)relay_w : 0;
+                    while (aim >= 0 && entry_row(aim) <= cp.stop_row + 64) aim = pieces[(size_t)relay_pts[(size_t)aim].piece].target;
+                    const int32_t stop = aim >= 0 ? entry_row(aim) : 0;
                     const int id = add_piece(cp.unit, cb, cp.ot, cp.oq, cp.stop_row, cp.stop_row, stop, 0, x, aim);
                     pieces[(size_t)x].cont = id;
                     return id;
@@ -940,7 +980,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 // rejected hand-overs are continued at once, whether or not a side has reached them yet: a side then never
                 // waits more than one launch per rejection on its path
                 for (size_t x = first_new; x < launched; x++)
-                    if (outs[x].stopped && outs[x].overflow == 0 && pieces[x].target_anchor >= 0) {
+                    if (outs[x].stopped && outs[x].overflow == 0 && pieces[x].target >= 0) {
                         if (accepted((int)x)) n_verify_ok++;
                         else { n_verify_bad++; make_cont((int)x); }
                     }
@@ -967,10 +1007,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                             sd.done = true;
                             break;
                         }
-                        if (cp.target_anchor >= 0 && accepted(tp)) {
+                        if (cp.target >= 0 && accepted(tp)) {
                             // the relay's rows are the rows of this DP from its entry row on
                             const VerifyOut &v = vres[(size_t)cp.vjob];
-                            const int np0 = relay_piece.at(relay_key(cp.unit, cp.target_anchor, cp.dir));
+                            const int np0 = relay_pts[(size_t)cp.target].piece;
                             sd.acc_cells += o.cells - sd.entry_cells; sd.acc_rows += o.rows - sd.entry_rows;
                             sd.entry_cells = v.n_cells; sd.entry_rows = v.n_rows;
                             sd.c_off += v.c;

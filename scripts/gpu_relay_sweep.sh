@@ -1,13 +1,13 @@
 #!/bin/bash
 # sweep of the relay knobs on the default bench pair
-for cfg in "1024 2048 512 256" "512 2048 512 4096" "256 2048 256 4096" "512 1536 256 4096" "512 1024 256 4096" "256 1024 256 4096" "256 1024 128 4096" "256 768 128 4096"; do
+for cfg in "512 2048 256" "256 2048 256" "256 1536 192" "256 1024 128" "128 1024 128" "256 1280 128" "128 768 128"; do
   set -- $cfg
-  echo "== S0=$1 S=$2 W=$3 MAX=$4"
-  MIBLAST_RELAY_S0=$1 MIBLAST_RELAY_S=$2 MIBLAST_RELAY_W=$3 MIBLAST_RELAY_MAX=$4 MIBLAST_DEBUG=1 timeout 300 python bench.py --steps 4 --warmup 1 --cpu-sample 0 --seed-leg 0 2>&1 | grep "round 0:\|metric" | tail -2 | python -c "
+  echo "== S0=$1 S=$2 W=$3"
+  MIBLAST_RELAY_S0=$1 MIBLAST_RELAY_S=$2 MIBLAST_RELAY_W=$3 MIBLAST_DEBUG=1 timeout 300 python bench.py --steps 4 --warmup 1 --cpu-sample 0 --seed-leg 0 2>&1 | grep "round 0\.\|round 0:\|metric" | tail -4 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('   ms/step', round(d['ms_per_step'], 2), 'ydrop ms', round(d['stage_kernel_ms_per_step']['ydrop'], 2), 't_gapped', round(d['stage_seconds_per_step']['t_gapped']*1e3, 2))
-    else: print('  ', l.strip()[:200])
+        d = json.loads(l); print('   ms/step', round(d['ms_per_step'], 2), 'ydrop ms', round(d['stage_kernel_ms_per_step']['ydrop'], 2), 't_gapped', round(d['stage_seconds_per_step']['t_gapped']*1e3, 2), 'spec', round(d['speculation_factor'], 2))
+    else: print('  ', l.strip()[:170])
 "
 done
