@@ -642,7 +642,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long relay_s0 = env_long("MIBLAST_RELAY_S0", 256), relay_s_env = env_long("MIBLAST_RELAY_S", 0);
     long relay_s = std::max(256l, relay_s_env > 0 ? relay_s_env : 1280l);
     const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 192)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
-    const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8));
+    const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
+               relay_tail = env_long("MIBLAST_RELAY_TAIL", 3);
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
     Workspace &g = *ctx.ws;
@@ -782,7 +783,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         std::vector<DpOut> outs;
         std::vector<VerifyJob> vjobs;
         std::vector<VerifyOut> vres;
-        struct RelayPt { int unit; int32_t t, q, dir; int piece; };      // origin of a relay; piece = its fresh DP (-1: not queued yet)
+        struct RelayPt { int unit; int32_t t, q, dir; int piece; int tail; };   // origin of a relay; piece = its fresh DP (-1: not queued yet); tail = virtual relays since the last anchor
         std::vector<RelayPt> relay_pts;
         std::unordered_map<unsigned long long, int> relay_id;          // (unit, direction, t, q) -> index into relay_pts
         bool arena_full = false;
@@ -799,13 +800,13 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 while (true) {
                     k2 = k2 * 6364136223846793005ull + 1442695040888963407ull;
                     auto i2 = relay_id.find(k2);
-                    if (i2 == relay_id.end()) { relay_id[k2] = (int)relay_pts.size(); relay_pts.push_back(RelayPt{unit, t, q, dir, -1}); return (int)relay_pts.size() - 1; }
+                    if (i2 == relay_id.end()) { relay_id[k2] = (int)relay_pts.size(); relay_pts.push_back(RelayPt{unit, t, q, dir, -1, 0}); return (int)relay_pts.size() - 1; }
                     const RelayPt &r2 = relay_pts[(size_t)i2->second];
                     if (r2.unit == unit && r2.t == t && r2.q == q && r2.dir == dir) return i2->second;
                 }
             }
             relay_id[key] = (int)relay_pts.size();
-            relay_pts.push_back(RelayPt{unit, t, q, dir, -1});
+            relay_pts.push_back(RelayPt{unit, t, q, dir, -1, 0});
             return (int)relay_pts.size() - 1;
         };
         // the relay after the point (t, q) of a unit, walking in direction dir: in the first q-bucket of width relay_s at least
@@ -815,41 +816,51 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // its state converges all the same; k_verify decides) so that stretches without seeds (soft-masked repeats)
         // do not turn into one long piece.  No anchor within relay_gap buckets: the chain ends.
         // Depends on the unit's anchors and the point only, so chains started from different heads merge.
-        auto next_relay = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq) -> int {
+        auto next_relay = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) -> int {
             const Unit &u = units[(size_t)unit];
             const int32_t dirn = b.dir;
             const long s_from = (long)dirn * q + min_dq;                 // first admissible position in walking order, s = dir * q
-            const long bucket0 = s_from >= 0 ? s_from / relay_s : -((-s_from + relay_s - 1) / relay_s);      // floor
-            for (long bucket = bucket0; bucket < bucket0 + relay_gap; bucket++) {
-                // bucket covers s in [bucket * S, (bucket + 1) * S) with s = dirn * q
-                const long s_lo = std::max(bucket * relay_s, s_from), s_hi = (bucket + 1) * relay_s;
+            const long line = (s_from >= 0 ? (s_from + relay_s - 1) / relay_s : -((-s_from) / relay_s)) * relay_s;   // next lattice line (ceil)
+            auto in_bounds = [&](int32_t ct, int32_t cq) -> bool {
+                const int32_t dr = (cq - b.q0) * dirn, dc = (ct - b.t0) * dirn;
+                return dr > 0 && dc > 0 && dc < b.na - 64 && dr < b.nb - (int32_t)relay_w - 64;
+            };
+            // anchors with s in [s_lo, s_hi), nearest to the lattice line first
+            auto scan = [&](long s_lo, long s_hi, long want) -> long {
                 const long q_lo = dirn > 0 ? s_lo : -(s_hi - 1), q_hi = dirn > 0 ? s_hi : -s_lo + 1;      // [q_lo, q_hi)
                 auto it = std::lower_bound(u.by_q.begin(), u.by_q.end(), q_lo, [&](uint32_t x, long qq) { return (long)u.anchors[x].q < qq; });
-                long best = -1, best_near = -1;
+                long best = -1, best_d = 0;
                 for (; it != u.by_q.end() && (long)u.anchors[*it].q < q_hi; ++it) {
                     const Anchor &c = u.anchors[*it];
                     if (u.cov[*it]) continue;                           // inside a committed alignment: not where a new one runs
-                    const int32_t dr = (c.q - b.q0) * dirn, dc = (c.t - b.t0) * dirn;
-                    if (dr <= 0 || dc <= 0 || dc >= b.na - 64 || dr >= b.nb - (int32_t)relay_w - 64) continue;
+                    if (!in_bounds(c.t, c.q)) continue;
                     if (std::labs((long)(c.t - c.q) - (long)(t - q)) > relay_tol) continue;
-                    if (best < 0 || (long)*it < best) best = (long)*it;
-                    if ((long)dirn * c.q - bucket * relay_s < relay_s / 4 && (best_near < 0 || (long)*it < best_near)) best_near = (long)*it;
+                    const long d = std::labs((long)dirn * c.q - want);
+                    if (best < 0 || d < best_d || (d == best_d && (long)*it < best)) { best = (long)*it; best_d = d; }
                 }
-                if (best_near >= 0) best = best_near;
-                if (best < 0) continue;
-                const Anchor &c = u.anchors[(size_t)best];
-                if (bucket == bucket0) return relay_at(unit, dirn, c.t, c.q);
-                // virtual relay at the start of the first bucket, on the straight line from (t, q) to the anchor
-                const long vs = std::max(bucket0 * relay_s, s_from);
-                const int32_t vq = (int32_t)(dirn * vs);
-                const long span = (long)(c.q - q) * dirn, step = (long)(vq - q) * dirn;
-                const long ddiag = (long)(c.t - c.q) - (long)(t - q);
-                const int32_t vt = (int32_t)((long)t + (long)(vq - q) + (span > 0 ? ddiag * step / span : 0));
-                const int32_t dr = (vq - b.q0) * dirn, dc = (vt - b.t0) * dirn;
-                if (step <= 0 || dr <= 0 || dc <= 0 || dc >= b.na - 64 || dr >= b.nb - (int32_t)relay_w - 64) return relay_at(unit, dirn, c.t, c.q);
-                return relay_at(unit, dirn, vt, vq);
+                return best;
+            };
+            const long near = scan(std::max(s_from, line - relay_s / 4), line + relay_s / 4, line);
+            if (near >= 0) return relay_at(unit, dirn, u.anchors[(size_t)near].t, u.anchors[(size_t)near].q);
+            // no anchor at this lattice line: bridge towards the next anchor further down, if there is one
+            const long far = scan(line + relay_s / 4, line + relay_gap * relay_s, line);
+            if (far < 0) {
+                // past the last anchor an alignment may still run on for a while (soft-masked sequence has no seeds): a few
+                // more virtual relays straight down the diagonal keep that tail from becoming one long piece
+                if (from_tail >= relay_tail) return -1;
+                const int32_t vq = (int32_t)(dirn * line), vt = (int32_t)((long)t + (long)(vq - q));
+                if ((long)(vq - q) * dirn <= 0 || !in_bounds(vt, vq)) return -1;
+                const int id = relay_at(unit, dirn, vt, vq);
+                relay_pts[(size_t)id].tail = from_tail + 1;
+                return id;
             }
-            return -1;
+            const Anchor &c = u.anchors[(size_t)far];
+            const int32_t vq = (int32_t)(dirn * line);
+            const long span = (long)(c.q - q) * dirn, step = (long)(vq - q) * dirn;
+            const long ddiag = (long)(c.t - c.q) - (long)(t - q);
+            const int32_t vt = (int32_t)((long)t + (long)(vq - q) + (span > 0 ? ddiag * step / span : 0));
+            if (step <= 0 || !in_bounds(vt, vq)) return relay_at(unit, dirn, c.t, c.q);
+            return relay_at(unit, dirn, vt, vq);
         };
         while (true) {                                   // retried with a larger arena if the trace does not fit
             sides.assign((size_t)nsides, SideRun());
@@ -883,7 +894,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 for (long n = 0; a >= 0 && n < relay_max; n++) {
                     if (relay_pts[(size_t)a].piece >= 0) return;                 // the rest of the chain exists already
                     const RelayPt c = relay_pts[(size_t)a];                      // (copy: next_relay may grow the table)
-                    int nx = next_relay(unit, base, c.t, c.q, (int32_t)(relay_s / 4));
+                    int nx = next_relay(unit, base, c.t, c.q, (int32_t)(relay_s / 2), c.tail);
                     int32_t stop = nx >= 0 ? (relay_pts[(size_t)nx].q - c.q) * base.dir + (int32_t)relay_w : 0;
                     if (nx >= 0 && n + 1 == relay_max) { nx = -1; stop = (int32_t)(relay_s + relay_w); }   // chain cut: whoever gets here plants the rest
                     const int id = add_piece(unit, base, c.t, c.q, 0, (int32_t)relay_w, stop, (int32_t)relay_w, -1, nx);
@@ -941,6 +952,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     for (size_t x = launched; x < pieces.size(); x++) {
                         const int r = outs[x].rows - (pieces[x].init_piece >= 0 ? outs[(size_t)pieces[x].init_piece].rows : 0);
                         if (r > maxrows) { maxrows = r; clk = outs[x].clocks; }
+                        if (2 * r > 3 * (relay_s + relay_w) && relay_s0 > 0 && env_long("MIBLAST_DEBUG", 0) > 1)
+                            fprintf(stderr, "[miblast]   long piece %zu: origin (%d,%d) dir %d row_lo %d stop_row %d target %d rows %d stopped %d na %d nb %d\n", x, pieces[x].ot, pieces[x].oq,
+                                    pieces[x].dir, pieces[x].row_lo, pieces[x].stop_row, pieces[x].target, r, outs[x].stopped, probs[x].na, probs[x].nb);
                     }
                     fprintf(stderr, "[miblast] round %d.%ld: %zu pieces, %zu checks, max rows %d (%lld shader clocks = %.0f per row), dp kernel total %.2f ms so far, shadow_q %ld\n",
                             round, n_subrounds, n_new, v_new, maxrows, clk, (double)clk / std::max(1, maxrows), st.t_dp_kernel_ms, shadow_q);
@@ -964,10 +978,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     else if (relay_s0 > 0) {
                         // a stop without an aim (first stop of a side, end of a capped chain): the lattice relay beyond the best cell
                         const DpOut &o = outs[(size_t)x];
-                        aim = next_relay(cp.unit, cb, cp.ot + cp.dir * o.bj, cp.oq + cp.dir * o.bi, 0);
+                        aim = next_relay(cp.unit, cb, cp.ot + cp.dir * o.bj, cp.oq + cp.dir * o.bi, 0, 0);
                         while (aim >= 0 && entry_row(aim) <= cp.stop_row + 64) {
                             const RelayPt r = relay_pts[(size_t)aim];
-                            aim = next_relay(cp.unit, cb, r.t, r.q, (int32_t)(relay_s / 4));
+                            aim = next_relay(cp.unit, cb, r.t, r.q, (int32_t)(relay_s / 2), r.tail);
                         }
                         if (aim >= 0) plant_chain(cp.unit, cb, aim);
                     }
