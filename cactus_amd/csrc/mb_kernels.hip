@@ -49,6 +49,12 @@ __device__ __forceinline__ bool window_word(const uint8_t *codes, int64_t p, uin
     return (bad & 0xFCu) == 0;
 }
 
+// Pointers read from a table in memory are generic for the compiler: it then emits FLAT loads and, because those may
+// complete out of order with LDS, waits for every outstanding memory operation around them.  The sequence pointers of
+// PairPtrs are global memory: say so.
+typedef const uint8_t __attribute__((address_space(1))) *gbytes;
+__device__ __forceinline__ gbytes as_global(const uint8_t *p) { return (gbytes)(unsigned long long)p; }
+
 // ---- wave-level helpers (DPP scans, SGPR pinning) --------------------------------------------------------
 constexpr int kNeg2 = -(1 << 30);            // below every real score: fill value for shifted-in lanes
 constexpr int kRowChunk = 4096;              // rows per row-info chunk (16 B each = one 64 KiB arena block)
@@ -599,8 +605,8 @@ struct YdShared {                            // LDS of one DP problem (LDS-ring 
 //       all waves reduce the four records identically, so no third barrier is needed.
 // C/D of the previous row live in an LDS ring of int2 indexed by column, overwritten in place.
 template <bool GLOBAL, bool PROF>
-__device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const uint8_t *__restrict__ tc,
-                                           const uint8_t *__restrict__ qc, const int O, const int E, const int Y,
+__device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const gbytes tc,
+                                           const gbytes qc, const int O, const int E, const int Y,
                                            int2 *CD, uint8_t *Tb, const int cap, YdShared *sh,
                                            uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                                            unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
@@ -844,8 +850,8 @@ __global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__
     if (pi >= n) return;
     DpProb pr = probs[pi];
     const PairPtrs pp = pairs[pr.pad0];
-    const uint8_t *tc = pp.tc;
-    const uint8_t *qc = pr.strand ? pp.qr : pp.qf;
+    const gbytes tc = as_global(pp.tc);
+    const gbytes qc = as_global(pr.strand ? pp.qr : pp.qf);
     __shared__ YdShared sh;
     if (GLOBAL_ROWS) {
         int2 *CD = (int2 *)(grows + (size_t)pi * 2 * kGlobalRowCap);
@@ -868,6 +874,318 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
     if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else if (prof) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_ydrop1: the same one-sided Y-drop DP as k_ydrop, ONE wave per piece.  Lane l owns the K adjacent columns
+// jb + K l .. jb + K l + K-1 of the window (jb = first column, a multiple of K); C and D of the previous row, the target
+// bases of its columns and everything else live in registers -- no LDS, no barriers.  With relays a launch
+// holds thousands of pieces, so what counts is instructions per row per CU: one wave x ~200 instructions instead of four
+// waves x ~290.  Per row: K cells per lane (scores of 4 bases with one v_perm), thread-local prefixes, two DPP max-scans
+// (horizontal gap X = M + rel and running best M, as in k_ydrop), y-drop test with sign-bit arithmetic, ballots for
+// {first break, first alive, last alive}, K trace bytes per lane in one store.  When the window's left edge has moved K
+// columns the lanes shift by one (wave_shl DPP moves); the target bases entering on the right come from a register
+// prefetch two window widths ahead.  Columns outside the previous row's window need no masking (their C is dead, kNeg,
+// and their D is below any threshold that can matter again: k_ydrop's note).  Windows wider than 64 K columns make the
+// piece overflow (1): the host reruns it with k_ydrop (LDS ring), then with the HBM ring.
+template <int K> struct BaseVec;
+template <> struct BaseVec<4> { using T = uint32_t; };
+template <> struct BaseVec<8> { using T = unsigned long long; };
+
+__device__ __forceinline__ int dpp_shl1(int v, int fill) {            // lane l <- lane l+1, lane 63 <- fill
+    return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false);
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_ydrop1(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
+                                               const PairPtrs *__restrict__ pairs, const int O, const int E, const int Y,
+                                               uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
+                                               unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
+                                               unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps) {
+    const int pi = blockIdx.x;
+    if (pi >= n) return;
+    using TV = typename BaseVec<K>::T;
+    constexpr int kCap = 64 * K;
+    constexpr unsigned kAll = (1u << K) - 1u;
+    const DpProb pr = probs[pi];
+    const PairPtrs pp = pairs[pr.pad0];
+    const gbytes tc = as_global(pp.tc);
+    const gbytes qc = as_global(pr.strand ? pp.qr : pp.qf);
+    DpOut *out = &outs[pi];
+    const int lane = threadIdx.x & 63;
+    const int na = pr.na, nb = pr.nb, dir = pr.dir;
+    const int64_t t0 = pr.t0, q0 = pr.q0;
+    const int row_lo = pr.row_lo;
+    const long long clk0 = clock64();
+    const int OE = O + E;
+    const int grow = (Y >= O ? (Y - O) / E : 0) + 2;          // a row can outgrow the previous window by at most this
+    int overflow = 0;
+    int R0 = 0;
+    if (Y >= O) { R0 = (Y - O) / E; if (R0 > na) R0 = na; }
+    // target bases of the K columns c0 .. c0+K-1 (byte k = column c0 + k); columns beyond the contig are never alive
+    auto load_t = [&](int c0) -> TV {
+        TV v = 0;
+        if (c0 <= na) {
+            typedef const TV __attribute__((address_space(1), aligned(1))) *gvec;
+            if (dir > 0) v = *(gvec)(tc + (t0 + c0 - 1));
+            else {
+                const TV w = *(gvec)(tc + (t0 - c0 - (K - 1)));
+                if (K == 4) v = (TV)__builtin_bswap32((uint32_t)w); else v = (TV)__builtin_bswap64((unsigned long long)w);
+            }
+        }
+        return v;
+    };
+    // ---- trace arena bookkeeping (lane 0 does the atomics) ----
+    unsigned long long blk_off = 0, chunk_off = 0;
+    unsigned blk_used = 0;
+    auto arena_take = [&](unsigned nblk) -> unsigned long long {          // returns ~0 when the arena is exhausted
+        unsigned long long o1 = 0;
+        if (lane == 0) o1 = atomicAdd(arena_next, (unsigned long long)nblk * blk_bytes);
+        o1 = uni64(o1);
+        return o1 + (unsigned long long)nblk * blk_bytes > arena_bytes ? ~0ull : o1;
+    };
+    if (R0 + 1 + 2 * K > kCap) overflow = 1;
+    if (!overflow) {
+        const unsigned long long o1 = arena_take(2);
+        if (o1 == ~0ull) overflow = 3;
+        else { blk_off = o1; chunk_off = o1 + blk_bytes; }
+    }
+    unsigned rb_lo = 0, rb_hi = 0, rb_ly = 0;                             // row records buffered 64 at a time (lane = record & 63)
+    auto flush_rows = [&](int last_rec) {
+        const int r = (last_rec & ~63) + lane;
+        if (r <= last_rec) {
+            RowInfo ri; ri.off = ((unsigned long long)rb_hi << 32) | rb_lo; ri.ly = rb_ly; ri.pad = 0;
+            ((RowInfo *)(arena + chunk_off))[r & (kRowChunk - 1)] = ri;
+        }
+    };
+    int C[K], D[K];
+    int jb = 0, LY = 0, RY = R0 + 1, best = 0, bi = 0, bj = 0, rows = 1;
+    long long cells = R0 + 1;
+    if (!overflow && row_lo == 0) {
+        // ---- row 0: C = -(O + jE) while within ydrop of 0, every cell reached by a horizontal gap from the origin
+        uint32_t tb0[K / 4];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int j = K * lane + k;
+            C[k] = j == 0 ? 0 : (j <= R0 ? -(O + j * E) : kNeg);
+            D[k] = kNeg;
+            const uint32_t b = j == 0 ? 3u : (2u | (j >= 2 ? 8u : 0u));
+            if ((k & 3) == 0) tb0[k / 4] = 0;
+            tb0[k / 4] |= b << (8 * (k & 3));
+        }
+        if (K * lane <= R0) __builtin_memcpy(arena + blk_off + K * lane, tb0, K);
+        if (lane == 0) { rb_lo = (unsigned)blk_off; rb_hi = (unsigned)(blk_off >> 32); rb_ly = 0; }
+        blk_used = (unsigned)(R0 + K) & ~(unsigned)(K - 1);
+    } else if (!overflow) {
+        // ---- continuation: the state after row row_lo comes from a snapshot (record 0 of this piece stays unused)
+        const uint8_t *sp = snaps + (size_t)pr.init_snap * kSnapBytes;
+        const SnapHdr *h = (const SnapHdr *)sp;
+        const int *sC = (const int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
+        LY = uni(h->LY); RY = uni(h->RY); best = uni(h->best); bi = uni(h->bi); bj = uni(h->bj); rows = uni(h->rows);
+        cells = (long long)uni64((unsigned long long)h->cells);
+        jb = LY & ~(K - 1);
+        if (RY - jb + 2 * K > kCap) overflow = 1;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int j = jb + K * lane + k;
+            const bool in = j >= LY && j < RY && !overflow;
+            C[k] = in ? sC[j - LY] : kNeg;
+            D[k] = in ? sD[j - LY] : kNeg;
+        }
+    }
+    if (!overflow && lane == 0) rowdir[pr.row_off] = chunk_off;
+    TV tw = load_t(jb + K * lane);                                       // bases of this lane's columns
+    TV tfa = load_t(jb + kCap + K * lane), tfb = load_t(jb + 2 * kCap + K * lane);   // the next two window widths
+    int tf_used = 0, tf_base = jb + 3 * kCap;                            // lanes of tfa consumed; first column not yet requested
+    int qblk0 = 1 + (row_lo & ~255);                                     // first row of the 256-row block held in qv (4 rows per lane)
+    auto load_q = [&](int r0) -> unsigned {
+        typedef const uint32_t __attribute__((address_space(1), aligned(1))) *gword;
+        const int r = r0 + 4 * lane;                                      // rows r .. r+3 (rows beyond nb are never evaluated)
+        if (r > nb) return 0x04040404u;
+        return dir > 0 ? *(gword)(qc + (q0 + r - 1)) : __builtin_bswap32(*(gword)(qc + (q0 - r - 3)));
+    };
+    unsigned qv = load_q(qblk0);
+    const uint32_t lutv = row_score_lut((unsigned)min(lane, 4));     // lane k holds the packed score row of query base k
+    const int laneKE = lane * K * E;
+    // everything loaded so far is waited for HERE: a load still in flight at the loop entry would put a wait for all
+    // outstanding memory operations (trace stores included) at the top of every row
+    asm volatile("" : "+v"(qv), "+v"(tw), "+v"(tfa), "+v"(tfb));
+#pragma unroll
+    for (int k = 0; k < K; k++) asm volatile("" : "+v"(C[k]), "+v"(D[k]));
+    int i = row_lo + 1;
+    int stopped = 0, exit_j = 0;
+    for (; i <= nb && !overflow; i++) {
+        const int rho = i - row_lo;
+        // No load may be in flight when the loop turns around: the compiler would otherwise wait for ALL outstanding
+        // memory operations -- including the previous row's trace store -- at the top of every row.
+        if (i - qblk0 >= 256) { qblk0 += 256; qv = load_q(qblk0); asm volatile("" : "+v"(qv)); }      // (every 256 rows: waited for on the spot)
+        const unsigned qword = (unsigned)__builtin_amdgcn_readlane((int)qv, (i - qblk0) >> 2);
+        const uint32_t lut = (uint32_t)__builtin_amdgcn_readlane((int)lutv, min((int)((qword >> (8 * ((i - qblk0) & 3))) & 7u), 4));
+        // ---- the window's left edge moved K columns or more: shift the lanes
+        while (LY - jb >= K) {
+#pragma unroll
+            for (int k = 0; k < K; k++) { C[k] = dpp_shl1(C[k], kNeg); D[k] = dpp_shl1(D[k], kNeg); }
+            const uint32_t in_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tfa, tf_used);
+            uint32_t lo = (uint32_t)dpp_shl1((int)(uint32_t)tw, (int)in_lo);
+            if (K == 8) {
+                const uint32_t in_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)tfa >> 32), tf_used);
+                const uint32_t hi = (uint32_t)dpp_shl1((int)(uint32_t)((unsigned long long)tw >> 32), (int)in_hi);
+                tw = (TV)(((unsigned long long)hi << 32) | lo);
+            } else tw = (TV)lo;
+            jb += K;
+            if (++tf_used == 64) {                                        // (every 64 K columns: waited for on the spot, see above)
+                tfa = tfb; tfb = load_t(tf_base + K * lane); tf_base += kCap; tf_used = 0;
+                asm volatile("" : "+v"(tfb));
+            }
+        }
+        // The row can reach at most column RY + grow, but it rarely does: the lanes only have to hold the old window here; a
+        // row whose break is not found within the lanes makes the piece overflow AFTER the fact (it is rerun elsewhere).
+        if (RY - jb + K > kCap) { overflow = 1; break; }
+        const int reach = min(min(na, RY + grow), jb + kCap - 1);
+        const int need = reach - jb + 1 + 2 * K;
+        const bool new_blk = blk_used + (unsigned)need > blk_bytes;
+        const bool new_chunk = (rho & (kRowChunk - 1)) == 0;
+        if ((rho & 63) == 0) flush_rows(rho - 1);
+        if (new_blk || new_chunk) {
+            const unsigned nblk = (new_blk ? 1u : 0u) + (new_chunk ? 1u : 0u);
+            unsigned long long o1 = arena_take(nblk);
+            if (o1 == ~0ull) { overflow = 3; break; }
+            if (new_blk) { blk_off = o1; blk_used = 0; o1 += blk_bytes; }
+            if (new_chunk) { chunk_off = o1; if (lane == 0) rowdir[pr.row_off + (unsigned)(rho / kRowChunk)] = chunk_off; }
+        }
+        if (lane == (rho & 63)) { const unsigned long long ro = blk_off + blk_used; rb_lo = (unsigned)ro; rb_hi = (unsigned)(ro >> 32); rb_ly = (unsigned)jb; }
+        // ---- the cells of the row
+        const int j0 = jb + K * lane;
+        const bool edge = jb + kCap - 1 > na;                             // some column lies beyond the contig: those are dead and count as breaks
+        const int kna = na - j0;
+        uint32_t sc[K / 4];
+        sc[0] = __builtin_amdgcn_perm(0x1c1c1c1cu, lut, (uint32_t)tw & 0x07070707u);
+        if (K == 8) sc[K / 4 - 1] = __builtin_amdgcn_perm(0x1c1c1c1cu, lut, (uint32_t)((unsigned long long)tw >> 32) & 0x07070707u);
+        const int cpl = dpp_shr1(C[K - 1], kNeg);                         // C of the column left of this lane's first
+        int diag[K], Dv[K], X[K], Mm[K];
+        bool dex[K];
+        int prev = cpl;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            diag[k] = prev + (int)((sc[k / 4] >> (8 * (k & 3))) & 0xFFu) - 128;
+            const int de = D[k] - E, dn = C[k] - OE;
+            Dv[k] = max(de, dn);
+            dex[k] = de >= dn;
+            const int Mv = max(diag[k], Dv[k]);
+            X[k] = Mv + laneKE + k * E;
+            Mm[k] = (!edge || k <= kna) ? Mv : kNeg;
+            prev = C[k];
+        }
+        int lp[K], mi[K];                                                 // max X over the lane's columns before k; max M up to and including k
+        lp[0] = kNeg2; mi[0] = Mm[0];
+#pragma unroll
+        for (int k = 1; k < K; k++) { lp[k] = max(lp[k - 1], X[k - 1]); mi[k] = max(mi[k - 1], Mm[k]); }
+        const int PX = dpp_scan_max(max(lp[K - 1], X[K - 1]));
+        const int PM = dpp_scan_max(mi[K - 1]);
+        const int ex = dpp_shr1(PX, kNeg2);                               // max X over every column left of this lane
+        const int emY = max(dpp_shr1(PM, kNeg2), best) - Y;               // (running best before this lane's columns) - Y
+        const int allm = uni(__builtin_amdgcn_readlane(PM, 63));
+        int pex[K], Iv[K], gm[K];
+        unsigned dm = 0;                                                  // bit k: column k is dead
+        const int ORel = O + laneKE;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            pex[k] = max(ex, lp[k]);
+            Iv[k] = pex[k] - (ORel + k * E);
+            gm[k] = max(Dv[k], Iv[k]);
+            const int Cv = max(diag[k], gm[k]);
+            int q = (Cv - max(emY, mi[k] - Y)) >> 31;                     // all ones iff below (running best incl. this cell) - Y
+            if (edge) q |= (kna - k) >> 31;
+            C[k] = (Cv & ~q) | (kNeg & q);
+            D[k] = Dv[k];
+            dm |= (unsigned)q & (1u << k);
+        }
+        const int fnext = pex[K - 1] >= X[K - 1] ? 1 : 0;                // the gap into the next lane's first column extends
+        const int fprev = dpp_shr1(fnext, 0);
+        // ---- first break, first and last alive column
+        const int hi = RY - j0;                                           // column k is right of the old window iff k >= hi
+        const unsigned am = ~dm & kAll;
+        unsigned bm = dm & (kAll << min(max(hi, 0), K));
+        if (edge) bm |= kAll << min(max(kna + 1, 0), K);
+        bm &= kAll;
+        const unsigned long long bl = __ballot(bm != 0u), al = __ballot(am != 0u);
+        const int lb = (int)__ffsll((long long)bl) - 1;
+        const unsigned vb = (unsigned)__builtin_amdgcn_readlane((int)bm, lb & 63);
+        if (!bl) { overflow = 1; break; }                               // every column up to the last lane is still alive
+        const int pbrk = K * lb + (__ffs((int)vb) - 1);                   // relative to jb
+        const int nvalid = min(pbrk + ((jb + pbrk) <= na ? 1 : 0), kCap);
+        int first_alive = -1, last_alive = -1;
+        if (al) {
+            const int lf = (int)__ffsll((long long)al) - 1, ll = 63 - (int)__clzll((long long)al);
+            const unsigned vf = (unsigned)__builtin_amdgcn_readlane((int)am, lf), vl = (unsigned)__builtin_amdgcn_readlane((int)am, ll);
+            first_alive = jb + K * lf + (__ffs((int)vf) - 1);
+            last_alive = jb + K * ll + (31 - __clz((int)vl));
+        }
+        if (allm > best) {
+            // the first cell of the row that reaches the new best
+            unsigned wm = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) wm |= ((!edge || k <= kna) && max(diag[k], gm[k]) == allm) ? (1u << k) : 0u;
+            const unsigned long long wl = __ballot(wm != 0u);
+            const int lw = (int)__ffsll((long long)wl) - 1;
+            const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)wm, lw & 63);
+            best = allm; bi = i; bj = jb + K * lw + (__ffs((int)vw) - 1);
+        }
+        // ---- trace bytes of the lane's columns, one store
+        if (K * lane < nvalid) {
+            uint32_t tb[K / 4];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const bool iex = k == 0 ? fprev != 0 : pex[k - 1] >= X[k - 1];
+                const unsigned src = diag[k] >= gm[k] ? 0u : (Dv[k] >= Iv[k] ? 1u : 2u);   // tie preference diag > D > I
+                const unsigned b = src | (dex[k] ? 4u : 0u) | (iex ? 8u : 0u);
+                if ((k & 3) == 0) tb[k / 4] = 0;
+                tb[k / 4] |= b << (8 * (k & 3));
+            }
+            __builtin_memcpy(arena + blk_off + blk_used + (unsigned)(K * lane), tb, K);
+        }
+        blk_used += (unsigned)(nvalid + K - 1) & ~(unsigned)(K - 1);
+        cells += nvalid - (LY - jb);
+        rows++;
+        if (first_alive < 0) { i++; break; }
+        LY = first_alive;
+        RY = last_alive + 1;
+        if (i == pr.snap_row || i == pr.stop_row) {
+            // state after row i
+            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : 0)) * kSnapBytes;
+            int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
+            int lmax = kNeg2, lk = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int j = j0 + k;
+                if (j >= LY && j < RY) { sC[j - LY] = C[k]; sD[j - LY] = D[k]; if (C[k] > lmax) { lmax = C[k]; lk = k; } }
+            }
+            const int wmax = uni(__builtin_amdgcn_readlane(dpp_scan_max(lmax), 63));
+            const unsigned long long ml = __ballot(lmax == wmax);
+            const int lm = (int)__ffsll((long long)ml) - 1;
+            exit_j = jb + K * lm + uni(__builtin_amdgcn_readlane(lk, lm & 63));
+            if (lane == 0) {
+                SnapHdr *h = (SnapHdr *)sp;
+                h->LY = LY; h->RY = RY; h->best = best; h->bi = bi; h->bj = bj; h->row = i; h->rows = rows; h->cells = cells;
+                h->valid = 1;
+            }
+            if (i == pr.stop_row) { stopped = 1; i++; break; }
+        }
+    }
+    if (!overflow) flush_rows(i - 1 - row_lo);
+    if (lane == 0) {
+        out->best = best; out->bi = bi; out->bj = bj; out->rows = rows;
+        out->cells = cells; out->clocks = clock64() - clk0; out->overflow = overflow; out->n_ops = 0; out->stopped = stopped; out->exit_j = exit_j;
+    }
+}
+
+void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena,
+                   unsigned long long arena_bytes, unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir,
+                   uint8_t *snaps, hipStream_t s) {
+    if (n <= 0) return;
+    dim3 g((unsigned)n), b(64);
+    if (K == 4) hipLaunchKernelGGL((k_ydrop1<4>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    else hipLaunchKernelGGL((k_ydrop1<8>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
 }
 
 // ------------------------------------------------------------------------------------------------

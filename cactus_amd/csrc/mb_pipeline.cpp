@@ -332,12 +332,20 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
     return 0;
 }
 
-static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, bool global_rows, const DpProb *probs, DpOut *outs, int n,
+// kernel of a DP launch: one wave per piece with K columns per lane in registers (K = 4 or 8), the 4-wave kernel with the
+// LDS ring (windows up to ~1400 columns), or the 4-wave kernel with the ring in HBM (any width)
+enum DpKernel { kDpWave4 = 4, kDpWave8 = 8, kDpLds = 100, kDpHbm = 101 };
+
+static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpProb *probs, DpOut *outs, int n,
                             const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes) {
     Workspace &g = *ctx.ws;
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
-    launch_ydrop(global_rows, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
-                 (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
+    if (kernel == kDpWave4 || kernel == kDpWave8)
+        launch_ydrop1(kernel, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.arena.p, (unsigned long long)g.arena.n - 64, g.arena_next.p,
+                      blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
+    else
+        launch_ydrop(kernel == kDpHbm, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
+                     (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
     MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     MB_HIP(hipEventSynchronize(ctx.ev1));
     float ms = 0;
@@ -645,6 +653,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
                relay_tail = env_long("MIBLAST_RELAY_TAIL", 3);
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
+    // DP kernel of the pieces: the typical window is (Y-O)/E columns to the right of the path and about a quarter of that to
+    // the left; windows that outgrow the lanes make the piece overflow and it is rerun with the next wider kernel
+    const long win_typ = (p.ydrop > p.gap_open ? (p.ydrop - p.gap_open) / std::max(1, p.gap_extend) : 0) * 5 / 4 + 32;
+    const long dp_kernel_env = env_long("MIBLAST_DP_KERNEL", 0);         // 4 / 8: columns per lane of the one-wave kernel, 100: 4-wave LDS kernel
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
     Workspace &g = *ctx.ws;
     hipStream_t s = ctx.stream;
@@ -777,6 +789,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
         // anyway, longer pieces waste less on warm-up overlap.
         if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 1280;
+        // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
+        // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
+        const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : (win_typ <= 224 && nsides > 96) ? kDpWave4 : kDpWave8;
         std::vector<SideRun> sides;
         std::vector<Piece> pieces;
         std::vector<DpProb> probs;
@@ -832,7 +847,6 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 long best = -1, best_d = 0;
                 for (; it != u.by_q.end() && (long)u.anchors[*it].q < q_hi; ++it) {
                     const Anchor &c = u.anchors[*it];
-                    if (u.cov[*it]) continue;                           // inside a committed alignment: not where a new one runs
                     if (!in_bounds(c.t, c.q)) continue;
                     if (std::labs((long)(c.t - c.q) - (long)(t - q)) > relay_tol) continue;
                     const long d = std::labs((long)dirn * c.q - want);
@@ -934,9 +948,28 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 MB_HIP(hipMemcpyAsync(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), hipMemcpyHostToDevice, s));
                 if (v_new) MB_HIP(hipMemcpyAsync(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), hipMemcpyHostToDevice, s));
                 MB_HIP(hipMemsetAsync(g.snaps.p + launched * 2 * kSnapBytes, 0, n_new * 2 * kSnapBytes, s));      // valid = 0
-                run_ydrop_timed(ctx, st, false, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk);
-                launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
+                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk);
+                if (debug) fprintf(stderr, "[miblast]   first pass (kernel %d): dp kernel total %.2f ms\n", dp_kernel, st.t_dp_kernel_ms);
                 MB_HIP(hipMemcpyAsync(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), hipMemcpyDeviceToHost, s));
+                MB_HIP(hipStreamSynchronize(s));
+                if (dp_kernel != kDpLds) {
+                    // pieces whose window outgrew the lanes of the one-wave kernel: once more with the LDS ring (same snapshots)
+                    std::vector<size_t> again;
+                    for (size_t x = launched; x < pieces.size(); x++) if (outs[x].overflow == 1) again.push_back(x);
+                    if (!again.empty()) {
+                        std::vector<DpProb> sub(again.size());
+                        for (size_t y = 0; y < again.size(); y++) sub[y] = probs[again[y]];
+                        g.probs.ensure_keep(pieces.size() + again.size()); g.outs.ensure_keep(pieces.size() + again.size());
+                        MB_HIP(hipMemcpyAsync(g.probs.p + pieces.size(), sub.data(), sub.size() * sizeof(DpProb), hipMemcpyHostToDevice, s));
+                        run_ydrop_timed(ctx, st, kDpLds, g.probs.p + pieces.size(), g.outs.p + pieces.size(), (int)again.size(), g.pair_ptrs.p, p, kBlk);
+                        std::vector<DpOut> so(again.size());
+                        MB_HIP(hipMemcpy(so.data(), g.outs.p + pieces.size(), so.size() * sizeof(DpOut), hipMemcpyDeviceToHost));
+                        for (size_t y = 0; y < again.size(); y++) outs[again[y]] = so[y];
+                        st.dp_reruns += (int64_t)again.size();
+                        if (debug) fprintf(stderr, "[miblast]   %zu of %zu pieces outgrew the one-wave kernel and were rerun (dp kernel total %.2f ms)\n", again.size(), n_new, st.t_dp_kernel_ms);
+                    }
+                }
+                launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
                 if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
                 MB_HIP(hipStreamSynchronize(s));
                 for (size_t x = launched; x < pieces.size(); x++) arena_full |= outs[x].overflow == 3;
@@ -1058,7 +1091,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     outs.resize(pieces.size());
                     g.grows.ensure(n_new * 2 * (size_t)kGlobalRowCap);
                     MB_HIP(hipMemcpy(g.probs.p + first, probs.data() + first, n_new * sizeof(DpProb), hipMemcpyHostToDevice));
-                    run_ydrop_timed(ctx, st, true, g.probs.p + first, g.outs.p + first, (int)n_new, g.pair_ptrs.p, p, kBlkWide);
+                    run_ydrop_timed(ctx, st, kDpHbm, g.probs.p + first, g.outs.p + first, (int)n_new, g.pair_ptrs.p, p, kBlkWide);
                     MB_HIP(hipMemcpy(outs.data() + first, g.outs.p + first, n_new * sizeof(DpOut), hipMemcpyDeviceToHost));
                     for (size_t x = first; x < pieces.size(); x++) {
                         const DpOut &o = outs[x];
@@ -1278,7 +1311,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         miblast_stats &d = j->res->stats;
         d.t_gapped = st.t_gapped; d.gapped_rounds = st.gapped_rounds; d.dp_sides_run = st.dp_sides_run; d.dp_cells_run = st.dp_cells_run;
         d.dp_rows_run = st.dp_rows_run; d.t_dp_kernel_ms = st.t_dp_kernel_ms; d.dp_kernel_launches = st.dp_kernel_launches;
-        d.relay_accepted = st.relay_accepted; d.relay_rejected = st.relay_rejected; d.t_traceback_ms = st.t_traceback_ms; d.t_merge_ms = st.t_merge_ms;
+        d.relay_accepted = st.relay_accepted; d.relay_rejected = st.relay_rejected; d.dp_reruns = st.dp_reruns; d.t_traceback_ms = st.t_traceback_ms; d.t_merge_ms = st.t_merge_ms;
     }
     return MIBLAST_OK;
 

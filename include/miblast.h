@@ -122,6 +122,7 @@ typedef struct miblast_stats {          /* counters defined by SURVEY.md section
     int64_t dp_rows_run;                    /* DP rows evaluated incl. speculative work                */
     int64_t relay_accepted, relay_rejected; /* hand-overs between concurrently evaluated pieces of long DPs */
     double  t_traceback_ms, t_merge_ms;     /* host wall time of the traceback (kernels + copies) and of the trace merge  */
+    int64_t dp_reruns;                      /* pieces rerun with a wider DP kernel (window outgrew the one-wave kernel)    */
 } miblast_stats;
 
 typedef struct miblast_result miblast_result;

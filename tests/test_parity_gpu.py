@@ -57,7 +57,11 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
     base = gpu_ctx.align(T, Q, pm)
     assert base.paf.count(b"\n") >= 3
     for env in ({"MIBLAST_GAPPED_BATCH_MAX": "1"}, {"MIBLAST_SHADOW_Q": "0", "MIBLAST_SHADOW_D": "0"},
-                {"MIBLAST_SHADOW_Q": "100000000"}, {"MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_ARENA_MB": "1"}):
+                {"MIBLAST_SHADOW_Q": "100000000"}, {"MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_ARENA_MB": "1"},
+                # DP kernel: one wave per piece with 4 / 8 columns per lane (windows that outgrow the lanes are rerun with the
+                # 4-wave LDS-ring kernel), or the 4-wave kernel from the start
+                {"MIBLAST_DP_KERNEL": "4"}, {"MIBLAST_DP_KERNEL": "8"}, {"MIBLAST_DP_KERNEL": "100"},
+                {"MIBLAST_DP_KERNEL": "4", "MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "3"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         again = gpu_ctx.align(T, Q, pm)
