@@ -674,12 +674,17 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
     }
     if (!overflow && tid == 0) rowdir[pr.row_off] = chunk_off;
     int t_hi = max(LY - 1, 0);                                          // highest target column staged in Tb
-    int qblk0 = 1 + (row_lo & ~63);                                     // first row of the block held in qv
+    int qblk0 = 1 + (row_lo & ~255);                                    // first row of the 256-row block held in qv (4 rows per lane of a wave)
     auto load_q = [&](int r0) -> unsigned {
-        const int r = r0 + lane;
-        return (r >= 1 && r <= nb) ? (unsigned)qc[dir > 0 ? q0 + r - 1 : q0 - r] : 4u;
+        typedef const uint32_t __attribute__((address_space(1), aligned(1))) *gword;
+        const int r = r0 + 4 * lane;                                      // rows r .. r+3 (rows beyond nb are never evaluated)
+        if (r > nb) return 0x04040404u;
+        return dir > 0 ? *(gword)(qc + (q0 + r - 1)) : __builtin_bswap32(*(gword)(qc + (q0 - r - 3)));
     };
-    unsigned qv = load_q(qblk0), qnext = load_q(qblk0 + 64);
+    unsigned qv = load_q(qblk0);
+    // No load may be in flight when the row loop starts or turns around: the compiler would otherwise wait for ALL
+    // outstanding memory operations -- including the previous row's trace stores -- at the top of every row.
+    asm volatile("" : "+v"(qv));
     const uint32_t lutv = row_score_lut((unsigned)min(lane, 4));     // lane k holds the packed score row of query base k
     const int tidE = tid * E;
     __syncthreads();
@@ -688,8 +693,9 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
     for (; i <= nb && !overflow; i++) {
         if (PROF) pt = clock64();
         const int rho = i - row_lo;
-        if (i - qblk0 >= 64) { qblk0 += 64; qv = qnext; qnext = load_q(qblk0 + 64); }
-        const uint32_t lut = (uint32_t)__builtin_amdgcn_readlane((int)lutv, min(__builtin_amdgcn_readlane((int)qv, i - qblk0) & 7, 4));
+        if (i - qblk0 >= 256) { qblk0 += 256; qv = load_q(qblk0); asm volatile("" : "+v"(qv)); }      // (every 256 rows: waited for on the spot)
+        const unsigned qword = (unsigned)__builtin_amdgcn_readlane((int)qv, (i - qblk0) >> 2);
+        const uint32_t lut = (uint32_t)__builtin_amdgcn_readlane((int)lutv, min((int)((qword >> (8 * ((i - qblk0) & 3))) & 7u), 4));
         // the row can reach at most column RY + grow; everything it may touch must be staged and fit the ring
         const int reach = min(na, RY + grow);
         if (reach - LY + 2 * kYdThreads + 64 > cap) { overflow = 1; break; }
