@@ -142,12 +142,14 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
         if os.path.exists(pmc_path) and not a.random_pair and a.size == 1_000_000 and a.lastz_args == DEFAULT_ARGS:
             ks = json.load(open(pmc_path))["kernels"]
-            k = next((v for name, v in ks.items() if "k_ydrop<false, false>" in name), None)
-            if k:
-                pmc_bytes = k["fetch_bytes_corrected_per_call"] + k["write_size_bytes_per_call"]
+            dp = [v for name, v in ks.items() if "k_ydrop" in name]         # every DP kernel variant (one wave / four waves per piece)
+            calls = sum(v["calls"] for v in dp)
+            if calls:
+                pmc_bytes = sum(v["calls"] * (v["fetch_bytes_corrected_per_call"] + v["write_size_bytes_per_call"]) for v in dp) / calls
                 traffic = pmc_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None
-                traffic_note = ("PMC bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, "
-                                "profiles/r01_hbm_traffic_pmc.json: %.1f MB) / this run's launch duration" % (pmc_bytes / 1e6))
+                traffic_note = ("PMC bytes per DP launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, "
+                                "profiles/r01_hbm_traffic_pmc.json: %.1f MB averaged over the %d launches profiled) / this run's average launch duration"
+                                % (pmc_bytes / 1e6, calls))
         out = {
             "metric": "gapped X-drop Gcell/s (blast phase, whole job)",
             "value": tot["dp_cells"] / elapsed / 1e9,
@@ -173,11 +175,11 @@ def main():
                       "handovers_rejected_per_step": tot["relay_rejected"] / a.steps / world,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / a.steps / world, "merge_ms_per_step": tot["t_merge_ms"] / a.steps / world,
                       "note": "long one-sided DPs run as concurrently evaluated pieces with verified hand-overs (DESIGN.md section 5)"},
-            "roofline": {"bound": "hbm", "kernel": "k_ydrop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_ydrop1 (one-sided Y-drop DP, all launches of a step; k_ydrop for over-wide windows)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": dp_ms, "launches_per_step": launches / a.steps / world,
                          "traffic_note": traffic_note,
-                         "note": "a DP row is a latency-bound exchange between 4 waves (~2300 clocks per row); the roofline fraction rises with the number of pieces in flight (SURVEY 8d caveat, DESIGN.md section 5)"},
+                         "note": "a launch lasts as long as its longest piece (rows x ~2900 clocks per row for a lone wave); the roofline fraction rises with the number of pieces in flight (SURVEY 8d caveat, DESIGN.md section 5)"},
         }
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, pm, ctx)
