@@ -104,6 +104,7 @@ struct Anchor { int32_t t, q, score; };
 
 struct Cached {                // result of one anchor's two one-sided DPs
     bool accepted = false;
+    bool traced = false;       // ops / dmin / dmax are valid (an accepted result is traced unless an earlier one of its unit covers it)
     int32_t score = 0, t_lo = 0, t_hi = 0, q_lo = 0, q_hi = 0, dmin = 0, dmax = 0;
     int64_t cells = 0, rows = 0;
     std::vector<uint32_t> ops;           // merged run-length ops, forward order
@@ -681,6 +682,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 auto it = u.cache.find(u.next);
                 if (it == u.cache.end()) break;
                 Cached &c = it->second;
+                if (c.accepted && !c.traced) { u.cache.erase(it); break; }    // predicted covered, but is not: evaluate it again
                 PS(u).dp_sides += 2; PS(u).dp_cells += c.cells; PS(u).dp_rows += c.rows;
                 if (c.accepted) {
                     miblast_aln A;
@@ -1117,11 +1119,12 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (debug) fprintf(stderr, "[miblast] round %d: %d sides in %zu pieces, %ld launches, hand-overs %ld accepted / %ld rejected\n",
                            round, nsides, pieces.size(), n_subrounds, n_verify_ok, n_verify_bad);
 
-        // ---- traceback of every anchor reaching --gappedthresh ------------------------------------------
-        std::vector<size_t> acc;                        // indices into pend
-        std::vector<TbSide> tbs;
-        std::vector<TbWalk> tbw;
-        uint64_t ooff = 0, roff = 0, soff = 0;          // run slots, row records (3 x u32 each), segments
+        // ---- results of the round; traceback of the anchors reaching --gappedthresh -----------------------------
+        // Speculation produces duplicates: anchors whose DP found an alignment that an earlier anchor of the unit will have
+        // committed by the time their turn comes (they are then skipped as covered).  Tracing and merging those is wasted, so
+        // the traceback runs in two phases: first the results that lie in no earlier accepted box of their unit (nothing can
+        // cover them: they will be committed), then -- their diagonal bands now known -- the rest minus what they cover.
+        std::vector<Cached *> cres(pend.size(), nullptr);
         for (size_t k = 0; k < pend.size(); k++) {
             Unit &u = units[pend[k].unit];
             Cached c;
@@ -1131,9 +1134,15 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             c.cells = R.acc_cells + L.acc_cells; c.rows = R.acc_rows + L.acc_rows;
             c.t_lo = a.t - L.gbj; c.t_hi = a.t + R.gbj; c.q_lo = a.q - L.gbi; c.q_hi = a.q + R.gbi;
             c.accepted = c.score >= p.gappedthresh;
-            c.dmin = 0x7fffffff; c.dmax = -0x7fffffff - 1;          // set by the merge below; until then covers nothing
-            if (c.accepted) {
-                acc.push_back(k);
+            c.traced = false;
+            c.dmin = 0x7fffffff; c.dmax = -0x7fffffff - 1;          // set by the merge; until then covers nothing
+            cres[k] = &u.cache.emplace(pend[k].anchor, std::move(c)).first->second;      // (references into an unordered_map stay valid)
+        }
+        auto trace = [&](const std::vector<size_t> &acc) -> int {
+        std::vector<TbSide> tbs;
+        std::vector<TbWalk> tbw;
+        uint64_t ooff = 0, roff = 0, soff = 0;          // run slots, row records (3 x u32 each), segments
+        for (size_t k : acc) {
                 for (int side = 0; side < 2; side++) {
                     const SideRun &sd = sides[2 * k + (size_t)side];
                     TbSide ts;
@@ -1166,9 +1175,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     ts.seg_off = soff; soff += 2 * (uint64_t)ts.n_walks + 1;
                     tbs.push_back(ts);
                 }
-            }
-            u.cache.emplace(pend[k].anchor, std::move(c));
-        }
+                    }
         const double t_tb0 = now_s();
         std::vector<unsigned long long> coff;           // first packed run of every side (+ total)
         if (!acc.empty()) {
@@ -1276,8 +1283,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             });
             const double t_mg2 = now_s();
             if (debug) fprintf(stderr, "[miblast]   merge: prefix %.2f ms, %zu tasks %.2f ms (hw threads %u)\n", (t_mg1 - t_mg0) * 1e3, tasks.size(), (t_mg2 - t_mg1) * 1e3, std::thread::hardware_concurrency());
-            int bad = 0;
-            for (size_t x = 0; x < acc.size(); x++) {
+            std::atomic<int> bad{0};
+            parallel_for(acc.size(), [&](size_t x) {
                 Cached &c = *cptr[x];
                 size_t total = 0;
                 for (size_t ti = task_range[x].first; ti < task_range[x].second; ti++) total += tasks[ti].ops.size();
@@ -1300,10 +1307,52 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                                 L.gbest, L.gbi, L.gbj, L.chain.size());
                     }
                 }
-            }
-            if (bad) { set_error("internal: traceback does not span the alignment box"); return MIBLAST_EHIP; }
+            });
+            if (bad) { set_error("internal: traceback does not span the alignment box"); return (int)MIBLAST_EHIP; }
+            for (Cached *c : cptr) c->traced = true;
             st.t_merge_ms += (now_s() - t_mg0) * 1e3;
             if (debug) fprintf(stderr, "[miblast]   host merge: %.2f ms\n", (now_s() - t_mg0) * 1e3);
+        }
+        return (int)MIBLAST_OK;
+        };
+        {
+            // commit order inside a unit = anchor index; group this round's accepted results by unit
+            std::unordered_map<size_t, std::vector<size_t>> by_unit;
+            for (size_t k = 0; k < pend.size(); k++) if (cres[k]->accepted) by_unit[pend[k].unit].push_back(k);
+            std::vector<size_t> first, later;
+            struct Box { size_t anchor; const Cached *c; };
+            std::unordered_map<size_t, std::vector<Box>> boxes;     // per unit: accepted results, old (traced in earlier rounds) and new
+            for (auto &kv : by_unit) {
+                Unit &u = units[kv.first];
+                std::vector<size_t> &ks = kv.second;
+                std::sort(ks.begin(), ks.end(), [&](size_t x, size_t y) { return pend[x].anchor < pend[y].anchor; });
+                std::vector<Box> &bx = boxes[kv.first];
+                for (const auto &e : u.cache) if (e.second.accepted) bx.push_back(Box{e.first, &e.second});
+                for (size_t k : ks) {
+                    const Anchor &a = u.anchors[pend[k].anchor];
+                    bool inside = false;
+                    for (const Box &b : bx)
+                        if (b.anchor < pend[k].anchor && a.t >= b.c->t_lo && a.t < b.c->t_hi && a.q >= b.c->q_lo && a.q < b.c->q_hi) { inside = true; break; }
+                    (inside ? later : first).push_back(k);
+                }
+            }
+            std::sort(first.begin(), first.end());
+            int rc = trace(first);
+            if (rc != MIBLAST_OK) return rc;
+            std::vector<size_t> second;
+            for (size_t k : later) {
+                const Unit &u = units[pend[k].unit];
+                const Anchor &a = u.anchors[pend[k].anchor];
+                const int32_t d = a.t - a.q;
+                bool covered = false;
+                for (const Box &b : boxes[pend[k].unit])
+                    if (b.c->traced && b.anchor < pend[k].anchor && a.t >= b.c->t_lo && a.t < b.c->t_hi && a.q >= b.c->q_lo && a.q < b.c->q_hi &&
+                        d >= b.c->dmin && d <= b.c->dmax) { covered = true; break; }
+                if (!covered) second.push_back(k);
+            }
+            std::sort(second.begin(), second.end());
+            rc = trace(second);
+            if (rc != MIBLAST_OK) return rc;
         }
     }
     st.t_gapped = now_s() - t_g0;
