@@ -73,6 +73,16 @@ __device__ __forceinline__ int dpp_scan_max(int v) {                  // inclusi
     return v;
 }
 
+__device__ __forceinline__ int dpp_scan_add(int v) {                   // inclusive prefix sum over the wave
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }          // pin a wave-uniform value to an SGPR
 
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
@@ -282,6 +292,55 @@ void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qto
                        offsets, positions, transitions ? 1 + kSeedWeight : 1, hit_off, keys);
 }
 
+// seed search in one pass: count, reserve and fill.  Every block counts the hits of its 256 query positions (the bucket
+// bounds of the 13 word variants stay in registers), takes its share of the key buffer with ONE atomicAdd and writes the
+// keys.  The key order in the buffer depends on the order the blocks get there, but a (diagonal, q_end) key occurs at
+// most once and the keys are radix-sorted next, so the result does not.  total[0] receives the number of hits even when
+// they did not fit (cap): the host then falls back to the two-pass path (k_seed_count, scan, k_seed_fill).
+__global__ __launch_bounds__(256) void k_seed_search(const uint8_t *__restrict__ qcodes, int64_t qn, int64_t qtot,
+                                                     const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ positions, int nvar,
+                                                     unsigned long long *__restrict__ keys, unsigned long long cap,
+                                                     unsigned long long *__restrict__ total) {
+    __shared__ unsigned wave_sum[4];
+    __shared__ unsigned long long block_base;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t b0[1 + kSeedWeight], b1[1 + kSeedWeight];
+    unsigned cnt = 0;
+    uint32_t w;
+    const bool valid = q < qn && q + kSeedSpan <= qn && window_word(qcodes, q, w);
+#pragma unroll
+    for (int v = 0; v < 1 + kSeedWeight; v++) {
+        b0[v] = b1[v] = 0;
+        if (valid && v < nvar) { const uint32_t wvv = variant_word(w, v); b0[v] = offsets[wvv]; b1[v] = offsets[wvv + 1]; cnt += b1[v] - b0[v]; }
+    }
+    const unsigned incl = (unsigned)dpp_scan_add((int)cnt);
+    if (lane == 63) wave_sum[wv] = incl;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const unsigned ws = wave_sum[k]; all += ws; if (k < wv) before += ws; }
+    if (threadIdx.x == 0) block_base = all ? atomicAdd(total, (unsigned long long)all) : 0ull;
+    __syncthreads();
+    unsigned long long o = block_base + before + (incl - cnt);
+    if (block_base + all > cap) return;                                  // does not fit: the host reruns the strand in two passes
+    const unsigned long long q_end = (unsigned long long)(q + kSeedSpan);
+#pragma unroll
+    for (int v = 0; v < 1 + kSeedWeight; v++)
+        for (uint32_t k = b0[v]; k < b1[v]; k++) {
+            // diagonal d = t_end - q_end = p - q ; stored biased by qtot so it is non-negative
+            const unsigned long long dq = (unsigned long long)((int64_t)positions[k] - q + qtot);
+            keys[o++] = (dq << 32) | q_end;
+        }
+}
+
+void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *positions, int transitions,
+                        unsigned long long *keys, unsigned long long cap, unsigned long long *total, hipStream_t s) {
+    if (qtot <= 0) return;
+    hipLaunchKernelGGL(k_seed_search, dim3((unsigned)((qtot + 255) / 256)), dim3(256), 0, s, qcodes, qtot, qtot, offsets, positions,
+                       transitions ? 1 + kSeedWeight : 1, keys, cap, total);
+}
+
 size_t sort_keys_temp_bytes(int64_t n, int end_bit) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0,
@@ -425,15 +484,6 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
 }
 
 // ---- wave-per-run variant for busy diagonals --------------------------------------------------------------------
-__device__ __forceinline__ int dpp_scan_add(int v) {                   // inclusive prefix sum over the wave
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
-    return v;
-}
 
 // One x-drop direction evaluated by a whole wave, 64 columns per step: running score = prefix sum, "best so far" =
 // exclusive prefix max, the first lane where run < best - xdrop ends the extension (ballot).  Bit-identical to the

@@ -503,6 +503,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
 
     // ---- seed search + ungapped extension, per strand ----------------------------------------------
     const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
+    const bool one_pass = env_long("MIBLAST_SEED_ONE_PASS", 1) != 0;
     const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
     DevBuf<int32_t> &extent = w.extent;
     extent.ensure((size_t)(ttot + qtot + 2));
@@ -523,32 +524,18 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
         const double t0 = now_s();
         MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
-        launch_seed_count(qc_d[strand], qtot, w.offsets.p, p.transitions, qcnt.p, s);
-        launch_block_sums(qcnt.p, qtot, qbsum.p, s);
-        MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
-        MB_HIP(hipStreamSynchronize(s));
         std::vector<DevHsp> found;
-        int64_t b0 = 0;
-        while (b0 < n_qblk) {
-            // greedy batch of whole 2048-position blocks with at most hit_cap hits
-            int64_t b1 = b0;
-            unsigned long long nh = 0;
-            while (b1 < n_qblk && (b1 == b0 || nh + h_qbsum[(size_t)b1] <= (unsigned long long)hit_cap)) nh += h_qbsum[(size_t)b1++];
-            const int64_t q0 = b0 * 2048, q1 = std::min(qtot, b1 * 2048);
-            b0 = b1;
-            if (nh == 0) continue;
-            if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one 2048-base query block (unmasked repeat?)"); return MIBLAST_ELIMIT; }
+        int rc_batch = MIBLAST_OK;
+        // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
+        auto extend_batch = [&](unsigned long long nh, bool timed_fill) -> int {
+            if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one batch (unmasked repeat?)"); return MIBLAST_ELIMIT; }
             st.seed_hits += (int64_t)nh;
             st.seed_batches++;
-            hit_off.ensure((size_t)(q1 - q0));
-            keys_a.ensure((size_t)nh); keys_b.ensure((size_t)nh);
+            keys_b.ensure((size_t)nh);
             d_hsps.ensure((size_t)nh);
             w.heads.ensure((size_t)nh + (size_t)nh / 4 + 8); w.n_heads.ensure(2);
             size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
             sort_temp.ensure(tb + 16);
-            MB_HIP(hipEventRecord(ctx.ev0, s));
-            launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
-            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
             MB_HIP(hipEventRecord(ctx.ev1, s));
             sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, sort_bits, s);
             MB_HIP(hipEventRecord(ctx.ev2, s));
@@ -561,7 +548,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipMemcpyAsync(&hc, d_ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
             float ms;
-            MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1)); st.t_seedfill_ms += ms;
+            if (timed_fill) { MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1)); st.t_seedfill_ms += ms; }
             MB_HIP(hipEventElapsedTime(&ms, ctx.ev1, ctx.ev2)); st.t_sort_ms += ms;
             MB_HIP(hipEventElapsedTime(&ms, ctx.ev3, ctx.ev4)); st.t_ungapped_kernel_ms += ms; st.ungapped_kernel_launches++;
             st.hits_extended += (int64_t)hc.extended;
@@ -570,6 +557,47 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             size_t base = found.size();
             found.resize(base + (size_t)hc.hsps);
             if (hc.hsps) MB_HIP(hipMemcpy(found.data() + base, d_hsps.p, (size_t)hc.hsps * sizeof(DevHsp), hipMemcpyDeviceToHost));
+            return MIBLAST_OK;
+        };
+        // One pass (count, reserve with one atomic per block, fill) when the key buffer of an earlier call is likely to hold
+        // all hits of the strand; otherwise, or if they did not fit, the two-pass path below with exact sizes and q-batches.
+        bool one_pass_done = false;
+        const unsigned long long cap1 = std::min<unsigned long long>((unsigned long long)keys_a.n, (unsigned long long)hit_cap);
+        if (one_pass && cap1 > 0) {
+            qbsum.ensure(2);
+            MB_HIP(hipMemsetAsync(qbsum.p, 0, 8, s));
+            MB_HIP(hipEventRecord(ctx.ev0, s));
+            launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
+            unsigned long long total = 0;
+            MB_HIP(hipMemcpyAsync(&total, qbsum.p, 8, hipMemcpyDeviceToHost, s));
+            MB_HIP(hipStreamSynchronize(s));
+            if (total <= cap1) {
+                one_pass_done = true;
+                if (total) { rc_batch = extend_batch(total, true); if (rc_batch != MIBLAST_OK) return rc_batch; }
+            }
+        }
+        if (!one_pass_done) {
+        launch_seed_count(qc_d[strand], qtot, w.offsets.p, p.transitions, qcnt.p, s);
+        launch_block_sums(qcnt.p, qtot, qbsum.p, s);
+        MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));
+        int64_t b0 = 0;
+        while (b0 < n_qblk) {
+            // greedy batch of whole 2048-position blocks with at most hit_cap hits
+            int64_t b1 = b0;
+            unsigned long long nh = 0;
+            while (b1 < n_qblk && (b1 == b0 || nh + h_qbsum[(size_t)b1] <= (unsigned long long)hit_cap)) nh += h_qbsum[(size_t)b1++];
+            const int64_t q0 = b0 * 2048, q1 = std::min(qtot, b1 * 2048);
+            b0 = b1;
+            if (nh == 0) continue;
+            hit_off.ensure((size_t)(q1 - q0));
+            keys_a.ensure((size_t)nh);
+            MB_HIP(hipEventRecord(ctx.ev0, s));
+            launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
+            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
+            rc_batch = extend_batch(nh, true);
+            if (rc_batch != MIBLAST_OK) return rc_batch;
+        }
         }
         job.found[strand].swap(found);
         st.t_seed += now_s() - t0;
