@@ -676,7 +676,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     // relay hand-over (see the DP section below): first stop, relay spacing, warm-up rows, diagonal tolerance, relays per side
-    const long relay_s0 = env_long("MIBLAST_RELAY_S0", 256), relay_s_env = env_long("MIBLAST_RELAY_S", 0);
+    const long relay_s0_env = env_long("MIBLAST_RELAY_S0", -1), relay_s_env = env_long("MIBLAST_RELAY_S", 0);
+    long relay_s0 = relay_s0_env >= 0 ? relay_s0_env : 256;
     long relay_s = std::max(256l, relay_s_env > 0 ? relay_s_env : 1280l);
     const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 192)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
     const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
@@ -819,6 +820,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
         // anyway, longer pieces waste less on warm-up overlap.
         if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 1280;
+        if (relay_s0_env < 0) relay_s0 = nsides > 96 ? 256 : 128;
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
         const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : (win_typ <= 224 && nsides > 96) ? kDpWave4 : kDpWave8;
