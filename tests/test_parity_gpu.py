@@ -94,7 +94,9 @@ def test_relay_handover_matches_oracle(gpu_ctx, olz, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for n, seed, sub, indel, args in ((60000, 33, 0.15, 0.01, DEFAULT), (90000, 77, 0.05, 0.02, ["--ydrop=4000", "--hspthresh=2200", "--gappedthresh=2400"]),
-                                      (30000, 5, 0.25, 0.03, DEFAULT)):
+                                      (30000, 5, 0.25, 0.03, DEFAULT),
+                                      # lastz's own y-drop (9400): windows of ~400 columns, 8 columns per lane, the widest rows rerun with the LDS ring
+                                      (50000, 91, 0.10, 0.02, ["--ambiguous=iupac,100,100", "--hspthresh=2200"])):
         t, q = gen.make_pair(n, seed, sub_rate=sub, indel_rate=indel)
         tf, qf = gen.fasta_bytes([("T|c0", t)]), gen.fasta_bytes([("Q|c0", q)])
         pm = _params(args)
