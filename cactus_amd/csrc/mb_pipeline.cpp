@@ -679,9 +679,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long relay_s0_env = env_long("MIBLAST_RELAY_S0", -1), relay_s_env = env_long("MIBLAST_RELAY_S", 0);
     long relay_s0 = relay_s0_env >= 0 ? relay_s0_env : 256;
     long relay_s = std::max(256l, relay_s_env > 0 ? relay_s_env : 1280l);
-    const long relay_w = std::max(64l, env_long("MIBLAST_RELAY_W", 192)), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
+    const long relay_w_env = env_long("MIBLAST_RELAY_W", 0), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
+    long relay_w = std::max(64l, relay_w_env > 0 ? relay_w_env : 192l);
     const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
-               relay_tail = env_long("MIBLAST_RELAY_TAIL", 3);
+               relay_tail_rows = env_long("MIBLAST_RELAY_TAIL_ROWS", 4096);     // how far past the last anchor virtual relays are planted
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
     // DP kernel of the pieces: the typical window is (Y-O)/E columns to the right of the path and about a quarter of that to
     // the left; windows that outgrow the lanes make the piece overflow and it is rerun with the next wider kernel
@@ -819,8 +820,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         const int nsides = (int)pend.size() * 2;
         // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
         // anyway, longer pieces waste less on warm-up overlap.
-        if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 1280;
-        if (relay_s0_env < 0) relay_s0 = nsides > 96 ? 256 : 128;
+        if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 640;
+        if (relay_s0_env < 0) relay_s0 = nsides > 96 ? 256 : 64;
+        if (relay_w_env <= 0) relay_w = nsides > 96 ? 192 : 128;
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
         const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : (win_typ <= 224 && nsides > 96) ? kDpWave4 : kDpWave8;
@@ -893,7 +895,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             if (far < 0) {
                 // past the last anchor an alignment may still run on for a while (soft-masked sequence has no seeds): a few
                 // more virtual relays straight down the diagonal keep that tail from becoming one long piece
-                if (from_tail >= relay_tail) return -1;
+                if ((long)(from_tail + 1) * relay_s > relay_tail_rows) return -1;
                 const int32_t vq = (int32_t)(dirn * line), vt = (int32_t)((long)t + (long)(vq - q));
                 if ((long)(vq - q) * dirn <= 0 || !in_bounds(vt, vq)) return -1;
                 const int id = relay_at(unit, dirn, vt, vq);
