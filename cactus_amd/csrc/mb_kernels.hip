@@ -292,13 +292,30 @@ void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qto
                        offsets, positions, transitions ? 1 + kSeedWeight : 1, hit_off, keys);
 }
 
+// occupancy bitmap of the seed table: bit b of word w = bucket 32 w + b holds at least one position.  2 MiB for the 2^24
+// buckets, so it stays in L2 while the 64 MiB offset table does not: k_seed_search asks it first and only touches the
+// offset table for occupied buckets (a 1 Mb target occupies ~6 % of the buckets).
+__global__ void k_bucket_bitmap(const uint32_t *__restrict__ offsets, uint32_t *__restrict__ occ) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;            // one bucket per thread, one word per 32 lanes
+    if (b >= kBuckets) return;
+    const unsigned long long m = __ballot(offsets[b + 1] != offsets[b]);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) occ[b >> 5] = (uint32_t)m;
+    else if (lane == 32) occ[b >> 5] = (uint32_t)(m >> 32);
+}
+
+void launch_bucket_bitmap(const uint32_t *offsets, uint32_t *occ, hipStream_t s) {
+    hipLaunchKernelGGL(k_bucket_bitmap, dim3(kBuckets / 256), dim3(256), 0, s, offsets, occ);
+}
+
 // seed search in one pass: count, reserve and fill.  Every block counts the hits of its 256 query positions (the bucket
 // bounds of the 13 word variants stay in registers), takes its share of the key buffer with ONE atomicAdd and writes the
 // keys.  The key order in the buffer depends on the order the blocks get there, but a (diagonal, q_end) key occurs at
 // most once and the keys are radix-sorted next, so the result does not.  total[0] receives the number of hits even when
 // they did not fit (cap): the host then falls back to the two-pass path (k_seed_count, scan, k_seed_fill).
 __global__ __launch_bounds__(256) void k_seed_search(const uint8_t *__restrict__ qcodes, int64_t qn, int64_t qtot,
-                                                     const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ positions, int nvar,
+                                                     const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ occ,
+                                                     const uint32_t *__restrict__ positions, int nvar,
                                                      unsigned long long *__restrict__ keys, unsigned long long cap,
                                                      unsigned long long *__restrict__ total) {
     __shared__ unsigned wave_sum[4];
@@ -312,7 +329,10 @@ __global__ __launch_bounds__(256) void k_seed_search(const uint8_t *__restrict__
 #pragma unroll
     for (int v = 0; v < 1 + kSeedWeight; v++) {
         b0[v] = b1[v] = 0;
-        if (valid && v < nvar) { const uint32_t wvv = variant_word(w, v); b0[v] = offsets[wvv]; b1[v] = offsets[wvv + 1]; cnt += b1[v] - b0[v]; }
+        if (valid && v < nvar) {
+            const uint32_t wvv = variant_word(w, v);
+            if ((occ[wvv >> 5] >> (wvv & 31u)) & 1u) { b0[v] = offsets[wvv]; b1[v] = offsets[wvv + 1]; cnt += b1[v] - b0[v]; }
+        }
     }
     const unsigned incl = (unsigned)dpp_scan_add((int)cnt);
     if (lane == 63) wave_sum[wv] = incl;
@@ -334,10 +354,10 @@ __global__ __launch_bounds__(256) void k_seed_search(const uint8_t *__restrict__
         }
 }
 
-void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *positions, int transitions,
+void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *occ, const uint32_t *positions, int transitions,
                         unsigned long long *keys, unsigned long long cap, unsigned long long *total, hipStream_t s) {
     if (qtot <= 0) return;
-    hipLaunchKernelGGL(k_seed_search, dim3((unsigned)((qtot + 255) / 256)), dim3(256), 0, s, qcodes, qtot, qtot, offsets, positions,
+    hipLaunchKernelGGL(k_seed_search, dim3((unsigned)((qtot + 255) / 256)), dim3(256), 0, s, qcodes, qtot, qtot, offsets, occ, positions,
                        transitions ? 1 + kSeedWeight : 1, keys, cap, total);
 }
 

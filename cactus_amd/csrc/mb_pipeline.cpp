@@ -262,7 +262,7 @@ void release_seqset(SeqSet &s) {
 // --------------------------------------------------------------------------------------------------
 struct Workspace {                      // device buffers that persist across miblast_align() calls of one context
     // seed position table
-    DevBuf<uint32_t> words, counts, offsets, positions;
+    DevBuf<uint32_t> words, counts, offsets, positions, occ;
     DevBuf<unsigned long long> bsum;
     // seed search / ungapped
     DevBuf<uint8_t> rc;
@@ -313,6 +313,8 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     launch_scan_u32(w.counts.p, w.offsets.p, (int64_t)kBuckets + 1, w.bsum.p, s);
     MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
     launch_index_scatter(w.words.p, n_slots, step, w.offsets.p, w.counts.p, w.positions.p, s);
+    w.occ.ensure((size_t)kBuckets / 32);
+    launch_bucket_bitmap(w.offsets.p, w.occ.p, s);
     MB_HIP(hipMemcpyAsync(&ix.n_positions, w.offsets.p + kBuckets, 4, hipMemcpyDeviceToHost, s));
     MB_HIP(hipStreamSynchronize(s));
 }
@@ -567,7 +569,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             qbsum.ensure(2);
             MB_HIP(hipMemsetAsync(qbsum.p, 0, 8, s));
             MB_HIP(hipEventRecord(ctx.ev0, s));
-            launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
+            launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
             unsigned long long total = 0;
             MB_HIP(hipMemcpyAsync(&total, qbsum.p, 8, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
