@@ -337,13 +337,13 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
 
 // kernel of a DP launch: one wave per piece with K columns per lane in registers (K = 4 or 8), the 4-wave kernel with the
 // LDS ring (windows up to ~1400 columns), or the 4-wave kernel with the ring in HBM (any width)
-enum DpKernel { kDpWave4 = 4, kDpWave8 = 8, kDpLds = 100, kDpHbm = 101 };
+enum DpKernel { kDpWave2x4 = 2, kDpWave4 = 4, kDpWave8 = 8, kDpLds = 100, kDpHbm = 101 };
 
 static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpProb *probs, DpOut *outs, int n,
                             const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes) {
     Workspace &g = *ctx.ws;
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
-    if (kernel == kDpWave4 || kernel == kDpWave8)
+    if (kernel == kDpWave2x4 || kernel == kDpWave4 || kernel == kDpWave8)
         launch_ydrop1(kernel, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.arena.p, (unsigned long long)g.arena.n - 64, g.arena_next.p,
                       blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
     else
@@ -827,7 +827,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (relay_w_env <= 0) relay_w = nsides > 96 ? 192 : 128;
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
-        const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : (win_typ <= 224 && nsides > 96) ? kDpWave4 : kDpWave8;
+        const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : win_typ <= 224 ? kDpWave2x4 : kDpWave8;
         std::vector<SideRun> sides;
         std::vector<Piece> pieces;
         std::vector<DpProb> probs;

@@ -58,9 +58,9 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
     assert base.paf.count(b"\n") >= 3
     for env in ({"MIBLAST_GAPPED_BATCH_MAX": "1"}, {"MIBLAST_SHADOW_Q": "0", "MIBLAST_SHADOW_D": "0"},
                 {"MIBLAST_SHADOW_Q": "100000000"}, {"MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_ARENA_MB": "1"},
-                # DP kernel: one wave per piece with 4 / 8 columns per lane (windows that outgrow the lanes are rerun with the
-                # 4-wave LDS-ring kernel), or the 4-wave kernel from the start
-                {"MIBLAST_DP_KERNEL": "4"}, {"MIBLAST_DP_KERNEL": "8"}, {"MIBLAST_DP_KERNEL": "100"},
+                # DP kernel: one wave per piece with 2 x 4, 4 or 8 columns per lane (windows that outgrow the lanes are rerun with
+                # the 4-wave LDS-ring kernel), or the 4-wave kernel from the start
+                {"MIBLAST_DP_KERNEL": "2"}, {"MIBLAST_DP_KERNEL": "4"}, {"MIBLAST_DP_KERNEL": "8"}, {"MIBLAST_DP_KERNEL": "100"},
                 {"MIBLAST_SEED_ONE_PASS": "0"},                 # two-pass seed search (count, scan, fill) instead of the fused one
                 {"MIBLAST_DP_KERNEL": "4", "MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "3"}):
         for k, v in env.items():
