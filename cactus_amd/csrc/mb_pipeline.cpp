@@ -266,6 +266,7 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<unsigned long long> bsum;
     // seed search / ungapped
     DevBuf<uint8_t> rc;
+    PinBuf<uint8_t> h_rc;
     DevBuf<int32_t> extent;
     DevBuf<uint32_t> qcnt, hit_off;
     DevBuf<unsigned long long> qbsum, scan_scratch, keys_a, keys_b;
@@ -370,6 +371,7 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     std::vector<DevHsp> found[2];         // HSPs as the device found them, per strand
     struct HostOut { int64_t lookups = 0, pre = 0, kept = 0; double seconds = 0; } host_out[2];
     bool defer_host = false;              // batched calls run the host half of the seed stage on worker threads
+    int64_t valid_windows = -1;           // seed windows of the '+' strand without N / soft-masked bases (counter seed_lookups)
     std::vector<Unit> units;              // anchors of this pair (merged into the call's unit list in pair order)
     double t_begin = 0;
 };
@@ -387,9 +389,15 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
     PairJob::HostOut &out = job.host_out[strand];
         // number of seed word lookups = valid query windows x variants (counter only)
         {
-            int64_t run = 0, valid = 0;
-            const uint8_t *qc = qc_h[strand];
-            for (int64_t i = 0; i < qtot; i++) { run = qc[i] < 4 ? run + 1 : 0; valid += run >= kSeedSpan; }
+            // (the '-' strand is the contig-wise mirror image of the '+' strand: same number of valid windows)
+            int64_t valid = strand == 1 ? job.valid_windows : -1;
+            if (valid < 0) {
+                int64_t run = 0;
+                valid = 0;
+                const uint8_t *qc = qc_h[strand];
+                for (int64_t i = 0; i < qtot; i++) { run = qc[i] < 4 ? run + 1 : 0; valid += run >= kSeedSpan; }
+                if (strand == 0) job.valid_windows = valid;
+            }
             out.lookups = valid * (p.transitions ? 1 + kSeedWeight : 1);
         }
         out.pre = (int64_t)found.size();
@@ -495,11 +503,21 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     d_rc.ensure((size_t)qtot + 2 * kDevPad);
     MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
     launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
-    std::vector<uint8_t> &h_rc = job.h_rc;
-    h_rc.assign((size_t)qtot + 2, 0);
-    MB_HIP(hipMemcpyAsync(h_rc.data(), d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
-    MB_HIP(hipStreamSynchronize(s));
-    job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc.data() + 1;
+    // host copy of the '-' strand (discovery order, anchors, '='/'X' classification).  Pair 0 of a call uses the context's
+    // pinned buffer: the copy is asynchronous and is complete long before the first host read (the host half of strand '-'
+    // comes after several synchronisations of this stream); other pairs of a batch use pageable memory and wait here.
+    uint8_t *h_rc_p;
+    if (job.use_ws_rc) {
+        w.h_rc.ensure((size_t)qtot + 2);
+        h_rc_p = w.h_rc.p;
+        MB_HIP(hipMemcpyAsync(h_rc_p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
+    } else {
+        job.h_rc.resize((size_t)qtot + 2);
+        h_rc_p = job.h_rc.data();
+        MB_HIP(hipMemcpyAsync(h_rc_p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));
+    }
+    job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc_p + 1;
     job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
     const uint8_t *const *qc_d = job.qc_d;
 
