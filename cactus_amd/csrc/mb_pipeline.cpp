@@ -640,6 +640,7 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
     const uint8_t *tc_h = job.tc_h;
     const uint8_t *const *qc_h = job.qc_h;
     std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
+    const size_t first_unit = units.size();
     if (p.gapped) {
         for (int strand = 0; strand < 2; strand++) {
             std::vector<std::vector<Anchor>> per((size_t)Q.starts.size());
@@ -674,16 +675,19 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                 Unit u;
                 u.pair = pair; u.strand = strand; u.q_contig = (int)qc_i;
                 u.anchors.swap(per[qc_i]);
-                std::sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
-                    if (a.score != b.score) return a.score > b.score;
-                    if (a.t != b.t) return a.t < b.t;
-                    return a.q < b.q;
-                });
                 st.anchors += (int64_t)u.anchors.size();
-                u.index_anchors();
                 units.push_back(std::move(u));
             }
         }
+        parallel_for(units.size() - first_unit, [&](size_t x) {
+            Unit &u = units[first_unit + x];
+            std::sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
+                if (a.score != b.score) return a.score > b.score;
+                if (a.t != b.t) return a.t < b.t;
+                return a.q < b.q;
+            });
+            u.index_anchors();
+        });
     }
 }
 
