@@ -1727,20 +1727,39 @@ __global__ __launch_bounds__(64) void k_trace_join(TbSide *__restrict__ sides, i
     push_seg(W0.ops_off, W0.n_runs, 0);
     int i = uni(W0.ei + W0.dr), j = uni(W0.ej + W0.dc), state = uni(W0.estate);
     unsigned long long jp = sd.jops_off;                          // next free slot of the join walk's own runs
-    for (int k = 1; k < sd.n_walks; k++) {
-        const TbWalk W = walks[sd.first_walk + k];
-        RunOut ro{ops + jp, 0, -1, 0};
-        const bool joined = walk_piece<1>(W, i, j, state, ro, const_cast<uint32_t *>(recs) + W.rec_off, arena, arena_bytes, rowdir);
-        ro.emit(-2, 0, lane);
-        push_seg(jp, ro.n_runs, 0);
-        jp += (unsigned)ro.n_runs;
-        if (joined) {
-            const uint32_t *q = recs + W.rec_off + 3ull * (unsigned)(W.si - i);
-            const int nr = (int)q[1], sub = (int)(q[2] >> 2);
-            push_seg(W.ops_off + (unsigned)nr, W.n_runs - nr, sub);
-            i = W.ei; j = W.ej; state = W.estate;
+    // The guessed start of a piece is usually the cell the true path enters it through: then the whole guessed walk is spliced
+    // and nothing has to be read but the walker's record.  The records of 64 walkers are fetched at once (one per lane), so
+    // that chain of hand-overs costs no memory latency.
+    for (int k0 = 1; k0 < sd.n_walks; k0 += 64) {
+        const int kk = k0 + lane;
+        TbWalk Wl;
+        if (kk < sd.n_walks) Wl = walks[sd.first_walk + kk];
+        else { Wl.si = -1; Wl.sj = -1; Wl.dr = Wl.dc = 0; Wl.ops_off = 0; Wl.n_runs = 0; Wl.ei = Wl.ej = Wl.estate = 0; }
+        const int cnt = min(64, sd.n_walks - k0);
+        for (int t = 0; t < cnt; t++) {
+            const int si = __builtin_amdgcn_readlane(Wl.si, t), sj = __builtin_amdgcn_readlane(Wl.sj, t);
+            const int wdr = __builtin_amdgcn_readlane(Wl.dr, t), wdc = __builtin_amdgcn_readlane(Wl.dc, t);
+            if (i == si && j == sj && state == 0) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)Wl.ops_off, t);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(Wl.ops_off >> 32), t);
+                push_seg(((unsigned long long)hi << 32) | lo, __builtin_amdgcn_readlane(Wl.n_runs, t), 0);
+                i = __builtin_amdgcn_readlane(Wl.ei, t); j = __builtin_amdgcn_readlane(Wl.ej, t); state = __builtin_amdgcn_readlane(Wl.estate, t);
+            } else {
+                const TbWalk W = walks[sd.first_walk + k0 + t];
+                RunOut ro{ops + jp, 0, -1, 0};
+                const bool joined = walk_piece<1>(W, i, j, state, ro, const_cast<uint32_t *>(recs) + W.rec_off, arena, arena_bytes, rowdir);
+                ro.emit(-2, 0, lane);
+                push_seg(jp, ro.n_runs, 0);
+                jp += (unsigned)ro.n_runs;
+                if (joined) {
+                    const uint32_t *q = recs + W.rec_off + 3ull * (unsigned)(W.si - i);
+                    const int nr = (int)q[1], sub = (int)(q[2] >> 2);
+                    push_seg(W.ops_off + (unsigned)nr, W.n_runs - nr, sub);
+                    i = W.ei; j = W.ej; state = W.estate;
+                }
+            }
+            i = uni(i + wdr); j = uni(j + wdc); state = uni(state);
         }
-        i = uni(i + W.dr); j = uni(j + W.dc); state = uni(state);
     }
     if (lane == 0) sides[slot].n_segs = n_segs;
 }
