@@ -847,6 +847,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 640;
         if (relay_s0_env < 0) relay_s0 = nsides > 96 ? 256 : 64;
         if (relay_w_env <= 0) relay_w = nsides > 96 ? 192 : 128;
+        const bool plant_at_once = nsides <= 96 && env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1) != 0;
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
         const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : win_typ <= 224 ? kDpWave2x4 : kDpWave8;
@@ -989,7 +990,17 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     else { b.dir = -1; b.na = (int32_t)(a.t - tlo); b.nb = (int32_t)(a.q - qlo); }
                     SideRun &sd = sides[2 * k + (size_t)sdn];
                     sd.base = b; sd.unit = (int)pend[k].unit;
-                    const int id = add_piece(sd.unit, b, b.t0, b.q0, 0, -1, (int32_t)relay_s0, 0, -1, -1);
+                    // Few sides in flight (one chunk pair): the relay chain of every head is planted at once and the head is aimed
+                    // at its first relay -- one launch less on the critical path.  Many sides: most alignments are short, so a side
+                    // first has to survive relay_s0 rows before relays are spent on it.
+                    int aim = -1;
+                    int32_t stop = (int32_t)relay_s0;
+                    if (relay_s0 > 0 && plant_at_once) {
+                        aim = next_relay(sd.unit, b, b.t0, b.q0, (int32_t)(relay_s / 2), 0);
+                        if (aim >= 0) { plant_chain(sd.unit, b, aim); stop = (relay_pts[(size_t)aim].q - b.q0) * b.dir + (int32_t)relay_w; }
+                        else stop = 0;
+                    }
+                    const int id = add_piece(sd.unit, b, b.t0, b.q0, 0, -1, stop, 0, -1, aim);
                     sd.cur.push_back(id); sd.chain.push_back(id);
                 }
             }
