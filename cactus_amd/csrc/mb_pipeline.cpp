@@ -938,6 +938,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         while (true) {                                   // retried with a larger arena if the trace does not fit
             sides.assign((size_t)nsides, SideRun());
             pieces.clear(); probs.clear(); outs.clear(); vjobs.clear(); vres.clear(); relay_pts.clear(); relay_id.clear();
+            pieces.reserve(4096); probs.reserve(4096); vjobs.reserve(4096); relay_pts.reserve(4096); relay_id.reserve(8192);
             arena_full = false;
             uint64_t dir_entries = 0;
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
