@@ -175,11 +175,11 @@ def main():
                       "handovers_rejected_per_step": tot["relay_rejected"] / a.steps / world,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / a.steps / world, "merge_ms_per_step": tot["t_merge_ms"] / a.steps / world,
                       "note": "long one-sided DPs run as concurrently evaluated pieces with verified hand-overs (DESIGN.md section 5)"},
-            "roofline": {"bound": "hbm", "kernel": "k_ydrop1 (one-sided Y-drop DP, all launches of a step; k_ydrop for over-wide windows)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_ydrop2 (one-sided Y-drop DP, one wave per piece; k_ydrop1 / k_ydrop for wider windows)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": dp_ms, "launches_per_step": launches / a.steps / world,
                          "traffic_note": traffic_note,
-                         "note": "a launch lasts as long as its longest piece (rows x ~2900 clocks per row for a lone wave); the roofline fraction rises with the number of pieces in flight (SURVEY 8d caveat, DESIGN.md section 5)"},
+                         "note": "a launch is bound by latency per row (~2100 clocks for a lone wave, ~3500 with thousands resident) and instruction issue, not HBM; the roofline fraction rises with the number of pieces in flight (SURVEY 8d caveat, DESIGN.md section 5)"},
         }
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, pm, ctx)
