@@ -1,14 +1,16 @@
 // mb_pipeline.cpp -- host orchestration of one blast job (= one `lastz target query` process of
 // /root/reference/src/cactus/paf/local_alignment.py:65-73) on one MI355X.
 //
-//   index build  ->  per strand: seed count / batch / fill / sort / ungapped  ->  HSP filters (host,
-//   entropy in IEEE double like lastz)  ->  anchors  ->  score-ordered gapped extension with
-//   speculative batches of Y-drop DPs  ->  PAF text.
+//   index build  ->  per strand: seed search / sort / ungapped  ->  HSP filters (host, entropy in IEEE
+//   double like lastz)  ->  anchors  ->  score-ordered gapped extension: speculative batches of Y-drop
+//   DPs, long ones cut into concurrently evaluated pieces with verified hand-overs  ->  PAF text.
 //
 // The sequential rules of SURVEY.md A.10 that look order dependent are kept exact:
 //   * diagonal suppression: hits are sorted by (diagonal, q) and each diagonal run is walked in order;
 //   * "anchor covered by an earlier alignment": DPs are independent of each other, so they are run
-//     speculatively in score-ranked batches and a host pass commits them strictly in anchor order.
+//     speculatively in score-ranked batches and a host pass commits them strictly in anchor order;
+//   * a one-sided DP is a chain of rows: it is cut at relays (fresh DPs started downstream) whose state
+//     after a warm-up must equal the upstream state exactly, else the upstream piece is continued.
 #include "mb_pipeline.h"
 
 #include <algorithm>
