@@ -80,10 +80,16 @@ struct PinBuf {
 };
 
 // host substitution score (HOXD70 + N = -100)
+struct HostScoreTable {                     // 8 x 8 by the low three code bits: branch-free lookups in the anchor window scan
+    int8_t s[64];
+    HostScoreTable() {
+        static const int M[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
+        for (unsigned x = 0; x < 8; x++) for (unsigned y = 0; y < 8; y++) s[x * 8 + y] = (int8_t)((x > 3u || y > 3u) ? -100 : M[x][y]);
+    }
+};
 inline int host_score(unsigned a, unsigned b) {
-    static const int M[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
-    unsigned x = a & 7u, y = b & 7u;
-    return (x > 3u || y > 3u) ? -100 : M[x][y];
+    static const HostScoreTable T;
+    return T.s[(a & 7u) * 8u + (b & 7u)];
 }
 
 inline uint32_t host_word(const uint8_t *c, int64_t p) {
@@ -112,6 +118,8 @@ struct Cached {                // result of one anchor's two one-sided DPs
     std::vector<uint32_t> ops;           // merged run-length ops, forward order
 };
 
+template <typename It, typename Cmp> void parallel_sort(It first, It last, Cmp cmp);      // (defined with the worker pool below)
+
 struct Unit {                  // one (pair, query contig, strand): anchors are committed strictly in order
     int pair = 0, strand = 0, q_contig = 0;
     std::vector<Anchor> anchors;
@@ -128,7 +136,7 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
     void index_anchors() {
         by_q.resize(anchors.size());
         for (size_t k = 0; k < by_q.size(); k++) by_q[k] = (uint32_t)k;
-        std::sort(by_q.begin(), by_q.end(), [&](uint32_t x, uint32_t y) { return anchors[x].q < anchors[y].q; });
+        parallel_sort(by_q.begin(), by_q.end(), [&](uint32_t x, uint32_t y) { return anchors[x].q != anchors[y].q ? anchors[x].q < anchors[y].q : x < y; });
         cov.assign(anchors.size(), 0);
         tent.assign(anchors.size(), 0);
     }
@@ -228,6 +236,25 @@ template <typename F>
 void parallel_for(size_t n, F &&f) {
     const std::function<void(size_t)> fn = std::ref(f);
     Pool::get().run(n, fn);
+}
+
+// sort on the worker threads: chunks sorted independently, then merged pairwise (the comparators used with it are total
+// orders, so the result does not depend on the split)
+template <typename It, typename Cmp>
+void parallel_sort(It first, It last, Cmp cmp) {
+    const size_t n = (size_t)(last - first);
+    const size_t kMin = 1024;
+    if (n < 2 * kMin) { std::sort(first, last, cmp); return; }
+    size_t parts = 1;
+    while (parts < 16 && n / (parts * 2) >= kMin) parts *= 2;
+    std::vector<size_t> cut(parts + 1);
+    for (size_t p = 0; p <= parts; p++) cut[p] = n * p / parts;
+    parallel_for(parts, [&](size_t p) { std::sort(first + (long)cut[p], first + (long)cut[p + 1], cmp); });
+    for (size_t width = 1; width < parts; width *= 2)
+        parallel_for(parts / (2 * width), [&](size_t m) {
+            const size_t a = 2 * width * m;
+            std::inplace_merge(first + (long)cut[a], first + (long)cut[a + width], first + (long)cut[a + 2 * width], cmp);
+        });
 }
 
 long env_long(const char *name, long dflt) {
@@ -643,8 +670,10 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
     const uint8_t *const *qc_h = job.qc_h;
     std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
     const size_t first_unit = units.size();
+    double t_bu[4] = {0, 0, 0, 0};
     if (p.gapped) {
         for (int strand = 0; strand < 2; strand++) {
+            const double t_b0 = now_s();
             std::vector<std::vector<Anchor>> per((size_t)Q.starts.size());
             const uint8_t *qc = qc_h[strand];
             // anchor = middle of the best-scoring 31-column window (first on ties); SURVEY A.6
@@ -657,12 +686,16 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                     int off;
                     if (h.len <= 31) off = h.len / 2;
                     else {
-                        int64_t sum = 0;
-                        for (int k = 0; k < 31; k++) sum += host_score(tc_h[h.t_start + k], qc[h.q_start + k]);
-                        int64_t bestsum = sum; int bestc = 0;
+                        // every column is scored once: the scores of the window live in a 32-entry ring
+                        const uint8_t *tp = tc_h + h.t_start, *qp = qc + h.q_start;
+                        int8_t ring[32];
+                        int sum = 0;
+                        for (int k = 0; k < 31; k++) { ring[k] = (int8_t)host_score(tp[k], qp[k]); sum += ring[k]; }
+                        int bestsum = sum, bestc = 0;
                         for (int cc = 1; cc + 31 <= h.len; cc++) {
-                            sum += host_score(tc_h[h.t_start + cc + 30], qc[h.q_start + cc + 30]);
-                            sum -= host_score(tc_h[h.t_start + cc - 1], qc[h.q_start + cc - 1]);
+                            const int in = host_score(tp[cc + 30], qp[cc + 30]);
+                            sum += in - ring[(cc - 1) & 31];
+                            ring[(cc + 30) & 31] = (int8_t)in;
                             if (sum > bestsum) { bestsum = sum; bestc = cc; }
                         }
                         off = bestc + 15;
@@ -670,6 +703,7 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                     offs[x] = off;
                 }
             });
+            const double t_b1 = now_s();
             for (size_t x = 0; x < hs.size(); x++)
                 per[(size_t)hs[x].q_contig].push_back(Anchor{hs[x].t_start + offs[x], hs[x].q_start + offs[x], hs[x].score});
             for (size_t qc_i = 0; qc_i < per.size(); qc_i++) {
@@ -680,16 +714,20 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                 st.anchors += (int64_t)u.anchors.size();
                 units.push_back(std::move(u));
             }
+            t_bu[0] += t_b1 - t_b0; t_bu[1] += now_s() - t_b1;
         }
-        parallel_for(units.size() - first_unit, [&](size_t x) {
-            Unit &u = units[first_unit + x];
-            std::sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
+        const double t_b2 = now_s();
+        for (size_t x = first_unit; x < units.size(); x++) {
+            Unit &u = units[x];
+            parallel_sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
                 if (a.score != b.score) return a.score > b.score;
                 if (a.t != b.t) return a.t < b.t;
                 return a.q < b.q;
             });
             u.index_anchors();
-        });
+        }
+        t_bu[2] = now_s() - t_b2;
+        if (env_long("MIBLAST_DEBUG", 0) > 1) fprintf(stderr, "[miblast]   build_units: window scan %.2f ms, distribute %.2f ms, sorts %.2f ms\n", t_bu[0] * 1e3, t_bu[1] * 1e3, t_bu[2] * 1e3);
     }
 }
 
@@ -1468,13 +1506,13 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         while (n) res.paf.push_back(buf[--n]);
     };
     // the cigar text of long alignments is formatted in chunks on several threads
-    struct CigarTask { size_t aln; int64_t k0, k1; std::string text; };
+    struct CigarTask { size_t aln; int64_t k0, k1; std::string text; int64_t nmatch, alen; size_t at; };
     std::vector<CigarTask> ctasks;
     std::vector<size_t> cfirst(res.alns.size() + 1, 0);
     const int64_t kOpsPerTask = 16384;
     for (size_t x = 0; x < res.alns.size(); x++) {
         cfirst[x] = ctasks.size();
-        for (int64_t k0 = 0; k0 < res.alns[x].n_ops; k0 += kOpsPerTask) ctasks.push_back(CigarTask{x, k0, std::min(res.alns[x].n_ops, k0 + kOpsPerTask), {}});
+        for (int64_t k0 = 0; k0 < res.alns[x].n_ops; k0 += kOpsPerTask) ctasks.push_back(CigarTask{x, k0, std::min(res.alns[x].n_ops, k0 + kOpsPerTask), {}, 0, 0, 0});
     }
     cfirst[res.alns.size()] = ctasks.size();
     parallel_for(ctasks.size(), [&](size_t ti) {
@@ -1483,6 +1521,8 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         t.text.reserve((size_t)(t.k1 - t.k0) * 5);
         for (int64_t k = t.k0; k < t.k1; k++) {
             const uint32_t o = res.ops[(size_t)(A.ops_off + k)];
+            t.alen += o >> 2;
+            if ((o & 3u) == 0) t.nmatch += o >> 2;
             char buf[12]; int n = 0;
             uint32_t u = o >> 2;
             do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
@@ -1490,6 +1530,10 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
             t.text.push_back("=XID"[o & 3u]);
         }
     });
+    // line heads first (short), then every piece of text is copied to its place on the worker threads
+    std::vector<std::string> heads(res.alns.size());
+    size_t total = res.paf.size();
+    const size_t paf0 = total;
     for (size_t ai = 0; ai < res.alns.size(); ai++) {
         const miblast_aln &A = res.alns[ai];
         int64_t qst = Q.starts[(size_t)A.q_contig], qlen = Q.lens[(size_t)A.q_contig];
@@ -1497,22 +1541,32 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         int64_t qs = A.q_lo - qst, qe = A.q_hi - qst;
         if (A.strand) { int64_t s2 = qlen - qe, e2 = qlen - qs; qs = s2; qe = e2; }
         int64_t nmatch = 0, alen = 0;
-        for (int64_t k = 0; k < A.n_ops; k++) {
-            uint32_t o = res.ops[(size_t)(A.ops_off + k)];
-            alen += o >> 2;
-            if ((o & 3u) == 0) nmatch += o >> 2;
-        }
+        for (size_t ti = cfirst[ai]; ti < cfirst[ai + 1]; ti++) { nmatch += ctasks[ti].nmatch; alen += ctasks[ti].alen; }
         // qname qlen qstart qend strand tname tlen tstart tend nmatch alnlen 255 AS:i:<score> cg:Z:<cigar>  
-        res.paf += Q.names[(size_t)A.q_contig]; res.paf.push_back('\t');
-        put_num(qlen); res.paf.push_back('\t'); put_num(qs); res.paf.push_back('\t'); put_num(qe); res.paf.push_back('\t');
-        res.paf.push_back(A.strand ? '-' : '+'); res.paf.push_back('\t');
-        res.paf += T.names[(size_t)A.t_contig]; res.paf.push_back('\t');
-        put_num(tlen); res.paf.push_back('\t'); put_num(A.t_lo - tst); res.paf.push_back('\t'); put_num(A.t_hi - tst); res.paf.push_back('\t');
-        put_num(nmatch); res.paf.push_back('\t'); put_num(alen);
-        res.paf += "\t255\tAS:i:"; put_num(A.score); res.paf += "\tcg:Z:";
-        for (size_t ti = cfirst[ai]; ti < cfirst[ai + 1]; ti++) res.paf += ctasks[ti].text;
-        res.paf.push_back('\n');
+        std::string &h = heads[ai];
+        auto num = [&](long long v) { h += std::to_string(v); };
+        h += Q.names[(size_t)A.q_contig]; h.push_back('\t');
+        num(qlen); h.push_back('\t'); num(qs); h.push_back('\t'); num(qe); h.push_back('\t');
+        h.push_back(A.strand ? '-' : '+'); h.push_back('\t');
+        h += T.names[(size_t)A.t_contig]; h.push_back('\t');
+        num(tlen); h.push_back('\t'); num(A.t_lo - tst); h.push_back('\t'); num(A.t_hi - tst); h.push_back('\t');
+        num(nmatch); h.push_back('\t'); num(alen);
+        h += "\t255\tAS:i:"; num(A.score); h += "\tcg:Z:";
+        total += h.size();
+        for (size_t ti = cfirst[ai]; ti < cfirst[ai + 1]; ti++) { ctasks[ti].at = total; total += ctasks[ti].text.size(); }
+        total += 1;                                     // '\n'
     }
+    res.paf.resize(total);
+    {
+        size_t at = paf0;
+        for (size_t ai = 0; ai < res.alns.size(); ai++) {
+            memcpy(&res.paf[at], heads[ai].data(), heads[ai].size());
+            at += heads[ai].size();
+            for (size_t ti = cfirst[ai]; ti < cfirst[ai + 1]; ti++) at += ctasks[ti].text.size();
+            res.paf[at++] = '\n';
+        }
+    }
+    parallel_for(ctasks.size(), [&](size_t ti) { if (!ctasks[ti].text.empty()) memcpy(&res.paf[ctasks[ti].at], ctasks[ti].text.data(), ctasks[ti].text.size()); });
     if (p.format == 1) {
         // --format=general:name1,zstart1,end1,name2,zstart2+,end2+ (cactus_lastzRepeatMask.py:104): one line per HSP
         res.paf += "#name1\tzstart1\tend1\tname2\tzstart2+\tend2+\n";
