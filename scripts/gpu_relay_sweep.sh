@@ -1,9 +1,9 @@
 #!/bin/bash
 # sweep of the relay knobs on the default bench pair
-for cfg in "128 1280 192" "128 960 128" "128 640 128" "64 640 96" "64 480 96" "64 384 96"; do
+for cfg in "640 128" "640 96" "768 96" "896 96" "1024 128" "512 96"; do
   set -- $cfg
-  echo "== S0=$1 S=$2 W=$3"
-  MIBLAST_RELAY_S0=$1 MIBLAST_RELAY_S=$2 MIBLAST_RELAY_W=$3 MIBLAST_DEBUG=1 timeout 300 python bench.py --steps 4 --warmup 1 --cpu-sample 0 --seed-leg 0 2>&1 | grep "round 0\.2\|round 0:\|metric" | tail -3 | python -c "
+  echo "== S=$1 W=$2"
+  MIBLAST_RELAY_S=$1 MIBLAST_RELAY_W=$2 MIBLAST_DEBUG=1 timeout 300 python bench.py --steps 6 --warmup 2 --cpu-sample 0 --seed-leg 0 2>&1 | grep "round 0:\|metric" | tail -2 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
