@@ -81,6 +81,9 @@ RELAY_CONFIGS = [
     {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "2"},
     {"MIBLAST_RELAY_S0": "32", "MIBLAST_RELAY_S": "300", "MIBLAST_RELAY_W": "70", "MIBLAST_RELAY_FORCE_REJECT": "3", "MIBLAST_RELAY_TOL": "40"},
     {"MIBLAST_RELAY_S0": "512", "MIBLAST_RELAY_S": "2048", "MIBLAST_RELAY_W": "256", "MIBLAST_RELAY_FORCE_REJECT": "5"},
+    # the policy of batched calls on a single pair: a side first has to survive S0 rows, relays are planted at its first stop
+    {"MIBLAST_RELAY_S0": "48", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_PLANT_AT_ONCE": "0"},
+    {"MIBLAST_RELAY_S0": "256", "MIBLAST_RELAY_S": "640", "MIBLAST_RELAY_W": "128", "MIBLAST_RELAY_PLANT_AT_ONCE": "0", "MIBLAST_RELAY_FORCE_REJECT": "3"},
 ]
 
 
