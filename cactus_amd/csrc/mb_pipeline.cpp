@@ -369,8 +369,15 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
 // LDS ring (windows up to ~1400 columns), or the 4-wave kernel with the ring in HBM (any width)
 enum DpKernel { kDpWave2x4 = 2, kDpWave4 = 4, kDpWave8 = 8, kDpLds = 100, kDpHbm = 101 };
 
+static void collect_dp_time(Ctx &ctx, miblast_stats &st) {             // after the stream has been synchronised
+    float ms = 0;
+    MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+    st.t_dp_kernel_ms += ms;
+    st.dp_kernel_launches++;
+}
+
 static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpProb *probs, DpOut *outs, int n,
-                            const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes) {
+                            const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes, bool defer = false) {
     Workspace &g = *ctx.ws;
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     if (kernel == kDpWave2x4 || kernel == kDpWave4 || kernel == kDpWave8)
@@ -380,11 +387,9 @@ static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpPro
         launch_ydrop(kernel == kDpHbm, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
                      (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
     MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+    if (defer) return;                                                  // the caller synchronises once for several things
     MB_HIP(hipEventSynchronize(ctx.ev1));
-    float ms = 0;
-    MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-    st.t_dp_kernel_ms += ms;
-    st.dp_kernel_launches++;
+    collect_dp_time(ctx, st);
 }
 
 struct PairJob {                          // one chunk pair of a (possibly batched) call
@@ -1058,10 +1063,15 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 MB_HIP(hipMemcpyAsync(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), hipMemcpyHostToDevice, s));
                 if (v_new) MB_HIP(hipMemcpyAsync(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), hipMemcpyHostToDevice, s));
                 MB_HIP(hipMemsetAsync(g.snaps.p + launched * 2 * kSnapBytes, 0, n_new * 2 * kSnapBytes, s));      // valid = 0
-                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk);
-                if (debug) fprintf(stderr, "[miblast]   first pass (kernel %d): dp kernel total %.2f ms\n", dp_kernel, st.t_dp_kernel_ms);
+                // DP launch, hand-over checks and the copies of both results: one synchronisation.  (Checks made on pieces that
+                // turn out to need a rerun are simply made again.)
+                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true);
+                launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
                 MB_HIP(hipMemcpyAsync(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), hipMemcpyDeviceToHost, s));
+                if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
                 MB_HIP(hipStreamSynchronize(s));
+                collect_dp_time(ctx, st);
+                if (debug) fprintf(stderr, "[miblast]   first pass (kernel %d): dp kernel total %.2f ms\n", dp_kernel, st.t_dp_kernel_ms);
                 if (dp_kernel != kDpLds) {
                     // pieces whose window outgrew the lanes of the one-wave kernel: once more with the LDS ring (same snapshots)
                     std::vector<size_t> again;
@@ -1077,11 +1087,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         for (size_t y = 0; y < again.size(); y++) outs[again[y]] = so[y];
                         st.dp_reruns += (int64_t)again.size();
                         if (debug) fprintf(stderr, "[miblast]   %zu of %zu pieces outgrew the one-wave kernel and were rerun (dp kernel total %.2f ms)\n", again.size(), n_new, st.t_dp_kernel_ms);
+                        launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
+                        if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
+                        MB_HIP(hipStreamSynchronize(s));
                     }
                 }
-                launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
-                if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
-                MB_HIP(hipStreamSynchronize(s));
                 for (size_t x = launched; x < pieces.size(); x++) arena_full |= outs[x].overflow == 3;
                 if (arena_full) break;
                 for (size_t x = launched; x < pieces.size(); x++) {
