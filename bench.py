@@ -66,6 +66,8 @@ def main():
     torch.cuda.set_device(local_rank)
 
     pm = miblast.params_from_args(a.lastz_args.split())
+    from cactus_amd.multigpu import share_host_cores
+    host_threads = share_host_cores(int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else miblast.set_host_threads(0)
     ctx = miblast.Context(local_rank)
     # each rank aligns its own chunk pair (chunk-pair sharding)
     P = max(1, a.pairs_per_gpu)
@@ -162,7 +164,7 @@ def main():
                                    f"{', pure-random variant' if a.random_pair else ''}), seed {a.seed}+pair index, identical on every rank",
                        "lastz_args": a.lastz_args, "chunk_pairs": world * P, "pairs_per_gpu": P,
                        "sharding": "chunk pairs sharded over GPUs (batched per GPU when pairs_per_gpu > 1), gather of PAF to rank 0",
-                       "collective_backend": coll_backend},
+                       "collective_backend": coll_backend, "host_threads_per_rank": host_threads},
             "seeds_per_s": tot["seed_hits"] / elapsed,
             "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
             "stage_seconds_per_step": {k: tot[k] / a.steps / world for k in ("t_index", "t_seed", "t_gapped", "t_total")},

@@ -132,6 +132,14 @@ int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const cha
     return MIBLAST_OK;
 }
 
+int miblast_set_host_threads(int n) {
+    return guarded([&] {
+        int got = mb::set_host_threads(n);
+        if (got < 0) { mb::set_error("miblast_set_host_threads: an alignment call is running"); return (int)MIBLAST_EINVAL; }
+        return got;
+    });
+}
+
 int miblast_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

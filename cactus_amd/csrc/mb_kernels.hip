@@ -1266,11 +1266,11 @@ __global__ __launch_bounds__(64) void k_ydrop1(const DpProb *__restrict__ probs,
 // that reach further -- the ones that make k_ydrop1<4> overflow and rerun -- just evaluate group B as well, with the scan
 // carries of group A.  B can be skipped whenever the previous row's window ended inside A and this row's break is found in
 // A: no column of B was alive in the previous row then, so all of them already hold dead values (k_ydrop1's invariant).
-__global__ __launch_bounds__(64) void k_ydrop2(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
-                                               const PairPtrs *__restrict__ pairs, const int O, const int E, const int Y,
-                                               uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
-                                               unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
-                                               unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps) {
+static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
+                                                    const PairPtrs *__restrict__ pairs, const int O, const int E, const int Y,
+                                                    uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
+                                                    unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
+                                                    unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps) {
     const int pi = blockIdx.x;
     if (pi >= n) return;
     constexpr int K = 4, G = 2, kHalf = 64 * K, kCap = G * kHalf;
@@ -1558,12 +1558,32 @@ __global__ __launch_bounds__(64) void k_ydrop2(const DpProb *__restrict__ probs,
     }
 }
 
+// The piece evaluator needs 129 VGPRs when the compiler is left alone: 3 waves per SIMD.  k_ydrop2 asks for 4 (128 VGPRs, the
+// same instruction stream, no scratch), which matters once thousands of pieces are resident; k_ydrop2_w3 is the
+// unconstrained build (MIBLAST_DP_WAVES=3).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_ydrop2(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
+              const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
+              unsigned long long *__restrict__ arena_next, const unsigned blk_bytes, unsigned long long *__restrict__ rowdir,
+              uint8_t *__restrict__ snaps) {
+    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+}
+__global__ __launch_bounds__(64)
+void k_ydrop2_w3(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
+                 const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
+                 unsigned long long *__restrict__ arena_next, const unsigned blk_bytes, unsigned long long *__restrict__ rowdir,
+                 uint8_t *__restrict__ snaps) {
+    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+}
+
 void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena,
                    unsigned long long arena_bytes, unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir,
                    uint8_t *snaps, hipStream_t s) {
     if (n <= 0) return;
     dim3 g((unsigned)n), b(64);
-    if (K == 2) hipLaunchKernelGGL(k_ydrop2, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    static const bool three_waves = [] { const char *e = getenv("MIBLAST_DP_WAVES"); return e && atoi(e) == 3; }();
+    if (K == 2 && three_waves) hipLaunchKernelGGL(k_ydrop2_w3, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    else if (K == 2) hipLaunchKernelGGL(k_ydrop2, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else if (K == 4) hipLaunchKernelGGL((k_ydrop1<4>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else hipLaunchKernelGGL((k_ydrop1<8>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
 }

@@ -25,6 +25,7 @@
 #include <future>
 #include <memory>
 #include <mutex>
+#include <sched.h>
 #include <thread>
 #include <unordered_map>
 
@@ -192,18 +193,56 @@ class Pool {
             }
         }
     }
-public:
-    Pool() {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned nt = std::min(15u, hw > 1 ? hw - 1 : 0u);
-        for (unsigned t = 0; t < nt; t++) th.emplace_back([this] { worker(); });
-    }
-    ~Pool() {
+    void join_all() {
         { std::lock_guard<std::mutex> lk(m); stop = true; stop_a = true; }
         cv.notify_all();
         for (std::thread &t : th) t.join();
+        th.clear();
+        { std::lock_guard<std::mutex> lk(m); stop = false; stop_a = false; }
     }
+public:
+    // host cores this process may use: the affinity mask, cut down to the cgroup CPU quota when there is one (a job of a
+    // workflow engine or one rank of several on a node must not spin on cores it does not own)
+    static unsigned cores_available() {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+            fclose(f);
+        }
+        return n;
+    }
+    static unsigned default_threads() {
+        long v = 0;
+        if (const char *e = getenv("MIBLAST_THREADS")) v = atol(e);
+        if (v <= 0) v = std::min(16u, cores_available());
+        return (unsigned)std::min(64l, std::max(1l, v));
+    }
+    Pool() { spawn(default_threads()); }
+    ~Pool() { join_all(); }
     static Pool &get() { static Pool p; return p; }
+    unsigned threads() const { return (unsigned)th.size() + 1; }
+    void spawn(unsigned total) {                                   // `total` threads including the caller
+        for (unsigned t = 1; t < total; t++) th.emplace_back([this] { worker(); });
+    }
+    // change the number of threads (caller included); refused while a job keeps the workers awake
+    bool resize(unsigned total) {
+        std::unique_lock<std::mutex> one(run_m, std::try_to_lock);
+        if (!one.owns_lock() || hot_a.load() > 0) return false;
+        if (total == 0) total = default_threads();
+        total = std::min(64u, std::max(1u, total));
+        if (total == threads()) return true;
+        join_all();
+        {
+            std::lock_guard<std::mutex> lk(m);                      // a fresh generation: new workers start in step with it
+            fn = nullptr; n = 0;
+        }
+        spawn(total);
+        return true;
+    }
     struct Hot {                              // keeps the workers awake for the duration of a job
         Hot() { Pool &p = get(); p.hot_a++; p.cv.notify_all(); }
         ~Hot() { get().hot_a--; }
@@ -256,6 +295,13 @@ void parallel_sort(It first, It last, Cmp cmp) {
             std::inplace_merge(first + (long)cut[a], first + (long)cut[a + width], first + (long)cut[a + 2 * width], cmp);
         });
 }
+
+}  // namespace
+
+int set_host_threads(int n) { return Pool::get().resize(n < 0 ? 0u : (unsigned)n) ? (int)Pool::get().threads() : -1; }
+int host_threads() { return (int)Pool::get().threads(); }
+
+namespace {
 
 long env_long(const char *name, long dflt) {
     const char *v = getenv(name);

@@ -28,6 +28,8 @@ void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
 int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &p, Result &res);
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &p, Result **results);
+int set_host_threads(int n);      // 0 = automatic; returns the threads in use or -1 (a job is running)
+int host_threads();
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions);
 
 }  // namespace mb

@@ -70,6 +70,7 @@ def load() -> C.CDLL:
         "miblast_params_default": (None, [P(Params)]),
         "miblast_params_from_argv": (C.c_int, [C.c_int, P(cp), P(Params), P(cp), P(C.c_int), P(C.c_int)]),
         "miblast_device_count": (C.c_int, []),
+        "miblast_set_host_threads": (C.c_int, [C.c_int]),
         "miblast_ctx_create": (C.c_int, [C.c_int, P(vp)]),
         "miblast_ctx_destroy": (None, [vp]),
         "miblast_seqset_from_fasta_file": (C.c_int, [vp, cp, P(vp)]),
@@ -101,7 +102,8 @@ def load() -> C.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_ctx_create",
+EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_set_host_threads",
+                    "miblast_ctx_create",
                     "miblast_ctx_destroy", "miblast_seqset_from_fasta_file", "miblast_seqset_from_fasta_mem",
                     "miblast_seqset_free", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
                     "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_align_pairs", "miblast_result_free",
@@ -136,6 +138,14 @@ def params_from_args(args) -> Params:
 
 def device_count() -> int:
     return load().miblast_device_count()
+
+
+def set_host_threads(n: int = 0) -> int:
+    """Host threads beside the GPU (KegAlign's --num_threads = job.cores, local_alignment.py:58); 0 = automatic."""
+    got = load().miblast_set_host_threads(int(n))
+    if got < 0:
+        _check(got)
+    return got
 
 
 @dataclass

@@ -23,6 +23,16 @@ def assign_pairs(weights: Sequence[float], world_size: int) -> List[List[int]]:
     return out
 
 
+def share_host_cores(local_world_size: int) -> int:
+    """One rank per GPU on a node: every rank takes an equal share of the host cores for its worker threads (the reference
+    passes job.cores as --num_threads for the same reason, /root/reference/src/cactus/paf/local_alignment.py:58).
+    Returns the threads now in use by this rank."""
+    import os
+    from cactus_amd import miblast
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return miblast.set_host_threads(max(1, min(16, cores // max(1, local_world_size))))
+
+
 def gather_bytes(payload: bytes, dist, rank: int, world_size: int, device) -> Optional[List[bytes]]:
     """Variable-length gather to rank 0: all_gather of the byte counts, then one padded gather
     (the 'gatherv' of SURVEY 8e; payload is small next to xGMI bandwidth, so latency matters, not size)."""

@@ -71,6 +71,12 @@ typedef struct miblast_ctx miblast_ctx;
 
 /* Replaces `count_nvidia_gpus` (/root/reference/src/cactus/shared/configWrapper.py:307).      */
 int miblast_device_count(void);
+/* Host threads of this process that parse, sort anchors, merge traces and format PAF beside the GPU (the calling thread
+ * included).  Replaces KegAlign's `--num_threads C`, which run_lastz sets to job.cores (local_alignment.py:58): a job
+ * must not occupy cores the workflow engine gave to other jobs.  n = 0: automatic = min(16, cores of the affinity mask
+ * and of the cgroup CPU quota), or $MIBLAST_THREADS.  Returns the number now in use, or MIBLAST_EINVAL while an
+ * alignment call is running in another thread.                                                                     */
+int miblast_set_host_threads(int n);
 /* One context per process per GPU (ordinal after HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES). */
 int miblast_ctx_create(int device, miblast_ctx **ctx);
 void miblast_ctx_destroy(miblast_ctx *ctx);

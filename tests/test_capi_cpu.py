@@ -80,6 +80,19 @@ def test_argv_needs_two_files():
     assert _argv(["lastz", "A.fa"])[0] == -1
 
 
+def test_host_threads_follow_num_threads():
+    # KegAlign's --num_threads = job.cores (local_alignment.py:58) bounds the host threads beside the GPU
+    assert miblast.set_host_threads(3) == 3
+    assert miblast.set_host_threads(1) == 1
+    assert miblast.set_host_threads(1000) == 64
+    auto = miblast.set_host_threads(0)
+    assert 1 <= auto <= 16 and auto <= (os.cpu_count() or 1)
+    env = dict(os.environ, MIBLAST_THREADS="5")
+    out = subprocess.run(["python", "-c", "from cactus_amd import miblast; print(miblast.set_host_threads(0))"], capture_output=True, text=True,
+                         env=env, cwd=ROOT)
+    assert out.stdout.strip() == "5", out.stderr
+
+
 def test_no_device_means_loud_refusal_not_cpu_fallback():
     if not _no_gpu():
         pytest.skip("a GPU is visible here")
