@@ -15,9 +15,6 @@ static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
 }  // namespace mb
 
-struct miblast_ctx { mb::Ctx c; };
-struct miblast_seqset { mb::SeqSet s; };
-struct miblast_result { mb::Result r; };
 
 namespace {
 

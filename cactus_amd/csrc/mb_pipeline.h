@@ -33,3 +33,8 @@ int host_threads();
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions);
 
 }  // namespace mb
+
+// the opaque handles of include/miblast.h (shared by mb_capi.cpp and mp_chain.cpp)
+struct miblast_ctx { mb::Ctx c; };
+struct miblast_seqset { mb::SeqSet s; };
+struct miblast_result { mb::Result r; };

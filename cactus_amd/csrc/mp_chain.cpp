@@ -1,0 +1,787 @@
+// mp_chain.cpp -- host side and C ABI (include/mipaf.h) of the chaining stage: PAF records in and out, the orchestration
+// of the sorts and of k_chain_dp / k_tile / k_trim (mp_kernels.hip), and the O(n) bookkeeping between them (group
+// boundaries, peeling chains off in score order, splicing trimmed op lists).  Replaces the paffy sub-commands of
+// /root/reference/src/cactus/paf/local_alignment.py:607-727; rules in DESIGN.md section 11.  No CPU path for the
+// three compute steps: without a device context they cannot be called at all.
+#include "mp_common.h"
+#include "mb_pipeline.h"
+
+#include "../../include/mipaf.h"
+
+#include <algorithm>
+#include <charconv>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <unistd.h>
+#include <vector>
+
+namespace mb {
+namespace {
+
+struct PafRec {
+    uint32_t qn = 0, tn = 0;              // name ids
+    int64_t ql = 0, qs = 0, qe = 0, tl = 0, ts = 0, te = 0, nm = 0, nb = 0, mq = 0;
+    uint8_t same = 1, has_as = 0, has_cg = 0;
+    char tp = 0;
+    int64_t as = 0, tile = -1, cn = -1, s1 = -1;
+    uint64_t ops_off = 0;                 // the record's ops: PafSet::ops[ops_off .. ops_off + n_ops)
+    uint32_t n_ops = 0;
+};
+
+}  // namespace
+
+struct PafSet {
+    std::vector<std::string> names;
+    std::unordered_map<std::string, uint32_t> name_id;
+    std::vector<PafRec> recs;
+    std::vector<uint32_t> ops;
+    uint32_t intern(const char *s, size_t n) {
+        std::string key(s, n);
+        auto it = name_id.find(key);
+        if (it != name_id.end()) return it->second;
+        uint32_t id = (uint32_t)names.size();
+        names.push_back(key);
+        name_id.emplace(std::move(key), id);
+        return id;
+    }
+};
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <typename T>
+struct Dev {                               // device array with the lifetime of one call
+    T *p = nullptr;
+    size_t n = 0;
+    Dev() = default;
+    explicit Dev(size_t count) { alloc(count); }
+    Dev(const Dev &) = delete;
+    Dev &operator=(const Dev &) = delete;
+    ~Dev() { if (p) (void)hipFree(p); }
+    void alloc(size_t count) {
+        n = count;
+        MB_HIP(hipMalloc((void **)&p, std::max<size_t>(1, count) * sizeof(T)));
+    }
+    void upload(const std::vector<T> &v, hipStream_t s) {
+        if (!p) alloc(v.size());
+        if (!v.empty()) MB_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(std::vector<T> &v, hipStream_t s) const {
+        v.resize(n);
+        if (n) MB_HIP(hipMemcpyAsync(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+};
+
+struct EventTimer {                        // HIP-event time of a stretch of the stream
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit EventTimer(hipStream_t st) : s(st) {
+        MB_HIP(hipEventCreate(&a));
+        MB_HIP(hipEventCreate(&b));
+        MB_HIP(hipEventRecord(a, s));
+    }
+    ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    double stop_ms() {
+        MB_HIP(hipEventRecord(b, s));
+        MB_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        MB_HIP(hipEventElapsedTime(&ms, a, b));
+        return ms;
+    }
+};
+
+int bits_for(unsigned long long mx) {
+    int b = 1;
+    while (b < 64 && (mx >> b)) b++;
+    return b;
+}
+
+// ---- text -> records -----------------------------------------------------------------------------------------------
+bool parse_i64(const char *b, const char *e, int64_t &v) {
+    if (b == e) return false;
+    auto r = std::from_chars(b, e, v);
+    return r.ec == std::errc() && r.ptr == e;
+}
+
+int parse_line(PafSet &set, const char *b, const char *e, size_t line_no) {
+    const char *col[13];
+    const char *end[13];
+    int n = 0;
+    const char *p = b;
+    const char *tags = nullptr;
+    while (n < 12) {
+        const char *t = (const char *)memchr(p, '\t', (size_t)(e - p));
+        col[n] = p;
+        end[n] = t ? t : e;
+        n++;
+        if (!t) { p = e; break; }
+        p = t + 1;
+        if (n == 12) tags = p;
+    }
+    auto bad = [&](const char *what) {
+        set_error("PAF line " + std::to_string(line_no) + ": " + what);
+        return MIBLAST_EINVAL;
+    };
+    if (n < 12) return bad("fewer than 12 columns");
+    PafRec r;
+    r.qn = set.intern(col[0], (size_t)(end[0] - col[0]));
+    r.tn = set.intern(col[5], (size_t)(end[5] - col[5]));
+    int64_t *num[] = {&r.ql, &r.qs, &r.qe, nullptr, nullptr, &r.tl, &r.ts, &r.te, &r.nm, &r.nb, &r.mq};
+    for (int k = 1; k < 12; k++) {
+        if (k == 4 || k == 5) continue;
+        if (!parse_i64(col[k], end[k], *num[k - 1])) return bad("a numeric column does not parse");
+    }
+    if (end[4] - col[4] != 1 || (col[4][0] != '+' && col[4][0] != '-')) return bad("strand is neither + nor -");
+    r.same = col[4][0] == '+';
+    for (p = tags; p && p < e;) {
+        const char *t = (const char *)memchr(p, '\t', (size_t)(e - p));
+        const char *te = t ? t : e;
+        if (te - p >= 5) {
+            const char *val = p + 5;
+            if (!memcmp(p, "tp:A:", 5)) r.tp = val < te ? *val : 0;
+            else if (!memcmp(p, "AS:i:", 5)) { if (!parse_i64(val, te, r.as)) return bad("AS:i: does not parse"); r.has_as = 1; }
+            else if (!memcmp(p, "tl:i:", 5)) { if (!parse_i64(val, te, r.tile)) return bad("tl:i: does not parse"); }
+            else if (!memcmp(p, "cn:i:", 5)) { if (!parse_i64(val, te, r.cn)) return bad("cn:i: does not parse"); }
+            else if (!memcmp(p, "s1:i:", 5)) { if (!parse_i64(val, te, r.s1)) return bad("s1:i: does not parse"); }
+            else if (!memcmp(p, "cg:Z:", 5)) {
+                r.has_cg = 1;
+                r.ops_off = set.ops.size();
+                for (const char *c = val; c < te;) {
+                    uint64_t len = 0;
+                    if (*c < '0' || *c > '9') return bad("cigar: a length is expected");
+                    while (c < te && *c >= '0' && *c <= '9') { len = len * 10 + (uint64_t)(*c++ - '0'); if (len >= (1u << 28)) return bad("cigar: op longer than 2^28"); }
+                    if (c == te) return bad("cigar: op letter missing");
+                    uint32_t code = *c == '=' ? kOpEq : *c == 'X' ? kOpX : *c == 'M' ? kOpM : *c == 'I' ? kOpI : *c == 'D' ? kOpD : 99u;
+                    if (code == 99u || len == 0) return bad("cigar: unknown op or zero length");
+                    c++;
+                    set.ops.push_back((uint32_t)(len << 3) | code);
+                }
+                r.n_ops = (uint32_t)(set.ops.size() - r.ops_off);
+            }
+        }
+        p = t ? t + 1 : e;
+    }
+    set.recs.push_back(r);
+    return MIBLAST_OK;
+}
+
+int parse_text(PafSet &set, const char *text, size_t len) {
+    size_t line_no = 0;
+    for (const char *p = text, *end = text + len; p < end;) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *e = nl ? nl : end;
+        const char *le = e;
+        while (le > p && (le[-1] == '\r' || le[-1] == '\n')) le--;
+        line_no++;
+        if (le > p) {
+            int rc = parse_line(set, p, le, line_no);
+            if (rc != MIBLAST_OK) return rc;
+        }
+        p = nl ? nl + 1 : end;
+    }
+    return MIBLAST_OK;
+}
+
+// ---- records -> text -----------------------------------------------------------------------------------------------
+void put_i64(std::string &out, int64_t v) {
+    char buf[24];
+    auto r = std::to_chars(buf, buf + sizeof buf, v);
+    out.append(buf, (size_t)(r.ptr - buf));
+}
+
+void format_rec(const PafSet &set, const PafRec &r, std::string &out) {
+    static const char kOpCh[5] = {'=', 'X', 'M', 'I', 'D'};
+    out += set.names[r.qn]; out += '\t';
+    put_i64(out, r.ql); out += '\t'; put_i64(out, r.qs); out += '\t'; put_i64(out, r.qe); out += '\t';
+    out += r.same ? '+' : '-'; out += '\t';
+    out += set.names[r.tn]; out += '\t';
+    put_i64(out, r.tl); out += '\t'; put_i64(out, r.ts); out += '\t'; put_i64(out, r.te); out += '\t';
+    put_i64(out, r.nm); out += '\t'; put_i64(out, r.nb); out += '\t'; put_i64(out, r.mq);
+    if (r.tp || r.tile != -1) { out += "\ttp:A:"; out += r.tp ? r.tp : (r.tile > 1 ? 'S' : 'P'); }
+    if (r.has_as) { out += "\tAS:i:"; put_i64(out, r.as); }
+    if (r.tile != -1) { out += "\ttl:i:"; put_i64(out, r.tile); }
+    if (r.cn != -1) { out += "\tcn:i:"; put_i64(out, r.cn); }
+    if (r.s1 != -1) { out += "\ts1:i:"; put_i64(out, r.s1); }
+    if (r.has_cg) {
+        out += "\tcg:Z:";
+        for (uint32_t k = 0; k < r.n_ops; k++) {
+            const uint32_t o = set.ops[r.ops_off + k];
+            put_i64(out, (int64_t)(o >> 3));
+            out += kOpCh[o & 7u];
+        }
+    }
+    out += '\n';
+}
+
+std::string format_set(const PafSet &set) {
+    std::string out;
+    out.reserve(set.recs.size() * 96 + set.ops.size() * 4);
+    for (const PafRec &r : set.recs) format_rec(set, r, out);
+    return out;
+}
+
+int write_all(int fd, const char *p, size_t n) {
+    while (n) {
+        ssize_t w = write(fd, p, n);
+        if (w < 0) { set_error("write failed"); return MIBLAST_EIO; }
+        p += w; n -= (size_t)w;
+    }
+    return MIBLAST_OK;
+}
+
+// a cigar must walk exactly the intervals of its record (the contract caf asserts later)
+int check_cigars(const PafSet &set) {
+    for (size_t i = 0; i < set.recs.size(); i++) {
+        const PafRec &r = set.recs[i];
+        bool ok = r.qs >= 0 && r.qs <= r.qe && r.qe <= r.ql && r.ts >= 0 && r.ts <= r.te && r.te <= r.tl;
+        if (ok && r.has_cg) {
+            int64_t q = 0, t = 0;
+            for (uint32_t k = 0; k < r.n_ops; k++) {
+                const uint32_t o = set.ops[r.ops_off + k];
+                if ((o & 7u) != kOpD) q += o >> 3;
+                if ((o & 7u) != kOpI) t += o >> 3;
+            }
+            ok = q == r.qe - r.qs && t == r.te - r.ts;
+        }
+        if (!ok) {
+            set_error("PAF record " + std::to_string(i + 1) + ": coordinates and cigar do not agree");
+            return MIBLAST_EINVAL;
+        }
+    }
+    return MIBLAST_OK;
+}
+
+int64_t record_score(const PafRec &r) { return r.has_as ? r.as : r.nm; }
+
+// ---- paffy chain ---------------------------------------------------------------------------------------------------
+void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st) {
+    const size_t n = set.recs.size();
+    st.records = (int64_t)n;
+    if (n == 0) return;
+    if (n >= (1ull << 31)) throw std::length_error("more than 2^31 PAF records in one chaining job");
+    MB_HIP(hipSetDevice(ctx.device));
+    hipStream_t s = ctx.stream;
+    // R-C1: names compare as byte strings; a group = (query, target, strand), numbered in that order
+    std::vector<uint32_t> by_name(set.names.size()), name_rank(set.names.size());
+    for (uint32_t i = 0; i < by_name.size(); i++) by_name[i] = i;
+    std::sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) { return strcmp(set.names[a].c_str(), set.names[b].c_str()) < 0; });
+    for (uint32_t i = 0; i < by_name.size(); i++) name_rank[by_name[i]] = i;
+    std::vector<unsigned long long> gkey(n);
+    for (size_t i = 0; i < n; i++) {
+        const PafRec &r = set.recs[i];
+        gkey[i] = ((unsigned long long)name_rank[r.qn] << 33) | ((unsigned long long)name_rank[r.tn] << 1) | (unsigned long long)r.same;
+    }
+    std::vector<unsigned long long> uniq(gkey);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    const size_t ng = uniq.size();
+    st.groups = (int64_t)ng;
+    std::vector<unsigned long long> k_grp(n), k_qs(n), k_ts(n);
+    std::vector<ChainRec> crec(n);
+    std::vector<uint32_t> gcount(ng + 1, 0);
+    std::vector<int64_t> glmax(ng, 0);
+    unsigned long long max_qs = 0, max_ts = 0;
+    for (size_t i = 0; i < n; i++) {
+        const PafRec &r = set.recs[i];
+        const size_t g = (size_t)(std::lower_bound(uniq.begin(), uniq.end(), gkey[i]) - uniq.begin());
+        k_grp[i] = g; k_qs[i] = (unsigned long long)r.qs; k_ts[i] = (unsigned long long)r.ts;
+        max_qs = std::max(max_qs, k_qs[i]); max_ts = std::max(max_ts, k_ts[i]);
+        gcount[g + 1]++;
+        glmax[g] = std::max(glmax[g], r.qe - r.qs);
+        // R-C2 (host arithmetic, the same expression as the oracle's)
+        const int64_t tq = (int64_t)((double)(r.qe - r.qs) * cp.trim_fraction / 2.0);
+        const int64_t tt = (int64_t)((double)(r.te - r.ts) * cp.trim_fraction / 2.0);
+        crec[i] = ChainRec{r.qs, r.qs + tq, r.qe - tq, r.ts + tt, r.te - tt, record_score(r), (int32_t)r.same, 0};
+    }
+    for (size_t g = 0; g < ng; g++) gcount[g + 1] += gcount[g];
+
+    Dev<unsigned long long> d_key(n), d_key2(n), d_ts, d_qs, d_grp;
+    Dev<uint32_t> d_pa(n), d_pb(n), d_gstart;
+    Dev<ChainRec> d_rec, d_sorted(n);
+    Dev<int64_t> d_lmax;
+    Dev<long long> d_cs(n);
+    Dev<int32_t> d_pred(n);
+    size_t temp_bytes = 0;
+    for (int bits : {bits_for(max_ts), bits_for(max_qs), bits_for(ng), 64}) temp_bytes = std::max(temp_bytes, sort_pairs_temp_bytes((int64_t)n, bits));
+    Dev<uint8_t> d_temp(temp_bytes);
+    d_rec.upload(crec, s);
+    d_gstart.upload(gcount, s);
+    d_lmax.upload(glmax, s);
+    d_ts.upload(k_ts, s);
+    d_qs.upload(k_qs, s);
+    d_grp.upload(k_grp, s);
+
+    EventTimer t_sort(s);
+    // LSD over the sort keys: target start, then query start, then group; ties keep the input order (the sorts are stable)
+    launch_iota(d_pa.p, (int64_t)n, s);
+    sort_pairs(d_temp.p, temp_bytes, d_ts.p, d_key2.p, d_pa.p, d_pb.p, (int64_t)n, bits_for(max_ts), s);
+    launch_gather_u64(d_qs.p, d_pb.p, d_key.p, (int64_t)n, s);
+    sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pb.p, d_pa.p, (int64_t)n, bits_for(max_qs), s);
+    launch_gather_u64(d_grp.p, d_pa.p, d_key.p, (int64_t)n, s);
+    sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pa.p, d_pb.p, (int64_t)n, bits_for(ng), s);
+    launch_gather_chain(d_rec.p, d_pb.p, d_sorted.p, (int64_t)n, s);
+    st.t_sort_ms += t_sort.stop_ms();
+
+    EventTimer t_dp(s);
+    launch_chain_dp(d_sorted.p, d_gstart.p, d_lmax.p, (int)ng, cp.max_gap_length, cp.gap_open, cp.gap_extend, d_cs.p, d_pred.p, s);
+    st.t_chain_dp_ms += t_dp.stop_ms();
+
+    // R-C6 order: chain score descending, R-C1 position on ties
+    EventTimer t_sort2(s);
+    launch_desc_keys(d_cs.p, d_key.p, (int64_t)n, s);
+    launch_iota(d_pa.p, (int64_t)n, s);
+    Dev<uint32_t> d_rank(n);
+    sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pa.p, d_rank.p, (int64_t)n, 64, s);
+    st.t_sort_ms += t_sort2.stop_ms();
+
+    std::vector<uint32_t> order, rank;
+    std::vector<long long> cs;
+    std::vector<int32_t> pred;
+    d_pb.download(order, s);                                // order[k] = input index of the k-th record in R-C1 order
+    d_rank.download(rank, s);
+    d_cs.download(cs, s);
+    d_pred.download(pred, s);
+    MB_HIP(hipStreamSynchronize(s));
+
+    // peel the chains off (R-C6): sequential by nature, O(n)
+    std::vector<int64_t> cn(n, -1), s1(n, -1);              // by R-C1 position
+    int64_t next_id = 0;
+    for (size_t k = 0; k < n; k++) {
+        uint32_t p = rank[k];
+        if (cn[p] != -1) continue;
+        const int64_t id = next_id++, score = cs[p];
+        for (;;) {
+            cn[p] = id; s1[p] = score;
+            if (pred[p] < 0 || cn[(size_t)pred[p]] != -1) break;
+            p = (uint32_t)pred[p];
+        }
+    }
+    // R-C7: chains by number, members in R-C1 order = a counting sort of the R-C1 positions by chain number
+    std::vector<size_t> at((size_t)next_id + 1, 0);
+    for (size_t p = 0; p < n; p++) at[(size_t)cn[p] + 1]++;
+    for (size_t c = 0; c < (size_t)next_id; c++) at[c + 1] += at[c];
+    std::vector<PafRec> out(n);
+    for (size_t p = 0; p < n; p++) {
+        PafRec r = set.recs[order[p]];
+        r.cn = cn[p]; r.s1 = s1[p];
+        out[at[(size_t)cn[p]]++] = r;
+    }
+    set.recs.swap(out);
+    // pairs (j before i) inside the groups: the upper bound of the candidates the DP inspects (56 B of ChainRec + 8 B of cs each)
+    st.chain_pairs = 0;
+    for (size_t g = 0; g < ng; g++) { const int64_t m = gcount[g + 1] - gcount[g]; st.chain_pairs += m * (m - 1) / 2; }
+}
+
+// ---- paffy tile ----------------------------------------------------------------------------------------------------
+void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
+    const size_t n = set.recs.size();
+    st.records = (int64_t)n;
+    if (n == 0) return;
+    if (n >= (1ull << 31)) throw std::length_error("more than 2^31 PAF records in one tiling job");
+    if (hist_bins <= 0) hist_bins = 4096;
+    hist_bins = std::min(8192, std::max(2, hist_bins));
+    MB_HIP(hipSetDevice(ctx.device));
+    hipStream_t s = ctx.stream;
+    // R-T1 order on the device, then grouped by query sequence (stable, so the order inside a sequence is kept)
+    std::vector<unsigned long long> key(n), qkey(n);
+    std::vector<uint32_t> qid_of_name(set.names.size(), UINT32_MAX);
+    std::vector<int64_t> qlen;
+    for (size_t i = 0; i < n; i++) {
+        const PafRec &r = set.recs[i];
+        const int64_t k = r.s1 != -1 ? r.s1 : record_score(r);
+        key[i] = ~((unsigned long long)k ^ 0x8000000000000000ull);
+        if (qid_of_name[r.qn] == UINT32_MAX) { qid_of_name[r.qn] = (uint32_t)qlen.size(); qlen.push_back(r.ql); }
+        qlen[qid_of_name[r.qn]] = std::max(qlen[qid_of_name[r.qn]], r.ql);
+        qkey[i] = qid_of_name[r.qn];
+    }
+    const size_t nq = qlen.size();
+    st.query_sequences = (int64_t)nq;
+    Dev<unsigned long long> d_key, d_key2(n), d_qkey, d_g(n);
+    Dev<uint32_t> d_pa(n), d_rank(n), d_grouped(n);
+    const size_t temp_bytes = std::max(sort_pairs_temp_bytes((int64_t)n, 64), sort_pairs_temp_bytes((int64_t)n, bits_for(nq)));
+    Dev<uint8_t> d_temp(temp_bytes);
+    d_key.upload(key, s);
+    d_qkey.upload(qkey, s);
+    EventTimer t_sort(s);
+    launch_iota(d_pa.p, (int64_t)n, s);
+    sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pa.p, d_rank.p, (int64_t)n, 64, s);
+    launch_gather_u64(d_qkey.p, d_rank.p, d_g.p, (int64_t)n, s);
+    sort_pairs(d_temp.p, temp_bytes, d_g.p, d_key2.p, d_rank.p, d_grouped.p, (int64_t)n, bits_for(nq), s);
+    st.t_sort_ms += t_sort.stop_ms();
+    std::vector<uint32_t> rank, grouped;
+    d_rank.download(rank, s);
+    d_grouped.download(grouped, s);
+    MB_HIP(hipStreamSynchronize(s));
+
+    // per-op query offsets (op order) and the records as the kernel reads them
+    std::vector<uint32_t> qoff(set.ops.size());
+    std::vector<TileRec> trec(n);
+    std::vector<uint32_t> qstart(nq + 1, 0);
+    for (size_t k = 0; k < n; k++) {
+        const PafRec &r = set.recs[grouped[k]];
+        uint32_t q = 0;
+        if (r.has_cg)
+            for (uint32_t o = 0; o < r.n_ops; o++) {
+                qoff[r.ops_off + o] = q;
+                if ((set.ops[r.ops_off + o] & 7u) != kOpD) q += set.ops[r.ops_off + o] >> 3;
+            }
+        trec[k] = TileRec{r.ops_off, r.has_cg ? r.n_ops : 0u, (int32_t)r.same, r.qs, r.qe, grouped[k], 0u};
+        qstart[qid_of_name[r.qn] + 1]++;
+    }
+    for (size_t q = 0; q < nq; q++) qstart[q + 1] += qstart[q];
+    std::vector<uint64_t> cnt_off(nq + 1, 0);
+    for (size_t q = 0; q < nq; q++) cnt_off[q + 1] = cnt_off[q] + (uint64_t)std::max<int64_t>(qlen[q], 0);
+    st.ops = (int64_t)set.ops.size();
+
+    Dev<TileRec> d_rec;
+    Dev<uint32_t> d_qstart, d_ops, d_qoff;
+    Dev<uint64_t> d_cnt_off;
+    Dev<uint16_t> d_cnt((size_t)cnt_off[nq]);
+    Dev<int32_t> d_level(n);
+    d_rec.upload(trec, s);
+    d_qstart.upload(qstart, s);
+    d_cnt_off.upload(cnt_off, s);
+    d_ops.upload(set.ops, s);
+    d_qoff.upload(qoff, s);
+    MB_HIP(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(1, (size_t)cnt_off[nq]) * sizeof(uint16_t), s));
+    EventTimer t_tile(s);
+    launch_tile(d_rec.p, d_qstart.p, d_cnt_off.p, (int)nq, d_cnt.p, d_ops.p, d_qoff.p, hist_bins, d_level.p, s);
+    st.t_tile_ms += t_tile.stop_ms();
+    std::vector<int32_t> level;
+    d_level.download(level, s);
+    MB_HIP(hipStreamSynchronize(s));
+    std::vector<PafRec> out(n);
+    for (size_t k = 0; k < n; k++) {                         // R-T5
+        PafRec r = set.recs[rank[k]];
+        r.tile = level[rank[k]];
+        r.tp = r.tile == 1 ? 'P' : 'S';
+        out[k] = r;
+    }
+    set.recs.swap(out);
+}
+
+// ---- paffy trim ----------------------------------------------------------------------------------------------------
+bool parse_fraction(const char *s, long long &num, long long &den) {
+    num = 0; den = 1;
+    int digits = 0;
+    bool dot = false;
+    if (!s) return false;
+    for (; *s; s++) {
+        if (*s == '.' && !dot) { dot = true; continue; }
+        if (*s < '0' || *s > '9' || ++digits > 6) return false;
+        num = num * 10 + (*s - '0');
+        if (dot) den *= 10;
+    }
+    return digits > 0 && num <= den;
+}
+
+void trim(Ctx &ctx, PafSet &set, long long num, long long den, mipaf_stats &st) {
+    const size_t n = set.recs.size();
+    st.records = (int64_t)n;
+    std::vector<TrimRec> trec;
+    std::vector<uint32_t> which;
+    std::vector<uint8_t> drop(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (set.recs[i].has_cg && set.recs[i].n_ops) { trec.push_back(TrimRec{set.recs[i].ops_off, set.recs[i].n_ops, 0u}); which.push_back((uint32_t)i); }
+        else if (set.recs[i].has_cg) drop[i] = 1;             // an empty cigar has no column to keep (R-R3)
+    }
+    std::vector<TrimOut> res;
+    if (!trec.empty()) {
+        MB_HIP(hipSetDevice(ctx.device));
+        hipStream_t s = ctx.stream;
+        Dev<TrimRec> d_rec;
+        Dev<uint32_t> d_ops;
+        Dev<TrimOut> d_out(trec.size());
+        d_rec.upload(trec, s);
+        d_ops.upload(set.ops, s);
+        st.ops = (int64_t)set.ops.size();
+        EventTimer t(s);
+        launch_trim(d_rec.p, (int64_t)trec.size(), d_ops.p, num, den, d_out.p, s);
+        st.t_trim_ms += t.stop_ms();
+        d_out.download(res, s);
+        MB_HIP(hipStreamSynchronize(s));
+    }
+    for (size_t k = 0; k < res.size(); k++) {
+        PafRec &r = set.recs[which[k]];
+        const TrimOut &t = res[k];
+        if (t.pre + t.suf >= t.cols) { drop[which[k]] = 1; continue; }      // R-R3
+        if (t.pre == 0 && t.suf == 0) continue;
+        uint32_t *ops = set.ops.data() + r.ops_off;
+        const uint32_t code_f = ops[t.first_op] & 7u, code_l = ops[t.last_op] & 7u;
+        if (t.first_op == t.last_op) {
+            const uint32_t len = ops[t.first_op] >> 3;
+            ops[t.first_op] = ((t.first_len + t.last_len - len) << 3) | code_f;
+        } else {
+            ops[t.first_op] = (t.first_len << 3) | code_f;
+            ops[t.last_op] = (t.last_len << 3) | code_l;
+        }
+        r.ops_off += t.first_op;
+        r.n_ops = t.last_op - t.first_op + 1;
+        r.ts += t.ta; r.te -= t.tb;
+        if (r.same) { r.qs += t.qa; r.qe -= t.qb; } else { r.qe -= t.qa; r.qs += t.qb; }
+        r.nm = t.nm; r.nb = t.nb;
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < n; i++)
+        if (!drop[i]) set.recs[w++] = set.recs[i];
+    set.recs.resize(w);
+}
+
+void invert(PafSet &set) {
+    for (PafRec &r : set.recs) {
+        std::swap(r.qn, r.tn); std::swap(r.ql, r.tl); std::swap(r.qs, r.ts); std::swap(r.qe, r.te);
+        if (!r.has_cg) continue;
+        uint32_t *ops = set.ops.data() + r.ops_off;
+        if (!r.same) std::reverse(ops, ops + r.n_ops);
+        for (uint32_t k = 0; k < r.n_ops; k++) {
+            const uint32_t c = ops[k] & 7u;
+            if (c == kOpI || c == kOpD) ops[k] = (ops[k] & ~7u) | (c == kOpI ? kOpD : kOpI);
+        }
+    }
+}
+
+void filter(PafSet &set, int64_t max_tile, int64_t min_chain, bool inv) {
+    size_t w = 0;
+    for (size_t i = 0; i < set.recs.size(); i++) {
+        const PafRec &r = set.recs[i];
+        const bool ok = (max_tile < 0 || r.tile <= max_tile) && (min_chain < 0 || r.s1 >= min_chain);
+        if (ok != inv) set.recs[w++] = r;
+    }
+    set.recs.resize(w);
+}
+
+template <typename F>
+int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const HipFailure &e) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "HIP call did not succeed: %s -> %s (%s:%d)", e.what, hipGetErrorString(e.code), e.file, e.line);
+        set_error(buf);
+        return e.code == hipErrorNoDevice || e.code == hipErrorInvalidDevice ? MIBLAST_ENODEV : MIBLAST_EHIP;
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory");
+        return MIBLAST_ELIMIT;
+    } catch (const std::length_error &e) {
+        set_error(e.what());
+        return MIBLAST_ELIMIT;
+    } catch (const std::exception &e) {
+        set_error(std::string("internal: ") + e.what());
+        return MIBLAST_EHIP;
+    }
+}
+
+int need(const void *ctx, const void *s, const char *fn) {
+    if (!s) { set_error(std::string(fn) + ": null set"); return MIBLAST_EINVAL; }
+    if (!ctx) { set_error(std::string(fn) + ": no device context (this build has no CPU path)"); return MIBLAST_ENODEV; }
+    return MIBLAST_OK;
+}
+
+}  // namespace
+}  // namespace mb
+
+struct mipaf_set { mb::PafSet s; };
+
+extern "C" {
+
+int mipaf_set_from_mem(const char *text, size_t len, mipaf_set **out) {
+    return mb::guarded([&] {
+        if (!out || (!text && len)) { mb::set_error("mipaf_set_from_mem: null argument"); return (int)MIBLAST_EINVAL; }
+        mipaf_set *s = new mipaf_set();
+        int rc = mb::parse_text(s->s, text, len);
+        if (rc != MIBLAST_OK) { delete s; return rc; }
+        *out = s;
+        return (int)MIBLAST_OK;
+    });
+}
+
+int mipaf_set_from_file(const char *path, mipaf_set **out) {
+    return mb::guarded([&] {
+        if (!path || !out) { mb::set_error("mipaf_set_from_file: null argument"); return (int)MIBLAST_EINVAL; }
+        std::string text;
+        if (!strcmp(path, "-") || !strcmp(path, "/dev/stdin")) {
+            char buf[1 << 16];
+            ssize_t got;
+            while ((got = read(0, buf, sizeof buf)) > 0) text.append(buf, (size_t)got);
+        } else {
+            std::ifstream f(path, std::ios::binary);
+            if (!f) { mb::set_error(std::string("cannot open ") + path); return (int)MIBLAST_EIO; }
+            text.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        }
+        return mipaf_set_from_mem(text.data(), text.size(), out);
+    });
+}
+
+void mipaf_set_free(mipaf_set *s) { delete s; }
+int64_t mipaf_set_size(const mipaf_set *s) { return s ? (int64_t)s->s.recs.size() : 0; }
+
+int mipaf_set_text(const mipaf_set *s, char **text, size_t *len) {
+    return mb::guarded([&] {
+        if (!s || !text || !len) { mb::set_error("mipaf_set_text: null argument"); return (int)MIBLAST_EINVAL; }
+        std::string t = mb::format_set(s->s);
+        char *buf = (char *)malloc(t.size() + 1);
+        if (!buf) throw std::bad_alloc();
+        memcpy(buf, t.data(), t.size());
+        buf[t.size()] = 0;
+        *text = buf; *len = t.size();
+        return (int)MIBLAST_OK;
+    });
+}
+
+int mipaf_set_write(const mipaf_set *s, int fd) {
+    return mb::guarded([&] {
+        if (!s) { mb::set_error("mipaf_set_write: null set"); return (int)MIBLAST_EINVAL; }
+        std::string t = mb::format_set(s->s);
+        return mb::write_all(fd, t.data(), t.size());
+    });
+}
+
+int mipaf_invert(mipaf_set *s) {
+    return mb::guarded([&] {
+        if (!s) { mb::set_error("mipaf_invert: null set"); return (int)MIBLAST_EINVAL; }
+        mb::invert(s->s);
+        return (int)MIBLAST_OK;
+    });
+}
+
+void mipaf_chain_params_default(mipaf_chain_params *p) {
+    p->max_gap_length = 1000000; p->gap_open = 5000; p->gap_extend = 1; p->trim_fraction = 1.0;
+}
+
+int mipaf_chain(miblast_ctx *ctx, mipaf_set *s, const mipaf_chain_params *p, mipaf_stats *stats) {
+    return mb::guarded([&] {
+        int rc = mb::need(ctx, s, "mipaf_chain");
+        if (rc != MIBLAST_OK) return rc;
+        mipaf_chain_params cp;
+        mipaf_chain_params_default(&cp);
+        if (p) cp = *p;
+        if (cp.max_gap_length < 0 || cp.trim_fraction < 0.0 || cp.trim_fraction > 1.0) { mb::set_error("mipaf_chain: parameter out of range"); return (int)MIBLAST_EINVAL; }
+        mipaf_stats st{};
+        const double t0 = mb::now_s();
+        mb::chain(ctx->c, s->s, cp, st);
+        st.t_total_s = mb::now_s() - t0;
+        if (stats) *stats = st;
+        return (int)MIBLAST_OK;
+    });
+}
+
+int mipaf_tile(miblast_ctx *ctx, mipaf_set *s, int32_t hist_bins, mipaf_stats *stats) {
+    return mb::guarded([&] {
+        int rc = mb::need(ctx, s, "mipaf_tile");
+        if (rc != MIBLAST_OK) return rc;
+        rc = mb::check_cigars(s->s);
+        if (rc != MIBLAST_OK) return rc;
+        mipaf_stats st{};
+        const double t0 = mb::now_s();
+        mb::tile(ctx->c, s->s, hist_bins, st);
+        st.t_total_s = mb::now_s() - t0;
+        if (stats) *stats = st;
+        return (int)MIBLAST_OK;
+    });
+}
+
+int mipaf_trim(miblast_ctx *ctx, mipaf_set *s, const char *trim_identity, mipaf_stats *stats) {
+    return mb::guarded([&] {
+        int rc = mb::need(ctx, s, "mipaf_trim");
+        if (rc != MIBLAST_OK) return rc;
+        long long num, den;
+        if (!mb::parse_fraction(trim_identity, num, den)) { mb::set_error("mipaf_trim: --trimIdentity must be a decimal in [0, 1] with at most 6 digits"); return (int)MIBLAST_EINVAL; }
+        rc = mb::check_cigars(s->s);
+        if (rc != MIBLAST_OK) return rc;
+        mipaf_stats st{};
+        const double t0 = mb::now_s();
+        mb::trim(ctx->c, s->s, num, den, st);
+        st.t_total_s = mb::now_s() - t0;
+        if (stats) *stats = st;
+        return (int)MIBLAST_OK;
+    });
+}
+
+int mipaf_filter(mipaf_set *s, int64_t max_tile_level, int64_t min_chain_score, int32_t invert) {
+    return mb::guarded([&] {
+        if (!s) { mb::set_error("mipaf_filter: null set"); return (int)MIBLAST_EINVAL; }
+        mb::filter(s->s, max_tile_level, min_chain_score, invert != 0);
+        return (int)MIBLAST_OK;
+    });
+}
+
+int mipaf_split_by_query(const mipaf_set *s, const char *prefix, int64_t min_length, int32_t *n_parts) {
+    return mb::guarded([&] {
+        if (!s || !prefix) { mb::set_error("mipaf_split_by_query: null argument"); return (int)MIBLAST_EINVAL; }
+        const mb::PafSet &set = s->s;
+        std::vector<int32_t> part_of(set.names.size(), -1);
+        std::vector<std::string> parts;
+        int32_t part = 0;
+        int64_t acc = 0;
+        for (const mb::PafRec &r : set.recs) {                // R-S1
+            if (part_of[r.qn] < 0) {
+                part_of[r.qn] = part;
+                if ((size_t)part == parts.size()) parts.emplace_back();
+                acc += r.ql;
+                if (acc >= min_length) { part++; acc = 0; }
+            }
+            mb::format_rec(set, r, parts[(size_t)part_of[r.qn]]);
+        }
+        for (size_t k = 0; k < parts.size(); k++) {
+            const std::string path = std::string(prefix) + std::to_string(k) + ".paf";
+            FILE *f = fopen(path.c_str(), "wb");
+            if (!f || fwrite(parts[k].data(), 1, parts[k].size(), f) != parts[k].size()) { if (f) fclose(f); mb::set_error("cannot write " + path); return (int)MIBLAST_EIO; }
+            fclose(f);
+        }
+        if (n_parts) *n_parts = (int32_t)parts.size();
+        return (int)MIBLAST_OK;
+    });
+}
+
+int mipaf_chain_tile_trim_filter(miblast_ctx *ctx, mipaf_set *s, const mipaf_chain_params *p, const char *trim_identity,
+                                 int64_t min_primary_chain_score, int32_t output_secondary, mipaf_stats *stats) {
+    return mb::guarded([&] {
+        int rc = mb::need(ctx, s, "mipaf_chain_tile_trim_filter");
+        if (rc != MIBLAST_OK) return rc;
+        mipaf_chain_params cp;
+        mipaf_chain_params_default(&cp);
+        if (p) cp = *p;
+        long long num, den;
+        if (!mb::parse_fraction(trim_identity, num, den)) { mb::set_error("mipaf_chain_tile_trim_filter: bad trim identity"); return (int)MIBLAST_EINVAL; }
+        rc = mb::check_cigars(s->s);
+        if (rc != MIBLAST_OK) return rc;
+        mipaf_stats st{};
+        const double t0 = mb::now_s();
+        mb::PafSet &set = s->s;
+        mb::chain(ctx->c, set, cp, st);                       // local_alignment.py:684-690 (and :694-699)
+        mb::tile(ctx->c, set, 0, st);
+        mb::trim(ctx->c, set, num, den, st);
+        mb::filter(set, 1, -1, false);
+        std::vector<mb::PafRec> secondary;
+        if (output_secondary)                                 // :702-704 applies `filter --maxTileLevel 1 --invert` to filter.paf, i.e. to
+            for (const mb::PafRec &r : set.recs)              // what the line above already kept: as in the reference, nothing passes
+                if (!(r.tile <= 1)) secondary.push_back(r);
+        mb::chain(ctx->c, set, cp, st);
+        if (output_secondary) {                               // :710-723
+            std::vector<mb::PafRec> out(secondary);
+            for (const mb::PafRec &r : set.recs) if (r.s1 >= min_primary_chain_score) out.push_back(r);
+            for (mb::PafRec r : set.recs)
+                if (!(r.s1 >= min_primary_chain_score)) {     // sed 's/tp:A:P/tp:A:S/' | sed 's/tl:i:1/tl:i:2/'
+                    if (r.tp == 'P') r.tp = 'S';
+                    if (r.tile == 1) r.tile = 2;
+                    out.push_back(r);
+                }
+            set.recs.swap(out);
+        } else {
+            mb::filter(set, -1, min_primary_chain_score, false);
+        }
+        st.records = (int64_t)set.recs.size();
+        st.t_total_s = mb::now_s() - t0;
+        if (stats) *stats = st;
+        return (int)MIBLAST_OK;
+    });
+}
+
+}  // extern "C"

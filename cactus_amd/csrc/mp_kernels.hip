@@ -1,0 +1,301 @@
+// mp_kernels.hip -- gfx950 kernels of the chaining stage (rules in DESIGN.md section 11).
+//
+//   sort_pairs / k_iota / k_gather_*   ordering of alignment records (R-C1, R-C6, R-C7, R-T1): stable LSD radix sorts of
+//                                       (key, index) pairs, one pass per sort key, keys re-gathered through the permutation
+//   k_chain_dp                          R-C3..R-C5: one workgroup per (query, target, strand) group; the records of a group are
+//                                       visited in R-C1 order, the 256 lanes share the scan of the predecessor window
+//   k_tile                              R-T2..R-T4: one workgroup per query sequence; per alignment a histogram of the
+//                                       per-base cover counters (LDS) gives the median, then the counters go up
+//   k_trim                              R-R1..R-R3: one lane per alignment, closed-form cut inside every op
+//
+// All of it is integer work on coordinates, scores and cigar ops; nothing here touches sequence bytes.
+#include "mp_common.h"
+
+#include <climits>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace mb {
+
+// ------------------------------------------------------------------------------------------------
+size_t sort_pairs_temp_bytes(int64_t n, int end_bit) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                    (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, end_bit, (hipStream_t)0);
+    return bytes;
+}
+
+void sort_pairs(void *temp, size_t temp_bytes, const unsigned long long *kin, unsigned long long *kout, const uint32_t *vin,
+                uint32_t *vout, int64_t n, int end_bit, hipStream_t s) {
+    if (sort_pairs_temp_bytes(n, end_bit) > temp_bytes) throw HipFailure{hipErrorInvalidValue, "sort_pairs: temporary storage too small", __FILE__, __LINE__};
+    MB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, s));
+}
+
+__global__ void k_iota(uint32_t *__restrict__ v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+void launch_iota(uint32_t *v, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n);
+}
+
+__global__ void k_gather_u64(const unsigned long long *__restrict__ src, const uint32_t *__restrict__ perm,
+                             unsigned long long *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+void launch_gather_u64(const unsigned long long *src, const uint32_t *perm, unsigned long long *dst, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, perm, dst, n);
+}
+
+// descending order of signed scores as an ascending u64 key
+__global__ void k_desc_keys(const long long *__restrict__ v, unsigned long long *__restrict__ key, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = ~((unsigned long long)v[i] ^ 0x8000000000000000ull);
+}
+void launch_desc_keys(const long long *v, unsigned long long *key, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_desc_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, key, n);
+}
+
+__global__ void k_gather_chain(const ChainRec *__restrict__ src, const uint32_t *__restrict__ perm, ChainRec *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+void launch_gather_chain(const ChainRec *src, const uint32_t *perm, ChainRec *dst, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_chain, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, perm, dst, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chain DP.  recs are in R-C1 order, group g = [gstart[g], gstart[g+1]).  cs_i needs cs_j of every earlier record of
+// the group, so a group is walked in order; the predecessor window of record i starts at the first j with
+// qs_j >= tqs_i - maxGap - (longest query span of the group): an earlier j ends too far back to satisfy gq <= maxGap.
+// Per lane candidates are visited in ascending j with a strict ">", the cross-lane reduction prefers the smaller j on
+// equal values: together the first maximal j in R-C1 order (R-C5).
+__global__ __launch_bounds__(256) void k_chain_dp(const ChainRec *__restrict__ recs, const uint32_t *__restrict__ gstart,
+                                                  const int64_t *__restrict__ glmax, const long long G, const long long gap_open,
+                                                  const long long gap_extend, long long *cs, int32_t *__restrict__ pred) {
+    const int g = blockIdx.x;
+    const int lo = (int)gstart[g], hi = (int)gstart[g + 1];
+    const long long lmax = glmax[g];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ long long s_val[4];
+    __shared__ int s_j[4];
+    for (int i = lo; i < hi; i++) {
+        const ChainRec r = recs[i];
+        const long long need = r.tqs - G - lmax;
+        int a = lo, b = i;
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (recs[m].qs < need) a = m + 1; else b = m;
+        }
+        long long best = 0;
+        int bj = INT_MAX;
+        for (int j = a + tid; j < i; j += 256) {
+            const ChainRec q = recs[j];
+            const long long gq = r.tqs - q.tqe;
+            const long long gt = r.same ? r.tts - q.tte : q.tts - r.tte;
+            if (gq >= 0 && gt >= 0 && gq <= G && gt <= G) {
+                const long long val = cs[j] - (gap_open + gap_extend * (gq + gt));
+                if (val > best) { best = val; bj = j; }
+            }
+        }
+        for (int off = 32; off; off >>= 1) {
+            const long long ov = __shfl_xor(best, off);
+            const int oj = __shfl_xor(bj, off);
+            if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_j[wave] = bj; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; w++)
+                if (s_val[w] > best || (s_val[w] == best && s_j[w] < bj)) { best = s_val[w]; bj = s_j[w]; }
+            cs[i] = r.score + best;
+            pred[i] = best > 0 ? bj : -1;
+        }
+        __syncthreads();                                   // cs[i] is read by the records that follow
+    }
+}
+
+void launch_chain_dp(const ChainRec *recs, const uint32_t *gstart, const int64_t *glmax, int n_groups, long long max_gap,
+                     long long gap_open, long long gap_extend, long long *cs, int32_t *pred, hipStream_t s) {
+    if (n_groups > 0)
+        hipLaunchKernelGGL(k_chain_dp, dim3((unsigned)n_groups), dim3(256), 0, s, recs, gstart, glmax, max_gap, gap_open, gap_extend, cs, pred);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiling.  recs are grouped by query sequence (block q owns [qstart[q], qstart[q+1])), inside a group in R-T1 order.
+// cnt + cnt_off[q] are the u16 cover counters of the sequence.  Wave w takes ops w, w+4, ... of the alignment, its lanes
+// the bases of the op (qoff[k] = query bases before op k, in op order; on the '-' strand the ops run down the query).
+// The median comes from a histogram of the counters in LDS: bins 0 .. bins-2 are exact, bin bins-1 lumps everything
+// above; when the median lies in there it is found by bisection over re-walks of the alignment (never seen with real
+// inputs -- it needs half of an alignment's bases covered by thousands of better ones -- and exercised by the tests with
+// a tiny histogram).
+template <typename F>
+__device__ __forceinline__ void for_aligned_bases(const TileRec &r, const uint32_t *__restrict__ ops, const uint32_t *__restrict__ qoff,
+                                                  int wave, int lane, F &&f) {
+    for (uint32_t o = (uint32_t)wave; o < r.n_ops; o += 4) {
+        const uint32_t op = ops[r.ops_off + o];
+        if ((op & 7u) > kOpM) continue;
+        const uint32_t len = op >> 3;
+        const long long q0 = (long long)qoff[r.ops_off + o];
+        for (uint32_t j = (uint32_t)lane; j < len; j += 64) f(r.same ? r.qs + q0 + j : r.qe - 1 - q0 - j);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile(const TileRec *__restrict__ recs, const uint32_t *__restrict__ qstart,
+                                              const uint64_t *__restrict__ cnt_off, uint16_t *cnt, const uint32_t *__restrict__ ops,
+                                              const uint32_t *__restrict__ qoff, const int bins, int32_t *__restrict__ level_out) {
+    extern __shared__ unsigned hist[];
+    __shared__ unsigned long long s_aligned, s_count;
+    __shared__ unsigned s_max;
+    __shared__ int s_level;
+    const int qi = blockIdx.x;
+    uint16_t *c = cnt + cnt_off[qi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned top = (unsigned)bins - 1u;
+    unsigned dirty = top;                                   // highest bin that may be non-zero
+    for (uint32_t k = qstart[qi]; k < qstart[qi + 1]; k++) {
+        const TileRec r = recs[k];
+        for (unsigned b = (unsigned)tid; b <= dirty; b += 256) hist[b] = 0;
+        if (tid == 0) { s_aligned = 0; s_max = 0; s_level = -1; }
+        __syncthreads();
+        unsigned long long al = 0;
+        unsigned mx = 0;
+        for_aligned_bases(r, ops, qoff, wave, lane, [&](long long b) {
+            const unsigned v = c[b];
+            atomicAdd(&hist[v < top ? v : top], 1u);
+            mx = v > mx ? v : mx;
+            al++;
+        });
+        for (int off = 32; off; off >>= 1) {
+            al += __shfl_xor(al, off);
+            const unsigned om = __shfl_xor(mx, off);
+            mx = om > mx ? om : mx;
+        }
+        if (lane == 0) { atomicAdd(&s_aligned, al); atomicMax(&s_max, mx); }
+        __syncthreads();
+        const unsigned long long aligned = s_aligned;
+        const unsigned maxl = s_max;
+        if (tid == 0) {
+            int level = 0;
+            if (aligned > 0) {
+                level = -1;
+                unsigned long long cum = 0;
+                const unsigned last = maxl < top ? maxl : top - 1u;      // bins 0 .. top-1 are exact (bins >= 2)
+                for (unsigned l = 0; l <= last; l++) {
+                    cum += hist[l];
+                    if (2 * cum >= aligned) { level = (int)l; break; }
+                }
+            }
+            s_level = level;
+        }
+        __syncthreads();
+        int level = s_level;
+        if (level < 0) {                                    // the median is >= top: bisect on #(counter <= mid)
+            unsigned a = top, b = maxl;
+            while (a < b) {
+                const unsigned mid = a + (b - a) / 2;
+                if (tid == 0) s_count = 0;
+                __syncthreads();
+                unsigned long long n_le = 0;
+                for_aligned_bases(r, ops, qoff, wave, lane, [&](long long x) { n_le += c[x] <= mid; });
+                for (int off = 32; off; off >>= 1) n_le += __shfl_xor(n_le, off);
+                if (lane == 0) atomicAdd(&s_count, n_le);
+                __syncthreads();
+                const unsigned long long tot = s_count;
+                __syncthreads();
+                if (2 * tot >= aligned) b = mid; else a = mid + 1;
+            }
+            level = (int)a;
+        }
+        if (tid == 0) level_out[r.rec] = level + 1;
+        for_aligned_bases(r, ops, qoff, wave, lane, [&](long long b) {
+            const unsigned v = c[b];
+            if (v < 32767u) c[b] = (uint16_t)(v + 1u);
+        });
+        dirty = maxl < top ? maxl : top;
+        __syncthreads();                                    // the counters are read by the next alignment of the sequence
+    }
+}
+
+void launch_tile(const TileRec *recs, const uint32_t *qstart, const uint64_t *cnt_off, int n_queries, uint16_t *cnt,
+                 const uint32_t *ops, const uint32_t *qoff, int hist_bins, int32_t *level, hipStream_t s) {
+    if (n_queries > 0)
+        hipLaunchKernelGGL(k_tile, dim3((unsigned)n_queries), dim3(256), (size_t)hist_bins * sizeof(unsigned), s, recs, qstart, cnt_off, cnt,
+                           ops, qoff, hist_bins, level);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Trim by identity.  The longest prefix with matches / columns < num / den: inside a run of non-matching columns the
+// identity only falls, so only the end of the run can be the longest; inside a run of matches that starts with m
+// matches in c columns, (m + t) / (c + t) < num / den  <=>  t (den - num) < num c - den m, a closed form for the last t.
+__device__ __forceinline__ void identity_cut(const uint32_t *__restrict__ ops, uint32_t n, bool rev, long long num, long long den,
+                                             long long &cut, long long &cols, long long &matches) {
+    long long m = 0, c = 0;
+    cut = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t o = ops[rev ? n - 1 - k : k];
+        const long long len = o >> 3;
+        const uint32_t code = o & 7u;
+        if (code == kOpEq || code == kOpM) {
+            const long long rhs = num * c - den * m;
+            long long t = 0;
+            if (den == num) t = rhs > 0 ? len : 0;
+            else if (rhs > 0) { t = (rhs + (den - num) - 1) / (den - num) - 1; if (t > len) t = len; }
+            if (t >= 1) cut = c + t;
+            m += len; c += len;
+        } else {
+            c += len;
+            if (m * den < num * c) cut = c;
+        }
+    }
+    cols = c; matches = m;
+}
+
+// the op the cut ends in, what is left of it, and the bases / matches the cut held
+__device__ __forceinline__ void consume_cut(const uint32_t *__restrict__ ops, uint32_t n, bool rev, long long cut, uint32_t &op_at,
+                                            uint32_t &left_len, long long &qdel, long long &tdel, long long &mdel) {
+    qdel = tdel = mdel = 0;
+    uint32_t k = 0;
+    left_len = 0;
+    while (cut > 0) {
+        const uint32_t o = ops[rev ? n - 1 - k : k];
+        const long long len = o >> 3;
+        const uint32_t code = o & 7u;
+        const long long take = len < cut ? len : cut;
+        if (code != kOpD) qdel += take;
+        if (code != kOpI) tdel += take;
+        if (code == kOpEq || code == kOpM) mdel += take;
+        cut -= take;
+        if (take < len) { left_len = (uint32_t)(len - take); break; }
+        k++;
+    }
+    if (left_len == 0) left_len = ops[rev ? n - 1 - k : k] >> 3;        // the cut ended on an op boundary: op k is whole
+    op_at = rev ? n - 1 - k : k;
+}
+
+__global__ __launch_bounds__(256) void k_trim(const TrimRec *__restrict__ recs, int64_t n, const uint32_t *__restrict__ ops,
+                                              const long long num, const long long den, TrimOut *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const TrimRec r = recs[i];
+    const uint32_t *o = ops + r.ops_off;
+    TrimOut t{};
+    long long m_all, cols2, m2;
+    identity_cut(o, r.n_ops, false, num, den, t.pre, t.cols, m_all);
+    identity_cut(o, r.n_ops, true, num, den, t.suf, cols2, m2);
+    if (t.pre + t.suf < t.cols) {
+        long long ma, mb_;
+        consume_cut(o, r.n_ops, false, t.pre, t.first_op, t.first_len, t.qa, t.ta, ma);
+        consume_cut(o, r.n_ops, true, t.suf, t.last_op, t.last_len, t.qb, t.tb, mb_);
+        t.nm = m_all - ma - mb_;
+        t.nb = t.cols - t.pre - t.suf;
+    }
+    out[i] = t;
+}
+
+void launch_trim(const TrimRec *recs, int64_t n, const uint32_t *ops, long long num, long long den, TrimOut *out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_trim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, ops, num, den, out);
+}
+
+}  // namespace mb

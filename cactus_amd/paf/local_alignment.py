@@ -6,19 +6,24 @@ reference's callers:
     run_lastz                 :29-97    one chunk-pair job  -> PAF file id
     make_chunked_alignments   :370-408  chunk both genomes, all-vs-all run_lastz, then combine
     combine_chunks            :336-356  dechunk + concatenate
+    chain_alignments          :607-657  merge, add the inverted copies, split by query contig when large
+    chain_tile_trim_filter_one_contig :660-727  paffy chain | tile | trim | filter | chain | filter
 
 What differs, on purpose: the `lastz` / `run_kegalign` found on PATH are the MI355X front ends in
 <repo>/bin (or, with MIBLAST_INPROCESS=1, the same code through the C ABI via ctypes), AMD GPUs are
-requested as 'rocm:N', and faffy/paffy are replaced by cactus_amd.paf.chunking.  Everything after
-combine_chunks (chaining, trimming, cactus_consolidated) is untouched by design.
+requested as 'rocm:N', faffy and paffy's chunk/dechunk are replaced by cactus_amd.paf.chunking, and the `paffy`
+of the chaining stage is <repo>/bin/paffy (chain, tile and trim run on the GPU; with MIBLAST_INPROCESS=1 the whole
+per-contig job is one call through include/mipaf.h).  cactus_consolidated and everything after it are untouched.
 """
 from __future__ import annotations
 
+import glob
 import math
 import os
+import shutil
 
 from cactus_amd.paf import chunking
-from cactus_amd.shared.common import cactus_call, getOptionalAttrib
+from cactus_amd.shared.common import cactus_call, cactus_clamp_memory, getLogLevelString, getOptionalAttrib
 from cactus_amd.shared.configWrapper import accelerator_string
 
 STDERR_KEYWORDS = ['terminate', 'error', 'fail', 'assert', 'signal', 'abort', 'segmentation', 'sigsegv', 'kill']
@@ -226,3 +231,117 @@ def make_ingroup_to_outgroup_alignments_3(job, ingroup_event, ingroup_seq_file, 
     chunking.paf_dechunk(a2, merged, query_only=True, append=True)
     job.fileStore.deleteGlobalFile(ingroup_seq_file)
     return job.fileStore.writeGlobalFile(merged)
+
+
+# ---- chaining stage (local_alignment.py:594-734): chain -> tile -> trim -> filter -> chain -> filter ---------------------------
+def concat_global_files(job, file_ids, output_path):
+    """:594-604"""
+    with open(output_path, 'wb') as outf:
+        for file_id in file_ids:
+            local_path = job.fileStore.readGlobalFile(file_id)
+            with open(local_path, 'rb') as inf:
+                shutil.copyfileobj(inf, outf)
+            job.fileStore.deleteGlobalFile(file_id)
+
+
+def chain_alignments(job, alignment_files, alignment_names, reference_event_name, params,
+                     include_inverted_alignments=True, total_sequence_size=0):
+    """:607-657 -- same flow and thresholds; `paffy` is bin/paffy."""
+    work_dir = job.fileStore.getLocalTempDir()
+    merged_path = os.path.join(work_dir, 'merged.paf')
+    concat_global_files(job, alignment_files, merged_path)
+
+    if include_inverted_alignments:
+        inv_path = os.path.join(work_dir, 'merged_copy.paf')
+        shutil.copyfile(merged_path, inv_path)
+        cactus_call(parameters=['paffy', 'invert', '--inputFile', inv_path], outfile=merged_path, outappend=True,
+                    job_memory=job.memory)
+        os.remove(inv_path)
+
+    merged_size = os.path.getsize(merged_path)
+    chain_split_min_size = int(params.find("blast").attrib.get("chainSplitMinSize", "1000000000"))
+
+    if merged_size <= chain_split_min_size:
+        merged_file_id = job.fileStore.writeGlobalFile(merged_path)
+        return job.addChildJobFn(chain_tile_trim_filter_one_contig, merged_file_id, reference_event_name, params,
+                                 disk=4 * merged_size, memory=cactus_clamp_memory(4 * merged_size)).rv()
+
+    contig_group_size = int(params.find("blast").attrib.get("chainContigGroupSize", "10000000"))
+    split_prefix = os.path.join(work_dir, 'split_')
+    cactus_call(parameters=['paffy', 'split_file', '--inputFile', merged_path, '--query', '--prefix', split_prefix,
+                            '--minLength', str(contig_group_size), '--logLevel', getLogLevelString()], job_memory=job.memory)
+    processed_rvs = []
+    for split_path in sorted(glob.glob(split_prefix + '*.paf'), key=lambda p: int(p[len(split_prefix):-4])):
+        split_size = os.path.getsize(split_path)
+        split_file_id = job.fileStore.writeGlobalFile(split_path)
+        processed_rvs.append(job.addChildJobFn(chain_tile_trim_filter_one_contig, split_file_id, reference_event_name, params,
+                                               disk=4 * split_size, memory=cactus_clamp_memory(4 * split_size)).rv())
+    return job.addFollowOnJobFn(merge_processed_alignments, processed_rvs).rv()
+
+
+def chain_tile_trim_filter_one_contig(job, split_file_id, reference_event_name, params):
+    """:660-727.  With MIBLAST_INPROCESS=1 the job is one mipaf_chain_tile_trim_filter call (one device context instead of
+    one per piped process); the bytes are the same either way (tests/test_zz_chain_gpu.py)."""
+    work_dir = job.fileStore.getLocalTempDir()
+    input_path = os.path.join(work_dir, 'input.paf')
+    job.fileStore.readGlobalFile(split_file_id, input_path)
+
+    blast = params.find("blast").attrib
+    output_path = os.path.join(work_dir, 'output.paf')
+    use_secondary_alignments = int(blast["outputSecondaryAlignments"])
+
+    if os.environ.get("MIBLAST_INPROCESS") == "1":
+        from cactus_amd import miblast, mipaf
+        ctx = miblast.Context(0)
+        try:
+            cp = mipaf.default_chain_params(max_gap_length=int(blast["chainMaxGapLength"]), gap_open=int(blast["chainGapOpen"]),
+                                            gap_extend=int(blast["chainGapExtend"]), trim_fraction=float(blast["chainTrimFraction"]))
+            s = mipaf.PafSet.from_file(input_path)
+            s.chain_tile_trim_filter(ctx, cp, blast["pafTrimIdentity"], int(blast["minPrimaryChainScore"]),
+                                     output_secondary=bool(use_secondary_alignments))
+            s.write(output_path)
+            s.close()
+        finally:
+            ctx.close()
+        processed_alignment_file_id = job.fileStore.writeGlobalFile(output_path)
+        job.fileStore.deleteGlobalFile(split_file_id)
+        return processed_alignment_file_id
+
+    chain_cmd = ['paffy', 'chain',
+                 '--maxGapLength', blast["chainMaxGapLength"],
+                 '--chainGapOpen', blast["chainGapOpen"],
+                 '--chainGapExtend', blast["chainGapExtend"],
+                 '--trimFraction', blast["chainTrimFraction"],
+                 '--logLevel', getLogLevelString()]
+    tile_cmd = ['paffy', 'tile', '--logLevel', getLogLevelString()]
+    trim_cmd = ['paffy', 'trim', '--trimIdentity', blast["pafTrimIdentity"]]
+    filter_primary_cmd = ['paffy', 'filter', '--maxTileLevel', '1']
+    filter_score_cmd = ['paffy', 'filter', '--minChainScore', blast["minPrimaryChainScore"]]
+
+    if not use_secondary_alignments:
+        cactus_call(parameters=[chain_cmd + ['--inputFile', input_path], tile_cmd, trim_cmd, filter_primary_cmd, chain_cmd[:],
+                                filter_score_cmd], outfile=output_path, job_memory=job.memory)
+    else:
+        filter_path = os.path.join(work_dir, 'filter.paf')
+        cactus_call(parameters=[chain_cmd + ['--inputFile', input_path], tile_cmd, trim_cmd, filter_primary_cmd],
+                    outfile=filter_path, job_memory=job.memory)
+        cactus_call(parameters=[['paffy', 'filter', '--inputFile', filter_path, '--maxTileLevel', '1', '--invert']],
+                    outfile=output_path, job_memory=job.memory)
+        primary_chain_path = os.path.join(work_dir, 'primary_chain.paf')
+        cactus_call(parameters=[chain_cmd + ['--inputFile', filter_path]], outfile=primary_chain_path, job_memory=job.memory)
+        cactus_call(parameters=[['paffy', 'filter', '--inputFile', primary_chain_path, '--minChainScore', blast["minPrimaryChainScore"]]],
+                    outfile=output_path, outappend=True, job_memory=job.memory)
+        cactus_call(parameters=[['paffy', 'filter', '--inputFile', primary_chain_path, '--invert', '--minChainScore', blast["minPrimaryChainScore"]],
+                                ['sed', 's/tp:A:P/tp:A:S/'], ['sed', 's/tl:i:1/tl:i:2/']], outfile=output_path, outappend=True)
+
+    processed_alignment_file_id = job.fileStore.writeGlobalFile(output_path)
+    job.fileStore.deleteGlobalFile(split_file_id)
+    return processed_alignment_file_id
+
+
+def merge_processed_alignments(job, processed_file_ids):
+    """:730-737"""
+    work_dir = job.fileStore.getLocalTempDir()
+    output_path = os.path.join(work_dir, 'final.paf')
+    concat_global_files(job, processed_file_ids, output_path)
+    return job.fileStore.writeGlobalFile(output_path)

@@ -3,7 +3,7 @@
 argument names, stdout->outfile behaviour and RuntimeError-on-non-zero-exit convention
 (:962-988).  Docker / singularity modes, memory accounting and realtime logging are out of
 scope (orchestration, unchanged).  The MI355X front ends live in <repo>/bin and
-are put first on PATH, which is how CACTUS_BINARIES_MODE=local finds `lastz` (:793-795)."""
+are put first on PATH, which is how CACTUS_BINARIES_MODE=local finds `lastz` and `paffy` (:793-795)."""
 from __future__ import annotations
 
 import os
@@ -33,9 +33,12 @@ def getOptionalAttrib(node, attribName, typeFn=None, default=None, errorIfNotPre
 
 def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpus=None, cpus=None, job_memory=None,
                 outappend=False, check_output=False, env=None):
-    """Runs one command locally.  stdout goes to `outfile` (or is returned when check_output), stderr is
-    captured; non-zero exit raises RuntimeError carrying the command line and stderr."""
-    assert parameters and isinstance(parameters[0], str), "pipelines are not needed on the blast path"
+    """Runs one command locally, or -- when `parameters` is a list of commands -- the commands piped into each other as the
+    reference's cactus_call does for the chaining stage (local_alignment.py:684-691).  stdout of the last command goes to
+    `outfile` (or is returned when check_output), stderr is captured; a non-zero exit of any command raises RuntimeError
+    carrying the command line and stderr."""
+    assert parameters
+    commands = [parameters] if isinstance(parameters[0], str) else list(parameters)
     call_env = dict(os.environ if env is None else env)
     call_env["PATH"] = BIN_DIR + os.pathsep + call_env.get("PATH", "")
     stdout = subprocess.PIPE if check_output else None
@@ -43,17 +46,36 @@ def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpu
     if outfile is not None:
         fh = open(outfile, "ab" if outappend else "wb")
         stdout = fh
+    procs = []
     try:
-        proc = subprocess.Popen(parameters, stdout=stdout, stderr=subprocess.PIPE, cwd=work_dir, env=call_env)
-        out, err = proc.communicate()
+        for k, cmd in enumerate(commands):
+            last = k == len(commands) - 1
+            procs.append(subprocess.Popen(cmd, stdin=procs[-1].stdout if procs else None, stdout=stdout if last else subprocess.PIPE,
+                                          stderr=subprocess.PIPE, cwd=work_dir, env=call_env))
+            if len(procs) > 1:
+                procs[-2].stdout.close()                       # the reader owns the pipe now (SIGPIPE reaches the writer)
+        out, err = procs[-1].communicate()
+        errs = [p.stderr.read() if p is not procs[-1] else err for p in procs]
+        for p in procs[:-1]:
+            p.wait()
     finally:
         if fh is not None:
             fh.close()
-    err_text = err.decode(errors="replace") if err else ""
-    if proc.returncode != 0:
-        raise RuntimeError("Command {} exited {}: stderr={}".format(parameters, proc.returncode, err_text))
+    err_text = "".join(e.decode(errors="replace") for e in errs if e)
+    for p, cmd in zip(procs, commands):
+        if p.returncode != 0:
+            raise RuntimeError("Command {} exited {}: stderr={}".format(cmd, p.returncode, err_text))
     if check_output:
         return out.decode()
     if returnStdErr:
         return err_text
     return None
+
+
+def cactus_clamp_memory(memory, floor=2 ** 28, ceiling=2 ** 40):
+    """common.py's clamp of a job's memory request to a sane range"""
+    return int(min(max(memory, floor), ceiling))
+
+
+def getLogLevelString():
+    return "INFO"

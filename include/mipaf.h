@@ -1,0 +1,82 @@
+/*
+ * mipaf.h -- C ABI of the chaining stage of libmiblast.so (MI355X / gfx950).
+ *
+ * The step right after the blast phase: chain_alignments and
+ * chain_tile_trim_filter_one_contig (/root/reference/src/cactus/paf/local_alignment.py:607-727) pipe the PAF of
+ * all chunk pairs through
+ *
+ *     paffy invert | paffy chain | paffy tile | paffy trim | paffy filter | paffy chain | paffy filter
+ *
+ * The reference binds these as SUBPROCESSES (cactus_call, local_alignment.py:624,:684-691); bin/paffy honours that argv
+ * for the sub-commands named here, and the functions below are the same code for in-process use.  Each function
+ * cites the call site it replaces.  paffy itself is an absent submodule of the reference: the rules these functions
+ * implement are the ones written down in DESIGN.md section 11 and restated by oracle/paffy_oracle.c.
+ *
+ * Conventions are those of miblast.h: int return (MIBLAST_OK or < 0), miblast_last_error(), no exceptions and no
+ * abort() across the ABI, caller-owned inputs, library-allocated outputs freed with the matching *_free /
+ * miblast_free.  chain, tile and trim run on the GPU of the context and return MIBLAST_ENODEV without one (there is no
+ * CPU path); parse, invert, filter, split and write are text handling on the host.
+ */
+#ifndef MIPAF_H
+#define MIPAF_H
+
+#include "miblast.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A list of PAF records in order (paffy's in-memory stList of Paf).  Of the optional tags the ones paffy itself
+ * writes are kept: tp:A, AS:i, tl:i, cn:i, s1:i, cg:Z -- written back in that order.                              */
+typedef struct mipaf_set mipaf_set;
+
+int mipaf_set_from_mem(const char *text, size_t len, mipaf_set **out);
+int mipaf_set_from_file(const char *path, mipaf_set **out);             /* paffy's --inputFile                       */
+void mipaf_set_free(mipaf_set *s);
+int64_t mipaf_set_size(const mipaf_set *s);
+/* PAF text of the set; *text is allocated by the library (miblast_free).                                         */
+int mipaf_set_text(const mipaf_set *s, char **text, size_t *len);
+int mipaf_set_write(const mipaf_set *s, int fd);                        /* paffy's stdout / --outputFile             */
+
+/* `paffy invert` (local_alignment.py:624 and :411-418): query <-> target.                                        */
+int mipaf_invert(mipaf_set *s);
+
+typedef struct mipaf_chain_params {     /* `paffy chain` options (local_alignment.py:672-677, values xml:108-111)  */
+    int64_t max_gap_length;             /* --maxGapLength  (chainMaxGapLength 1000000)                            */
+    int64_t gap_open;                   /* --chainGapOpen  (chainGapOpen 5000)                                    */
+    int64_t gap_extend;                 /* --chainGapExtend (chainGapExtend 1)                                    */
+    double trim_fraction;               /* --trimFraction  (chainTrimFraction 1.0)                                */
+} mipaf_chain_params;
+void mipaf_chain_params_default(mipaf_chain_params *p);                 /* the values of cactus_progressive_config.xml */
+
+typedef struct mipaf_stats {            /* of the last chain / tile / trim call; milliseconds are HIP-event times  */
+    int64_t records, groups, query_sequences, ops;
+    int64_t chain_pairs;                /* predecessor candidates inspected by the chain DP                       */
+    double t_sort_ms, t_chain_dp_ms, t_tile_ms, t_trim_ms;
+    double t_total_s;                   /* host wall time of the call                                             */
+} mipaf_stats;
+
+/* `paffy chain` (local_alignment.py:672-677, first and second use :684-690): orders the records, links them into
+ * chains and writes cn:i / s1:i (rules R-C1..R-C7).  stats may be NULL.                                          */
+int mipaf_chain(miblast_ctx *ctx, mipaf_set *s, const mipaf_chain_params *p, mipaf_stats *stats);
+/* `paffy tile` (:678): tl:i / tp:A from the median cover of the query bases (R-T1..R-T5).  hist_bins = 0 picks the
+ * default size of the LDS histogram; the result does not depend on it.                                           */
+int mipaf_tile(miblast_ctx *ctx, mipaf_set *s, int32_t hist_bins, mipaf_stats *stats);
+/* `paffy trim --trimIdentity x` (:679; x = pafTrimIdentity "0.2"): x is the decimal text, at most 6 digits.      */
+int mipaf_trim(miblast_ctx *ctx, mipaf_set *s, const char *trim_identity, mipaf_stats *stats);
+/* `paffy filter [--maxTileLevel L] [--minChainScore S] [--invert]` (:680-681,:696,:710-715); -1 = option absent. */
+int mipaf_filter(mipaf_set *s, int64_t max_tile_level, int64_t min_chain_score, int32_t invert);
+/* `paffy split_file --query --prefix P --minLength N` (:638-642): writes P<k>.paf, returns the number of parts.  */
+int mipaf_split_by_query(const mipaf_set *s, const char *prefix, int64_t min_length, int32_t *n_parts);
+
+/* One chain_tile_trim_filter_one_contig job (local_alignment.py:660-727) without the pipes: chain | tile | trim |
+ * filter --maxTileLevel 1 | chain | filter --minChainScore S, and with output_secondary != 0 the second branch of
+ * that function (secondaries first, then the primaries that keep their chain score, then the demoted ones as
+ * tp:A:S tl:i:2).  The set is replaced by the job's output.                                                      */
+int mipaf_chain_tile_trim_filter(miblast_ctx *ctx, mipaf_set *s, const mipaf_chain_params *p, const char *trim_identity,
+                                 int64_t min_primary_chain_score, int32_t output_secondary, mipaf_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -160,3 +160,16 @@ def test_unaligned_bed_and_extract_round_trip(tmp_path):
     # an alignment on an extracted piece maps back with dechunk --query
     line = "id=I|c1|3000|1200\t1800\t10\t60\t+\tt\t9\t0\t9\t50\t50\t255\tAS:i:1\tcg:Z:50=\n"
     assert chunking.paf_dechunk_line(line, query_only=True).split("\t")[:4] == ["id=I|c1", "3000", "1210", "1260"]
+
+
+def test_cactus_call_pipes_commands_like_the_reference(tmp_path):
+    # local_alignment.py:684-691 passes a list of commands; stdout of the last goes to outfile, any non-zero exit raises
+    from cactus_amd.shared.common import cactus_call
+    assert cactus_call([["printf", "b\\na\\nc\\n"], ["sort"], ["head", "-n", "2"]], check_output=True) == "a\nb\n"
+    out = tmp_path / "o.txt"
+    cactus_call([["printf", "x\\n"], ["cat"]], outfile=str(out))
+    cactus_call([["printf", "y\\n"]], outfile=str(out), outappend=True)
+    assert out.read_text() == "x\ny\n"
+    with pytest.raises(RuntimeError) as e:
+        cactus_call([["printf", "x\\n"], ["sh", "-c", "cat >/dev/null; echo boom >&2; exit 3"], ["cat"]], check_output=True)
+    assert "exited 3" in str(e.value) and "boom" in str(e.value)
