@@ -24,7 +24,7 @@ int main(int argc, char **argv) {
     mipaf_chain_params_default(&cp);
     cp.max_gap_length = 50000;                              // stand-alone default; Cactus always passes its own values
     long long max_tile = -1, min_chain = -1, min_length = 0;
-    int invert = 0;
+    int invert = 0, hist_bins = 0;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
         else if (a == "--minChainScore") min_chain = atoll(v);
         else if (a == "--prefix") prefix = v;
         else if (a == "--minLength") min_length = atoll(v);
+        else if (a == "--mipaf-hist-bins") hist_bins = atoi(v);   // private, never passed by Cactus: size of k_tile's LDS histogram
         else return fail(2, "unknown option " + a);
     }
     const bool needs_gpu = cmd == "chain" || cmd == "tile" || cmd == "trim";
@@ -59,7 +60,7 @@ int main(int argc, char **argv) {
     if (rc == MIBLAST_OK) {
         if (cmd == "invert") rc = mipaf_invert(set);
         else if (cmd == "chain") rc = mipaf_chain(ctx, set, &cp, nullptr);
-        else if (cmd == "tile") rc = mipaf_tile(ctx, set, 0, nullptr);
+        else if (cmd == "tile") rc = mipaf_tile(ctx, set, hist_bins, nullptr);
         else if (cmd == "trim") rc = mipaf_trim(ctx, set, trim_identity, nullptr);
         else if (cmd == "filter") rc = mipaf_filter(set, max_tile, min_chain, invert);
         else rc = mipaf_split_by_query(set, prefix, min_length, nullptr);

@@ -1,0 +1,68 @@
+"""Chaining stage without a GPU: the product's own sources (cactus_amd/csrc/mp_chain.cpp, mp_kernels.hip, mp_paffy_main.cpp) built
+for the host against the stand-in HIP headers of tests/emu (one pthread per work-item, barriers for __syncthreads and the wave
+shuffles) and compared with the oracle byte for byte.  This covers the host orchestration (sort passes, group bounds, chain
+peeling, op splicing) and the kernels' logic in the CPU suite; the GPU parity tests proper are tests/test_zz_chain_gpu.py.
+The emulation is test infrastructure: it is not part of libmiblast.so, which has no CPU path."""
+import os
+import subprocess
+
+import pytest
+
+from tests import pyref_paffy as ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle", "oracle_paffy")
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU = os.path.join(EMU_DIR, "emu_paffy")
+CHAIN_ARGS = ["--maxGapLength", "1000000", "--chainGapOpen", "5000", "--chainGapExtend", "1", "--trimFraction", "1.0"]
+TIGHT_ARGS = ["--maxGapLength", "3000", "--chainGapOpen", "100", "--chainGapExtend", "3", "--trimFraction", "0.25"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.run(["make", "-C", EMU_DIR], check=True, capture_output=True)
+
+
+def run(exe, cmd, text, *args):
+    p = subprocess.run([exe, cmd, *args], input=text.encode(), capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout.decode()
+
+
+def both_ways(seed, **kw):
+    text = ref.random_paf(seed, **kw)
+    return text + ref.dump(ref.invert(ref.parse(text)))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_emulated_kernels_match_the_oracle_step_by_step(seed):
+    text = both_ways(seed, n_series=4 + seed, noise=8, contig_len=60_000 if seed % 2 else 200_000)
+    chained = run(ORACLE, "chain", text, *CHAIN_ARGS)
+    assert run(EMU, "chain", text, *CHAIN_ARGS) == chained
+    assert run(EMU, "chain", text, *TIGHT_ARGS) == run(ORACLE, "chain", text, *TIGHT_ARGS)
+    tiled = run(ORACLE, "tile", chained)
+    assert run(EMU, "tile", chained) == tiled
+    assert run(EMU, "tile", chained, "--mipaf-hist-bins", "2") == tiled          # every level above 1 through the bisection
+    for x in ("0.2", "0.97", "1"):
+        assert run(EMU, "trim", tiled, "--trimIdentity", x) == run(ORACLE, "trim", tiled, "--trimIdentity", x), x
+
+
+def test_emulated_deep_tiling_and_long_groups():
+    # one query/target pair, many overlapping alignments: long groups, equal scores, levels >= 3
+    text = both_ways(77, n_series=14, per_series=(15, 30), n_q=1, n_t=1, contig_len=400_000, noise=120)
+    assert len(text.splitlines()) > 600
+    chained = run(ORACLE, "chain", text, *CHAIN_ARGS)
+    assert run(EMU, "chain", text, *CHAIN_ARGS) == chained
+    tiled = run(ORACLE, "tile", chained)
+    assert max(int(l.split("tl:i:")[1].split("\t")[0]) for l in tiled.splitlines()) >= 3
+    assert run(EMU, "tile", chained) == tiled
+    assert run(EMU, "tile", chained, "--mipaf-hist-bins", "3") == tiled
+
+
+def test_emulated_edge_cases():
+    assert run(EMU, "chain", "") == "" and run(EMU, "tile", "") == "" and run(EMU, "trim", "", "--trimIdentity", "0.2") == ""
+    one = "q\t100\t10\t20\t-\tt\t200\t30\t40\t10\t10\t255\n"
+    for cmd, args in (("chain", CHAIN_ARGS), ("tile", []), ("trim", ["--trimIdentity", "0.2"])):
+        assert run(EMU, cmd, one, *args) == run(ORACLE, cmd, one, *args)
+    p = subprocess.run([EMU, "tile"], input=b"q\t100\t10\t20\t+\tt\t200\t30\t40\t10\t10\t255\tcg:Z:11=\n", capture_output=True)
+    assert p.returncode == 1 and b"do not agree" in p.stderr and p.stdout == b""
