@@ -1558,18 +1558,20 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
     }
 }
 
-// The piece evaluator needs 129 VGPRs when the compiler is left alone: 3 waves per SIMD.  k_ydrop2 asks for 4 (128 VGPRs, the
-// same instruction stream, no scratch), which matters once thousands of pieces are resident; k_ydrop2_w3 is the
-// unconstrained build (MIBLAST_DP_WAVES=3).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// The piece evaluator needs 129 VGPRs when the compiler is left alone: 3 waves per SIMD (k_ydrop2).  k_ydrop2_w4 is the same
+// instruction stream held to 128 VGPRs = 4 waves per SIMD (no scratch).  Measured on the 1 Mb pairs: one pair (2 653 pieces,
+// all resident either way) 1.673 ms with 3 waves vs 1.686 ms with 4; 16 pairs (~6 000 pieces per launch) 3.17 ms vs 2.99 ms.
+// So the 4-wave build is launched when the pieces outnumber the 3 x 1024 wave slots of the 3-wave build
+// (MIBLAST_DP_WAVES=3 / 4 forces one of them).
+__global__ __launch_bounds__(64)
 void k_ydrop2(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
               const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
               unsigned long long *__restrict__ arena_next, const unsigned blk_bytes, unsigned long long *__restrict__ rowdir,
               uint8_t *__restrict__ snaps) {
     ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
 }
-__global__ __launch_bounds__(64)
-void k_ydrop2_w3(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_ydrop2_w4(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
                  const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                  unsigned long long *__restrict__ arena_next, const unsigned blk_bytes, unsigned long long *__restrict__ rowdir,
                  uint8_t *__restrict__ snaps) {
@@ -1581,8 +1583,10 @@ void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtr
                    uint8_t *snaps, hipStream_t s) {
     if (n <= 0) return;
     dim3 g((unsigned)n), b(64);
-    static const bool three_waves = [] { const char *e = getenv("MIBLAST_DP_WAVES"); return e && atoi(e) == 3; }();
-    if (K == 2 && three_waves) hipLaunchKernelGGL(k_ydrop2_w3, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    const char *we = getenv("MIBLAST_DP_WAVES");
+    const int waves = we ? atoi(we) : 0;
+    const bool four = waves == 4 || (waves != 3 && n > 3 * 1024);
+    if (K == 2 && four) hipLaunchKernelGGL(k_ydrop2_w4, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else if (K == 2) hipLaunchKernelGGL(k_ydrop2, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else if (K == 4) hipLaunchKernelGGL((k_ydrop1<4>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else hipLaunchKernelGGL((k_ydrop1<8>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
