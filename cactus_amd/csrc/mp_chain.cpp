@@ -97,6 +97,11 @@ struct EventTimer {                        // HIP-event time of a stretch of the
     }
 };
 
+long env_long_mp(const char *name, long dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atol(v) : dflt;
+}
+
 int bits_for(unsigned long long mx) {
     int b = 1;
     while (b < 64 && (mx >> b)) b++;
@@ -380,16 +385,102 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
 }
 
 // ---- paffy tile ----------------------------------------------------------------------------------------------------
+// Sort-based levelling (mp_kernels.hip "Tiling without the walk").  rank[k] = input index of the k-th record in R-T1 order;
+// seq_off[q] = first global base of query sequence q.  Returns false, leaving `level` alone, when the number of pieces
+// would exceed `max_pieces` (deep pile-ups): the caller then takes the counter walk.
+bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &rank, const std::vector<uint32_t> &qid_of_name,
+                     const std::vector<uint64_t> &seq_off, uint64_t max_pieces, std::vector<int32_t> &level_by_rank, mipaf_stats &st) {
+    const size_t n = rank.size();
+    hipStream_t s = ctx.stream;
+    // maximal runs of aligned query bases (= X M; a D does not move along the query, an I ends the run)
+    std::vector<unsigned long long> rs, re, bounds;
+    std::vector<uint32_t> rrank;
+    for (size_t k = 0; k < n; k++) {
+        const PafRec &r = set.recs[rank[k]];
+        if (!r.has_cg) continue;
+        const uint64_t base = seq_off[qid_of_name[r.qn]];
+        int64_t q = r.same ? r.qs : r.qe, open_at = -1;
+        auto close = [&](int64_t at) {
+            if (open_at < 0) return;
+            const uint64_t a = base + (uint64_t)std::min(open_at, at), b = base + (uint64_t)std::max(open_at, at);
+            if (b > a) { rs.push_back(a); re.push_back(b); rrank.push_back((uint32_t)k); }
+            open_at = -1;
+        };
+        for (uint32_t o = 0; o < r.n_ops; o++) {
+            const uint32_t op = set.ops[r.ops_off + o], code = op & 7u;
+            const int64_t len = op >> 3;
+            if (code == kOpD) continue;
+            if (code == kOpI) { close(q); q += r.same ? len : -len; continue; }
+            if (open_at < 0) open_at = q;
+            q += r.same ? len : -len;
+        }
+        close(q);
+    }
+    const size_t nr = rs.size();
+    level_by_rank.assign(n, 1);
+    if (nr == 0) return true;
+    bounds.reserve(2 * nr);
+    bounds.insert(bounds.end(), rs.begin(), rs.end());
+    bounds.insert(bounds.end(), re.begin(), re.end());
+    const size_t nb = bounds.size();
+    const int coord_bits = bits_for(seq_off.back());
+
+    EventTimer t(s);
+    Dev<unsigned long long> d_b, d_bs(nb), d_flag(nb), d_pos(nb), d_rs, d_re, d_cnt(nr), d_off(nr);
+    Dev<uint32_t> d_lo(nr), d_rrank;
+    d_b.upload(bounds, s); d_rs.upload(rs, s); d_re.upload(re, s); d_rrank.upload(rrank, s);
+    size_t temp_bytes = std::max(sort_keys64_temp_bytes((int64_t)nb, coord_bits), scan_u64_temp_bytes((int64_t)nb));
+    Dev<uint8_t> d_temp(temp_bytes);
+    sort_keys64(d_temp.p, temp_bytes, d_b.p, d_bs.p, (int64_t)nb, coord_bits, s);
+    launch_tile_heads(d_bs.p, (int64_t)nb, d_flag.p, s);
+    scan_u64(d_temp.p, temp_bytes, d_flag.p, d_pos.p, (int64_t)nb, false, s);
+    unsigned long long last_pos = 0, last_flag = 0;
+    MB_HIP(hipMemcpyAsync(&last_pos, d_pos.p + (nb - 1), sizeof last_pos, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipMemcpyAsync(&last_flag, d_flag.p + (nb - 1), sizeof last_flag, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipStreamSynchronize(s));
+    const size_t nu = (size_t)(last_pos + last_flag);
+    Dev<unsigned long long> d_u(nu);
+    launch_tile_unique(d_bs.p, d_flag.p, d_pos.p, (int64_t)nb, d_u.p, s);
+    launch_tile_span(d_rs.p, d_re.p, (int64_t)nr, d_u.p, (int64_t)nu, d_lo.p, d_cnt.p, s);
+    scan_u64(d_temp.p, temp_bytes, d_cnt.p, d_off.p, (int64_t)nr, false, s);
+    unsigned long long last_off = 0, last_cnt = 0;
+    MB_HIP(hipMemcpyAsync(&last_off, d_off.p + (nr - 1), sizeof last_off, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipMemcpyAsync(&last_cnt, d_cnt.p + (nr - 1), sizeof last_cnt, hipMemcpyDeviceToHost, s));
+    MB_HIP(hipStreamSynchronize(s));
+    const uint64_t np = last_off + last_cnt;
+    if (np > max_pieces) { st.t_tile_ms += t.stop_ms(); return false; }
+    Dev<unsigned long long> d_key(np), d_key_s(np), d_key2(np), d_w64(np), d_wsum(np);
+    Dev<uint32_t> d_w(np), d_w_s(np);
+    const int piece_bits = 32 + bits_for(nu);
+    const int key2_bits = 15 + bits_for(n);
+    size_t temp2 = std::max({sort_keys64_temp_bytes((int64_t)np, piece_bits), sort_pairs_temp_bytes((int64_t)np, key2_bits), scan_u64_temp_bytes((int64_t)np)});
+    Dev<uint8_t> d_temp2(temp2);
+    launch_tile_expand(d_lo.p, d_cnt.p, d_off.p, d_rrank.p, (int64_t)nr, d_key.p, s);
+    sort_keys64(d_temp2.p, temp2, d_key.p, d_key_s.p, (int64_t)np, piece_bits, s);
+    launch_tile_cover(d_key_s.p, (int64_t)np, d_u.p, d_key2.p, d_w.p, s);
+    sort_pairs(d_temp2.p, temp2, d_key2.p, d_key.p, d_w.p, d_w_s.p, (int64_t)np, key2_bits, s);      // d_key now holds the sorted key2
+    launch_widen(d_w_s.p, d_w64.p, (int64_t)np, s);
+    scan_u64(d_temp2.p, temp2, d_w64.p, d_wsum.p, (int64_t)np, true, s);
+    Dev<int32_t> d_level(n);
+    launch_tile_median(d_key.p, d_wsum.p, (int64_t)np, (int64_t)n, d_level.p, s);
+    st.t_tile_ms += t.stop_ms();
+    d_level.download(level_by_rank, s);
+    MB_HIP(hipStreamSynchronize(s));
+    st.ops = (int64_t)np;                                    // pieces: the unit of work of this path
+    return true;
+}
+
 void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     const size_t n = set.recs.size();
     st.records = (int64_t)n;
     if (n == 0) return;
     if (n >= (1ull << 31)) throw std::length_error("more than 2^31 PAF records in one tiling job");
+    const bool force_walk = hist_bins > 0;
     if (hist_bins <= 0) hist_bins = 4096;
     hist_bins = std::min(8192, std::max(2, hist_bins));
     MB_HIP(hipSetDevice(ctx.device));
     hipStream_t s = ctx.stream;
-    // R-T1 order on the device, then grouped by query sequence (stable, so the order inside a sequence is kept)
+    // R-T1 order on the device
     std::vector<unsigned long long> key(n), qkey(n);
     std::vector<uint32_t> qid_of_name(set.names.size(), UINT32_MAX);
     std::vector<int64_t> qlen;
@@ -403,20 +494,44 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     }
     const size_t nq = qlen.size();
     st.query_sequences = (int64_t)nq;
+    std::vector<uint64_t> cnt_off(nq + 1, 0);
+    for (size_t q = 0; q < nq; q++) cnt_off[q + 1] = cnt_off[q] + (uint64_t)std::max<int64_t>(qlen[q], 0);
     Dev<unsigned long long> d_key, d_key2(n), d_qkey, d_g(n);
     Dev<uint32_t> d_pa(n), d_rank(n), d_grouped(n);
     const size_t temp_bytes = std::max(sort_pairs_temp_bytes((int64_t)n, 64), sort_pairs_temp_bytes((int64_t)n, bits_for(nq)));
     Dev<uint8_t> d_temp(temp_bytes);
     d_key.upload(key, s);
     d_qkey.upload(qkey, s);
-    EventTimer t_sort(s);
-    launch_iota(d_pa.p, (int64_t)n, s);
-    sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pa.p, d_rank.p, (int64_t)n, 64, s);
-    launch_gather_u64(d_qkey.p, d_rank.p, d_g.p, (int64_t)n, s);
-    sort_pairs(d_temp.p, temp_bytes, d_g.p, d_key2.p, d_rank.p, d_grouped.p, (int64_t)n, bits_for(nq), s);
-    st.t_sort_ms += t_sort.stop_ms();
     std::vector<uint32_t> rank, grouped;
+    {
+        EventTimer t_sort(s);
+        launch_iota(d_pa.p, (int64_t)n, s);
+        sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pa.p, d_rank.p, (int64_t)n, 64, s);
+        st.t_sort_ms += t_sort.stop_ms();
+    }
     d_rank.download(rank, s);
+    MB_HIP(hipStreamSynchronize(s));
+
+    std::vector<int32_t> level;                              // by input index
+    bool done = false;
+    if (!force_walk) {
+        // pieces beyond this (default 2^28 ~ 7 GiB of keys and weights) mean a pile-up: take the bounded-memory walk instead
+        const uint64_t max_pieces = (uint64_t)std::max(1l, env_long_mp("MIPAF_TILE_MAX_PIECES", 1l << 28));
+        std::vector<int32_t> by_rank;
+        if (tile_by_sorting(ctx, set, rank, qid_of_name, cnt_off, max_pieces, by_rank, st)) {
+            level.assign(n, 1);
+            for (size_t k = 0; k < n; k++) level[rank[k]] = by_rank[k];
+            done = true;
+        }
+    }
+    if (!done) {
+    // the counter walk: grouped by query sequence (stable, so the R-T1 order inside a sequence is kept)
+    {
+        EventTimer t_sort(s);
+        launch_gather_u64(d_qkey.p, d_rank.p, d_g.p, (int64_t)n, s);
+        sort_pairs(d_temp.p, temp_bytes, d_g.p, d_key2.p, d_rank.p, d_grouped.p, (int64_t)n, bits_for(nq), s);
+        st.t_sort_ms += t_sort.stop_ms();
+    }
     d_grouped.download(grouped, s);
     MB_HIP(hipStreamSynchronize(s));
 
@@ -436,8 +551,6 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
         qstart[qid_of_name[r.qn] + 1]++;
     }
     for (size_t q = 0; q < nq; q++) qstart[q + 1] += qstart[q];
-    std::vector<uint64_t> cnt_off(nq + 1, 0);
-    for (size_t q = 0; q < nq; q++) cnt_off[q + 1] = cnt_off[q] + (uint64_t)std::max<int64_t>(qlen[q], 0);
     st.ops = (int64_t)set.ops.size();
 
     Dev<TileRec> d_rec;
@@ -454,9 +567,9 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     EventTimer t_tile(s);
     launch_tile(d_rec.p, d_qstart.p, d_cnt_off.p, (int)nq, d_cnt.p, d_ops.p, d_qoff.p, hist_bins, d_level.p, s);
     st.t_tile_ms += t_tile.stop_ms();
-    std::vector<int32_t> level;
     d_level.download(level, s);
     MB_HIP(hipStreamSynchronize(s));
+    }
     std::vector<PafRec> out(n);
     for (size_t k = 0; k < n; k++) {                         // R-T5
         PafRec r = set.recs[rank[k]];

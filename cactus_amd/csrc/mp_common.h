@@ -47,6 +47,20 @@ void launch_chain_dp(const ChainRec *recs, const uint32_t *gstart, const int64_t
                      long long gap_open, long long gap_extend, long long *cs, int32_t *pred, hipStream_t s);
 void launch_tile(const TileRec *recs, const uint32_t *qstart, const uint64_t *cnt_off, int n_queries, uint16_t *cnt,
                  const uint32_t *ops, const uint32_t *qoff, int hist_bins, int32_t *level, hipStream_t s);
+// sort-based tiling (mp_kernels.hip "Tiling without the walk")
+size_t sort_keys64_temp_bytes(int64_t n, int end_bit);
+void sort_keys64(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, int64_t n, int end_bit, hipStream_t s);
+size_t scan_u64_temp_bytes(int64_t n);
+void scan_u64(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, int64_t n, bool inclusive, hipStream_t s);
+void launch_tile_heads(const unsigned long long *b, int64_t n, unsigned long long *flag, hipStream_t s);
+void launch_tile_unique(const unsigned long long *b, const unsigned long long *flag, const unsigned long long *pos, int64_t n, unsigned long long *u, hipStream_t s);
+void launch_tile_span(const unsigned long long *rs, const unsigned long long *re, int64_t n_runs, const unsigned long long *u, int64_t n_u, uint32_t *lo,
+                      unsigned long long *cnt, hipStream_t s);
+void launch_tile_expand(const uint32_t *lo, const unsigned long long *cnt, const unsigned long long *off, const uint32_t *rrank, int64_t n_runs,
+                        unsigned long long *key, hipStream_t s);
+void launch_tile_cover(const unsigned long long *key, int64_t n_pieces, const unsigned long long *u, unsigned long long *key2, uint32_t *weight, hipStream_t s);
+void launch_widen(const uint32_t *in, unsigned long long *out, int64_t n, hipStream_t s);
+void launch_tile_median(const unsigned long long *key2, const unsigned long long *wsum, int64_t n_pieces, int64_t n_recs, int32_t *level_by_rank, hipStream_t s);
 void launch_trim(const TrimRec *recs, int64_t n, const uint32_t *ops, long long num, long long den, TrimOut *out, hipStream_t s);
 
 }  // namespace mb

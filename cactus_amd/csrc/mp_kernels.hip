@@ -14,6 +14,7 @@
 #include <climits>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace mb {
 
@@ -223,6 +224,141 @@ void launch_tile(const TileRec *recs, const uint32_t *qstart, const uint64_t *cn
     if (n_queries > 0)
         hipLaunchKernelGGL(k_tile, dim3((unsigned)n_queries), dim3(256), (size_t)hist_bins * sizeof(unsigned), s, recs, qstart, cnt_off, cnt,
                            ops, qoff, hist_bins, level);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiling without the walk (the default).  The counter an alignment reads at a base is just the number of BETTER-ranked
+// alignments whose aligned columns hold that base -- a function of the input, not of an evaluation order -- so every
+// alignment can be levelled at once:
+//   runs       maximal stretches of aligned query bases of every alignment (host, from the ops; global base coordinates)
+//   intervals  the sorted, de-duplicated run boundaries cut the bases into elementary intervals with a constant cover set
+//   pieces     a run is cut into the intervals it spans: key (interval << 32 | rank); after a sort by that key the position
+//              of a piece inside its interval's segment is its cover count (k_tile_cover), saturated like the u16 counters
+//   median     pieces re-sorted by (rank << 15 | cover) with the interval length as weight; a prefix sum of the weights
+//              and two bisections per alignment give the smallest cover L with 2 * (bases with cover <= L) >= bases
+// Work and memory are proportional to the number of pieces = sum over intervals of their depth; the host falls back to
+// k_tile (bounded memory, sequential per sequence) when a pile-up would make that number explode.
+size_t sort_keys64_temp_bytes(int64_t n, int end_bit) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0, end_bit,
+                                   (hipStream_t)0);
+    return bytes;
+}
+void sort_keys64(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, int64_t n, int end_bit, hipStream_t s) {
+    if (sort_keys64_temp_bytes(n, end_bit) > temp_bytes) throw HipFailure{hipErrorInvalidValue, "sort_keys64: temporary storage too small", __FILE__, __LINE__};
+    MB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, end_bit, s));
+}
+size_t scan_u64_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n,
+                                  rocprim::plus<unsigned long long>(), (hipStream_t)0);
+    size_t b2 = 0;
+    (void)rocprim::exclusive_scan(nullptr, b2, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull, (size_t)n,
+                                  rocprim::plus<unsigned long long>(), (hipStream_t)0);
+    return bytes > b2 ? bytes : b2;
+}
+void scan_u64(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, int64_t n, bool inclusive, hipStream_t s) {
+    if (n <= 0) return;
+    if (scan_u64_temp_bytes(n) > temp_bytes) throw HipFailure{hipErrorInvalidValue, "scan_u64: temporary storage too small", __FILE__, __LINE__};
+    if (inclusive) MB_HIP(rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<unsigned long long>(), s));
+    else MB_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), s));
+}
+
+__device__ __forceinline__ int64_t lower_bound_u64(const unsigned long long *__restrict__ v, int64_t n, unsigned long long x) {
+    int64_t a = 0, b = n;
+    while (a < b) {
+        const int64_t m = (a + b) >> 1;
+        if (v[m] < x) a = m + 1; else b = m;
+    }
+    return a;
+}
+
+// 1 where a sorted boundary differs from its predecessor
+__global__ void k_tile_heads(const unsigned long long *__restrict__ b, int64_t n, unsigned long long *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || b[i] != b[i - 1]) ? 1ull : 0ull;
+}
+// pos = exclusive scan of the head flags: the distinct boundaries, in order
+__global__ void k_tile_unique(const unsigned long long *__restrict__ b, const unsigned long long *__restrict__ flag,
+                              const unsigned long long *__restrict__ pos, int64_t n, unsigned long long *__restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) u[pos[i]] = b[i];
+}
+// the elementary intervals [lo, lo + cnt) a run spans
+__global__ void k_tile_span(const unsigned long long *__restrict__ rs, const unsigned long long *__restrict__ re, int64_t n_runs,
+                            const unsigned long long *__restrict__ u, int64_t n_u, uint32_t *__restrict__ lo, unsigned long long *__restrict__ cnt) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_runs) return;
+    const int64_t a = lower_bound_u64(u, n_u, rs[k]), b = lower_bound_u64(u, n_u, re[k]);
+    lo[k] = (uint32_t)a;
+    cnt[k] = (unsigned long long)(b - a);
+}
+__global__ void k_tile_expand(const uint32_t *__restrict__ lo, const unsigned long long *__restrict__ cnt, const unsigned long long *__restrict__ off,
+                              const uint32_t *__restrict__ rrank, int64_t n_runs, unsigned long long *__restrict__ key) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_runs) return;
+    const unsigned long long base = off[k], e0 = lo[k], r = rrank[k];
+    for (unsigned long long j = 0; j < cnt[k]; j++) key[base + j] = ((e0 + j) << 32) | r;
+}
+// position inside the interval's segment = number of better-ranked alignments on these bases
+__global__ void k_tile_cover(const unsigned long long *__restrict__ key, int64_t n_pieces, const unsigned long long *__restrict__ u,
+                             unsigned long long *__restrict__ key2, uint32_t *__restrict__ weight) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const unsigned long long k = key[i], e = k >> 32, rank = k & 0xffffffffull;
+    const int64_t seg = lower_bound_u64(key, i + 1, e << 32);
+    unsigned long long cover = (unsigned long long)(i - seg);
+    if (cover > 32767ull) cover = 32767ull;
+    key2[i] = (rank << 15) | cover;
+    weight[i] = (uint32_t)(u[e + 1] - u[e]);
+}
+__global__ void k_widen(const uint32_t *__restrict__ in, unsigned long long *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+// wsum = inclusive prefix sum of the weights in key2 order; one lane per alignment (rank)
+__global__ void k_tile_median(const unsigned long long *__restrict__ key2, const unsigned long long *__restrict__ wsum, int64_t n_pieces,
+                              int64_t n_recs, int32_t *__restrict__ level_by_rank) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_recs) return;
+    const int64_t a = lower_bound_u64(key2, n_pieces, (unsigned long long)r << 15);
+    const int64_t b = lower_bound_u64(key2, n_pieces, (unsigned long long)(r + 1) << 15);
+    int32_t level = 0;
+    if (b > a) {
+        const unsigned long long base = a ? wsum[a - 1] : 0ull, total = wsum[b - 1] - base;
+        int64_t x = a, y = b - 1;                              // first t in [a, b) with 2 * (wsum[t] - base) >= total
+        while (x < y) {
+            const int64_t m = (x + y) >> 1;
+            if (2 * (wsum[m] - base) >= total) y = m; else x = m + 1;
+        }
+        level = (int32_t)(key2[x] & 0x7fffull);
+    }
+    level_by_rank[r] = level + 1;
+}
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+void launch_tile_heads(const unsigned long long *b, int64_t n, unsigned long long *flag, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_tile_heads, grid_for(n), dim3(256), 0, s, b, n, flag);
+}
+void launch_tile_unique(const unsigned long long *b, const unsigned long long *flag, const unsigned long long *pos, int64_t n, unsigned long long *u, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_tile_unique, grid_for(n), dim3(256), 0, s, b, flag, pos, n, u);
+}
+void launch_tile_span(const unsigned long long *rs, const unsigned long long *re, int64_t n_runs, const unsigned long long *u, int64_t n_u, uint32_t *lo,
+                      unsigned long long *cnt, hipStream_t s) {
+    if (n_runs > 0) hipLaunchKernelGGL(k_tile_span, grid_for(n_runs), dim3(256), 0, s, rs, re, n_runs, u, n_u, lo, cnt);
+}
+void launch_tile_expand(const uint32_t *lo, const unsigned long long *cnt, const unsigned long long *off, const uint32_t *rrank, int64_t n_runs,
+                        unsigned long long *key, hipStream_t s) {
+    if (n_runs > 0) hipLaunchKernelGGL(k_tile_expand, grid_for(n_runs), dim3(256), 0, s, lo, cnt, off, rrank, n_runs, key);
+}
+void launch_tile_cover(const unsigned long long *key, int64_t n_pieces, const unsigned long long *u, unsigned long long *key2, uint32_t *weight, hipStream_t s) {
+    if (n_pieces > 0) hipLaunchKernelGGL(k_tile_cover, grid_for(n_pieces), dim3(256), 0, s, key, n_pieces, u, key2, weight);
+}
+void launch_widen(const uint32_t *in, unsigned long long *out, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_widen, grid_for(n), dim3(256), 0, s, in, out, n);
+}
+void launch_tile_median(const unsigned long long *key2, const unsigned long long *wsum, int64_t n_pieces, int64_t n_recs, int32_t *level_by_rank, hipStream_t s) {
+    if (n_recs > 0) hipLaunchKernelGGL(k_tile_median, grid_for(n_recs), dim3(256), 0, s, key2, wsum, n_pieces, n_recs, level_by_rank);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -59,8 +59,10 @@ typedef struct mipaf_stats {            /* of the last chain / tile / trim call;
 /* `paffy chain` (local_alignment.py:672-677, first and second use :684-690): orders the records, links them into
  * chains and writes cn:i / s1:i (rules R-C1..R-C7).  stats may be NULL.                                          */
 int mipaf_chain(miblast_ctx *ctx, mipaf_set *s, const mipaf_chain_params *p, mipaf_stats *stats);
-/* `paffy tile` (:678): tl:i / tp:A from the median cover of the query bases (R-T1..R-T5).  hist_bins = 0 picks the
- * default size of the LDS histogram; the result does not depend on it.                                           */
+/* `paffy tile` (:678): tl:i / tp:A from the median cover of the query bases (R-T1..R-T5).  hist_bins = 0: the
+ * sort-based levelling (all alignments at once; falls back to the counter walk when a pile-up would need more than
+ * $MIPAF_TILE_MAX_PIECES, default 2^28, pieces).  hist_bins > 0 forces the counter walk with an LDS histogram of
+ * that many bins.  The result does not depend on the choice.                                                     */
 int mipaf_tile(miblast_ctx *ctx, mipaf_set *s, int32_t hist_bins, mipaf_stats *stats);
 /* `paffy trim --trimIdentity x` (:679; x = pafTrimIdentity "0.2"): x is the decimal text, at most 6 digits.      */
 int mipaf_trim(miblast_ctx *ctx, mipaf_set *s, const char *trim_identity, mipaf_stats *stats);

@@ -21,3 +21,15 @@ hipError_t radix_sort_pairs(void *temp, size_t &bytes, const K *kin, K *kout, co
     return hipSuccess;
 }
 }  // namespace rocprim
+
+namespace rocprim {
+template <typename K>
+hipError_t radix_sort_keys(void *temp, size_t &bytes, const K *kin, K *kout, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t) {
+    if (!temp) { bytes = 64; return hipSuccess; }
+    const K mask = end_bit >= 8 * sizeof(K) ? ~K(0) : ((K(1) << end_bit) - 1);
+    std::vector<K> ks(kin, kin + n);
+    std::stable_sort(ks.begin(), ks.end(), [&](K a, K b) { return ((a & mask) >> begin_bit) < ((b & mask) >> begin_bit); });
+    std::copy(ks.begin(), ks.end(), kout);
+    return hipSuccess;
+}
+}  // namespace rocprim

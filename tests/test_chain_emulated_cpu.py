@@ -41,8 +41,8 @@ def test_emulated_kernels_match_the_oracle_step_by_step(seed):
     assert run(EMU, "chain", text, *CHAIN_ARGS) == chained
     assert run(EMU, "chain", text, *TIGHT_ARGS) == run(ORACLE, "chain", text, *TIGHT_ARGS)
     tiled = run(ORACLE, "tile", chained)
-    assert run(EMU, "tile", chained) == tiled
-    assert run(EMU, "tile", chained, "--mipaf-hist-bins", "2") == tiled          # every level above 1 through the bisection
+    assert run(EMU, "tile", chained) == tiled                                     # sort-based levelling
+    assert run(EMU, "tile", chained, "--mipaf-hist-bins", "2") == tiled          # counter walk, every level above 1 through the bisection
     for x in ("0.2", "0.97", "1"):
         assert run(EMU, "trim", tiled, "--trimIdentity", x) == run(ORACLE, "trim", tiled, "--trimIdentity", x), x
 
@@ -57,6 +57,8 @@ def test_emulated_deep_tiling_and_long_groups():
     assert max(int(l.split("tl:i:")[1].split("\t")[0]) for l in tiled.splitlines()) >= 3
     assert run(EMU, "tile", chained) == tiled
     assert run(EMU, "tile", chained, "--mipaf-hist-bins", "3") == tiled
+    p = subprocess.run([EMU, "tile"], input=chained.encode(), capture_output=True, env=dict(os.environ, MIPAF_TILE_MAX_PIECES="100"))
+    assert p.returncode == 0 and p.stdout.decode() == tiled                       # pile-up guard: falls back to the walk
 
 
 def test_emulated_edge_cases():

@@ -58,9 +58,10 @@ def test_each_sub_command_matches_the_oracle(ctx, seed):
     chained = mipaf.PafSet.from_text(text).chain(ctx).text()
     assert chained == oracle("chain", text, *CHAIN_ARGS)
     assert mipaf.PafSet.from_text(text).chain(ctx, TIGHT).text() == oracle("chain", text, *TIGHT_ARGS)
-    tiled = mipaf.PafSet.from_text(chained).tile(ctx).text()
+    tiled = mipaf.PafSet.from_text(chained).tile(ctx).text()                                   # sort-based levelling
     assert tiled == oracle("tile", chained)
-    # a 2-bin histogram sends every alignment above level 1 through the bisection path: same answer
+    # the counter walk (what a pile-up falls back to); a 2-bin histogram sends every level above 1 through its bisection
+    assert mipaf.PafSet.from_text(chained).tile(ctx, hist_bins=4096).text() == tiled
     assert mipaf.PafSet.from_text(chained).tile(ctx, hist_bins=2).text() == tiled
     assert mipaf.PafSet.from_text(text).tile(ctx).text() == oracle("tile", text)                 # no chain scores: AS decides
     for x in ("0.2", "0.5", "0.97", "0", "1"):
@@ -115,9 +116,18 @@ def test_large_groups_windows_and_ties(ctx):
     chained = oracle("chain", text, *CHAIN_ARGS)
     tiled = mipaf.PafSet.from_text(chained).tile(ctx).text()
     assert tiled == oracle("tile", chained)
+    assert mipaf.PafSet.from_text(chained).tile(ctx, hist_bins=4096).text() == tiled and mipaf.PafSet.from_text(chained).tile(ctx, hist_bins=3).text() == tiled
     assert max(int(l.split("tl:i:")[1].split("\t")[0]) for l in tiled.splitlines()) >= 3
     assert mipaf.PafSet.from_text(tiled).trim(ctx, "0.2").text() == oracle("trim", tiled, "--trimIdentity", "0.2")
     assert mipaf.PafSet.from_text(text).chain_tile_trim_filter(ctx, None, "0.2", 10000).text() == oracle_job(text)
+
+
+def test_pile_up_falls_back_to_the_counter_walk(ctx, monkeypatch):
+    text = both_ways(9, n_series=8, noise=30)
+    chained = oracle("chain", text, *CHAIN_ARGS)
+    monkeypatch.setenv("MIPAF_TILE_MAX_PIECES", "50")
+    s = mipaf.PafSet.from_text(chained).tile(ctx)
+    assert s.text() == oracle("tile", chained)
 
 
 def test_edge_cases(ctx):
