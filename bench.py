@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--random-pair", action="store_true", help="pure-random pair (seed/ungapped isolation)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="chunk size for the CPU-oracle baseline leg (0 = skip); repeated until ~10 s of CPU work")
+    ap.add_argument("--chain-leg", type=int, default=400,
+                    help="syntenic series in the synthetic PAF of the chaining-stage leg (0 = skip); reported under chain_stage, never in value")
     ap.add_argument("--lastz-args", default=DEFAULT_ARGS)
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="chunk pairs per GPU per step, aligned in ONE batched call (merged gapped launches).  The default 1 is "
@@ -185,6 +187,8 @@ def main():
         }
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, pm, ctx)
+        if a.chain_leg > 0:
+            out["chain_stage"] = chain_stage_leg(a, ctx)
         if a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(a, pm)
         print(json.dumps(out), flush=True)
@@ -219,6 +223,49 @@ def seed_stage_leg(a, pm, ctx):
             "kernel_ms": {"ungapped": s["t_ungapped_kernel_ms"], "sort": s["t_sort_ms"], "seed_fill": s["t_seedfill_ms"]},
             "algorithmic_GBps": algo / max(1e-9, s["t_seed"] + s["t_index"]) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
             "chance_alignments": s["alignments"], "gapped_gcells_per_s_kernel": s["dp_cells_run"] / max(1e-9, s["t_dp_kernel_ms"] * 1e-3) / 1e9}
+
+
+def chain_stage_leg(a, ctx):
+    """The step after the blast phase (local_alignment.py:660-727): one chain | tile | trim | filter | chain |
+    filter job on a synthetic PAF (both orientations, as chain_alignments feeds it), text in and text out, with the HIP-event
+    times of its kernels; beside it the oracle's six piped processes on the same text (1 core each, as paffy runs)."""
+    import subprocess
+    from cactus_amd import gen, mipaf
+    text = gen.random_paf(1234, n_series=a.chain_leg, per_series=(20, 60), n_q=2, n_t=2, contig_len=20_000_000, noise=10 * a.chain_leg, ragged=False)
+    text += mipaf.PafSet.from_text(text).invert().text()
+    n = len(text.splitlines())
+
+    def job():
+        t0 = time.perf_counter()
+        s = mipaf.PafSet.from_text(text)
+        t1 = time.perf_counter()
+        s.chain_tile_trim_filter(ctx, None, "0.2", 10000)
+        t2 = time.perf_counter()
+        out = s.text()
+        t3 = time.perf_counter()
+        st = s.stats
+        s.close()
+        return out, st, (t1 - t0, t2 - t1, t3 - t2)
+
+    job()
+    best = None
+    for _ in range(3):
+        out, st, (tp, tj, tw) = job()
+        if best is None or tp + tj + tw < sum(best[2]):
+            best = (out, st, (tp, tj, tw))
+    out, st, (tp, tj, tw) = best
+    oracle = os.path.join(ROOT, "oracle", "oracle_paffy")
+    chain = f"{oracle} chain --maxGapLength 1000000 --chainGapOpen 5000 --chainGapExtend 1 --trimFraction 1.0"
+    cmd = f"{chain} | {oracle} tile | {oracle} trim --trimIdentity 0.2 | {oracle} filter --maxTileLevel 1 | {chain} | {oracle} filter --minChainScore 10000"
+    t0 = time.perf_counter()
+    p = subprocess.run(["bash", "-o", "pipefail", "-c", cmd], input=text.encode(), capture_output=True)
+    t_cpu = time.perf_counter() - t0
+    return {"workload": f"{n} PAF records ({len(text) / 1e6:.1f} MB; {a.chain_leg} syntenic series + noise, both orientations), Cactus's chaining parameters",
+            "records_per_s": n / (tp + tj + tw), "seconds": tp + tj + tw,
+            "seconds_parse_job_write": [tp, tj, tw], "records_out": len(out.splitlines()),
+            "kernel_ms": {"sorts": st["t_sort_ms"], "chain_dp": st["t_chain_dp_ms"], "tile": st["t_tile_ms"], "trim": st["t_trim_ms"]},
+            "cpu_baseline": {"seconds": t_cpu, "records_per_s": n / t_cpu, "cores": 6, "kind": "port",
+                             "sample": "the same text through the oracle's six piped processes", "same_bytes": p.returncode == 0 and p.stdout.decode() == out}}
 
 
 def cpu_baseline(a, pm):

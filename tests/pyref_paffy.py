@@ -3,7 +3,6 @@ oracle/paffy_oracle.c on small inputs: per-column loops and exact fractions inst
 bookkeeping instead of sorted arrays.  Test infrastructure only."""
 from __future__ import annotations
 
-import random
 import re
 from dataclasses import dataclass, field
 from fractions import Fraction
@@ -206,72 +205,5 @@ def filt(recs, max_tile=-1, min_chain=-1, invert_=False):
     return [r for r in recs if (((max_tile < 0 or r.tile <= max_tile) and (min_chain < 0 or r.s1 >= min_chain)) != invert_)]
 
 
-# ---- random, valid PAF sets (no sequences needed: the chaining stage only reads coordinates, scores and cigars) -------------
-def random_paf(seed: int, n_series: int = 6, per_series=(1, 12), n_q: int = 2, n_t: int = 2, contig_len: int = 200_000, noise: int = 10,
-               ragged: bool = True) -> str:
-    rng = random.Random(seed)
-    qnames = [f"id=Q|chr{k}" for k in range(n_q)]
-    tnames = [f"id=T|chr{k}" for k in range(n_t)]
-
-    def cigar(max_cols):
-        ops, cols = [], 0
-        first = True
-        while cols < max_cols:
-            r = rng.random()
-            if first and ragged and r < 0.15:
-                o, n = rng.choice("XID"), rng.randint(1, 6)                # alignments a real aligner would not emit, the tool must still be defined
-            elif ops and ops[-1][1] == "=":
-                o = rng.choice("XXXID")
-                n = rng.randint(1, 3) if o == "X" else rng.randint(1, 40)
-            else:
-                o, n = "=", rng.randint(1, 120)
-            if ops and ops[-1][1] == o:
-                continue
-            ops.append((n, o)); cols += n; first = False
-        if not ragged or rng.random() < 0.8:
-            if ops[-1][1] != "=":
-                ops.append((rng.randint(1, 50), "="))
-        return ops
-
-    lines = []
-
-    def emit(qn, tn, strand, qpos, tpos, ops):
-        ql = tl = contig_len
-        qspan = sum(n for n, o in ops if o != "D"); tspan = sum(n for n, o in ops if o != "I")
-        if strand == "+":
-            qs, qe = qpos, qpos + qspan
-        else:
-            qe, qs = qpos, qpos - qspan
-        ts, te = tpos, tpos + tspan
-        if qs < 0 or qe > ql or te > tl or qspan == 0 or tspan == 0:
-            return None
-        nm = sum(n for n, o in ops if o == "=")
-        nb = sum(n for n, _ in ops)
-        score = max(1, 95 * nm - 110 * sum(n for n, o in ops if o == "X") - sum(400 + 30 * n for n, o in ops if o in "ID"))
-        if rng.random() < 0.1:
-            score = 5000                                                    # ties
-        tags = [f"AS:i:{score}"] if rng.random() < 0.97 else []
-        if rng.random() < 0.97:
-            tags.append("cg:Z:" + "".join(f"{n}{o}" for n, o in ops))
-        lines.append("\t".join(str(x) for x in [qn, ql, qs, qe, strand, tn, tl, ts, te, nm, nb, 255] + tags))
-        return qspan, tspan
-
-    for _ in range(n_series):
-        qn, tn, strand = rng.choice(qnames), rng.choice(tnames), rng.choice("+-")
-        qpos = rng.randint(1000, contig_len // 2) if strand == "+" else rng.randint(contig_len // 2, contig_len - 1000)
-        tpos = rng.randint(1000, contig_len // 2)
-        for _ in range(rng.randint(*per_series)):
-            ops = cigar(rng.randint(30, 3000))
-            got = emit(qn, tn, strand, qpos, tpos, ops)
-            if got is None:
-                break
-            gq, gt = rng.choice([0, 0, 5, 300, 4000, 60000]), rng.choice([0, 3, 200, 5000])
-            if rng.random() < 0.2:
-                gq, gt = -rng.randint(1, 200), -rng.randint(1, 200)            # overlapping neighbours
-            qpos = qpos + got[0] + gq if strand == "+" else qpos - got[0] - gq
-            tpos = tpos + got[1] + gt
-    for _ in range(noise):
-        qn, tn, strand = rng.choice(qnames), rng.choice(tnames), rng.choice("+-")
-        emit(qn, tn, strand, rng.randint(5000, contig_len - 5000), rng.randint(0, contig_len - 5000), cigar(rng.randint(20, 600)))
-    rng.shuffle(lines)
-    return "".join(l + "\n" for l in lines)
+# ---- random, valid PAF sets: cactus_amd.gen.random_paf (shared with bench.py) ------------------------------------------------
+from cactus_amd.gen import random_paf  # noqa: E402,F401
