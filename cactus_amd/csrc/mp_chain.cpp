@@ -283,6 +283,11 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
         const PafRec &r = set.recs[i];
         gkey[i] = ((unsigned long long)name_rank[r.qn] << 33) | ((unsigned long long)name_rank[r.tn] << 1) | (unsigned long long)r.same;
     }
+    {   // k_chain_dp packs (value, lane) into 64 bits: chain scores must stay below 2^57
+        long double sum = 0;
+        for (const PafRec &r : set.recs) sum += (long double)std::max<int64_t>(0, record_score(r));
+        if (sum >= 7.2e16L) throw std::length_error("chain scores could exceed 2^56: outside the range of the chain DP");
+    }
     std::vector<unsigned long long> uniq(gkey);
     std::sort(uniq.begin(), uniq.end());
     uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
@@ -311,7 +316,7 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
     Dev<uint32_t> d_pa(n), d_pb(n), d_gstart;
     Dev<ChainRec> d_rec, d_sorted(n);
     Dev<int64_t> d_lmax;
-    Dev<long long> d_cs(n);
+    Dev<long long> d_cs(n), d_tqe(n), d_tend(n);
     Dev<int32_t> d_pred(n);
     size_t temp_bytes = 0;
     for (int bits : {bits_for(max_ts), bits_for(max_qs), bits_for(ng), 64}) temp_bytes = std::max(temp_bytes, sort_pairs_temp_bytes((int64_t)n, bits));
@@ -331,11 +336,12 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
     sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pb.p, d_pa.p, (int64_t)n, bits_for(max_qs), s);
     launch_gather_u64(d_grp.p, d_pa.p, d_key.p, (int64_t)n, s);
     sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pa.p, d_pb.p, (int64_t)n, bits_for(ng), s);
-    launch_gather_chain(d_rec.p, d_pb.p, d_sorted.p, (int64_t)n, s);
+    launch_gather_chain(d_rec.p, d_pb.p, d_sorted.p, d_tqe.p, d_tend.p, (int64_t)n, s);
     st.t_sort_ms += t_sort.stop_ms();
 
     EventTimer t_dp(s);
-    launch_chain_dp(d_sorted.p, d_gstart.p, d_lmax.p, (int)ng, cp.max_gap_length, cp.gap_open, cp.gap_extend, d_cs.p, d_pred.p, s);
+    launch_chain_dp(d_sorted.p, d_tqe.p, d_tend.p, d_gstart.p, d_lmax.p, (int)ng, cp.max_gap_length, cp.gap_open, cp.gap_extend, d_cs.p, d_pred.p,
+                    (int)env_long_mp("MIPAF_CHAIN_THREADS", 1024), s);
     st.t_chain_dp_ms += t_dp.stop_ms();
 
     // R-C6 order: chain score descending, R-C1 position on ties

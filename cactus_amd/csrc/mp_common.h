@@ -42,9 +42,10 @@ void sort_pairs(void *temp, size_t temp_bytes, const unsigned long long *kin, un
 void launch_iota(uint32_t *v, int64_t n, hipStream_t s);
 void launch_gather_u64(const unsigned long long *src, const uint32_t *perm, unsigned long long *dst, int64_t n, hipStream_t s);
 void launch_desc_keys(const long long *v, unsigned long long *key, int64_t n, hipStream_t s);
-void launch_gather_chain(const ChainRec *src, const uint32_t *perm, ChainRec *dst, int64_t n, hipStream_t s);
-void launch_chain_dp(const ChainRec *recs, const uint32_t *gstart, const int64_t *glmax, int n_groups, long long max_gap,
-                     long long gap_open, long long gap_extend, long long *cs, int32_t *pred, hipStream_t s);
+void launch_gather_chain(const ChainRec *src, const uint32_t *perm, ChainRec *dst, long long *tqe, long long *tend, int64_t n, hipStream_t s);
+void launch_chain_dp(const ChainRec *recs, const long long *tqe, const long long *tend, const uint32_t *gstart, const int64_t *glmax,
+                     int n_groups, long long max_gap, long long gap_open, long long gap_extend, long long *cs, int32_t *pred, int threads,
+                     hipStream_t s);
 void launch_tile(const TileRec *recs, const uint32_t *qstart, const uint64_t *cnt_off, int n_queries, uint16_t *cnt,
                  const uint32_t *ops, const uint32_t *qoff, int hist_bins, int32_t *level, hipStream_t s);
 // sort-based tiling (mp_kernels.hip "Tiling without the walk")

@@ -58,69 +58,115 @@ void launch_desc_keys(const long long *v, unsigned long long *key, int64_t n, hi
     if (n > 0) hipLaunchKernelGGL(k_desc_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, key, n);
 }
 
-__global__ void k_gather_chain(const ChainRec *__restrict__ src, const uint32_t *__restrict__ perm, ChainRec *__restrict__ dst, int64_t n) {
+// records into R-C1 order; beside the records the two coordinates a candidate predecessor is asked for, as plain arrays (the
+// window scan of k_chain_dp reads 24 B per candidate, coalesced, instead of the 64-byte record)
+__global__ void k_gather_chain(const ChainRec *__restrict__ src, const uint32_t *__restrict__ perm, ChainRec *__restrict__ dst,
+                               long long *__restrict__ tqe, long long *__restrict__ tend, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[perm[i]];
+    if (i >= n) return;
+    const ChainRec r = src[perm[i]];
+    dst[i] = r;
+    tqe[i] = r.tqe;
+    tend[i] = r.same ? r.tte : r.tts;                        // the end a successor's gap is measured from (R-C3)
 }
-void launch_gather_chain(const ChainRec *src, const uint32_t *perm, ChainRec *dst, int64_t n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_gather_chain, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, perm, dst, n);
+void launch_gather_chain(const ChainRec *src, const uint32_t *perm, ChainRec *dst, long long *tqe, long long *tend, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_chain, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, perm, dst, tqe, tend, n);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Chain DP.  recs are in R-C1 order, group g = [gstart[g], gstart[g+1]).  cs_i needs cs_j of every earlier record of
-// the group, so a group is walked in order; the predecessor window of record i starts at the first j with
-// qs_j >= tqs_i - maxGap - (longest query span of the group): an earlier j ends too far back to satisfy gq <= maxGap.
-// Per lane candidates are visited in ascending j with a strict ">", the cross-lane reduction prefers the smaller j on
-// equal values: together the first maximal j in R-C1 order (R-C5).
-__global__ __launch_bounds__(256) void k_chain_dp(const ChainRec *__restrict__ recs, const uint32_t *__restrict__ gstart,
-                                                  const int64_t *__restrict__ glmax, const long long G, const long long gap_open,
-                                                  const long long gap_extend, long long *cs, int32_t *__restrict__ pred) {
+// Chain DP.  recs are in R-C1 order, group g = [gstart[g], gstart[g+1]); one workgroup per group.  cs_i needs cs_j of
+// earlier records of the group, so a group is walked in order -- 64 records (a tile) at a time:
+//   phase A  candidates BEFORE the tile (their cs is final): the waves share the tile's records, the 64 lanes of a wave stride
+//            over the window of one record.  The window starts at the first j with qs_j >= tqs_i - maxGap - (longest query
+//            span of the group): an earlier j ends too far back to satisfy gq <= maxGap.
+//   phase B  candidates INSIDE the tile: one wave, lane l keeps record l and its cs in registers; record after record takes
+//            the maximum over the lanes before it (one 64-bit max-reduction of value << 6 | 63 - lane) and the phase A result.
+// Ties go to the smaller j everywhere (per lane ascending j with a strict ">", smaller j preferred across lanes, phase A
+// before phase B): the first maximal j in R-C1 order (R-C5).  Chain scores must stay below 2^57 (checked by the host).
+__global__ __launch_bounds__(1024) void k_chain_dp(const ChainRec *__restrict__ recs, const long long *__restrict__ tqe,
+                                                   const long long *__restrict__ tend, const uint32_t *__restrict__ gstart,
+                                                   const int64_t *__restrict__ glmax, const long long G, const long long gap_open,
+                                                   const long long gap_extend, long long *cs, int32_t *__restrict__ pred) {
     const int g = blockIdx.x;
     const int lo = (int)gstart[g], hi = (int)gstart[g + 1];
+    if (lo >= hi) return;
     const long long lmax = glmax[g];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ long long s_val[4];
-    __shared__ int s_j[4];
-    for (int i = lo; i < hi; i++) {
-        const ChainRec r = recs[i];
-        const long long need = r.tqs - G - lmax;
-        int a = lo, b = i;
-        while (a < b) {
-            const int m = (a + b) >> 1;
-            if (recs[m].qs < need) a = m + 1; else b = m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+    const bool same = recs[lo].same != 0;
+    __shared__ long long s_tqs[64], s_tqe[64], s_tts[64], s_tte[64], s_score[64], s_ext[64];
+    __shared__ int s_extj[64];
+    for (int t0 = lo; t0 < hi; t0 += 64) {
+        const int tn = hi - t0 < 64 ? hi - t0 : 64;
+        if (tid < tn) {
+            const ChainRec r = recs[t0 + tid];
+            s_tqs[tid] = r.tqs; s_tqe[tid] = r.tqe; s_tts[tid] = r.tts; s_tte[tid] = r.tte; s_score[tid] = r.score;
         }
-        long long best = 0;
-        int bj = INT_MAX;
-        for (int j = a + tid; j < i; j += 256) {
-            const ChainRec q = recs[j];
-            const long long gq = r.tqs - q.tqe;
-            const long long gt = r.same ? r.tts - q.tte : q.tts - r.tte;
-            if (gq >= 0 && gt >= 0 && gq <= G && gt <= G) {
-                const long long val = cs[j] - (gap_open + gap_extend * (gq + gt));
-                if (val > best) { best = val; bj = j; }
+        __syncthreads();
+        for (int ii = wave; ii < tn; ii += nw) {             // phase A
+            const long long rtqs = s_tqs[ii], rt = same ? s_tts[ii] : s_tte[ii];
+            const long long need = rtqs - G - lmax;
+            int a = lo, b = t0;
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if (recs[m].qs < need) a = m + 1; else b = m;
+            }
+            long long best = 0;
+            int bj = INT_MAX;
+            for (int j = a + lane; j < t0; j += 64) {
+                const long long gq = rtqs - tqe[j];
+                const long long gt = same ? rt - tend[j] : tend[j] - rt;
+                if (gq >= 0 && gt >= 0 && gq <= G && gt <= G) {
+                    const long long val = cs[j] - (gap_open + gap_extend * (gq + gt));
+                    if (val > best) { best = val; bj = j; }
+                }
+            }
+            for (int off = 32; off; off >>= 1) {
+                const long long ov = __shfl_xor(best, off);
+                const int oj = __shfl_xor(bj, off);
+                if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+            }
+            if (lane == 0) { s_ext[ii] = best; s_extj[ii] = bj; }
+        }
+        __syncthreads();
+        if (wave == 0) {                                     // phase B
+            long long my_cs = 0;
+            const long long q_tqe = lane < tn ? s_tqe[lane] : 0;
+            const long long q_tend = lane < tn ? (same ? s_tte[lane] : s_tts[lane]) : 0;
+            for (int ii = 0; ii < tn; ii++) {
+                const long long rtqs = s_tqs[ii], rt = same ? s_tts[ii] : s_tte[ii];
+                unsigned long long key = 0;
+                if (lane < ii) {
+                    const long long gq = rtqs - q_tqe;
+                    const long long gt = same ? rt - q_tend : q_tend - rt;
+                    if (gq >= 0 && gt >= 0 && gq <= G && gt <= G) {
+                        const long long val = my_cs - (gap_open + gap_extend * (gq + gt));
+                        if (val > 0) key = ((unsigned long long)val << 6) | (unsigned long long)(63 - lane);
+                    }
+                }
+                for (int off = 32; off; off >>= 1) {
+                    const unsigned long long o = __shfl_xor(key, off);
+                    key = o > key ? o : key;
+                }
+                long long best = (long long)(key >> 6);
+                int bj = best > 0 ? t0 + 63 - (int)(key & 63ull) : INT_MAX;
+                const long long ev = s_ext[ii];
+                if (ev > 0 && ev >= best) { best = ev; bj = s_extj[ii]; }
+                const long long c = s_score[ii] + best;
+                if (lane == ii) my_cs = c;
+                if (lane == 0) { cs[t0 + ii] = c; pred[t0 + ii] = best > 0 ? bj : -1; }
             }
         }
-        for (int off = 32; off; off >>= 1) {
-            const long long ov = __shfl_xor(best, off);
-            const int oj = __shfl_xor(bj, off);
-            if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
-        }
-        if (lane == 0) { s_val[wave] = best; s_j[wave] = bj; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; w++)
-                if (s_val[w] > best || (s_val[w] == best && s_j[w] < bj)) { best = s_val[w]; bj = s_j[w]; }
-            cs[i] = r.score + best;
-            pred[i] = best > 0 ? bj : -1;
-        }
-        __syncthreads();                                   // cs[i] is read by the records that follow
+        __syncthreads();                                     // the tile's cs are read by the tiles that follow
     }
 }
 
-void launch_chain_dp(const ChainRec *recs, const uint32_t *gstart, const int64_t *glmax, int n_groups, long long max_gap,
-                     long long gap_open, long long gap_extend, long long *cs, int32_t *pred, hipStream_t s) {
+void launch_chain_dp(const ChainRec *recs, const long long *tqe, const long long *tend, const uint32_t *gstart, const int64_t *glmax,
+                     int n_groups, long long max_gap, long long gap_open, long long gap_extend, long long *cs, int32_t *pred, int threads,
+                     hipStream_t s) {
+    threads = threads < 64 ? 64 : threads > 1024 ? 1024 : threads & ~63;
     if (n_groups > 0)
-        hipLaunchKernelGGL(k_chain_dp, dim3((unsigned)n_groups), dim3(256), 0, s, recs, gstart, glmax, max_gap, gap_open, gap_extend, cs, pred);
+        hipLaunchKernelGGL(k_chain_dp, dim3((unsigned)n_groups), dim3((unsigned)threads), 0, s, recs, tqe, tend, gstart, glmax, max_gap, gap_open,
+                           gap_extend, cs, pred);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -24,7 +24,8 @@ def built():
 
 
 def run(exe, cmd, text, *args):
-    p = subprocess.run([exe, cmd, *args], input=text.encode(), capture_output=True)
+    # 4 waves per workgroup of the chain DP instead of 16: fewer pthreads per emulated group, same code path
+    p = subprocess.run([exe, cmd, *args], input=text.encode(), capture_output=True, env=dict(os.environ, MIPAF_CHAIN_THREADS="256"))
     assert p.returncode == 0, p.stderr.decode()
     return p.stdout.decode()
 
@@ -40,6 +41,10 @@ def test_emulated_kernels_match_the_oracle_step_by_step(seed):
     chained = run(ORACLE, "chain", text, *CHAIN_ARGS)
     assert run(EMU, "chain", text, *CHAIN_ARGS) == chained
     assert run(EMU, "chain", text, *TIGHT_ARGS) == run(ORACLE, "chain", text, *TIGHT_ARGS)
+    if seed == 0:                                            # one wave / sixteen waves per workgroup
+        for threads in ("64", "1024"):
+            p = subprocess.run([EMU, "chain", *CHAIN_ARGS], input=text.encode(), capture_output=True, env=dict(os.environ, MIPAF_CHAIN_THREADS=threads))
+            assert p.returncode == 0 and p.stdout.decode() == chained, threads
     tiled = run(ORACLE, "tile", chained)
     assert run(EMU, "tile", chained) == tiled                                     # sort-based levelling
     assert run(EMU, "tile", chained, "--mipaf-hist-bins", "2") == tiled          # counter walk, every level above 1 through the bisection

@@ -122,6 +122,14 @@ def test_large_groups_windows_and_ties(ctx):
     assert mipaf.PafSet.from_text(text).chain_tile_trim_filter(ctx, None, "0.2", 10000).text() == oracle_job(text)
 
 
+@pytest.mark.parametrize("threads", ["64", "256", "512"])
+def test_chain_dp_workgroup_size_does_not_change_a_byte(ctx, monkeypatch, threads):
+    text = both_ways(43, n_series=30, per_series=(10, 40), n_q=1, n_t=1, contig_len=2_000_000, noise=300)
+    monkeypatch.setenv("MIPAF_CHAIN_THREADS", threads)
+    assert mipaf.PafSet.from_text(text).chain(ctx).text() == oracle("chain", text, *CHAIN_ARGS)
+    assert mipaf.PafSet.from_text(text).chain(ctx, TIGHT).text() == oracle("chain", text, *TIGHT_ARGS)
+
+
 def test_pile_up_falls_back_to_the_counter_walk(ctx, monkeypatch):
     text = both_ways(9, n_series=8, noise=30)
     chained = oracle("chain", text, *CHAIN_ARGS)
