@@ -182,6 +182,7 @@ void miblast_ctx_destroy(miblast_ctx *c) {
     if (c->c.ev4) (void)hipEventDestroy(c->c.ev4);
     if (c->c.stream) (void)hipStreamDestroy(c->c.stream);
     mb::workspace_destroy(c->c.ws);
+    mb::chain_cache_destroy(c->c.chain_cache);
     delete c;
 }
 

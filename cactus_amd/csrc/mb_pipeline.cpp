@@ -298,6 +298,11 @@ void parallel_sort(It first, It last, Cmp cmp) {
 
 }  // namespace
 
+// the worker pool for the other translation units of the library (mp_chain.cpp)
+void host_parallel_for(size_t n, const std::function<void(size_t)> &f) { Pool::get().run(n, f); }
+HostHot::HostHot() { Pool::get(); new (&impl) Pool::Hot(); }
+HostHot::~HostHot() { reinterpret_cast<Pool::Hot *>(&impl)->~Hot(); }
+
 int set_host_threads(int n) { return Pool::get().resize(n < 0 ? 0u : (unsigned)n) ? (int)Pool::get().threads() : -1; }
 int host_threads() { return (int)Pool::get().threads(); }
 

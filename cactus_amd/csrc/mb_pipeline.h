@@ -3,6 +3,8 @@
 
 #include "mb_common.h"
 
+#include <functional>
+
 namespace mb {
 
 struct Workspace;
@@ -14,7 +16,9 @@ struct Ctx {
     Workspace *ws = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
+    void *chain_cache = nullptr;        // device buffers the chaining stage keeps between calls (mp_chain.cpp)
 };
+void chain_cache_destroy(void *cache);  // mp_chain.cpp
 
 struct Result {
     std::string paf;
@@ -28,6 +32,16 @@ void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
 int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &p, Result &res);
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &p, Result **results);
+// independent work items on the library's persistent worker threads (the caller takes part; nested calls run inline)
+void host_parallel_for(size_t n, const std::function<void(size_t)> &f);
+struct HostHot {                        // keeps the workers spinning for the duration of a job (they sleep otherwise)
+    HostHot();
+    ~HostHot();
+    HostHot(const HostHot &) = delete;
+    HostHot &operator=(const HostHot &) = delete;
+private:
+    alignas(8) unsigned char impl[8];
+};
 int set_host_threads(int n);      // 0 = automatic; returns the threads in use or -1 (a job is running)
 int host_threads();
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions);

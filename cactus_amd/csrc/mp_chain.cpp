@@ -56,18 +56,72 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+long env_long_mp(const char *name, long dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atol(v) : dflt;
+}
+
+// Device buffers of the chaining stage are kept by the context between calls: a job makes ~60 temporaries and hipMalloc /
+// hipFree (which synchronises) cost more than its kernels.  get() hands out the smallest free buffer that fits without
+// wasting more than 4x, else allocates; buffers return on destruction of their Dev<>.  One job at a time per context.
+struct DevCache {
+    struct Slot { void *p; size_t cap; bool used; };
+    std::vector<Slot> slots;
+    size_t total = 0;
+    void *get(size_t bytes, size_t &cap) {
+        bytes = std::max<size_t>(bytes, 256);
+        int best = -1;
+        for (size_t i = 0; i < slots.size(); i++)
+            if (!slots[i].used && slots[i].cap >= bytes && slots[i].cap <= 4 * bytes + (1u << 20) && (best < 0 || slots[i].cap < slots[(size_t)best].cap)) best = (int)i;
+        if (best >= 0) { slots[(size_t)best].used = true; cap = slots[(size_t)best].cap; return slots[(size_t)best].p; }
+        const size_t want = ((bytes + bytes / 4 + 0xffff) >> 16) << 16;
+        void *p = nullptr;
+        MB_HIP(hipMalloc(&p, want));
+        slots.push_back(Slot{p, want, true});
+        total += want;
+        cap = want;
+        return p;
+    }
+    void put(void *p) {
+        for (Slot &s : slots) if (s.p == p) { s.used = false; return; }
+    }
+    void trim(size_t keep_bytes) {                            // after a job: give back what is idle beyond the budget
+        for (size_t i = slots.size(); i-- > 0 && total > keep_bytes;)
+            if (!slots[i].used) { (void)hipFree(slots[i].p); total -= slots[i].cap; slots.erase(slots.begin() + (long)i); }
+    }
+    ~DevCache() { for (Slot &s : slots) (void)hipFree(s.p); }
+};
+thread_local DevCache *g_cache = nullptr;
+struct UseCache {                          // the calling thread's Dev<> objects draw from this context's cache
+    DevCache *prev;
+    explicit UseCache(Ctx &ctx) : prev(g_cache) {
+        if (!ctx.chain_cache) ctx.chain_cache = new DevCache();
+        g_cache = (DevCache *)ctx.chain_cache;
+    }
+    ~UseCache() {
+        if (g_cache) g_cache->trim((size_t)std::max(0l, env_long_mp("MIPAF_CACHE_MB", 8192)) << 20);
+        g_cache = prev;
+    }
+};
+
 template <typename T>
 struct Dev {                               // device array with the lifetime of one call
     T *p = nullptr;
     size_t n = 0;
+    DevCache *from = nullptr;
     Dev() = default;
     explicit Dev(size_t count) { alloc(count); }
     Dev(const Dev &) = delete;
     Dev &operator=(const Dev &) = delete;
-    ~Dev() { if (p) (void)hipFree(p); }
+    ~Dev() {
+        if (!p) return;
+        if (from) from->put(p); else (void)hipFree(p);
+    }
     void alloc(size_t count) {
         n = count;
-        MB_HIP(hipMalloc((void **)&p, std::max<size_t>(1, count) * sizeof(T)));
+        const size_t bytes = std::max<size_t>(1, count) * sizeof(T);
+        if (g_cache) { size_t cap; p = (T *)g_cache->get(bytes, cap); from = g_cache; }
+        else MB_HIP(hipMalloc((void **)&p, bytes));
     }
     void upload(const std::vector<T> &v, hipStream_t s) {
         if (!p) alloc(v.size());
@@ -97,10 +151,19 @@ struct EventTimer {                        // HIP-event time of a stretch of the
     }
 };
 
-long env_long_mp(const char *name, long dflt) {
-    const char *v = getenv(name);
-    return v && *v ? atol(v) : dflt;
-}
+struct PhaseLog {                          // MIPAF_DEBUG=1: host wall time per phase of a call, on stderr
+    const char *what;
+    bool on;
+    double t0, last;
+    explicit PhaseLog(const char *w) : what(w), on(getenv("MIPAF_DEBUG") != nullptr), t0(now_s()), last(t0) {}
+    void mark(const char *phase) {
+        if (!on) return;
+        const double t = now_s();
+        fprintf(stderr, "[mipaf] %s: %-28s %7.2f ms\n", what, phase, (t - last) * 1e3);
+        last = t;
+    }
+    ~PhaseLog() { if (on) fprintf(stderr, "[mipaf] %s: total %.2f ms\n", what, (now_s() - t0) * 1e3); }
+};
 
 int bits_for(unsigned long long mx) {
     int b = 1;
@@ -115,7 +178,7 @@ bool parse_i64(const char *b, const char *e, int64_t &v) {
     return r.ec == std::errc() && r.ptr == e;
 }
 
-int parse_line(PafSet &set, const char *b, const char *e, size_t line_no) {
+int parse_line(PafSet &set, const char *b, const char *e, std::string &err) {
     const char *col[13];
     const char *end[13];
     int n = 0;
@@ -131,7 +194,7 @@ int parse_line(PafSet &set, const char *b, const char *e, size_t line_no) {
         if (n == 12) tags = p;
     }
     auto bad = [&](const char *what) {
-        set_error("PAF line " + std::to_string(line_no) + ": " + what);
+        err = what;
         return MIBLAST_EINVAL;
     };
     if (n < 12) return bad("fewer than 12 columns");
@@ -177,7 +240,8 @@ int parse_line(PafSet &set, const char *b, const char *e, size_t line_no) {
     return MIBLAST_OK;
 }
 
-int parse_text(PafSet &set, const char *text, size_t len) {
+// parses text[0, len) into `set`; on a malformed line returns its 1-based number (within this text) in bad_line
+int parse_chunk(PafSet &set, const char *text, size_t len, size_t &bad_line, std::string &err) {
     size_t line_no = 0;
     for (const char *p = text, *end = text + len; p < end;) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
@@ -186,10 +250,59 @@ int parse_text(PafSet &set, const char *text, size_t len) {
         while (le > p && (le[-1] == '\r' || le[-1] == '\n')) le--;
         line_no++;
         if (le > p) {
-            int rc = parse_line(set, p, le, line_no);
-            if (rc != MIBLAST_OK) return rc;
+            int rc = parse_line(set, p, le, err);
+            if (rc != MIBLAST_OK) { bad_line = line_no; return rc; }
         }
         p = nl ? nl + 1 : end;
+    }
+    return MIBLAST_OK;
+}
+
+// Large inputs are cut at line ends into one chunk per worker thread, parsed into private sets and merged in order (names
+// re-interned, op offsets shifted): the result is the same as one pass over the text.
+int parse_text(PafSet &set, const char *text, size_t len) {
+    const size_t kMinChunk = 1u << 19;
+    size_t parts = std::min<size_t>((size_t)std::max(1, host_threads()), len / kMinChunk);
+    if (parts <= 1) {
+        size_t bad = 0;
+        std::string err;
+        int rc = parse_chunk(set, text, len, bad, err);
+        if (rc != MIBLAST_OK) set_error("PAF line " + std::to_string(bad) + ": " + err);
+        return rc;
+    }
+    std::vector<size_t> cut(parts + 1, len);
+    cut[0] = 0;
+    for (size_t k = 1; k < parts; k++) {
+        size_t at = std::max(cut[k - 1], len * k / parts);
+        const char *nl = at < len ? (const char *)memchr(text + at, '\n', len - at) : nullptr;
+        cut[k] = nl ? (size_t)(nl - text) + 1 : len;
+    }
+    std::vector<PafSet> sub(parts);
+    std::vector<int> rc(parts, MIBLAST_OK);
+    std::vector<size_t> bad(parts, 0);
+    std::vector<std::string> err(parts);
+    host_parallel_for(parts, [&](size_t k) { rc[k] = parse_chunk(sub[k], text + cut[k], cut[k + 1] - cut[k], bad[k], err[k]); });
+    for (size_t k = 0; k < parts; k++)
+        if (rc[k] != MIBLAST_OK) {
+            size_t before = 0;
+            for (const char *p = text; (p = (const char *)memchr(p, '\n', (size_t)(text + cut[k] - p))) != nullptr; p++) before++;
+            set_error("PAF line " + std::to_string(before + bad[k]) + ": " + err[k]);
+            return rc[k];
+        }
+    size_t n_recs = set.recs.size(), n_ops = set.ops.size();
+    for (const PafSet &p : sub) { n_recs += p.recs.size(); n_ops += p.ops.size(); }
+    set.recs.reserve(n_recs);
+    set.ops.reserve(n_ops);
+    for (PafSet &p : sub) {
+        std::vector<uint32_t> remap(p.names.size());
+        for (size_t i = 0; i < p.names.size(); i++) remap[i] = set.intern(p.names[i].data(), p.names[i].size());
+        const uint64_t shift = set.ops.size();
+        set.ops.insert(set.ops.end(), p.ops.begin(), p.ops.end());
+        for (PafRec r : p.recs) {
+            r.qn = remap[r.qn]; r.tn = remap[r.tn];
+            if (r.has_cg) r.ops_off += shift;
+            set.recs.push_back(r);
+        }
     }
     return MIBLAST_OK;
 }
@@ -226,9 +339,21 @@ void format_rec(const PafSet &set, const PafRec &r, std::string &out) {
 }
 
 std::string format_set(const PafSet &set) {
-    std::string out;
-    out.reserve(set.recs.size() * 96 + set.ops.size() * 4);
-    for (const PafRec &r : set.recs) format_rec(set, r, out);
+    const size_t n = set.recs.size();
+    const size_t parts = std::min<size_t>((size_t)std::max(1, host_threads()), std::max<size_t>(1, n / 2048));
+    std::vector<std::string> piece(parts);
+    host_parallel_for(parts, [&](size_t k) {
+        const size_t a = n * k / parts, b = n * (k + 1) / parts;
+        size_t ops = 0;
+        for (size_t i = a; i < b; i++) ops += set.recs[i].n_ops;
+        piece[k].reserve((b - a) * 112 + ops * 5);
+        for (size_t i = a; i < b; i++) format_rec(set, set.recs[i], piece[k]);
+    });
+    if (parts == 1) return std::move(piece[0]);
+    std::vector<size_t> at(parts + 1, 0);
+    for (size_t k = 0; k < parts; k++) at[k + 1] = at[k] + piece[k].size();
+    std::string out(at[parts], '\0');
+    host_parallel_for(parts, [&](size_t k) { memcpy(&out[at[k]], piece[k].data(), piece[k].size()); });
     return out;
 }
 
@@ -243,23 +368,30 @@ int write_all(int fd, const char *p, size_t n) {
 
 // a cigar must walk exactly the intervals of its record (the contract caf asserts later)
 int check_cigars(const PafSet &set) {
-    for (size_t i = 0; i < set.recs.size(); i++) {
-        const PafRec &r = set.recs[i];
-        bool ok = r.qs >= 0 && r.qs <= r.qe && r.qe <= r.ql && r.ts >= 0 && r.ts <= r.te && r.te <= r.tl;
-        if (ok && r.has_cg) {
-            int64_t q = 0, t = 0;
-            for (uint32_t k = 0; k < r.n_ops; k++) {
-                const uint32_t o = set.ops[r.ops_off + k];
-                if ((o & 7u) != kOpD) q += o >> 3;
-                if ((o & 7u) != kOpI) t += o >> 3;
+    const size_t n = set.recs.size();
+    const size_t parts = std::min<size_t>((size_t)std::max(1, host_threads()), std::max<size_t>(1, n / 4096));
+    std::vector<size_t> first_bad(parts, SIZE_MAX);
+    host_parallel_for(parts, [&](size_t k) {
+        for (size_t i = n * k / parts, e = n * (k + 1) / parts; i < e; i++) {
+            const PafRec &r = set.recs[i];
+            bool ok = r.qs >= 0 && r.qs <= r.qe && r.qe <= r.ql && r.ts >= 0 && r.ts <= r.te && r.te <= r.tl;
+            if (ok && r.has_cg) {
+                int64_t q = 0, t = 0;
+                for (uint32_t o = 0; o < r.n_ops; o++) {
+                    const uint32_t op = set.ops[r.ops_off + o];
+                    if ((op & 7u) != kOpD) q += op >> 3;
+                    if ((op & 7u) != kOpI) t += op >> 3;
+                }
+                ok = q == r.qe - r.qs && t == r.te - r.ts;
             }
-            ok = q == r.qe - r.qs && t == r.te - r.ts;
+            if (!ok) { first_bad[k] = i; return; }
         }
-        if (!ok) {
-            set_error("PAF record " + std::to_string(i + 1) + ": coordinates and cigar do not agree");
+    });
+    for (size_t k = 0; k < parts; k++)
+        if (first_bad[k] != SIZE_MAX) {
+            set_error("PAF record " + std::to_string(first_bad[k] + 1) + ": coordinates and cigar do not agree");
             return MIBLAST_EINVAL;
         }
-    }
     return MIBLAST_OK;
 }
 
@@ -273,6 +405,8 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
     if (n >= (1ull << 31)) throw std::length_error("more than 2^31 PAF records in one chaining job");
     MB_HIP(hipSetDevice(ctx.device));
     hipStream_t s = ctx.stream;
+    UseCache use_cache(ctx);
+    PhaseLog log("chain");
     // R-C1: names compare as byte strings; a group = (query, target, strand), numbered in that order
     std::vector<uint32_t> by_name(set.names.size()), name_rank(set.names.size());
     for (uint32_t i = 0; i < by_name.size(); i++) by_name[i] = i;
@@ -312,6 +446,7 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
     }
     for (size_t g = 0; g < ng; g++) gcount[g + 1] += gcount[g];
 
+    log.mark("keys, groups, boxes (host)");
     Dev<unsigned long long> d_key(n), d_key2(n), d_ts, d_qs, d_grp;
     Dev<uint32_t> d_pa(n), d_pb(n), d_gstart;
     Dev<ChainRec> d_rec, d_sorted(n);
@@ -328,6 +463,7 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
     d_qs.upload(k_qs, s);
     d_grp.upload(k_grp, s);
 
+    log.mark("alloc + upload");
     EventTimer t_sort(s);
     // LSD over the sort keys: target start, then query start, then group; ties keep the input order (the sorts are stable)
     launch_iota(d_pa.p, (int64_t)n, s);
@@ -361,6 +497,7 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
     d_pred.download(pred, s);
     MB_HIP(hipStreamSynchronize(s));
 
+    log.mark("sorts + dp + download");
     // peel the chains off (R-C6): sequential by nature, O(n)
     std::vector<int64_t> cn(n, -1), s1(n, -1);              // by R-C1 position
     int64_t next_id = 0;
@@ -385,6 +522,7 @@ void chain(Ctx &ctx, PafSet &set, const mipaf_chain_params &cp, mipaf_stats &st)
         out[at[(size_t)cn[p]]++] = r;
     }
     set.recs.swap(out);
+    log.mark("peel + reorder (host)");
     // pairs (j before i) inside the groups: the upper bound of the candidates the DP inspects (56 B of ChainRec + 8 B of cs each)
     st.chain_pairs = 0;
     for (size_t g = 0; g < ng; g++) { const int64_t m = gcount[g + 1] - gcount[g]; st.chain_pairs += m * (m - 1) / 2; }
@@ -398,29 +536,47 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
                      const std::vector<uint64_t> &seq_off, uint64_t max_pieces, std::vector<int32_t> &level_by_rank, mipaf_stats &st) {
     const size_t n = rank.size();
     hipStream_t s = ctx.stream;
+    PhaseLog log("tile/sorting");
     // maximal runs of aligned query bases (= X M; a D does not move along the query, an I ends the run)
     std::vector<unsigned long long> rs, re, bounds;
     std::vector<uint32_t> rrank;
-    for (size_t k = 0; k < n; k++) {
-        const PafRec &r = set.recs[rank[k]];
-        if (!r.has_cg) continue;
-        const uint64_t base = seq_off[qid_of_name[r.qn]];
-        int64_t q = r.same ? r.qs : r.qe, open_at = -1;
-        auto close = [&](int64_t at) {
-            if (open_at < 0) return;
-            const uint64_t a = base + (uint64_t)std::min(open_at, at), b = base + (uint64_t)std::max(open_at, at);
-            if (b > a) { rs.push_back(a); re.push_back(b); rrank.push_back((uint32_t)k); }
-            open_at = -1;
-        };
-        for (uint32_t o = 0; o < r.n_ops; o++) {
-            const uint32_t op = set.ops[r.ops_off + o], code = op & 7u;
-            const int64_t len = op >> 3;
-            if (code == kOpD) continue;
-            if (code == kOpI) { close(q); q += r.same ? len : -len; continue; }
-            if (open_at < 0) open_at = q;
-            q += r.same ? len : -len;
-        }
-        close(q);
+    {
+        const size_t parts = std::min<size_t>((size_t)std::max(1, host_threads()), std::max<size_t>(1, n / 1024));
+        std::vector<std::vector<unsigned long long>> prs(parts), pre(parts);
+        std::vector<std::vector<uint32_t>> prk(parts);
+        host_parallel_for(parts, [&](size_t part) {
+            std::vector<unsigned long long> &lrs = prs[part], &lre = pre[part];
+            std::vector<uint32_t> &lrk = prk[part];
+            for (size_t k = n * part / parts, k_end = n * (part + 1) / parts; k < k_end; k++) {
+                const PafRec &r = set.recs[rank[k]];
+                if (!r.has_cg) continue;
+                const uint64_t base = seq_off[qid_of_name[r.qn]];
+                int64_t q = r.same ? r.qs : r.qe, open_at = -1;
+                auto close = [&](int64_t at) {
+                    if (open_at < 0) return;
+                    const uint64_t a = base + (uint64_t)std::min(open_at, at), b = base + (uint64_t)std::max(open_at, at);
+                    if (b > a) { lrs.push_back(a); lre.push_back(b); lrk.push_back((uint32_t)k); }
+                    open_at = -1;
+                };
+                for (uint32_t o = 0; o < r.n_ops; o++) {
+                    const uint32_t op = set.ops[r.ops_off + o], code = op & 7u;
+                    const int64_t len = op >> 3;
+                    if (code == kOpD) continue;
+                    if (code == kOpI) { close(q); q += r.same ? len : -len; continue; }
+                    if (open_at < 0) open_at = q;
+                    q += r.same ? len : -len;
+                }
+                close(q);
+            }
+        });
+        std::vector<size_t> at(parts + 1, 0);
+        for (size_t p = 0; p < parts; p++) at[p + 1] = at[p] + prs[p].size();
+        rs.resize(at[parts]); re.resize(at[parts]); rrank.resize(at[parts]);
+        host_parallel_for(parts, [&](size_t p) {
+            std::copy(prs[p].begin(), prs[p].end(), rs.begin() + (long)at[p]);
+            std::copy(pre[p].begin(), pre[p].end(), re.begin() + (long)at[p]);
+            std::copy(prk[p].begin(), prk[p].end(), rrank.begin() + (long)at[p]);
+        });
     }
     const size_t nr = rs.size();
     level_by_rank.assign(n, 1);
@@ -430,6 +586,7 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
     bounds.insert(bounds.end(), re.begin(), re.end());
     const size_t nb = bounds.size();
     const int coord_bits = bits_for(seq_off.back());
+    log.mark("runs (host)");
 
     EventTimer t(s);
     Dev<unsigned long long> d_b, d_bs(nb), d_flag(nb), d_pos(nb), d_rs, d_re, d_cnt(nr), d_off(nr);
@@ -437,6 +594,7 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
     d_b.upload(bounds, s); d_rs.upload(rs, s); d_re.upload(re, s); d_rrank.upload(rrank, s);
     size_t temp_bytes = std::max(sort_keys64_temp_bytes((int64_t)nb, coord_bits), scan_u64_temp_bytes((int64_t)nb));
     Dev<uint8_t> d_temp(temp_bytes);
+    log.mark("alloc + upload");
     sort_keys64(d_temp.p, temp_bytes, d_b.p, d_bs.p, (int64_t)nb, coord_bits, s);
     launch_tile_heads(d_bs.p, (int64_t)nb, d_flag.p, s);
     scan_u64(d_temp.p, temp_bytes, d_flag.p, d_pos.p, (int64_t)nb, false, s);
@@ -454,6 +612,7 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
     MB_HIP(hipMemcpyAsync(&last_cnt, d_cnt.p + (nr - 1), sizeof last_cnt, hipMemcpyDeviceToHost, s));
     MB_HIP(hipStreamSynchronize(s));
     const uint64_t np = last_off + last_cnt;
+    log.mark("intervals + spans");
     if (np > max_pieces) { st.t_tile_ms += t.stop_ms(); return false; }
     Dev<unsigned long long> d_key(np), d_key_s(np), d_key2(np), d_w64(np), d_wsum(np);
     Dev<uint32_t> d_w(np), d_w_s(np);
@@ -472,6 +631,7 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
     st.t_tile_ms += t.stop_ms();
     d_level.download(level_by_rank, s);
     MB_HIP(hipStreamSynchronize(s));
+    log.mark("pieces, sorts, median");
     st.ops = (int64_t)np;                                    // pieces: the unit of work of this path
     return true;
 }
@@ -481,6 +641,8 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     st.records = (int64_t)n;
     if (n == 0) return;
     if (n >= (1ull << 31)) throw std::length_error("more than 2^31 PAF records in one tiling job");
+    UseCache use_cache(ctx);
+    PhaseLog log("tile");
     const bool force_walk = hist_bins > 0;
     if (hist_bins <= 0) hist_bins = 4096;
     hist_bins = std::min(8192, std::max(2, hist_bins));
@@ -517,6 +679,7 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     }
     d_rank.download(rank, s);
     MB_HIP(hipStreamSynchronize(s));
+    log.mark("keys + order");
 
     std::vector<int32_t> level;                              // by input index
     bool done = false;
@@ -576,6 +739,7 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     d_level.download(level, s);
     MB_HIP(hipStreamSynchronize(s));
     }
+    log.mark("levels");
     std::vector<PafRec> out(n);
     for (size_t k = 0; k < n; k++) {                         // R-T5
         PafRec r = set.recs[rank[k]];
@@ -611,6 +775,8 @@ void trim(Ctx &ctx, PafSet &set, long long num, long long den, mipaf_stats &st) 
         if (set.recs[i].has_cg && set.recs[i].n_ops) { trec.push_back(TrimRec{set.recs[i].ops_off, set.recs[i].n_ops, 0u}); which.push_back((uint32_t)i); }
         else if (set.recs[i].has_cg) drop[i] = 1;             // an empty cigar has no column to keep (R-R3)
     }
+    UseCache use_cache(ctx);
+    PhaseLog log("trim");
     std::vector<TrimOut> res;
     if (!trec.empty()) {
         MB_HIP(hipSetDevice(ctx.device));
@@ -627,6 +793,7 @@ void trim(Ctx &ctx, PafSet &set, long long num, long long den, mipaf_stats &st) 
         d_out.download(res, s);
         MB_HIP(hipStreamSynchronize(s));
     }
+    log.mark("upload + kernel + download");
     for (size_t k = 0; k < res.size(); k++) {
         PafRec &r = set.recs[which[k]];
         const TrimOut &t = res[k];
@@ -704,6 +871,9 @@ int need(const void *ctx, const void *s, const char *fn) {
 }
 
 }  // namespace
+
+void chain_cache_destroy(void *cache) { delete (DevCache *)cache; }
+
 }  // namespace mb
 
 struct mipaf_set { mb::PafSet s; };
@@ -714,6 +884,7 @@ int mipaf_set_from_mem(const char *text, size_t len, mipaf_set **out) {
     return mb::guarded([&] {
         if (!out || (!text && len)) { mb::set_error("mipaf_set_from_mem: null argument"); return (int)MIBLAST_EINVAL; }
         mipaf_set *s = new mipaf_set();
+        mb::HostHot keep_workers_awake;
         int rc = mb::parse_text(s->s, text, len);
         if (rc != MIBLAST_OK) { delete s; return rc; }
         *out = s;
@@ -744,6 +915,7 @@ int64_t mipaf_set_size(const mipaf_set *s) { return s ? (int64_t)s->s.recs.size(
 int mipaf_set_text(const mipaf_set *s, char **text, size_t *len) {
     return mb::guarded([&] {
         if (!s || !text || !len) { mb::set_error("mipaf_set_text: null argument"); return (int)MIBLAST_EINVAL; }
+        mb::HostHot keep_workers_awake;
         std::string t = mb::format_set(s->s);
         char *buf = (char *)malloc(t.size() + 1);
         if (!buf) throw std::bad_alloc();
@@ -873,6 +1045,7 @@ int mipaf_chain_tile_trim_filter(miblast_ctx *ctx, mipaf_set *s, const mipaf_cha
         if (rc != MIBLAST_OK) return rc;
         mipaf_stats st{};
         const double t0 = mb::now_s();
+        mb::HostHot keep_workers_awake;
         mb::PafSet &set = s->s;
         mb::chain(ctx->c, set, cp, st);                       // local_alignment.py:684-690 (and :694-699)
         mb::tile(ctx->c, set, 0, st);

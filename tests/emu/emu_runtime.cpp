@@ -32,6 +32,10 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block) {
 }  // namespace emu
 
 namespace mb {
+void host_parallel_for(size_t n, const std::function<void(size_t)> &f) { for (size_t i = 0; i < n; i++) f(i); }
+HostHot::HostHot() {}
+HostHot::~HostHot() {}
+int host_threads() { return 4; }                              // several chunks, run one after another: the merge paths are exercised
 unsigned hist[8192];                                          // the dynamic LDS of k_tile
 static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
@@ -40,7 +44,7 @@ void set_error(const std::string &m) { g_err = m; }
 extern "C" {
 int miblast_device_count(void) { return 1; }
 int miblast_ctx_create(int, miblast_ctx **ctx) { *ctx = new miblast_ctx(); return MIBLAST_OK; }
-void miblast_ctx_destroy(miblast_ctx *ctx) { delete ctx; }
+void miblast_ctx_destroy(miblast_ctx *ctx) { if (ctx) mb::chain_cache_destroy(ctx->c.chain_cache); delete ctx; }
 const char *miblast_last_error(void) { return mb::g_err.c_str(); }
 void miblast_free(void *p) { free(p); }
 }

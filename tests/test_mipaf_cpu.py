@@ -97,3 +97,20 @@ def test_gpu_sub_commands_have_no_cpu_path(tmp_path):
         assert p.returncode == 3 and p.stdout == b"" and b"no CPU path" in p.stderr
     p = subprocess.run([PAFFY, "chain", "--frobnicate", "1"], input=b"", capture_output=True)
     assert p.returncode == 2 and b"unknown option" in p.stderr
+
+
+def test_large_text_is_parsed_in_chunks_with_the_same_result():
+    # > 512 KiB per worker chunk: the threaded parse / format paths; the oracle reads the same text in one pass
+    text = ref.random_paf(99, n_series=120, per_series=(20, 60), n_q=3, n_t=3, contig_len=5_000_000, noise=1500, ragged=False)
+    text += mipaf.PafSet.from_text(text).invert().text()
+    assert len(text) > 2_000_000
+    s = mipaf.PafSet.from_text(text)
+    assert len(s) == len(text.splitlines())
+    assert s.text() == oracle("filter", text)
+    assert s.invert().text() == oracle("invert", text)
+    lines = text.splitlines(keepends=True)
+    k = len(lines) * 3 // 4
+    lines[k] = lines[k].replace("\t+\t", "\t?\t").replace("\t-\t", "\t?\t")
+    with pytest.raises(miblast.MiblastError) as e:
+        mipaf.PafSet.from_text("".join(lines))
+    assert f"PAF line {k + 1}:" in str(e.value)
