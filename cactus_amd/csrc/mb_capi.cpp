@@ -13,6 +13,7 @@
 namespace mb {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
+const std::string &last_error_text() { return g_last_error; }
 }  // namespace mb
 
 

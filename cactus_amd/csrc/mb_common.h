@@ -120,6 +120,7 @@ int parse_fasta(const char *buf, size_t len, SeqSet &out);   // mb_seq.cpp
 
 // ---- error plumbing ----------------------------------------------------------------------------
 void set_error(const std::string &msg);
+const std::string &last_error_text();       // of the calling thread
 struct HipFailure { hipError_t code; const char *what; const char *file; int line; };
 
 #define MB_HIP(expr)                                                                              \

@@ -372,10 +372,33 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<VerifyJob> vjobs;
     DevBuf<VerifyOut> vres;
     DevBuf<PairPtrs> pair_ptrs;
+    // batched calls: extra lanes (own stream, events and seed-stage buffers) so that the seed stages of several pairs are on
+    // the device at the same time
+    std::vector<Ctx *> lanes;
 };
 
 Workspace *workspace_create() { return new Workspace(); }
-void workspace_destroy(Workspace *w) { delete w; }
+
+static Ctx *lane_create(int device) {
+    Ctx *c = new Ctx();
+    c->device = device;
+    c->ws = workspace_create();
+    MB_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MB_HIP(hipEventCreate(&c->ev0)); MB_HIP(hipEventCreate(&c->ev1)); MB_HIP(hipEventCreate(&c->ev2));
+    MB_HIP(hipEventCreate(&c->ev3)); MB_HIP(hipEventCreate(&c->ev4));
+    return c;
+}
+
+void workspace_destroy(Workspace *w) {
+    if (!w) return;
+    for (Ctx *c : w->lanes) {
+        for (hipEvent_t e : {c->ev0, c->ev1, c->ev2, c->ev3, c->ev4}) if (e) (void)hipEventDestroy(e);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        workspace_destroy(c->ws);
+        delete c;
+    }
+    delete w;
+}
 
 struct Index { uint32_t n_positions = 0; };
 
@@ -1665,16 +1688,53 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     std::vector<std::unique_ptr<PairJob>> store;
     std::vector<PairJob *> jobs;
     std::vector<Unit> units;
-    // Seed stages run back to back on the device; in a batched call the host half of every pair (discovery order, entropy
-    // filter, anchors) runs on worker threads meanwhile.
-    std::vector<std::future<void>> host_tasks;
-    size_t waited = 0;
     for (size_t k = 0; k < n; k++) {
         store.emplace_back(new PairJob());
         PairJob &j = *store.back();
         j.T = Ts[k]; j.Q = Qs[k]; j.res = results[k]; j.use_ws_rc = (k == 0);
         j.defer_host = n > 1;
         jobs.push_back(&j);
+    }
+    const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, env_long("MIBLAST_SEED_LANES", 4))) : 1;
+    if (n_lanes > 1) {
+        // Batched call: the pairs are dealt to a few lanes, each a host thread with its own stream and seed-stage buffers.  A
+        // lane runs the device half of a pair's seed stage, then the host half (discovery order, entropy filter, anchors)
+        // while the other lanes keep the device busy.  A pair's result does not depend on its lane.
+        Workspace &w = *ctx.ws;
+        while (w.lanes.size() < n_lanes) w.lanes.push_back(lane_create(ctx.device));
+        std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
+        std::vector<std::string> lane_err(n_lanes);
+        std::vector<std::future<void>> lane_threads;
+        for (size_t lane = 0; lane < n_lanes; lane++)
+            lane_threads.push_back(std::async(std::launch::async, [&, lane] {
+                try {
+                    MB_HIP(hipSetDevice(ctx.device));
+                    Ctx &lc = *w.lanes[lane];
+                    for (size_t k = lane; k < n; k += n_lanes) {
+                        PairJob &j = *jobs[k];
+                        int rc = seed_phase(lc, p, j);
+                        if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
+                        seed_host(p, j, 0); seed_host(p, j, 1); seed_finish(j);
+                        build_units(p, j, (int)k, j.units);
+                    }
+                } catch (const HipFailure &e) {
+                    lane_rc[lane] = MIBLAST_EHIP;
+                    lane_err[lane] = std::string("HIP call did not succeed: ") + e.what + " -> " + hipGetErrorString(e.code);
+                } catch (const std::exception &e) {
+                    lane_rc[lane] = MIBLAST_EHIP;
+                    lane_err[lane] = std::string("internal: ") + e.what();
+                }
+            }));
+        for (auto &f : lane_threads) f.get();
+        for (size_t lane = 0; lane < n_lanes; lane++)
+            if (lane_rc[lane] != MIBLAST_OK) { set_error(lane_err[lane]); return lane_rc[lane]; }
+    } else {
+    // Seed stages run back to back on the device; in a batched call the host half of every pair (discovery order, entropy
+    // filter, anchors) runs on worker threads meanwhile.
+    std::vector<std::future<void>> host_tasks;
+    size_t waited = 0;
+    for (size_t k = 0; k < n; k++) {
+        PairJob &j = *jobs[k];
         const double t_a = now_s();
         int rc = seed_phase(ctx, p, j);
         if (rc != MIBLAST_OK) { for (auto &f : host_tasks) if (f.valid()) f.wait(); return rc; }
@@ -1691,6 +1751,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         }
     }
     for (; waited < host_tasks.size(); waited++) host_tasks[waited].get();
+    }
     for (size_t k = 0; k < n; k++) {
         for (Unit &u : jobs[k]->units) units.push_back(std::move(u));
         jobs[k]->units.clear();

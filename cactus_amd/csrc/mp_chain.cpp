@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -538,8 +539,9 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
     hipStream_t s = ctx.stream;
     PhaseLog log("tile/sorting");
     // maximal runs of aligned query bases (= X M; a D does not move along the query, an I ends the run)
-    std::vector<unsigned long long> rs, re, bounds;
-    std::vector<uint32_t> rrank;
+    std::unique_ptr<unsigned long long[]> bounds;
+    std::unique_ptr<uint32_t[]> rrank;
+    size_t nr = 0;
     {
         const size_t parts = std::min<size_t>((size_t)std::max(1, host_threads()), std::max<size_t>(1, n / 1024));
         std::vector<std::vector<unsigned long long>> prs(parts), pre(parts);
@@ -571,27 +573,26 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
         });
         std::vector<size_t> at(parts + 1, 0);
         for (size_t p = 0; p < parts; p++) at[p + 1] = at[p] + prs[p].size();
-        rs.resize(at[parts]); re.resize(at[parts]); rrank.resize(at[parts]);
+        nr = at[parts];
+        bounds.reset(new unsigned long long[std::max<size_t>(1, 2 * nr)]);      // starts, then ends: no zero fill, no second copy
+        rrank.reset(new uint32_t[std::max<size_t>(1, nr)]);
         host_parallel_for(parts, [&](size_t p) {
-            std::copy(prs[p].begin(), prs[p].end(), rs.begin() + (long)at[p]);
-            std::copy(pre[p].begin(), pre[p].end(), re.begin() + (long)at[p]);
-            std::copy(prk[p].begin(), prk[p].end(), rrank.begin() + (long)at[p]);
+            std::copy(prs[p].begin(), prs[p].end(), bounds.get() + at[p]);
+            std::copy(pre[p].begin(), pre[p].end(), bounds.get() + nr + at[p]);
+            std::copy(prk[p].begin(), prk[p].end(), rrank.get() + at[p]);
         });
     }
-    const size_t nr = rs.size();
     level_by_rank.assign(n, 1);
     if (nr == 0) return true;
-    bounds.reserve(2 * nr);
-    bounds.insert(bounds.end(), rs.begin(), rs.end());
-    bounds.insert(bounds.end(), re.begin(), re.end());
-    const size_t nb = bounds.size();
+    const size_t nb = 2 * nr;
     const int coord_bits = bits_for(seq_off.back());
     log.mark("runs (host)");
 
     EventTimer t(s);
-    Dev<unsigned long long> d_b, d_bs(nb), d_flag(nb), d_pos(nb), d_rs, d_re, d_cnt(nr), d_off(nr);
-    Dev<uint32_t> d_lo(nr), d_rrank;
-    d_b.upload(bounds, s); d_rs.upload(rs, s); d_re.upload(re, s); d_rrank.upload(rrank, s);
+    Dev<unsigned long long> d_b(nb), d_bs(nb), d_flag(nb), d_pos(nb), d_cnt(nr), d_off(nr);
+    Dev<uint32_t> d_lo(nr), d_rrank(nr);
+    MB_HIP(hipMemcpyAsync(d_b.p, bounds.get(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    MB_HIP(hipMemcpyAsync(d_rrank.p, rrank.get(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     size_t temp_bytes = std::max(sort_keys64_temp_bytes((int64_t)nb, coord_bits), scan_u64_temp_bytes((int64_t)nb));
     Dev<uint8_t> d_temp(temp_bytes);
     log.mark("alloc + upload");
@@ -605,7 +606,7 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
     const size_t nu = (size_t)(last_pos + last_flag);
     Dev<unsigned long long> d_u(nu);
     launch_tile_unique(d_bs.p, d_flag.p, d_pos.p, (int64_t)nb, d_u.p, s);
-    launch_tile_span(d_rs.p, d_re.p, (int64_t)nr, d_u.p, (int64_t)nu, d_lo.p, d_cnt.p, s);
+    launch_tile_span(d_b.p, d_b.p + nr, (int64_t)nr, d_u.p, (int64_t)nu, d_lo.p, d_cnt.p, s);
     scan_u64(d_temp.p, temp_bytes, d_cnt.p, d_off.p, (int64_t)nr, false, s);
     unsigned long long last_off = 0, last_cnt = 0;
     MB_HIP(hipMemcpyAsync(&last_off, d_off.p + (nr - 1), sizeof last_off, hipMemcpyDeviceToHost, s));

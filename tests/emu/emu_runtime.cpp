@@ -39,6 +39,7 @@ int host_threads() { return 4; }                              // several chunks,
 unsigned hist[8192];                                          // the dynamic LDS of k_tile
 static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
+const std::string &last_error_text() { return g_err; }
 }  // namespace mb
 
 extern "C" {

@@ -325,11 +325,14 @@ def test_ingroup_to_outgroup_trimming_chain(gpu_ctx, tmp_path):
     assert cov["id=O2|chr1"][:20000].mean() < 0.01 and (cov["id=O1|chr1"] & cov["id=O2|chr1"]).sum() <= 2 * 100 * n
 
 
-def test_batched_pairs_equal_single_calls(gpu_ctx):
-    """miblast_align_pairs: several chunk pairs in one call (merged gapped launches) must return, pair by pair, exactly
-    the bytes and counters of separate miblast_align calls -- including pairs with no alignment and different contig sets."""
+@pytest.mark.parametrize("lanes", ["4", "1", "3"])
+def test_batched_pairs_equal_single_calls(gpu_ctx, monkeypatch, lanes):
+    """miblast_align_pairs: several chunk pairs in one call (seed stages dealt to concurrent lanes, merged gapped launches) must
+    return, pair by pair, exactly the bytes and counters of separate miblast_align calls -- including pairs with no alignment
+    and different contig sets; the number of lanes must not matter."""
     from cases import CASES, DEFAULT
     from cactus_amd import miblast
+    monkeypatch.setenv("MIBLAST_SEED_LANES", lanes)
     pm = miblast.params_from_args(DEFAULT)
     chosen = [c for c in CASES if c[0] in ("homolog_20k_default", "random_50k", "multi_contig_ragged", "tandem_repeats", "revcomp_query", "empty_query")]
     sets = [(gpu_ctx.seqset_from_fasta_bytes(c[1]), gpu_ctx.seqset_from_fasta_bytes(c[2])) for c in chosen]
