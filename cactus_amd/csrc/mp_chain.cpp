@@ -23,7 +23,6 @@
 #include <vector>
 
 namespace mb {
-namespace {
 
 struct PafRec {
     uint32_t qn = 0, tn = 0;              // name ids
@@ -34,8 +33,6 @@ struct PafRec {
     uint64_t ops_off = 0;                 // the record's ops: PafSet::ops[ops_off .. ops_off + n_ops)
     uint32_t n_ops = 0;
 };
-
-}  // namespace
 
 struct PafSet {
     std::vector<std::string> names;
@@ -637,6 +634,46 @@ bool tile_by_sorting(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &r
     return true;
 }
 
+// The literal counter walk (k_tile): records grouped by query sequence, R-T1 order inside a sequence; level by input index.
+void tile_by_walking(Ctx &ctx, const PafSet &set, const std::vector<uint32_t> &rank, const std::vector<uint32_t> &qid_of_name,
+                     const std::vector<uint64_t> &seq_off, int hist_bins, std::vector<int32_t> &level, mipaf_stats &st) {
+    const size_t n = rank.size(), nq = seq_off.size() - 1;
+    hipStream_t s = ctx.stream;
+    std::vector<uint32_t> qstart(nq + 1, 0);
+    for (size_t k = 0; k < n; k++) qstart[qid_of_name[set.recs[rank[k]].qn] + 1]++;
+    for (size_t q = 0; q < nq; q++) qstart[q + 1] += qstart[q];
+    // per-op query offsets (op order) and the records as the kernel reads them, by a stable counting sort on the sequence
+    std::vector<uint32_t> at(qstart.begin(), qstart.end() - 1), qoff(set.ops.size());
+    std::vector<TileRec> trec(n);
+    for (size_t k = 0; k < n; k++) {
+        const PafRec &r = set.recs[rank[k]];
+        uint32_t q = 0;
+        if (r.has_cg)
+            for (uint32_t o = 0; o < r.n_ops; o++) {
+                qoff[r.ops_off + o] = q;
+                if ((set.ops[r.ops_off + o] & 7u) != kOpD) q += set.ops[r.ops_off + o] >> 3;
+            }
+        trec[at[qid_of_name[r.qn]]++] = TileRec{r.ops_off, r.has_cg ? r.n_ops : 0u, (int32_t)r.same, r.qs, r.qe, rank[k], 0u};
+    }
+    st.ops = (int64_t)set.ops.size();
+    Dev<TileRec> d_rec;
+    Dev<uint32_t> d_qstart, d_ops, d_qoff;
+    Dev<uint64_t> d_cnt_off;
+    Dev<uint16_t> d_cnt((size_t)seq_off[nq]);
+    Dev<int32_t> d_level(n);
+    d_rec.upload(trec, s);
+    d_qstart.upload(qstart, s);
+    d_cnt_off.upload(seq_off, s);
+    d_ops.upload(set.ops, s);
+    d_qoff.upload(qoff, s);
+    MB_HIP(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(1, (size_t)seq_off[nq]) * sizeof(uint16_t), s));
+    EventTimer t_tile(s);
+    launch_tile(d_rec.p, d_qstart.p, d_cnt_off.p, (int)nq, d_cnt.p, d_ops.p, d_qoff.p, hist_bins, d_level.p, s);
+    st.t_tile_ms += t_tile.stop_ms();
+    d_level.download(level, s);
+    MB_HIP(hipStreamSynchronize(s));
+}
+
 void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     const size_t n = set.recs.size();
     st.records = (int64_t)n;
@@ -645,12 +682,11 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
     UseCache use_cache(ctx);
     PhaseLog log("tile");
     const bool force_walk = hist_bins > 0;
-    if (hist_bins <= 0) hist_bins = 4096;
-    hist_bins = std::min(8192, std::max(2, hist_bins));
+    hist_bins = force_walk ? std::min(8192, std::max(2, hist_bins)) : 4096;
     MB_HIP(hipSetDevice(ctx.device));
     hipStream_t s = ctx.stream;
-    // R-T1 order on the device
-    std::vector<unsigned long long> key(n), qkey(n);
+    // R-T1 order on the device; query sequences numbered by first appearance, laid end to end in one base coordinate
+    std::vector<unsigned long long> key(n);
     std::vector<uint32_t> qid_of_name(set.names.size(), UINT32_MAX);
     std::vector<int64_t> qlen;
     for (size_t i = 0; i < n; i++) {
@@ -659,27 +695,25 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
         key[i] = ~((unsigned long long)k ^ 0x8000000000000000ull);
         if (qid_of_name[r.qn] == UINT32_MAX) { qid_of_name[r.qn] = (uint32_t)qlen.size(); qlen.push_back(r.ql); }
         qlen[qid_of_name[r.qn]] = std::max(qlen[qid_of_name[r.qn]], r.ql);
-        qkey[i] = qid_of_name[r.qn];
     }
     const size_t nq = qlen.size();
     st.query_sequences = (int64_t)nq;
-    std::vector<uint64_t> cnt_off(nq + 1, 0);
-    for (size_t q = 0; q < nq; q++) cnt_off[q + 1] = cnt_off[q] + (uint64_t)std::max<int64_t>(qlen[q], 0);
-    Dev<unsigned long long> d_key, d_key2(n), d_qkey, d_g(n);
-    Dev<uint32_t> d_pa(n), d_rank(n), d_grouped(n);
-    const size_t temp_bytes = std::max(sort_pairs_temp_bytes((int64_t)n, 64), sort_pairs_temp_bytes((int64_t)n, bits_for(nq)));
-    Dev<uint8_t> d_temp(temp_bytes);
-    d_key.upload(key, s);
-    d_qkey.upload(qkey, s);
-    std::vector<uint32_t> rank, grouped;
+    std::vector<uint64_t> seq_off(nq + 1, 0);
+    for (size_t q = 0; q < nq; q++) seq_off[q + 1] = seq_off[q] + (uint64_t)std::max<int64_t>(qlen[q], 0);
+    std::vector<uint32_t> rank;
     {
+        Dev<unsigned long long> d_key, d_key2(n);
+        Dev<uint32_t> d_pa(n), d_rank(n);
+        const size_t temp_bytes = sort_pairs_temp_bytes((int64_t)n, 64);
+        Dev<uint8_t> d_temp(temp_bytes);
+        d_key.upload(key, s);
         EventTimer t_sort(s);
         launch_iota(d_pa.p, (int64_t)n, s);
         sort_pairs(d_temp.p, temp_bytes, d_key.p, d_key2.p, d_pa.p, d_rank.p, (int64_t)n, 64, s);
         st.t_sort_ms += t_sort.stop_ms();
+        d_rank.download(rank, s);
+        MB_HIP(hipStreamSynchronize(s));
     }
-    d_rank.download(rank, s);
-    MB_HIP(hipStreamSynchronize(s));
     log.mark("keys + order");
 
     std::vector<int32_t> level;                              // by input index
@@ -688,58 +722,13 @@ void tile(Ctx &ctx, PafSet &set, int hist_bins, mipaf_stats &st) {
         // pieces beyond this (default 2^28 ~ 7 GiB of keys and weights) mean a pile-up: take the bounded-memory walk instead
         const uint64_t max_pieces = (uint64_t)std::max(1l, env_long_mp("MIPAF_TILE_MAX_PIECES", 1l << 28));
         std::vector<int32_t> by_rank;
-        if (tile_by_sorting(ctx, set, rank, qid_of_name, cnt_off, max_pieces, by_rank, st)) {
+        if (tile_by_sorting(ctx, set, rank, qid_of_name, seq_off, max_pieces, by_rank, st)) {
             level.assign(n, 1);
             for (size_t k = 0; k < n; k++) level[rank[k]] = by_rank[k];
             done = true;
         }
     }
-    if (!done) {
-    // the counter walk: grouped by query sequence (stable, so the R-T1 order inside a sequence is kept)
-    {
-        EventTimer t_sort(s);
-        launch_gather_u64(d_qkey.p, d_rank.p, d_g.p, (int64_t)n, s);
-        sort_pairs(d_temp.p, temp_bytes, d_g.p, d_key2.p, d_rank.p, d_grouped.p, (int64_t)n, bits_for(nq), s);
-        st.t_sort_ms += t_sort.stop_ms();
-    }
-    d_grouped.download(grouped, s);
-    MB_HIP(hipStreamSynchronize(s));
-
-    // per-op query offsets (op order) and the records as the kernel reads them
-    std::vector<uint32_t> qoff(set.ops.size());
-    std::vector<TileRec> trec(n);
-    std::vector<uint32_t> qstart(nq + 1, 0);
-    for (size_t k = 0; k < n; k++) {
-        const PafRec &r = set.recs[grouped[k]];
-        uint32_t q = 0;
-        if (r.has_cg)
-            for (uint32_t o = 0; o < r.n_ops; o++) {
-                qoff[r.ops_off + o] = q;
-                if ((set.ops[r.ops_off + o] & 7u) != kOpD) q += set.ops[r.ops_off + o] >> 3;
-            }
-        trec[k] = TileRec{r.ops_off, r.has_cg ? r.n_ops : 0u, (int32_t)r.same, r.qs, r.qe, grouped[k], 0u};
-        qstart[qid_of_name[r.qn] + 1]++;
-    }
-    for (size_t q = 0; q < nq; q++) qstart[q + 1] += qstart[q];
-    st.ops = (int64_t)set.ops.size();
-
-    Dev<TileRec> d_rec;
-    Dev<uint32_t> d_qstart, d_ops, d_qoff;
-    Dev<uint64_t> d_cnt_off;
-    Dev<uint16_t> d_cnt((size_t)cnt_off[nq]);
-    Dev<int32_t> d_level(n);
-    d_rec.upload(trec, s);
-    d_qstart.upload(qstart, s);
-    d_cnt_off.upload(cnt_off, s);
-    d_ops.upload(set.ops, s);
-    d_qoff.upload(qoff, s);
-    MB_HIP(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(1, (size_t)cnt_off[nq]) * sizeof(uint16_t), s));
-    EventTimer t_tile(s);
-    launch_tile(d_rec.p, d_qstart.p, d_cnt_off.p, (int)nq, d_cnt.p, d_ops.p, d_qoff.p, hist_bins, d_level.p, s);
-    st.t_tile_ms += t_tile.stop_ms();
-    d_level.download(level, s);
-    MB_HIP(hipStreamSynchronize(s));
-    }
+    if (!done) tile_by_walking(ctx, set, rank, qid_of_name, seq_off, hist_bins, level, st);
     log.mark("levels");
     std::vector<PafRec> out(n);
     for (size_t k = 0; k < n; k++) {                         // R-T5
