@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1_000_000, help="bases per chunk (config 2: 1 Mb)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--random-pair", action="store_true", help="pure-random pair (seed/ungapped isolation)")
