@@ -26,7 +26,12 @@ for rep in range(2):
     print(f"rep {rep}: {dt * 1e3:.1f} ms, {s['dp_cells'] / dt / 1e9:.2f} Gcell/s, {s['seed_hits'] / max(1e-9, s['t_seed']):.3g} seeds/s, alignments {s['alignments']}, rounds {s['gapped_rounds']}, "
           f"dp launches {s['dp_kernel_launches']}, dp kernel {s['t_dp_kernel_ms']:.1f} ms, index {s['t_index'] * 1e3:.1f} seed {s['t_seed'] * 1e3:.1f} gapped {s['t_gapped'] * 1e3:.1f} ms, "
           f"relays {s['relay_accepted']}/{s['relay_rejected']}, reruns {s['dp_reruns']}, spec {s['dp_cells_run'] / max(1, s['dp_cells']):.2f}", flush=True)
-print("same bytes:", digests[0] == digests[1], "PAF bytes:", len(r.paf))
+print("same bytes:", digests[0] == digests[1], "PAF bytes:", len(r.paf), "md5", digests[1], "dp_cells", s["dp_cells"])
+# the CPU oracle on the same 30 Mb pair (61.5 s, 1.7 GB; run in the build container, where it is off the GPU clock):
+#   olz.align(tf, qf, olz.default_params(step=2, transitions=0, ydrop=3000, queryhspbest=100000)) -> md5 below, dp_cells 2988193947
+ORACLE_30MB = ("077738f6583a69f9133af03b5882bf5d", 2988193947)
+if n == 30_000_000:
+    print("equal to the oracle's PAF and dp_cells:", (digests[1], s["dp_cells"]) == ORACLE_30MB)
 t0 = time.time()
 ps = mipaf.PafSet.from_text(r.paf)
 ps.tile(ctx)                                               # refuses records whose cigar does not walk its intervals
