@@ -346,6 +346,24 @@ def test_batched_pairs_equal_single_calls(gpu_ctx, monkeypatch, lanes):
             assert a.stats[k] == b.stats[k], (name, k)
 
 
+def test_full_size_chunk_pair_equals_the_oracle_digest(gpu_ctx):
+    """One chunk pair at Cactus's full chunk size (30 Mb x 30 Mb, 1.3 % divergence, half soft-masked, parameter
+    set "one"): PAF bytes and counters equal the CPU oracle's, which takes a minute on this input and is therefore committed as a
+    digest (tests/golden/cfg4_30mb.json, written by scripts/oracle_cfg4.py)."""
+    import hashlib, json, os
+    from cactus_amd import gen, miblast
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_30mb.json")))
+    t, q = gen.make_pair(30_000_000, 3001, sub_rate=0.013, indel_rate=0.002, mask_frac=0.5)
+    T = gpu_ctx.seqset_from_fasta_bytes(gen.fasta_bytes([("id=simT|chr20", t)]))
+    Q = gpu_ctx.seqset_from_fasta_bytes(gen.fasta_bytes([("id=simQ|chr20", q)]))
+    pm = miblast.params_from_args("--step=2 --ambiguous=iupac,100,100 --ydrop=3000 --notransition --queryhspbest=100000".split())
+    r = gpu_ctx.align(T, Q, pm, details=False)
+    T.close(); Q.close()
+    assert (hashlib.md5(r.paf).hexdigest(), len(r.paf)) == (want["paf_md5"], want["paf_bytes"])
+    for k in ("alignments", "dp_cells", "seed_hits", "hsps"):
+        assert r.stats[k] == want[k], k
+
+
 def test_randomised_differential_fuzz():
     """A slice of scripts/gpu_fuzz.py (random structures x random lastz options, GPU vs oracle byte for byte).  The
     full script found two real bugs during development (x-drop stop exactly at lane 63 of the wave-parallel extension;
