@@ -758,32 +758,44 @@ bool parse_fraction(const char *s, long long &num, long long &den) {
 void trim(Ctx &ctx, PafSet &set, long long num, long long den, mipaf_stats &st) {
     const size_t n = set.recs.size();
     st.records = (int64_t)n;
-    std::vector<TrimRec> trec;
-    std::vector<uint32_t> which;
+    std::vector<uint32_t> which;                             // the records with a cigar, by ascending position in the op arena
     std::vector<uint8_t> drop(n, 0);
     for (size_t i = 0; i < n; i++) {
-        if (set.recs[i].has_cg && set.recs[i].n_ops) { trec.push_back(TrimRec{set.recs[i].ops_off, set.recs[i].n_ops, 0u}); which.push_back((uint32_t)i); }
+        if (set.recs[i].has_cg && set.recs[i].n_ops) which.push_back((uint32_t)i);
         else if (set.recs[i].has_cg) drop[i] = 1;             // an empty cigar has no column to keep (R-R3)
     }
+    std::sort(which.begin(), which.end(), [&](uint32_t a, uint32_t b) { return set.recs[a].ops_off < set.recs[b].ops_off; });
     UseCache use_cache(ctx);
     PhaseLog log("trim");
     std::vector<TrimOut> res;
-    if (!trec.empty()) {
+    if (!which.empty()) {
         MB_HIP(hipSetDevice(ctx.device));
         hipStream_t s = ctx.stream;
-        Dev<TrimRec> d_rec;
-        Dev<uint32_t> d_ops;
-        Dev<TrimOut> d_out(trec.size());
-        d_rec.upload(trec, s);
+        const size_t nr = which.size(), n_ops = set.ops.size();
+        std::vector<unsigned long long> rec_start(nr);
+        std::vector<uint32_t> rec_n(nr);
+        for (size_t k = 0; k < nr; k++) { rec_start[k] = set.recs[which[k]].ops_off; rec_n[k] = set.recs[which[k]].n_ops; }
+        Dev<uint32_t> d_ops, d_rec_n;
+        Dev<unsigned long long> d_rec_start, d_pc(n_ops + 1), d_pm(n_ops + 1), d_pq(n_ops + 1), d_pt(n_ops + 1), d_pre(nr), d_suf(nr);
+        Dev<TrimOut> d_out(nr);
+        const size_t temp_bytes = scan_u64_temp_bytes((int64_t)n_ops + 1);
+        Dev<uint8_t> d_temp(temp_bytes);
         d_ops.upload(set.ops, s);
-        st.ops = (int64_t)set.ops.size();
+        d_rec_start.upload(rec_start, s);
+        d_rec_n.upload(rec_n, s);
+        st.ops = (int64_t)n_ops;
         EventTimer t(s);
-        launch_trim(d_rec.p, (int64_t)trec.size(), d_ops.p, num, den, d_out.p, s);
+        MB_HIP(hipMemsetAsync(d_pre.p, 0, nr * sizeof(unsigned long long), s));
+        MB_HIP(hipMemsetAsync(d_suf.p, 0, nr * sizeof(unsigned long long), s));
+        launch_trim_values(d_ops.p, (int64_t)n_ops, d_pc.p, d_pm.p, d_pq.p, d_pt.p, s);
+        for (unsigned long long *p : {d_pc.p, d_pm.p, d_pq.p, d_pt.p}) scan_u64(d_temp.p, temp_bytes, p, p, (int64_t)n_ops + 1, false, s);
+        launch_trim_ops(d_ops.p, (int64_t)n_ops, d_rec_start.p, d_rec_n.p, (int64_t)nr, d_pc.p, d_pm.p, num, den, d_pre.p, d_suf.p, s);
+        launch_trim_finish(d_ops.p, d_rec_start.p, d_rec_n.p, (int64_t)nr, d_pc.p, d_pm.p, d_pq.p, d_pt.p, d_pre.p, d_suf.p, d_out.p, s);
         st.t_trim_ms += t.stop_ms();
         d_out.download(res, s);
         MB_HIP(hipStreamSynchronize(s));
     }
-    log.mark("upload + kernel + download");
+    log.mark("upload + kernels + download");
     for (size_t k = 0; k < res.size(); k++) {
         PafRec &r = set.recs[which[k]];
         const TrimOut &t = res[k];

@@ -26,7 +26,6 @@ struct TileRec {                       // one alignment as the tiling sees it
     uint32_t pad;
 };
 
-struct TrimRec { uint64_t ops_off; uint32_t n_ops; uint32_t pad; };
 struct TrimOut {                       // R-R2 / R-R3, all in the record's own op order
     long long cols, pre, suf;          // alignment columns; columns cut at the front / at the back
     long long qa, ta, qb, tb;          // query / target bases inside the two cuts
@@ -62,6 +61,13 @@ void launch_tile_expand(const uint32_t *lo, const unsigned long long *cnt, const
 void launch_tile_cover(const unsigned long long *key, int64_t n_pieces, const unsigned long long *u, unsigned long long *key2, uint32_t *weight, hipStream_t s);
 void launch_widen(const uint32_t *in, unsigned long long *out, int64_t n, hipStream_t s);
 void launch_tile_median(const unsigned long long *key2, const unsigned long long *wsum, int64_t n_pieces, int64_t n_recs, int32_t *level_by_rank, hipStream_t s);
-void launch_trim(const TrimRec *recs, int64_t n, const uint32_t *ops, long long num, long long den, TrimOut *out, hipStream_t s);
+void launch_trim_values(const uint32_t *ops, int64_t n_ops, unsigned long long *vc, unsigned long long *vm, unsigned long long *vq,
+                        unsigned long long *vt, hipStream_t s);             // n_ops + 1 entries each (the last one 0)
+void launch_trim_ops(const uint32_t *ops, int64_t n_ops, const unsigned long long *rec_start, const uint32_t *rec_n, int64_t n_recs,
+                     const unsigned long long *Pc, const unsigned long long *Pm, long long num, long long den, unsigned long long *pre,
+                     unsigned long long *suf, hipStream_t s);
+void launch_trim_finish(const uint32_t *ops, const unsigned long long *rec_start, const uint32_t *rec_n, int64_t n_recs, const unsigned long long *Pc,
+                        const unsigned long long *Pm, const unsigned long long *Pq, const unsigned long long *Pt, const unsigned long long *pre,
+                        const unsigned long long *suf, TrimOut *out, hipStream_t s);
 
 }  // namespace mb

@@ -6,7 +6,8 @@
 //                                       visited in R-C1 order, the 256 lanes share the scan of the predecessor window
 //   k_tile                              R-T2..R-T4: one workgroup per query sequence; per alignment a histogram of the
 //                                       per-base cover counters (LDS) gives the median, then the counters go up
-//   k_trim                              R-R1..R-R3: one lane per alignment, closed-form cut inside every op
+//   k_trim_values/ops/finish + scans    R-R1..R-R3: one lane per OP (closed-form candidate cut from prefix sums), maximum per
+//                                       record, then bisection for the ops the cuts end in
 //
 // All of it is integer work on coordinates, scores and cigar ops; nothing here touches sequence bytes.
 #include "mp_common.h"
@@ -408,76 +409,126 @@ void launch_tile_median(const unsigned long long *key2, const unsigned long long
 }
 
 // ------------------------------------------------------------------------------------------------
-// Trim by identity.  The longest prefix with matches / columns < num / den: inside a run of non-matching columns the
-// identity only falls, so only the end of the run can be the longest; inside a run of matches that starts with m
-// matches in c columns, (m + t) / (c + t) < num / den  <=>  t (den - num) < num c - den m, a closed form for the last t.
-__device__ __forceinline__ void identity_cut(const uint32_t *__restrict__ ops, uint32_t n, bool rev, long long num, long long den,
-                                             long long &cut, long long &cols, long long &matches) {
-    long long m = 0, c = 0;
-    cut = 0;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t o = ops[rev ? n - 1 - k : k];
-        const long long len = o >> 3;
-        const uint32_t code = o & 7u;
-        if (code == kOpEq || code == kOpM) {
-            const long long rhs = num * c - den * m;
-            long long t = 0;
-            if (den == num) t = rhs > 0 ? len : 0;
-            else if (rhs > 0) { t = (rhs + (den - num) - 1) / (den - num) - 1; if (t > len) t = len; }
-            if (t >= 1) cut = c + t;
-            m += len; c += len;
-        } else {
-            c += len;
-            if (m * den < num * c) cut = c;
-        }
+// Trim by identity, parallel over OPS (a lastz alignment of a whole chunk has a million ops; one lane per record would walk
+// them alone).  The longest prefix with matches / columns < num / den ends in the LAST op that has a qualifying column:
+// inside a run of non-matching columns the identity only falls, so only the end of the run can qualify; inside a run of
+// matches that starts after m matches in c columns, (m + t) / (c + t) < num / den  <=>  t (den - num) < num c - den m, a
+// closed form for the last qualifying t.  With prefix sums of columns and matches every op evaluates its own candidate
+// (forward, and backward from the record's totals) and the record takes the maximum; the cut positions are then turned
+// into ops, remaining lengths and consumed bases by bisection on the same prefix sums.
+// P* are exclusive prefix sums over the whole op arena with one extra entry (the total); rec_start is ascending.
+__device__ __forceinline__ long long run_candidate(bool is_match, long long len, long long c, long long m, long long num, long long den) {
+    if (is_match) {
+        const long long rhs = num * c - den * m;
+        long long t = 0;
+        if (den == num) t = rhs > 0 ? len : 0;
+        else if (rhs > 0) { t = (rhs + (den - num) - 1) / (den - num) - 1; if (t > len) t = len; }
+        return t >= 1 ? c + t : 0;
     }
-    cols = c; matches = m;
+    const long long c1 = c + len;
+    return m * den < num * c1 ? c1 : 0;
 }
 
-// the op the cut ends in, what is left of it, and the bases / matches the cut held
-__device__ __forceinline__ void consume_cut(const uint32_t *__restrict__ ops, uint32_t n, bool rev, long long cut, uint32_t &op_at,
-                                            uint32_t &left_len, long long &qdel, long long &tdel, long long &mdel) {
-    qdel = tdel = mdel = 0;
-    uint32_t k = 0;
-    left_len = 0;
-    while (cut > 0) {
-        const uint32_t o = ops[rev ? n - 1 - k : k];
-        const long long len = o >> 3;
-        const uint32_t code = o & 7u;
-        const long long take = len < cut ? len : cut;
-        if (code != kOpD) qdel += take;
-        if (code != kOpI) tdel += take;
-        if (code == kOpEq || code == kOpM) mdel += take;
-        cut -= take;
-        if (take < len) { left_len = (uint32_t)(len - take); break; }
-        k++;
-    }
-    if (left_len == 0) left_len = ops[rev ? n - 1 - k : k] >> 3;        // the cut ended on an op boundary: op k is whole
-    op_at = rev ? n - 1 - k : k;
-}
-
-__global__ __launch_bounds__(256) void k_trim(const TrimRec *__restrict__ recs, int64_t n, const uint32_t *__restrict__ ops,
-                                              const long long num, const long long den, TrimOut *__restrict__ out) {
+__global__ void k_trim_values(const uint32_t *__restrict__ ops, int64_t n_ops, unsigned long long *__restrict__ vc, unsigned long long *__restrict__ vm,
+                              unsigned long long *__restrict__ vq, unsigned long long *__restrict__ vt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const TrimRec r = recs[i];
-    const uint32_t *o = ops + r.ops_off;
+    if (i > n_ops) return;
+    unsigned long long len = 0;
+    uint32_t code = kOpD + 1;
+    if (i < n_ops) { len = ops[i] >> 3; code = ops[i] & 7u; }
+    vc[i] = len;
+    vm[i] = (code == kOpEq || code == kOpM) ? len : 0ull;
+    vq[i] = (code <= kOpI) ? len : 0ull;                      // = X M I move along the query
+    vt[i] = (code <= kOpM || code == kOpD) ? len : 0ull;      // = X M D move along the target
+}
+
+__global__ void k_trim_ops(const uint32_t *__restrict__ ops, int64_t n_ops, const unsigned long long *__restrict__ rec_start,
+                           const uint32_t *__restrict__ rec_n, int64_t n_recs, const unsigned long long *__restrict__ Pc,
+                           const unsigned long long *__restrict__ Pm, const long long num, const long long den,
+                           unsigned long long *__restrict__ pre, unsigned long long *__restrict__ suf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ops) return;
+    int64_t a = 0, b = n_recs;                                 // the record whose op range holds i, if any
+    while (a < b) {
+        const int64_t m = (a + b) >> 1;
+        if (rec_start[m] <= (unsigned long long)i) a = m + 1; else b = m;
+    }
+    const int64_t r = a - 1;
+    if (r < 0) return;
+    const unsigned long long s0 = rec_start[r], e0 = s0 + rec_n[r];
+    if ((unsigned long long)i >= e0) return;
+    const uint32_t op = ops[i], code = op & 7u;
+    const bool is_match = code == kOpEq || code == kOpM;
+    const long long len = op >> 3, mlen = is_match ? len : 0;
+    const long long c0 = (long long)(Pc[i] - Pc[s0]), m0 = (long long)(Pm[i] - Pm[s0]);
+    const long long C = (long long)(Pc[e0] - Pc[s0]), M = (long long)(Pm[e0] - Pm[s0]);
+    const long long f = run_candidate(is_match, len, c0, m0, num, den);
+    const long long g = run_candidate(is_match, len, C - c0 - len, M - m0 - mlen, num, den);
+    if (f > 0) atomicMax(&pre[r], (unsigned long long)f);
+    if (g > 0) atomicMax(&suf[r], (unsigned long long)g);
+}
+
+__global__ void k_trim_finish(const uint32_t *__restrict__ ops, const unsigned long long *__restrict__ rec_start, const uint32_t *__restrict__ rec_n,
+                              int64_t n_recs, const unsigned long long *__restrict__ Pc, const unsigned long long *__restrict__ Pm,
+                              const unsigned long long *__restrict__ Pq, const unsigned long long *__restrict__ Pt,
+                              const unsigned long long *__restrict__ pre, const unsigned long long *__restrict__ suf, TrimOut *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_recs) return;
+    const unsigned long long s0 = rec_start[r], e0 = s0 + rec_n[r];
     TrimOut t{};
-    long long m_all, cols2, m2;
-    identity_cut(o, r.n_ops, false, num, den, t.pre, t.cols, m_all);
-    identity_cut(o, r.n_ops, true, num, den, t.suf, cols2, m2);
+    t.cols = (long long)(Pc[e0] - Pc[s0]);
+    t.pre = (long long)pre[r];
+    t.suf = (long long)suf[r];
     if (t.pre + t.suf < t.cols) {
-        long long ma, mb_;
-        consume_cut(o, r.n_ops, false, t.pre, t.first_op, t.first_len, t.qa, t.ta, ma);
-        consume_cut(o, r.n_ops, true, t.suf, t.last_op, t.last_len, t.qb, t.tb, mb_);
-        t.nm = m_all - ma - mb_;
+        const long long M = (long long)(Pm[e0] - Pm[s0]), Q = (long long)(Pq[e0] - Pq[s0]), T = (long long)(Pt[e0] - Pt[s0]);
+        // the op that holds column x (0-based, within the record): the last op whose first column is <= x
+        auto op_of_column = [&](long long x) {
+            unsigned long long a = s0, b = e0 - 1;
+            while (a < b) {
+                const unsigned long long m = (a + b + 1) >> 1;
+                if ((long long)(Pc[m] - Pc[s0]) <= x) a = m; else b = m - 1;
+            }
+            return a;
+        };
+        const unsigned long long kf = op_of_column(t.pre);
+        {
+            const uint32_t code = ops[kf] & 7u;
+            const long long used = t.pre - (long long)(Pc[kf] - Pc[s0]);
+            t.first_op = (uint32_t)(kf - s0);
+            t.first_len = (uint32_t)((long long)(ops[kf] >> 3) - used);
+            t.qa = (long long)(Pq[kf] - Pq[s0]) + (code != kOpD ? used : 0);
+            t.ta = (long long)(Pt[kf] - Pt[s0]) + (code != kOpI ? used : 0);
+            t.nm = (long long)(Pm[kf] - Pm[s0]) + ((code == kOpEq || code == kOpM) ? used : 0);      // matches inside the prefix cut
+        }
+        const unsigned long long kl = op_of_column(t.cols - t.suf - 1);
+        {
+            const uint32_t code = ops[kl] & 7u;
+            const long long kept = (t.cols - t.suf) - (long long)(Pc[kl] - Pc[s0]);
+            t.last_op = (uint32_t)(kl - s0);
+            t.last_len = (uint32_t)kept;
+            t.qb = Q - (long long)(Pq[kl] - Pq[s0]) - (code != kOpD ? kept : 0);
+            t.tb = T - (long long)(Pt[kl] - Pt[s0]) - (code != kOpI ? kept : 0);
+            const long long mb_ = M - (long long)(Pm[kl] - Pm[s0]) - ((code == kOpEq || code == kOpM) ? kept : 0);
+            t.nm = M - t.nm - mb_;
+        }
         t.nb = t.cols - t.pre - t.suf;
     }
-    out[i] = t;
+    out[r] = t;
 }
 
-void launch_trim(const TrimRec *recs, int64_t n, const uint32_t *ops, long long num, long long den, TrimOut *out, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_trim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, ops, num, den, out);
+void launch_trim_values(const uint32_t *ops, int64_t n_ops, unsigned long long *vc, unsigned long long *vm, unsigned long long *vq,
+                        unsigned long long *vt, hipStream_t s) {
+    hipLaunchKernelGGL(k_trim_values, grid_for(n_ops + 1), dim3(256), 0, s, ops, n_ops, vc, vm, vq, vt);
+}
+void launch_trim_ops(const uint32_t *ops, int64_t n_ops, const unsigned long long *rec_start, const uint32_t *rec_n, int64_t n_recs,
+                     const unsigned long long *Pc, const unsigned long long *Pm, long long num, long long den, unsigned long long *pre,
+                     unsigned long long *suf, hipStream_t s) {
+    if (n_ops > 0 && n_recs > 0) hipLaunchKernelGGL(k_trim_ops, grid_for(n_ops), dim3(256), 0, s, ops, n_ops, rec_start, rec_n, n_recs, Pc, Pm, num, den, pre, suf);
+}
+void launch_trim_finish(const uint32_t *ops, const unsigned long long *rec_start, const uint32_t *rec_n, int64_t n_recs, const unsigned long long *Pc,
+                        const unsigned long long *Pm, const unsigned long long *Pq, const unsigned long long *Pt, const unsigned long long *pre,
+                        const unsigned long long *suf, TrimOut *out, hipStream_t s) {
+    if (n_recs > 0) hipLaunchKernelGGL(k_trim_finish, grid_for(n_recs), dim3(256), 0, s, ops, rec_start, rec_n, n_recs, Pc, Pm, Pq, Pt, pre, suf, out);
 }
 
 }  // namespace mb

@@ -66,6 +66,9 @@ def test_each_sub_command_matches_the_oracle(ctx, seed):
     assert mipaf.PafSet.from_text(text).tile(ctx).text() == oracle("tile", text)                 # no chain scores: AS decides
     for x in ("0.2", "0.5", "0.97", "0", "1"):
         assert mipaf.PafSet.from_text(tiled).trim(ctx, x).text() == oracle("trim", tiled, "--trimIdentity", x), x
+    # op ranges that no record owns any more (filtered records, ops cut by an earlier trim) lie between the live ones
+    twice = mipaf.PafSet.from_text(tiled).filter(max_tile_level=1).trim(ctx, "0.5").trim(ctx, "0.97").text()
+    assert twice == oracle("trim", oracle("trim", oracle("filter", tiled, "--maxTileLevel", "1"), "--trimIdentity", "0.5"), "--trimIdentity", "0.97")
 
 
 @pytest.mark.parametrize("seed", [21, 22, 23])
@@ -128,6 +131,32 @@ def test_chain_dp_workgroup_size_does_not_change_a_byte(ctx, monkeypatch, thread
     monkeypatch.setenv("MIPAF_CHAIN_THREADS", threads)
     assert mipaf.PafSet.from_text(text).chain(ctx).text() == oracle("chain", text, *CHAIN_ARGS)
     assert mipaf.PafSet.from_text(text).chain(ctx, TIGHT).text() == oracle("chain", text, *TIGHT_ARGS)
+
+
+def test_trim_of_a_few_very_long_cigars(ctx):
+    # whole-chunk alignments: a handful of records with tens of thousands of ops each (one lane per op, not per record)
+    text = both_ways(61, n_series=3, per_series=(1, 2), n_q=1, n_t=1, contig_len=40_000_000, noise=0, ragged=True)
+    long_text = "".join(l for l in text.splitlines(keepends=True))
+    import re
+    def stretch(line):                                      # repeat the cigar 300 times and fix the coordinates
+        c = line.rstrip("\n").split("\t")
+        cg = [x for x in c if x.startswith("cg:Z:")]
+        if not cg:
+            return line
+        ops = re.findall(r"(\d+)([=XID])", cg[0][5:]) * 300
+        qspan = sum(int(n) for n, o in ops if o != "D"); tspan = sum(int(n) for n, o in ops if o != "I")
+        c[1] = c[6] = "40000000"
+        c[2], c[3] = "1000", str(1000 + qspan)
+        c[7], c[8] = "2000", str(2000 + tspan)
+        c[9] = str(sum(int(n) for n, o in ops if o == "="))
+        c[10] = str(sum(int(n) for n, o in ops))
+        c[c.index(cg[0])] = "cg:Z:" + "".join(n + o for n, o in ops)
+        return "\t".join(c) + "\n"
+    long_text = "".join(stretch(l) for l in long_text.splitlines(keepends=True))
+    for x in ("0.2", "0.9", "1"):
+        assert mipaf.PafSet.from_text(long_text).trim(ctx, x).text() == oracle("trim", long_text, "--trimIdentity", x), x
+    tiled = oracle("tile", long_text)
+    assert mipaf.PafSet.from_text(long_text).tile(ctx).text() == tiled
 
 
 def test_pile_up_falls_back_to_the_counter_walk(ctx, monkeypatch):
