@@ -74,3 +74,13 @@ def test_emulated_edge_cases():
         assert run(EMU, cmd, one, *args) == run(ORACLE, cmd, one, *args)
     p = subprocess.run([EMU, "tile"], input=b"q\t100\t10\t20\t+\tt\t200\t30\t40\t10\t10\t255\tcg:Z:11=\n", capture_output=True)
     assert p.returncode == 1 and b"do not agree" in p.stderr and p.stdout == b""
+
+
+def test_emulated_pipeline_reproduces_the_committed_chain_fixtures():
+    g = lambda name: open(os.path.join(ROOT, "tests", "golden", f"chain_{name}.paf")).read()      # noqa: E731
+    assert run(EMU, "chain", g("input"), *CHAIN_ARGS) == g("chain")
+    assert run(EMU, "tile", g("chain")) == g("tile")
+    assert run(EMU, "trim", g("tile"), "--trimIdentity", "0.2") == g("trim")
+    assert run(EMU, "filter", g("trim"), "--maxTileLevel", "1") == g("primary")
+    assert run(EMU, "chain", g("primary"), *CHAIN_ARGS) == g("rechain")
+    assert run(EMU, "filter", g("rechain"), "--minChainScore", "10000") == g("output")

@@ -139,3 +139,25 @@ def test_oracle_equals_naive_restatement_on_random_sets(seed):
     rechained = oracle("chain", prim, *CHAIN_ARGS)
     assert rechained == ref.dump(ref.chain(ref.parse(prim), 1_000_000, 5000, 1, 1.0))
     assert oracle("filter", rechained, "--minChainScore", "10000") == ref.dump(ref.filt(ref.parse(rechained), min_chain=10000))
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN_STEPS = [("chain", "input", CHAIN_ARGS), ("tile", "chain", []), ("trim", "tile", ["--trimIdentity", "0.2"]), ("filter", "trim", ["--maxTileLevel", "1"]),
+                ("chain", "primary", CHAIN_ARGS), ("filter", "rechain", ["--minChainScore", "10000"])]
+GOLDEN_OUT = ["chain", "tile", "trim", "primary", "rechain", "output"]
+
+
+def golden(name):
+    return open(os.path.join(GOLDEN, f"chain_{name}.paf")).read()
+
+
+def test_oracle_and_naive_restatement_reproduce_the_committed_chain_fixtures():
+    # tests/golden/chain_*.paf (make_chain_golden.py): regression pins of the rules, step by step
+    for (cmd, src, args), dst in zip(GOLDEN_STEPS, GOLDEN_OUT):
+        assert oracle(cmd, golden(src), *args) == golden(dst), (cmd, src)
+    recs = ref.parse(golden("input"))
+    assert ref.dump(ref.chain(recs, 1_000_000, 5000, 1, 1.0)) == golden("chain")
+    assert ref.dump(ref.tile(ref.parse(golden("chain")))) == golden("tile")
+    assert ref.dump(ref.trim(ref.parse(golden("tile")), "0.2")) == golden("trim")
+    assert ref.dump(ref.filt(ref.parse(golden("trim")), max_tile=1)) == golden("primary")
+    assert ref.dump(ref.filt(ref.parse(golden("rechain")), min_chain=10000)) == golden("output")

@@ -221,6 +221,18 @@ def test_chain_alignments_job_function(monkeypatch, inprocess, secondary):
     assert out == want and len(groups) >= 2
 
 
+def test_committed_chain_fixtures(ctx):
+    """tests/golden/chain_*.paf (written by tests/golden/make_chain_golden.py from the oracle): every step and the whole job."""
+    g = lambda name: open(os.path.join(ROOT, "tests", "golden", f"chain_{name}.paf")).read()      # noqa: E731
+    assert mipaf.PafSet.from_text(g("input")).chain(ctx).text() == g("chain")
+    assert mipaf.PafSet.from_text(g("chain")).tile(ctx).text() == g("tile")
+    assert mipaf.PafSet.from_text(g("chain")).tile(ctx, hist_bins=4096).text() == g("tile")
+    assert mipaf.PafSet.from_text(g("tile")).trim(ctx, "0.2").text() == g("trim")
+    assert mipaf.PafSet.from_text(g("trim")).filter(max_tile_level=1).text() == g("primary")
+    assert mipaf.PafSet.from_text(g("primary")).chain(ctx).text() == g("rechain")
+    assert mipaf.PafSet.from_text(g("input")).chain_tile_trim_filter(ctx, None, "0.2", 10000).text() == g("output")
+
+
 def test_chain_stage_differential_fuzz_slice():
     """A slice of scripts/gpu_chain_fuzz.py (random PAF sets x random chain / trim parameters, every sub-command and the whole
     job against the oracle); 1 800 cases of the full script ran clean during development."""
