@@ -185,6 +185,20 @@ def main():
                          "traffic_note": traffic_note,
                          "note": "a launch is bound by latency per row (~2100 clocks for a lone wave, ~3500 with thousands resident) and instruction issue, not HBM; the roofline fraction rises with the number of pieces in flight (SURVEY 8d caveat, DESIGN.md section 5)"},
         }
+        try:
+            # the DP is VALU / issue bound, so its cells/s are also put against the int32 VALU peak: evaluated cells
+            # (speculative ones included) x the ~10 integer operations the recurrence needs per cell (3 max, 3 add, score lookup,
+            # 2 compares for the y-drop test, trace code) / (CUs x 4 SIMDs x 16 lanes x clock)
+            prop = torch.cuda.get_device_properties(local_rank)
+            clock_hz = float(getattr(prop, "clock_rate", 2_400_000)) * 1e3
+            peak_ops = prop.multi_processor_count * 4 * 16 * clock_hz
+            cells_per_s = tot["dp_cells_run"] / max(1e-12, tot["t_dp_kernel_ms"] * 1e-3)
+            out["roofline"]["valu"] = {"cells_evaluated_per_s": cells_per_s, "min_int_ops_per_cell": 10, "peak_lane_ops_per_s": peak_ops,
+                                       "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9,
+                                       "note": "k_ydrop2 issues ~330 wave instructions per DP row of up to 256 column slots (scans, pruning, trace codes, window bookkeeping included); "
+                                               "with 2-3 resident waves per SIMD a row takes ~3500 clocks, i.e. the SIMDs that hold pieces issue close to one instruction per 4 clocks"}
+        except Exception as e:                               # noqa: BLE001  (never lose the line over a device-property quirk)
+            out["roofline"]["valu"] = {"error": str(e)}
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, pm, ctx)
         if a.chain_leg > 0:
