@@ -234,114 +234,116 @@ def make_ingroup_to_outgroup_alignments_3(job, ingroup_event, ingroup_seq_file, 
 
 
 # ---- chaining stage (local_alignment.py:594-734): chain -> tile -> trim -> filter -> chain -> filter ---------------------------
+# Same job functions, arguments, file flow and thresholds as the reference; written around two small helpers (the paffy command
+# lines of one per-contig job, and "run these piped commands into this file").
 def concat_global_files(job, file_ids, output_path):
-    """:594-604"""
-    with open(output_path, 'wb') as outf:
-        for file_id in file_ids:
-            local_path = job.fileStore.readGlobalFile(file_id)
-            with open(local_path, 'rb') as inf:
-                shutil.copyfileobj(inf, outf)
-            job.fileStore.deleteGlobalFile(file_id)
+    """:594-604 -- the global files end to end in output_path; they are deleted from the store as they are consumed."""
+    with open(output_path, 'wb') as sink:
+        for fid in file_ids:
+            with open(job.fileStore.readGlobalFile(fid), 'rb') as src:
+                shutil.copyfileobj(src, sink)
+            job.fileStore.deleteGlobalFile(fid)
+
+
+def _blast_attrib(params, name, default=None):
+    attrib = params.find("blast").attrib
+    return attrib[name] if default is None else attrib.get(name, default)
+
+
+def _paffy_commands(params):
+    """The command lines of chain_tile_trim_filter_one_contig (:672-681), keyed by role."""
+    level = getLogLevelString()
+    chain = ['paffy', 'chain']
+    for option, attribute in (('--maxGapLength', 'chainMaxGapLength'), ('--chainGapOpen', 'chainGapOpen'),
+                              ('--chainGapExtend', 'chainGapExtend'), ('--trimFraction', 'chainTrimFraction')):
+        chain += [option, _blast_attrib(params, attribute)]
+    return {'chain': chain + ['--logLevel', level],
+            'tile': ['paffy', 'tile', '--logLevel', level],
+            'trim': ['paffy', 'trim', '--trimIdentity', _blast_attrib(params, 'pafTrimIdentity')],
+            'primary': ['paffy', 'filter', '--maxTileLevel', '1'],
+            'score': ['paffy', 'filter', '--minChainScore', _blast_attrib(params, 'minPrimaryChainScore')]}
+
+
+def _pipe_to(job, commands, path, append=False):
+    cactus_call(parameters=commands, outfile=path, outappend=append, job_memory=job.memory)
 
 
 def chain_alignments(job, alignment_files, alignment_names, reference_event_name, params,
                      include_inverted_alignments=True, total_sequence_size=0):
-    """:607-657 -- same flow and thresholds; `paffy` is bin/paffy."""
+    """:607-657 -- merge the PAF files, append their inverted copy, and chain the lot: in one job when the merged file is at most
+    chainSplitMinSize bytes, else split by query contig (paffy split_file, parts of >= chainContigGroupSize bases) with one job
+    per part and a merge at the end."""
     work_dir = job.fileStore.getLocalTempDir()
-    merged_path = os.path.join(work_dir, 'merged.paf')
-    concat_global_files(job, alignment_files, merged_path)
-
+    merged = os.path.join(work_dir, 'merged.paf')
+    concat_global_files(job, alignment_files, merged)
     if include_inverted_alignments:
-        inv_path = os.path.join(work_dir, 'merged_copy.paf')
-        shutil.copyfile(merged_path, inv_path)
-        cactus_call(parameters=['paffy', 'invert', '--inputFile', inv_path], outfile=merged_path, outappend=True,
-                    job_memory=job.memory)
-        os.remove(inv_path)
+        snapshot = os.path.join(work_dir, 'merged_copy.paf')           # invert reads a copy while its output is appended to the original
+        shutil.copyfile(merged, snapshot)
+        _pipe_to(job, ['paffy', 'invert', '--inputFile', snapshot], merged, append=True)
+        os.remove(snapshot)
 
-    merged_size = os.path.getsize(merged_path)
-    chain_split_min_size = int(params.find("blast").attrib.get("chainSplitMinSize", "1000000000"))
+    def one_job(path):
+        size = os.path.getsize(path)
+        return job.addChildJobFn(chain_tile_trim_filter_one_contig, job.fileStore.writeGlobalFile(path), reference_event_name, params,
+                                 disk=4 * size, memory=cactus_clamp_memory(4 * size)).rv()
 
-    if merged_size <= chain_split_min_size:
-        merged_file_id = job.fileStore.writeGlobalFile(merged_path)
-        return job.addChildJobFn(chain_tile_trim_filter_one_contig, merged_file_id, reference_event_name, params,
-                                 disk=4 * merged_size, memory=cactus_clamp_memory(4 * merged_size)).rv()
-
-    contig_group_size = int(params.find("blast").attrib.get("chainContigGroupSize", "10000000"))
-    split_prefix = os.path.join(work_dir, 'split_')
-    cactus_call(parameters=['paffy', 'split_file', '--inputFile', merged_path, '--query', '--prefix', split_prefix,
-                            '--minLength', str(contig_group_size), '--logLevel', getLogLevelString()], job_memory=job.memory)
-    processed_rvs = []
-    for split_path in sorted(glob.glob(split_prefix + '*.paf'), key=lambda p: int(p[len(split_prefix):-4])):
-        split_size = os.path.getsize(split_path)
-        split_file_id = job.fileStore.writeGlobalFile(split_path)
-        processed_rvs.append(job.addChildJobFn(chain_tile_trim_filter_one_contig, split_file_id, reference_event_name, params,
-                                               disk=4 * split_size, memory=cactus_clamp_memory(4 * split_size)).rv())
-    return job.addFollowOnJobFn(merge_processed_alignments, processed_rvs).rv()
+    if os.path.getsize(merged) <= int(_blast_attrib(params, "chainSplitMinSize", "1000000000")):
+        return one_job(merged)
+    prefix = os.path.join(work_dir, 'split_')
+    cactus_call(parameters=['paffy', 'split_file', '--inputFile', merged, '--query', '--prefix', prefix,
+                            '--minLength', str(int(_blast_attrib(params, "chainContigGroupSize", "10000000"))),
+                            '--logLevel', getLogLevelString()], job_memory=job.memory)
+    parts = sorted(glob.glob(prefix + '*.paf'), key=lambda path: int(path[len(prefix):-len('.paf')]))
+    return job.addFollowOnJobFn(merge_processed_alignments, [one_job(path) for path in parts]).rv()
 
 
 def chain_tile_trim_filter_one_contig(job, split_file_id, reference_event_name, params):
-    """:660-727.  With MIBLAST_INPROCESS=1 the job is one mipaf_chain_tile_trim_filter call (one device context instead of
-    one per piped process); the bytes are the same either way (tests/test_zz_chain_gpu.py)."""
+    """:660-727 -- chain | tile | trim | filter --maxTileLevel 1 | chain | filter --minChainScore on one part.  With
+    outputSecondaryAlignments the reference's second branch: what `filter --maxTileLevel 1 --invert` finds in the filtered file,
+    then the primaries that keep their chain score, then the demoted ones relabelled tp:A:S / tl:i:2.  With MIBLAST_INPROCESS=1 the
+    job is one mipaf_chain_tile_trim_filter call (one device context instead of one per piped process); the bytes are the same
+    either way (tests/test_zz_chain_gpu.py)."""
     work_dir = job.fileStore.getLocalTempDir()
-    input_path = os.path.join(work_dir, 'input.paf')
-    job.fileStore.readGlobalFile(split_file_id, input_path)
-
-    blast = params.find("blast").attrib
-    output_path = os.path.join(work_dir, 'output.paf')
-    use_secondary_alignments = int(blast["outputSecondaryAlignments"])
+    source = os.path.join(work_dir, 'input.paf')
+    result = os.path.join(work_dir, 'output.paf')
+    job.fileStore.readGlobalFile(split_file_id, source)
+    secondary = int(_blast_attrib(params, "outputSecondaryAlignments")) != 0
 
     if os.environ.get("MIBLAST_INPROCESS") == "1":
         from cactus_amd import miblast, mipaf
         ctx = miblast.Context(0)
         try:
-            cp = mipaf.default_chain_params(max_gap_length=int(blast["chainMaxGapLength"]), gap_open=int(blast["chainGapOpen"]),
-                                            gap_extend=int(blast["chainGapExtend"]), trim_fraction=float(blast["chainTrimFraction"]))
-            s = mipaf.PafSet.from_file(input_path)
-            s.chain_tile_trim_filter(ctx, cp, blast["pafTrimIdentity"], int(blast["minPrimaryChainScore"]),
-                                     output_secondary=bool(use_secondary_alignments))
-            s.write(output_path)
+            cp = mipaf.default_chain_params(max_gap_length=int(_blast_attrib(params, "chainMaxGapLength")), gap_open=int(_blast_attrib(params, "chainGapOpen")),
+                                            gap_extend=int(_blast_attrib(params, "chainGapExtend")), trim_fraction=float(_blast_attrib(params, "chainTrimFraction")))
+            s = mipaf.PafSet.from_file(source)
+            s.chain_tile_trim_filter(ctx, cp, _blast_attrib(params, "pafTrimIdentity"), int(_blast_attrib(params, "minPrimaryChainScore")),
+                                     output_secondary=secondary)
+            s.write(result)
             s.close()
         finally:
             ctx.close()
-        processed_alignment_file_id = job.fileStore.writeGlobalFile(output_path)
-        job.fileStore.deleteGlobalFile(split_file_id)
-        return processed_alignment_file_id
-
-    chain_cmd = ['paffy', 'chain',
-                 '--maxGapLength', blast["chainMaxGapLength"],
-                 '--chainGapOpen', blast["chainGapOpen"],
-                 '--chainGapExtend', blast["chainGapExtend"],
-                 '--trimFraction', blast["chainTrimFraction"],
-                 '--logLevel', getLogLevelString()]
-    tile_cmd = ['paffy', 'tile', '--logLevel', getLogLevelString()]
-    trim_cmd = ['paffy', 'trim', '--trimIdentity', blast["pafTrimIdentity"]]
-    filter_primary_cmd = ['paffy', 'filter', '--maxTileLevel', '1']
-    filter_score_cmd = ['paffy', 'filter', '--minChainScore', blast["minPrimaryChainScore"]]
-
-    if not use_secondary_alignments:
-        cactus_call(parameters=[chain_cmd + ['--inputFile', input_path], tile_cmd, trim_cmd, filter_primary_cmd, chain_cmd[:],
-                                filter_score_cmd], outfile=output_path, job_memory=job.memory)
     else:
-        filter_path = os.path.join(work_dir, 'filter.paf')
-        cactus_call(parameters=[chain_cmd + ['--inputFile', input_path], tile_cmd, trim_cmd, filter_primary_cmd],
-                    outfile=filter_path, job_memory=job.memory)
-        cactus_call(parameters=[['paffy', 'filter', '--inputFile', filter_path, '--maxTileLevel', '1', '--invert']],
-                    outfile=output_path, job_memory=job.memory)
-        primary_chain_path = os.path.join(work_dir, 'primary_chain.paf')
-        cactus_call(parameters=[chain_cmd + ['--inputFile', filter_path]], outfile=primary_chain_path, job_memory=job.memory)
-        cactus_call(parameters=[['paffy', 'filter', '--inputFile', primary_chain_path, '--minChainScore', blast["minPrimaryChainScore"]]],
-                    outfile=output_path, outappend=True, job_memory=job.memory)
-        cactus_call(parameters=[['paffy', 'filter', '--inputFile', primary_chain_path, '--invert', '--minChainScore', blast["minPrimaryChainScore"]],
-                                ['sed', 's/tp:A:P/tp:A:S/'], ['sed', 's/tl:i:1/tl:i:2/']], outfile=output_path, outappend=True)
+        cmd = _paffy_commands(params)
+        first_pass = [cmd['chain'] + ['--inputFile', source], cmd['tile'], cmd['trim'], cmd['primary']]
+        if not secondary:
+            _pipe_to(job, first_pass + [cmd['chain'], cmd['score']], result)
+        else:
+            filtered = os.path.join(work_dir, 'filter.paf')
+            rechained = os.path.join(work_dir, 'primary_chain.paf')
+            _pipe_to(job, first_pass, filtered)
+            _pipe_to(job, [cmd['primary'] + ['--inputFile', filtered, '--invert']], result)
+            _pipe_to(job, [cmd['chain'] + ['--inputFile', filtered]], rechained)
+            _pipe_to(job, [cmd['score'] + ['--inputFile', rechained]], result, append=True)
+            cactus_call(parameters=[cmd['score'] + ['--inputFile', rechained, '--invert'], ['sed', 's/tp:A:P/tp:A:S/'], ['sed', 's/tl:i:1/tl:i:2/']],
+                        outfile=result, outappend=True)
 
-    processed_alignment_file_id = job.fileStore.writeGlobalFile(output_path)
+    processed = job.fileStore.writeGlobalFile(result)
     job.fileStore.deleteGlobalFile(split_file_id)
-    return processed_alignment_file_id
+    return processed
 
 
 def merge_processed_alignments(job, processed_file_ids):
-    """:730-737"""
-    work_dir = job.fileStore.getLocalTempDir()
-    output_path = os.path.join(work_dir, 'final.paf')
-    concat_global_files(job, processed_file_ids, output_path)
-    return job.fileStore.writeGlobalFile(output_path)
+    """:730-737 -- the per-part outputs end to end."""
+    final = os.path.join(job.fileStore.getLocalTempDir(), 'final.paf')
+    concat_global_files(job, processed_file_ids, final)
+    return job.fileStore.writeGlobalFile(final)

@@ -84,3 +84,53 @@ def test_emulated_pipeline_reproduces_the_committed_chain_fixtures():
     assert run(EMU, "filter", g("trim"), "--maxTileLevel", "1") == g("primary")
     assert run(EMU, "chain", g("primary"), *CHAIN_ARGS) == g("rechain")
     assert run(EMU, "filter", g("rechain"), "--minChainScore", "10000") == g("output")
+
+
+@pytest.mark.parametrize("secondary", ["0", "1"])
+def test_chain_alignments_job_function_over_the_emulated_front_end(tmp_path, monkeypatch, secondary):
+    """chain_alignments / chain_tile_trim_filter_one_contig (the mirrors of local_alignment.py:607-727) as the reference's caller runs
+    them, with `paffy` on PATH being the host build of the product's sources: merged input, inverted copies, split by query contig,
+    piped per-part jobs (both outputSecondaryAlignments modes), merge.  The GPU suite runs the same test with bin/paffy."""
+    import xml.etree.ElementTree as ET
+    from cactus_amd.paf import local_alignment as la
+    from cactus_amd.shared import common
+    from cactus_amd.shared.localjob import LocalJob
+    (tmp_path / "bin").mkdir()
+    os.symlink(EMU, tmp_path / "bin" / "paffy")
+    monkeypatch.setattr(common, "BIN_DIR", str(tmp_path / "bin"))
+    monkeypatch.setenv("MIPAF_CHAIN_THREADS", "256")
+    monkeypatch.delenv("MIBLAST_INPROCESS", raising=False)
+    params = ET.parse(os.path.join(ROOT, "cactus_amd", "blast_config.xml")).getroot()
+    blast = params.find("blast")
+    blast.attrib["outputSecondaryAlignments"] = secondary
+    blast.attrib["chainSplitMinSize"] = "1000"
+    blast.attrib["chainContigGroupSize"] = "150000"
+    job = LocalJob()
+    parts = [ref.random_paf(51, n_series=4, noise=6), ref.random_paf(52, n_series=4, noise=6)]
+    ids = []
+    for k, text in enumerate(parts):
+        path = os.path.join(job.fileStore.getLocalTempDir(), f"{k}.paf")
+        open(path, "w").write(text)
+        ids.append(job.fileStore.writeGlobalFile(path))
+    out = open(str(la.chain_alignments(job, ids, ["a", "b"], "Anc0", params))).read()
+
+    def oracle_job(text):
+        filt = run(ORACLE, "filter", run(ORACLE, "trim", run(ORACLE, "tile", run(ORACLE, "chain", text, *CHAIN_ARGS)), "--trimIdentity", "0.2"), "--maxTileLevel", "1")
+        rechained = run(ORACLE, "chain", filt, *CHAIN_ARGS)
+        if secondary == "0":
+            return run(ORACLE, "filter", rechained, "--minChainScore", "10000")
+        demoted = run(ORACLE, "filter", rechained, "--invert", "--minChainScore", "10000").replace("tp:A:P", "tp:A:S").replace("tl:i:1", "tl:i:2")
+        return run(ORACLE, "filter", filt, "--maxTileLevel", "1", "--invert") + run(ORACLE, "filter", rechained, "--minChainScore", "10000") + demoted
+
+    merged = "".join(parts)
+    merged += run(ORACLE, "invert", merged)
+    groups, seen, acc = [[]], {}, 0                          # R-S1: parts close at >= 150 kb of query sequence, first appearance order
+    for line in merged.splitlines(keepends=True):
+        c = line.split("\t")
+        if c[0] not in seen:
+            seen[c[0]] = len(groups) - 1
+            acc += int(c[1])
+            if acc >= 150000:
+                groups.append([]); acc = 0
+        groups[seen[c[0]]].append(line)
+    assert out == "".join(oracle_job("".join(g)) for g in groups if g) and len([g for g in groups if g]) >= 2

@@ -173,3 +173,46 @@ def test_cactus_call_pipes_commands_like_the_reference(tmp_path):
     with pytest.raises(RuntimeError) as e:
         cactus_call([["printf", "x\\n"], ["sh", "-c", "cat >/dev/null; echo boom >&2; exit 3"], ["cat"]], check_output=True)
     assert "exited 3" in str(e.value) and "boom" in str(e.value)
+
+
+def test_inprocess_chaining_job_passes_the_config_values_to_the_c_abi(tmp_path, monkeypatch):
+    # chain_tile_trim_filter_one_contig with MIBLAST_INPROCESS=1: one mipaf_chain_tile_trim_filter call carrying the <blast> attributes
+    import xml.etree.ElementTree as ET
+    from cactus_amd import miblast, mipaf
+    from cactus_amd.paf import local_alignment as la
+    calls = {}
+
+    class FakeCtx:
+        def __init__(self, device):
+            calls["device"] = device
+
+        def close(self):
+            calls["closed"] = True
+
+    class FakeSet:
+        @classmethod
+        def from_file(cls, path):
+            calls["input"] = open(path).read()
+            return cls()
+
+        def chain_tile_trim_filter(self, ctx, cp, identity, min_score, output_secondary=False):
+            calls["args"] = (cp.max_gap_length, cp.gap_open, cp.gap_extend, cp.trim_fraction, identity, min_score, output_secondary)
+
+        def write(self, path):
+            open(path, "w").write("out\n")
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(miblast, "Context", FakeCtx)
+    monkeypatch.setattr(mipaf, "PafSet", FakeSet)
+    monkeypatch.setenv("MIBLAST_INPROCESS", "1")
+    params = ET.parse(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cactus_amd", "blast_config.xml")).getroot()
+    job = LocalJob()
+    src = tmp_path / "in.paf"
+    src.write_text("x\n")
+    fid = job.fileStore.writeGlobalFile(str(src))
+    out = la.chain_tile_trim_filter_one_contig(job, fid, "Anc0", params)
+    assert open(str(out)).read() == "out\n" and calls["input"] == "x\n" and calls["closed"] and calls["device"] == 0
+    assert calls["args"] == (1000000, 5000, 1, 1.0, "0.2", 10000, False)           # cactus_progressive_config.xml:108-113
+    assert not os.path.exists(str(fid))
