@@ -84,6 +84,15 @@ def blast_pairs_sharded(pairs: Sequence, weights: Sequence[float], align_fn: Cal
     return b"".join(by_index[i] for i in range(len(pairs)))
 
 
+def chain_parts_sharded(parts: Sequence[bytes], job_fn: Callable[[bytes], bytes], dist, rank: int, world_size: int, device) -> Optional[bytes]:
+    """The chaining stage over several GPUs: the per-contig parts chain_alignments makes with `paffy split_file`
+    (/root/reference/src/cactus/paf/local_alignment.py:636-657) are independent jobs, exactly like chunk pairs, so they shard the
+    same way -- longest part first to the least loaded rank, no data-path collective, one gather of the outputs to rank 0, which
+    returns them concatenated in part order (what merge_processed_alignments does).  job_fn(part_text) -> output text is one
+    chain_tile_trim_filter_one_contig job (mipaf.PafSet...chain_tile_trim_filter on that rank's GPU)."""
+    return blast_pairs_sharded(parts, [float(len(p)) for p in parts], job_fn, dist, rank, world_size, device)
+
+
 def align_pairs_concurrent(pairs, params, device: int = 0, workers: int = 4):
     """Several chunk pairs of ONE GPU in flight at once (the reference schedules many single-threaded lastz jobs per
     node, /root/reference/src/cactus/paf/local_alignment.py:399-405).  A single pair cannot fill an MI355X -- its gapped

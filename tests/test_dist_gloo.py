@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cactus_amd.multigpu import assign_pairs, blast_pairs_sharded
+from cactus_amd.multigpu import assign_pairs, blast_pairs_sharded, chain_parts_sharded
 
 
 def _fake_align(pair):
@@ -58,3 +58,43 @@ def test_two_rank_gloo_gather_equals_single_process():
         assert p.exitcode == 0
     assert got[1] is None
     assert got[0] == single == b"".join(_fake_align(p) for p in pairs)
+
+
+# ---- chaining stage: per-contig parts sharded over ranks (the job itself is the oracle here: CPU test) ------------------------------
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_chain_job(part: bytes) -> bytes:
+    import subprocess
+    o = os.path.join(_ROOT, "oracle", "oracle_paffy")
+    chain = f"{o} chain --maxGapLength 1000000 --chainGapOpen 5000 --chainGapExtend 1 --trimFraction 1.0"
+    cmd = f"{chain} | {o} tile | {o} trim --trimIdentity 0.2 | {o} filter --maxTileLevel 1 | {chain} | {o} filter --minChainScore 10000"
+    return subprocess.run(["bash", "-o", "pipefail", "-c", cmd], input=part, capture_output=True, check=True).stdout
+
+
+def _chain_worker(rank, world, port, parts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = chain_parts_sharded(parts, _oracle_chain_job, dist, rank, world, torch.device("cpu"))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_chaining_of_contig_parts_equals_single_process():
+    from cactus_amd import gen
+    parts = [gen.random_paf(70 + k, n_series=3 + k, noise=5 * k, n_q=1, n_t=2).replace("id=Q|chr0", f"id=Q|chr{k}").encode() for k in range(5)]
+    single = chain_parts_sharded(parts, _oracle_chain_job, None, 0, 1, torch.device("cpu"))
+    assert single == b"".join(_oracle_chain_job(p) for p in parts) and single
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chain_worker, args=(r, 2, port, parts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[1] is None and got[0] == single
