@@ -2,12 +2,17 @@
 // chain_alignments / chain_tile_trim_filter_one_contig can stay as they are:
 //   * argv of /root/reference/src/cactus/paf/local_alignment.py:624 (invert), :638-642 (split_file), :672-681 (chain, tile,
 //     trim, filter), :696-715 (filter --inputFile / --invert); input from --inputFile or stdin, PAF on stdout;
-//   * unknown sub-command or option -> exit 2 with a message; no GPU for chain / tile / trim -> exit 3, nothing on stdout.
+//   * `dechunk` (:352, :515) is text-only and done here; any OTHER sub-command (view, to_bed, upconvert, add_mismatches ...) is
+//     handed to the next `paffy` on PATH, so that putting <repo>/bin first on PATH does not hide the real tool;
+//   * unknown option, or a foreign sub-command with no other paffy on PATH -> exit 2 with a message; no GPU for chain / tile /
+//     trim -> exit 3, nothing on stdout.
 // Everything is done by libmiblast.so through include/mipaf.h.
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unistd.h>
 
 #include "../../include/mipaf.h"
 
@@ -16,21 +21,99 @@ static int fail(int code, const std::string &msg) {
     return code;
 }
 
+// `paffy dechunk -i X [--query]`: NAME|SEQLEN|CHUNKSTART -> NAME, coordinates shifted by CHUNKSTART, length restored
+// (Appendix B of SURVEY.md; every other column and tag is passed through untouched)
+static bool dechunk_name(std::string &name, std::string &len, long long &start) {
+    const size_t b = name.rfind('|');
+    if (b == std::string::npos || b == 0) return false;
+    const size_t a = name.rfind('|', b - 1);
+    if (a == std::string::npos) return false;
+    char *end = nullptr;
+    start = strtoll(name.c_str() + b + 1, &end, 10);
+    if (!end || *end) return false;
+    len = name.substr(a + 1, b - a - 1);
+    if (len.empty() || len.find_first_not_of("0123456789") != std::string::npos) return false;
+    name.resize(a);
+    return true;
+}
+
+static int dechunk(const char *input, bool query_only) {
+    FILE *in = input ? fopen(input, "r") : stdin;
+    if (!in) return fail(1, std::string("cannot open ") + input);
+    char *line = nullptr;
+    size_t cap = 0;
+    ssize_t got;
+    size_t line_no = 0;
+    std::string out;
+    while ((got = getline(&line, &cap, in)) > 0) {
+        line_no++;
+        while (got > 0 && (line[got - 1] == '\n' || line[got - 1] == '\r')) line[--got] = 0;
+        if (got == 0) continue;
+        std::string col[9];
+        const char *p = line;
+        int n = 0;
+        for (; n < 9; n++) {
+            const char *t = strchr(p, '\t');
+            if (!t) { col[n++] = p; p = nullptr; break; }
+            col[n].assign(p, (size_t)(t - p));
+            p = t + 1;
+        }
+        if (n < 9) { free(line); return fail(1, "dechunk: PAF line " + std::to_string(line_no) + " has fewer than 9 columns"); }
+        for (int side = 0; side < (query_only ? 1 : 2); side++) {
+            const int c = side == 0 ? 0 : 5;
+            std::string len;
+            long long start = 0;
+            if (!dechunk_name(col[c], len, start)) { free(line); return fail(1, "dechunk: PAF line " + std::to_string(line_no) + ": name is not NAME|LENGTH|START"); }
+            col[c + 1] = len;
+            col[c + 2] = std::to_string(atoll(col[c + 2].c_str()) + start);
+            col[c + 3] = std::to_string(atoll(col[c + 3].c_str()) + start);
+        }
+        for (int k = 0; k < 9; k++) { if (k) out += '\t'; out += col[k]; }
+        if (p) { out += '\t'; out += p; }
+        out += '\n';
+        if (out.size() > (1u << 20)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
+    }
+    fwrite(out.data(), 1, out.size(), stdout);
+    free(line);
+    if (input) fclose(in);
+    return 0;
+}
+
+// a sub-command this front end does not provide: run the next paffy on PATH in our place
+static int delegate(char **argv) {
+    char self[PATH_MAX] = {0}, other[PATH_MAX];
+    if (!realpath("/proc/self/exe", self)) self[0] = 0;
+    const char *path = getenv("PATH");
+    for (const char *p = path; p && *p;) {
+        const char *e = strchr(p, ':');
+        const std::string dir(p, e ? (size_t)(e - p) : strlen(p));
+        p = e ? e + 1 : nullptr;
+        if (dir.empty()) continue;
+        const std::string cand = dir + "/paffy";
+        if (access(cand.c_str(), X_OK) != 0 || !realpath(cand.c_str(), other) || !strcmp(other, self)) continue;
+        execv(cand.c_str(), argv);
+    }
+    return fail(2, std::string("sub-command ") + argv[1] + " is not provided by this front end (invert, chain, tile, trim, filter, split_file, dechunk) "
+                "and no other paffy is on PATH");
+}
+
 int main(int argc, char **argv) {
-    if (argc < 2) return fail(2, "usage: paffy <invert|chain|tile|trim|filter|split_file> [options]");
+    if (argc < 2) return fail(2, "usage: paffy <invert|chain|tile|trim|filter|split_file|dechunk> [options]");
     const std::string cmd = argv[1];
+    if (cmd != "invert" && cmd != "chain" && cmd != "tile" && cmd != "trim" && cmd != "filter" && cmd != "split_file" && cmd != "dechunk") return delegate(argv);
     const char *input = nullptr, *output = nullptr, *prefix = "split_", *trim_identity = nullptr;
     mipaf_chain_params cp;
     mipaf_chain_params_default(&cp);
     cp.max_gap_length = 50000;                              // stand-alone default; Cactus always passes its own values
     long long max_tile = -1, min_chain = -1, min_length = 0;
     int invert = 0, hist_bins = 0;
+    bool query_flag = false;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
         const char *v = nullptr;
         if (a == "--invert") { invert = 1; continue; }
-        if (a == "--query") continue;
+        if (a == "--query") { query_flag = true; continue; }
         if (!(v = val())) return fail(2, "option " + a + " needs a value");
         if (a == "--inputFile" || a == "-i") input = v;
         else if (a == "--outputFile" || a == "-o") output = v;
@@ -47,8 +130,8 @@ int main(int argc, char **argv) {
         else if (a == "--mipaf-hist-bins") hist_bins = atoi(v);   // private, never passed by Cactus: size of k_tile's LDS histogram
         else return fail(2, "unknown option " + a);
     }
+    if (cmd == "dechunk") return dechunk(input, query_flag);
     const bool needs_gpu = cmd == "chain" || cmd == "tile" || cmd == "trim";
-    if (!needs_gpu && cmd != "invert" && cmd != "filter" && cmd != "split_file") return fail(2, "unknown sub-command " + cmd);
     if (cmd == "trim" && !trim_identity) return fail(2, "trim: only --trimIdentity is implemented (the option Cactus passes)");
     miblast_ctx *ctx = nullptr;
     if (needs_gpu) {

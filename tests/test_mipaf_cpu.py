@@ -114,3 +114,25 @@ def test_large_text_is_parsed_in_chunks_with_the_same_result():
     with pytest.raises(miblast.MiblastError) as e:
         mipaf.PafSet.from_text("".join(lines))
     assert f"PAF line {k + 1}:" in str(e.value)
+
+
+def test_front_end_dechunks_and_hands_foreign_sub_commands_to_the_next_paffy(tmp_path):
+    from cactus_amd.paf import chunking
+    # `paffy dechunk -i X [--query]` (local_alignment.py:352, :515): same text as cactus_amd.paf.chunking, every other column kept
+    lines = [f"id=Q|c{k}|{1000 + k}|{100 * k}\t50\t5\t20\t{'+-'[k % 2]}\tid=T|x|2000|{300 + k}\t80\t7\t30\t10\t15\t255\tAS:i:{k}\tzz:Z:keep\n" for k in range(5)]
+    src = tmp_path / "c.paf"
+    src.write_text("".join(lines))
+    for extra, query_only in (([], False), (["--query", "--logLevel", "INFO"], True)):
+        p = subprocess.run([PAFFY, "dechunk", "-i", str(src), *extra], capture_output=True)
+        assert p.returncode == 0 and p.stdout.decode() == "".join(chunking.paf_dechunk_line(l, query_only) for l in lines)
+    assert subprocess.run([PAFFY, "dechunk"], input=b"q\t1\t0\t1\t+\tt|9|0\t1\t0\t1\t1\t1\t255\n", capture_output=True).returncode == 1
+    # any sub-command this front end does not provide goes to the next paffy on PATH (so <repo>/bin first on PATH hides nothing)
+    other = tmp_path / "elsewhere"
+    other.mkdir()
+    (other / "paffy").write_text("#!/bin/sh\necho real paffy got: \"$@\"\nexit 7\n")
+    (other / "paffy").chmod(0o755)
+    env = dict(os.environ, PATH=BIN_DIR + os.pathsep + str(other) + os.pathsep + os.environ.get("PATH", ""))
+    p = subprocess.run(["paffy", "view", "a.fa", "b.fa", "-i", "x.paf"], capture_output=True, env=env)
+    assert p.returncode == 7 and p.stdout == b"real paffy got: view a.fa b.fa -i x.paf\n"
+    p = subprocess.run([PAFFY, "to_bed", "--binary"], capture_output=True, env=dict(os.environ, PATH=BIN_DIR + os.pathsep + "/usr/bin:/bin"))
+    assert p.returncode == 2 and b"no other paffy is on PATH" in p.stderr
