@@ -800,6 +800,7 @@ void trim(Ctx &ctx, PafSet &set, long long num, long long den, mipaf_stats &st) 
         PafRec &r = set.recs[which[k]];
         const TrimOut &t = res[k];
         if (t.pre + t.suf >= t.cols) { drop[which[k]] = 1; continue; }      // R-R3
+        r.nm = t.nm; r.nb = t.nb;                                           // R-R3: columns 10/11 always follow the cigar, trimmed or not
         if (t.pre == 0 && t.suf == 0) continue;
         uint32_t *ops = set.ops.data() + r.ops_off;
         const uint32_t code_f = ops[t.first_op] & 7u, code_l = ops[t.last_op] & 7u;

@@ -80,7 +80,7 @@ static int dechunk(const char *input, bool query_only) {
 }
 
 // a sub-command this front end does not provide: run the next paffy on PATH in our place
-static int delegate(char **argv) {
+static int delegate(char **argv, bool required = true) {
     char self[PATH_MAX] = {0}, other[PATH_MAX];
     if (!realpath("/proc/self/exe", self)) self[0] = 0;
     const char *path = getenv("PATH");
@@ -93,6 +93,7 @@ static int delegate(char **argv) {
         if (access(cand.c_str(), X_OK) != 0 || !realpath(cand.c_str(), other) || !strcmp(other, self)) continue;
         execv(cand.c_str(), argv);
     }
+    if (!required) return -1;
     return fail(2, std::string("sub-command ") + argv[1] + " is not provided by this front end (invert, chain, tile, trim, filter, split_file, dechunk) "
                 "and no other paffy is on PATH");
 }
@@ -101,6 +102,13 @@ int main(int argc, char **argv) {
     if (argc < 2) return fail(2, "usage: paffy <invert|chain|tile|trim|filter|split_file|dechunk> [options]");
     const std::string cmd = argv[1];
     if (cmd != "invert" && cmd != "chain" && cmd != "tile" && cmd != "trim" && cmd != "filter" && cmd != "split_file" && cmd != "dechunk") return delegate(argv);
+    // The chaining rules of this front end are restated from paffy's description (PARITY UNPINNED: the
+    // reference's paffy submodule is empty).  A real paffy further down PATH is therefore never shadowed unless asked for
+    // with MIPAF_NATIVE=1; without one there is nothing to shadow and the native path runs.
+    {
+        const char *native = getenv("MIPAF_NATIVE");
+        if (!(native && *native && strcmp(native, "0") != 0)) delegate(argv, false);      // returns only if no other paffy exists
+    }
     const char *input = nullptr, *output = nullptr, *prefix = "split_", *trim_identity = nullptr;
     mipaf_chain_params cp;
     mipaf_chain_params_default(&cp);

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import os
 import subprocess
+import threading
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BIN_DIR = os.path.join(REPO_ROOT, "bin")
@@ -54,8 +55,20 @@ def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpu
                                           stderr=subprocess.PIPE, cwd=work_dir, env=call_env))
             if len(procs) > 1:
                 procs[-2].stdout.close()                       # the reader owns the pipe now (SIGPIPE reaches the writer)
+        # stderr of the intermediate stages is drained while they run: a stage that writes more than a pipe buffer of
+        # diagnostics would otherwise block for ever with the last stage waiting on its output
+        drained = [b""] * len(procs)
+
+        def drain(i):
+            drained[i] = procs[i].stderr.read()
+
+        readers = [threading.Thread(target=drain, args=(i,), daemon=True) for i in range(len(procs) - 1)]
+        for t in readers:
+            t.start()
         out, err = procs[-1].communicate()
-        errs = [p.stderr.read() if p is not procs[-1] else err for p in procs]
+        for t in readers:
+            t.join()
+        errs = drained[:-1] + [err]
         for p in procs[:-1]:
             p.wait()
     finally:

@@ -72,6 +72,11 @@ def test_emulated_edge_cases():
     one = "q\t100\t10\t20\t-\tt\t200\t30\t40\t10\t10\t255\n"
     for cmd, args in (("chain", CHAIN_ARGS), ("tile", []), ("trim", ["--trimIdentity", "0.2"])):
         assert run(EMU, cmd, one, *args) == run(ORACLE, cmd, one, *args)
+    # columns 10/11 that disagree with the cigar: R-R3 rewrites them for every kept record, trimmed or not
+    odd = "q\t1000\t100\t200\t+\tt\t2000\t300\t400\t50\t70\t255\tAS:i:9000\tcg:Z:100=\n" \
+          "q\t1000\t300\t420\t-\tt\t2000\t500\t600\t7\t9\t255\tAS:i:500\tcg:Z:40=20I10X50=\n"
+    got = run(EMU, "trim", odd, "--trimIdentity", "0.2")
+    assert got == run(ORACLE, "trim", odd, "--trimIdentity", "0.2") and "\t100\t100\t255" in got
     p = subprocess.run([EMU, "tile"], input=b"q\t100\t10\t20\t+\tt\t200\t30\t40\t10\t10\t255\tcg:Z:11=\n", capture_output=True)
     assert p.returncode == 1 and b"do not agree" in p.stderr and p.stdout == b""
 
@@ -94,7 +99,7 @@ def test_chain_alignments_job_function_over_the_emulated_front_end(tmp_path, mon
     import xml.etree.ElementTree as ET
     from cactus_amd.paf import local_alignment as la
     from cactus_amd.shared import common
-    from cactus_amd.shared.localjob import LocalJob
+    from localjob import LocalJob
     (tmp_path / "bin").mkdir()
     os.symlink(EMU, tmp_path / "bin" / "paffy")
     monkeypatch.setattr(common, "BIN_DIR", str(tmp_path / "bin"))

@@ -11,7 +11,7 @@ from cactus_amd.paf import chunking
 from cactus_amd.paf.local_alignment import select_lastz_params, combine_chunks
 from cactus_amd.shared import configWrapper
 from cactus_amd.shared.common import cactus_call, getOptionalAttrib
-from cactus_amd.shared.localjob import FileID, LocalFileStore, LocalJob
+from localjob import FileID, LocalFileStore, LocalJob
 
 
 def test_distance_selects_the_reference_parameter_sets():

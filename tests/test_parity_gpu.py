@@ -191,7 +191,7 @@ def test_run_lastz_job_interface(gpu_ctx, olz, tmp_path, monkeypatch):
     in-process boundary: identical PAF, equal to the oracle run with the parameter set the distance selects."""
     from cactus_amd.paf.local_alignment import run_lastz, select_lastz_params
     from cactus_amd.shared.configWrapper import load_config
-    from cactus_amd.shared.localjob import LocalJob, LocalFileStore, FileID
+    from localjob import LocalJob, LocalFileStore, FileID
     from cactus_amd import miblast
     from cases import pair
     tf, qf = pair(30000, 35, sub_rate=0.1, indel_rate=0.005)
@@ -246,7 +246,7 @@ def test_repeat_mask_call_site_general_format(gpu_ctx, olz, tmp_path):
     from cactus_amd import gen, miblast
     from cactus_amd.preprocessor.lastz_repeat_mask import LastzRepeatMaskJob, RepeatMaskOptions, fasta_fragments
     from cactus_amd.shared.common import BIN_DIR
-    from cactus_amd.shared.localjob import LocalFileStore, FileID
+    from localjob import LocalFileStore, FileID
     rng = np.random.default_rng(9)
     unit = gen.random_sequence(600, rng)
     parts, truth = [], []
@@ -295,7 +295,7 @@ def test_ingroup_to_outgroup_trimming_chain(gpu_ctx, tmp_path):
     from cactus_amd import gen, pafcheck
     from cactus_amd.paf.local_alignment import make_ingroup_to_outgroup_alignments_0
     from cactus_amd.shared.configWrapper import load_config
-    from cactus_amd.shared.localjob import LocalJob, LocalFileStore, FileID
+    from localjob import LocalJob, LocalFileStore, FileID
     rng = np.random.default_rng(21)
     anc = gen.random_sequence(60000, rng)
     ingroup = gen.mutate(anc, rng, 0.03, 0.002)

@@ -190,7 +190,7 @@ def test_chain_alignments_job_function(monkeypatch, inprocess, secondary):
     added, split by query contig (threshold lowered so the split path runs), per-contig jobs, merged output."""
     import xml.etree.ElementTree as ET
     from cactus_amd.paf import local_alignment as la
-    from cactus_amd.shared.localjob import LocalJob
+    from localjob import LocalJob
     monkeypatch.setenv("MIBLAST_INPROCESS", inprocess)
     params = ET.parse(os.path.join(ROOT, "cactus_amd", "blast_config.xml")).getroot()
     blast = params.find("blast")
