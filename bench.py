@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- blast-phase throughput of the MI355X-native lastz replacement.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): one 1 Mb x 1 Mb synthetic chunk pair
-per GPU (ancestor + mutated copy: 15 % substitutions, 1 % indels, one inversion, one replaced
-segment, 20 % soft-masked, two N runs), lastz "default" parameter set of
-cactus_progressive_config.xml:136.  A step = one full blast job (index build, seed search both
-strands, ungapped extension, gapped Y-drop extension, PAF) with both sequence sets already
-resident in HBM.  N>1: one process per GPU, each with its own copy of the chunk pair (weak scaling with the
-per-GPU work held exactly constant, no data-path collective); the only exchange is the gather of the final PAF bytes to rank 0 over RCCL,
-inside the timed region.
+Workload of the headline line (BASELINE.json configs[2], SURVEY.md 8d "Config 3"): the blast phase of a whole progressive run
+over the evolverMammals guide tree (/root/reference/examples/evolverMammals.txt:1) on a synthetic stand-in for its five genomes
+(the FASTA files are URLs; 600 kb ancestor, seed 2001, cactus_amd/gen.py): per internal node (mr, Anc1, Anc2, Anc0) one lastz call
+per ingroup pair and, per ingroup, a chain of calls to the <= 3 nearest outgroups with the still-unaligned sequence only
+(/root/reference/src/cactus/paf/local_alignment.py:806-835, 421-526) -- 20 lastz calls of ~0.6 Mb x <= 0.6 Mb,
+each with the option set its phylogenetic distance selects (cactus_progressive_config.xml:10-13,130-137).  A step = that whole
+phase once, with the genomes already resident in HBM: the calls of one dependency level that share an option set go through ONE
+miblast_align_pairs call (they are independent Toil jobs in the reference); trimmed sub-sequences are products of the step and are
+uploaded inside it.  `--workload pair` is the bring-up configuration configs[1] (one 1 Mb x 1 Mb pair per GPU).
 
-Prints ONE JSON line on rank 0.  metric value = dp_cells (the oracle-defined counter: cells of
-committed anchors only, speculative work NOT counted) per second, whole job.
+N > 1: one process per GPU (`--gpus N` spawns them when not started under torchrun), each running the same phase on its own
+copy of the data (weak scaling, per-GPU work held constant, no data-path collective); the only exchange is the gather of the
+final PAF bytes to rank 0 over RCCL, inside the timed region.
+
+Prints ONE JSON line on rank 0.  value = dp_cells (the oracle-defined counter: cells of committed anchors only, speculative
+work NOT counted) per second of whole-job wall time.  cpu_baseline runs the CPU oracle on the same calls and reports whether
+every call's PAF bytes are equal (`same_bytes`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,104 +34,226 @@ sys.path.insert(0, ROOT)
 
 DEFAULT_ARGS = "--step=1 --ambiguous=iupac,100,100 --ydrop=4000 --hspthresh=2200 --gappedthresh=2400 --queryhspbest=100000"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+TRACE_BYTES_PER_CELL = 0.5     # SURVEY 8d "Gapped: write 0.5*C (4-bit traceback)": the algorithmic figure roofline.achieved is computed from
+TRACE_BYTES_WRITTEN = 1.0      # what the DP kernels write per evaluated cell today (one byte holding a 4-bit code)
+PER_PAIR = ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_sides", "dp_cells", "dp_rows", "alignments",
+            "t_index", "t_seed", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms")
+PER_BATCH = ("t_gapped", "gapped_rounds", "dp_sides_run", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms", "dp_kernel_launches",
+             "relay_accepted", "relay_rejected", "t_traceback_ms", "t_merge_ms", "dp_reruns")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=1_000_000, help="bases per chunk (config 2: 1 Mb)")
+    ap.add_argument("--workload", choices=("evolver", "pair"), default="evolver",
+                    help="evolver: BASELINE configs[2] stand-in (default); pair: configs[1], one synthetic chunk pair per GPU")
+    ap.add_argument("--ancestor", type=int, default=600_000, help="ancestor length of the evolverMammals stand-in (SURVEY 8d config 3: 600 kb)")
+    ap.add_argument("--size", type=int, default=1_000_000, help="bases per chunk of the pair workload / pair leg (config 2: 1 Mb)")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--random-pair", action="store_true", help="pure-random pair (seed/ungapped isolation)")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="chunk size for the CPU-oracle baseline leg (0 = skip); repeated until ~10 s of CPU work")
+    ap.add_argument("--random-pair", action="store_true", help="pair workload: pure-random pair (seed/ungapped isolation)")
+    ap.add_argument("--cpu-sample", type=int, default=1, help="0 = skip the CPU-oracle baseline leg")
     ap.add_argument("--chain-leg", type=int, default=400,
                     help="syntenic series in the synthetic PAF of the chaining-stage leg (0 = skip); reported under chain_stage, never in value")
-    ap.add_argument("--lastz-args", default=DEFAULT_ARGS)
-    ap.add_argument("--pairs-per-gpu", type=int, default=1,
-                    help="chunk pairs per GPU per step, aligned in ONE batched call (merged gapped launches).  The default 1 is "
-                         "BASELINE.json configs[1]; larger values are the many-pairs regime of configs[2..4]")
+    ap.add_argument("--lastz-args", default=DEFAULT_ARGS, help="option set of the pair workload")
+    ap.add_argument("--pairs-per-gpu", type=int, default=1, help="pair workload: chunk pairs per GPU per step, aligned in ONE batched call")
+    ap.add_argument("--pair-leg", type=int, default=1, help="evolver workload: also time the 1 Mb x 1 Mb pair of configs[1] (0 = skip); reported under pair_1mb")
     ap.add_argument("--seed-leg", type=int, default=8_000_000,
                     help="chunk size of the extra seed-stage leg on a pure-random pair (0 = skip); reported under seed_stage, never in value")
-    a = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (one process per GPU, the launch contract's env
+    variables), stream rank 0's line through, fail if any rank does."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def add_stats(agg, stats_list):
+    """counters of one batched call: per-pair counters add up, launch-level figures (shared by the pairs in flight) count once"""
+    for k in PER_PAIR:
+        agg[k] = agg.get(k, 0) + sum(s[k] for s in stats_list)
+    for k in PER_BATCH:
+        agg[k] = agg.get(k, 0) + stats_list[0][k]
+
+
+class EvolverPhase:
+    """BASELINE configs[2] stand-in on one GPU (see the module docstring)."""
+
+    def __init__(self, a, ctx, rank):
+        from cactus_amd import blast_phase as bp, gen, miblast
+        from cactus_amd.paf.local_alignment import select_lastz_params
+        from cactus_amd.shared.configWrapper import load_config
+        self.bp, self.miblast, self.ctx = bp, miblast, ctx
+        cfg = load_config()
+        self.options = lambda d: select_lastz_params(d, cfg, 0)
+        blast = cfg.find("blast")
+        self.trim = (int(blast.attrib["trimMinSize"]), int(blast.attrib["trimFlanking"]))
+        max_div = float(cfg.find("constants").find("divergences").attrib["five"])
+        self.calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE), max_div=max_div, max_outgroups=3)
+        genomes = gen.make_tree_genomes(a.ancestor, 2001, ancestors=True)
+        # every rank runs the same phase (weak scaling with per-GPU work held exactly constant); only the names differ
+        self.fasta = {k: gen.fasta_bytes([("id=%s|%s_r%d" % (k, k, rank), v)]) for k, v in genomes.items()}
+        self.resident = {fa: ctx.seqset_from_fasta_bytes(fa) for fa in self.fasta.values()}      # genomes resident in HBM before the timed region
+        self.params = {}
+        self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
+                         f"examples/evolverMammals.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 2001), ingroup trimming between outgroups, "
+                         "option set per call by distance (1 x \"four\", rest \"default\")")
+
+    def step(self, keep=None):
+        agg = {}
+        made = []
+
+        def align_batch(pairs, opts):
+            pm = self.params.get(opts)
+            if pm is None:
+                pm = self.params[opts] = self.miblast.params_from_args(opts.split())
+            sets = []
+            for tf, qf in pairs:
+                s = []
+                for fa in (tf, qf):
+                    h = self.resident.get(fa)
+                    if h is None:
+                        h = self.ctx.seqset_from_fasta_bytes(fa)
+                        made.append(h)
+                    s.append(h)
+                sets.append(tuple(s))
+            rs = self.ctx.align_pairs(sets, pm)
+            add_stats(agg, [r.stats for r in rs])
+            return [r.paf for r in rs]
+
+        res = self.bp.run_blast_phase(self.fasta, self.calls, self.options, align_batch, *self.trim,
+                                      on_call=(lambda c, tf, qf, paf: keep.append((tf, qf, self.options(c.distance), paf))) if keep is not None else None)
+        for h in made:
+            h.close()
+        paf = b"".join(v["ingroup"] + v["outgroup"] for v in res.values())
+        return agg, paf
+
+
+class PairWorkload:
+    """BASELINE configs[1]: P synthetic chunk pairs per GPU (SURVEY 8d config 2 recipe), one batched call per step."""
+
+    def __init__(self, a, ctx, rank):
+        from cactus_amd import gen, miblast
+        self.ctx = ctx
+        self.pm = miblast.params_from_args(a.lastz_args.split())
+        self.sets, self.fasta = [], []
+        for k in range(max(1, a.pairs_per_gpu)):
+            t, q = gen.make_pair(a.size, a.seed + k, homologous=not a.random_pair)
+            tf, qf = gen.fasta_bytes([(f"id=simT{rank}_{k}|chr1", t)]), gen.fasta_bytes([(f"id=simQ{rank}_{k}|chr1", q)])
+            self.fasta.append((tf, qf))
+            self.sets.append((ctx.seqset_from_fasta_bytes(tf), ctx.seqset_from_fasta_bytes(qf)))
+        self.args = a.lastz_args
+        self.describe = (f"{len(self.sets)} x ({a.size} x {a.size}) synthetic chunk pair(s) per GPU (BASELINE configs[1], SURVEY 8d config 2"
+                         f"{', pure-random variant' if a.random_pair else ''}), seed {a.seed}+pair index, identical on every rank")
+
+    def step(self, keep=None):
+        agg = {}
+        rs = self.ctx.align_pairs(self.sets, self.pm) if len(self.sets) > 1 else [self.ctx.align(*self.sets[0], self.pm, details=False)]
+        add_stats(agg, [r.stats for r in rs])
+        if keep is not None:
+            keep.extend((tf, qf, self.args, r.paf) for (tf, qf), r in zip(self.fasta, rs))
+        return agg, b"".join(r.paf for r in rs)
+
+
+def timed_steps(work, steps, warmup, sync, gather):
+    for _ in range(warmup):
+        gather(work.step()[1])
+    sync()
+    t0 = time.perf_counter()
+    tot, keep = {}, None
+    for k in range(steps):
+        keep = [] if k == steps - 1 else None          # the calls of the last timed step are kept for the byte diff with the oracle
+        agg, paf = work.step(keep)
+        gather(paf)
+        for key, v in agg.items():
+            tot[key] = tot.get(key, 0) + v
+    sync()
+    return time.perf_counter() - t0, tot, keep
+
+
+def dp_roofline(tot, profile_name):
+    """Dominant kernel (k_ydrop2) against both roofs.  HBM: algorithmic bytes per launch = SURVEY 8d's 0.5 B per evaluated cell
+    (4-bit trace codes) + 16 B row record + ~2 sequence bytes per row, / the average launch duration measured with HIP events
+    on the library's own stream.  bytes_per_cell_written is what the kernel stores per cell; traffic is the PMC figure."""
+    launches = max(1.0, tot["dp_kernel_launches"])
+    cells, rows = tot["dp_cells_run"] / launches, tot["dp_rows_run"] / launches
+    dp_ms = tot["t_dp_kernel_ms"] / launches
+    algo = cells * TRACE_BYTES_PER_CELL + rows * 18.0
+    achieved = algo / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+    traffic, note = None, "no committed PMC summary for this workload"
+    path = os.path.join(ROOT, "profiles", profile_name)
+    if os.path.exists(path):
+        ks = json.load(open(path))["kernels"]
+        dp = [v for name, v in ks.items() if "k_ydrop" in name]
+        calls = sum(v["calls"] for v in dp)
+        if calls:
+            pmc = sum(v["calls"] * (v["fetch_bytes_corrected_per_call"] + v["write_size_bytes_per_call"]) for v in dp) / calls
+            traffic = pmc / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None
+            note = ("PMC bytes per DP launch (corrected FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/%s: %.1f MB averaged over the %d "
+                    "launches profiled) / this run's average launch duration" % (profile_name, pmc / 1e6, calls))
+    return {"bound": "hbm", "kernel": "k_ydrop2 (one-sided Y-drop DP, one wave per piece; k_ydrop1 / k_ydrop for wider windows)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo, "bytes_per_cell": TRACE_BYTES_PER_CELL, "bytes_per_cell_written": TRACE_BYTES_WRITTEN, "cells_per_launch": cells, "rows_per_launch": rows,
+            "launch_ms": dp_ms, "traffic_note": note,
+            "note": "the DP is bound by instruction issue and latency per row, not by HBM (SURVEY 8d caveat): see roofline.valu for its meaningful ceiling"}
+
+
+def run_rank(a):
     import torch
-    from cactus_amd import gen, miblast
+    from cactus_amd import miblast
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MIBLAST_BENCH_SINGLE_DEVICE"):      # test hook: several ranks on one GPU (use with MIBLAST_BENCH_BACKEND=gloo)
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}, or without a launcher")
     dist = None
     coll_backend = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        coll_backend = os.environ.get("MIBLAST_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
-        dist.init_process_group(backend=coll_backend, device_id=torch.device("cuda", local_rank) if coll_backend == "nccl" else None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libmiblast has no CPU path")
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        coll_backend = os.environ.get("MIBLAST_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=coll_backend, device_id=torch.device("cuda", local_rank) if coll_backend == "nccl" else None)
 
-    pm = miblast.params_from_args(a.lastz_args.split())
-    from cactus_amd.multigpu import share_host_cores
+    from cactus_amd.multigpu import gather_bytes, share_host_cores
     host_threads = share_host_cores(int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else miblast.set_host_threads(0)
     ctx = miblast.Context(local_rank)
-    # each rank aligns its own chunk pair (chunk-pair sharding)
-    P = max(1, a.pairs_per_gpu)
-    sets = []
-    for k in range(P):
-        # weak scaling with per-GPU work held exactly constant: every rank gets the same P chunk pairs (same seeds), only
-        # the sequence names differ; different seeds would turn the max-over-ranks time into a lottery over the longest DP
-        t, q = gen.make_pair(a.size, a.seed + k, homologous=not a.random_pair)
-        sets.append((ctx.seqset_from_fasta_bytes(gen.fasta_bytes([(f"id=simT{rank}_{k}|chr1", t)])),
-                     ctx.seqset_from_fasta_bytes(gen.fasta_bytes([(f"id=simQ{rank}_{k}|chr1", q)]))))
-    T, Q = sets[0]
-
-    from cactus_amd.multigpu import gather_bytes
     coll_dev = torch.device("cuda", local_rank) if coll_backend != "gloo" else torch.device("cpu")
+    work = EvolverPhase(a, ctx, rank) if a.workload == "evolver" else PairWorkload(a, ctx, rank)
+    gathered = {}
 
-    def gather_paf(paf: bytes):
+    def gather(paf: bytes):
         """final hit list -> rank 0 (RCCL over xGMI)"""
-        return gather_bytes(paf, dist, rank, world, coll_dev)
+        gathered["last"] = gather_bytes(paf, dist, rank, world, coll_dev)
 
-    def step():
-        if P == 1:
-            r = ctx.align(T, Q, pm, details=False)
-            pafs = gather_paf(r.paf)
-            return r, pafs
-        rs = ctx.align_pairs(sets, pm)
-        pafs = gather_paf(b"".join(x.paf for x in rs))
-        # per-pair counters add up; launch-level figures (shared by the pairs in flight) are taken once
-        shared = ("t_gapped", "gapped_rounds", "dp_sides_run", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms", "dp_kernel_launches",
-                  "relay_accepted", "relay_rejected", "t_traceback_ms", "t_merge_ms")
-        merged = {k: (rs[0].stats[k] if k in shared else sum(x.stats[k] for x in rs)) for k in rs[0].stats}
-        rs[0].stats.update(merged)
-        return rs[0], pafs
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
 
-    for _ in range(a.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    agg = None
-    for _ in range(a.steps):
-        r, pafs = step()
-        if agg is None:
-            agg = {k: 0 for k in r.stats}
-        for k, v in r.stats.items():
-            agg[k] += v
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    keys = ["dp_cells", "seed_hits", "seed_lookups", "ungapped_cols", "alignments", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms",
-            "dp_kernel_launches", "t_index", "t_seed", "t_gapped", "t_total", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms",
-            "relay_accepted", "relay_rejected", "t_traceback_ms", "t_merge_ms", "dp_sides_run"]
-    vec = torch.tensor([float(agg[k]) for k in keys] + [elapsed], dtype=torch.float64, device=coll_dev)
+    elapsed, tot, keep = timed_steps(work, a.steps, a.warmup, sync, gather)
+    keys = sorted(tot)
+    vec = torch.tensor([float(tot[k]) for k in keys] + [elapsed], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         tmax = vec[-1:].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -132,28 +262,7 @@ def main():
     tot = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
 
     if rank == 0:
-        launches = max(1.0, tot["dp_kernel_launches"])
-        cells_per_launch = tot["dp_cells_run"] / launches
-        rows_per_launch = tot["dp_rows_run"] / launches
-        # Algorithmic HBM bytes of one k_ydrop launch (SURVEY 8d "Gapped"): one trace byte
-        # written per evaluated cell + one 16-byte {offset, LY} record per row + ~2 sequence bytes read per row
-        # (one query base, ~one new target column).  The launch duration is measured inside libmiblast with HIP
-        # events on its own stream.
-        algo_bytes = cells_per_launch * 1.0 + rows_per_launch * (16.0 + 2.0)
-        dp_ms = tot["t_dp_kernel_ms"] / launches
-        achieved = algo_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
-        traffic, traffic_note = None, "no committed PMC summary"
-        pmc_path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
-        if os.path.exists(pmc_path) and not a.random_pair and a.size == 1_000_000 and a.lastz_args == DEFAULT_ARGS:
-            ks = json.load(open(pmc_path))["kernels"]
-            dp = [v for name, v in ks.items() if "k_ydrop" in name]         # every DP kernel variant (one wave / four waves per piece)
-            calls = sum(v["calls"] for v in dp)
-            if calls:
-                pmc_bytes = sum(v["calls"] * (v["fetch_bytes_corrected_per_call"] + v["write_size_bytes_per_call"]) for v in dp) / calls
-                traffic = pmc_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None
-                traffic_note = ("PMC bytes per DP launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, "
-                                "profiles/r01_hbm_traffic_pmc.json: %.1f MB averaged over the %d launches profiled) / this run's average launch duration"
-                                % (pmc_bytes / 1e6, calls))
+        per = a.steps * world
         out = {
             "metric": "gapped X-drop Gcell/s (blast phase, whole job)",
             "value": tot["dp_cells"] / elapsed / 1e9,
@@ -162,28 +271,22 @@ def main():
             "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{a.size} x {a.size} synthetic chunk pair per GPU (SURVEY 8d config 2"
-                                   f"{', pure-random variant' if a.random_pair else ''}), seed {a.seed}+pair index, identical on every rank",
-                       "lastz_args": a.lastz_args, "chunk_pairs": world * P, "pairs_per_gpu": P,
-                       "sharding": "chunk pairs sharded over GPUs (batched per GPU when pairs_per_gpu > 1), gather of PAF to rank 0",
-                       "collective_backend": coll_backend, "host_threads_per_rank": host_threads},
+            "config": {"workload": work.describe, "sharding": "every GPU runs its own copy of the phase (chunk pairs are independent jobs); gather of the PAF to rank 0",
+                       "collective_backend": coll_backend, "host_threads_per_rank": host_threads,
+                       "paf_bytes_gathered_per_step": sum(len(x) for x in gathered["last"]) if gathered.get("last") else 0},
             "seeds_per_s": tot["seed_hits"] / elapsed,
             "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
-            "stage_seconds_per_step": {k: tot[k] / a.steps / world for k in ("t_index", "t_seed", "t_gapped", "t_total")},
-            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / a.steps / world, "ungapped": tot["t_ungapped_kernel_ms"] / a.steps / world,
-                                         "sort": tot["t_sort_ms"] / a.steps / world, "seed_fill": tot["t_seedfill_ms"] / a.steps / world},
+            "dp_cells_per_step": tot["dp_cells"] / per, "seed_hits_per_step": tot["seed_hits"] / per, "alignments_per_step": tot["alignments"] / per,
+            "stage_seconds_per_step": {k: tot[k] / per for k in ("t_index", "t_seed", "t_gapped")},
+            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / per, "ungapped": tot["t_ungapped_kernel_ms"] / per,
+                                         "sort": tot["t_sort_ms"] / per, "seed_fill": tot["t_seedfill_ms"] / per},
             "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3 / world) / 1e9,
             "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
-            "alignments_per_step": tot["alignments"] / a.steps,
-            "relay": {"pieces_per_step": tot["dp_sides_run"] / a.steps / world, "handovers_accepted_per_step": tot["relay_accepted"] / a.steps / world,
-                      "handovers_rejected_per_step": tot["relay_rejected"] / a.steps / world,
-                      "traceback_ms_per_step": tot["t_traceback_ms"] / a.steps / world, "merge_ms_per_step": tot["t_merge_ms"] / a.steps / world,
-                      "note": "long one-sided DPs run as concurrently evaluated pieces with verified hand-overs (DESIGN.md section 5)"},
-            "roofline": {"bound": "hbm", "kernel": "k_ydrop2 (one-sided Y-drop DP, one wave per piece; k_ydrop1 / k_ydrop for wider windows)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": dp_ms, "launches_per_step": launches / a.steps / world,
-                         "traffic_note": traffic_note,
-                         "note": "a launch is bound by latency per row (~2100 clocks for a lone wave, ~3500 with thousands resident) and instruction issue, not HBM; the roofline fraction rises with the number of pieces in flight (SURVEY 8d caveat, DESIGN.md section 5)"},
+            "relay": {"pieces_per_step": tot["dp_sides_run"] / per, "dp_launches_per_step": tot["dp_kernel_launches"] / per,
+                      "handovers_accepted_per_step": tot["relay_accepted"] / per, "handovers_rejected_per_step": tot["relay_rejected"] / per,
+                      "reruns_per_step": tot["dp_reruns"] / per,
+                      "traceback_ms_per_step": tot["t_traceback_ms"] / per, "merge_ms_per_step": tot["t_merge_ms"] / per},
+            "roofline": dp_roofline(tot, "r02_hbm_traffic_pmc.json" if a.workload == "evolver" else "r02_pair_hbm_traffic_pmc.json"),
         }
         try:
             # the DP is VALU / issue bound, so its cells/s are also put against the int32 VALU peak: evaluated cells
@@ -192,32 +295,55 @@ def main():
             prop = torch.cuda.get_device_properties(local_rank)
             clock_hz = float(getattr(prop, "clock_rate", 2_400_000)) * 1e3
             peak_ops = prop.multi_processor_count * 4 * 16 * clock_hz
-            cells_per_s = tot["dp_cells_run"] / max(1e-12, tot["t_dp_kernel_ms"] * 1e-3)
-            out["roofline"]["valu"] = {"cells_evaluated_per_s": cells_per_s, "min_int_ops_per_cell": 10, "peak_lane_ops_per_s": peak_ops,
-                                       "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9,
-                                       "note": "k_ydrop2 issues ~330 wave instructions per DP row of up to 256 column slots (scans, pruning, trace codes, window bookkeeping included); "
-                                               "with 2-3 resident waves per SIMD a row takes ~3500 clocks, i.e. the SIMDs that hold pieces issue close to one instruction per 4 clocks"}
+            cells_per_s = tot["dp_cells_run"] / max(1e-12, tot["t_dp_kernel_ms"] * 1e-3 / world)
+            out["roofline"]["valu"] = {"cells_evaluated_per_s_per_gpu": cells_per_s, "min_int_ops_per_cell": 10, "peak_lane_ops_per_s": peak_ops,
+                                       "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9}
         except Exception as e:                               # noqa: BLE001  (never lose the line over a device-property quirk)
             out["roofline"]["valu"] = {"error": str(e)}
+        if a.workload == "evolver" and a.pair_leg > 0:
+            out["pair_1mb"] = pair_leg(a, ctx)
         if a.seed_leg > 0 and not a.random_pair:
-            out["seed_stage"] = seed_stage_leg(a, pm, ctx)
+            out["seed_stage"] = seed_stage_leg(a, ctx)
         if a.chain_leg > 0:
             out["chain_stage"] = chain_stage_leg(a, ctx)
         if a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(a, pm)
+            out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / per, work.describe)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def seed_stage_leg(a, pm, ctx):
-    """seeds/s where it means something: the benchmark pair is dominated by a few long gapped extensions, so the seed
-    half of BASELINE.json's metric is measured on the pure-random variant of the recipe (SURVEY 8d "pure-random pair ...
-    to isolate seed/ungapped throughput"), large enough not to be launch bound.  One untimed + one timed job."""
-    from cactus_amd import gen
+def pair_leg(a, ctx):
+    """BASELINE configs[1], the bring-up configuration and round 1's headline: one 1 Mb x 1 Mb pair, one call per step; diffed
+    against the oracle (1.6 s)."""
+    import types
+    b = types.SimpleNamespace(size=a.size, seed=a.seed, random_pair=False, lastz_args=DEFAULT_ARGS, pairs_per_gpu=1)
+    w = PairWorkload(b, ctx, 0)
+    elapsed, tot, keep = timed_steps(w, a.steps, a.warmup, lambda: None, lambda paf: None)
+    r = dp_roofline(tot, "r02_pair_hbm_traffic_pmc.json")
+    out = {"workload": w.describe, "ms_per_step": 1e3 * elapsed / a.steps, "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
+           "seeds_per_s": tot["seed_hits"] / elapsed, "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
+           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3) / 1e9,
+           "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / a.steps, "ungapped": tot["t_ungapped_kernel_ms"] / a.steps,
+                                        "sort": tot["t_sort_ms"] / a.steps, "seed_fill": tot["t_seedfill_ms"] / a.steps},
+           "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "launch_ms", "cells_per_launch")}}
+    if a.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / a.steps, w.describe)
+    for t, q in w.sets:
+        t.close(); q.close()
+    return out
+
+
+def seed_stage_leg(a, ctx):
+    """seeds/s where it means something: the headline workloads are dominated by long gapped extensions, so the seed half of
+    BASELINE.json's metric is measured on the pure-random variant of the config-2 recipe (SURVEY 8d "pure-random pair ... to
+    isolate seed/ungapped throughput"), large enough not to be launch bound.  One untimed + one timed job.  The algorithmic
+    bytes are exactly SURVEY 8d's list (no sort term, packed sequences)."""
+    from cactus_amd import gen, miblast
     import numpy as np
     n = a.seed_leg
+    pm = miblast.params_from_args(DEFAULT_ARGS.split())
     rng = np.random.default_rng(43)
     t, q = gen.random_sequence(n, rng), gen.random_sequence(n, rng)
     T = ctx.seqset_from_fasta_bytes(gen.fasta_bytes([("id=randT|chr1", t)]))
@@ -228,22 +354,23 @@ def seed_stage_leg(a, pm, ctx):
     dt = time.perf_counter() - t0
     s = r.stats
     T.close(); Q.close()
-    hits, look = s["seed_hits"], s["seed_lookups"]
-    # algorithmic HBM bytes of the seed stage: index build 1*T + 4*T + 2*64 MiB; search 1*Q*S + 8 B per lookup
-    # + 4 B per hit read, 8 B per hit written; sort ~ 6 passes x 16 B per hit; ungapped 8 B per hit + 2 B per column
-    algo = (5.0 * n + 2 * 64 * 2**20) + (2.0 * n + 8.0 * look + 12.0 * hits) + 96.0 * hits + (8.0 * hits + 2.0 * s["ungapped_cols"])
-    return {"workload": f"{n} x {n} pure-random pair, seed 43, same lastz options", "seeds_per_s": hits / dt, "seed_lookups_per_s": look / dt,
+    hits, look, cols = s["seed_hits"], s["seed_lookups"], s["ungapped_cols"]
+    # SURVEY 8d, read + write terms: index build 1*T + 0.375*T + 0.375*T + 4*(T/step) + 2*64 MiB; seed search 0.375*Q*S + 8 B per
+    # lookup + 4 B per hit read, 8 B per hit written; ungapped 8 B per hit + 2 * 0.25 B per column, 24 B per HSP written
+    algo = (1.75 * n + 4.0 * n + 2 * 64 * 2**20) + (0.375 * n * 2 + 8.0 * look + 12.0 * hits) + (8.0 * hits + 0.5 * cols + 24.0 * s["hsps"])
+    t_stage = max(1e-9, s["t_seed"] + s["t_index"])
+    return {"workload": f"{n} x {n} pure-random pair, seed 43, lastz default option set", "seeds_per_s": hits / dt, "seed_lookups_per_s": look / dt,
             "seconds": dt, "seed_hits": hits, "t_seed_s": s["t_seed"], "t_index_s": s["t_index"],
             "kernel_ms": {"ungapped": s["t_ungapped_kernel_ms"], "sort": s["t_sort_ms"], "seed_fill": s["t_seedfill_ms"]},
-            "algorithmic_GBps": algo / max(1e-9, s["t_seed"] + s["t_index"]) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
-            "chance_alignments": s["alignments"], "gapped_gcells_per_s_kernel": s["dp_cells_run"] / max(1e-9, s["t_dp_kernel_ms"] * 1e-3) / 1e9}
+            "algorithmic_bytes": algo, "algorithmic_GBps": algo / t_stage / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS, "frac": algo / t_stage / 1e9 / HBM_PEAK_GBS,
+            "bytes_note": "SURVEY 8d terms only: no sort passes, 0.375 B/base packed sequences, 0.5 B per ungapped column",
+            "chance_alignments": s["alignments"]}
 
 
 def chain_stage_leg(a, ctx):
     """The step after the blast phase (local_alignment.py:660-727): one chain | tile | trim | filter | chain |
     filter job on a synthetic PAF (both orientations, as chain_alignments feeds it), text in and text out, with the HIP-event
     times of its kernels; beside it the oracle's six piped processes on the same text (1 core each, as paffy runs)."""
-    import subprocess
     from cactus_amd import gen, mipaf
     text = gen.random_paf(1234, n_series=a.chain_leg, per_series=(20, 60), n_q=2, n_t=2, contig_len=20_000_000, noise=10 * a.chain_leg, ragged=False)
     text += mipaf.PafSet.from_text(text).invert().text()
@@ -282,29 +409,34 @@ def chain_stage_leg(a, ctx):
                              "sample": "the same text through the oracle's six piped processes", "same_bytes": p.returncode == 0 and p.stdout.decode() == out}}
 
 
-def cpu_baseline(a, pm):
-    """CPU oracle (kind "port": the in-repo C restatement, 1 thread like a lastz job) on a bounded
-    sample of the same recipe, timed on this box's host cores."""
-    from cactus_amd import gen
+def cpu_baseline(kept_calls, dp_cells_gpu, describe):
+    """CPU oracle (kind "port": the in-repo C restatement, 1 thread like a lastz job) on the lastz calls of the last timed step --
+    the same FASTA bytes and option strings, call by call -- timed on this box's host cores, every PAF compared with the GPU's."""
+    from cactus_amd import miblast
     from oracle import olz
-    n = min(a.size, a.cpu_sample)
-    t, q = gen.make_pair(n, a.seed, homologous=not a.random_pair)
-    tf, qf = gen.fasta_bytes([("id=simT|chr1", t)]), gen.fasta_bytes([("id=simQ|chr1", q)])
-    po = olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_})
     cells = hits = 0
-    reps = 0
+    same = True
+    n_diff = 0
     t0 = time.perf_counter()
-    while True:
-        o = olz.align(tf, qf, po, details=False)
-        c = o["counters"]
-        cells += c["dp_cells"]; hits += c["seed_hits"]; reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= 10.0 or reps >= 8:
-            break
+    for tf, qf, opts, paf in kept_calls:
+        pm = miblast.params_from_args(opts.split())
+        o = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}), details=False)
+        cells += o["counters"]["dp_cells"]; hits += o["counters"]["seed_hits"]
+        if o["paf"] != paf:
+            same = False
+            n_diff += 1
+    dt = time.perf_counter() - t0
     return {"value": cells / dt / 1e9, "unit": "Gcell/s", "cores": 1, "kind": "port",
-            "sample": f"{n} x {n} pair of the same recipe, seed {a.seed}, whole job {reps} times in {dt:.1f} s",
-            "seeds_per_s": hits / dt, "seconds": dt, "seconds_per_job": dt / reps,
-            "stage_seconds": {k: c[k] for k in ("t_index", "t_seed", "t_gapped", "t_total")}}
+            "sample": f"all {len(kept_calls)} lastz calls of one step of: {describe} ({dt:.1f} s of CPU work, one after the other on one core)",
+            "seeds_per_s": hits / dt, "seconds": dt, "calls": len(kept_calls),
+            "same_bytes": same, "calls_differing": n_diff, "same_dp_cells": int(cells) == int(round(dp_cells_gpu))}
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+    run_rank(a)
 
 
 if __name__ == "__main__":

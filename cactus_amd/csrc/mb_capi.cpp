@@ -138,23 +138,39 @@ int miblast_set_host_threads(int n) {
     });
 }
 
-int miblast_device_count(void) {
+// $MIBLAST_DEVICE_MAP = "0,0,1": logical device k is HIP ordinal map[k] (several logical devices may share a GPU)
+static std::vector<int> device_map() {
+    std::vector<int> m;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return n;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    const char *e = getenv("MIBLAST_DEVICE_MAP");
+    if (e && *e) {
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (v >= 0 && v < n) m.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+        return m;
+    }
+    for (int d = 0; d < n; d++) m.push_back(d);
+    return m;
 }
+
+int miblast_device_count(void) { return (int)device_map().size(); }
 
 int miblast_ctx_create(int device, miblast_ctx **out) {
     if (!out) return MIBLAST_EINVAL;
     *out = nullptr;
     return guarded([&]() -> int {
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-            (void)hipGetLastError();
+        const std::vector<int> map = device_map();
+        if (map.empty()) {
             mb::set_error("no HIP device visible: libmiblast has no CPU path");
             return MIBLAST_ENODEV;
         }
-        if (device < 0 || device >= n) { mb::set_error("device ordinal out of range"); return MIBLAST_ENODEV; }
+        if (device < 0 || device >= (int)map.size()) { mb::set_error("device ordinal out of range"); return MIBLAST_ENODEV; }
+        device = map[(size_t)device];
         hipDeviceProp_t prop;
         MB_HIP(hipGetDeviceProperties(&prop, device));
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("MIBLAST_ALLOW_ANY_ARCH")) {
@@ -199,10 +215,8 @@ int miblast_seqset_from_fasta_mem(miblast_ctx *ctx, const char *buf, size_t len,
     });
 }
 
-int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_seqset **out) {
-    if (!ctx || !out || !path) return MIBLAST_EINVAL;
-    *out = nullptr;
-    // accept lastz's trailing [actions] on the file name (local_alignment.py:60-62)
+// a FASTA file as lastz is handed it: trailing [actions] on the name are accepted (local_alignment.py:60-62)
+static int read_fasta_file(const char *path, std::string &data) {
     std::string file(path);
     size_t br = file.find('[');
     bool unmask = false;
@@ -210,9 +224,16 @@ int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_s
         unmask = file.find("unmask", br) != std::string::npos;     // [unmask] / [multiple,unmask] (cactus_lastzRepeatMask.py:88)
         file.resize(br);
     }
-    std::ifstream f(file, std::ios::binary);
+    FILE *f = fopen(file.c_str(), "rb");
     if (!f) { mb::set_error("cannot open " + file); return MIBLAST_EIO; }
-    std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    data.clear();
+    if (fseeko(f, 0, SEEK_END) == 0) { const off_t sz = ftello(f); if (sz > 0) data.reserve((size_t)sz); }
+    rewind(f);
+    std::vector<char> buf(1 << 22);
+    for (size_t n; (n = fread(buf.data(), 1, buf.size(), f)) > 0;) data.append(buf.data(), n);
+    const bool bad = ferror(f) != 0;
+    fclose(f);
+    if (bad) { mb::set_error("cannot read " + file); return MIBLAST_EIO; }
     if (unmask) {                                                    // lastz [unmask]: soft-masking is removed on load
         bool header = false;
         for (char &c : data) {
@@ -221,7 +242,27 @@ int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_s
             else if (!header && c >= 'a' && c <= 'z') c = (char)(c - 32);
         }
     }
-    return miblast_seqset_from_fasta_mem(ctx, data.data(), data.size(), out);
+    return MIBLAST_OK;
+}
+
+static int write_all(int fd, const char *p, size_t len) {
+    size_t done = 0;
+    while (done < len) {
+        ssize_t w = write(fd, p + done, len - done);
+        if (w <= 0) { mb::set_error("cannot write PAF output"); return MIBLAST_EIO; }
+        done += (size_t)w;
+    }
+    return MIBLAST_OK;
+}
+
+int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_seqset **out) {
+    if (!ctx || !out || !path) return MIBLAST_EINVAL;
+    *out = nullptr;
+    std::string data;
+    return guarded([&]() -> int {
+        int rc = read_fasta_file(path, data);
+        return rc != MIBLAST_OK ? rc : miblast_seqset_from_fasta_mem(ctx, data.data(), data.size(), out);
+    });
 }
 
 void miblast_seqset_free(miblast_seqset *s) {
@@ -297,28 +338,94 @@ const uint32_t *miblast_result_ops(const miblast_result *r, int64_t *n) {
     return r ? r->r.ops.data() : nullptr;
 }
 
+// both files parsed on the host, then the blocked path over the given contexts (mb_multi.cpp)
+static int align_files_over(const std::vector<mb::Ctx *> &ctxs, const char *target_fa, const char *query_fa, const miblast_params *p, int out_fd,
+                            miblast_stats *stats) {
+    return guarded([&]() -> int {
+        mb::SeqSet T, Q;
+        {
+            std::string data;
+            int rc = read_fasta_file(target_fa, data);
+            if (rc != MIBLAST_OK) return rc;
+            mb::parse_fasta(data.data(), data.size(), T);
+            rc = read_fasta_file(query_fa, data);
+            if (rc != MIBLAST_OK) return rc;
+            mb::parse_fasta(data.data(), data.size(), Q);
+        }
+        const mb::SeqSet *tp = &T, *qp = &Q;
+        std::string paf;
+        int rc = mb::align_blocked(ctxs, &tp, &qp, 1, *p, paf, stats);
+        return rc != MIBLAST_OK ? rc : write_all(out_fd, paf.data(), paf.size());
+    });
+}
+
 int miblast_align_files(miblast_ctx *ctx, const char *target_fa, const char *query_fa, const miblast_params *p, int out_fd,
                         miblast_stats *stats) {
     if (!ctx || !target_fa || !query_fa || !p) return MIBLAST_EINVAL;
-    miblast_seqset *t = nullptr, *q = nullptr;
-    miblast_result *r = nullptr;
-    int rc = miblast_seqset_from_fasta_file(ctx, target_fa, &t);
-    if (rc == MIBLAST_OK) rc = miblast_seqset_from_fasta_file(ctx, query_fa, &q);
-    if (rc == MIBLAST_OK) rc = miblast_align(ctx, t, q, p, &r);
-    if (rc == MIBLAST_OK) {
-        size_t len = 0, done = 0;
-        const char *paf = miblast_result_paf(r, &len);
-        while (done < len) {
-            ssize_t w = write(out_fd, paf + done, len - done);
-            if (w <= 0) { mb::set_error("cannot write PAF output"); rc = MIBLAST_EIO; break; }
-            done += (size_t)w;
-        }
-        if (stats) *stats = *miblast_result_stats(r);
+    return align_files_over(std::vector<mb::Ctx *>{&ctx->c}, target_fa, query_fa, p, out_fd, stats);
+}
+
+int miblast_multi_create(int num_gpu, miblast_multi **out) {
+    if (!out) return MIBLAST_EINVAL;
+    *out = nullptr;
+    const int n = miblast_device_count();
+    if (n <= 0) { mb::set_error("no HIP device visible: libmiblast has no CPU path"); return MIBLAST_ENODEV; }
+    if (num_gpu < 1 || num_gpu > n) { mb::set_error("num_gpu out of range: " + std::to_string(num_gpu) + " asked, " + std::to_string(n) + " visible"); return MIBLAST_ENODEV; }
+    miblast_multi *m = new (std::nothrow) miblast_multi();
+    if (!m) return MIBLAST_ELIMIT;
+    for (int d = 0; d < num_gpu; d++) {
+        miblast_ctx *c = nullptr;
+        const int rc = miblast_ctx_create(d, &c);
+        if (rc != MIBLAST_OK) { miblast_multi_destroy(m); return rc; }
+        m->ctxs.push_back(c);
     }
-    miblast_result_free(r);
-    miblast_seqset_free(q);
-    miblast_seqset_free(t);
-    return rc;
+    *out = m;
+    return MIBLAST_OK;
+}
+
+void miblast_multi_destroy(miblast_multi *m) {
+    if (!m) return;
+    for (miblast_ctx *c : m->ctxs) miblast_ctx_destroy(c);
+    delete m;
+}
+
+int miblast_multi_num_gpu(const miblast_multi *m) { return m ? (int)m->ctxs.size() : 0; }
+
+static std::vector<mb::Ctx *> ctx_list(miblast_multi *m) {
+    std::vector<mb::Ctx *> v;
+    for (miblast_ctx *c : m->ctxs) v.push_back(&c->c);
+    return v;
+}
+
+int miblast_multi_align_files(miblast_multi *m, const char *target_fa, const char *query_fa, const miblast_params *p, int out_fd,
+                              miblast_stats *stats) {
+    if (!m || m->ctxs.empty() || !target_fa || !query_fa || !p) return MIBLAST_EINVAL;
+    return align_files_over(ctx_list(m), target_fa, query_fa, p, out_fd, stats);
+}
+
+int miblast_multi_align_fasta_pairs(miblast_multi *m, const miblast_fasta_pair *pairs, size_t n_pairs, const miblast_params *p,
+                                    char **paf, size_t *paf_len, miblast_stats *stats) {
+    if (!m || m->ctxs.empty() || !pairs || n_pairs == 0 || !p || !paf || !paf_len) return MIBLAST_EINVAL;
+    *paf = nullptr; *paf_len = 0;
+    return guarded([&]() -> int {
+        std::vector<mb::SeqSet> T(n_pairs), Q(n_pairs);
+        std::vector<const mb::SeqSet *> tp(n_pairs), qp(n_pairs);
+        for (size_t k = 0; k < n_pairs; k++) {
+            if ((!pairs[k].target && pairs[k].target_len) || (!pairs[k].query && pairs[k].query_len)) return (int)MIBLAST_EINVAL;
+            mb::parse_fasta(pairs[k].target, pairs[k].target_len, T[k]);
+            mb::parse_fasta(pairs[k].query, pairs[k].query_len, Q[k]);
+            tp[k] = &T[k]; qp[k] = &Q[k];
+        }
+        std::string text;
+        const int rc = mb::align_blocked(ctx_list(m), tp.data(), qp.data(), n_pairs, *p, text, stats);
+        if (rc != MIBLAST_OK) return rc;
+        char *buf = (char *)malloc(text.size() + 1);
+        if (!buf) { mb::set_error("out of host memory"); return (int)MIBLAST_ELIMIT; }
+        memcpy(buf, text.data(), text.size());
+        buf[text.size()] = 0;
+        *paf = buf; *paf_len = text.size();
+        return MIBLAST_OK;
+    });
 }
 
 int miblast_build_index(miblast_ctx *ctx, const miblast_seqset *target, int32_t step, uint32_t **offsets, uint32_t **positions) {

@@ -107,11 +107,13 @@ struct SeqSet {
     std::vector<int64_t> starts, lens;
     int64_t total = 0;                        // concatenated length (one separator between contigs)
     std::vector<uint8_t> codes;               // [SEP] codes[0..total) [SEP]  -> codes.data()+1 is position 0
+    const uint8_t *view = nullptr;            // a block of another set (mb_multi.cpp): position 0 inside the parent's codes, nothing owned
+    int64_t origin = 0;                       // concatenated position of this set's position 0 in the file it is a block of (--step phase)
     int device = -1;
     uint8_t *d_buf = nullptr;                 // device copy of `codes`, kDevPad separator bytes on both sides
     int64_t *d_starts = nullptr;              // contig starts / lens on the device (revcomp kernel)
     int64_t *d_lens = nullptr;
-    const uint8_t *host() const { return codes.data() + 1; }
+    const uint8_t *host() const { return view ? view : codes.data() + 1; }
     const uint8_t *dev() const { return d_buf + kDevPad; }
     int contig_of(int64_t pos) const;
 };
@@ -132,9 +134,10 @@ struct HipFailure { hipError_t code; const char *what; const char *file; int lin
 // ---- kernel launch wrappers (mb_kernels.hip) ---------------------------------------------------
 void launch_revcomp(const uint8_t *src, uint8_t *dst, const int64_t *starts, const int64_t *lens, int n_contigs,
                     int64_t total, hipStream_t s);
-void launch_index_words(const uint8_t *codes, int64_t n, int step, uint32_t *words, int64_t n_slots, uint32_t *counts,
+// slot k of the index <-> position first + k * step (first = the block's --step phase, 0 for a whole file)
+void launch_index_words(const uint8_t *codes, int64_t n, int step, int64_t first, uint32_t *words, int64_t n_slots, uint32_t *counts,
                         hipStream_t s);
-void launch_index_scatter(const uint32_t *words, int64_t n_slots, int step, const uint32_t *offsets, uint32_t *cursor,
+void launch_index_scatter(const uint32_t *words, int64_t n_slots, int step, int64_t first, const uint32_t *offsets, uint32_t *cursor,
                           uint32_t *positions, hipStream_t s);
 // exclusive scan of n u32 values; out may alias in; block_sums (u64, one per 2048 inputs) is scratch of
 // ceil(n/2048)+1 entries and on return holds the exclusive prefix of the per-block totals, total last.

@@ -119,11 +119,11 @@ void launch_revcomp(const uint8_t *src, uint8_t *dst, const int64_t *starts, con
 
 // ------------------------------------------------------------------------------------------------
 // seed index
-__global__ void k_index_words(const uint8_t *__restrict__ codes, int64_t n, int step, uint32_t *__restrict__ words,
+__global__ void k_index_words(const uint8_t *__restrict__ codes, int64_t n, int step, int64_t first, uint32_t *__restrict__ words,
                               int64_t n_slots, uint32_t *__restrict__ counts) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
-    int64_t p = s * step;
+    int64_t p = first + s * step;
     uint32_t w = 0xFFFFFFFFu;
     if (p + kSeedSpan <= n) {
         uint32_t ww;
@@ -132,14 +132,14 @@ __global__ void k_index_words(const uint8_t *__restrict__ codes, int64_t n, int 
     words[s] = w;
 }
 
-void launch_index_words(const uint8_t *codes, int64_t n, int step, uint32_t *words, int64_t n_slots, uint32_t *counts,
+void launch_index_words(const uint8_t *codes, int64_t n, int step, int64_t first, uint32_t *words, int64_t n_slots, uint32_t *counts,
                         hipStream_t s) {
     if (n_slots <= 0) return;
-    hipLaunchKernelGGL(k_index_words, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, codes, n, step, words,
+    hipLaunchKernelGGL(k_index_words, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, codes, n, step, first, words,
                        n_slots, counts);
 }
 
-__global__ void k_index_scatter(const uint32_t *__restrict__ words, int64_t n_slots, int step,
+__global__ void k_index_scatter(const uint32_t *__restrict__ words, int64_t n_slots, int step, int64_t first,
                                 const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
                                 uint32_t *__restrict__ positions) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,13 +147,13 @@ __global__ void k_index_scatter(const uint32_t *__restrict__ words, int64_t n_sl
     uint32_t w = words[s];
     if (w == 0xFFFFFFFFu) return;
     uint32_t k = atomicAdd(&cursor[w], 1u);
-    positions[offsets[w] + k] = (uint32_t)(s * step);
+    positions[offsets[w] + k] = (uint32_t)(first + s * step);
 }
 
-void launch_index_scatter(const uint32_t *words, int64_t n_slots, int step, const uint32_t *offsets, uint32_t *cursor,
+void launch_index_scatter(const uint32_t *words, int64_t n_slots, int step, int64_t first, const uint32_t *offsets, uint32_t *cursor,
                           uint32_t *positions, hipStream_t s) {
     if (n_slots <= 0) return;
-    hipLaunchKernelGGL(k_index_scatter, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, words, n_slots, step,
+    hipLaunchKernelGGL(k_index_scatter, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, words, n_slots, step, first,
                        offsets, cursor, positions);
 }
 

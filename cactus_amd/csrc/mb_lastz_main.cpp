@@ -35,12 +35,13 @@ int main(int argc, char **argv) {
     int ndev = miblast_device_count();
     if (ndev <= 0) { fprintf(stderr, "lastz (miblast): no MI355X visible; this build has no CPU path\n"); return 3; }
     if (num_gpu > ndev) { fprintf(stderr, "lastz (miblast): --num_gpu %d but only %d visible\n", num_gpu, ndev); return 3; }
-    miblast_ctx *ctx = nullptr;
-    int rc = miblast_ctx_create(0, &ctx);
+    // one context per GPU of the job; block pairs of the two files are dealt to them (include/miblast.h, miblast_multi)
+    miblast_multi *ctx = nullptr;
+    int rc = miblast_multi_create(num_gpu, &ctx);
     miblast_stats st;
     memset(&st, 0, sizeof st);
-    if (rc == MIBLAST_OK) rc = miblast_align_files(ctx, files[0], files[1], &p, 1 /* stdout */, &st);
-    if (rc != MIBLAST_OK) { fprintf(stderr, "lastz (miblast): %s\n", miblast_last_error()); miblast_ctx_destroy(ctx); return 1; }
+    if (rc == MIBLAST_OK) rc = miblast_multi_align_files(ctx, files[0], files[1], &p, 1 /* stdout */, &st);
+    if (rc != MIBLAST_OK) { fprintf(stderr, "lastz (miblast): %s\n", miblast_last_error()); miblast_multi_destroy(ctx); return 1; }
     if (show_stats)
         fprintf(stderr,
                 "{\"seed_lookups\":%lld,\"seed_hits\":%lld,\"hits_extended\":%lld,\"ungapped_cols\":%lld,\"hsps\":%lld,"
@@ -50,6 +51,6 @@ int main(int argc, char **argv) {
                 (long long)st.hsps, (long long)st.anchors, (long long)st.anchors_skipped, (long long)st.dp_sides,
                 (long long)st.dp_cells, (long long)st.dp_rows, (long long)st.alignments, (long long)st.dp_cells_run,
                 (long long)st.gapped_rounds, st.t_index, st.t_seed, st.t_gapped, st.t_total);
-    miblast_ctx_destroy(ctx);
+    miblast_multi_destroy(ctx);
     return 0;
 }

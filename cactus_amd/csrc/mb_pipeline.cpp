@@ -127,6 +127,7 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
     size_t next = 0;           // first anchor not yet committed
     std::unordered_map<size_t, Cached> cache;
     std::vector<miblast_aln> kept;          // ops_off indexes unit_ops
+    std::vector<int32_t> kept_anchor_score; // HSP score of the anchor of kept[k] (anchor order = (-score, t, q): the merge key of blocked runs)
     std::vector<uint32_t> unit_ops;
     // coverage bookkeeping: anchors indexed by q so that an alignment only visits the anchors inside its q range
     // (units of a 30 Mb chunk pair hold up to --queryhspbest=100000 anchors and thousands of alignments)
@@ -321,7 +322,7 @@ void upload_seqset(SeqSet &s, int device) {
     s.device = device;
     MB_HIP(hipMalloc((void **)&s.d_buf, (size_t)s.total + 2 * kDevPad));
     MB_HIP(hipMemset(s.d_buf, 0xFF, (size_t)s.total + 2 * kDevPad));
-    if (s.total) MB_HIP(hipMemcpy(s.d_buf + kDevPad, s.codes.data() + 1, (size_t)s.total, hipMemcpyHostToDevice));
+    if (s.total) MB_HIP(hipMemcpy(s.d_buf + kDevPad, s.host(), (size_t)s.total, hipMemcpyHostToDevice));
     size_t nc = std::max<size_t>(1, s.starts.size());
     MB_HIP(hipMalloc((void **)&s.d_starts, nc * sizeof(int64_t)));
     MB_HIP(hipMalloc((void **)&s.d_lens, nc * sizeof(int64_t)));
@@ -405,7 +406,9 @@ struct Index { uint32_t n_positions = 0; };
 static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     hipStream_t s = ctx.stream;
     Workspace &w = *ctx.ws;
-    int64_t n_slots = (T.total + step - 1) / step;
+    // indexed positions are those with (origin + p) % step == 0: a block of a larger file keeps the file's phase
+    const int64_t first = (step - T.origin % step) % step;
+    int64_t n_slots = T.total > first ? (T.total - first + step - 1) / step : 0;
     w.words.ensure((size_t)std::max<int64_t>(1, n_slots));
     w.counts.ensure((size_t)kBuckets + 1);
     w.offsets.ensure((size_t)kBuckets + 1);
@@ -413,10 +416,10 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     int64_t nblk = ((int64_t)kBuckets + 1 + 2047) / 2048;
     w.bsum.ensure((size_t)nblk + 2);
     MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
-    launch_index_words(T.dev(), T.total, step, w.words.p, n_slots, w.counts.p, s);
+    launch_index_words(T.dev(), T.total, step, first, w.words.p, n_slots, w.counts.p, s);
     launch_scan_u32(w.counts.p, w.offsets.p, (int64_t)kBuckets + 1, w.bsum.p, s);
     MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
-    launch_index_scatter(w.words.p, n_slots, step, w.offsets.p, w.counts.p, w.positions.p, s);
+    launch_index_scatter(w.words.p, n_slots, step, first, w.offsets.p, w.counts.p, w.positions.p, s);
     w.occ.ensure((size_t)kBuckets / 32);
     launch_bucket_bitmap(w.offsets.p, w.occ.p, s);
     MB_HIP(hipMemcpyAsync(&ix.n_positions, w.offsets.p + kBuckets, 4, hipMemcpyDeviceToHost, s));
@@ -863,6 +866,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     A.strand = u.strand; A.q_contig = u.q_contig; A.t_contig = jobs[(size_t)u.pair]->T->contig_of(a.t);
                     A.t_lo = c.t_lo; A.t_hi = c.t_hi; A.q_lo = c.q_lo; A.q_hi = c.q_hi;
                     A.score = c.score; A.dmin = c.dmin; A.dmax = c.dmax; A.anchor_t = a.t; A.anchor_q = a.q;
+                    u.kept_anchor_score.push_back(a.score);
                     A.ops_off = (int64_t)u.unit_ops.size(); A.n_ops = (int64_t)c.ops.size();
                     u.unit_ops.insert(u.unit_ops.end(), c.ops.begin(), c.ops.end());
                     u.kept.push_back(A);
@@ -1568,6 +1572,7 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         for (int strand = 0; strand < 2; strand++)
             for (Unit &u : units) {
                 if (u.pair != pair || u.q_contig != qc_i || u.strand != strand) continue;
+                res.aln_anchor_score.insert(res.aln_anchor_score.end(), u.kept_anchor_score.begin(), u.kept_anchor_score.end());
                 for (miblast_aln A : u.kept) {
                     int64_t off = (int64_t)res.ops.size();
                     res.ops.insert(res.ops.end(), u.unit_ops.begin() + A.ops_off, u.unit_ops.begin() + A.ops_off + A.n_ops);
@@ -1643,12 +1648,15 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
     res.paf.resize(total);
     {
         size_t at = paf0;
+        res.line_off.clear();
         for (size_t ai = 0; ai < res.alns.size(); ai++) {
+            res.line_off.push_back(at);
             memcpy(&res.paf[at], heads[ai].data(), heads[ai].size());
             at += heads[ai].size();
             for (size_t ti = cfirst[ai]; ti < cfirst[ai + 1]; ti++) at += ctasks[ti].text.size();
             res.paf[at++] = '\n';
         }
+        res.line_off.push_back(at);
     }
     parallel_for(ctasks.size(), [&](size_t ti) { if (!ctasks[ti].text.empty()) memcpy(&res.paf[ctasks[ti].at], ctasks[ti].text.data(), ctasks[ti].text.size()); });
     if (p.format == 1) {

@@ -26,12 +26,18 @@ struct Result {
     std::vector<miblast_aln> alns;
     std::vector<uint32_t> ops;
     miblast_stats stats{};
+    std::vector<int32_t> aln_anchor_score;   // per alignment: score of the HSP its anchor came from
+    std::vector<size_t> line_off;            // PAF line k of alns[k] = paf[line_off[k], line_off[k+1])
 };
 
 void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
 int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &p, Result &res);
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &p, Result **results);
+// mb_multi.cpp: n_pairs (target, query) sets parsed on the host (not uploaded), cut into blocks of whole contigs, the block pairs
+// dealt to the contexts' devices; `paf` = the pairs' outputs in pair order, each as one lastz process over the whole files writes it
+int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n_pairs,
+                  const miblast_params &p, std::string &paf, miblast_stats *stats);
 // independent work items on the library's persistent worker threads (the caller takes part; nested calls run inline)
 void host_parallel_for(size_t n, const std::function<void(size_t)> &f);
 struct HostHot {                        // keeps the workers spinning for the duration of a job (they sleep otherwise)
@@ -52,3 +58,4 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
 struct miblast_ctx { mb::Ctx c; };
 struct miblast_seqset { mb::SeqSet s; };
 struct miblast_result { mb::Result r; };
+struct miblast_multi { std::vector<miblast_ctx *> ctxs; };

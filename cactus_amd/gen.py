@@ -124,11 +124,14 @@ def write_fasta(path: str, records) -> None:
         f.write(fasta_bytes(records))
 
 
-def make_tree_genomes(ancestor_len: int, seed: int, tree=None):
+def make_tree_genomes(ancestor_len: int, seed: int, tree=None, ancestors: bool = False):
     """Synthetic stand-in for the evolver data sets (their FASTA files are URLs,
     /root/reference/examples/evolverMammals.txt:3-7; no network): leaves evolved from one ancestor along the
     branch lengths of the evolverMammals guide tree (/root/reference/examples/evolverMammals.txt:1).
-    Returns {leaf_name: uint8 array}.  Per-branch substitution rate = branch length (capped), indel rate = 1/15 of it."""
+    Returns {leaf_name: uint8 array}.  Per-branch substitution rate = branch length (capped), indel rate = 1/15 of it.
+    ancestors=True also returns the internal nodes' sequences (the blast phase of a progressive run aligns reconstructed
+    ancestors as ingroups; the stand-in uses the true ones, unmasked) and the root as "Anc0"; the leaves are
+    the same bytes either way."""
     if tree is None:
         # ((simHuman_chr6:0.144018,(simMouse_chr6:0.084509,simRat_chr6:0.091589):0.271974):0.020593,
         #  (simCow_chr6:0.18908,simDog_chr6:0.16303):0.032898);
@@ -147,10 +150,14 @@ def make_tree_genomes(ancestor_len: int, seed: int, tree=None):
                 a = int(rng.integers(0, n - n // 20)); child[a:a + n // 20] = revcomp(child[a:a + n // 20])
                 d = int(rng.integers(0, n - n // 40)); child = np.concatenate([child[:d], child[d + n // 40:]])
             if kids:
+                if ancestors:
+                    out[{"hmr": "Anc1", "cd": "Anc2"}.get(name, name)] = child.copy()
                 walk(kids, child)
             else:
                 out[name] = soft_mask(child, rng, 0.15)
 
+    if ancestors:
+        out["Anc0"] = root_seq.copy()
     walk(tree[1], root_seq)
     return out
 

@@ -52,6 +52,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class FastaPair(C.Structure):
+    """miblast_fasta_pair: FASTA text of one chunk pair in memory"""
+    _fields_ = [("target", C.c_char_p), ("target_len", C.c_size_t), ("query", C.c_char_p), ("query_len", C.c_size_t)]
+
+
 _lib = None
 
 
@@ -90,6 +95,11 @@ def load() -> C.CDLL:
         "miblast_result_alns": (P(Aln), [vp, P(i64)]),
         "miblast_result_ops": (P(C.c_uint32), [vp, P(i64)]),
         "miblast_align_files": (C.c_int, [vp, cp, cp, P(Params), C.c_int, P(Stats)]),
+        "miblast_multi_create": (C.c_int, [C.c_int, P(vp)]),
+        "miblast_multi_destroy": (None, [vp]),
+        "miblast_multi_num_gpu": (C.c_int, [vp]),
+        "miblast_multi_align_files": (C.c_int, [vp, cp, cp, P(Params), C.c_int, P(Stats)]),
+        "miblast_multi_align_fasta_pairs": (C.c_int, [vp, P(FastaPair), C.c_size_t, P(Params), P(vp), P(C.c_size_t), P(Stats)]),
         "miblast_build_index": (C.c_int, [vp, vp, i32, P(P(C.c_uint32)), P(P(C.c_uint32))]),
         "miblast_free": (None, [vp]),
         "miblast_last_error": (cp, []),
@@ -108,7 +118,8 @@ EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "mibla
                     "miblast_seqset_free", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
                     "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_align_pairs", "miblast_result_free",
                     "miblast_result_paf", "miblast_result_stats", "miblast_result_hsps", "miblast_result_alns",
-                    "miblast_result_ops", "miblast_align_files", "miblast_build_index", "miblast_free",
+                    "miblast_result_ops", "miblast_align_files", "miblast_multi_create", "miblast_multi_destroy", "miblast_multi_num_gpu",
+                    "miblast_multi_align_files", "miblast_multi_align_fasta_pairs", "miblast_build_index", "miblast_free",
                     "miblast_last_error", "miblast_version")
 
 
@@ -279,6 +290,45 @@ class Context:
     def close(self):
         if self._h:
             load().miblast_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Multi:
+    """Several MI355X driven from this process (miblast_multi): what `run_kegalign ... --num_gpu N` is inside.  Block pairs of
+    the inputs are dealt to the devices; the PAF bytes do not depend on num_gpu (include/miblast.h)."""
+
+    def __init__(self, num_gpu: int = 1):
+        h = C.c_void_p()
+        _check(load().miblast_multi_create(int(num_gpu), C.byref(h)))
+        self._h = h
+        self.num_gpu = int(num_gpu)
+
+    def align_files(self, target_fa: str, query_fa: str, params: Params, out_fd: int):
+        st = Stats()
+        _check(load().miblast_multi_align_files(self._h, target_fa.encode(), query_fa.encode(), C.byref(params), int(out_fd), C.byref(st)))
+        return st.as_dict()
+
+    def align_fasta_pairs(self, pairs, params: Params):
+        """pairs: list of (target FASTA bytes, query FASTA bytes) -> (PAF bytes of all pairs in pair order, stats totals)"""
+        lib = load()
+        n = len(pairs)
+        arr = (FastaPair * n)(*[FastaPair(t, len(t), q, len(q)) for t, q in pairs])
+        out, ln, st = C.c_void_p(), C.c_size_t(), Stats()
+        _check(lib.miblast_multi_align_fasta_pairs(self._h, arr, n, C.byref(params), C.byref(out), C.byref(ln), C.byref(st)))
+        try:
+            return (C.string_at(out, ln.value) if ln.value else b""), st.as_dict()
+        finally:
+            lib.miblast_free(out)
+
+    def close(self):
+        if self._h:
+            load().miblast_multi_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -92,19 +92,18 @@ def paf_invert_line(line: str) -> str:
     return "\t".join(f) + "\n"
 
 
-def paf_to_bed_unaligned(paf_path: str, query_fasta: str, min_size: int):
-    """`paffy to_bed --excludeAligned --binary --minSize N -i paf --queryFastaFile fa` (local_alignment.py:460-466):
-    BED intervals (name, start, end) of QUERY sequence not covered by any alignment, at least min_size long."""
+def unaligned_intervals(paf_lines, seq_lens, min_size: int):
+    """Core of `paffy to_bed --excludeAligned --binary --minSize N` on PAF lines and [(query sequence name, length)]: the
+    (name, start, end) intervals of QUERY sequence no alignment covers, at least min_size long, in sequence order."""
     import numpy as np
-    cover = {name.split()[0]: np.zeros(len(seq) + 1, dtype=np.int32) for name, seq in _read_fasta(query_fasta)}
-    with open(paf_path) as f:
-        for line in f:
-            if not line.strip():
-                continue
-            t = line.split("\t")
-            c = cover[t[0]]
-            c[int(t[2])] += 1
-            c[int(t[3])] -= 1
+    cover = {name: np.zeros(n + 1, dtype=np.int32) for name, n in seq_lens}
+    for line in paf_lines:
+        if not line.strip():
+            continue
+        t = line.split("\t", 4)
+        c = cover[t[0]]
+        c[int(t[2])] += 1
+        c[int(t[3])] -= 1
     out = []
     for name, diff in cover.items():
         free = np.cumsum(diff[:-1]) == 0
@@ -115,24 +114,40 @@ def paf_to_bed_unaligned(paf_path: str, query_fasta: str, min_size: int):
     return out
 
 
+def extract_records(bed, records, flank: int):
+    """Core of `faffy extract -i bed fa --flank F` on [(name, sequence)] (str or uint8 array): the BED intervals widened by flank
+    (overlapping widened intervals merged) as [(NAME|SEQLEN|START, piece)], in sequence order."""
+    by = {}
+    lens = {name: len(seq) for name, seq in records}
+    for name, s, e in bed:
+        by.setdefault(name, []).append((max(0, s - flank), min(lens[name], e + flank)))
+    out = []
+    for name, seq in records:
+        merged = []
+        for s, e in sorted(by.get(name, [])):
+            if merged and s <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], e))
+            else:
+                merged.append((s, e))
+        for s, e in merged:
+            out.append(("{}|{}|{}".format(name, len(seq), s), seq[s:e]))
+    return out
+
+
+def paf_to_bed_unaligned(paf_path: str, query_fasta: str, min_size: int):
+    """`paffy to_bed --excludeAligned --binary --minSize N -i paf --queryFastaFile fa` (local_alignment.py:460-466):
+    BED intervals (name, start, end) of QUERY sequence not covered by any alignment, at least min_size long."""
+    with open(paf_path) as f:
+        return unaligned_intervals(f, [(name.split()[0], len(seq)) for name, seq in _read_fasta(query_fasta)], min_size)
+
+
 def fasta_extract(bed, fasta_path: str, out_path: str, flank: int):
     """`faffy extract -i bed fa --flank F` (local_alignment.py:470-475): the BED intervals, widened by `flank` on
     both sides (overlapping widened intervals are merged), written as records named NAME|SEQLEN|START so that
     `paffy dechunk --query` (paf_dechunk(..., query_only=True)) restores full-sequence coordinates."""
-    seqs = {name.split()[0]: seq for name, seq in _read_fasta(fasta_path)}
-    by = {}
-    for name, s, e in bed:
-        by.setdefault(name, []).append((max(0, s - flank), min(len(seqs[name]), e + flank)))
+    records = [(name.split()[0], seq) for name, seq in _read_fasta(fasta_path)]
     with open(out_path, "w") as out:
-        for name in seqs:
-            merged = []
-            for s, e in sorted(by.get(name, [])):
-                if merged and s <= merged[-1][1]:
-                    merged[-1] = (merged[-1][0], max(merged[-1][1], e))
-                else:
-                    merged.append((s, e))
-            for s, e in merged:
-                out.write(">{}|{}|{}\n".format(name, len(seqs[name]), s))
-                piece = seqs[name][s:e]
-                for i in range(0, len(piece), 100):
-                    out.write(piece[i:i + 100] + "\n")
+        for name, piece in extract_records(bed, records, flank):
+            out.write(">{}\n".format(name))
+            for i in range(0, len(piece), 100):
+                out.write(piece[i:i + 100] + "\n")

@@ -151,10 +151,34 @@ const miblast_hsp *miblast_result_hsps(const miblast_result *r, int64_t *n);
 const miblast_aln *miblast_result_alns(const miblast_result *r, int64_t *n);
 const uint32_t *miblast_result_ops(const miblast_result *r, int64_t *n);   /* (len<<2)|op, op 0 '=',1 'X',2 'I',3 'D' */
 
-/* File-level convenience = what bin/lastz does: load both FASTA files, align, write PAF to fd.
- * Replaces the whole cactus_call(lastz ...) invocation (local_alignment.py:72).                */
+/* File-level convenience: load both FASTA files, align on the context's device, write PAF to fd.
+ * Replaces the whole cactus_call(lastz ...) invocation (local_alignment.py:72).  Inputs of any size (blocks
+ * of whole sequences, see miblast_multi below).                                                  */
 int miblast_align_files(miblast_ctx *ctx, const char *target_fa, const char *query_fa,
                         const miblast_params *p, int out_fd, miblast_stats *stats);
+
+/* ---- several GPUs from one process, inputs of any size ----------------------------------------
+ * The reference's GPU branch starts ONE process per genome pair and gives it every GPU of the job:
+ *   run_kegalign A.fa B.fa --format=paf:wfmash <opts> --num_gpu G --num_threads C   (local_alignment.py:54-58),
+ *   accelerators 'cuda:G' per job (local_alignment.py:393,405), inputs up to bigChunkSize = 6 000 000 000 bases
+ *   (cactus_progressive_config.xml:47,91; local_alignment.py:376).
+ * A miblast_multi owns one context per device 0..num_gpu-1.  Its calls cut both inputs into blocks of whole
+ * sequences (at most 2^30 bases each), deal the block pairs to the devices longest-first (no data-path collective;
+ * chunk pairs are independent) and assemble the PAF in the order ONE lastz process over the whole files
+ * writes it: the bytes do not depend on num_gpu or on the block size.  $MIBLAST_DEVICE_MAP
+ * ("0,0,1": logical -> physical ordinals) lets several logical devices share a GPU (tests on a one-GPU box).     */
+typedef struct miblast_multi miblast_multi;
+int miblast_multi_create(int num_gpu, miblast_multi **out);          /* num_gpu <= miblast_device_count() */
+void miblast_multi_destroy(miblast_multi *m);
+int miblast_multi_num_gpu(const miblast_multi *m);
+/* = one `run_kegalign target query <opts> --num_gpu G` process (PAF to out_fd); also what bin/lastz runs with G = 1 */
+int miblast_multi_align_files(miblast_multi *m, const char *target_fa, const char *query_fa, const miblast_params *p,
+                              int out_fd, miblast_stats *stats);
+/* A list of chunk pairs (FASTA text in memory) sharded over the devices: SURVEY 8b's multi-GPU entry.  *paf receives
+ * the pairs' PAF in pair order (free with miblast_free); stats (may be NULL) = totals over the call.            */
+typedef struct miblast_fasta_pair { const char *target; size_t target_len; const char *query; size_t query_len; } miblast_fasta_pair;
+int miblast_multi_align_fasta_pairs(miblast_multi *m, const miblast_fasta_pair *pairs, size_t n_pairs, const miblast_params *p,
+                                    char **paf, size_t *paf_len, miblast_stats *stats);
 
 /* Stage export for parity tests: the target seed position table (lastz pos_table)
  * as CSR.  offsets has 2^24+1 entries; positions are ascending inside a bucket.  Caller frees

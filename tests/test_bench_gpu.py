@@ -1,0 +1,103 @@
+"""-m gpu : the measurement harness and the one-process-per-GPU form of the sharding.  bench.py must really start N ranks for
+--gpus N (the driver's scaling runs depend on it), attach the oracle's bytes to the benched workload, and the gloo/RCCL gather
+must carry the product's output, not a stand-in's.  A one-GPU box hosts both ranks ($MIBLAST_BENCH_SINGLE_DEVICE, gloo)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0", "--pair-leg", "0"]
+
+
+def _bench(args, **env):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **env), cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_carries_the_oracle_diff_of_the_benched_workload():
+    out = _bench(SMALL)
+    assert out["n_gpus"] == 1 and out["unit"] == "Gcell/s" and out["value"] > 0
+    assert "evolverMammals" in out["config"]["workload"] and "configs[2]" in out["config"]["workload"]
+    cb = out["cpu_baseline"]
+    assert cb["same_bytes"] is True and cb["calls_differing"] == 0 and cb["same_dp_cells"] is True and cb["calls"] >= 14
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0 < r["valu"]["frac"] < 1
+
+
+def test_bench_gpus_2_really_runs_two_ranks():
+    one = _bench(SMALL + ["--cpu-sample", "0"])
+    two = _bench(SMALL + ["--cpu-sample", "0", "--gpus", "2"], MIBLAST_BENCH_SINGLE_DEVICE="1", MIBLAST_BENCH_BACKEND="gloo")
+    assert two["n_gpus"] == 2 and two["config"]["collective_backend"] == "gloo"
+    # both ranks' PAF reached rank 0 inside the timed region: twice the bytes, twice the work
+    assert two["config"]["paf_bytes_gathered_per_step"] == 2 * one["config"]["paf_bytes_gathered_per_step"] > 0
+    assert two["dp_cells_per_step"] == one["dp_cells_per_step"]              # per rank and step
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL], capture_output=True, text=True,
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr                   # a launcher that started the wrong number of ranks is an error
+
+
+def _rank_main(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import CASES, DEFAULT
+    from cactus_amd import miblast
+    from cactus_amd.multigpu import blast_pairs_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = miblast.Context(0)
+    pm = miblast.params_from_args(DEFAULT)
+    pairs = [(c[1], c[2]) for c in CASES if c[0] in ("homolog_20k_default", "random_50k", "multi_contig_ragged", "tandem_repeats", "empty_query", "revcomp_query")]
+
+    def align(pair):
+        T, Q = ctx.seqset_from_fasta_bytes(pair[0]), ctx.seqset_from_fasta_bytes(pair[1])
+        try:
+            return ctx.align(T, Q, pm, details=False).paf
+        finally:
+            T.close(); Q.close()
+
+    out = blast_pairs_sharded(pairs, [float(len(a) * len(b)) for a, b in pairs], align, dist if world > 1 else None, rank, world, torch.device("cpu"))
+    if rank == 0:
+        open(out_path, "wb").write(out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_of_the_real_library_gather_the_oracle_bytes(olz, tmp_path):
+    """SURVEY 8e determinism with the PRODUCT in the loop: chunk pairs sharded over two ranks (both on this box's GPU), PAF
+    gathered to rank 0 in pair order == the single-rank run == the oracle."""
+    import torch.multiprocessing as mp
+    from cases import CASES, DEFAULT
+    from cactus_amd import miblast
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    outs = {}
+    for world in (1, 2):
+        path = str(tmp_path / f"w{world}.paf")
+        procs = [ctx.Process(target=_rank_main, args=(r, world, port + world, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0
+        outs[world] = open(path, "rb").read()
+    pm = miblast.params_from_args(DEFAULT)
+    po = olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_})
+    want = b"".join(olz.align(c[1], c[2], po, details=False)["paf"]
+                    for c in CASES if c[0] in ("homolog_20k_default", "random_50k", "multi_contig_ragged", "tandem_repeats", "empty_query", "revcomp_query"))
+    assert outs[1] == outs[2] == want and want.count(b"\n") > 5

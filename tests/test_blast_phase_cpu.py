@@ -1,0 +1,125 @@
+"""CPU tests of the blast-phase schedule (cactus_amd/blast_phase.py): which lastz calls a progressive run makes and with which
+option sets -- mirror of /root/reference/src/cactus/paf/paf.py:29-71 and local_alignment.py:751-858, 421-526 -- and the data flow
+of the ingroup->outgroup chain, run here with the CPU oracle as the aligner (the GPU suite runs the same driver on the MI355X
+and diffs every call)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cactus_amd import blast_phase as bp
+from cactus_amd import gen, pafcheck
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_distances_are_tree_path_lengths():
+    t = bp.parse_newick(bp.EVOLVER_MAMMALS_TREE)
+    d = bp.get_distances(t)
+    assert abs(d[("simMouse_chr6", "simRat_chr6")] - 0.176098) < 1e-9
+    assert abs(d[("simHuman_chr6", "simMouse_chr6")] - (0.144018 + 0.271974 + 0.084509)) < 1e-9
+    assert abs(d[("simCow_chr6", "simMouse_chr6")] - (0.18908 + 0.032898 + 0.020593 + 0.271974 + 0.084509)) < 1e-9
+    assert d[("mr", "mr")] == 0.0 and d[("Anc0", "simDog_chr6")] == d[("simDog_chr6", "Anc0")]
+    pairs = [(a.iD, b.iD) for a, b, _ in bp.get_event_pairs(t, t.leaves())]
+    assert len(pairs) == 10 and pairs[0] == ("simHuman_chr6", "simMouse_chr6")          # list order, i < j (paf.py:61-71)
+    unnamed = bp.parse_newick("((a:1,b:2):3,(c:4,d:5):6);")
+    assert [n.iD for n in unnamed.subtree() if n.children] == ["Anc0", "Anc1", "Anc2"]
+
+
+def test_ancestor_upweighting_follows_progressive_decomposition():
+    # progressive_decomposition.py:231-239: height added to the branch above an ancestor, capped at max_div, long branches untouched
+    s = bp.ancestor_scaled_tree(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE), 0.25)
+    assert abs(bp.get_node(s, "mr").distance - 0.271974) < 1e-12                      # already >= 0.25
+    assert abs(bp.get_node(s, "Anc1").distance - 0.25) < 1e-12                        # 0.020593 + 0.363563 capped
+    assert abs(bp.get_node(s, "Anc2").distance - (0.032898 + 0.18908)) < 1e-12
+    assert abs(bp.get_node(s, "simHuman_chr6").distance - 0.144018) < 1e-12           # leaves untouched
+
+
+def test_evolver_mammals_schedule_is_appendix_d():
+    from cactus_amd.paf.local_alignment import select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE))
+    assert len(calls) == 20 <= 28 and [c.node for c in calls if c.kind == "ingroup"] == ["mr", "Anc1", "Anc2", "Anc0"]
+    sets = {(c.target, c.query): select_lastz_params(c.distance, cfg, 0) for c in calls}
+    assert sets[("simMouse_chr6", "simRat_chr6")].startswith("--step=3 ") and "--hspthresh=2600" in sets[("simMouse_chr6", "simRat_chr6")]      # "four"
+    assert all(v.startswith("--step=1 ") for k, v in sets.items() if k != ("simMouse_chr6", "simRat_chr6"))                                # "default"
+    mr_mouse = [c for c in calls if c.chain == ("mr", "simMouse_chr6")]
+    assert [(c.target, c.level) for c in mr_mouse] == [("simHuman_chr6", 0), ("simDog_chr6", 1), ("simCow_chr6", 2)]      # nearest outgroup first (:818)
+    assert all(c.query == "simMouse_chr6" for c in mr_mouse)                                                              # outgroup = file A, ingroup = file B (:444-448)
+    assert not [c for c in calls if c.node == "Anc0" and c.kind == "outgroup"]
+    prim = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_PRIMATES_TREE))
+    assert len(prim) <= 21 and all(select_lastz_params(c.distance, cfg, 0).startswith("--step=2 ") for c in prim if c.kind == "ingroup" and c.node == "hc")
+
+
+def test_phase_driver_data_flow_with_the_oracle(olz):
+    """20 kb stand-in: every call of the phase through the oracle; the assembled per-node PAFs validate against the FULL
+    sequences (cigars, coordinates after two levels of `dechunk --query`, inversion), later outgroups only see what earlier ones
+    left unaligned, and equal-option calls of a level arrive as one batch."""
+    from cactus_amd import miblast
+    from cactus_amd.paf.local_alignment import select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE))
+    genomes = gen.make_tree_genomes(20_000, 2001, ancestors=True)
+    fasta = {k: gen.fasta_bytes([("id=%s|%s" % (k, k), v)]) for k, v in genomes.items()}
+    batches, seen = [], []
+
+    def align_batch(pairs, opts):
+        batches.append((len(pairs), opts))
+        pm = miblast.params_from_args(opts.split())
+        po = olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_})
+        return [olz.align(t, q, po, details=False)["paf"] for t, q in pairs]
+
+    res = bp.run_blast_phase(fasta, calls, lambda d: select_lastz_params(d, cfg, 0), align_batch,
+                             on_call=lambda c, tf, qf, paf: seen.append((c, len(qf), paf)))
+    assert set(res) == {"mr", "Anc1", "Anc2", "Anc0"} and batches[0][0] + batches[1][0] == 10       # level 0: 1 x "four" + 9 x "default"
+    full = {}
+    for fa in fasta.values():
+        for name, seq in bp.parse_fasta_bytes(fa):
+            full[name] = seq.tobytes().decode()
+    n_checked = 0
+    for node, parts in res.items():
+        for kind in ("ingroup", "outgroup"):
+            if parts[kind]:
+                n_checked += pafcheck.check_paf(parts[kind].decode(), full, full)
+    assert n_checked >= 20
+    # an outgroup call of level k+1 is handed less sequence than level k, and only sub-sequence records (NAME|LEN|START)
+    by_chain = {}
+    for c, qlen, paf in seen:
+        if c.chain:
+            by_chain.setdefault(c.chain, []).append((c.level, qlen))
+    assert all(sorted(v)[0][1] > sorted(v)[-1][1] for v in by_chain.values() if len(v) > 1)
+    # inverted: in the outgroup file the ingroup is the TARGET (local_alignment.py:427)
+    for line in res["mr"]["outgroup"].decode().splitlines():
+        f = line.split("\t")
+        assert f[5] in ("id=simMouse_chr6|simMouse_chr6", "id=simRat_chr6|simRat_chr6") and int(f[6]) in (len(genomes["simMouse_chr6"]), len(genomes["simRat_chr6"]))
+
+
+def test_unaligned_fasta_nests_subsequence_names():
+    rng = np.random.default_rng(3)
+    seq = gen.random_sequence(1000, rng)
+    fa = gen.fasta_bytes([("id=A|c", seq)])
+    paf = b"id=A|c\t1000\t100\t400\t+\tt\t9\t0\t1\t1\t1\t255\n"
+    left = bp.unaligned_fasta(paf, fa, 100, 50)
+    recs = bp.parse_fasta_bytes(left)
+    assert [n for n, _ in recs] == ["id=A|c|1000|0", "id=A|c|1000|350"] and [len(s) for _, s in recs] == [150, 650]
+    paf2 = b"id=A|c|1000|350\t650\t0\t300\t-\tt\t9\t0\t1\t1\t1\t255\n"
+    again = bp.parse_fasta_bytes(bp.unaligned_fasta(paf2, left, 100, 0))
+    assert [n for n, _ in again] == ["id=A|c|1000|0|150|0", "id=A|c|1000|350|650|300"]
+    assert bp.dechunk_query(paf2).split(b"\t")[:4] == [b"id=A|c", b"1000", b"350", b"650"]
+    assert bp.unaligned_fasta(b"id=A|c\t1000\t0\t1000\t+\tt\t9\t0\t1\t1\t1\t255\n", fa, 100, 50) == b""
+
+
+def test_bench_refuses_a_wrong_world_size_and_spawns_ranks():
+    # no GPU here: the spawned ranks must fail loudly (no CPU path), and the launcher's exit code must say so
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       env=dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+    from cactus_amd import miblast
+    if miblast.device_count() == 0:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+        assert p.returncode != 0 and p.stderr.count("needs a GPU") == 2 and "{" not in p.stdout

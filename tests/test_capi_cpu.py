@@ -101,6 +101,18 @@ def test_no_device_means_loud_refusal_not_cpu_fallback():
     assert "no CPU path" in str(e.value)
 
 
+def test_multi_device_entry_refuses_without_gpu_too(monkeypatch):
+    # miblast_multi (run_kegalign --num_gpu N): no device, no contexts; a device map cannot invent devices
+    if not _no_gpu():
+        pytest.skip("a GPU is visible here")
+    monkeypatch.setenv("MIBLAST_DEVICE_MAP", "0,0")
+    assert miblast.device_count() == 0
+    with pytest.raises(miblast.MiblastError) as e:
+        miblast.Multi(2)
+    assert "no CPU path" in str(e.value)
+    assert C.sizeof(miblast.FastaPair) == 32
+
+
 def test_front_end_binaries_exist_and_refuse_without_gpu(tmp_path):
     for name in ("lastz", "run_kegalign"):
         exe = os.path.join(BIN_DIR, name)

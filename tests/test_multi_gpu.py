@@ -1,0 +1,140 @@
+"""-m gpu : one job over several devices and over blocks of the inputs (cactus_amd/csrc/mb_multi.cpp, include/miblast.h
+miblast_multi) -- the inside of `run_kegalign A.fa B.fa ... --num_gpu G` (/root/reference/src/cactus/paf/local_alignment.py:54-58,
+393-405; bigChunkSize, cactus_progressive_config.xml:91).  The contract under test: the PAF bytes equal what ONE oracle run over
+the whole files writes, whatever the number of devices, the block size or the dealing of block pairs.  A one-GPU box plays
+several devices through $MIBLAST_DEVICE_MAP (logical -> physical ordinals)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import KEG_DEFAULT, DEFAULT, multi_contig
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEG_FOUR = "--step=3 --ambiguous=iupac,100,100 --ydrop=3500 --hspthresh=2600 --gappedthresh=2800".split()
+
+
+def genome_like(seed, n_t=7, n_q=6):
+    """Two assemblies of several contigs: every query contig is stitched from mutated pieces of TWO target contigs (one of them
+    reverse-complemented now and then), so that a query sequence has alignments in several target blocks and the merge of the
+    blocks' lists on anchor order is exercised; plus ragged and empty records."""
+    from cactus_amd import gen
+    rng = np.random.default_rng(seed)
+    tl = [int(x) for x in rng.integers(2500, 9000, size=n_t)]
+    trecs = [("id=T|c%d" % i, gen.random_sequence(n, rng)) for i, n in enumerate(tl)]
+    trecs.insert(3, ("id=T|tiny", gen.random_sequence(12, rng)))
+    qrecs = []
+    for j in range(n_q):
+        a, b = int(rng.integers(0, n_t)), int(rng.integers(0, n_t))
+        pa = gen.mutate(trecs[a if a < 3 else a + 1][1], rng, 0.07, 0.004)
+        pb = gen.mutate(trecs[b if b < 3 else b + 1][1], rng, 0.10, 0.006)
+        if j % 3 == 1:
+            pb = gen.revcomp(pb)
+        qrecs.append(("id=Q|s%d" % j, np.concatenate([pa[: len(pa) * 2 // 3], gen.random_sequence(300, rng), pb[len(pb) // 4:]])))
+    qrecs.insert(2, ("id=Q|empty", np.zeros(0, dtype=np.uint8)))
+    return gen.fasta_bytes(trecs), gen.fasta_bytes(qrecs)
+
+
+def _oracle(olz, tf, qf, args):
+    from cactus_amd import miblast
+    pm = miblast.params_from_args(args)
+    return pm, olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}))
+
+
+@pytest.mark.parametrize("args,block", [(KEG_DEFAULT, "9000"), (KEG_FOUR, "7000"), (KEG_DEFAULT, "20000"), (KEG_FOUR, None)],
+                         ids=["default_9k", "step3_phase_7k", "default_20k", "step3_unblocked"])
+def test_blocked_job_equals_one_oracle_run_over_the_whole_files(olz, monkeypatch, args, block):
+    """Target and query cut into blocks of whole contigs (forced small here; 2^30 bases in production): bytes and counters of
+    the assembled job equal the oracle's single run, including the --step phase of blocks that do not start at a multiple of
+    the step and the order of a query's alignments across target blocks."""
+    from cactus_amd import miblast
+    tf, qf = genome_like(101)
+    pm, want = _oracle(olz, tf, qf, args)
+    assert want["paf"].count(b"\n") >= 8
+    if block:
+        monkeypatch.setenv("MIBLAST_BLOCK_BASES", block)
+    m = miblast.Multi(1)
+    try:
+        paf, st = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert paf == want["paf"]
+    for k in ("seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "anchors_skipped", "dp_sides", "dp_cells", "dp_rows", "alignments"):
+        assert st[k] == want["counters"][k], k
+
+
+@pytest.mark.parametrize("ngpu", [2, 3])
+def test_num_gpu_does_not_change_a_byte(olz, monkeypatch, ngpu):
+    """SURVEY 8e determinism: n_gpu in {1, 2, 3} (logical devices sharing this box's GPU) give the oracle's bytes, with and
+    without forced target blocks; every device gets work."""
+    from cactus_amd import miblast
+    tf, qf = genome_like(202, n_t=9, n_q=8)
+    pm, want = _oracle(olz, tf, qf, KEG_DEFAULT)
+    monkeypatch.setenv("MIBLAST_DEVICE_MAP", ",".join(["0"] * ngpu))
+    assert miblast.device_count() == ngpu
+    for block in (None, "12000"):
+        if block:
+            monkeypatch.setenv("MIBLAST_BLOCK_BASES", block)
+        m = miblast.Multi(ngpu)
+        try:
+            paf, st = m.align_fasta_pairs([(tf, qf)], pm)
+        finally:
+            m.close()
+        assert paf == want["paf"], block
+        assert st["dp_cells"] == want["counters"]["dp_cells"] and st["seed_hits"] == want["counters"]["seed_hits"]
+
+
+def test_chunk_pair_list_sharded_over_devices(olz, monkeypatch):
+    """miblast_multi_align_fasta_pairs = SURVEY 8b's multi-GPU entry: a list of chunk pairs dealt to the devices, output in pair
+    order = the concatenation of the single jobs, for 1 and 2 devices (queryhspbest allowed: single-block targets)."""
+    from cactus_amd import miblast
+    from cases import pair
+    pairs = [pair(20000, 61), multi_contig(62), pair(30000, 63, sub_rate=0.05, indel_rate=0.003), pair(8000, 64, homologous=False), genome_like(65)]
+    pm = miblast.params_from_args(DEFAULT)
+    want = b"".join(olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}))["paf"] for tf, qf in pairs)
+    for ngpu in (1, 2):
+        monkeypatch.setenv("MIBLAST_DEVICE_MAP", ",".join(["0"] * ngpu))
+        m = miblast.Multi(ngpu)
+        try:
+            paf, _ = m.align_fasta_pairs(pairs, pm)
+        finally:
+            m.close()
+        assert paf == want, ngpu
+
+
+def test_run_kegalign_front_end_uses_every_gpu_of_the_job(olz, tmp_path, monkeypatch):
+    """bin/run_kegalign with the argv of local_alignment.py:54-58 and --num_gpu 2: same bytes as --num_gpu 1 and as the oracle,
+    empty stderr (the GPU branch greps it, :75-83)."""
+    tf, qf = genome_like(303)
+    (tmp_path / "A.fa").write_bytes(tf)
+    (tmp_path / "B.fa").write_bytes(qf)
+    _, want = _oracle(olz, tf, qf, KEG_DEFAULT)
+    env = dict(os.environ, MIBLAST_DEVICE_MAP="0,0", MIBLAST_BLOCK_BASES="15000")
+    outs = []
+    for ngpu in ("1", "2"):
+        p = subprocess.run([os.path.join(ROOT, "bin", "run_kegalign"), str(tmp_path / "A.fa"), str(tmp_path / "B.fa"), "--format=paf:wfmash",
+                            *KEG_DEFAULT, "--num_gpu", ngpu, "--num_threads", "2"], capture_output=True, env=env)
+        assert p.returncode == 0 and p.stderr == b"", p.stderr
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] == want["paf"]
+    p = subprocess.run([os.path.join(ROOT, "bin", "run_kegalign"), str(tmp_path / "A.fa"), str(tmp_path / "B.fa"), "--format=paf:wfmash",
+                        *KEG_DEFAULT, "--num_gpu", "3"], capture_output=True, env=env)
+    assert p.returncode != 0 and b"num_gpu" in p.stderr
+
+
+def test_limits_of_the_blocked_path_are_refused_loudly(monkeypatch):
+    from cactus_amd import miblast
+    tf, qf = genome_like(404)
+    monkeypatch.setenv("MIBLAST_BLOCK_BASES", "9000")
+    m = miblast.Multi(1)
+    try:
+        with pytest.raises(miblast.MiblastError, match="queryhspbest"):
+            m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(DEFAULT))
+        monkeypatch.setenv("MIBLAST_BLOCK_BASES", "2000")          # smaller than a contig
+        with pytest.raises(miblast.MiblastError, match="longer than"):
+            m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(KEG_DEFAULT))
+    finally:
+        m.close()
