@@ -291,10 +291,11 @@ def run_rank(a):
         try:
             # the DP is VALU / issue bound, so its cells/s are also put against the int32 VALU peak: evaluated cells
             # (speculative ones included) x the ~10 integer operations the recurrence needs per cell (3 max, 3 add, score lookup,
-            # 2 compares for the y-drop test, trace code) / (CUs x 4 SIMDs x 16 lanes x clock)
+            # 2 compares for the y-drop test, trace code) / (CUs x 4 SIMD-32 units x 32 lanes x clock = the int32 VALU peak,
+            # half the 157 TFLOP/s fp32 FMA figure of MI355X_MICROARCH.md)
             prop = torch.cuda.get_device_properties(local_rank)
             clock_hz = float(getattr(prop, "clock_rate", 2_400_000)) * 1e3
-            peak_ops = prop.multi_processor_count * 4 * 16 * clock_hz
+            peak_ops = prop.multi_processor_count * 4 * 32 * clock_hz
             cells_per_s = tot["dp_cells_run"] / max(1e-12, tot["t_dp_kernel_ms"] * 1e-3 / world)
             out["roofline"]["valu"] = {"cells_evaluated_per_s_per_gpu": cells_per_s, "min_int_ops_per_cell": 10, "peak_lane_ops_per_s": peak_ops,
                                        "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9}

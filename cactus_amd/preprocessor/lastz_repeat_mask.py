@@ -106,20 +106,33 @@ def covered_intervals(general_lines, M: int = 1, origin_one: bool = False, query
     return "".join(out)
 
 
-def softmask_intervals(fasta_text: str, interval_lines, origin_one: bool = False, unmask: bool = False, wrap: int = 100) -> str:
-    """cactus_fasta_softmask_intervals.py: lower-case the listed intervals of each sequence."""
+def softmask_intervals(fasta_text: str, interval_lines, origin_one: bool = False, unmask: bool = False, wrap: int = 100, min_length=None) -> str:
+    """cactus_fasta_softmask_intervals.py:80-155: lower-case the listed intervals (`chrom start end`, origin-zero half-open, or
+    origin-one closed) of each sequence; output wrapped at `wrap`.  Error behaviour as the script's asserts: a malformed or empty
+    interval, two sequences of one name, or intervals for a sequence the FASTA does not hold raise AssertionError."""
     by_chrom = {}
-    for line in interval_lines:
+    for n, line in enumerate(interval_lines, 1):
         line = line.strip()
         if not line or line.startswith("#"):
             continue
-        c, s, e = line.split()[:3]
-        s, e = int(s), int(e)
-        if origin_one:
-            s -= 1
-        by_chrom.setdefault(c, []).append((s, e))
+        f = line.split()
+        assert len(f) >= 3, "not enough fields (line %s): %s" % (n, line)
+        try:
+            c, s, e = f[0], int(f[1]), int(f[2])
+            if origin_one:
+                s -= 1
+            if s < 0 or s >= e:
+                raise ValueError
+        except ValueError:
+            raise AssertionError("bad line (line %s): %s" % (n, line))
+        by_chrom.setdefault(c, [])
+        if min_length is None or e - s >= min_length:
+            by_chrom[c].append((s, e))
     out = []
+    seen = set()
     for name, seq in _fasta_records(fasta_text):
+        assert name not in seen, "more than one sequence is named %s" % name
+        seen.add(name)
         if unmask:
             seq = seq.upper()
         arr = np.frombuffer(seq.encode(), dtype=np.uint8).copy()
@@ -130,6 +143,8 @@ def softmask_intervals(fasta_text: str, interval_lines, origin_one: bool = False
         seq = arr.tobytes().decode()
         out.append(">%s\n" % name)
         out.extend(seq[i:i + wrap] + "\n" for i in range(0, len(seq), wrap))
+    missing = [c for c in by_chrom if c not in seen]
+    assert missing == [], "missing fasta sequence %s" % (", ".join(missing))
     return "".join(out)
 
 
