@@ -101,12 +101,17 @@ def _run_inprocess(lastz_cmd, work_dir, alignment_file):
     rc = lib.miblast_params_from_argv(len(argv), arr, C.byref(p), files, C.byref(ng), C.byref(nt))
     if rc != 0:
         raise RuntimeError("Command {} exited {}: stderr={}".format(lastz_cmd, 2, lib.miblast_last_error().decode()))
-    ctx = miblast.Context(0)
+    # one context per GPU of the job (--num_gpu of the run_kegalign form, 1 for lastz): the block pairs of the two files are
+    # dealt to them (include/miblast.h, miblast_multi)
+    try:
+        ctx = miblast.Multi(max(1, ng.value))
+    except miblast.MiblastError as e:
+        raise RuntimeError("Command {} exited {}: stderr={}".format(lastz_cmd, 3, e))
     try:
         fd = os.open(alignment_file, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:
-            rc = lib.miblast_align_files(ctx._h, os.path.join(work_dir, files[0].decode()).encode(),
-                                         os.path.join(work_dir, files[1].decode()).encode(), C.byref(p), fd, None)
+            rc = lib.miblast_multi_align_files(ctx._h, os.path.join(work_dir, files[0].decode()).encode(),
+                                               os.path.join(work_dir, files[1].decode()).encode(), C.byref(p), fd, None)
         finally:
             os.close(fd)
         if rc != 0:

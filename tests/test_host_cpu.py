@@ -216,3 +216,46 @@ def test_inprocess_chaining_job_passes_the_config_values_to_the_c_abi(tmp_path, 
     assert open(str(out)).read() == "out\n" and calls["input"] == "x\n" and calls["closed"] and calls["device"] == 0
     assert calls["args"] == (1000000, 5000, 1, 1.0, "0.2", 10000, False)           # cactus_progressive_config.xml:108-113
     assert not os.path.exists(str(fid))
+
+
+def test_initLastz_resolves_gpu_cores_and_memory_like_the_reference(monkeypatch):
+    """ConfigWrapper.initLastz (/root/reference/src/cactus/shared/configWrapper.py:281-393): --gpu N|all -> <blast gpu> and the
+    lastzRepeatMask preprocessors; cores default to the whole machine with GPUs on (one process drives them all); --lastzCores /
+    --lastzMemory land where make_chunked_alignments reads them; realign goes off; bad values and --latest raise."""
+    import copy
+    import types
+    import xml.etree.ElementTree as ET
+    base = configWrapper.load_config()
+    ET.SubElement(base, "preprocessor", preprocessJob="lastzRepeatMask", gpu="0", active="0")
+    base.find("blast").attrib["realign"] = "1"
+    monkeypatch.setattr(configWrapper, "count_amd_gpus", lambda: 8)
+    ns = types.SimpleNamespace
+
+    cfg = configWrapper.initLastz(copy.deepcopy(base), ns(gpu="all", batchSystem="single_machine", maxCores=None, lastzCores=None, lastzMemory=None))
+    b = cfg.find("blast")
+    assert b.attrib["gpu"] == "8" and cfg.find("preprocessor").attrib["gpu"] == "8"
+    assert int(b.attrib["cpu"]) == configWrapper.cactus_cpu_count() and b.attrib["realign"] == "0"
+    assert "lastz_memory" not in b.attrib
+
+    cfg = configWrapper.initLastz(copy.deepcopy(base), ns(gpu=2, batchSystem="slurm", maxCores=None, lastzCores=16, lastzMemory=12345))
+    b = cfg.find("blast")
+    assert (b.attrib["gpu"], b.attrib["cpu"], b.attrib["lastz_memory"]) == ("2", "16", "12345")
+    assert cfg.find("preprocessor").attrib["cpu"] == "16" and cfg.find("preprocessor").attrib["lastz_memory"] == "12345"
+
+    cfg = configWrapper.initLastz(copy.deepcopy(base), ns(gpu=4, batchSystem="single_machine", maxCores=24, lastzCores=None, lastzMemory=None))
+    assert cfg.find("blast").attrib["cpu"] == "24"
+    cfg = configWrapper.initLastz(copy.deepcopy(base), ns(gpu=None, batchSystem="single_machine", maxCores=None, lastzCores=None, lastzMemory=None))
+    assert cfg.find("blast").attrib["gpu"] == "0" and "cpu" not in cfg.find("blast").attrib and cfg.find("blast").attrib["realign"] == "1"
+    legacy = copy.deepcopy(base)
+    legacy.find("blast").attrib["gpu"] = "true"                                   # old boolean configs (:322-325)
+    assert configWrapper.initLastz(legacy, ns(gpu=None, batchSystem="single_machine")).find("blast").attrib["gpu"] == "8"
+    assert configWrapper.initLastz(copy.deepcopy(base), 3).find("blast").attrib["gpu"] == "3"       # bare --gpu value
+
+    for bad, msg in ((ns(gpu="many", batchSystem="single_machine"), "Invalid value"), (ns(gpu=9, batchSystem="single_machine"), "only 8 visible"),
+                     (ns(gpu="all", batchSystem="slurm"), "--gpu N required"), (ns(gpu=2, batchSystem="slurm", lastzCores=None), "--lastzCores must be used"),
+                     (ns(gpu=1, batchSystem="single_machine", latest=True), "--latest")):
+        with pytest.raises(RuntimeError, match=msg):
+            configWrapper.initLastz(copy.deepcopy(base), bad)
+    monkeypatch.setattr(configWrapper, "count_amd_gpus", lambda: 0)
+    with pytest.raises(RuntimeError, match="Unable to automatically determine"):
+        configWrapper.initLastz(copy.deepcopy(base), ns(gpu="all", batchSystem="single_machine"))

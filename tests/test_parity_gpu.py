@@ -373,3 +373,51 @@ def test_randomised_differential_fuzz():
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz.py"), "30", "5000"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "30 cases, 0 mismatches" in p.stdout
+
+
+def test_chunked_genome_pair_through_the_job_functions(gpu_ctx, olz, tmp_path):
+    """SURVEY 8 rows a3 / a4 at reduced size (config 4's shape: chunkSize + overlapSize -> 3 x 3 chunk pairs): the mirrored
+    make_chunked_alignments (local_alignment.py:370-408: faffy chunk both genomes, one run_lastz job per chunk pair) and
+    combine_chunks (:336-356: paffy dechunk + concatenate) give exactly the per-pair oracle PAFs passed through the same dechunk,
+    in chunk-pair order; every record validates against the UNCHUNKED sequences (coordinates restored by dechunk); and the nine
+    pairs in ONE miblast_align_pairs call equal nine single calls."""
+    import copy
+    from cactus_amd import gen, miblast, pafcheck
+    from cactus_amd.paf import chunking
+    from cactus_amd.paf.local_alignment import make_chunked_alignments, select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    from localjob import LocalJob, LocalFileStore, FileID
+    cfg = copy.deepcopy(load_config())
+    cfg.find("blast").attrib.update(chunkSize="900000", overlapSize="10000")
+    t, q = gen.make_pair(2_000_000, 3001, sub_rate=0.013, indel_rate=0.002, mask_frac=0.5)
+    pa, pb = tmp_path / "A.fa", tmp_path / "B.fa"
+    gen.write_fasta(str(pa), [("id=simT|chr20", t)])
+    gen.write_fasta(str(pb), [("id=simQ|chr20", q)])
+    (tmp_path / "js").mkdir()
+    job = LocalJob(LocalFileStore(str(tmp_path / "js")))
+    dist = 0.03                                                             # <= 0.05: option set "one"
+    out = make_chunked_alignments(job, "simT", FileID.of(str(pa)), "simQ", FileID.of(str(pb)), dist, cfg)
+    got = open(str(out)).read()
+    # expectation: the same chunk files, the oracle per pair, the same dechunk
+    ca = chunking.fasta_chunk(str(pa), str(tmp_path / "ca"), 900000, 10000)
+    cb = chunking.fasta_chunk(str(pb), str(tmp_path / "cb"), 900000, 10000)
+    assert len(ca) == 3 and len(cb) == 3
+    args = select_lastz_params(dist, cfg, 0).split(" ")
+    assert args[0] == "--step=2"
+    pm = miblast.params_from_args(args)
+    po = olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_})
+    want, single = "", []
+    for a in ca:
+        for b in cb:
+            fa, fb = open(a, "rb").read(), open(b, "rb").read()
+            paf = olz.align(fa, fb, po, details=False)["paf"]
+            single.append((fa, fb, paf))
+            want += "".join(chunking.paf_dechunk_line(l) for l in paf.decode().splitlines())
+    assert got == want and got.count("\n") >= 6
+    full = {"id=simT|chr20": t.tobytes().decode(), "id=simQ|chr20": q.tobytes().decode()}
+    assert pafcheck.check_paf(got, full, full) == got.count("\n")
+    sets = [(gpu_ctx.seqset_from_fasta_bytes(fa), gpu_ctx.seqset_from_fasta_bytes(fb)) for fa, fb, _ in single]
+    batched = gpu_ctx.align_pairs(sets, pm)
+    assert [r.paf for r in batched] == [p for _, _, p in single]
+    for a, b in sets:
+        a.close(); b.close()
