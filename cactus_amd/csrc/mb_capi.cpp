@@ -51,7 +51,7 @@ extern "C" {
 void miblast_params_default(miblast_params *p) {
     p->step = 1; p->transitions = 1; p->xdrop = 910; p->ydrop = 9400; p->hspthresh = 3000; p->gappedthresh = -1;
     p->gap_open = 400; p->gap_extend = 30; p->entropy = 1; p->queryhspbest = 0; p->ambiguous_n = 1; p->gapped = 1;
-    p->format = 0; p->markend = 0; p->queryhsplimit = 0;
+    p->format = 0; p->markend = 0; p->queryhsplimit = 0; p->diag_hash16 = 0; p->walls = 0;
 }
 
 int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const char *files[2], int *num_gpu, int *num_threads) {
@@ -111,7 +111,11 @@ int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const cha
             // "has no effect when --ungapped is passed" (cactus_lastzRepeatMask.py:100); accepted for that case only
             if (!val || strncmp(val, "keep,nowarn:", 12) || !parse_int(val + 12, v) || v < 1) return bad(a, "unsupported --querydepth form");
             querydepth_seen = true;
-        } else if (key == "--num_gpu") {                       // run_kegalign form: "--num_gpu N" (local_alignment.py:58)
+        } else if (key == "--miblast-diag") {                  // oracle comparison switches: parsed so that one argv serves both, refused at run time
+            if (!val || (strcmp(val, "exact") && strcmp(val, "hash16"))) return bad(a, "unsupported --miblast-diag form");
+            p->diag_hash16 = !strcmp(val, "hash16");
+        } else if (key == "--miblast-walls" && !val) p->walls = 1;
+        else if (key == "--num_gpu") {                       // run_kegalign form: "--num_gpu N" (local_alignment.py:58)
             if (val) { if (!parse_int(val, v) || v < 1) return bad(a, "bad value for option"); }
             else { if (i + 1 >= argc || !parse_int(argv[++i], v) || v < 1) return bad(a, "bad value for option"); }
             ng = (int)v;

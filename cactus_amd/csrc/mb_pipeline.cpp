@@ -1691,6 +1691,11 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     MB_HIP(hipSetDevice(ctx.device));
     Pool::Hot keep_workers_awake;
     miblast_params p = pin;
+    if (p.diag_hash16 || p.walls) {
+        set_error("diag=hash16 / walls are comparison modes of the CPU oracle only -- oracle only (SURVEY A.9 #4, #8): the MI355X path implements exact "
+                  "per-diagonal suppression and no walls");
+        return MIBLAST_EINVAL;
+    }
     if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
     if (p.step < 1) p.step = 1;
     std::vector<std::unique_ptr<PairJob>> store;

@@ -55,6 +55,11 @@ typedef struct miblast_params {
     int32_t format;        /* 0 = paf:wfmash ; 1 = general:name1,zstart1,end1,name2,zstart2+,end2+ (HSP list, needs gapped=0) */
     int32_t markend;       /* --markend: terminate the output with "# lastz end-of-file"                  */
     int32_t queryhsplimit; /* --queryhsplimit=keep,nowarn:N : per query sequence and strand keep only the first N HSPs found; 0 = off */
+    /* The oracle's named comparison switches (oracle/lastz_oracle.h), kept in the same place so that the
+     * two structs stay copy-compatible.  The MI355X path implements the default reading only: a non-zero value is refused
+     * with MIBLAST_EINVAL, never ignored.                                                                                  */
+    int32_t diag_hash16;   /* --miblast-diag=hash16 */
+    int32_t walls;         /* --miblast-walls       */
 } miblast_params;
 
 void miblast_params_default(miblast_params *p);

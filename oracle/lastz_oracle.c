@@ -49,6 +49,7 @@ void olz_params_default(olz_params *p) {
     p->format = 0;
     p->markend = 0;
     p->queryhsplimit = 0;
+    p->diag_hash16 = 0; p->walls = 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -313,7 +314,19 @@ typedef struct {
     int64_t n_ops;
 } side_t;
 
-static side_t one_sided(ctx_t *x, int64_t t0, int64_t q0, int dir, int64_t na, int64_t nb) {
+/* walls (olz_params.walls): per earlier alignment, the target interval its path occupies in every query row it spans */
+typedef struct { int64_t q_lo, q_hi; int32_t *tmin, *tmax; } wall_t;
+typedef struct { const wall_t *w; int64_t n; } walls_t;
+
+static int walled(const walls_t *ws, int64_t t, int64_t q) {
+    for (int64_t m = 0; m < ws->n; m++) {
+        const wall_t *w = &ws->w[m];
+        if (q >= w->q_lo && q < w->q_hi && w->tmin[q - w->q_lo] >= 0 && t >= w->tmin[q - w->q_lo] && t <= w->tmax[q - w->q_lo]) return 1;
+    }
+    return 0;
+}
+
+static side_t one_sided(ctx_t *x, int64_t t0, int64_t q0, int dir, int64_t na, int64_t nb, const walls_t *ws) {
     const int32_t O = x->p->gap_open, E = x->p->gap_extend, Y = x->p->ydrop;
     const uint8_t *tc = x->tc, *qc = x->qc;
     side_t r;
@@ -370,8 +383,12 @@ static side_t one_sided(ctx_t *x, int64_t t0, int64_t q0, int dir, int64_t na, i
             else if (Dv >= Iv) { Cv = Dv; src = 1; }
             else { Cv = Iv; src = 2; }
             r.cells++;
+            /* walls switch: the cell pairs target base j with query base i; if that pair lies on an earlier path the cell is
+             * dead and neither gap state survives it */
+            int blocked = ws && ws->n && j >= 1 && walled(ws, dir > 0 ? t0 + j - 1 : t0 - j, dir > 0 ? q0 + i - 1 : q0 - i);
+            if (blocked) { Cv = NEG; Dv = NEG; Iv = NEG; }
             if (Cv > best) { best = Cv; bi = i; bj = j; }
-            int alive = (Cv >= best - Y);
+            int alive = !blocked && (Cv >= best - Y);
             if (!alive) Cv = NEG;
             Cc[idx] = Cv; Dc[idx] = Dv; Cleft = Cv;
             if (tlen + 1 > tcap) { tcap *= 2; tr = realloc(tr, (size_t)tcap); }
@@ -459,6 +476,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
 
     uint8_t *qrc = revcomp_codes(Q);
     int64_t ndiag = T->total + Q->total + 2;
+    if (ndiag < 65536) ndiag = 65536;                      /* diag_hash16 indexes 2^16 entries */
     int32_t *extent = (int32_t *)malloc((size_t)ndiag * 4);
 
     olz_hsp *hsps = NULL; int64_t nh = 0, caph = 0;          /* all strands, filtered */
@@ -491,7 +509,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
                     int64_t pt = posv[k - 1];
                     int64_t t_end = pt + SEED_SPAN, q_end = q + SEED_SPAN;
                     res->c.seed_hits++;
-                    int64_t d = t_end - q_end + Q->total;
+                    int64_t d = p.diag_hash16 ? ((t_end - q_end) & 0xFFFF) : t_end - q_end + Q->total;      /* A.4: exact / lastz's 16-bit hash */
                     if (q_end <= extent[d]) continue;          /* suppression rule (A.9 #4) */
                     olz_hsp h = ungapped(&x, t_end, q_end);
                     res->c.hits_extended++;
@@ -554,6 +572,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
                 res->c.anchors += nan_;
                 int64_t first_aln = na_;
                 int64_t qlo = Q->starts[qc_i], qhi = qlo + Q->lens[qc_i];
+                wall_t *wl = NULL; int64_t nwl = 0, capwl = 0;         /* paths of this unit's alignments (walls switch) */
                 for (int64_t k = 0; k < nan_; k++) {
                     int32_t at = an[k].t, aq = an[k].q;
                     int covered = 0;
@@ -565,8 +584,9 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
                     if (covered) { res->c.anchors_skipped++; continue; }
                     int tcg = contig_of(T, at);
                     int64_t tlo = T->starts[tcg], thi = tlo + T->lens[tcg];
-                    side_t R = one_sided(&x, at, aq, +1, thi - at, qhi - aq);
-                    side_t Ls = one_sided(&x, at, aq, -1, at - tlo, aq - qlo);
+                    walls_t ws; ws.w = wl; ws.n = p.walls ? nwl : 0;
+                    side_t R = one_sided(&x, at, aq, +1, thi - at, qhi - aq, &ws);
+                    side_t Ls = one_sided(&x, at, aq, -1, at - tlo, aq - qlo, &ws);
                     res->c.dp_sides += 2;
                     res->c.dp_cells += R.cells + Ls.cells;
                     res->c.dp_rows += R.rows + Ls.rows;
@@ -585,6 +605,11 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
                         int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
                         int64_t ncol = Ls.n_ops + R.n_ops;
                         uint32_t cur_op = 0, cur_len = 0;
+                        wall_t W; W.q_lo = A.q_lo; W.q_hi = A.q_hi; W.tmin = W.tmax = NULL;
+                        if (p.walls) {
+                            W.tmin = (int32_t *)malloc((size_t)(A.q_hi - A.q_lo + 1) * 4); W.tmax = (int32_t *)malloc((size_t)(A.q_hi - A.q_lo + 1) * 4);
+                            for (int64_t r = 0; r <= A.q_hi - A.q_lo; r++) { W.tmin[r] = -1; W.tmax[r] = -1; }
+                        }
                         for (int64_t c = 0; c < ncol; c++) {
                             uint8_t o = (c < Ls.n_ops) ? Ls.ops[c] : R.ops[R.n_ops - 1 - (c - Ls.n_ops)];
                             uint32_t op;
@@ -594,6 +619,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
                                 int32_t d = (int32_t)(tt - qq);
                                 if (d < dmin) dmin = d;
                                 if (d > dmax) dmax = d;
+                                if (p.walls) { int64_t r = qq - A.q_lo; if (W.tmin[r] < 0) W.tmin[r] = (int32_t)tt; W.tmax[r] = (int32_t)tt; }
                                 tt++; qq++;
                             } else if (o == 2) { op = 2; qq++; }
                             else { op = 3; tt++; }
@@ -604,11 +630,14 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
                         A.n_ops = nops - A.ops_off;
                         A.dmin = dmin; A.dmax = dmax;
                         PUSH(alns, na_, capa, A);
+                        if (p.walls) PUSH(wl, nwl, capwl, W);
                     }
                     free(R.ops); free(Ls.ops);
                 }
                 aln_ranges[qc_i * 2 + strand].a0 = first_aln;
                 aln_ranges[qc_i * 2 + strand].a1 = na_;
+                for (int64_t m = 0; m < nwl; m++) { free(wl[m].tmin); free(wl[m].tmax); }
+                free(wl);
                 free(an);
             }
         }

@@ -51,6 +51,13 @@ typedef struct olz_params {
     int32_t format;        /* 0 paf:wfmash ; 1 general:name1,zstart1,end1,name2,zstart2+,end2+ (ungapped HSPs) */
     int32_t markend;       /* --markend */
     int32_t queryhsplimit; /* --queryhsplimit=keep,nowarn:N (0 = off): first N HSPs found per query contig and strand */
+    /* Named switches for the two points of SURVEY A.9 (#4, #8) where a real lastz may differ from the rules fixed in A.10.
+     * Both default to 0 (= A.10, what the MI355X path implements and every parity test uses); they exist so that the day a
+     * lastz binary is at hand (tests/test_p1_lastz_binary.py) the oracle can be flipped to the other reading at once.      */
+    int32_t diag_hash16;   /* 1: diagonal suppression state indexed by (t_end - q_end) & 0xFFFF as lastz's diagEnd[] (A.4): hits on
+                              colliding diagonals are silently dropped; sequential in hit generation order                   */
+    int32_t walls;         /* 1: base pairs on the path of an earlier alignment of the same query sequence and strand are hard
+                              walls for later DPs (A.7): a cell pairing such bases is dead and no gap passes through it      */
 } olz_params;
 
 void olz_params_default(olz_params *p);

@@ -156,3 +156,58 @@ def test_reference_parameter_pins():
     for node in ("lastzArguments", "kegalignArguments"):
         for k, v in cfg.find("blast").find(node).attrib.items():
             miblast.params_from_args(v.split())
+
+
+def test_named_switches_for_the_points_a_real_lastz_may_differ_on(olz):
+    """diag=hash16 (lastz's 16-bit diagEnd hash, A.4) and walls (earlier alignments bound later DPs, A.7) are
+    default-off modes of the oracle.  Off = A.10 = every committed expectation; on, they change what they are meant to change."""
+    import numpy as np
+    from cactus_amd import gen, pafcheck
+    rng = np.random.default_rng(5)
+    p0 = olz.default_params(hspthresh=2200, gappedthresh=2400, ydrop=4000)
+    assert (p0.diag_hash16, p0.walls) == (0, 0)
+    # (1) hash16: the query matches two target copies 65536 apart -- their diagonals collide in the 16-bit hash, so after the
+    # first copy's extension the hits of the second copy at the same query positions look "already extended" and are dropped;
+    # with exact diagonals both copies are extended
+    a = gen.random_sequence(1500, rng)
+    t = np.concatenate([a, gen.random_sequence(65536 - 1500, rng), gen.mutate(a, rng, 0.03, 0.0), gen.random_sequence(300, rng)])
+    q = gen.mutate(a, rng, 0.03, 0.0)
+    tf, qf = gen.fasta_bytes([("T|h", t)]), gen.fasta_bytes([("Q|h", q)])
+    exact = olz.align(tf, qf, p0)
+    hashed = olz.align(tf, qf, olz.default_params(hspthresh=2200, gappedthresh=2400, ydrop=4000, diag_hash16=1))
+    assert exact["counters"]["seed_hits"] == hashed["counters"]["seed_hits"]
+    assert hashed["counters"]["hits_extended"] < exact["counters"]["hits_extended"]            # collisions drop hits (A.4 "silently")
+    assert len(hashed["hsps"]) <= len(exact["hsps"])
+    # without a collision the two modes agree byte for byte
+    tf2, qf2 = gen.fasta_bytes([("T|n", t[:30000])]), gen.fasta_bytes([("Q|n", gen.mutate(t[2000:12000], rng, 0.05, 0.003))])
+    assert olz.align(tf2, qf2, p0)["paf"] == olz.align(tf2, qf2, olz.default_params(hspthresh=2200, gappedthresh=2400, ydrop=4000, diag_hash16=1))["paf"]
+    # (2) walls: a tandem duplication in the query makes the second alignment run along the first one's path region; with walls no
+    # base pair is used twice, without them later alignments may overlap earlier ones
+    unit = gen.random_sequence(2500, rng)
+    t3 = np.concatenate([gen.random_sequence(800, rng), unit, gen.random_sequence(800, rng)])
+    q3 = np.concatenate([gen.random_sequence(500, rng), gen.mutate(unit, rng, 0.04, 0.002), gen.mutate(unit, rng, 0.04, 0.002), gen.random_sequence(500, rng)])
+    tf3, qf3 = gen.fasta_bytes([("T|w", t3)]), gen.fasta_bytes([("Q|w", q3)])
+    free = olz.align(tf3, qf3, p0)
+    walled = olz.align(tf3, qf3, olz.default_params(hspthresh=2200, gappedthresh=2400, ydrop=4000, walls=1))
+    full = {"T|w": t3.tobytes().decode(), "Q|w": q3.tobytes().decode()}
+    assert pafcheck.check_paf(walled["paf"].decode(), full, full) >= 2
+
+    def pairs(res):
+        used = []
+        for al, ops in zip(res["alns"], res["ops"]):
+            tt, qq = al[3], al[5]
+            s = set()
+            for o in ops:
+                ln, op = o >> 2, o & 3
+                if op < 2:
+                    s.update((al[0], tt + k, qq + k) for k in range(ln)); tt += ln; qq += ln
+                elif op == 2:
+                    qq += ln
+                else:
+                    tt += ln
+            used.append(s)
+        return used
+
+    w = pairs(walled)
+    assert all(not (w[i] & w[j]) for i in range(len(w)) for j in range(i + 1, len(w)))          # no base pair on two paths
+    assert walled["alns"][0] == free["alns"][0]                                                # the first alignment has nothing to respect

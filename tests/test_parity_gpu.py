@@ -421,3 +421,16 @@ def test_chunked_genome_pair_through_the_job_functions(gpu_ctx, olz, tmp_path):
     assert [r.paf for r in batched] == [p for _, _, p in single]
     for a, b in sets:
         a.close(); b.close()
+
+
+def test_oracle_only_comparison_switches_are_refused_not_ignored(gpu_ctx):
+    """diag=hash16 / walls exist in the oracle for the day a lastz binary can be compared; the MI355X path
+    implements the default reading only and must say so rather than silently compute something else."""
+    from cactus_amd import miblast
+    from cases import pair, KEG_DEFAULT
+    tf, qf = pair(5000, 3)
+    T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+    for extra in (["--miblast-diag=hash16"], ["--miblast-walls"]):
+        with pytest.raises(miblast.MiblastError, match="oracle only"):
+            gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + extra))
+    assert gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + ["--miblast-diag=exact"])).paf
