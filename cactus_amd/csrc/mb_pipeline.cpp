@@ -970,7 +970,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 640;
         if (relay_s0_env < 0) relay_s0 = nsides > 96 ? 256 : 64;
         if (relay_w_env <= 0) relay_w = nsides > 96 ? 192 : 128;
-        const bool plant_at_once = nsides <= 96 && env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1) != 0;
+        const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: when few sides are in flight, 2: always
+        const bool plant_at_once = plant_env == 2 || (nsides <= 96 && plant_env != 0);
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
         const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : win_typ <= 224 ? kDpWave2x4 : kDpWave8;
