@@ -390,59 +390,124 @@ __device__ __forceinline__ unsigned long long load8(const uint8_t *p) {
 // Heads of the diagonal runs of the sorted hit keys, compacted into two lists: runs of at most kLongRun hits go to
 // the lane-per-run kernel, longer ones (busy diagonals of real homology: hundreds to millions of hits, almost all of
 // them suppressed) to the wave-per-run kernel.  One atomic pair per 1024-key block; list order is irrelevant.
-constexpr int kLongRun = 32;                  // equal cost to 12 on random data; 4 is 7x slower (wave-per-run has a fixed cost)
+// The threshold follows the hit density (launch_ungapped): on dense random data a diagonal holds several chance hits and the
+// lane-per-run kernel is the cheap one (32: equal cost to 12 there, 4 is 7x slower -- the wave-per-run kernel has a fixed
+// cost); on a small or sparse pair the runs longer than a handful are real homology, where one lane walking 32 extensions
+// of hundreds of columns each is the critical path of the whole launch.
+constexpr int kLongRunMax = 32;
 
-__global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits,
-                                                    unsigned *__restrict__ heads_short, unsigned *__restrict__ heads_long,
-                                                    unsigned *__restrict__ n_heads /* [0] short, [1] long */) {
-    __shared__ unsigned cnt_s[16], cnt_l[16];
-    __shared__ unsigned base_s, base_l;
+constexpr int kRunClasses = 4;                // lane-per-run lists by run length: 1, 2-3, 4-7, 8..kLongRun (a wave then holds runs of similar length)
+
+__global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
+                                                    unsigned *__restrict__ heads, unsigned *__restrict__ n_heads /* [0..3] short classes, [4] long */) {
+    // list c of the short classes starts at heads + off(c): class 0 at 0 (<= n runs), class 1 at n (<= n/2), class 2 at 3n/2 (<= n/4),
+    // class 3 at 7n/4 (<= n/8); the long-run list at 15n/8 + 8 (<= n/(kLongRun+1) <= n/5)
+    __shared__ unsigned cnt[kRunClasses + 1][16];
+    __shared__ unsigned base[kRunClasses + 1];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool head = false, is_long = false;
+    int cls = -1;
     if (i < n_hits) {
         const uint32_t d = (uint32_t)(keys[i] >> 32);
-        head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != d);
-        if (head) is_long = (i + kLongRun < n_hits) && ((uint32_t)(keys[i + kLongRun] >> 32) == d);
+        const bool head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != d);
+        auto same = [&](int k) -> bool { return (i + k < n_hits) && ((uint32_t)(keys[i + k] >> 32) == d); };
+        if (head) cls = same(kLongRun) ? kRunClasses : same(7) ? 3 : same(3) ? 2 : same(1) ? 1 : 0;
     }
-    const unsigned long long ms = __ballot(head && !is_long), ml = __ballot(head && is_long);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { cnt_s[w] = (unsigned)__popcll(ms); cnt_l[w] = (unsigned)__popcll(ml); }
+    unsigned long long m[kRunClasses + 1];
+#pragma unroll
+    for (int c = 0; c <= kRunClasses; c++) { m[c] = __ballot(cls == c); if (lane == 0) cnt[c][w] = (unsigned)__popcll(m[c]); }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned ts = 0, tl = 0;
-        for (int k = 0; k < 16; k++) { unsigned c = cnt_s[k]; cnt_s[k] = ts; ts += c; c = cnt_l[k]; cnt_l[k] = tl; tl += c; }
-        base_s = ts ? atomicAdd(&n_heads[0], ts) : 0u;
-        base_l = tl ? atomicAdd(&n_heads[1], tl) : 0u;
+    if (threadIdx.x <= kRunClasses) {
+        const int c = threadIdx.x;
+        unsigned t = 0;
+        for (int k = 0; k < 16; k++) { const unsigned v = cnt[c][k]; cnt[c][k] = t; t += v; }
+        base[c] = t ? atomicAdd(&n_heads[c], t) : 0u;
     }
     __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (head && !is_long) heads_short[base_s + cnt_s[w] + (unsigned)__popcll(ms & below)] = (unsigned)i;
-    if (head && is_long) heads_long[base_l + cnt_l[w] + (unsigned)__popcll(ml & below)] = (unsigned)i;
+    if (cls >= 0) {
+        const uint64_t n = (uint64_t)n_hits;
+        const uint64_t off = cls == 0 ? 0 : cls == 1 ? n : cls == 2 ? n + n / 2 : cls == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
+        heads[off + base[cls] + cnt[cls][w] + (unsigned)__popcll(m[cls] & ((1ull << lane) - 1ull))] = (unsigned)i;
+    }
 }
 
-// one x-drop direction, 8 columns per load, branch-free inside a chunk (every per-lane condition is a select)
+// One x-drop direction, 8 columns per load, branch-free inside a chunk (every per-lane condition is a select).  The first
+// NPRE chunks of both sequences arrive PRELOADED: the extension of a chance hit ends within ~35 columns to the left (the seed
+// itself is 19 of them) and ~17 to the right, and a chunk-by-chunk loop would pay one dependent cache-line round trip per
+// chunk and sequence -- the whole cost of this stage.  The caller issues every preload of both directions before the first
+// column is scored, so a typical hit waits for memory once.
+struct XState { int run, best, bpos; bool live; };
+
+// four substitution scores at once: byte m of the result = score(a_m, b_m) + 128 for the code bytes a_m, b_m of a4 / b4.
+// HOXD70 is a function of (a ^ b) and of whether a is C/G: one v_perm_b32 over an 8-byte table; N (code bit 2) scores -100.
+// (Separator bytes have bit 2 set as well: the caller deals with them before looking at the score.)
+__device__ __forceinline__ uint32_t scores4(const uint32_t a4, const uint32_t b4) {
+    const uint32_t d = (a4 ^ b4) & 0x03030303u;                       // 0 match, 2 transition, 1 / 3 the two transversion classes
+    const uint32_t cg = ((a4 ^ (a4 >> 1)) & 0x01010101u) << 2;        // 4 where a is C or G
+    constexpr uint32_t kAT = 219u | (14u << 8) | (97u << 16) | (5u << 24);      // a in {A,T}: 91, -114, -31, -123 (+128)
+    constexpr uint32_t kCG = 228u | (14u << 8) | (97u << 16) | (3u << 24);      // a in {C,G}: 100, -114, -31, -125
+    const uint32_t s = __builtin_amdgcn_perm(kCG, kAT, d | cg);       // selector 0..3 -> kAT, 4..7 -> kCG
+    const uint32_t nm = (((a4 | b4) & 0x04040404u) >> 2) * 255u;      // 0xFF where either base is N
+    return (s & ~nm) | (0x1c1c1c1cu & nm);                            // -100 + 128
+}
+
 template <int DIR>
-__device__ __forceinline__ void xdrop_dir(const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp, const int xdrop,
-                                          int &best_out, int &pos_out, unsigned long long &ncols) {
-    int run = 0, best = 0, bpos = 0;
-    bool live = true;
-    for (int c = 0; live; c++) {
-        const unsigned long long a8 = DIR > 0 ? load8(tp + 8 * c) : load8(tp - 8 * (c + 1));
-        const unsigned long long b8 = DIR > 0 ? load8(qp + 8 * c) : load8(qp - 8 * (c + 1));
+__device__ __forceinline__ void xdrop_chunk(const unsigned long long a8, const unsigned long long b8, const int c, const int xdrop,
+                                            XState &x, unsigned long long &ncols) {
+    if (((a8 | b8) & 0x8080808080808080ull) != 0ull) {
+        // a contig separator (0xFF) inside the chunk -- the only codes with bit 7: the extension ends there, column by column
 #pragma unroll
         for (int m = 0; m < 8; m++) {
             const int sh = DIR > 0 ? 8 * m : 8 * (7 - m);
             const unsigned a = (unsigned)(a8 >> sh) & 0xFFu, b = (unsigned)(b8 >> sh) & 0xFFu;
-            live = live & (a != kSep) & (b != kSep);
-            run = live ? run + sub_score(a, b) : run;
-            ncols += live ? 1u : 0u;
-            const bool upd = live & (run > best);
-            best = upd ? run : best;
-            bpos = upd ? 8 * c + m + 1 : bpos;
-            live = live & (upd | (run >= best - xdrop));
+            x.live = x.live & (a != kSep) & (b != kSep);
+            x.run = x.live ? x.run + sub_score(a, b) : x.run;
+            ncols += x.live ? 1u : 0u;
+            const bool upd = x.live & (x.run > x.best);
+            x.best = upd ? x.run : x.best;
+            x.bpos = upd ? 8 * c + m + 1 : x.bpos;
+            x.live = x.live & (upd | (x.run >= x.best - xdrop));
         }
+        return;
     }
-    best_out = best; pos_out = bpos;
+    const uint32_t s_lo = scores4((uint32_t)a8, (uint32_t)b8), s_hi = scores4((uint32_t)(a8 >> 32), (uint32_t)(b8 >> 32));
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const int k = DIR > 0 ? m : 7 - m;                               // byte of the chunk holding column m
+        const int sc = (int)(((k < 4 ? s_lo : s_hi) >> (8 * (k & 3))) & 0xFFu) - 128;
+        x.run = x.live ? x.run + sc : x.run;
+        ncols += x.live ? 1u : 0u;
+        const bool upd = x.live & (x.run > x.best);
+        x.best = upd ? x.run : x.best;
+        x.bpos = upd ? 8 * c + m + 1 : x.bpos;
+        x.live = x.live & (upd | (x.run >= x.best - xdrop));
+    }
+}
+
+template <int DIR, int NPRE>
+__device__ __forceinline__ void xdrop_preload(const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp,
+                                              unsigned long long (&a)[NPRE], unsigned long long (&b)[NPRE]) {
+#pragma unroll
+    for (int c = 0; c < NPRE; c++) {
+        a[c] = DIR > 0 ? load8(tp + 8 * c) : load8(tp - 8 * (c + 1));
+        b[c] = DIR > 0 ? load8(qp + 8 * c) : load8(qp - 8 * (c + 1));
+    }
+}
+
+template <int DIR, int NPRE>
+__device__ __forceinline__ void xdrop_dir(const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp, const int xdrop,
+                                          const unsigned long long (&a)[NPRE], const unsigned long long (&b)[NPRE],
+                                          int &best_out, int &pos_out, unsigned long long &ncols) {
+    XState x{0, 0, 0, true};
+#pragma unroll
+    for (int c = 0; c < NPRE; c++)
+        if (x.live) xdrop_chunk<DIR>(a[c], b[c], c, xdrop, x, ncols);
+    for (int c = NPRE; x.live; c++) {
+        const unsigned long long a8 = DIR > 0 ? load8(tp + 8 * c) : load8(tp - 8 * (c + 1));
+        const unsigned long long b8 = DIR > 0 ? load8(qp + 8 * c) : load8(qp - 8 * (c + 1));
+        xdrop_chunk<DIR>(a8, b8, c, xdrop, x, ncols);
+    }
+    best_out = x.best; pos_out = x.bpos;
 }
 
 __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__restrict__ keys, int64_t n_hits,
@@ -451,9 +516,28 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
                                                   int32_t *__restrict__ extent, int xdrop, int K, DevHsp *__restrict__ hsps,
                                                   int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     unsigned long long n_ext = 0, n_cols = 0;
-    const unsigned n_heads = *n_heads_p;
+    // The blocks are dealt to the run-length classes, longest runs first (they start early, and a wave holds runs of similar
+    // length instead of waiting for its longest lane): class c owns ceil(n_c / 256) blocks.
+    unsigned n_heads = 0;
+    uint64_t list_off = 0;
+    {
+        const uint64_t n = (uint64_t)n_hits;
+        unsigned blk = blockIdx.x;
+        bool found = false;
+#pragma unroll
+        for (int c = kRunClasses - 1; c >= 0; c--) {
+            const unsigned nc = n_heads_p[c], nb = (nc + blockDim.x - 1) / blockDim.x;
+            if (!found && blk < nb) { found = true; n_heads = nc; list_off = c == 0 ? 0 : c == 1 ? n : c == 2 ? n + n / 2 : n + n / 2 + n / 4; }
+            if (!found) blk -= nb;
+        }
+        if (!found) return;
+        heads += list_off;
+        n_heads = min(n_heads, (blk + 1) * blockDim.x);
+        n_heads = blk * blockDim.x + threadIdx.x < n_heads ? n_heads : 0;
+        list_off = blk;                                                   // (reused: block index inside the class)
+    }
     // one diagonal run per thread (a long HSP must not delay further runs queued behind it in the same lane)
-    for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heads; h = n_heads) {
+    for (unsigned h = (unsigned)list_off * blockDim.x + threadIdx.x; h < n_heads; h = n_heads) {
         int64_t k = heads[h];
         unsigned long long key = keys[k];
         const uint32_t dq = (uint32_t)(key >> 32);
@@ -465,8 +549,12 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
                 // Separators (0xFF) bound every contig on both sides; device buffers carry kDevPad pad bytes, so the
                 // 8-byte loads may overrun harmlessly.  Left covers the seed, then beyond; right starts at the seed end.
                 int bestL, bl, bestR, br;
-                xdrop_dir<-1>(tc + t_end, qc + q_end, xdrop, bestL, bl, n_cols);
-                xdrop_dir<+1>(tc + t_end, qc + q_end, xdrop, bestR, br, n_cols);
+                constexpr int kPreL = 5, kPreR = 3;                      // 40 columns to the left (the seed is 19 of them), 24 to the right
+                unsigned long long aL[kPreL], bL[kPreL], aR[kPreR], bR[kPreR];
+                xdrop_preload<-1, kPreL>(tc + t_end, qc + q_end, aL, bL);
+                xdrop_preload<+1, kPreR>(tc + t_end, qc + q_end, aR, bR);
+                xdrop_dir<-1, kPreL>(tc + t_end, qc + q_end, xdrop, aL, bL, bestL, bl, n_cols);
+                xdrop_dir<+1, kPreR>(tc + t_end, qc + q_end, xdrop, aR, bR, bestR, br, n_cols);
                 n_ext++;
                 ext = q_end + br;
                 const int score = bestL + bestR;
@@ -610,18 +698,23 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
 }
 
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
-                     const uint8_t *qcodes, int64_t qtot, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
+                     const uint8_t *qcodes, int64_t qtot, int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, hipStream_t s) {
     if (n_hits <= 0) return;
-    // heads: [0, n_hits) short-run heads, [n_hits, n_hits + n_hits/kLongRun + 1) long-run heads; n_heads: two counters
-    unsigned *heads_long = heads + n_hits;
-    (void)hipMemsetAsync(n_heads, 0, 2 * sizeof(unsigned), s);
-    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, heads, heads_long, n_heads);
-    const int64_t blocks = (n_hits + 255) / 256;                                 // upper bound on the number of short runs
+    // runs longer than this go to the wave-per-run kernel: a few times the chance hits a diagonal holds on average
+    int kLongRun = (int)std::min<int64_t>(kLongRunMax, 6 + 4 * n_hits / std::max<int64_t>(1, n_diagonals));
+    if (const char *e = getenv("MIBLAST_LONG_RUN")) kLongRun = std::max(4, std::min(kLongRunMax, atoi(e)));      // (the long-run head list holds n_hits / 4 entries)
+    // heads: the four short-run lists by run length and the long-run list (offsets in k_run_heads; 2.1 n_hits + 16 entries);
+    // n_heads: five counters
+    const uint64_t n = (uint64_t)n_hits;
+    unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
+    (void)hipMemsetAsync(n_heads, 0, (kRunClasses + 1) * sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
+    const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;                   // upper bound: sum over classes of ceil(runs / 256)
     hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
                        qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
     const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
-    hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + 1,
+    hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
                        tcodes, qcodes, qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
 }
 

@@ -664,7 +664,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             st.seed_batches++;
             keys_b.ensure((size_t)nh);
             d_hsps.ensure((size_t)nh);
-            w.heads.ensure((size_t)nh + (size_t)nh / 4 + 8); w.n_heads.ensure(2);
+            w.heads.ensure(2 * (size_t)nh + (size_t)nh / 4 + 64); w.n_heads.ensure(8);       // four short-run lists + the long-run list (launch_ungapped)
             size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev1, s));
@@ -672,7 +672,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
-            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
+            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, ttot + qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, s);
             MB_HIP(hipEventRecord(ctx.ev4, s));
             UngappedCounters hc;
