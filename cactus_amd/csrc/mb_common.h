@@ -39,7 +39,9 @@ struct DpProb {                               // one one-sided Y-drop DP (SURVEY
     int32_t snap_row;                         // > 0: write the entry snapshot after this row
     int32_t init_snap;                        // snapshot to continue from (row_lo > 0)
     int32_t snap_idx;                         // entry snapshot slot; the exit snapshot is slot snap_idx + 1 (-1: none)
+    int32_t snap_row2, snap_row3;             // > 0: later entry snapshots (slots snap_idx + 2 / + 3): a hand-over rejected at snap_row is retried there
 };
+constexpr int kSnapSlots = 4;                 // snapshot slots per piece: entry, exit, entry 2, entry 3
 
 // DP state after a row (relay hand-over and continuation): header + C and D of the window [LY, RY)
 struct SnapHdr {

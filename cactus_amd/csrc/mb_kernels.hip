@@ -981,9 +981,9 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
         if (first_alive < 0) { i++; break; }
         LY = first_alive;
         RY = last_alive + 1;
-        if (!GLOBAL && (i == pr.snap_row || i == pr.stop_row)) {
+        if (!GLOBAL && (i == pr.snap_row || i == pr.stop_row || i == pr.snap_row2 || i == pr.snap_row3)) {
             // state after row i (the ring writes of the row are visible: they precede the row's last barrier)
-            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : 0)) * kSnapBytes;
+            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : i == pr.snap_row ? 0 : i == pr.snap_row2 ? 2 : 3)) * kSnapBytes;
             int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
             if (tid == 0) sh->smax = 0;
             __syncthreads();
@@ -1323,9 +1323,9 @@ __global__ __launch_bounds__(64) void k_ydrop1(const DpProb *__restrict__ probs,
         if (first_alive < 0) { i++; break; }
         LY = first_alive;
         RY = last_alive + 1;
-        if (i == pr.snap_row || i == pr.stop_row) {
+        if (i == pr.snap_row || i == pr.stop_row || i == pr.snap_row2 || i == pr.snap_row3) {
             // state after row i
-            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : 0)) * kSnapBytes;
+            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : i == pr.snap_row ? 0 : i == pr.snap_row2 ? 2 : 3)) * kSnapBytes;
             int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
             int lmax = kNeg2, lk = 0;
 #pragma unroll
@@ -1620,9 +1620,9 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
         if (first_alive < 0) { i++; break; }
         LY = first_alive;
         RY = last_alive + 1;
-        if (i == pr.snap_row || i == pr.stop_row) {
+        if (i == pr.snap_row || i == pr.stop_row || i == pr.snap_row2 || i == pr.snap_row3) {
             // state after row i
-            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : 0)) * kSnapBytes;
+            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : i == pr.snap_row ? 0 : i == pr.snap_row2 ? 2 : 3)) * kSnapBytes;
             int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
             int lmax = kNeg2, lj = 0;
 #pragma unroll

@@ -830,6 +830,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
                relay_tail_rows = env_long("MIBLAST_RELAY_TAIL_ROWS", 4096);     // how far past the last anchor virtual relays are planted
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
+    const bool relay_ckpt = env_long("MIBLAST_RELAY_CKPT", 1) != 0;             // retry a rejected hand-over at the relay's later entry snapshots
     // DP kernel of the pieces: the typical window is (Y-O)/E columns to the right of the path and about a quarter of that to
     // the left; windows that outgrow the lanes make the piece overflow and it is rerun with the next wider kernel
     const long win_typ = (p.ydrop > p.gap_open ? (p.ydrop - p.gap_open) / std::max(1, p.gap_extend) : 0) * 5 / 4 + 32;
@@ -949,6 +950,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             int unit; int32_t ot, oq, dir;      // origin (concatenated coordinates) and direction
             int32_t row_lo, min_row, stop_row;
             int target;                         // relay point the stop row is aimed at (index into relay_pts, -1: none)
+            int ckpt;                           // which entry snapshot of that relay the hand-over is checked against (0: after relay_w rows, 1: 2x, 2: 4x)
             int init_piece;                     // continuation: the piece whose exit snapshot it starts from
             int vjob;                           // index into vres of the hand-over check made after it ran (-1: none)
             int cont;                           // the piece that continues this one after a rejected hand-over (-1: none)
@@ -959,6 +961,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             std::vector<int> cur;               // pieces of the current run (one origin), in row order
             size_t accounted = 0;               // how many of them are folded into the result
             std::vector<int> chain;             // validated pieces, head first
+            std::vector<int32_t> chain_floor;   // per chain entry: the rows of that piece up to this one belong to the piece before it (head: -1)
             long long c_off = 0;                // score of the current run's origin in the head's scores
             long long acc_cells = 0, acc_rows = 0, entry_cells = 0, entry_rows = 0;
             int gbest = -1, gbi = 0, gbj = 0, best_piece = -1;
@@ -1066,24 +1069,32 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             arena_full = false;
             uint64_t dir_entries = 0;
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
+            // entry snapshots of a relay: after relay_w rows, and again after 2 and 4 times that -- a hand-over rejected at the first
+            // (the relay's state had not converged yet) is retried at the next with a SHORT continuation of the upstream piece
+            // instead of running it all the way to the relay after
             auto add_piece = [&](int unit, const DpProb &base, int32_t ot, int32_t oq, int32_t row_lo, int32_t min_row, int32_t stop_row,
-                                 int32_t snap_row, int init_piece, int target) -> int {
+                                 int32_t snap_row, int init_piece, int target, int ckpt = 0) -> int {
                 const int id = (int)pieces.size();
                 DpProb pr = base;
                 const int32_t dr = (oq - base.q0) * base.dir, dc = (ot - base.t0) * base.dir;
                 pr.t0 = ot; pr.q0 = oq; pr.na = base.na - dc; pr.nb = base.nb - dr;
                 pr.row_lo = row_lo; pr.stop_row = stop_row; pr.snap_row = snap_row;
-                pr.init_snap = init_piece >= 0 ? 2 * init_piece + 1 : -1; pr.snap_idx = 2 * id;
+                pr.snap_row2 = pr.snap_row3 = 0;
+                if (snap_row > 0 && relay_ckpt) {                        // a relay: later entry snapshots while it is still running
+                    if (stop_row == 0 || 2 * snap_row < stop_row) pr.snap_row2 = 2 * snap_row;
+                    if (stop_row == 0 || 4 * snap_row < stop_row) pr.snap_row3 = 4 * snap_row;
+                }
+                pr.init_snap = init_piece >= 0 ? kSnapSlots * init_piece + 1 : -1; pr.snap_idx = kSnapSlots * id;
                 pr.row_off = dir_entries;
                 const int64_t last = stop_row > 0 ? stop_row : pr.nb;
                 dir_entries += (uint64_t)((last - row_lo) / 4096) + 2;
                 probs.push_back(pr);
-                pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target, init_piece, -1, -1});
+                pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target, ckpt, init_piece, -1, -1});
                 if (target >= 0) {
                     // checked right after the launch: this piece's exit state against the aimed relay's entry state
                     const RelayPt ta = relay_pts[(size_t)target];
                     pieces.back().vjob = (int)vjobs.size();
-                    vjobs.push_back(VerifyJob{2 * id + 1, -1, (ta.t - ot) * base.dir, (ta.q - oq) * base.dir});   // nslot set at launch
+                    vjobs.push_back(VerifyJob{kSnapSlots * id + 1, -1, (ta.t - ot) * base.dir, (ta.q - oq) * base.dir});   // nslot set at launch
                 }
                 return id;
             };
@@ -1126,7 +1137,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         else stop = 0;
                     }
                     const int id = add_piece(sd.unit, b, b.t0, b.q0, 0, -1, stop, 0, -1, aim);
-                    sd.cur.push_back(id); sd.chain.push_back(id);
+                    sd.cur.push_back(id); sd.chain.push_back(id); sd.chain_floor.push_back(-1);
                 }
             }
             size_t launched = 0, vlaunched = 0;           // pieces [0, launched) have run, checks [0, vlaunched) are made
@@ -1134,14 +1145,15 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 n_subrounds++;
                 const size_t n_new = pieces.size() - launched, v_new = vjobs.size() - vlaunched;
                 g.probs.ensure_keep(pieces.size()); g.outs.ensure_keep(pieces.size()); g.rowdir.ensure_keep((size_t)dir_entries + 1);
-                g.snaps.ensure_keep(pieces.size() * 2 * kSnapBytes);
+                g.snaps.ensure_keep(pieces.size() * kSnapSlots * kSnapBytes);
                 g.vjobs.ensure(v_new + 1); g.vres.ensure(v_new + 1);
                 outs.resize(pieces.size()); vres.resize(vjobs.size());
                 for (size_t x = launched; x < pieces.size(); x++)
-                    if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = 2 * relay_pts[(size_t)pieces[x].target].piece;
+                    if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = kSnapSlots * relay_pts[(size_t)pieces[x].target].piece + (pieces[x].ckpt == 0 ? 0 : pieces[x].ckpt + 1);
                 MB_HIP(hipMemcpyAsync(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), hipMemcpyHostToDevice, s));
                 if (v_new) MB_HIP(hipMemcpyAsync(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), hipMemcpyHostToDevice, s));
-                MB_HIP(hipMemsetAsync(g.snaps.p + launched * 2 * kSnapBytes, 0, n_new * 2 * kSnapBytes, s));      // valid = 0
+                // valid = 0 in every header of the new pieces' slots (the headers only: the slots are 16 KiB apart)
+                MB_HIP(hipMemset2DAsync(g.snaps.p + launched * kSnapSlots * kSnapBytes, kSnapBytes, 0, sizeof(SnapHdr), n_new * kSnapSlots, s));
                 // DP launch, hand-over checks and the copies of both results: one synchronisation.  (Checks made on pieces that
                 // turn out to need a rerun are simply made again.)
                 run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true);
@@ -1206,6 +1218,17 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     const DpProb cb = probs[(size_t)x];
                     int aim = cp.target;
                     auto entry_row = [&](int r) -> int32_t { return (relay_pts[(size_t)r].q - cp.oq) * cp.dir + (int32_t)relay_w; };   // in this piece's rows
+                    if (aim >= 0 && relay_ckpt && cp.ckpt < 2) {
+                        // the same relay once more, at its next entry snapshot (if it has one): a short continuation
+                        const DpProb &rp = probs[(size_t)relay_pts[(size_t)aim].piece];
+                        const int32_t snap_next = cp.ckpt == 0 ? rp.snap_row2 : rp.snap_row3;
+                        const int32_t stop_next = (relay_pts[(size_t)aim].q - cp.oq) * cp.dir + snap_next;
+                        if (snap_next > 0 && stop_next > cp.stop_row) {
+                            const int id = add_piece(cp.unit, cb, cp.ot, cp.oq, cp.stop_row, cp.stop_row, stop_next, 0, x, aim, cp.ckpt + 1);
+                            pieces[(size_t)x].cont = id;
+                            return id;
+                        }
+                    }
                     if (aim >= 0) aim = pieces[(size_t)relay_pts[(size_t)aim].piece].target;      // the relay after the rejected one
                     else if (relay_s0 > 0) {
                         // a stop without an aim (first stop of a side, end of a capped chain): the lattice relay beyond the best cell
@@ -1261,11 +1284,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                             sd.entry_cells = v.n_cells; sd.entry_rows = v.n_rows;
                             sd.c_off += v.c;
                             sd.cur.assign(1, np0); sd.accounted = 0;
-                            sd.chain.push_back(np0);
+                            sd.chain.push_back(np0); sd.chain_floor.push_back(pieces[(size_t)np0].min_row * (cp.ckpt == 0 ? 1 : cp.ckpt == 1 ? 2 : 4));
                             continue;
                         }
                         const int id = make_cont(tp);
-                        sd.cur.push_back(id); sd.chain.push_back(id);
+                        sd.cur.push_back(id); sd.chain.push_back(id); sd.chain_floor.push_back(pieces[(size_t)id].min_row);
                     }
                 }
             }
@@ -1279,10 +1302,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     std::vector<int> owner;
                     for (size_t k = w0; k < w1; k++) {
                         SideRun &sd = sides[(size_t)wide[k]];
-                        sd.chain.clear(); sd.cur.clear(); sd.c_off = 0; sd.acc_cells = sd.acc_rows = sd.entry_cells = sd.entry_rows = 0; sd.gbest = -1;
+                        sd.chain.clear(); sd.chain_floor.clear(); sd.cur.clear(); sd.c_off = 0; sd.acc_cells = sd.acc_rows = sd.entry_cells = sd.entry_rows = 0; sd.gbest = -1;
                         const int id = add_piece(sd.unit, sd.base, sd.base.t0, sd.base.q0, 0, -1, 0, 0, -1, -1);
                         probs[(size_t)id].snap_idx = -1;
-                        sd.chain.push_back(id); sd.cur.push_back(id);
+                        sd.chain.push_back(id); sd.chain_floor.push_back(-1); sd.cur.push_back(id);
                         owner.push_back(wide[k]);
                     }
                     const size_t n_new = pieces.size() - first;
@@ -1354,7 +1377,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         const Piece &pp = pieces[(size_t)pc];
                         TbWalk w;
                         memset(&w, 0, sizeof w);
-                        w.row_off = probs[(size_t)pc].row_off; w.row_lo = pp.row_lo; w.floor = x > 0 ? pp.min_row : -1;
+                        w.row_off = probs[(size_t)pc].row_off; w.row_lo = pp.row_lo; w.floor = x > 0 ? sd.chain_floor[x] : -1;
                         if (x == at) { w.si = sd.gbi - (pp.oq - sd.base.q0) * pp.dir; w.sj = sd.gbj - (pp.ot - sd.base.t0) * pp.dir; }
                         else { w.si = pp.stop_row; w.sj = outs[(size_t)pc].exit_j; }      // guess: the best cell of the piece's last row
                         if (x > 0) {

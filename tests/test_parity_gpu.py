@@ -63,6 +63,8 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
                 {"MIBLAST_DP_KERNEL": "2"}, {"MIBLAST_DP_KERNEL": "4"}, {"MIBLAST_DP_KERNEL": "8"}, {"MIBLAST_DP_KERNEL": "100"},
                 {"MIBLAST_DP_WAVES": "4"}, {"MIBLAST_DP_WAVES": "3"},    # the 128-VGPR build of the one-wave DP kernel (4 waves per SIMD) / the default
                 {"MIBLAST_SEED_ONE_PASS": "0"},                 # two-pass seed search (count, scan, fill) instead of the fused one
+                {"MIBLAST_LONG_RUN": "4"}, {"MIBLAST_LONG_RUN": "32"},      # which diagonal runs go to the wave-per-run ungapped kernel
+                {"MIBLAST_RELAY_CKPT": "0"},                    # rejected hand-overs continue to the next relay instead of retrying at a later snapshot
                 {"MIBLAST_DP_KERNEL": "4", "MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "3"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -85,6 +87,9 @@ RELAY_CONFIGS = [
     # the policy of batched calls on a single pair: a side first has to survive S0 rows, relays are planted at its first stop
     {"MIBLAST_RELAY_S0": "48", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_PLANT_AT_ONCE": "0"},
     {"MIBLAST_RELAY_S0": "256", "MIBLAST_RELAY_S": "640", "MIBLAST_RELAY_W": "128", "MIBLAST_RELAY_PLANT_AT_ONCE": "0", "MIBLAST_RELAY_FORCE_REJECT": "3"},
+    # retries at the relays' later entry snapshots switched off / forced through all three checkpoints
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "512", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "2", "MIBLAST_RELAY_CKPT": "0"},
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "768", "MIBLAST_RELAY_W": "48", "MIBLAST_RELAY_FORCE_REJECT": "2"},
 ]
 
 
