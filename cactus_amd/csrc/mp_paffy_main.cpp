@@ -22,60 +22,19 @@ static int fail(int code, const std::string &msg) {
 }
 
 // `paffy dechunk -i X [--query]`: NAME|SEQLEN|CHUNKSTART -> NAME, coordinates shifted by CHUNKSTART, length restored
-// (Appendix B of SURVEY.md; every other column and tag is passed through untouched)
-static bool dechunk_name(std::string &name, std::string &len, long long &start) {
-    const size_t b = name.rfind('|');
-    if (b == std::string::npos || b == 0) return false;
-    const size_t a = name.rfind('|', b - 1);
-    if (a == std::string::npos) return false;
-    char *end = nullptr;
-    start = strtoll(name.c_str() + b + 1, &end, 10);
-    if (!end || *end) return false;
-    len = name.substr(a + 1, b - a - 1);
-    if (len.empty() || len.find_first_not_of("0123456789") != std::string::npos) return false;
-    name.resize(a);
-    return true;
-}
-
+// (Appendix B of SURVEY.md; every other column and tag is passed through untouched): mipaf_dechunk_text on the whole input
 static int dechunk(const char *input, bool query_only) {
     FILE *in = input ? fopen(input, "r") : stdin;
     if (!in) return fail(1, std::string("cannot open ") + input);
-    char *line = nullptr;
-    size_t cap = 0;
-    ssize_t got;
-    size_t line_no = 0;
-    std::string out;
-    while ((got = getline(&line, &cap, in)) > 0) {
-        line_no++;
-        while (got > 0 && (line[got - 1] == '\n' || line[got - 1] == '\r')) line[--got] = 0;
-        if (got == 0) continue;
-        std::string col[9];
-        const char *p = line;
-        int n = 0;
-        for (; n < 9; n++) {
-            const char *t = strchr(p, '\t');
-            if (!t) { col[n++] = p; p = nullptr; break; }
-            col[n].assign(p, (size_t)(t - p));
-            p = t + 1;
-        }
-        if (n < 9) { free(line); return fail(1, "dechunk: PAF line " + std::to_string(line_no) + " has fewer than 9 columns"); }
-        for (int side = 0; side < (query_only ? 1 : 2); side++) {
-            const int c = side == 0 ? 0 : 5;
-            std::string len;
-            long long start = 0;
-            if (!dechunk_name(col[c], len, start)) { free(line); return fail(1, "dechunk: PAF line " + std::to_string(line_no) + ": name is not NAME|LENGTH|START"); }
-            col[c + 1] = len;
-            col[c + 2] = std::to_string(atoll(col[c + 2].c_str()) + start);
-            col[c + 3] = std::to_string(atoll(col[c + 3].c_str()) + start);
-        }
-        for (int k = 0; k < 9; k++) { if (k) out += '\t'; out += col[k]; }
-        if (p) { out += '\t'; out += p; }
-        out += '\n';
-        if (out.size() > (1u << 20)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
-    }
-    fwrite(out.data(), 1, out.size(), stdout);
-    free(line);
+    std::string text;
+    char buf[1 << 16];
+    for (size_t n; (n = fread(buf, 1, sizeof buf, in)) > 0;) text.append(buf, n);
     if (input) fclose(in);
+    char *out = nullptr;
+    size_t out_len = 0;
+    if (mipaf_dechunk_text(text.data(), text.size(), query_only ? 1 : 0, &out, &out_len) != MIBLAST_OK) return fail(1, miblast_last_error());
+    fwrite(out, 1, out_len, stdout);
+    miblast_free(out);
     return 0;
 }
 

@@ -24,7 +24,7 @@ class Stats(C.Structure):
 
 
 EXPORTED_SYMBOLS = ("mipaf_set_from_mem", "mipaf_set_from_file", "mipaf_set_free", "mipaf_set_size", "mipaf_set_text", "mipaf_set_write",
-                    "mipaf_invert", "mipaf_chain_params_default", "mipaf_chain", "mipaf_tile", "mipaf_trim", "mipaf_filter",
+                    "mipaf_invert", "mipaf_dechunk_text", "mipaf_chain_params_default", "mipaf_chain", "mipaf_tile", "mipaf_trim", "mipaf_filter",
                     "mipaf_split_by_query", "mipaf_chain_tile_trim_filter")
 
 _bound = False
@@ -43,6 +43,7 @@ def _lib() -> C.CDLL:
             "mipaf_set_text": (C.c_int, [vp, P(vp), P(C.c_size_t)]),
             "mipaf_set_write": (C.c_int, [vp, C.c_int]),
             "mipaf_invert": (C.c_int, [vp]),
+            "mipaf_dechunk_text": (C.c_int, [cp, C.c_size_t, C.c_int32, P(vp), P(C.c_size_t)]),
             "mipaf_chain_params_default": (None, [P(ChainParams)]),
             "mipaf_chain": (C.c_int, [vp, vp, P(ChainParams), P(Stats)]),
             "mipaf_tile": (C.c_int, [vp, vp, C.c_int32, P(Stats)]),
@@ -69,6 +70,17 @@ def default_chain_params(**over) -> ChainParams:
     for k, v in over.items():
         setattr(p, k, v)
     return p
+
+
+def dechunk_text(paf: bytes, query_only: bool = False) -> bytes:
+    """`paffy dechunk [--query]` on PAF text (include/mipaf.h mipaf_dechunk_text)"""
+    lib = _lib()
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(lib.mipaf_dechunk_text(paf, len(paf), 1 if query_only else 0, C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value) if n.value else b""
+    finally:
+        lib.miblast_free(out)
 
 
 class PafSet:

@@ -41,6 +41,11 @@ int mipaf_set_write(const mipaf_set *s, int fd);                        /* paffy
 /* `paffy invert` (local_alignment.py:624 and :411-418): query <-> target.                                        */
 int mipaf_invert(mipaf_set *s);
 
+/* `paffy dechunk [--query]` (local_alignment.py:352 and :515) on PAF text: NAME|SEQLEN|CHUNKSTART -> NAME, start / end
+ * shifted by CHUNKSTART, length restored, on the query and (unless query_only) the target; every other column and
+ * tag passes through untouched, so this works on the text and not on a mipaf_set.  *out is freed with miblast_free. */
+int mipaf_dechunk_text(const char *paf, size_t len, int32_t query_only, char **out, size_t *out_len);
+
 typedef struct mipaf_chain_params {     /* `paffy chain` options (local_alignment.py:672-677, values xml:108-111)  */
     int64_t max_gap_length;             /* --maxGapLength  (chainMaxGapLength 1000000)                            */
     int64_t gap_open;                   /* --chainGapOpen  (chainGapOpen 5000)                                    */
