@@ -851,6 +851,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     }
     struct Pending { size_t unit, anchor; };
     for (int round = 0;; round++) {
+        double tm[6] = {0, 0, 0, 0, 0, 0};                 // debug: where a round's host time goes
+        double tm_t = now_s();
+        auto lap = [&](int k) { const double n = now_s(); tm[k] += n - tm_t; tm_t = n; };
         // commit what can be committed, then nominate the next speculative batch of every unit
         // commit what can be committed
         for (size_t ui = 0; ui < units.size(); ui++) {
@@ -933,6 +936,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         }
         if (pend.empty()) break;
         st.gapped_rounds++;
+        lap(0);
 
         // ---- the one-sided DPs of the round, trace stored in the arena -----------------------------------
         // A side (anchor, direction) is evaluated as a chain of PIECES (k_ydrop problems).  A one-sided DP is a
@@ -1148,6 +1152,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
             }
             size_t launched = 0, vlaunched = 0;           // pieces [0, launched) have run, checks [0, vlaunched) are made
+            lap(1);
             while (launched < pieces.size() && !arena_full) {
                 n_subrounds++;
                 const size_t n_new = pieces.size() - launched, v_new = vjobs.size() - vlaunched;
@@ -1169,6 +1174,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
                 MB_HIP(hipStreamSynchronize(s));
                 collect_dp_time(ctx, st);
+                lap(2);
                 if (debug) fprintf(stderr, "[miblast]   first pass (kernel %d): dp kernel total %.2f ms\n", dp_kernel, st.t_dp_kernel_ms);
                 if (dp_kernel != kDpLds) {
                     // pieces whose window outgrew the lanes of the one-wave kernel: once more with the LDS ring (same snapshots)
@@ -1342,6 +1348,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             g.arena.release();                                  // free first: old + new need not coexist
             g.arena.alloc(bigger);
         }
+        lap(3);
         st.relay_accepted += n_verify_ok; st.relay_rejected += n_verify_bad;
         if (debug) fprintf(stderr, "[miblast] round %d: %d sides in %zu pieces, %ld launches, hand-overs %ld accepted / %ld rejected\n",
                            round, nsides, pieces.size(), n_subrounds, n_verify_ok, n_verify_bad);
@@ -1581,6 +1588,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             rc = trace(second);
             if (rc != MIBLAST_OK) return rc;
         }
+        lap(4);
+        if (debug) fprintf(stderr, "[miblast]   round %d host timeline: commit+nominate %.2f ms, plant %.2f, launches+sync %.2f, advance+continuations %.2f, results+traceback %.2f\n",
+                           round, tm[0] * 1e3, tm[1] * 1e3, tm[2] * 1e3, tm[3] * 1e3, tm[4] * 1e3);
     }
     st.t_gapped = now_s() - t_g0;
     for (PairJob *j : jobs) {                // launch-level figures are shared by the pairs that were in flight together

@@ -94,23 +94,25 @@ def paf_invert_line(line: str) -> str:
 
 def unaligned_intervals(paf_lines, seq_lens, min_size: int):
     """Core of `paffy to_bed --excludeAligned --binary --minSize N` on PAF lines and [(query sequence name, length)]: the
-    (name, start, end) intervals of QUERY sequence no alignment covers, at least min_size long, in sequence order."""
-    import numpy as np
-    cover = {name: np.zeros(n + 1, dtype=np.int32) for name, n in seq_lens}
+    (name, start, end) intervals of QUERY sequence no alignment covers, at least min_size long, in sequence order.  Works on the
+    alignments' query intervals (sorted and merged), not on a per-base array: a whole-genome call has a handful of records."""
+    spans = {name: [] for name, _ in seq_lens}
     for line in paf_lines:
         if not line.strip():
             continue
         t = line.split("\t", 4)
-        c = cover[t[0]]
-        c[int(t[2])] += 1
-        c[int(t[3])] -= 1
+        s, e = int(t[2]), int(t[3])
+        if e > s:
+            spans[t[0]].append((s, e))
     out = []
-    for name, diff in cover.items():
-        free = np.cumsum(diff[:-1]) == 0
-        edges = np.diff(np.concatenate(([0], free.astype(np.int8), [0])))
-        for s, e in zip(np.nonzero(edges == 1)[0], np.nonzero(edges == -1)[0]):
-            if e - s >= min_size:
-                out.append((name, int(s), int(e)))
+    for name, n in seq_lens:
+        pos = 0
+        for s, e in sorted(spans[name]):
+            if s - pos >= min_size and s > pos:
+                out.append((name, pos, s))
+            pos = max(pos, e)
+        if n - pos >= min_size and n > pos:
+            out.append((name, pos, n))
     return out
 
 
