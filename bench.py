@@ -36,7 +36,7 @@ DEFAULT_ARGS = "--step=1 --ambiguous=iupac,100,100 --ydrop=4000 --hspthresh=2200
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 TRACE_BYTES_PER_CELL = 0.5     # SURVEY 8d "Gapped: write 0.5*C (4-bit traceback)": the algorithmic figure roofline.achieved is computed from
 TIMELINE = bool(os.environ.get("MIBLAST_BENCH_TIMELINE"))       # per-call wall times of a step on stderr
-TRACE_BYTES_WRITTEN = 1.0      # what the DP kernels write per evaluated cell today (one byte holding a 4-bit code)
+TRACE_BYTES_WRITTEN = 0.5      # what the DP kernels store per evaluated cell: 4-bit trace codes, two columns per byte
 PER_PAIR = ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_sides", "dp_cells", "dp_rows", "alignments",
             "t_index", "t_seed", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms")
 PER_BATCH = ("t_gapped", "gapped_rounds", "dp_sides_run", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms", "dp_kernel_launches",

@@ -730,7 +730,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
 //     both done with DPP row_shr / row_bcast steps (no LDS traffic), segment carries through SGPRs;
 //   * target bases are staged in an LDS byte ring ahead of the window, query bases 64 rows at a time
 //     in a register (v_readlane per row), so no global load sits on the row-to-row critical path;
-//   * one trace byte per evaluated cell goes to 64 KiB blocks bump-allocated from an HBM arena, with a
+//   * one 4-bit trace code per evaluated cell (two columns per byte) goes to 64 KiB blocks bump-allocated from an HBM arena, with a
 //     16-byte (offset, LY) record per row in 4096-row chunks found through a per-problem directory.
 struct RowInfo { unsigned long long off; uint32_t ly; uint32_t pad; };
 
@@ -824,12 +824,13 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
     if (!overflow && row_lo == 0) {
         // ---- row 0: C = -(O + jE) while within ydrop of 0, every cell reached by a horizontal gap from the origin
         uint8_t *tr = arena + blk_off;
-        for (int j = tid; j <= R0; j += kYdThreads) {
-            CD[j & mask] = make_int2((j == 0) ? 0 : -(O + j * E), kNeg);
-            tr[j] = (j == 0) ? 3 : (uint8_t)(2 | (j >= 2 ? 8 : 0));
+        for (int j = tid; j <= R0; j += kYdThreads) CD[j & mask] = make_int2((j == 0) ? 0 : -(O + j * E), kNeg);
+        for (int j = 2 * tid; j <= R0; j += 2 * kYdThreads) {           // two 4-bit trace codes per byte, even column in the low nibble
+            const unsigned lo = (j == 0) ? 3u : (2u | (j >= 2 ? 8u : 0u)), hi = (j + 1 <= R0) ? (2u | (j + 1 >= 2 ? 8u : 0u)) : 0u;
+            tr[j >> 1] = (uint8_t)(lo | (hi << 4));
         }
         if (lane == 0) { rb_lo = (unsigned)blk_off; rb_hi = (unsigned)(blk_off >> 32); rb_ly = 0; }
-        blk_used = (unsigned)(R0 + 1);
+        blk_used = (unsigned)(R0 + 2) >> 1;
     } else if (!overflow) {
         // ---- continuation: the state after row row_lo comes from a snapshot (record 0 of this piece stays unused)
         const uint8_t *sp = snaps + (size_t)pr.init_snap * kSnapBytes;
@@ -969,12 +970,17 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
             if (fa < kBig && first_alive < 0) first_alive = base + fa;
             if (la >= 0) last_alive = base + la;
             if (uni(allm) > row_best) { row_best = uni(allm); bi = i; bj = base + cand; }
-            if (tid < nvalid) arena[blk_off + blk_used + (unsigned)(nrow + tid)] = (uint8_t)(src | dext | iext);
+            {
+                // two codes per byte: the even thread of a pair stores both (nrow is a multiple of the pass width, so pairs never straddle passes)
+                const unsigned code = tid < nvalid ? (unsigned)(src | dext | iext) : 0u;
+                const unsigned next = (unsigned)__shfl_down((int)code, 1);
+                if (!(tid & 1) && tid < nvalid) arena[blk_off + blk_used + (unsigned)((nrow + tid) >> 1)] = (uint8_t)(code | (next << 4));
+            }
             nrow += nvalid;
             if (!done) { carry_x = uni(allx); carry_m = uni(allm); carry_iv = uni(sh->iv_last); carry_cp = uni(sh->cp_last); }
             MB_TICK(5);
         }
-        blk_used += (unsigned)nrow;
+        blk_used += (unsigned)(nrow + 1) >> 1;
         cells += nrow;
         rows++;
         best = row_best;
@@ -1136,19 +1142,18 @@ __global__ __launch_bounds__(64) void k_ydrop1(const DpProb *__restrict__ probs,
     long long cells = R0 + 1;
     if (!overflow && row_lo == 0) {
         // ---- row 0: C = -(O + jE) while within ydrop of 0, every cell reached by a horizontal gap from the origin
-        uint32_t tb0[K / 4];
+        uint32_t tb0 = 0;                                                  // K 4-bit trace codes, column k in nibble k
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int j = K * lane + k;
             C[k] = j == 0 ? 0 : (j <= R0 ? -(O + j * E) : kNeg);
             D[k] = kNeg;
             const uint32_t b = j == 0 ? 3u : (2u | (j >= 2 ? 8u : 0u));
-            if ((k & 3) == 0) tb0[k / 4] = 0;
-            tb0[k / 4] |= b << (8 * (k & 3));
+            tb0 |= b << (4 * k);
         }
-        if (K * lane <= R0) __builtin_memcpy(arena + blk_off + K * lane, tb0, K);
+        if (K * lane <= R0) __builtin_memcpy(arena + blk_off + (K / 2) * lane, &tb0, K / 2);
         if (lane == 0) { rb_lo = (unsigned)blk_off; rb_hi = (unsigned)(blk_off >> 32); rb_ly = 0; }
-        blk_used = (unsigned)(R0 + K) & ~(unsigned)(K - 1);
+        blk_used = ((unsigned)(R0 + K) & ~(unsigned)(K - 1)) >> 1;
     } else if (!overflow) {
         // ---- continuation: the state after row row_lo comes from a snapshot (record 0 of this piece stays unused)
         const uint8_t *sp = snaps + (size_t)pr.init_snap * kSnapBytes;
@@ -1304,20 +1309,18 @@ __global__ __launch_bounds__(64) void k_ydrop1(const DpProb *__restrict__ probs,
             const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)wm, lw & 63);
             best = allm; bi = i; bj = jb + K * lw + (__ffs((int)vw) - 1);
         }
-        // ---- trace bytes of the lane's columns, one store
+        // ---- trace codes of the lane's columns (4 bits each), one store
         if (K * lane < nvalid) {
-            uint32_t tb[K / 4];
+            uint32_t tb = 0;                                              // K 4-bit codes: K / 2 bytes per lane
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const bool iex = k == 0 ? fprev != 0 : pex[k - 1] >= X[k - 1];
                 const unsigned src = diag[k] >= gm[k] ? 0u : (Dv[k] >= Iv[k] ? 1u : 2u);   // tie preference diag > D > I
-                const unsigned b = src | (dex[k] ? 4u : 0u) | (iex ? 8u : 0u);
-                if ((k & 3) == 0) tb[k / 4] = 0;
-                tb[k / 4] |= b << (8 * (k & 3));
+                tb |= (src | (dex[k] ? 4u : 0u) | (iex ? 8u : 0u)) << (4 * k);
             }
-            __builtin_memcpy(arena + blk_off + blk_used + (unsigned)(K * lane), tb, K);
+            __builtin_memcpy(arena + blk_off + blk_used + (unsigned)((K / 2) * lane), &tb, K / 2);
         }
-        blk_used += (unsigned)(nvalid + K - 1) & ~(unsigned)(K - 1);
+        blk_used += ((unsigned)(nvalid + K - 1) & ~(unsigned)(K - 1)) >> 1;
         cells += nvalid - (LY - jb);
         rows++;
         if (first_alive < 0) { i++; break; }
@@ -1419,18 +1422,18 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
         // ---- row 0: C = -(O + jE) while within ydrop of 0, every cell reached by a horizontal gap from the origin
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            uint32_t tb0 = 0;
+            uint32_t tb0 = 0;                                              // four 4-bit trace codes = one 16-bit store per lane
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const int j = g * kHalf + K * lane + k;
                 C[g][k] = j == 0 ? 0 : (j <= R0 ? -(O + j * E) : kNeg);
                 D[g][k] = kNeg;
-                tb0 |= (j == 0 ? 3u : (2u | (j >= 2 ? 8u : 0u))) << (8 * k);
+                tb0 |= (j == 0 ? 3u : (2u | (j >= 2 ? 8u : 0u))) << (4 * k);
             }
-            if (g * kHalf + K * lane <= R0) *(uint32_t *)(arena + blk_off + g * kHalf + K * lane) = tb0;
+            if (g * kHalf + K * lane <= R0) *(uint16_t *)(arena + blk_off + (g * kHalf + K * lane) / 2) = (uint16_t)tb0;
         }
         if (lane == 0) { rb_lo = (unsigned)blk_off; rb_hi = (unsigned)(blk_off >> 32); rb_ly = 0; }
-        blk_used = (unsigned)(R0 + K) & ~(unsigned)(K - 1);
+        blk_used = ((unsigned)(R0 + K) & ~(unsigned)(K - 1)) >> 1;
     } else if (!overflow) {
         // ---- continuation: the state after row row_lo comes from a snapshot (record 0 of this piece stays unused)
         const uint8_t *sp = snaps + (size_t)pr.init_snap * kSnapBytes;
@@ -1575,7 +1578,7 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
             for (int k = 0; k < K; k++) {
                 const bool iex = k == 0 ? fprev != 0 : pex[k - 1] >= X[k - 1];
                 const unsigned src = diag[k] >= gm[k] ? 0u : (Dv[k] >= Iv[k] ? 1u : 2u);   // tie preference diag > D > I
-                tb |= (src | (dex[k] ? 4u : 0u) | (iex ? 8u : 0u)) << (8 * k);
+                tb |= (src | (dex[k] ? 4u : 0u) | (iex ? 8u : 0u)) << (4 * k);
             }
             tbg[g] = tb;
         };
@@ -1610,11 +1613,12 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
             else { const int lw = (int)__ffsll((long long)wlB) - 1; bjn = jb + kHalf + K * (lw & 63) + (__ffs(__builtin_amdgcn_readlane((int)wmB, lw & 63)) - 1); }
             best = allm; bi = i; bj = bjn;
         }
-        // ---- trace bytes of the lane's columns
+        // ---- trace codes of the lane's columns
+        // 4-bit codes, two columns per byte (0.5 B per cell): one 16-bit store per lane and group
         uint8_t *rowp = arena + blk_off + blk_used;
-        if (K * lane < nvalid) *(uint32_t *)(rowp + K * lane) = tbg[0];
-        if (need_b && kHalf + K * lane < nvalid) *(uint32_t *)(rowp + kHalf + K * lane) = tbg[1];
-        blk_used += (unsigned)(nvalid + K - 1) & ~(unsigned)(K - 1);
+        if (K * lane < nvalid) *(uint16_t *)(rowp + (K / 2) * lane) = (uint16_t)tbg[0];
+        if (need_b && kHalf + K * lane < nvalid) *(uint16_t *)(rowp + kHalf / 2 + (K / 2) * lane) = (uint16_t)tbg[1];
+        blk_used += ((unsigned)(nvalid + K - 1) & ~(unsigned)(K - 1)) >> 1;
         cells += nvalid - (LY - jb);
         rows++;
         if (first_alive < 0) { i++; break; }
@@ -1748,9 +1752,9 @@ __device__ __forceinline__ bool walk_piece(const TbWalk &P, int &i, int &j, int 
             for (int k = 0; k < 8; k++) {
                 const int c = wc0 + k;
                 unsigned b = 0xFFu;                             // never a diagonal source: stops runs left of the row
-                // bytes right of the stored row are never consulted, but a long gap can put the predicted column far
-                // beyond it: never read past the arena
-                if (c >= wly && ri.off + (unsigned long long)(c - wly) < arena_bytes) b = rowp[c - wly];
+                // codes right of the stored row are never consulted, but a long gap can put the predicted column far
+                // beyond it: never read past the arena.  Two 4-bit codes per byte, even column of the row in the low nibble.
+                if (c >= wly && ri.off + (unsigned long long)((c - wly) >> 1) < arena_bytes) b = ((unsigned)rowp[(c - wly) >> 1] >> (4 * ((c - wly) & 1))) & 0xFu;
                 win |= (unsigned long long)b << (8 * k);
             }
             if (MODE == 1 && r <= si) { const uint32_t *q = rec_at(r); rj = q[0]; rs = q[2] & 3u; }
