@@ -27,6 +27,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -60,6 +61,8 @@ def parse_args():
     ap.add_argument("--lastz-args", default=DEFAULT_ARGS, help="option set of the pair workload")
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="pair workload: chunk pairs per GPU per step, aligned in ONE batched call")
     ap.add_argument("--pair-leg", type=int, default=1, help="evolver workload: also time the 1 Mb x 1 Mb pair of configs[1] (0 = skip); reported under pair_1mb")
+    ap.add_argument("--batch-leg", type=int, default=16,
+                    help="1 Mb x 1 Mb chunk pairs aligned in ONE miblast_align_pairs call (0 = skip); reported under batched_pairs, never in value")
     ap.add_argument("--seed-leg", type=int, default=8_000_000,
                     help="chunk size of the extra seed-stage leg on a pure-random pair (0 = skip); reported under seed_stage, never in value")
     return ap.parse_args()
@@ -111,6 +114,10 @@ class EvolverPhase:
         for fa in self.fasta.values():
             bp.parsed_records(fa, keep=True)                                                     # ... and parsed once on the host, like their upload
         self.params = {}
+        # the option sets of a dependency level are independent jobs too (1 x "four" beside 9 x "default" at level 0): each gets its
+        # own context (stream + workspace) on this GPU and they run concurrently, as Toil runs independent jobs of a node
+        self.contexts = [ctx, miblast.Context(ctx.device)]
+        self.free_contexts = list(self.contexts)
         self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
                          f"examples/evolverMammals.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 2001), ingroup trimming between outgroups, "
                          "option set per call by distance (1 x \"four\", rest \"default\")")
@@ -120,28 +127,36 @@ class EvolverPhase:
         made = []
         t_step = time.perf_counter()
 
+        lock = threading.Lock()
+
         def align_batch(pairs, opts):
-            pm = self.params.get(opts)
-            if pm is None:
-                pm = self.params[opts] = self.miblast.params_from_args(opts.split())
+            with lock:
+                cx = self.free_contexts.pop()
+                pm = self.params.get(opts)
+                if pm is None:
+                    pm = self.params[opts] = self.miblast.params_from_args(opts.split())
             sets = []
             for tf, qf in pairs:
                 s = []
                 for fa in (tf, qf):
                     h = self.resident.get(fa)
                     if h is None:
-                        h = self.ctx.seqset_from_fasta_bytes(fa)
-                        made.append(h)
+                        h = cx.seqset_from_fasta_bytes(fa)
+                        with lock:
+                            made.append(h)
                     s.append(h)
                 sets.append(tuple(s))
             t0 = time.perf_counter()
-            rs = self.ctx.align_pairs(sets, pm)
-            add_stats(agg, [r.stats for r in rs])
+            rs = cx.align_pairs(sets, pm)
+            with lock:
+                self.free_contexts.append(cx)
+                add_stats(agg, [r.stats for r in rs])
             if TIMELINE:
                 print(f"[bench] align_pairs of {len(pairs)} pairs: {(time.perf_counter() - t0) * 1e3:.2f} ms (since step start {(time.perf_counter() - t_step) * 1e3:.2f}); "
                       f"t_gapped {rs[0].stats['t_gapped'] * 1e3:.2f}, dp {rs[0].stats['t_dp_kernel_ms']:.2f}, max t_seed+index {max(r.stats['t_seed'] + r.stats['t_index'] for r in rs) * 1e3:.2f}", file=sys.stderr)
             return [r.paf for r in rs]
 
+        align_batch.concurrent = len(self.contexts)
         res = self.bp.run_blast_phase(self.fasta, self.calls, self.options, align_batch, *self.trim,
                                       on_call=(lambda c, tf, qf, paf: keep.append((tf, qf, self.options(c.distance), paf))) if keep is not None else None)
         for h in made:
@@ -313,6 +328,8 @@ def run_rank(a):
             out["roofline"]["valu"] = {"error": str(e)}
         if a.workload == "evolver" and a.pair_leg > 0:
             out["pair_1mb"] = pair_leg(a, ctx)
+        if a.batch_leg > 1:
+            out["batched_pairs"] = batch_leg(a, ctx)
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, ctx)
         if a.chain_leg > 0:
@@ -341,6 +358,25 @@ def pair_leg(a, ctx):
            "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "launch_ms", "cells_per_launch")}}
     if a.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / a.steps, w.describe)
+    for t, q in w.sets:
+        t.close(); q.close()
+    return out
+
+
+def batch_leg(a, ctx):
+    """Many chunk pairs of one GPU in one call (the regime of BASELINE configs[3..4]: a genome pair is tens to thousands of
+    30 Mb chunk pairs): P x (1 Mb x 1 Mb) pairs of the config-2 recipe through ONE miblast_align_pairs call -- seed stages on
+    concurrent lanes, gapped stages merged into shared DP launches."""
+    import types
+    b = types.SimpleNamespace(size=a.size, seed=a.seed, random_pair=False, lastz_args=DEFAULT_ARGS, pairs_per_gpu=a.batch_leg)
+    w = PairWorkload(b, ctx, 0)
+    elapsed, tot, _ = timed_steps(w, 3, 1, lambda: None, lambda paf: None)
+    r = dp_roofline(tot, "none")
+    out = {"workload": w.describe, "ms_per_call": 1e3 * elapsed / 3, "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
+           "seeds_per_s": tot["seed_hits"] / elapsed, "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
+           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3) / 1e9,
+           "dp_launches_per_call": tot["dp_kernel_launches"] / 3, "pieces_per_call": tot["dp_sides_run"] / 3,
+           "roofline": {k: r[k] for k in ("achieved", "frac", "launch_ms", "cells_per_launch")}}
     for t, q in w.sets:
         t.close(); q.close()
     return out

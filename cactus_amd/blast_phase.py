@@ -273,8 +273,15 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         by_opts: Dict[str, List[int]] = {}
         for i in todo:
             by_opts.setdefault(option_string(calls[i].distance), []).append(i)
-        for opts, idx in by_opts.items():
-            outs = align_batch([(genomes[calls[i].target], query_fa[i]) for i in idx], opts)
+        # the option sets of a level are independent jobs as well: handed over concurrently when the aligner can take it
+        # (align_batch.concurrent = how many calls it accepts at a time; each call still gets ONE option set)
+        groups = list(by_opts.items())
+        width = int(getattr(align_batch, "concurrent", 1))
+        if width > 1 and len(groups) > 1:
+            results = list(pool.map(lambda g: align_batch([(genomes[calls[i].target], query_fa[i]) for i in g[1]], g[0]), groups))
+        else:
+            results = [align_batch([(genomes[calls[i].target], query_fa[i]) for i in idx], opts) for opts, idx in groups]
+        for (opts, idx), outs in zip(groups, results):
             for i, paf in zip(idx, outs):
                 raw[i] = paf
                 if calls[i].chain is not None:

@@ -979,8 +979,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // Three regimes (measured on the bench workloads, scripts/gpu_r02_sched2.sh): a lone pair (few sides) -- 640-row pieces; a
         // batch of a few pairs (the evolver phase: hundreds of sides) -- 512-row pieces, still planted together with the heads: short
         // pieces balance the launch and a rejected hand-over costs one short retry; thousands of sides -- the GPU is full anyway,
-        // long pieces waste less on warm-up and relays are only spent on sides that survive relay_s0 rows.
-        const bool crowd = nsides > 2048;
+        // long pieces waste less on warm-up and relays are only spent on sides that survive relay_s0 rows (16 x 1 Mb pairs, ~600
+        // sides: 66 ms per call against 75 ms with the short pieces).
+        const bool crowd = nsides > 400;
         if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides > 96 ? 512 : 640;
         if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
         if (relay_w_env <= 0) relay_w = crowd ? 192 : 128;

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0", "--pair-leg", "0"]
+SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0", "--pair-leg", "0", "--batch-leg", "0"]
 
 
 def _bench(args, **env):
