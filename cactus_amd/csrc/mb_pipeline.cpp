@@ -134,13 +134,51 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
     std::vector<uint32_t> by_q;             // anchor indices sorted by q
     std::vector<uint8_t> cov;               // covered by a COMMITTED alignment (the rule of SURVEY A.10 GAPPED)
     std::vector<uint8_t> tent;              // would be covered by an accepted, not yet committed result (heuristic only)
+    std::vector<uint32_t> comp;             // colinear group of the anchor (heuristic only): anchors one gapped alignment is likely to run through
+    uint32_t n_comp = 0;
 
-    void index_anchors() {
+    // gap_q: how far apart in q two consecutive anchors of a group may lie; tol_d: how far apart their diagonals; a run of n_run
+    // or more N between two anchors (in either sequence) ends the group as well: no extension survives it (N scores -100)
+    void index_anchors(int32_t gap_q, int32_t tol_d, const uint8_t *tc, const uint8_t *qc, int32_t n_run) {
         by_q.resize(anchors.size());
         for (size_t k = 0; k < by_q.size(); k++) by_q[k] = (uint32_t)k;
         parallel_sort(by_q.begin(), by_q.end(), [&](uint32_t x, uint32_t y) { return anchors[x].q != anchors[y].q ? anchors[x].q < anchors[y].q : x < y; });
         cov.assign(anchors.size(), 0);
         tent.assign(anchors.size(), 0);
+        // Colinear groups: every anchor is linked to the next anchor in q order whose diagonal lies within tol_d (an indel larger
+        // than that ends a Y-drop extension anyway) and whose q lies within gap_q.  One speculative head per group and round is
+        // enough -- its relay chain covers the group in both directions; more heads on the same alignment only evaluate the
+        // stretch between them twice.  Purely a scheduling hint: commits stay in anchor order.
+        std::vector<uint32_t> parent(anchors.size());
+        for (size_t k = 0; k < parent.size(); k++) parent[k] = (uint32_t)k;
+        auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        for (size_t p = 0; p < by_q.size(); p++) {
+            const Anchor &a = anchors[by_q[p]];
+            const int32_t da = a.t - a.q;
+            for (size_t p2 = p + 1; p2 < by_q.size(); p2++) {
+                const Anchor &b = anchors[by_q[p2]];
+                if (b.q - a.q > gap_q) break;
+                const int32_t dd = (b.t - b.q) - da;
+                if (dd >= -tol_d && dd <= tol_d) {
+                    auto n_between = [&](const uint8_t *c, int32_t lo, int32_t hi) -> bool {      // a run of >= n_run N inside [lo, hi)
+                        if (!c || hi - lo < n_run) return false;
+                        int32_t run = 0;
+                        for (int32_t x = lo; x < hi; x++) { run = (c[x] & 7u) == 4u ? run + 1 : 0; if (run >= n_run) return true; }
+                        return false;
+                    };
+                    if (!n_between(qc, a.q, b.q) && !n_between(tc, a.t, b.t)) parent[find(by_q[p2])] = find(by_q[p]);
+                    break;
+                }
+            }
+        }
+        comp.assign(anchors.size(), 0);
+        std::vector<uint32_t> id(anchors.size(), 0xFFFFFFFFu);
+        n_comp = 0;
+        for (size_t k = 0; k < anchors.size(); k++) {
+            const uint32_t r = find((uint32_t)k);
+            if (id[r] == 0xFFFFFFFFu) id[r] = n_comp++;
+            comp[k] = id[r];
+        }
     }
     // marks every anchor inside the bounding box and diagonal band of an alignment
     void mark(std::vector<uint8_t> &flags, int32_t t_lo, int32_t t_hi, int32_t q_lo, int32_t q_hi, int32_t dmin, int32_t dmax) {
@@ -806,7 +844,8 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                 if (a.t != b.t) return a.t < b.t;
                 return a.q < b.q;
             });
-            u.index_anchors();
+            u.index_anchors((int32_t)env_long("MIBLAST_GROUP_GAP", 4096), (int32_t)env_long("MIBLAST_GROUP_TOL", 64), tc_h, qc_h[u.strand],
+                            (int32_t)std::max(8l, env_long("MIBLAST_GROUP_NRUN", p.ydrop / 100)));
         }
         t_bu[2] = now_s() - t_b2;
         if (env_long("MIBLAST_DEBUG", 0) > 1) fprintf(stderr, "[miblast]   build_units: window scan %.2f ms, distribute %.2f ms, sorts %.2f ms\n", t_bu[0] * 1e3, t_bu[1] * 1e3, t_bu[2] * 1e3);
@@ -832,6 +871,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
                relay_tail_rows = env_long("MIBLAST_RELAY_TAIL_ROWS", 4096);     // how far past the last anchor virtual relays are planted
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
+    const bool chain_heads = env_long("MIBLAST_CHAIN_HEADS", 1) != 0;            // first round: one speculative head per colinear group of anchors
     const bool relay_ckpt = env_long("MIBLAST_RELAY_CKPT", 1) != 0;             // retry a rejected hand-over at the relay's later entry snapshots
     // DP kernel of the pieces: the typical window is (Y-O)/E columns to the right of the path and about a quarter of that to
     // the left; windows that outgrow the lanes make the piece overflow and it is rerun with the next wider kernel
@@ -897,7 +937,24 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         }
         std::vector<Pending> pend;
         long shadow_q = shadow_q0;
-        for (int level = 0; level < 6; level++) {
+        // First round: one head per colinear group of anchors (Unit::index_anchors) -- the best anchor of the group that is still
+        // open; its relay chain covers the rest of the group.  Whatever is left uncovered after that round (groups that bridge a
+        // stretch the extension does not survive) goes through the spatial thinning below, many at a time.
+        if (round == 0 && chain_heads && relay_s0_env != 0) {
+            for (size_t ui = 0; ui < units.size(); ui++) {
+                Unit &u = units[ui];
+                std::vector<uint8_t> taken(u.n_comp, 0);
+                size_t n_taken = 0;
+                for (size_t k = u.next; k < u.anchors.size() && n_taken < batch_max; k++) {
+                    if (u.cov[k] || u.cache.count(k)) continue;
+                    if (k != u.next && (u.tent[k] || taken[u.comp[k]])) continue;
+                    taken[u.comp[k]] = 1;
+                    n_taken++;
+                    pend.push_back(Pending{ui, k});
+                }
+            }
+        }
+        for (int level = 0; level < 6 && !(round == 0 && chain_heads && relay_s0_env != 0); level++) {
             std::vector<Pending> cand;
             const long sq = std::max(64l, shadow_q0 >> (2 * level));
             for (size_t ui = 0; ui < units.size(); ui++) {

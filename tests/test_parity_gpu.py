@@ -65,6 +65,8 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
                 {"MIBLAST_SEED_ONE_PASS": "0"},                 # two-pass seed search (count, scan, fill) instead of the fused one
                 {"MIBLAST_LONG_RUN": "4"}, {"MIBLAST_LONG_RUN": "32"},      # which diagonal runs go to the wave-per-run ungapped kernel
                 {"MIBLAST_RELAY_CKPT": "0"},                    # rejected hand-overs continue to the next relay instead of retrying at a later snapshot
+                {"MIBLAST_CHAIN_HEADS": "0"},                   # first-round nomination by spatial thinning instead of one head per colinear anchor group
+                {"MIBLAST_GROUP_GAP": "200", "MIBLAST_GROUP_TOL": "8"}, {"MIBLAST_GROUP_GAP": "1000000", "MIBLAST_GROUP_TOL": "100000"},
                 {"MIBLAST_DP_KERNEL": "4", "MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "3"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
