@@ -138,3 +138,37 @@ def test_limits_of_the_blocked_path_are_refused_loudly(monkeypatch):
             m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(KEG_DEFAULT))
     finally:
         m.close()
+
+
+def test_blocked_equals_unblocked_at_chunk_scale(monkeypatch):
+    """Blocks at a realistic scale (4 contigs of 5 Mb per file, blocks of <= 6 Mb -> 4 x 4 block pairs on two logical devices,
+    batched per device): the assembled job equals the single unblocked job byte for byte (which the suite pins to the oracle at
+    small sizes), for a --step=2 option set whose block origins are odd."""
+    from cactus_amd import gen, miblast
+    rng = np.random.default_rng(77)
+    trecs, qrecs = [], []
+    for k in range(4):
+        t = gen.random_sequence(5_000_001 + 2 * k, rng)
+        q = gen.mutate(t, rng, 0.02, 0.002)
+        if k == 2:
+            q = gen.revcomp(q)
+        trecs.append(("id=T|chr%d" % k, gen.soft_mask(t, rng, 0.4)))
+        qrecs.append(("id=Q|chr%d" % k, gen.soft_mask(q, rng, 0.4)))
+    tf, qf = gen.fasta_bytes(trecs), gen.fasta_bytes([qrecs[i] for i in (2, 0, 3, 1)])
+    pm = miblast.params_from_args("--step=2 --ambiguous=iupac,100,100 --ydrop=3000 --notransition".split())
+    m = miblast.Multi(1)
+    try:
+        whole, st0 = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert whole.count(b"\n") >= 4
+    monkeypatch.setenv("MIBLAST_BLOCK_BASES", "6000000")
+    monkeypatch.setenv("MIBLAST_DEVICE_MAP", "0,0")
+    m = miblast.Multi(2)
+    try:
+        blocked, st1 = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert blocked == whole
+    for k in ("seed_hits", "hsps", "dp_cells", "alignments"):
+        assert st0[k] == st1[k], k
