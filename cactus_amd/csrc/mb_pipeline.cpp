@@ -844,7 +844,15 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                 if (a.t != b.t) return a.t < b.t;
                 return a.q < b.q;
             });
-            u.index_anchors((int32_t)env_long("MIBLAST_GROUP_GAP", 4096), (int32_t)env_long("MIBLAST_GROUP_TOL", 64), tc_h, qc_h[u.strand],
+            // group gap: a few dozen times the unit's mean anchor spacing (sparser seeding -- larger --step, soft-masked chunks -- must
+            // not fragment one alignment into a head per kilobase), within [4096, 65536]
+            long group_gap = env_long("MIBLAST_GROUP_GAP", 0);
+            if (group_gap <= 0 && !u.anchors.empty()) {
+                int32_t q_min = u.anchors[0].q, q_max = q_min;
+                for (const Anchor &a : u.anchors) { q_min = std::min(q_min, a.q); q_max = std::max(q_max, a.q); }
+                group_gap = std::min(65536l, std::max(4096l, 48l * (long)(q_max - q_min) / (long)u.anchors.size()));
+            }
+            u.index_anchors((int32_t)std::max(1l, group_gap), (int32_t)env_long("MIBLAST_GROUP_TOL", 64), tc_h, qc_h[u.strand],
                             (int32_t)std::max(8l, env_long("MIBLAST_GROUP_NRUN", p.ydrop / 100)));
         }
         t_bu[2] = now_s() - t_b2;
@@ -870,6 +878,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     long relay_w = std::max(64l, relay_w_env > 0 ? relay_w_env : 192l);
     const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
                relay_tail_rows = env_long("MIBLAST_RELAY_TAIL_ROWS", 4096);     // how far past the last anchor virtual relays are planted
+    // No piece of a relayed side runs unbounded: where a chain ends (no anchor ahead within the bridging distance -- a long
+    // soft-masked stretch has no seeds) the piece stops after a few lattice steps and, if the extension is still alive, the side
+    // looks for relays again from there (make_cont).  Without this one alignment running through a 10 kb seedless stretch of a
+    // 30 Mb chunk pair kept a single wave busy for a million rows (1 s).
+    const long relay_end_steps = std::max(1l, env_long("MIBLAST_RELAY_END_STEPS", 4));
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
     const bool chain_heads = env_long("MIBLAST_CHAIN_HEADS", 1) != 0;            // first round: one speculative head per colinear group of anchors
     const bool relay_ckpt = env_long("MIBLAST_RELAY_CKPT", 1) != 0;             // retry a rejected hand-over at the relay's later entry snapshots
@@ -1086,7 +1099,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // its state converges all the same; k_verify decides) so that stretches without seeds (soft-masked repeats)
         // do not turn into one long piece.  No anchor within relay_gap buckets: the chain ends.
         // Depends on the unit's anchors and the point only, so chains started from different heads merge.
-        auto next_relay = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) -> int {
+        struct NextPt { int32_t ok, t, q, set_tail; };                 // set_tail >= 0: a virtual tail relay, that many lattice lines past the last anchor
+        auto next_point = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) -> NextPt {
             const Unit &u = units[(size_t)unit];
             const int32_t dirn = b.dir;
             const long s_from = (long)dirn * q + min_dq;                 // first admissible position in walking order, s = dir * q
@@ -1110,27 +1124,89 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 return best;
             };
             const long near = scan(std::max(s_from, line - relay_s / 4), line + relay_s / 4, line);
-            if (near >= 0) return relay_at(unit, dirn, u.anchors[(size_t)near].t, u.anchors[(size_t)near].q);
+            if (near >= 0) return NextPt{1, u.anchors[(size_t)near].t, u.anchors[(size_t)near].q, -1};
             // no anchor at this lattice line: bridge towards the next anchor further down, if there is one
             const long far = scan(line + relay_s / 4, line + relay_gap * relay_s, line);
             if (far < 0) {
                 // past the last anchor an alignment may still run on for a while (soft-masked sequence has no seeds): a few
                 // more virtual relays straight down the diagonal keep that tail from becoming one long piece
-                if ((long)(from_tail + 1) * relay_s > relay_tail_rows) return -1;
+                if ((long)(from_tail + 1) * relay_s > relay_tail_rows) return NextPt{0, 0, 0, -1};
                 const int32_t vq = (int32_t)(dirn * line), vt = (int32_t)((long)t + (long)(vq - q));
-                if ((long)(vq - q) * dirn <= 0 || !in_bounds(vt, vq)) return -1;
-                const int id = relay_at(unit, dirn, vt, vq);
-                relay_pts[(size_t)id].tail = from_tail + 1;
-                return id;
+                if ((long)(vq - q) * dirn <= 0 || !in_bounds(vt, vq)) return NextPt{0, 0, 0, -1};
+                return NextPt{1, vt, vq, from_tail + 1};
             }
             const Anchor &c = u.anchors[(size_t)far];
             const int32_t vq = (int32_t)(dirn * line);
             const long span = (long)(c.q - q) * dirn, step = (long)(vq - q) * dirn;
             const long ddiag = (long)(c.t - c.q) - (long)(t - q);
             const int32_t vt = (int32_t)((long)t + (long)(vq - q) + (span > 0 ? ddiag * step / span : 0));
-            if (step <= 0 || !in_bounds(vt, vq)) return relay_at(unit, dirn, c.t, c.q);
-            return relay_at(unit, dirn, vt, vq);
+            if (step <= 0 || !in_bounds(vt, vq)) return NextPt{1, c.t, c.q, -1};
+            return NextPt{1, vt, vq, -1};
         };
+        // The lattice step is a pure function of the unit's anchors and the point, and it is where planting spends its time (two
+        // scans of the anchor index per step): the chains of all heads are therefore walked ahead of the planting, one task per
+        // (unit, direction) on the worker threads, into chain_memo; the serial planting below then finds its steps there.
+        std::vector<std::unordered_map<unsigned long long, NextPt>> chain_memo;
+        auto memo_key = [](int32_t t, int32_t q) -> unsigned long long { return ((unsigned long long)(uint32_t)t << 32) | (uint32_t)q; };
+        auto next_relay = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) -> int {
+            NextPt np{0, 0, 0, -1};
+            bool have = false;
+            if (min_dq == (int32_t)(relay_s / 2) && !chain_memo.empty()) {
+                const auto &m = chain_memo[2 * (size_t)unit + (b.dir > 0 ? 1 : 0)];
+                const auto it = m.find(memo_key(t, q));
+                if (it != m.end()) { np = it->second; have = true; }
+            }
+            if (!have) np = next_point(unit, b, t, q, min_dq, from_tail);
+            if (!np.ok) return -1;
+            const int id = relay_at(unit, b.dir, np.t, np.q);
+            if (np.set_tail >= 0) relay_pts[(size_t)id].tail = np.set_tail;
+            return id;
+        };
+        // base problem of every side (anchor, direction, room to the contig ends)
+        std::vector<DpProb> side_base((size_t)nsides);
+        for (size_t k = 0; k < pend.size(); k++) {
+            const Unit &u = units[pend[k].unit];
+            const Anchor &a = u.anchors[pend[k].anchor];
+            const SeqSet &T = *jobs[(size_t)u.pair]->T, &Q = *jobs[(size_t)u.pair]->Q;
+            const int tcg = T.contig_of(a.t);
+            const int64_t tlo = T.starts[(size_t)tcg], thi = tlo + T.lens[(size_t)tcg];
+            const int64_t qlo = Q.starts[(size_t)u.q_contig], qhi = qlo + Q.lens[(size_t)u.q_contig];
+            for (int sdn = 0; sdn < 2; sdn++) {
+                DpProb b;
+                memset(&b, 0, sizeof b);
+                b.t0 = a.t; b.q0 = a.q; b.strand = u.strand; b.pad0 = u.pair; b.init_snap = -1; b.snap_idx = -1;
+                if (sdn == 0) { b.dir = +1; b.na = (int32_t)(thi - a.t); b.nb = (int32_t)(qhi - a.q); }
+                else { b.dir = -1; b.na = (int32_t)(a.t - tlo); b.nb = (int32_t)(a.q - qlo); }
+                side_base[2 * k + (size_t)sdn] = b;
+            }
+        }
+        if (relay_s0 > 0 && plant_at_once && env_long("MIBLAST_PLANT_THREADS", 1) != 0) {
+            chain_memo.assign(2 * units.size(), {});
+            std::vector<std::vector<size_t>> group(2 * units.size());     // sides of a (unit, direction), in planting order
+            for (size_t si = 0; si < (size_t)nsides; si++) group[2 * pend[si / 2].unit + (side_base[si].dir > 0 ? 1 : 0)].push_back(si);
+            std::vector<size_t> busy;
+            for (size_t gi = 0; gi < group.size(); gi++) if (!group[gi].empty()) busy.push_back(gi);
+            parallel_for(busy.size(), [&](size_t bi) {
+                const size_t gi = busy[bi];
+                auto &memo = chain_memo[gi];
+                std::unordered_map<unsigned long long, int> tails;       // tail count of the points met so far (first writer wins, as relay_at does)
+                for (size_t si : group[gi]) {
+                    const DpProb &b = side_base[si];
+                    int32_t t = b.t0, q = b.q0;
+                    int tail = 0;
+                    for (long n = 0; n <= relay_max; n++) {
+                        const unsigned long long key = memo_key(t, q);
+                        if (memo.count(key)) break;                      // the rest of the chain is known
+                        const NextPt np = next_point((int)(gi / 2), b, t, q, (int32_t)(relay_s / 2), tail);
+                        memo.emplace(key, np);
+                        if (!np.ok) break;
+                        const unsigned long long nk = memo_key(np.t, np.q);
+                        if (np.set_tail >= 0) tails[nk] = np.set_tail; else tails.emplace(nk, 0);
+                        t = np.t; q = np.q; tail = tails[nk];
+                    }
+                }
+            });
+        }
         while (true) {                                   // retried with a larger arena if the trace does not fit
             sides.assign((size_t)nsides, SideRun());
             pieces.clear(); probs.clear(); outs.clear(); vjobs.clear(); vres.clear(); relay_pts.clear(); relay_id.clear();
@@ -1173,7 +1249,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     if (relay_pts[(size_t)a].piece >= 0) return;                 // the rest of the chain exists already
                     const RelayPt c = relay_pts[(size_t)a];                      // (copy: next_relay may grow the table)
                     int nx = next_relay(unit, base, c.t, c.q, (int32_t)(relay_s / 2), c.tail);
-                    int32_t stop = nx >= 0 ? (relay_pts[(size_t)nx].q - c.q) * base.dir + (int32_t)relay_w : 0;
+                    int32_t stop = nx >= 0 ? (relay_pts[(size_t)nx].q - c.q) * base.dir + (int32_t)relay_w : (int32_t)(relay_end_steps * relay_s + relay_w);
                     if (nx >= 0 && n + 1 == relay_max) { nx = -1; stop = (int32_t)(relay_s + relay_w); }   // chain cut: whoever gets here plants the rest
                     const int id = add_piece(unit, base, c.t, c.q, 0, (int32_t)relay_w, stop, (int32_t)relay_w, -1, nx);
                     relay_pts[(size_t)a].piece = id;
@@ -1181,18 +1257,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
             };
             for (size_t k = 0; k < pend.size(); k++) {
-                const Unit &u = units[pend[k].unit];
-                const Anchor &a = u.anchors[pend[k].anchor];
-                const SeqSet &T = *jobs[(size_t)u.pair]->T, &Q = *jobs[(size_t)u.pair]->Q;
-                int tcg = T.contig_of(a.t);
-                int64_t tlo = T.starts[(size_t)tcg], thi = tlo + T.lens[(size_t)tcg];
-                int64_t qlo = Q.starts[(size_t)u.q_contig], qhi = qlo + Q.lens[(size_t)u.q_contig];
                 for (int sdn = 0; sdn < 2; sdn++) {
-                    DpProb b;
-                    memset(&b, 0, sizeof b);
-                    b.t0 = a.t; b.q0 = a.q; b.strand = u.strand; b.pad0 = u.pair; b.init_snap = -1; b.snap_idx = -1;
-                    if (sdn == 0) { b.dir = +1; b.na = (int32_t)(thi - a.t); b.nb = (int32_t)(qhi - a.q); }
-                    else { b.dir = -1; b.na = (int32_t)(a.t - tlo); b.nb = (int32_t)(a.q - qlo); }
+                    const DpProb b = side_base[2 * k + (size_t)sdn];
                     SideRun &sd = sides[2 * k + (size_t)sdn];
                     sd.base = b; sd.unit = (int)pend[k].unit;
                     // Few sides in flight (one chunk pair): the relay chain of every head is planted at once and the head is aimed
@@ -1203,7 +1269,14 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     if (relay_s0 > 0 && plant_at_once) {
                         aim = next_relay(sd.unit, b, b.t0, b.q0, (int32_t)(relay_s / 2), 0);
                         if (aim >= 0) { plant_chain(sd.unit, b, aim); stop = (relay_pts[(size_t)aim].q - b.q0) * b.dir + (int32_t)relay_w; }
-                        else stop = 0;
+                        else stop = (int32_t)(relay_end_steps * relay_s);
+                        if (aim < 0 && env_long("MIBLAST_DEBUG", 0) > 2) {
+                            const Unit &uu = units[(size_t)sd.unit];
+                            long near_cnt = 0;
+                            for (const Anchor &c : uu.anchors) if (std::labs((long)c.q - b.q0) < 8 * relay_s && std::labs((long)(c.t - c.q) - (long)(b.t0 - b.q0)) <= relay_tol) near_cnt++;
+                            fprintf(stderr, "[miblast]   head without a relay: unit %d (%zu anchors, %u groups) at (%d,%d) dir %d na %d nb %d, %ld anchors within 8 S on the diagonal band\n",
+                                    sd.unit, uu.anchors.size(), uu.n_comp, b.t0, b.q0, b.dir, b.na, b.nb, near_cnt);
+                        }
                     }
                     const int id = add_piece(sd.unit, b, b.t0, b.q0, 0, -1, stop, 0, -1, aim);
                     sd.cur.push_back(id); sd.chain.push_back(id); sd.chain_floor.push_back(-1);
@@ -1312,7 +1385,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         if (aim >= 0) plant_chain(cp.unit, cb, aim);
                     }
                     while (aim >= 0 && entry_row(aim) <= cp.stop_row + 64) aim = pieces[(size_t)relay_pts[(size_t)aim].piece].target;
-                    const int32_t stop = aim >= 0 ? entry_row(aim) : 0;
+                    const int32_t stop = aim >= 0 ? entry_row(aim) : relay_s0 > 0 ? cp.stop_row + (int32_t)(relay_end_steps * relay_s) : 0;
                     const int id = add_piece(cp.unit, cb, cp.ot, cp.oq, cp.stop_row, cp.stop_row, stop, 0, x, aim);
                     pieces[(size_t)x].cont = id;
                     return id;
