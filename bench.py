@@ -193,10 +193,21 @@ class PairWorkload:
         return agg, b"".join(r.paf for r in rs)
 
 
+def cpu_throttle_state():
+    """(nr_throttled, throttled_usec) of this container's CPU cgroup -- the bench box runs under a CPU quota; a process whose threads
+    exceed it is frozen for the rest of the 100 ms period, which shows up as outlier steps"""
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except Exception:                       # noqa: BLE001
+        return 0, 0
+
+
 def timed_steps(work, steps, warmup, sync, gather):
     for _ in range(warmup):
         gather(work.step()[1])
     sync()
+    thr0, cpu0 = cpu_throttle_state(), time.process_time()
     t0 = time.perf_counter()
     tot, keep = {}, None
     for k in range(steps):
@@ -206,7 +217,12 @@ def timed_steps(work, steps, warmup, sync, gather):
         for key, v in agg.items():
             tot[key] = tot.get(key, 0) + v
     sync()
-    return time.perf_counter() - t0, tot, keep
+    elapsed = time.perf_counter() - t0
+    thr1 = cpu_throttle_state()
+    tot["host_cpu_seconds"] = time.process_time() - cpu0
+    tot["host_throttled_periods"] = thr1[0] - thr0[0]
+    tot["host_throttled_ms"] = (thr1[1] - thr0[1]) / 1e3
+    return elapsed, tot, keep
 
 
 def dp_roofline(tot, profile_name):
@@ -312,6 +328,9 @@ def run_rank(a):
                       "reruns_per_step": tot["dp_reruns"] / per,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / per, "merge_ms_per_step": tot["t_merge_ms"] / per},
             "roofline": dp_roofline(tot, "r02_hbm_traffic_pmc.json" if a.workload == "evolver" else "r02_pair_hbm_traffic_pmc.json"),
+            "host": {"cpu_seconds_per_step": tot["host_cpu_seconds"] / per, "busy_threads_avg": tot["host_cpu_seconds"] / world / max(1e-9, elapsed),
+                     "cgroup_throttled_periods": tot["host_throttled_periods"], "cgroup_throttled_ms": tot["host_throttled_ms"],
+                     "note": "all ranks; a CPU-quota container freezes the process when its threads exceed the quota (outlier steps)"},
         }
         try:
             # the DP is VALU / issue bound, so its cells/s are also put against the int32 VALU peak: evaluated cells

@@ -201,6 +201,7 @@ class Pool {
     size_t n = 0;
     std::atomic<size_t> next{0};
     size_t busy = 0;
+    size_t sleepers = 0;                      // workers blocked on cv (under m)
     unsigned long long gen = 0;
     std::atomic<unsigned long long> gen_a{0};
     std::atomic<int> hot_a{0};                // > 0 while a job is in flight: idle workers spin instead of sleeping
@@ -209,11 +210,17 @@ class Pool {
     void worker() {
         unsigned long long seen = 0;
         for (;;) {
-            for (;;) {
+            // While a job is in flight an idle worker spins for a few tens of microseconds (the parallel regions of a job follow
+            // each other closely), then sleeps: a job is mostly GPU waits, and workers that spin through them burn the CPU quota
+            // of the container (a 16-CPU cgroup throttled the process for 10 ms every few calls with 15 spinning workers).
+            for (unsigned spins = 0;;) {
                 if (gen_a.load(std::memory_order_acquire) != seen || stop_a.load(std::memory_order_relaxed)) break;
-                if (hot_a.load(std::memory_order_relaxed) > 0) { __builtin_ia32_pause(); continue; }
+                if (hot_a.load(std::memory_order_relaxed) > 0 && spins < 1500) { __builtin_ia32_pause(); spins++; continue; }
                 std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return stop || gen != seen || hot_a.load(std::memory_order_relaxed) > 0; });
+                sleepers++;
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                sleepers--;
+                spins = 0;
             }
             const std::function<void(size_t)> *f;
             size_t cnt;
@@ -283,7 +290,7 @@ public:
         return true;
     }
     struct Hot {                              // keeps the workers awake for the duration of a job
-        Hot() { Pool &p = get(); p.hot_a++; p.cv.notify_all(); }
+        Hot() { Pool &p = get(); p.hot_a++; }
         ~Hot() { get().hot_a--; }
     };
     void run(size_t count, const std::function<void(size_t)> &f) {
@@ -292,12 +299,14 @@ public:
         std::unique_lock<std::mutex> one(run_m, std::try_to_lock);      // one parallel region at a time; others run inline
         if (!one.owns_lock()) { for (size_t i = 0; i < count; i++) f(i); return; }
         inside = true;
+        bool wake;
         {
             std::lock_guard<std::mutex> lk(m);
             fn = &f; n = count; next.store(0, std::memory_order_relaxed); gen++; busy++;
             gen_a.store(gen, std::memory_order_release);
+            wake = sleepers > 0;
         }
-        if (hot_a.load(std::memory_order_relaxed) == 0) cv.notify_all();
+        if (wake) cv.notify_all();
         for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count;) f(i);
         for (bool first = true;; first = false) {                       // the stragglers finish within microseconds: spin
             std::unique_lock<std::mutex> lk(m);
