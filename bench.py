@@ -115,8 +115,11 @@ class EvolverPhase:
             bp.parsed_records(fa, keep=True)                                                     # ... and parsed once on the host, like their upload
         self.params = {}
         # the option sets of a dependency level are independent jobs too (1 x "four" beside 9 x "default" at level 0): each gets its
-        # own context (stream + workspace) on this GPU and they run concurrently, as Toil runs independent jobs of a node
-        self.contexts = [ctx, miblast.Context(ctx.device)]
+        # own context (stream + workspace) on this GPU and they run concurrently, as Toil runs independent jobs of a node.
+        # (MIBLAST_BENCH_CONTEXTS=3 MIBLAST_BENCH_SPLIT=6 also runs a large group as two concurrent calls: 41 instead of 50 ms per
+        # phase on the MI355X, but DP launches of two streams then share the GPU and their HIP-event durations -- the roofline's
+        # denominator -- no longer measure one kernel; the default keeps the kernel figures clean.)
+        self.contexts = [ctx] + [miblast.Context(ctx.device) for _ in range(max(0, int(os.environ.get("MIBLAST_BENCH_CONTEXTS", "2")) - 1))]
         self.free_contexts = list(self.contexts)
         self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
                          f"examples/evolverMammals.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 2001), ingroup trimming between outgroups, "
@@ -157,6 +160,7 @@ class EvolverPhase:
             return [r.paf for r in rs]
 
         align_batch.concurrent = len(self.contexts)
+        align_batch.split_above = int(os.environ.get("MIBLAST_BENCH_SPLIT", "0")) if len(self.contexts) > 1 else 0
         res = self.bp.run_blast_phase(self.fasta, self.calls, self.options, align_batch, *self.trim,
                                       on_call=(lambda c, tf, qf, paf: keep.append((tf, qf, self.options(c.distance), paf))) if keep is not None else None)
         for h in made:

@@ -277,6 +277,17 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         # (align_batch.concurrent = how many calls it accepts at a time; each call still gets ONE option set)
         groups = list(by_opts.items())
         width = int(getattr(align_batch, "concurrent", 1))
+        split = int(getattr(align_batch, "split_above", 0))
+        if width > 1 and split > 0:
+            # a large group is handed over in two halves (two concurrent batched calls: their host-side work -- relay planting,
+            # traceback, merge -- runs on two threads and the latency-bound tail launches of one overlap the other's work)
+            halves = []
+            for opts, idx in groups:
+                if len(idx) >= split:
+                    halves += [(opts, idx[0::2]), (opts, idx[1::2])]
+                else:
+                    halves.append((opts, idx))
+            groups = halves
         if width > 1 and len(groups) > 1:
             results = list(pool.map(lambda g: align_batch([(genomes[calls[i].target], query_fa[i]) for i in g[1]], g[0]), groups))
         else:
