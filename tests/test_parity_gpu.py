@@ -441,3 +441,47 @@ def test_oracle_only_comparison_switches_are_refused_not_ignored(gpu_ctx):
         with pytest.raises(miblast.MiblastError, match="oracle only"):
             gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + extra))
     assert gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + ["--miblast-diag=exact"])).paf
+
+
+def test_evolver_mammals_phase_at_full_size_equals_the_oracle_call_by_call(gpu_ctx, olz):
+    """BASELINE configs[2] as a parity test at the size SURVEY 8d config 3 states (600 kb ancestor, seed 2001, the guide tree of
+    examples/evolverMammals.txt:1): every one of the 20 lastz calls of the blast phase (cactus_amd/blast_phase.py: ingroup pairs
+    + ingroup -> outgroup chains with trimming, option set per call by distance) goes through miblast_align_pairs as bench.py runs
+    them and is diffed byte for byte against the oracle on the same FASTA bytes, counters included; the assembled per-node files
+    (dechunk --query, invert) validate against the full sequences."""
+    from cactus_amd import blast_phase as bp, gen, miblast, pafcheck
+    from cactus_amd.paf.local_alignment import select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE))
+    genomes = gen.make_tree_genomes(600_000, 2001, ancestors=True)
+    fasta = {k: gen.fasta_bytes([("id=%s|%s" % (k, k), v)]) for k, v in genomes.items()}
+    seen = []
+
+    def align_batch(pairs, opts):
+        pm = miblast.params_from_args(opts.split())
+        sets = [(gpu_ctx.seqset_from_fasta_bytes(t), gpu_ctx.seqset_from_fasta_bytes(q)) for t, q in pairs]
+        rs = gpu_ctx.align_pairs(sets, pm)
+        for (t, q), r in zip(pairs, rs):
+            seen.append((t, q, opts, r))
+        for a, b in sets:
+            a.close(); b.close()
+        return [r.paf for r in rs]
+
+    res = bp.run_blast_phase(fasta, calls, lambda d: select_lastz_params(d, cfg, 0), align_batch)
+    assert len(seen) == 20
+    cells = 0
+    for t, q, opts, r in seen:
+        pm = miblast.params_from_args(opts.split())
+        want = olz.align(t, q, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}), details=False)
+        assert r.paf == want["paf"]
+        for k in ("seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "anchors_skipped", "dp_sides", "dp_cells", "dp_rows", "alignments"):
+            assert r.stats[k] == want["counters"][k], k
+        cells += r.stats["dp_cells"]
+    assert cells > 5e8
+    full = {}
+    for fa in fasta.values():
+        for name, seq in bp.parse_fasta_bytes(fa):
+            full[name] = seq.tobytes().decode()
+    checked = sum(pafcheck.check_paf(parts[kind].decode(), full, full) for parts in res.values() for kind in ("ingroup", "outgroup") if parts[kind])
+    assert checked >= 100
