@@ -115,6 +115,7 @@ struct SeqSet {
     uint8_t *d_buf = nullptr;                 // device copy of `codes`, kDevPad separator bytes on both sides
     int64_t *d_starts = nullptr;              // contig starts / lens on the device (revcomp kernel)
     int64_t *d_lens = nullptr;
+    size_t d_cap = 0;                         // bytes of the device block d_buf heads (d_starts and d_lens live in its tail)
     const uint8_t *host() const { return view ? view : codes.data() + 1; }
     const uint8_t *dev() const { return d_buf + kDevPad; }
     int contig_of(int64_t pos) const;

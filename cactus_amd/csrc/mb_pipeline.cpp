@@ -80,6 +80,52 @@ struct PinBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
 };
 
+// Pinned staging for the small host<->device copies of a round.  A hipMemcpyAsync from or to PAGEABLE memory blocks its caller
+// until the copy is done and, measured on the MI355X box, now and then for 10-35 ms (the runtime pins or stages under a
+// process-wide lock); copies from pinned memory are queued in microseconds.  h2d() copies the host data into the pinned area
+// first; d2h() lands in the pinned area and done() -- called after the stream has been synchronised -- moves the bytes home.
+struct Stager {
+    std::vector<PinBuf<char> *> chunks;
+    size_t used = 0;                              // of the last chunk
+    struct Out { void *dst; const char *src; size_t n; };
+    std::vector<Out> pending;
+    Stager() = default;
+    Stager(const Stager &) = delete;
+    Stager &operator=(const Stager &) = delete;
+    ~Stager() { for (PinBuf<char> *c : chunks) delete c; }
+    char *take(size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        if (chunks.empty() || used + n > chunks.back()->n) {                // (earlier chunks may still be in flight: they stay)
+            size_t total = 0;
+            for (PinBuf<char> *c : chunks) total += c->n;
+            PinBuf<char> *c = new PinBuf<char>();
+            c->ensure(std::max<size_t>(std::max<size_t>(n, total), 1u << 20));
+            chunks.push_back(c); used = 0;
+        }
+        char *b = chunks.back()->p + used;
+        used += n;
+        return b;
+    }
+    void h2d(void *dev, const void *host, size_t n, hipStream_t s) {
+        if (!n) return;
+        char *b = take(n);
+        memcpy(b, host, n);
+        MB_HIP(hipMemcpyAsync(dev, b, n, hipMemcpyHostToDevice, s));
+    }
+    void d2h(void *host, const void *dev, size_t n, hipStream_t s) {
+        if (!n) return;
+        char *b = take(n);
+        MB_HIP(hipMemcpyAsync(b, dev, n, hipMemcpyDeviceToHost, s));
+        pending.push_back({host, b, n});
+    }
+    void done() {                                 // the stream is idle
+        for (const Out &o : pending) memcpy(o.dst, o.src, o.n);
+        pending.clear();
+        while (chunks.size() > 1) { delete chunks.front(); chunks.erase(chunks.begin()); }      // the last one is as large as all before it together
+        used = 0;
+    }
+};
+
 // host substitution score (HOXD70 + N = -100)
 struct HostScoreTable {                     // 8 x 8 by the low three code bits: branch-free lookups in the anchor window scan
     int8_t s[64];
@@ -364,15 +410,87 @@ long env_long(const char *name, long dflt) {
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
+// Sequence sets come and go with every call of a phase (trimmed ingroups, chunk files): their device blocks are recycled through a
+// small per-process cache, because hipMalloc / hipFree cost as much as the upload itself and hipFree synchronises the device; and
+// the image of a set (separator padding, codes, contig table) is put together in pinned memory and travels in ONE copy.
+namespace {
+struct DeviceBlocks {
+    struct Block { int device; void *p; size_t cap; };
+    std::mutex mu;
+    std::vector<Block> free_list;
+    size_t cached = 0;
+    static constexpr size_t kKeep = (size_t)1 << 30;
+    void *take(int device, size_t bytes, size_t &cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = free_list.size();
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].device == device && free_list[i].cap >= bytes && free_list[i].cap <= 2 * bytes + 4096 && (best == free_list.size() || free_list[i].cap < free_list[best].cap)) best = i;
+            if (best < free_list.size()) {
+                Block b = free_list[best];
+                free_list.erase(free_list.begin() + (long)best);
+                cached -= b.cap; cap = b.cap;
+                return b.p;
+            }
+        }
+        void *p = nullptr;
+        cap = (bytes + 4095) & ~(size_t)4095;
+        MB_HIP(hipMalloc(&p, cap));
+        return p;
+    }
+    void give(int device, void *p, size_t cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (cached + cap <= kKeep) { free_list.push_back({device, p, cap}); cached += cap; return; }
+        }
+        (void)hipFree(p);
+    }
+    ~DeviceBlocks() { for (Block &b : free_list) (void)hipFree(b.p); }
+};
+DeviceBlocks &device_blocks() { static DeviceBlocks *d = new DeviceBlocks(); return *d; }       // (never destroyed: the HIP runtime may be gone first)
+
+struct UploadStage {                               // pinned staging of set images up to kMax bytes; larger sets are copied from where they lie
+    std::mutex mu;
+    char *p = nullptr;
+    size_t n = 0;
+    static constexpr size_t kMax = (size_t)64 << 20;
+    char *ensure(size_t bytes) {
+        if (bytes > n) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; n = bytes + bytes / 4;
+            MB_HIP(hipHostMalloc((void **)&p, n, hipHostMallocDefault));
+        }
+        return p;
+    }
+};
+UploadStage &upload_stage() { static UploadStage *u = new UploadStage(); return *u; }
+}  // namespace
+
 void upload_seqset(SeqSet &s, int device) {
     MB_HIP(hipSetDevice(device));
     s.device = device;
-    MB_HIP(hipMalloc((void **)&s.d_buf, (size_t)s.total + 2 * kDevPad));
-    MB_HIP(hipMemset(s.d_buf, 0xFF, (size_t)s.total + 2 * kDevPad));
+    const size_t nc = std::max<size_t>(1, s.starts.size());
+    const size_t seq_bytes = ((size_t)s.total + 2 * kDevPad + 255) & ~(size_t)255, image = seq_bytes + 2 * nc * sizeof(int64_t);
+    s.d_buf = (uint8_t *)device_blocks().take(device, image, s.d_cap);
+    s.d_starts = (int64_t *)(s.d_buf + seq_bytes);
+    s.d_lens = s.d_starts + nc;
+    if (image <= UploadStage::kMax) {
+        UploadStage &u = upload_stage();
+        std::lock_guard<std::mutex> lk(u.mu);
+        char *h = u.ensure(image);
+        memset(h, 0xFF, kDevPad);
+        if (s.total) memcpy(h + kDevPad, s.host(), (size_t)s.total);
+        memset(h + kDevPad + (size_t)s.total, 0xFF, seq_bytes - kDevPad - (size_t)s.total);
+        memset(h + seq_bytes, 0, 2 * nc * sizeof(int64_t));
+        if (!s.starts.empty()) {
+            memcpy(h + seq_bytes, s.starts.data(), s.starts.size() * sizeof(int64_t));
+            memcpy(h + seq_bytes + nc * sizeof(int64_t), s.lens.data(), s.lens.size() * sizeof(int64_t));
+        }
+        MB_HIP(hipMemcpy(s.d_buf, h, image, hipMemcpyHostToDevice));
+        return;
+    }
+    MB_HIP(hipMemset(s.d_buf, 0xFF, seq_bytes));
     if (s.total) MB_HIP(hipMemcpy(s.d_buf + kDevPad, s.host(), (size_t)s.total, hipMemcpyHostToDevice));
-    size_t nc = std::max<size_t>(1, s.starts.size());
-    MB_HIP(hipMalloc((void **)&s.d_starts, nc * sizeof(int64_t)));
-    MB_HIP(hipMalloc((void **)&s.d_lens, nc * sizeof(int64_t)));
     if (!s.starts.empty()) {
         MB_HIP(hipMemcpy(s.d_starts, s.starts.data(), s.starts.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         MB_HIP(hipMemcpy(s.d_lens, s.lens.data(), s.lens.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -380,10 +498,8 @@ void upload_seqset(SeqSet &s, int device) {
 }
 
 void release_seqset(SeqSet &s) {
-    if (s.d_buf) (void)hipFree(s.d_buf);
-    if (s.d_starts) (void)hipFree(s.d_starts);
-    if (s.d_lens) (void)hipFree(s.d_lens);
-    s.d_buf = nullptr; s.d_starts = nullptr; s.d_lens = nullptr;
+    if (s.d_buf) device_blocks().give(s.device, s.d_buf, s.d_cap);
+    s.d_buf = nullptr; s.d_starts = nullptr; s.d_lens = nullptr; s.d_cap = 0;
 }
 
 
@@ -402,6 +518,15 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<DevHsp> hsps;
     DevBuf<UngappedCounters> ctr;
     DevBuf<unsigned> heads, n_heads;
+    // both strands of a pair in one go (seed_phase, fused path): events per strand, pinned read-back areas
+    hipEvent_t sev[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    unsigned long long last_strand_hits = 0;  // hits of the larger strand of the last pair seeded with this workspace
+    PinBuf<unsigned long long> pin_u64;
+    PinBuf<UngappedCounters> pin_ctr;
+    PinBuf<DevHsp> pin_hsps;
+    Stager stage;
+    struct RcSlot { DevBuf<uint8_t> d; PinBuf<uint8_t> h; };        // '-' strands of pairs 1.. of a batched call (device + pinned host copy)
+    std::vector<std::unique_ptr<RcSlot>> rc_pool;
     // gapped
     DevBuf<DpProb> probs;
     DevBuf<DpOut> outs;
@@ -439,6 +564,7 @@ static Ctx *lane_create(int device) {
 
 void workspace_destroy(Workspace *w) {
     if (!w) return;
+    for (auto &row : w->sev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
     for (Ctx *c : w->lanes) {
         for (hipEvent_t e : {c->ev0, c->ev1, c->ev2, c->ev3, c->ev4}) if (e) (void)hipEventDestroy(e);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -462,6 +588,9 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     w.positions.ensure((size_t)std::max<int64_t>(1, n_slots));
     int64_t nblk = ((int64_t)kBuckets + 1 + 2047) / 2048;
     w.bsum.ensure((size_t)nblk + 2);
+    static const long spike_ms = env_long("MIBLAST_DEBUG_SPIKE", 0);
+    const double t0 = now_s();
+    if (spike_ms) MB_HIP(hipEventRecord(ctx.ev0, s));
     MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
     launch_index_words(T.dev(), T.total, step, first, w.words.p, n_slots, w.counts.p, s);
     launch_scan_u32(w.counts.p, w.offsets.p, (int64_t)kBuckets + 1, w.bsum.p, s);
@@ -469,8 +598,18 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     launch_index_scatter(w.words.p, n_slots, step, first, w.offsets.p, w.counts.p, w.positions.p, s);
     w.occ.ensure((size_t)kBuckets / 32);
     launch_bucket_bitmap(w.offsets.p, w.occ.p, s);
-    MB_HIP(hipMemcpyAsync(&ix.n_positions, w.offsets.p + kBuckets, 4, hipMemcpyDeviceToHost, s));
+    if (spike_ms) MB_HIP(hipEventRecord(ctx.ev1, s));
+    const double t1 = now_s();
+    w.stage.d2h(&ix.n_positions, w.offsets.p + kBuckets, 4, s);
+    const double t2 = now_s();
     MB_HIP(hipStreamSynchronize(s));
+    w.stage.done();
+    if (spike_ms && (now_s() - t0) * 1e3 > (double)spike_ms) {
+        float ms = 0;
+        MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+        fprintf(stderr, "[miblast] slow index build: queueing %.2f ms, copy call %.2f ms, wait %.2f ms; device time first..last kernel %.2f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3,
+                (now_s() - t2) * 1e3, ms);
+    }
 }
 
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions) {
@@ -520,8 +659,8 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     const SeqSet *T = nullptr, *Q = nullptr;
     Result *res = nullptr;
     bool use_ws_rc = true;                // pair 0 keeps its '-' strand in the persistent workspace
-    DevBuf<uint8_t> own_rc;
-    std::vector<uint8_t> h_rc;
+    DevBuf<uint8_t> *slot_rc = nullptr;   // other pairs of a batch: a slot of the calling context's pool (Workspace::rc_pool)
+    PinBuf<uint8_t> *slot_h_rc = nullptr;
     const uint8_t *tc_h = nullptr;
     const uint8_t *qc_h[2] = {nullptr, nullptr};
     const uint8_t *qc_d[2] = {nullptr, nullptr};
@@ -655,26 +794,20 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     Index ix;
     build_index(ctx, T, p.step, ix);
     st.t_index = now_s() - t_begin;
+    double tp[8] = {t_begin, now_s(), 0, 0, 0, 0, 0, 0};          // MIBLAST_DEBUG_SPIKE: where a slow seed phase spent its time
 
     // ---- '-' strand of the query -----------------------------------------------------------------
-    DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : job.own_rc;
+    DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : *job.slot_rc;
     d_rc.ensure((size_t)qtot + 2 * kDevPad);
     MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
     launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
-    // host copy of the '-' strand (discovery order, anchors, '='/'X' classification).  Pair 0 of a call uses the context's
-    // pinned buffer: the copy is asynchronous and is complete long before the first host read (the host half of strand '-'
-    // comes after several synchronisations of this stream); other pairs of a batch use pageable memory and wait here.
-    uint8_t *h_rc_p;
-    if (job.use_ws_rc) {
-        w.h_rc.ensure((size_t)qtot + 2);
-        h_rc_p = w.h_rc.p;
-        MB_HIP(hipMemcpyAsync(h_rc_p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
-    } else {
-        job.h_rc.resize((size_t)qtot + 2);
-        h_rc_p = job.h_rc.data();
-        MB_HIP(hipMemcpyAsync(h_rc_p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
-        MB_HIP(hipStreamSynchronize(s));
-    }
+    // host copy of the '-' strand (discovery order, anchors, '='/'X' classification) in pinned memory -- the context's buffer for
+    // pair 0 of a call, a pooled slot for the other pairs of a batch: the copy is asynchronous and is complete long before the
+    // first host read (the host half of strand '-' comes after several synchronisations of this stream).
+    PinBuf<uint8_t> &h_rc = job.use_ws_rc ? w.h_rc : *job.slot_h_rc;
+    h_rc.ensure((size_t)qtot + 2);
+    uint8_t *h_rc_p = h_rc.p;
+    MB_HIP(hipMemcpyAsync(h_rc_p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
     job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc_p + 1;
     job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
     const uint8_t *const *qc_d = job.qc_d;
@@ -698,8 +831,95 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
     strand_hsps[0].clear(); strand_hsps[1].clear();
 
+    // ---- both strands in one go.  When the key buffer of an earlier call is likely to hold the hits of both strands (half each),
+    // the two seed searches are queued back to back with ONE read-back of their totals, then sort + ungapped extension of both
+    // strands back to back with ONE read-back of the counters, then the HSPs: three synchronisations per pair instead of six, and
+    // no bubble between the strands' kernels.  A strand whose hits do not fit goes through the per-strand path below.
+    bool strand_done[2] = {false, false};
+    unsigned long long strand_hits[2] = {0, 0};                  // (for sizing the key buffer of the next call)
     std::future<void> host0;
+    if (one_pass && qtot >= kSeedSpan && env_long("MIBLAST_SEED_FUSED", 1) != 0) {
+        const unsigned long long capH = std::min<unsigned long long>((unsigned long long)keys_a.n, (unsigned long long)hit_cap) / 2;
+        // (a pair like the previous one of this workspace must fit, else the attempt costs two searches for nothing)
+        if (capH > 0 && w.last_strand_hits + w.last_strand_hits / 8 <= capH) {
+            const double t0 = now_s();
+            for (auto &row : w.sev) for (hipEvent_t &e : row) if (!e) MB_HIP(hipEventCreate(&e));
+            qbsum.ensure(4); w.pin_u64.ensure(16); w.pin_ctr.ensure(2); d_ctr.ensure(2);
+            MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
+            for (int strand = 0; strand < 2; strand++) {
+                MB_HIP(hipEventRecord(w.sev[strand][0], s));
+                launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, keys_a.p + (size_t)strand * capH, capH, qbsum.p + strand, s);
+                MB_HIP(hipEventRecord(w.sev[strand][1], s));
+            }
+            MB_HIP(hipMemcpyAsync(w.pin_u64.p, qbsum.p, 16, hipMemcpyDeviceToHost, s));
+            tp[2] = now_s();
+            MB_HIP(hipStreamSynchronize(s));                                       // (1) hits per strand
+            tp[3] = now_s();
+            unsigned long long nh[2] = {w.pin_u64.p[0], w.pin_u64.p[1]};
+            bool fits[2] = {nh[0] <= capH && nh[0] < (1ull << 31), nh[1] <= capH && nh[1] < (1ull << 31)};
+            const unsigned long long nh_max = std::max(fits[0] ? nh[0] : 0ull, fits[1] ? nh[1] : 0ull);
+            const size_t hoff[2] = {0, fits[0] ? (size_t)nh[0] : 0};
+            if (nh_max) {
+                keys_b.ensure((size_t)nh_max);
+                d_hsps.ensure((fits[0] ? (size_t)nh[0] : 0) + (fits[1] ? (size_t)nh[1] : 0));
+                w.heads.ensure(2 * (size_t)nh_max + (size_t)nh_max / 4 + 64); w.n_heads.ensure(8);
+                const size_t tb = sort_keys_temp_bytes((int64_t)nh_max, sort_bits);
+                sort_temp.ensure(tb + 16);
+                MB_HIP(hipMemsetAsync(d_ctr.p, 0, 2 * sizeof(UngappedCounters), s));
+                // every strand's counters and its first kBlind HSPs are copied back right behind its kernels, so that the host half
+                // of strand '+' (discovery order, entropy filter) starts while the device is still busy with strand '-'
+                constexpr size_t kBlind = 16384;
+                size_t blind[2] = {0, 0};
+                w.pin_hsps.ensure(2 * kBlind);
+                for (int strand = 0; strand < 2; strand++) {
+                    if (!fits[strand] || !nh[strand]) continue;
+                    MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
+                    MB_HIP(hipEventRecord(w.sev[strand][2], s));
+                    sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], sort_bits, s);
+                    MB_HIP(hipEventRecord(w.sev[strand][3], s));
+                    MB_HIP(hipEventRecord(w.sev[strand][4], s));
+                    launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, ttot + qtot, extent.p, p.xdrop, p.hspthresh,
+                                    d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, s);
+                    MB_HIP(hipEventRecord(w.sev[strand][5], s));
+                    MB_HIP(hipMemcpyAsync(w.pin_ctr.p + strand, d_ctr.p + strand, sizeof(UngappedCounters), hipMemcpyDeviceToHost, s));
+                    blind[strand] = std::min<size_t>(kBlind, (size_t)nh[strand]);
+                    MB_HIP(hipMemcpyAsync(w.pin_hsps.p + (size_t)strand * kBlind, d_hsps.p + hoff[strand], blind[strand] * sizeof(DevHsp), hipMemcpyDeviceToHost, s));
+                    MB_HIP(hipEventRecord(strand == 0 ? ctx.ev0 : ctx.ev1, s));
+                }
+                for (int strand = 0; strand < 2; strand++) {
+                    if (!fits[strand] || !nh[strand]) continue;
+                    if (strand == 0) tp[4] = now_s();
+                    MB_HIP(hipEventSynchronize(strand == 0 ? ctx.ev0 : ctx.ev1));           // (2), (3): this strand is done (the other may still run)
+                    tp[5 + strand] = now_s();
+                    const UngappedCounters hc = w.pin_ctr.p[strand];
+                    if (hc.hsps > nh[strand]) { set_error("HSP buffer overflow"); return MIBLAST_ELIMIT; }
+                    st.hits_extended += (int64_t)hc.extended; st.ungapped_cols += (int64_t)hc.cols;
+                    float ms;
+                    MB_HIP(hipEventElapsedTime(&ms, w.sev[strand][0], w.sev[strand][1])); st.t_seedfill_ms += ms;
+                    MB_HIP(hipEventElapsedTime(&ms, w.sev[strand][2], w.sev[strand][3])); st.t_sort_ms += ms;
+                    MB_HIP(hipEventElapsedTime(&ms, w.sev[strand][4], w.sev[strand][5])); st.t_ungapped_kernel_ms += ms; st.ungapped_kernel_launches++;
+                    std::vector<DevHsp> &found = job.found[strand];
+                    found.assign(w.pin_hsps.p + (size_t)strand * kBlind, w.pin_hsps.p + (size_t)strand * kBlind + std::min<size_t>(blind[strand], (size_t)hc.hsps));
+                    if ((size_t)hc.hsps > blind[strand]) {                                   // more HSPs than the blind copy took: the rest now
+                        found.resize((size_t)hc.hsps);
+                        MB_HIP(hipMemcpy(found.data() + blind[strand], d_hsps.p + hoff[strand] + blind[strand], ((size_t)hc.hsps - blind[strand]) * sizeof(DevHsp), hipMemcpyDeviceToHost));
+                    }
+                    strand_done[strand] = true; strand_hits[strand] = nh[strand]; st.seed_hits += (int64_t)nh[strand]; st.seed_batches++;
+                    if (!job.defer_host && strand == 0) host0 = std::async(std::launch::async, [&p, &job] { seed_host(p, job, 0); });
+                }
+            } else {
+                float ms;
+                for (int strand = 0; strand < 2; strand++) { MB_HIP(hipEventElapsedTime(&ms, w.sev[strand][0], w.sev[strand][1])); st.t_seedfill_ms += ms; }
+            }
+            for (int strand = 0; strand < 2; strand++) if (fits[strand] && !nh[strand]) strand_done[strand] = true;      // a strand without a hit
+            st.t_seed += now_s() - t0;
+        }
+    }
     for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
+        if (strand_done[strand]) {
+            if (!job.defer_host && strand == 0 && !host0.valid()) host0 = std::async(std::launch::async, [&p, &job] { seed_host(p, job, 0); });
+            continue;
+        }
         const double t0 = now_s();
         MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
         std::vector<DevHsp> found;
@@ -707,6 +927,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
         auto extend_batch = [&](unsigned long long nh, bool timed_fill) -> int {
             if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one batch (unmasked repeat?)"); return MIBLAST_ELIMIT; }
+            strand_hits[strand] += nh;
             st.seed_hits += (int64_t)nh;
             st.seed_batches++;
             keys_b.ensure((size_t)nh);
@@ -723,8 +944,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                             (int64_t)d_hsps.n, d_ctr.p, s);
             MB_HIP(hipEventRecord(ctx.ev4, s));
             UngappedCounters hc;
-            MB_HIP(hipMemcpyAsync(&hc, d_ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
+            w.stage.d2h(&hc, d_ctr.p, sizeof hc, s);
             MB_HIP(hipStreamSynchronize(s));
+            w.stage.done();
             float ms;
             if (timed_fill) { MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1)); st.t_seedfill_ms += ms; }
             MB_HIP(hipEventElapsedTime(&ms, ctx.ev1, ctx.ev2)); st.t_sort_ms += ms;
@@ -747,8 +969,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev0, s));
             launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
             unsigned long long total = 0;
-            MB_HIP(hipMemcpyAsync(&total, qbsum.p, 8, hipMemcpyDeviceToHost, s));
+            w.stage.d2h(&total, qbsum.p, 8, s);
             MB_HIP(hipStreamSynchronize(s));
+            w.stage.done();
             if (total <= cap1) {
                 one_pass_done = true;
                 if (total) { rc_batch = extend_batch(total, true); if (rc_batch != MIBLAST_OK) return rc_batch; }
@@ -781,6 +1004,20 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         st.t_seed += now_s() - t0;
         // the host half of strand '+' (ordering, entropy filter) overlaps the device half of strand '-'
         if (!job.defer_host && strand == 0) host0 = std::async(std::launch::async, [&p, &job] { seed_host(p, job, 0); });
+    }
+    // room for both strands of a pair like this one in the key buffer, so that the next call takes the fused path
+    {
+        const unsigned long long want = 2 * (std::max(strand_hits[0], strand_hits[1]) + std::max(strand_hits[0], strand_hits[1]) / 4) + 1024;
+        if (want <= (unsigned long long)hit_cap && (unsigned long long)keys_a.n < want) keys_a.ensure((size_t)want);
+        w.last_strand_hits = std::max(strand_hits[0], strand_hits[1]);
+    }
+    {
+        static const long spike_ms = env_long("MIBLAST_DEBUG_SPIKE", 0);
+        tp[7] = now_s();
+        if (spike_ms > 0 && (tp[7] - tp[0]) * 1e3 > (double)spike_ms)
+            fprintf(stderr, "[miblast] slow seed phase %.2f ms (T %lld, Q %lld): index %.2f | to search queued %.2f | wait hits %.2f | to strands queued %.2f | wait '+' %.2f | wait '-' %.2f | rest %.2f\n",
+                    (tp[7] - tp[0]) * 1e3, (long long)ttot, (long long)qtot, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3, (tp[4] - tp[3]) * 1e3,
+                    (tp[5] - tp[4]) * 1e3, (tp[6] - tp[5]) * 1e3, (tp[7] - tp[6]) * 1e3);
     }
     if (host0.valid()) host0.get();
     if (!job.defer_host) {
@@ -1302,17 +1539,18 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 outs.resize(pieces.size()); vres.resize(vjobs.size());
                 for (size_t x = launched; x < pieces.size(); x++)
                     if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = kSnapSlots * relay_pts[(size_t)pieces[x].target].piece + (pieces[x].ckpt == 0 ? 0 : pieces[x].ckpt + 1);
-                MB_HIP(hipMemcpyAsync(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), hipMemcpyHostToDevice, s));
-                if (v_new) MB_HIP(hipMemcpyAsync(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), hipMemcpyHostToDevice, s));
+                g.stage.h2d(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), s);
+                g.stage.h2d(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), s);
                 // valid = 0 in every header of the new pieces' slots (the headers only: the slots are 16 KiB apart)
                 MB_HIP(hipMemset2DAsync(g.snaps.p + launched * kSnapSlots * kSnapBytes, kSnapBytes, 0, sizeof(SnapHdr), n_new * kSnapSlots, s));
                 // DP launch, hand-over checks and the copies of both results: one synchronisation.  (Checks made on pieces that
                 // turn out to need a rerun are simply made again.)
                 run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true);
                 launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
-                MB_HIP(hipMemcpyAsync(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), hipMemcpyDeviceToHost, s));
-                if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
+                g.stage.d2h(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), s);
+                g.stage.d2h(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), s);
                 MB_HIP(hipStreamSynchronize(s));
+                g.stage.done();
                 collect_dp_time(ctx, st);
                 lap(2);
                 if (debug) fprintf(stderr, "[miblast]   first pass (kernel %d): dp kernel total %.2f ms\n", dp_kernel, st.t_dp_kernel_ms);
@@ -1324,16 +1562,19 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         std::vector<DpProb> sub(again.size());
                         for (size_t y = 0; y < again.size(); y++) sub[y] = probs[again[y]];
                         g.probs.ensure_keep(pieces.size() + again.size()); g.outs.ensure_keep(pieces.size() + again.size());
-                        MB_HIP(hipMemcpyAsync(g.probs.p + pieces.size(), sub.data(), sub.size() * sizeof(DpProb), hipMemcpyHostToDevice, s));
+                        g.stage.h2d(g.probs.p + pieces.size(), sub.data(), sub.size() * sizeof(DpProb), s);
                         run_ydrop_timed(ctx, st, kDpLds, g.probs.p + pieces.size(), g.outs.p + pieces.size(), (int)again.size(), g.pair_ptrs.p, p, kBlk);
                         std::vector<DpOut> so(again.size());
-                        MB_HIP(hipMemcpy(so.data(), g.outs.p + pieces.size(), so.size() * sizeof(DpOut), hipMemcpyDeviceToHost));
+                        g.stage.d2h(so.data(), g.outs.p + pieces.size(), so.size() * sizeof(DpOut), s);
+                        MB_HIP(hipStreamSynchronize(s));
+                        g.stage.done();
                         for (size_t y = 0; y < again.size(); y++) outs[again[y]] = so[y];
                         st.dp_reruns += (int64_t)again.size();
                         if (debug) fprintf(stderr, "[miblast]   %zu of %zu pieces outgrew the one-wave kernel and were rerun (dp kernel total %.2f ms)\n", again.size(), n_new, st.t_dp_kernel_ms);
                         launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
-                        if (v_new) MB_HIP(hipMemcpyAsync(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), hipMemcpyDeviceToHost, s));
+                        g.stage.d2h(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), s);
                         MB_HIP(hipStreamSynchronize(s));
+                        g.stage.done();
                     }
                 }
                 for (size_t x = launched; x < pieces.size(); x++) arena_full |= outs[x].overflow == 3;
@@ -1465,9 +1706,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     g.probs.ensure_keep(pieces.size()); g.outs.ensure_keep(pieces.size()); g.rowdir.ensure_keep((size_t)dir_entries + 1);
                     outs.resize(pieces.size());
                     g.grows.ensure(n_new * 2 * (size_t)kGlobalRowCap);
-                    MB_HIP(hipMemcpy(g.probs.p + first, probs.data() + first, n_new * sizeof(DpProb), hipMemcpyHostToDevice));
+                    g.stage.h2d(g.probs.p + first, probs.data() + first, n_new * sizeof(DpProb), s);
                     run_ydrop_timed(ctx, st, kDpHbm, g.probs.p + first, g.outs.p + first, (int)n_new, g.pair_ptrs.p, p, kBlkWide);
-                    MB_HIP(hipMemcpy(outs.data() + first, g.outs.p + first, n_new * sizeof(DpOut), hipMemcpyDeviceToHost));
+                    g.stage.d2h(outs.data() + first, g.outs.p + first, n_new * sizeof(DpOut), s);
+                    MB_HIP(hipStreamSynchronize(s));
+                    g.stage.done();
                     for (size_t x = first; x < pieces.size(); x++) {
                         const DpOut &o = outs[x];
                         if (o.overflow == 1) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
@@ -1555,15 +1798,16 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (!acc.empty()) {
             g.tb_sides.ensure(tbs.size()); g.tb_walks.ensure(tbw.size()); g.tb_segs.ensure((size_t)soff + 1);
             g.ops.ensure((size_t)ooff + 64); g.recs.ensure((size_t)roff + 64);
-            MB_HIP(hipMemcpyAsync(g.tb_sides.p, tbs.data(), tbs.size() * sizeof(TbSide), hipMemcpyHostToDevice, s));
-            MB_HIP(hipMemcpyAsync(g.tb_walks.p, tbw.data(), tbw.size() * sizeof(TbWalk), hipMemcpyHostToDevice, s));
+            g.stage.h2d(g.tb_sides.p, tbs.data(), tbs.size() * sizeof(TbSide), s);
+            g.stage.h2d(g.tb_walks.p, tbw.data(), tbw.size() * sizeof(TbWalk), s);
             launch_trace_walk(g.tb_walks.p, (int)tbw.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, s);
             launch_trace_join(g.tb_sides.p, (int)tbs.size(), g.tb_walks.p, g.tb_segs.p, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p,
                               g.ops.p, g.recs.p, s);
             std::vector<TbSeg> segs((size_t)soff + 1);
-            MB_HIP(hipMemcpyAsync(tbs.data(), g.tb_sides.p, tbs.size() * sizeof(TbSide), hipMemcpyDeviceToHost, s));
-            MB_HIP(hipMemcpyAsync(segs.data(), g.tb_segs.p, (size_t)soff * sizeof(TbSeg), hipMemcpyDeviceToHost, s));
+            g.stage.d2h(tbs.data(), g.tb_sides.p, tbs.size() * sizeof(TbSide), s);
+            g.stage.d2h(segs.data(), g.tb_segs.p, (size_t)soff * sizeof(TbSeg), s);
             MB_HIP(hipStreamSynchronize(s));
+            g.stage.done();
             // only the run slots actually used travel: the segments are packed on the device in walk order, then one copy
             std::vector<TbSeg> flat;
             std::vector<unsigned long long> dst;
@@ -1578,11 +1822,12 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             }
             coff[tbs.size()] = ctot;
             g.tb_segs.ensure(flat.size() + 1); g.coff.ensure(dst.size() + 1); g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
-            MB_HIP(hipMemcpyAsync(g.tb_segs.p, flat.data(), flat.size() * sizeof(TbSeg), hipMemcpyHostToDevice, s));
-            MB_HIP(hipMemcpyAsync(g.coff.p, dst.data(), dst.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+            g.stage.h2d(g.tb_segs.p, flat.data(), flat.size() * sizeof(TbSeg), s);
+            g.stage.h2d(g.coff.p, dst.data(), dst.size() * sizeof(unsigned long long), s);
             launch_pack_segs(g.tb_segs.p, g.coff.p, (int)flat.size(), g.ops.p, g.ops_packed.p, s);
             if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
+            g.stage.done();
             const uint32_t *hops = g.hops.p;
             st.t_traceback_ms += (now_s() - t_tb0) * 1e3;
             if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, tbs.size(), (unsigned long long)ooff);
@@ -1886,6 +2131,11 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         store.emplace_back(new PairJob());
         PairJob &j = *store.back();
         j.T = Ts[k]; j.Q = Qs[k]; j.res = results[k]; j.use_ws_rc = (k == 0);
+        if (k > 0) {
+            Workspace &w0 = *ctx.ws;
+            while (w0.rc_pool.size() < k) w0.rc_pool.emplace_back(new Workspace::RcSlot());
+            j.slot_rc = &w0.rc_pool[k - 1]->d; j.slot_h_rc = &w0.rc_pool[k - 1]->h;
+        }
         j.defer_host = n > 1;
         jobs.push_back(&j);
     }
@@ -1955,7 +2205,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         std::vector<PairPtrs> pp(n);
         for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }
         ctx.ws->pair_ptrs.ensure(n);
-        MB_HIP(hipMemcpy(ctx.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), hipMemcpyHostToDevice));
+        ctx.ws->stage.h2d(ctx.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), ctx.stream);          // (in stream order before the first DP launch)
     }
     int rc = gapped_phase(ctx, p, jobs, units);
     if (rc != MIBLAST_OK) return rc;

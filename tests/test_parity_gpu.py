@@ -63,6 +63,7 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
                 {"MIBLAST_DP_KERNEL": "2"}, {"MIBLAST_DP_KERNEL": "4"}, {"MIBLAST_DP_KERNEL": "8"}, {"MIBLAST_DP_KERNEL": "100"},
                 {"MIBLAST_DP_WAVES": "4"}, {"MIBLAST_DP_WAVES": "3"},    # the 128-VGPR build of the one-wave DP kernel (4 waves per SIMD) / the default
                 {"MIBLAST_SEED_ONE_PASS": "0"},                 # two-pass seed search (count, scan, fill) instead of the fused one
+                {"MIBLAST_SEED_FUSED": "0"},                    # strands one after the other instead of both in one go
                 {"MIBLAST_LONG_RUN": "4"}, {"MIBLAST_LONG_RUN": "32"},      # which diagonal runs go to the wave-per-run ungapped kernel
                 {"MIBLAST_RELAY_CKPT": "0"},                    # rejected hand-overs continue to the next relay instead of retrying at a later snapshot
                 {"MIBLAST_CHAIN_HEADS": "0"},                   # first-round nomination by spatial thinning instead of one head per colinear anchor group
