@@ -208,6 +208,13 @@ def parsed_records(fa: bytes, keep: bool = False) -> List[Tuple[str, np.ndarray]
 def unaligned_fasta(paf: bytes, query_fa: bytes, min_size: int, flank: int) -> bytes:
     """`paffy to_bed --excludeAligned --minSize N` + `faffy extract --flank F` (local_alignment.py:460-475): the parts of the QUERY
     file no alignment of `paf` covers, at least min_size long, widened by flank, as records NAME|SEQLEN|START."""
+    from cactus_amd import mipaf
+    return mipaf.unaligned_fasta(paf, query_fa, min_size, flank)
+
+
+def unaligned_fasta_py(paf: bytes, query_fa: bytes, min_size: int, flank: int) -> bytes:
+    """the same through the Python cores of cactus_amd.paf.chunking (what the file-based front ends use; the native text code
+    is checked against this in tests/test_blast_phase_cpu.py)"""
     from cactus_amd import gen
     recs = parsed_records(query_fa)
     bed = chunking.unaligned_intervals(paf.decode().splitlines(), [(n, len(s)) for n, s in recs], min_size)
@@ -228,7 +235,7 @@ def invert(paf: bytes) -> bytes:
     from cactus_amd import mipaf
     s = mipaf.PafSet.from_text(paf)
     try:
-        return s.invert().text().encode()
+        return s.invert().text_bytes()
     finally:
         s.close()
 
@@ -249,6 +256,12 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     last_paf: Dict[Tuple[str, str], Tuple[bytes, bytes]] = {}       # (node, ingroup) -> (query FASTA, raw PAF) of the previous level
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=8)          # the chains of a level are independent jobs (numpy / the library release the GIL)
+    finished: Dict[int, object] = {}
+
+    def chain_share(paf: bytes, depth: int) -> bytes:
+        for _ in range(depth):
+            paf = dechunk_query(paf) if paf else paf
+        return invert(paf)
     for level in range(max(c.level for c in calls) + 1):
         todo: List[int] = []
         trimmed = {}
@@ -297,6 +310,9 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
                 raw[i] = paf
                 if calls[i].chain is not None:
                     last_paf[calls[i].chain] = (query_fa[i], paf)
+                    # its share of the chain's final file is a job of its own (dechunk and invert work record by record), started
+                    # now: it runs beside the next level's calls instead of after the last one
+                    finished[i] = pool.submit(chain_share, paf, level)
                 if on_call is not None:
                     on_call(calls[i], genomes[calls[i].target], query_fa[i], paf)
     # assemble: outgroup chains are merged innermost first (each level's sub-sequence coordinates fixed by dechunk --query,
@@ -310,14 +326,11 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     for i, c in enumerate(calls):
         if c.chain is not None:
             chains.setdefault(c.chain, []).append(i)
-    def assemble(idx):
-        idx = sorted(idx, key=lambda i: calls[i].level)
-        merged = b""
-        for i in reversed(idx):
-            merged = raw[i] + (dechunk_query(merged) if merged else b"")
-        return invert(merged)
-
-    for key, out in zip(chains, pool.map(assemble, chains.values())):
-        result[key[0]]["outgroup"] += out
+    # make_ingroup_to_outgroup_alignments_3 merges a chain innermost first -- merged = raw[k] + dechunk(merged of k+1 ..) -- and
+    # inverts the lot: per record that is invert(dechunk^k(record of level k)), in level order, which is what chain_share made
+    for key, idx in chains.items():
+        for i in sorted(idx, key=lambda i: calls[i].level):
+            if i in finished:
+                result[key[0]]["outgroup"] += finished[i].result()
     pool.shutdown()
     return result

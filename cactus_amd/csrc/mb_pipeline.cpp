@@ -2139,7 +2139,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         j.defer_host = n > 1;
         jobs.push_back(&j);
     }
-    const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, env_long("MIBLAST_SEED_LANES", 4))) : 1;
+    const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, env_long("MIBLAST_SEED_LANES", 12))) : 1;
     if (n_lanes > 1) {
         // Batched call: the pairs are dealt to a few lanes, each a host thread with its own stream and seed-stage buffers.  A
         // lane runs the device half of a pair's seed stage, then the host half (discovery order, entropy filter, anchors)

@@ -1007,6 +1007,113 @@ int mipaf_dechunk_text(const char *paf, size_t len, int32_t query_only, char **o
     return MIBLAST_OK;
 }
 
+int mipaf_unaligned_fasta(const char *paf, size_t paf_len, const char *fasta, size_t fasta_len, int64_t min_size, int64_t flank,
+                          char **out_text, size_t *out_len) {
+    if ((!paf && paf_len) || (!fasta && fasta_len) || !out_text || !out_len) return MIBLAST_EINVAL;
+    *out_text = nullptr; *out_len = 0;
+    // ---- records of the FASTA text: name = first word of the header, body = the lines up to the next '>' at a line start
+    struct Rec { std::string name; size_t body, body_end; int64_t len; std::vector<std::pair<int64_t, int64_t>> spans; };
+    std::vector<Rec> recs;
+    for (size_t pos = 0; pos < fasta_len;) {
+        if (fasta[pos] != '>') {                                   // (text before the first header is ignored, as the parsers do)
+            const char *nl = (const char *)memchr(fasta + pos, '\n', fasta_len - pos);
+            pos = nl ? (size_t)(nl - fasta) + 1 : fasta_len;
+            continue;
+        }
+        const char *nl = (const char *)memchr(fasta + pos, '\n', fasta_len - pos);
+        const size_t hend = nl ? (size_t)(nl - fasta) : fasta_len;
+        size_t a = pos + 1;
+        while (a < hend && (fasta[a] == ' ' || fasta[a] == '\t')) a++;
+        size_t b = a;
+        while (b < hend && fasta[b] != ' ' && fasta[b] != '\t' && fasta[b] != '\r') b++;
+        Rec r;
+        r.name.assign(fasta + a, b - a);
+        r.body = nl ? hend + 1 : fasta_len;
+        size_t q = r.body;
+        int64_t n = 0;
+        while (q < fasta_len && fasta[q] != '>') {                   // one line at a time
+            const char *e = (const char *)memchr(fasta + q, '\n', fasta_len - q);
+            size_t le = e ? (size_t)(e - fasta) : fasta_len;
+            const size_t next = e ? le + 1 : fasta_len;
+            while (le > q && fasta[le - 1] == '\r') le--;
+            n += (int64_t)(le - q);
+            q = next;
+        }
+        r.body_end = q; r.len = n;
+        recs.push_back(std::move(r));
+        pos = q;
+    }
+    std::unordered_map<std::string, size_t> by_name;
+    for (size_t k = 0; k < recs.size(); k++) by_name.emplace(recs[k].name, k);
+    // ---- query intervals of the alignments
+    size_t line_no = 0;
+    for (size_t pos = 0; pos < paf_len;) {
+        const char *nl = (const char *)memchr(paf + pos, '\n', paf_len - pos);
+        const size_t end = nl ? (size_t)(nl - paf) : paf_len;
+        line_no++;
+        size_t p = pos;
+        pos = end + 1;
+        bool blank = true;
+        for (size_t x = p; x < end && blank; x++) blank = paf[x] == ' ' || paf[x] == '\t' || paf[x] == '\r';
+        if (blank) continue;
+        const char *t[4];
+        bool ok = true;
+        size_t c = p;
+        for (int k = 0; k < 4 && ok; k++) {
+            t[k] = (const char *)memchr(paf + c, '\t', end - c);
+            if (!t[k]) ok = false; else c = (size_t)(t[k] - paf) + 1;
+        }
+        if (!ok) { mb::set_error("to_bed: PAF line " + std::to_string(line_no) + " has fewer than 5 columns"); return MIBLAST_EINVAL; }
+        const std::string name(paf + p, (size_t)(t[0] - (paf + p)));
+        const int64_t s0 = strtoll(t[1] + 1, nullptr, 10), e0 = strtoll(t[2] + 1, nullptr, 10);
+        auto it = by_name.find(name);
+        if (it == by_name.end()) { mb::set_error("to_bed: PAF line " + std::to_string(line_no) + ": query " + name + " is not in the FASTA file"); return MIBLAST_EINVAL; }
+        if (e0 > s0) recs[it->second].spans.emplace_back(s0, e0);
+    }
+    // ---- uncovered stretches >= min_size, widened by flank and merged, cut out with 60 columns per line
+    std::string out;
+    std::string seq;
+    for (Rec &r : recs) {
+        std::sort(r.spans.begin(), r.spans.end());
+        std::vector<std::pair<int64_t, int64_t>> cut;
+        auto add = [&](int64_t s, int64_t e) {
+            s = std::max<int64_t>(0, s - flank); e = std::min<int64_t>(r.len, e + flank);
+            if (!cut.empty() && s <= cut.back().second) cut.back().second = std::max(cut.back().second, e);
+            else cut.emplace_back(s, e);
+        };
+        int64_t at = 0;
+        for (const auto &sp : r.spans) {
+            if (sp.first - at >= min_size && sp.first > at) add(at, sp.first);
+            at = std::max(at, sp.second);
+        }
+        if (r.len - at >= min_size && r.len > at) add(at, r.len);
+        if (cut.empty()) continue;
+        seq.clear();
+        seq.reserve((size_t)r.len);
+        for (size_t q = r.body; q < r.body_end;) {
+            const char *e = (const char *)memchr(fasta + q, '\n', r.body_end - q);
+            size_t le = e ? (size_t)(e - fasta) : r.body_end;
+            const size_t next = e ? le + 1 : r.body_end;
+            while (le > q && fasta[le - 1] == '\r') le--;
+            seq.append(fasta + q, le - q);
+            q = next;
+        }
+        for (const auto &iv : cut) {
+            out += '>'; out += r.name; out += '|'; out += std::to_string(r.len); out += '|'; out += std::to_string(iv.first); out += '\n';
+            for (int64_t x = iv.first; x < iv.second; x += 60) {
+                out.append(seq, (size_t)x, (size_t)std::min<int64_t>(60, iv.second - x));
+                out += '\n';
+            }
+        }
+    }
+    char *buf = (char *)malloc(out.size() + 1);
+    if (!buf) { mb::set_error("out of host memory"); return MIBLAST_ELIMIT; }
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    *out_text = buf; *out_len = out.size();
+    return MIBLAST_OK;
+}
+
 void mipaf_chain_params_default(mipaf_chain_params *p) {
     p->max_gap_length = 1000000; p->gap_open = 5000; p->gap_extend = 1; p->trim_fraction = 1.0;
 }

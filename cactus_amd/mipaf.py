@@ -24,7 +24,7 @@ class Stats(C.Structure):
 
 
 EXPORTED_SYMBOLS = ("mipaf_set_from_mem", "mipaf_set_from_file", "mipaf_set_free", "mipaf_set_size", "mipaf_set_text", "mipaf_set_write",
-                    "mipaf_invert", "mipaf_dechunk_text", "mipaf_chain_params_default", "mipaf_chain", "mipaf_tile", "mipaf_trim", "mipaf_filter",
+                    "mipaf_invert", "mipaf_dechunk_text", "mipaf_unaligned_fasta", "mipaf_chain_params_default", "mipaf_chain", "mipaf_tile", "mipaf_trim", "mipaf_filter",
                     "mipaf_split_by_query", "mipaf_chain_tile_trim_filter")
 
 _bound = False
@@ -44,6 +44,7 @@ def _lib() -> C.CDLL:
             "mipaf_set_write": (C.c_int, [vp, C.c_int]),
             "mipaf_invert": (C.c_int, [vp]),
             "mipaf_dechunk_text": (C.c_int, [cp, C.c_size_t, C.c_int32, P(vp), P(C.c_size_t)]),
+            "mipaf_unaligned_fasta": (C.c_int, [cp, C.c_size_t, cp, C.c_size_t, C.c_int64, C.c_int64, P(vp), P(C.c_size_t)]),
             "mipaf_chain_params_default": (None, [P(ChainParams)]),
             "mipaf_chain": (C.c_int, [vp, vp, P(ChainParams), P(Stats)]),
             "mipaf_tile": (C.c_int, [vp, vp, C.c_int32, P(Stats)]),
@@ -83,6 +84,18 @@ def dechunk_text(paf: bytes, query_only: bool = False) -> bytes:
         lib.miblast_free(out)
 
 
+def unaligned_fasta(paf: bytes, fasta: bytes, min_size: int, flank: int) -> bytes:
+    """`paffy to_bed --excludeAligned --binary --minSize N` + `faffy extract --flank F` on text (include/mipaf.h
+    mipaf_unaligned_fasta): what is left of the query file for the next outgroup of a chain"""
+    lib = _lib()
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(lib.mipaf_unaligned_fasta(paf, len(paf), fasta, len(fasta), min_size, flank, C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value) if n.value else b""
+    finally:
+        lib.miblast_free(out)
+
+
 class PafSet:
     """A list of PAF records (mipaf_set).  The sub-commands change it in place and return self, so a pipeline reads like the
     reference's piped call: PafSet.from_text(t).chain(ctx).tile(ctx).trim(ctx, "0.2").filter(max_tile_level=1)."""
@@ -107,14 +120,17 @@ class PafSet:
     def __len__(self) -> int:
         return int(_lib().mipaf_set_size(self._h))
 
-    def text(self) -> str:
+    def text_bytes(self) -> bytes:
         lib = _lib()
         buf, n = C.c_void_p(), C.c_size_t()
         _check(lib.mipaf_set_text(self._h, C.byref(buf), C.byref(n)))
         try:
-            return C.string_at(buf, n.value).decode()
+            return C.string_at(buf, n.value)
         finally:
             lib.miblast_free(buf)
+
+    def text(self) -> str:
+        return self.text_bytes().decode()
 
     def write(self, path: str, append: bool = False):
         with open(path, "ab" if append else "wb") as f:

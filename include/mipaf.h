@@ -46,6 +46,15 @@ int mipaf_invert(mipaf_set *s);
  * tag passes through untouched, so this works on the text and not on a mipaf_set.  *out is freed with miblast_free. */
 int mipaf_dechunk_text(const char *paf, size_t len, int32_t query_only, char **out, size_t *out_len);
 
+/* `paffy to_bed --excludeAligned --binary --minSize N -i paf --queryFastaFile fa` followed by `faffy extract -i bed fa --flank F`
+ * (make_ingroup_to_outgroup_alignments_2, local_alignment.py:469-489) on text: the stretches of the QUERY sequences of `fasta`
+ * that no alignment of `paf` covers, at least min_size long, widened by flank (widened stretches that touch are merged), as
+ * FASTA records NAME|SEQLEN|START with 60 columns per line, in file order.  Host-side text code like mipaf_dechunk_text: this
+ * is the step between two outgroup calls of a chain, and its latency is part of the blast phase.  *out is freed with
+ * miblast_free; a PAF query name that is not in `fasta` is an error.                                                        */
+int mipaf_unaligned_fasta(const char *paf, size_t paf_len, const char *fasta, size_t fasta_len, int64_t min_size, int64_t flank,
+                          char **out, size_t *out_len);
+
 typedef struct mipaf_chain_params {     /* `paffy chain` options (local_alignment.py:672-677, values xml:108-111)  */
     int64_t max_gap_length;             /* --maxGapLength  (chainMaxGapLength 1000000)                            */
     int64_t gap_open;                   /* --chainGapOpen  (chainGapOpen 5000)                                    */

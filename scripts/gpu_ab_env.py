@@ -15,7 +15,9 @@ def main():
     sys.argv = [sys.argv[0]]
     a = bench.parse_args()
     ctx = miblast.Context(0)
-    for label, work in (("evolver", bench.EvolverPhase(a, ctx, 0)), ("pair", bench.PairWorkload(a, ctx, 0))):
+    import copy
+    a16 = copy.copy(a); a16.pairs_per_gpu = 16
+    for label, work in (("evolver", bench.EvolverPhase(a, ctx, 0)), ("pair", bench.PairWorkload(a, ctx, 0)), ("16 pairs", bench.PairWorkload(a16, ctx, 0))):
         t = {va: [], vb: []}
         for i in range(6 + 2 * steps):
             v = (va, vb)[i & 1]

@@ -1,8 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out/r02ab
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r02ab/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r02ab/pytest.log
-MIBLAST_DEBUG_SPIKE=12 MIBLAST_BENCH_TIMELINE=1 timeout 300 python bench.py --steps 40 --warmup 3 --chain-leg 0 --cpu-sample 0 --pair-leg 0 --batch-leg 0 --seed-leg 0 2>&1 | grep "slow index\|slow seed\|step total" | sort -k4 -n -t' ' | tail -50 | awk '{printf "%s ", $0} END {print ""}'
-timeout 300 python bench.py --steps 12 --warmup 3 --chain-leg 0 --cpu-sample 0 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('evolver', round(d['ms_per_step'],2), '| pair', round(d['pair_1mb']['ms_per_step'],2), '| batched', round(d['batched_pairs']['ms_per_call'],1), '| seed leg', round(d['seed_stage']['seconds']*1e3,1), d['seed_stage']['kernel_ms'])"
+MIBLAST_DEBUG_SPIKE=7 MIBLAST_BENCH_TIMELINE=1 timeout 300 python bench.py --steps 40 --warmup 3 --chain-leg 0 --cpu-sample 0 --pair-leg 0 --batch-leg 0 --seed-leg 0 2>&1 | grep "slow\|step total\|align_pairs" | tail -230 > gpurun_out/spike.log
+grep -c "slow" gpurun_out/spike.log

@@ -113,6 +113,37 @@ def test_unaligned_fasta_nests_subsequence_names():
     assert bp.unaligned_fasta(b"id=A|c\t1000\t0\t1000\t+\tt\t9\t0\t1\t1\t1\t255\n", fa, 100, 50) == b""
 
 
+def test_native_trimming_equals_the_python_cores():
+    """mipaf_unaligned_fasta (host-side text code of the library) against paf.chunking.unaligned_intervals + extract_records +
+    60-column FASTA, the mirror of `paffy to_bed --excludeAligned --minSize` + `faffy extract --flank`: random multi-record files,
+    overlapping / nested / touching alignments, alignments on both strands, records without a hit, empty PAF, empty records,
+    flanks that make neighbouring stretches merge, CRLF line ends; an unknown query name is refused by both."""
+    from cactus_amd import miblast
+    rng = np.random.default_rng(11)
+    for case in range(60):
+        n_rec = int(rng.integers(1, 5))
+        recs = [("id=G|r%d" % k if k % 2 else "r%d|77|5" % k, gen.random_sequence(int(rng.integers(0, 1500)) if case % 7 else 0, rng)) for k in range(n_rec)]
+        fa = gen.fasta_bytes(recs)
+        lines = []
+        for _ in range(int(rng.integers(0, 12)) if case % 5 else 0):
+            name, seq = recs[int(rng.integers(0, n_rec))]
+            if len(seq) < 2:
+                continue
+            s0 = int(rng.integers(0, len(seq) - 1))
+            e0 = int(rng.integers(s0, len(seq) + 1))                 # (now and then an empty interval)
+            lines.append("%s\t%d\t%d\t%d\t%s\tT\t5000\t1\t%d\t1\t1\t255\tcg:Z:%d=" % (name, len(seq), s0, e0, "+-"[int(rng.integers(0, 2))], 1 + e0 - s0, e0 - s0))
+        paf = ("\n".join(lines) + ("\n" if lines else "")).encode()
+        if case % 9 == 4:
+            paf, fa = paf.replace(b"\n", b"\r\n"), fa.replace(b"\n", b"\r\n")
+        for min_size, flank in ((100, 100), (1, 0), (37, 500), (400, 3)):
+            want = bp.unaligned_fasta_py(paf, fa, min_size, flank)
+            assert bp.unaligned_fasta(paf, fa, min_size, flank) == want, (case, min_size, flank)
+    with pytest.raises(miblast.MiblastError, match="not in the FASTA"):
+        bp.unaligned_fasta(b"nobody\t10\t0\t5\t+\tT\t9\t0\t5\t5\t5\t255\n", gen.fasta_bytes([("a", gen.random_sequence(10, rng))]), 1, 0)
+    with pytest.raises(KeyError):
+        bp.unaligned_fasta_py(b"nobody\t10\t0\t5\t+\tT\t9\t0\t5\t5\t5\t255\n", gen.fasta_bytes([("a", gen.random_sequence(10, rng))]), 1, 0)
+
+
 def test_bench_refuses_a_wrong_world_size_and_spawns_ranks():
     # no GPU here: the spawned ranks must fail loudly (no CPU path), and the launcher's exit code must say so
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
