@@ -23,19 +23,7 @@
 
 namespace mb {
 
-// ------------------------------------------------------------------------------------------------
-// substitution score on code bytes: HOXD70, N (code 4) scores -100 against anything (A.2)
-__device__ __forceinline__ int sub_score(unsigned a, unsigned b) {
-    // branch-free on purpose (the compiler turns an if-chain into exec-mask branches inside the hot loops):
-    // d = x ^ y selects match / transition / the two transversion classes, `at` tells A,T from C,G
-    const unsigned x = a & 7u, y = b & 7u;
-    const unsigned d = (x ^ y) & 3u;
-    const unsigned cg = (x ^ (x >> 1)) & 1u;                   // 1 for C,G ; 0 for A,T
-    // byte k of the table = score(d = k) + 128 :  match, A-C/G-T (-114), transition (-31), A-T / C-G
-    const unsigned lut = cg ? (228u | (14u << 8) | (97u << 16) | (3u << 24)) : (219u | (14u << 8) | (97u << 16) | (5u << 24));
-    const int v = (int)((lut >> (d * 8u)) & 0xFFu) - 128;
-    return ((x | y) & 4u) ? -100 : v;
-}
+#include "mb_xdrop.h"
 
 __device__ __forceinline__ bool window_word(const uint8_t *codes, int64_t p, uint32_t &word) {
     // care offsets of 1110100110010101111
@@ -381,12 +369,6 @@ void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned l
 // ungapped x-drop extension with exact per-diagonal suppression (A.4, A.5).
 // keys are sorted by (diagonal, q_end); the thread owning the first hit of a diagonal run walks
 // the run in q order carrying extent[d], exactly the sequential rule "skip iff q_end <= extent[d]".
-__device__ __forceinline__ unsigned long long load8(const uint8_t *p) {
-    unsigned long long v;
-    __builtin_memcpy(&v, p, 8);                       // unaligned global_load_dwordx2
-    return v;
-}
-
 // Heads of the diagonal runs of the sorted hit keys, compacted into two lists: runs of at most kLongRun hits go to
 // the lane-per-run kernel, longer ones (busy diagonals of real homology: hundreds to millions of hits, almost all of
 // them suppressed) to the wave-per-run kernel.  One atomic pair per 1024-key block; list order is irrelevant.
@@ -429,85 +411,6 @@ __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__
         const uint64_t off = cls == 0 ? 0 : cls == 1 ? n : cls == 2 ? n + n / 2 : cls == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
         heads[off + base[cls] + cnt[cls][w] + (unsigned)__popcll(m[cls] & ((1ull << lane) - 1ull))] = (unsigned)i;
     }
-}
-
-// One x-drop direction, 8 columns per load, branch-free inside a chunk (every per-lane condition is a select).  The first
-// NPRE chunks of both sequences arrive PRELOADED: the extension of a chance hit ends within ~35 columns to the left (the seed
-// itself is 19 of them) and ~17 to the right, and a chunk-by-chunk loop would pay one dependent cache-line round trip per
-// chunk and sequence -- the whole cost of this stage.  The caller issues every preload of both directions before the first
-// column is scored, so a typical hit waits for memory once.
-struct XState { int run, best, bpos; bool live; };
-
-// four substitution scores at once: byte m of the result = score(a_m, b_m) + 128 for the code bytes a_m, b_m of a4 / b4.
-// HOXD70 is a function of (a ^ b) and of whether a is C/G: one v_perm_b32 over an 8-byte table; N (code bit 2) scores -100.
-// (Separator bytes have bit 2 set as well: the caller deals with them before looking at the score.)
-__device__ __forceinline__ uint32_t scores4(const uint32_t a4, const uint32_t b4) {
-    const uint32_t d = (a4 ^ b4) & 0x03030303u;                       // 0 match, 2 transition, 1 / 3 the two transversion classes
-    const uint32_t cg = ((a4 ^ (a4 >> 1)) & 0x01010101u) << 2;        // 4 where a is C or G
-    constexpr uint32_t kAT = 219u | (14u << 8) | (97u << 16) | (5u << 24);      // a in {A,T}: 91, -114, -31, -123 (+128)
-    constexpr uint32_t kCG = 228u | (14u << 8) | (97u << 16) | (3u << 24);      // a in {C,G}: 100, -114, -31, -125
-    const uint32_t s = __builtin_amdgcn_perm(kCG, kAT, d | cg);       // selector 0..3 -> kAT, 4..7 -> kCG
-    const uint32_t nm = (((a4 | b4) & 0x04040404u) >> 2) * 255u;      // 0xFF where either base is N
-    return (s & ~nm) | (0x1c1c1c1cu & nm);                            // -100 + 128
-}
-
-template <int DIR>
-__device__ __forceinline__ void xdrop_chunk(const unsigned long long a8, const unsigned long long b8, const int c, const int xdrop,
-                                            XState &x, unsigned long long &ncols) {
-    if (((a8 | b8) & 0x8080808080808080ull) != 0ull) {
-        // a contig separator (0xFF) inside the chunk -- the only codes with bit 7: the extension ends there, column by column
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const int sh = DIR > 0 ? 8 * m : 8 * (7 - m);
-            const unsigned a = (unsigned)(a8 >> sh) & 0xFFu, b = (unsigned)(b8 >> sh) & 0xFFu;
-            x.live = x.live & (a != kSep) & (b != kSep);
-            x.run = x.live ? x.run + sub_score(a, b) : x.run;
-            ncols += x.live ? 1u : 0u;
-            const bool upd = x.live & (x.run > x.best);
-            x.best = upd ? x.run : x.best;
-            x.bpos = upd ? 8 * c + m + 1 : x.bpos;
-            x.live = x.live & (upd | (x.run >= x.best - xdrop));
-        }
-        return;
-    }
-    const uint32_t s_lo = scores4((uint32_t)a8, (uint32_t)b8), s_hi = scores4((uint32_t)(a8 >> 32), (uint32_t)(b8 >> 32));
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-        const int k = DIR > 0 ? m : 7 - m;                               // byte of the chunk holding column m
-        const int sc = (int)(((k < 4 ? s_lo : s_hi) >> (8 * (k & 3))) & 0xFFu) - 128;
-        x.run = x.live ? x.run + sc : x.run;
-        ncols += x.live ? 1u : 0u;
-        const bool upd = x.live & (x.run > x.best);
-        x.best = upd ? x.run : x.best;
-        x.bpos = upd ? 8 * c + m + 1 : x.bpos;
-        x.live = x.live & (upd | (x.run >= x.best - xdrop));
-    }
-}
-
-template <int DIR, int NPRE>
-__device__ __forceinline__ void xdrop_preload(const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp,
-                                              unsigned long long (&a)[NPRE], unsigned long long (&b)[NPRE]) {
-#pragma unroll
-    for (int c = 0; c < NPRE; c++) {
-        a[c] = DIR > 0 ? load8(tp + 8 * c) : load8(tp - 8 * (c + 1));
-        b[c] = DIR > 0 ? load8(qp + 8 * c) : load8(qp - 8 * (c + 1));
-    }
-}
-
-template <int DIR, int NPRE>
-__device__ __forceinline__ void xdrop_dir(const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp, const int xdrop,
-                                          const unsigned long long (&a)[NPRE], const unsigned long long (&b)[NPRE],
-                                          int &best_out, int &pos_out, unsigned long long &ncols) {
-    XState x{0, 0, 0, true};
-#pragma unroll
-    for (int c = 0; c < NPRE; c++)
-        if (x.live) xdrop_chunk<DIR>(a[c], b[c], c, xdrop, x, ncols);
-    for (int c = NPRE; x.live; c++) {
-        const unsigned long long a8 = DIR > 0 ? load8(tp + 8 * c) : load8(tp - 8 * (c + 1));
-        const unsigned long long b8 = DIR > 0 ? load8(qp + 8 * c) : load8(qp - 8 * (c + 1));
-        xdrop_chunk<DIR>(a8, b8, c, xdrop, x, ncols);
-    }
-    best_out = x.best; pos_out = x.bpos;
 }
 
 __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__restrict__ keys, int64_t n_hits,
@@ -697,6 +600,32 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
     }
 }
 
+// ---- PROTOTYPE (timing only, MIBLAST_UX_PROTO=1): level 1 of a level-synchronous extension -- one hit per lane, the preloaded
+// 5 + 3 chunks of both directions evaluated without any early exit, one 8-byte record per hit
+__global__ __launch_bounds__(256) void k_ux_proto(const unsigned long long *__restrict__ keys, int64_t n_hits, const uint8_t *__restrict__ tc,
+                                                  const uint8_t *__restrict__ qc, int64_t qtot, int xdrop, unsigned long long *__restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hits) return;
+    const unsigned long long key = keys[i];
+    const uint32_t dq = (uint32_t)(key >> 32);
+    const int32_t q_end = (int32_t)(uint32_t)key;
+    const int64_t t_end = (int64_t)dq - qtot + q_end;
+    constexpr int kPreL = 5, kPreR = 3;
+    unsigned long long aL[kPreL], bL[kPreL], aR[kPreR], bR[kPreR];
+    xdrop_preload<-1, kPreL>(tc + t_end, qc + q_end, aL, bL);
+    xdrop_preload<+1, kPreR>(tc + t_end, qc + q_end, aR, bR);
+    XState xl{0, 0, 0, true}, xr{0, 0, 0, true};
+    unsigned long long ncols = 0;
+#pragma unroll
+    for (int c = 0; c < kPreL; c++) xdrop_chunk<-1>(aL[c], bL[c], c, xdrop, xl, ncols);
+#pragma unroll
+    for (int c = 0; c < kPreR; c++) xdrop_chunk<+1>(aR[c], bR[c], c, xdrop, xr, ncols);
+    rec[i] = ((unsigned long long)(unsigned)(xr.bpos | (xl.live ? 0x40000000 : 0) | (xr.live ? 0x20000000 : 0)) << 32) | (unsigned)(ncols + (unsigned)(xl.best + xr.best));
+}
+
+// ---- eight-lanes-per-run variant of k_ungapped (the default for the short-run classes) -------------------------------
+#include "mb_ungapped_grp.h"
+
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
                      const uint8_t *qcodes, int64_t qtot, int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, hipStream_t s) {
@@ -710,9 +639,29 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
     (void)hipMemsetAsync(n_heads, 0, (kRunClasses + 1) * sizeof(unsigned), s);
     hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
-    const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;                   // upper bound: sum over classes of ceil(runs / 256)
-    hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
-                       qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+    // short runs: a group of 8 lanes per run, 64 columns per step (k_ungapped_grp); MIBLAST_UNGAPPED=lane selects the older
+    // lane-per-run kernel (same results).  The groups are persistent: at most kGrpBlocks blocks of 32 groups walk the runs in a
+    // strided order (MIBLAST_UNGAPPED_BLOCKS changes the bound).
+    static const bool lane_per_run = [] { const char *e = getenv("MIBLAST_UNGAPPED"); return e && !strcmp(e, "lane"); }();
+    static const int64_t grp_blocks = [] { const char *e = getenv("MIBLAST_UNGAPPED_BLOCKS"); return e ? std::max(1, atoi(e)) : 4096; }();
+    static const bool ux_proto = getenv("MIBLAST_UX_PROTO") != nullptr;
+    if (ux_proto)      // (timing prototype: scribbles over the long-run head list, which this launch does not need on random data)
+        hipLaunchKernelGGL(k_ux_proto, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, s, keys, n_hits, tcodes, qcodes, qtot, xdrop,
+                           (unsigned long long *)hsps);
+    if (lane_per_run) {
+        const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;               // upper bound: sum over classes of ceil(runs / 256)
+        hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
+                           qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+    } else {
+        const int64_t blocks = std::min<int64_t>((n_hits + 31) / 32, grp_blocks); // (a run has at least one hit)
+        static const int grp_waves = [] { const char *e = getenv("MIBLAST_UNGAPPED_WAVES"); return e ? atoi(e) : 5; }();
+        if (grp_waves >= 8)
+            hipLaunchKernelGGL(k_ungapped_grp<8>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
+                               qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+        else
+            hipLaunchKernelGGL(k_ungapped_grp<5>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
+                               qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+    }
     const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
     hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
                        tcodes, qcodes, qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
@@ -1519,22 +1468,23 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
         uint32_t tbg[G];
         int totx[G], totm[G], flast[G];
         const int cplB0 = __builtin_amdgcn_readlane(C[0][K - 1], 63);    // (read before group A overwrites it)
-        auto group = [&](auto gtag, const int cpl0, const int cx, const int cm, const int f0) {
+        // (EDGE: some column of the group lies beyond the contig -- those are dead and count as breaks; the common case carries none of
+        //  that masking.  The 4-bit trace codes are collected as sign bits, v_sub + v_alignbit per flag: no compare / select pairs.)
+        auto group = [&](auto gtag, auto etag, const int cpl0, const int cx, const int cm, const int f0) {
             constexpr int g = decltype(gtag)::value;                      // (compile-time: C[g][k] must stay in registers)
+            constexpr bool edge = decltype(etag)::value;
             const int j0 = jb + g * kHalf + K * lane;
-            const bool edge = jb + (g + 1) * kHalf - 1 > na;              // some column lies beyond the contig: dead, and a break
             const int kna = na - j0;
             const uint32_t sc = __builtin_amdgcn_perm(0x1c1c1c1cu, lut, tw[g] & 0x07070707u);
             const int relg = laneKE + g * kHalf * E;
-            int diag[K], Dv[K], X[K], Mm[K];
-            bool dex[K];
+            int diag[K], Dv[K], X[K], Mm[K], ddx[K];
             int prev = dpp_shr1(C[g][K - 1], cpl0);
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 diag[k] = prev + (int)((sc >> (8 * k)) & 0xFFu) - 128;
                 const int de = D[g][k] - E, dn = C[g][k] - OE;
                 Dv[k] = max(de, dn);
-                dex[k] = de >= dn;
+                ddx[k] = de - dn;                                         // sign: the vertical gap OPENS here (dex = de >= dn is its complement)
                 const int Mv = max(diag[k], Dv[k]);
                 X[k] = Mv + relg + k * E;
                 Mm[k] = (!edge || k <= kna) ? Mv : kNeg;
@@ -1566,28 +1516,43 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
                 D[g][k] = Dv[k];
                 dm |= (unsigned)q & (1u << k);
             }
-            const int fnext = pex[K - 1] >= X[K - 1] ? 1 : 0;
-            const int fprev = dpp_shr1(fnext, f0);
-            flast[g] = uni(__builtin_amdgcn_readlane(fnext, 63));
+            // sign of dnx: the gap into the NEXT column (the next lane's first) does not extend
+            const int dnx = pex[K - 1] - X[K - 1];
+            const int dpv = dpp_shr1(dnx, f0 - 1);                         // the same for this lane's first column (f0 = 1: it extends)
+            flast[g] = uni(__builtin_amdgcn_readlane(dnx, 63)) >= 0 ? 1 : 0;
             const int hi = RY - j0;                                       // column k is right of the old window iff k >= hi
             unsigned bm = dm & (kAll << min(max(hi, 0), K));
             if (edge) bm |= kAll << min(max(kna + 1, 0), K);
             dmg[g] = dm; amg[g] = ~dm & kAll; bmg[g] = bm & kAll;
-            uint32_t tb = 0;
+            // raw nibble of column k: bit 3 = gap into k does not extend, bit 2 = vertical gap opens, bit 1 = I beats D, bit 0 = a gap
+            // beats the diagonal (tie preference diag > D > I: strict comparisons).  Two chains of two columns each.
+            unsigned r01 = 0, r23 = 0;
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const bool iex = k == 0 ? fprev != 0 : pex[k - 1] >= X[k - 1];
-                const unsigned src = diag[k] >= gm[k] ? 0u : (Dv[k] >= Iv[k] ? 1u : 2u);   // tie preference diag > D > I
-                tb |= (src | (dex[k] ? 4u : 0u) | (iex ? 8u : 0u)) << (4 * k);
+            for (int k = 1; k >= 0; k--) {
+                r01 = __builtin_amdgcn_alignbit(r01, (unsigned)(k == 0 ? dpv : pex[k - 1] - X[k - 1]), 31);
+                r01 = __builtin_amdgcn_alignbit(r01, (unsigned)ddx[k], 31);
+                r01 = __builtin_amdgcn_alignbit(r01, (unsigned)(Dv[k] - Iv[k]), 31);
+                r01 = __builtin_amdgcn_alignbit(r01, (unsigned)(diag[k] - gm[k]), 31);
             }
-            tbg[g] = tb;
+#pragma unroll
+            for (int k = 3; k >= 2; k--) {
+                r23 = __builtin_amdgcn_alignbit(r23, (unsigned)(pex[k - 1] - X[k - 1]), 31);
+                r23 = __builtin_amdgcn_alignbit(r23, (unsigned)ddx[k], 31);
+                r23 = __builtin_amdgcn_alignbit(r23, (unsigned)(Dv[k] - Iv[k]), 31);
+                r23 = __builtin_amdgcn_alignbit(r23, (unsigned)(diag[k] - gm[k]), 31);
+            }
+            const unsigned raw = (r01 | (r23 << 8)) ^ 0xCCCCu;           // bit 3 -> the gap extends (iex), bit 2 -> the vertical gap extends (dex)
+            const unsigned ga = raw & 0x1111u, gi = (raw >> 1) & 0x1111u;
+            tbg[g] = (raw & 0xCCCCu) | (ga & ~gi) | ((ga & gi) << 1);     // src: 0 diagonal, 1 D, 2 I
         };
-        group(std::integral_constant<int, 0>{}, kNeg, kNeg2, best, 0);
+        const bool edgeA = jb + kHalf - 1 > na;                            // some column of group A lies beyond the contig
+        if (edgeA) group(std::integral_constant<int, 0>{}, std::true_type{}, kNeg, kNeg2, best, 0);
+        else group(std::integral_constant<int, 0>{}, std::false_type{}, kNeg, kNeg2, best, 0);
         const unsigned long long blA = __ballot(bmg[0] != 0u);
         const bool need_b = (RY - jb > kHalf) || !blA;                    // the old window reaches into B, or no break inside A
         unsigned long long blB = 0;
         if (need_b) {
-            group(std::integral_constant<int, 1>{}, cplB0, totx[0], totm[0], flast[0]);
+            group(std::integral_constant<int, 1>{}, std::true_type{}, cplB0, totx[0], totm[0], flast[0]);   // (rare: always the masking form)
             blB = __ballot(bmg[1] != 0u);
             if (!blA && !blB) { overflow = 1; break; }                    // every column up to the last lane is still alive
         }
@@ -1655,11 +1620,10 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
     }
 }
 
-// The piece evaluator needs 129 VGPRs when the compiler is left alone: 3 waves per SIMD (k_ydrop2).  k_ydrop2_w4 is the same
-// instruction stream held to 128 VGPRs = 4 waves per SIMD (no scratch).  Measured on the 1 Mb pairs: one pair (2 653 pieces,
-// all resident either way) 1.673 ms with 3 waves vs 1.686 ms with 4; 16 pairs (~6 000 pieces per launch) 3.17 ms vs 2.99 ms.
-// So the 4-wave build is launched when the pieces outnumber the 3 x 1024 wave slots of the 3-wave build
-// (MIBLAST_DP_WAVES=3 / 4 forces one of them).
+// The piece evaluator needs about 100 VGPRs when the compiler is left alone: 4 waves per SIMD (k_ydrop2).  k_ydrop2_w5 is the same
+// instruction stream held to 96 VGPRs = 5 waves per SIMD; it is launched when the pieces outnumber the 4 x 1024 wave slots of
+// k_ydrop2 (MIBLAST_DP_WAVES=4 / 5 forces one of them).  (Before the trace codes were collected as sign bits the evaluator
+// took 129 VGPRs, 3 waves per SIMD, and the squeezed build 128.)
 __global__ __launch_bounds__(64)
 void k_ydrop2(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
               const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
@@ -1667,8 +1631,8 @@ void k_ydrop2(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
               uint8_t *__restrict__ snaps) {
     ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_ydrop2_w4(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void k_ydrop2_w5(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
                  const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                  unsigned long long *__restrict__ arena_next, const unsigned blk_bytes, unsigned long long *__restrict__ rowdir,
                  uint8_t *__restrict__ snaps) {
@@ -1682,8 +1646,8 @@ void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtr
     dim3 g((unsigned)n), b(64);
     const char *we = getenv("MIBLAST_DP_WAVES");
     const int waves = we ? atoi(we) : 0;
-    const bool four = waves == 4 || (waves != 3 && n > 3 * 1024);
-    if (K == 2 && four) hipLaunchKernelGGL(k_ydrop2_w4, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    const bool five = waves == 5 || (waves != 4 && n > 4 * 1024);
+    if (K == 2 && five) hipLaunchKernelGGL(k_ydrop2_w5, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else if (K == 2) hipLaunchKernelGGL(k_ydrop2, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else if (K == 4) hipLaunchKernelGGL((k_ydrop1<4>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
     else hipLaunchKernelGGL((k_ydrop1<8>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);

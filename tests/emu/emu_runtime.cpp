@@ -4,32 +4,6 @@
 
 #include <string>
 
-namespace emu {
-thread_local Group *g_group = nullptr;
-thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
-
-void launch(const std::function<void()> &body, dim3 grid, dim3 block) {
-    const unsigned nt = block.x;
-    for (unsigned b = 0; b < grid.x; b++) {
-        Group g;
-        pthread_barrier_init(&g.all, nullptr, nt);
-        const unsigned nw = (nt + 63) / 64;
-        g.wave.resize(nw);
-        for (unsigned w = 0; w < nw; w++) pthread_barrier_init(&g.wave[w], nullptr, std::min(64u, nt - 64 * w));
-        g.slot.assign(nt, 0);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t] {
-                g_group = &g;
-                t_threadIdx = dim3(t); t_blockIdx = dim3(b); t_blockDim = block; t_gridDim = grid;
-                body();
-            });
-        for (std::thread &x : th) x.join();
-        pthread_barrier_destroy(&g.all);
-        for (unsigned w = 0; w < nw; w++) pthread_barrier_destroy(&g.wave[w]);
-    }
-}
-}  // namespace emu
 
 namespace mb {
 void host_parallel_for(size_t n, const std::function<void(size_t)> &f) { for (size_t i = 0; i < n; i++) f(i); }

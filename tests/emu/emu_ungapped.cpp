@@ -1,0 +1,213 @@
+// TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_ungapped_grp.h (the eight-lanes-per-run ungapped extension kernel) on the
+// HOST -- one pthread per work-item, DPP / ballot exchanged through per-wave barriers (see hip/hip_runtime.h) -- against a
+// sequential restatement of the rule (oracle/lastz_oracle.c:227-262, :508-521) on random sequence sets with planted homology,
+// separators, N bases and busy diagonals.  Nothing of this is shipped or measured.
+//   emu_ungapped <seed> <n_cases>      exit status 0 iff every case is identical (HSP records, extent[], counters)
+#define MB_EMU 1
+#include <hip/hip_runtime.h>
+#undef __launch_bounds__
+#define __launch_bounds__(...)
+
+#include <algorithm>
+#include <cstdio>
+#include <random>
+
+#include "mb_common.h"
+
+// ---- the wave primitives of the kernel, emulated ----------------------------------------------------------------
+static inline unsigned emu_tid() { return emu::t_threadIdx.x; }
+
+template <int CTRL, int BANK>
+inline int wdpp(int old, int v) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu_tid(), w = tid >> 6, lane = tid & 63, rl = lane & 15;
+    g->slot[tid] = (unsigned long long)(unsigned)v;
+    pthread_barrier_wait(&g->wave[w]);
+    int src = -1;
+    if (CTRL <= 0xFF) src = (int)((lane & ~3u) | ((unsigned)(CTRL >> (2 * (lane & 3))) & 3u));             // quad_perm
+    else if (CTRL >= 0x111 && CTRL <= 0x11F) src = rl >= (unsigned)(CTRL - 0x110) ? (int)lane - (CTRL - 0x110) : -1;   // row_shr:n
+    else if (CTRL == 0x141) src = (int)((lane & ~7u) | (7u - (lane & 7u)));                               // row_half_mirror
+    else abort();
+    const bool bank = (BANK >> (rl >> 2)) & 1;
+    const int out = (src >= 0 && bank) ? (int)(unsigned)g->slot[(tid & ~63u) | (unsigned)src] : old;
+    pthread_barrier_wait(&g->wave[w]);
+    return out;
+}
+inline unsigned long long wballot(bool p) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu_tid(), w = tid >> 6;
+    g->slot[tid] = p ? 1ull : 0ull;
+    pthread_barrier_wait(&g->wave[w]);
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64; l++) m |= g->slot[(tid & ~63u) | l] << l;
+    pthread_barrier_wait(&g->wave[w]);
+    return m;
+}
+inline uint32_t wperm(uint32_t hi, uint32_t lo, uint32_t sel) {                                           // v_perm_b32, selectors 0..7
+    uint32_t out = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned s = (sel >> (8 * i)) & 0xFFu;
+        if (s > 7) abort();
+        const uint32_t byte = s < 4 ? (lo >> (8 * s)) & 0xFFu : (hi >> (8 * (s - 4))) & 0xFFu;
+        out |= byte << (8 * i);
+    }
+    return out;
+}
+inline int wsdot4(uint32_t a, uint32_t b, int c) {
+    for (int i = 0; i < 4; i++) c += (int)(int8_t)(a >> (8 * i)) * (int)(int8_t)(b >> (8 * i));
+    return c;
+}
+inline unsigned wsignin(unsigned acc, int d) { return (acc << 1) | ((unsigned)d >> 31); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+using std::max;
+using std::min;
+
+namespace mb {
+inline unsigned long long load8(const uint8_t *p) { unsigned long long v; memcpy(&v, p, 8); return v; }
+#include "mb_ungapped_grp.h"
+}  // namespace mb
+
+// ---- the rule, sequentially ----------------------------------------------------------------------------------------
+static int score_of(unsigned a, unsigned b) {
+    static const int hox[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
+    const unsigned x = a & 7u, y = b & 7u;
+    if ((x | y) & 4u) return -100;
+    return hox[x][y];
+}
+
+struct Ref { std::vector<mb::DevHsp> hsps; std::vector<int32_t> extent; unsigned long long extended = 0, cols = 0; };
+
+static void reference(const std::vector<unsigned long long> &keys, const uint8_t *tc, const uint8_t *qc, int64_t qtot, int xdrop, int K,
+                      Ref &out) {
+    for (size_t i = 0; i < keys.size();) {
+        const uint32_t dq = (uint32_t)(keys[i] >> 32);
+        int32_t ext = out.extent[dq];
+        size_t j = i;
+        for (; j < keys.size() && (uint32_t)(keys[j] >> 32) == dq; j++) {
+            const int32_t q_end = (int32_t)(uint32_t)keys[j];
+            if (q_end <= ext) continue;
+            const int64_t t_end = (int64_t)dq - qtot + q_end;
+            int run = 0, bestL = 0, bestR = 0, bl = 0, br = 0;
+            for (int k = 1;; k++) {
+                const unsigned a = tc[t_end - k], b = qc[q_end - k];
+                if (a == mb::kSep || b == mb::kSep) break;
+                run += score_of(a, b); out.cols++;
+                if (run > bestL) { bestL = run; bl = k; } else if (run < bestL - xdrop) break;
+            }
+            run = 0;
+            for (int k = 0;; k++) {
+                const unsigned a = tc[t_end + k], b = qc[q_end + k];
+                if (a == mb::kSep || b == mb::kSep) break;
+                run += score_of(a, b); out.cols++;
+                if (run > bestR) { bestR = run; br = k + 1; } else if (run < bestR - xdrop) break;
+            }
+            out.extended++;
+            ext = q_end + br;
+            if (bestL + bestR >= K) {
+                mb::DevHsp h;
+                h.t_start = (int32_t)(t_end - bl); h.q_start = q_end - bl; h.len = bl + br; h.score = bestL + bestR;
+                h.seed_t_end = (int32_t)t_end; h.seed_q_end = q_end;
+                for (int c = 0; c < 4; c++) h.cnt[c] = 0;
+                for (int c = 0; c < h.len; c++) {
+                    const unsigned a = tc[h.t_start + c] & 7u, b = qc[h.q_start + c] & 7u;
+                    if (a < 4 && a == b) h.cnt[a]++;
+                }
+                out.hsps.push_back(h);
+            }
+        }
+        out.extent[dq] = ext;
+        i = j;
+    }
+}
+
+static bool hsp_less(const mb::DevHsp &a, const mb::DevHsp &b) {
+    return a.seed_t_end != b.seed_t_end ? a.seed_t_end < b.seed_t_end : a.seed_q_end < b.seed_q_end;
+}
+
+int main(int argc, char **argv) {
+    const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
+    const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
+    int bad = 0;
+    for (int cs = 0; cs < n_cases; cs++) {
+        std::mt19937 rng(seed0 * 7919u + (unsigned)cs);
+        auto rnd = [&](int n) { return (int)(rng() % (unsigned)n); };
+        const int64_t tn = 3000 + rnd(6000), qn = 3000 + rnd(6000);
+        const int xdrop = cs % 3 == 0 ? 910 : cs % 3 == 1 ? 300 + rnd(400) : 1500 + rnd(3000);
+        const int K = cs % 2 ? 3000 : 400 + rnd(1500);
+        std::vector<uint8_t> tb((size_t)tn + 2 * mb::kDevPad + 8, mb::kSep), qb((size_t)qn + 2 * mb::kDevPad + 8, mb::kSep);
+        uint8_t *tc = tb.data() + mb::kDevPad, *qc = qb.data() + mb::kDevPad;
+        for (int64_t i = 0; i < tn; i++) tc[i] = (uint8_t)rnd(4);
+        for (int64_t i = 0; i < qn; i++) qc[i] = (uint8_t)rnd(4);
+        // planted homology: stretches of Q copied from T with mutations
+        std::vector<std::pair<int64_t, int64_t>> diag_seeds;
+        for (int s = 0, ns = 3 + rnd(5); s < ns; s++) {
+            const int len = 50 + rnd(cs % 4 == 3 ? 1500 : 400);
+            const int64_t t0 = rnd((int)(tn - len)), q0 = rnd((int)(qn - len));
+            const int div = 2 + rnd(25);
+            for (int c = 0; c < len; c++) qc[q0 + c] = rnd(100) < div ? (uint8_t)rnd(4) : tc[t0 + c];
+            for (int h = 0, nhh = 1 + rnd(20); h < nhh; h++) { const int c = 1 + rnd(len - 1); diag_seeds.push_back({t0 + c, q0 + c}); }
+        }
+        // N bases, soft-mask bits, contig separators
+        for (int s = 0; s < 12; s++) { tc[rnd((int)tn)] = 4; qc[rnd((int)qn)] = 4; }
+        for (int s = 0; s < 200; s++) { tc[rnd((int)tn)] |= 8; qc[rnd((int)qn)] |= 8; }
+        for (int s = 0, ns = rnd(4); s < ns; s++) { tc[1 + rnd((int)tn - 2)] = mb::kSep; qc[1 + rnd((int)qn - 2)] = mb::kSep; }
+        // hits: (t_end, q_end) with the base before either end inside a contig; chance hits, hits on the planted diagonals, a busy diagonal
+        std::vector<unsigned long long> keys;
+        auto add = [&](int64_t t_end, int64_t q_end) {
+            if (t_end < 1 || t_end > tn || q_end < 1 || q_end > qn) return;
+            if (tc[t_end - 1] == mb::kSep || qc[q_end - 1] == mb::kSep) return;
+            const uint64_t d = (uint64_t)(t_end - q_end + qn);
+            keys.push_back((d << 32) | (uint64_t)(uint32_t)q_end);
+        };
+        for (int h = 0, nhh = 300 + rnd(1200); h < nhh; h++) add(1 + rnd((int)tn), 1 + rnd((int)qn));
+        for (auto &ds : diag_seeds) add(ds.first, ds.second);
+        { const int64_t d0 = rnd((int)tn / 2); for (int h = 0, nhh = rnd(40); h < nhh; h++) { const int q = 1 + rnd((int)std::min(qn, tn - d0) - 1); add(d0 + q, q); } }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        const int64_t n_hits = (int64_t)keys.size();
+        const int64_t ndiag = tn + qn + 2;
+        std::vector<int32_t> extent0((size_t)ndiag, 0);
+        for (int s = 0; s < 20; s++) extent0[(size_t)rnd((int)ndiag)] = rnd((int)qn);       // extents left by an earlier q batch
+        Ref ref; ref.extent = extent0;
+        reference(keys, tc, qc, qn, xdrop, K, ref);
+        // class lists as k_run_heads lays them out (every run is "short" here)
+        const uint64_t n = (uint64_t)n_hits;
+        std::vector<unsigned> heads((size_t)(2 * n + n / 8 + 64), 0u);
+        unsigned n_heads[5] = {0, 0, 0, 0, 0};
+        for (int64_t i = 0; i < n_hits;) {
+            int64_t j = i; while (j < n_hits && (keys[j] >> 32) == (keys[i] >> 32)) j++;
+            const int64_t len = j - i;
+            const int cls = len >= 8 ? 3 : len >= 4 ? 2 : len >= 2 ? 1 : 0;
+            const uint64_t off = cls == 0 ? 0 : cls == 1 ? n : cls == 2 ? n + n / 2 : n + n / 2 + n / 4;
+            heads[off + n_heads[cls]++] = (unsigned)i;
+            i = j;
+        }
+        std::vector<int32_t> extent = extent0;
+        std::vector<mb::DevHsp> hsps((size_t)n_hits + 8);
+        mb::UngappedCounters ctr = {0, 0, 0};
+        const unsigned blocks = 1 + (unsigned)rnd(3);                    // few groups: every group walks many runs
+        hipLaunchKernelGGL(mb::k_ungapped_grp<5>, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, tc, qc, (int64_t)qn,
+                           extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), &ctr);
+        hsps.resize((size_t)ctr.hsps);
+        std::sort(hsps.begin(), hsps.end(), hsp_less);
+        std::sort(ref.hsps.begin(), ref.hsps.end(), hsp_less);
+        bool ok = ctr.extended == ref.extended && ctr.cols == ref.cols && hsps.size() == ref.hsps.size() && extent == ref.extent;
+        for (size_t i = 0; ok && i < hsps.size(); i++) ok = memcmp(&hsps[i], &ref.hsps[i], sizeof(mb::DevHsp)) == 0;
+        printf("case %d: hits %lld runs %u xdrop %d K %d  hsps %zu/%zu extended %llu/%llu cols %llu/%llu  %s\n", cs, (long long)n_hits,
+               n_heads[0] + n_heads[1] + n_heads[2] + n_heads[3], xdrop, K, hsps.size(), ref.hsps.size(), ctr.extended, ref.extended, ctr.cols,
+               ref.cols, ok ? "ok" : "MISMATCH");
+        if (!ok) {
+            bad++;
+            for (size_t i = 0; i < std::min(hsps.size(), ref.hsps.size()); i++)
+                if (memcmp(&hsps[i], &ref.hsps[i], sizeof(mb::DevHsp)) != 0) {
+                    printf("  first differing hsp %zu: got t %d q %d len %d score %d seed %d/%d | want t %d q %d len %d score %d seed %d/%d\n", i, hsps[i].t_start,
+                           hsps[i].q_start, hsps[i].len, hsps[i].score, hsps[i].seed_t_end, hsps[i].seed_q_end, ref.hsps[i].t_start, ref.hsps[i].q_start,
+                           ref.hsps[i].len, ref.hsps[i].score, ref.hsps[i].seed_t_end, ref.hsps[i].seed_q_end);
+                    break;
+                }
+            for (size_t d = 0; d < extent.size(); d++)
+                if (extent[d] != ref.extent[d]) { printf("  first differing extent: diagonal %zu got %d want %d\n", d, extent[d], ref.extent[d]); break; }
+        }
+    }
+    return bad ? 1 : 0;
+}
