@@ -103,6 +103,30 @@ struct UngappedCounters {
     unsigned long long extended, cols, hsps;
 };
 
+// level-synchronous ungapped extension (mb_ungapped_ux.h)
+struct UxEntry {                              // a hit whose walks are not finished after level 2
+    uint32_t i;                               // index in the sorted key array
+    int32_t cl, cr;                           // next chunk (8 columns) of the left / right walk; -1: that walk is finished
+    int32_t run_l, best_l, bpos_l, run_r, best_r, bpos_r;
+    uint32_t cols;                            // columns counted so far
+};
+struct UxScratch {                            // device scratch of one launch_ungapped call (the pipeline owns the memory)
+    unsigned long long *rec;                  // n_hits records: low word = length to the right, high word = columns, or bit 31 + candidate slot
+    UxEntry *blk_entries;                     // unfinished hits: 16 slots per block of k_ux_extend (12 of its wave 0, 4 of its wave 1),
+    unsigned *blk_cnt;                        // ... slots in use, per (block, wave 0 / 1),
+    unsigned n_blk;                           // ... blocks;
+    UxEntry *entries;                         // and a shared list for what does not fit there
+    unsigned entry_cap;
+    unsigned *n_entries;                      // [0] list entries written (may exceed entry_cap: the overflowing lanes finish their hit themselves)
+    uint32_t *long_bits;                      // one bit per diagonal: the diagonal's run belongs to k_ungapped_long
+    uint32_t *dirty_bits;                     // one bit per diagonal: some walk of the run reaches the run's next hit (sequential rule needed)
+    unsigned *dirty_runs;                     // first hits of the dirty short runs (the entry list's memory, free after k_ux_tail); n_entries[1] counts them
+    unsigned dirty_cap;
+    const int32_t *extent;                    // extent[] of the launch, read by the first hit of a run when
+    int extent_live;                          // ... an earlier q batch may have left extents (0: extent[] is all zero)
+    int dbg;                                  // MIBLAST_UX_DBG: timing experiments (results are wrong when set)
+};
+
 // ---- host-side sequence set --------------------------------------------------------------------
 struct SeqSet {
     std::vector<std::string> names;
@@ -156,7 +180,7 @@ void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *off
                         unsigned long long *keys, unsigned long long cap, unsigned long long *total, hipStream_t s);
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
                      const uint8_t *qcodes, int64_t qtot, int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
-                     UngappedCounters *ctr, hipStream_t s);
+                     UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s);      // ux: scratch of the level-synchronous pipeline, or nullptr; extent_clean: extent[] is all zero
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
                   int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s);

@@ -600,35 +600,15 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
     }
 }
 
-// ---- PROTOTYPE (timing only, MIBLAST_UX_PROTO=1): level 1 of a level-synchronous extension -- one hit per lane, the preloaded
-// 5 + 3 chunks of both directions evaluated without any early exit, one 8-byte record per hit
-__global__ __launch_bounds__(256) void k_ux_proto(const unsigned long long *__restrict__ keys, int64_t n_hits, const uint8_t *__restrict__ tc,
-                                                  const uint8_t *__restrict__ qc, int64_t qtot, int xdrop, unsigned long long *__restrict__ rec) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_hits) return;
-    const unsigned long long key = keys[i];
-    const uint32_t dq = (uint32_t)(key >> 32);
-    const int32_t q_end = (int32_t)(uint32_t)key;
-    const int64_t t_end = (int64_t)dq - qtot + q_end;
-    constexpr int kPreL = 5, kPreR = 3;
-    unsigned long long aL[kPreL], bL[kPreL], aR[kPreR], bR[kPreR];
-    xdrop_preload<-1, kPreL>(tc + t_end, qc + q_end, aL, bL);
-    xdrop_preload<+1, kPreR>(tc + t_end, qc + q_end, aR, bR);
-    XState xl{0, 0, 0, true}, xr{0, 0, 0, true};
-    unsigned long long ncols = 0;
-#pragma unroll
-    for (int c = 0; c < kPreL; c++) xdrop_chunk<-1>(aL[c], bL[c], c, xdrop, xl, ncols);
-#pragma unroll
-    for (int c = 0; c < kPreR; c++) xdrop_chunk<+1>(aR[c], bR[c], c, xdrop, xr, ncols);
-    rec[i] = ((unsigned long long)(unsigned)(xr.bpos | (xl.live ? 0x40000000 : 0) | (xr.live ? 0x20000000 : 0)) << 32) | (unsigned)(ncols + (unsigned)(xl.best + xr.best));
-}
-
 // ---- eight-lanes-per-run variant of k_ungapped (the default for the short-run classes) -------------------------------
 #include "mb_ungapped_grp.h"
 
+// ---- level-synchronous pipeline for dense hit sets ------------------------------------------------------------------
+#include "mb_ungapped_ux.h"
+
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
                      const uint8_t *qcodes, int64_t qtot, int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
-                     UngappedCounters *ctr, hipStream_t s) {
+                     UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s) {
     if (n_hits <= 0) return;
     // runs longer than this go to the wave-per-run kernel: a few times the chance hits a diagonal holds on average
     int kLongRun = (int)std::min<int64_t>(kLongRunMax, 6 + 4 * n_hits / std::max<int64_t>(1, n_diagonals));
@@ -639,30 +619,46 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
     (void)hipMemsetAsync(n_heads, 0, (kRunClasses + 1) * sizeof(unsigned), s);
     hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
-    // short runs: a group of 8 lanes per run, 64 columns per step (k_ungapped_grp); MIBLAST_UNGAPPED=lane selects the older
-    // lane-per-run kernel (same results).  The groups are persistent: at most kGrpBlocks blocks of 32 groups walk the runs in a
-    // strided order (MIBLAST_UNGAPPED_BLOCKS changes the bound).
-    static const bool lane_per_run = [] { const char *e = getenv("MIBLAST_UNGAPPED"); return e && !strcmp(e, "lane"); }();
-    static const int64_t grp_blocks = [] { const char *e = getenv("MIBLAST_UNGAPPED_BLOCKS"); return e ? std::max(1, atoi(e)) : 4096; }();
-    static const bool ux_proto = getenv("MIBLAST_UX_PROTO") != nullptr;
-    if (ux_proto)      // (timing prototype: scribbles over the long-run head list, which this launch does not need on random data)
-        hipLaunchKernelGGL(k_ux_proto, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, s, keys, n_hits, tcodes, qcodes, qtot, xdrop,
-                           (unsigned long long *)hsps);
-    if (lane_per_run) {
+    const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
+    // Short runs.  Three kernels give the same results:
+    //   lane  k_ungapped: a run per lane (the default for sparse hit sets: the phase's 0.6 Mb pairs, where a launch is as long as
+    //         its longest chain of real extensions);
+    //   ux    the level-synchronous pipeline of mb_ungapped_ux.h (the default for dense hit sets: a hit per four diagonals or more and at
+    //         least 2^20 hits, where the work is chance hits);
+    //   grp   k_ungapped_grp: eight lanes per run (MIBLAST_UNGAPPED=grp only).
+    // MIBLAST_UNGAPPED=lane|ux|grp forces one.
+    const char *fe = getenv("MIBLAST_UNGAPPED");                                  // (read per launch: the tests switch it)
+    const int forced = !fe ? 0 : !strcmp(fe, "lane") ? 1 : !strcmp(fe, "ux") ? 2 : !strcmp(fe, "grp") ? 3 : 0;
+    int mode = forced ? forced : (ux && n_hits >= n_diagonals / 4 && n_hits >= (1 << 20)) ? 2 : 1;
+    if (mode == 2 && (!ux || xdrop >= (1 << 24))) mode = 1;
+    if (mode == 1) {
         const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;               // upper bound: sum over classes of ceil(runs / 256)
         hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
                            qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
-    } else {
+    } else if (mode == 3) {
+        // the groups are persistent: at most MIBLAST_UNGAPPED_BLOCKS blocks of 32 groups walk the runs in a strided order
+        static const int64_t grp_blocks = [] { const char *e = getenv("MIBLAST_UNGAPPED_BLOCKS"); return e ? std::max(1, atoi(e)) : 4096; }();
         const int64_t blocks = std::min<int64_t>((n_hits + 31) / 32, grp_blocks); // (a run has at least one hit)
-        static const int grp_waves = [] { const char *e = getenv("MIBLAST_UNGAPPED_WAVES"); return e ? atoi(e) : 5; }();
-        if (grp_waves >= 8)
-            hipLaunchKernelGGL(k_ungapped_grp<8>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
-                               qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
-        else
-            hipLaunchKernelGGL(k_ungapped_grp<5>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
-                               qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+        hipLaunchKernelGGL(k_ungapped_grp<5>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
+                           qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+    } else {
+        (void)hipMemsetAsync(ux->long_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s);
+        (void)hipMemsetAsync(ux->dirty_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s);
+        (void)hipMemsetAsync(ux->n_entries, 0, 2 * sizeof(unsigned), s);
+        (void)hipMemsetAsync(ux->blk_cnt, 0, 2 * (size_t)ux->n_blk * sizeof(unsigned), s);
+        UxScratch sc = *ux;
+        sc.extent = extent; sc.extent_live = extent_clean ? 0 : 1;
+        { static const int dbg = [] { const char *e = getenv("MIBLAST_UX_DBG"); return e ? atoi(e) : 0; }(); sc.dbg = dbg; }
+        ux = &sc;
+        hipLaunchKernelGGL(k_ux_mark_long, dim3((unsigned)((max_long + 255) / 256)), dim3(256), 0, s, keys, heads_long, n_heads + kRunClasses, ux->long_bits);
+        hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, tcodes, qcodes, qtot,
+                           xdrop, K, *ux, hsps, hsp_cap, ctr);
+        const unsigned tail_blocks = (unsigned)std::min<int64_t>(2048, ((int64_t)ux->entry_cap + 2 * (int64_t)ux->n_blk + 31) / 32);
+        hipLaunchKernelGGL(k_ux_tail, dim3(tail_blocks), dim3(256), 0, s, keys, n_hits, tcodes, qcodes, qtot, xdrop, K, *ux, hsps, hsp_cap, ctr);
+        hipLaunchKernelGGL(k_ux_accept, dim3((unsigned)std::min<int64_t>(4096, (n_hits + 255) / 256)), dim3(256), 0, s, keys, n_hits, extent, *ux, hsps, ctr);
+        hipLaunchKernelGGL(k_ux_resolve, dim3(256), dim3(256), 0, s, keys, n_hits, extent, *ux, hsps, ctr);
+        hipLaunchKernelGGL(k_ux_census, dim3(256), dim3(256), 0, s, tcodes, qcodes, hsps, hsp_cap, ctr);
     }
-    const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
     hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
                        tcodes, qcodes, qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
 }

@@ -518,6 +518,9 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<DevHsp> hsps;
     DevBuf<UngappedCounters> ctr;
     DevBuf<unsigned> heads, n_heads;
+    DevBuf<UxEntry> ux_entries;               // level-synchronous ungapped extension (mb_ungapped_ux.h): unfinished hits,
+    DevBuf<unsigned> ux_cnt;                  // their counter,
+    DevBuf<uint32_t> ux_bits;                 // two bit planes, one bit per diagonal each (runs of k_ungapped_long; runs that need the sequential rule)
     // both strands of a pair in one go (seed_phase, fused path): events per strand, pinned read-back areas
     hipEvent_t sev[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
     unsigned long long last_strand_hits = 0;  // hits of the larger strand of the last pair seeded with this workspace
@@ -673,6 +676,23 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     double t_begin = 0;
 };
 
+// scratch of the level-synchronous ungapped pipeline for nh hits; rec = nh free 8-byte slots (the strand's unsorted keys)
+static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, int64_t n_diagonals) {
+    UxScratch sc;
+    // unfinished hits: 16 slots per block of 256 hits + a shared list of nh / 16 + 4096 (40-byte entries: 5 bytes per hit); the same
+    // memory later holds the list of dirty runs (4-byte entries: room for 1.25 per hit)
+    const size_t n_blk = (nh + 255) / 256, blk_slots = n_blk * 16, cap = nh / 16 + 4096;
+    w.ux_entries.ensure(blk_slots + cap); w.ux_cnt.ensure(4 + 2 * n_blk);
+    const size_t plane = (size_t)((n_diagonals + 31) / 32) + 1; w.ux_bits.ensure(2 * plane);
+    sc.rec = rec;
+    sc.blk_entries = w.ux_entries.p; sc.blk_cnt = w.ux_cnt.p + 4; sc.n_blk = (unsigned)n_blk;
+    sc.entries = w.ux_entries.p + blk_slots; sc.entry_cap = (unsigned)std::min<size_t>(cap, 0x7fffffffu); sc.n_entries = w.ux_cnt.p;
+    sc.long_bits = w.ux_bits.p; sc.dirty_bits = w.ux_bits.p + plane;
+    sc.dirty_runs = (unsigned *)w.ux_entries.p; sc.dirty_cap = (unsigned)std::min<size_t>((blk_slots + cap) * (sizeof(UxEntry) / sizeof(unsigned)), 0x7fffffffu);
+    sc.extent = nullptr; sc.extent_live = 1; sc.dbg = 0;
+    return sc;
+}
+
 // host half of the seed stage of one strand: lookup counter, discovery order, entropy filter, --queryhsplimit/--queryhspbest.
 // Touches only the strand's own fields of the job, so it can run beside the device half of the other strand or pair.
 static void seed_host(const miblast_params &p, PairJob &job, int strand) {
@@ -697,6 +717,8 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
             }
             out.lookups = valid * (p.transitions ? 1 + kSeedWeight : 1);
         }
+        // (the level-synchronous kernels leave the candidates of hits that the suppression rule dropped in the list, marked)
+        found.erase(std::remove_if(found.begin(), found.end(), [](const DevHsp &d) { return d.score == INT32_MIN; }), found.end());
         out.pre = (int64_t)found.size();
         // order HSPs the way the sequential search discovers them: q ascending, word variant, target descending
         struct Key { int32_t q_end, rank, neg_t; size_t idx; };
@@ -878,8 +900,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], sort_bits, s);
                     MB_HIP(hipEventRecord(w.sev[strand][3], s));
                     MB_HIP(hipEventRecord(w.sev[strand][4], s));
+                    const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2);   // (the unsorted keys are free now)
                     launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, ttot + qtot, extent.p, p.xdrop, p.hspthresh,
-                                    d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, s);
+                                    d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, &uxs, true, s);
                     MB_HIP(hipEventRecord(w.sev[strand][5], s));
                     MB_HIP(hipMemcpyAsync(w.pin_ctr.p + strand, d_ctr.p + strand, sizeof(UngappedCounters), hipMemcpyDeviceToHost, s));
                     blind[strand] = std::min<size_t>(kBlind, (size_t)nh[strand]);
@@ -940,8 +963,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
+            const UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2);               // (the unsorted keys are free now)
             launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, ttot + qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
-                            (int64_t)d_hsps.n, d_ctr.p, s);
+                            (int64_t)d_hsps.n, d_ctr.p, &uxs, found.empty() && strand_hits[strand] == nh, s);     // (extent[] is all zero in the first batch only)
             MB_HIP(hipEventRecord(ctx.ev4, s));
             UngappedCounters hc;
             w.stage.d2h(&hc, d_ctr.p, sizeof hc, s);

@@ -75,6 +75,104 @@ __device__ __forceinline__ int first_sep4(const uint32_t w) {
     return m ? (__ffs((int)m) - 1) >> 3 : 4;
 }
 
+// One step of 64 columns of one direction for every group of the wave (all 64 lanes execute it; `act` says whether the lane's
+// group takes part).  tp / qp: the seed end in T and Q; base: columns of this direction already walked; bestrel: best so far minus
+// the run value at the step's origin.  Lane l8 takes columns 8 l8 .. 8 l8 + 7 of the step.
+struct StepOut {
+    bool stopped, improved;                   // the direction ends inside this step / a new best was found
+    int lim;                                  // columns looked at (counted)
+    int gmax, col;                            // improved: new best (relative to the step's origin) and its first column in the step
+    int gtot;                                 // !stopped: sum of the 64 scores
+};
+__device__ __forceinline__ StepOut grp_step(const bool act, const bool left, const uint8_t *__restrict__ tp, const uint8_t *__restrict__ qp,
+                                            const int base, const int bestrel, const int xdrop, const int l8) {
+    const bool ge1 = l8 >= 1;
+    const int m_ge1 = l8 >= 1 ? -1 : 0, m_ge2 = l8 >= 2 ? -1 : 0;
+    StepOut o_;
+    unsigned long long a8 = ~0ull, b8 = ~0ull;                    // (an idle group sees a separator in column 0)
+    if (act) {
+        const int64_t o = left ? -(int64_t)(base + 8 * (l8 + 1)) : (int64_t)(base + 8 * l8);
+        a8 = load8(tp + o);
+        b8 = load8(qp + o);
+    }
+    // column m of the lane = byte m: to the left the bytes come reversed
+    const uint32_t sel_lo = left ? 0x04050607u : 0x03020100u, sel_hi = left ? 0x00010203u : 0x07060504u;
+    const uint32_t a_lo = wperm((uint32_t)(a8 >> 32), (uint32_t)a8, sel_lo), a_hi = wperm((uint32_t)(a8 >> 32), (uint32_t)a8, sel_hi);
+    const uint32_t b_lo = wperm((uint32_t)(b8 >> 32), (uint32_t)b8, sel_lo), b_hi = wperm((uint32_t)(b8 >> 32), (uint32_t)b8, sel_hi);
+    uint32_t s_lo = scores4s(a_lo, b_lo), s_hi = scores4s(a_hi, b_hi);
+    int fsep = 8;                                                 // first separator column of the lane, 8 if none
+    const uint32_t ab_lo = a_lo | b_lo, ab_hi = a_hi | b_hi;
+    if (wballot(((ab_lo | ab_hi) & 0x84848484u) != 0u)) {         // an N or a separator somewhere in the wave's 8 x 64 columns: rare
+        s_lo = scores4_fix_n(s_lo, ab_lo); s_hi = scores4_fix_n(s_hi, ab_hi);
+        const int fs_lo = first_sep4(ab_lo), fs_hi = first_sep4(ab_hi);
+        fsep = fs_lo < 4 ? fs_lo : 4 + fs_hi;
+    }
+    // prefix sums of the lane's scores (relative to the lane's first column), and the same + xdrop
+    int p[8], q[8];
+    p[0] = wsdot4(s_lo, 0x00000001u, 0); p[1] = wsdot4(s_lo, 0x00000101u, 0);
+    p[2] = wsdot4(s_lo, 0x00010101u, 0); p[3] = wsdot4(s_lo, 0x01010101u, 0);
+    p[4] = wsdot4(s_hi, 0x00000001u, p[3]); p[5] = wsdot4(s_hi, 0x00000101u, p[3]);
+    p[6] = wsdot4(s_hi, 0x00010101u, p[3]); p[7] = wsdot4(s_hi, 0x01010101u, p[3]);
+#pragma unroll
+    for (int m = 0; m < 8; m++) q[m] = p[m] + xdrop;
+    int lm[8];                                                    // running maximum inside the lane
+    lm[0] = p[0];
+#pragma unroll
+    for (int m = 1; m < 8; m++) lm[m] = max(lm[m - 1], p[m]);
+    // exclusive sum of the lane totals over the group: the run value (relative to the step's origin) before the lane's first column
+    const int tot = p[7];
+    int inc = tot;
+    inc += wdpp<kShr1, 0xf>(0, inc) & m_ge1;
+    inc += wdpp<kShr2, 0xf>(0, inc) & m_ge2;
+    inc += wdpp<kShr4, 0xa>(0, inc);                              // (banks 1 and 3 = lanes 4..7 of either group)
+    const int L = inc - tot;
+    // exclusive maximum over the lanes before this one of (run value at the lane's best column)
+    constexpr int kIdMax = -2147483647 - 1;                        // (identity as `old`: the DPP moves fold into the v_max)
+    int mx = L + lm[7];
+    mx = max(mx, wdpp<kQ0022, 0xf>(kIdMax, mx));
+    mx = max(mx, wdpp<kQ0111, 0xf>(kIdMax, mx));
+    { const int t = wdpp<kQ3333, 0xf>(kIdMax, mx); mx = max(mx, wdpp<kShr4, 0xa>(kIdMax, t)); }
+    int ex = wdpp<kShr1, 0xf>(kIdMax, mx);
+    ex = ge1 ? ex : kIdMax;
+        const int gl = max(bestrel, ex) - L;                          // best before the lane's first column, relative to the lane
+    // x-drop test of the lane's columns: stop at m iff p[m] + xdrop < (best before m)
+    unsigned sm = 0;
+#pragma unroll
+    for (int m = 7; m >= 0; m--) {
+        const int thr = m == 0 ? gl : max(gl, lm[m - 1]);
+        const int d = q[m] - thr;
+        sm = wsignin(sm, d);
+    }
+    const int fx = sm ? __ffs((int)sm) - 1 : 8;
+    // candidate = 2 * column for a separator (the column is not looked at), 2 * column + 1 for an x-drop stop (it is)
+    const int c_sep = fsep < 8 ? 16 * l8 + 2 * fsep : kNone, c_x = fx < 8 ? 16 * l8 + 2 * fx + 1 : kNone;
+    const int gc = grp_min(min(c_sep, c_x));
+    const bool stopped = gc != kNone;
+    const int lim = stopped ? (gc + 1) >> 1 : 64;                 // columns looked at in this step
+    const int cb = stopped ? gc >> 1 : 64;                        // columns that may hold a new best (the stop column never does)
+    // the lane's best among its eligible columns: lm[e], e = cb - 8 l8 - 1 clamped
+    const int e = cb - 8 * l8 - 1;
+    const int e7 = min(e, 7);
+    const int b0 = -(e7 & 1), b1 = -((e7 >> 1) & 1), b2 = -((e7 >> 2) & 1);
+    auto sel = [](int mask, int one, int zero) { return (one & mask) | (zero & ~mask); };
+    const int lmE = sel(b2, sel(b1, sel(b0, lm[7], lm[6]), sel(b0, lm[5], lm[4])), sel(b1, sel(b0, lm[3], lm[2]), sel(b0, lm[1], lm[0])));
+    const int mE = e < 0 ? kNegG : L + lmE;
+    const int gmax = grp_max(mE);
+    o_.improved = act && gmax > bestrel;
+    // first column that attains it: lm is non-decreasing, so inside the lane it is the number of columns with lm < target
+    const int tgt = gmax - L;
+    const int m1 = (lm[3] - tgt) >> 31;
+    const int x1 = sel(m1, lm[5], lm[1]);
+    const int m2 = (x1 - tgt) >> 31;
+    const int y1 = sel(m1, sel(m2, lm[6], lm[4]), sel(m2, lm[2], lm[0]));
+    const int m3 = (y1 - tgt) >> 31;
+    const int idx = (m1 & 4) | (m2 & 2) | (m3 & 1);
+    o_.col = grp_min(mE == gmax ? 8 * l8 + idx : kNone);
+    o_.gtot = grp_sum(tot);
+    o_.stopped = stopped; o_.lim = lim; o_.gmax = gmax;
+    return o_;
+}
+
 }  // namespace ugrp
 
 template <int kMinWaves>
@@ -86,8 +184,6 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
     using namespace ugrp;
     const int lane = threadIdx.x & 63;
     const int l8 = lane & 7;
-    const bool ge1 = l8 >= 1;
-    const int m_ge1 = l8 >= 1 ? -1 : 0, m_ge2 = l8 >= 2 ? -1 : 0;
     // the short-run lists of k_run_heads, longest class first: run r of the concatenation
     const unsigned n3 = n_heads_p[3], n2 = n_heads_p[2], n1 = n_heads_p[1], n0 = n_heads_p[0];
     const unsigned r32 = n3 + n2, r321 = r32 + n1, total = r321 + n0;
@@ -154,89 +250,10 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
             if (!wballot(phase == 0)) break;                           // every group of the wave is out of runs
             continue;
         }
-        // ---- one step of 64 columns for every active group; lane l8 takes columns 8 l8 .. 8 l8 + 7 of the step
-        const bool left = phase == 1;
-        unsigned long long a8 = ~0ull, b8 = ~0ull;                    // (an idle group sees a separator in column 0)
-        if (act) {
-            const int64_t o = left ? -(int64_t)(base + 8 * (l8 + 1)) : (int64_t)(base + 8 * l8);
-            a8 = load8(tc + t_end + o);
-            b8 = load8(qc + q_end + o);
-        }
-        // column m of the lane = byte m: to the left the bytes come reversed
-        const uint32_t sel_lo = left ? 0x04050607u : 0x03020100u, sel_hi = left ? 0x00010203u : 0x07060504u;
-        const uint32_t a_lo = wperm((uint32_t)(a8 >> 32), (uint32_t)a8, sel_lo), a_hi = wperm((uint32_t)(a8 >> 32), (uint32_t)a8, sel_hi);
-        const uint32_t b_lo = wperm((uint32_t)(b8 >> 32), (uint32_t)b8, sel_lo), b_hi = wperm((uint32_t)(b8 >> 32), (uint32_t)b8, sel_hi);
-        uint32_t s_lo = scores4s(a_lo, b_lo), s_hi = scores4s(a_hi, b_hi);
-        int fsep = 8;                                                 // first separator column of the lane, 8 if none
-        const uint32_t ab_lo = a_lo | b_lo, ab_hi = a_hi | b_hi;
-        if (wballot(((ab_lo | ab_hi) & 0x84848484u) != 0u)) {         // an N or a separator somewhere in the wave's 8 x 64 columns: rare
-            s_lo = scores4_fix_n(s_lo, ab_lo); s_hi = scores4_fix_n(s_hi, ab_hi);
-            const int fs_lo = first_sep4(ab_lo), fs_hi = first_sep4(ab_hi);
-            fsep = fs_lo < 4 ? fs_lo : 4 + fs_hi;
-        }
-        // prefix sums of the lane's scores (relative to the lane's first column), and the same + xdrop
-        int p[8], q[8];
-        p[0] = wsdot4(s_lo, 0x00000001u, 0); p[1] = wsdot4(s_lo, 0x00000101u, 0);
-        p[2] = wsdot4(s_lo, 0x00010101u, 0); p[3] = wsdot4(s_lo, 0x01010101u, 0);
-        p[4] = wsdot4(s_hi, 0x00000001u, p[3]); p[5] = wsdot4(s_hi, 0x00000101u, p[3]);
-        p[6] = wsdot4(s_hi, 0x00010101u, p[3]); p[7] = wsdot4(s_hi, 0x01010101u, p[3]);
-#pragma unroll
-        for (int m = 0; m < 8; m++) q[m] = p[m] + xdrop;
-        int lm[8];                                                    // running maximum inside the lane
-        lm[0] = p[0];
-#pragma unroll
-        for (int m = 1; m < 8; m++) lm[m] = max(lm[m - 1], p[m]);
-        // exclusive sum of the lane totals over the group: the run value (relative to the step's origin) before the lane's first column
-        const int tot = p[7];
-        int inc = tot;
-        inc += wdpp<kShr1, 0xf>(0, inc) & m_ge1;
-        inc += wdpp<kShr2, 0xf>(0, inc) & m_ge2;
-        inc += wdpp<kShr4, 0xa>(0, inc);                              // (banks 1 and 3 = lanes 4..7 of either group)
-        const int L = inc - tot;
-        // exclusive maximum over the lanes before this one of (run value at the lane's best column)
-        constexpr int kIdMax = -2147483647 - 1;                        // (identity as `old`: the DPP moves fold into the v_max)
-        int mx = L + lm[7];
-        mx = max(mx, wdpp<kQ0022, 0xf>(kIdMax, mx));
-        mx = max(mx, wdpp<kQ0111, 0xf>(kIdMax, mx));
-        { const int t = wdpp<kQ3333, 0xf>(kIdMax, mx); mx = max(mx, wdpp<kShr4, 0xa>(kIdMax, t)); }
-        int ex = wdpp<kShr1, 0xf>(kIdMax, mx);
-        ex = ge1 ? ex : kIdMax;
-        const int bestrel = best - runb;                               // best so far, relative to the step's origin
-        const int gl = max(bestrel, ex) - L;                          // best before the lane's first column, relative to the lane
-        // x-drop test of the lane's columns: stop at m iff p[m] + xdrop < (best before m)
-        unsigned sm = 0;
-#pragma unroll
-        for (int m = 7; m >= 0; m--) {
-            const int thr = m == 0 ? gl : max(gl, lm[m - 1]);
-            const int d = q[m] - thr;
-            sm = wsignin(sm, d);
-        }
-        const int fx = sm ? __ffs((int)sm) - 1 : 8;
-        // candidate = 2 * column for a separator (the column is not looked at), 2 * column + 1 for an x-drop stop (it is)
-        const int c_sep = fsep < 8 ? 16 * l8 + 2 * fsep : kNone, c_x = fx < 8 ? 16 * l8 + 2 * fx + 1 : kNone;
-        const int gc = grp_min(min(c_sep, c_x));
-        const bool stopped = gc != kNone;
-        const int lim = stopped ? (gc + 1) >> 1 : 64;                 // columns looked at in this step
-        const int cb = stopped ? gc >> 1 : 64;                        // columns that may hold a new best (the stop column never does)
-        // the lane's best among its eligible columns: lm[e], e = cb - 8 l8 - 1 clamped
-        const int e = cb - 8 * l8 - 1;
-        const int e7 = min(e, 7);
-        const int b0 = -(e7 & 1), b1 = -((e7 >> 1) & 1), b2 = -((e7 >> 2) & 1);
-        auto sel = [](int mask, int one, int zero) { return (one & mask) | (zero & ~mask); };
-        const int lmE = sel(b2, sel(b1, sel(b0, lm[7], lm[6]), sel(b0, lm[5], lm[4])), sel(b1, sel(b0, lm[3], lm[2]), sel(b0, lm[1], lm[0])));
-        const int mE = e < 0 ? kNegG : L + lmE;
-        const int gmax = grp_max(mE);
-        const bool improved = act && gmax > bestrel;
-        // first column that attains it: lm is non-decreasing, so inside the lane it is the number of columns with lm < target
-        const int tgt = gmax - L;
-        const int m1 = (lm[3] - tgt) >> 31;
-        const int x1 = sel(m1, lm[5], lm[1]);
-        const int m2 = (x1 - tgt) >> 31;
-        const int y1 = sel(m1, sel(m2, lm[6], lm[4]), sel(m2, lm[2], lm[0]));
-        const int m3 = (y1 - tgt) >> 31;
-        const int idx = (m1 & 4) | (m2 & 2) | (m3 & 1);
-        const int col = grp_min(mE == gmax ? 8 * l8 + idx : kNone);
-        const int gtot = grp_sum(tot);
+        // ---- one step of 64 columns for every active group
+        const StepOut so = grp_step(act, phase == 1, tc + t_end, qc + q_end, base, best - runb, xdrop, l8);
+        const bool stopped = so.stopped, improved = so.improved, left = phase == 1;
+        const int lim = so.lim, gmax = so.gmax, col = so.col, gtot = so.gtot;
         // ---- group state after the step
         if (act) n_cols += (unsigned long long)lim;
         if (improved) { best = runb + gmax; bpos = base + col + 1; }

@@ -10,6 +10,7 @@ __device__ __forceinline__ int wdpp(int old, int v) { return __builtin_amdgcn_up
 __device__ __forceinline__ unsigned long long wballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ uint32_t wperm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ int wsdot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+__device__ __forceinline__ int wreadlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }                      // l: wave-uniform
 __device__ __forceinline__ unsigned wsignin(unsigned acc, int d) { return __builtin_amdgcn_alignbit(acc, (unsigned)d, 31); }    // (acc << 1) | sign(d)
 #endif
 
@@ -55,9 +56,9 @@ __device__ __forceinline__ uint32_t scores4(const uint32_t a4, const uint32_t b4
     return (s & ~nm) | (0x1c1c1c1cu & nm);                            // -100 + 128
 }
 
-template <int DIR>
+template <int DIR, typename CNT>
 __device__ __forceinline__ void xdrop_chunk(const unsigned long long a8, const unsigned long long b8, const int c, const int xdrop,
-                                            XState &x, unsigned long long &ncols) {
+                                            XState &x, CNT &ncols) {
     if (((a8 | b8) & 0x8080808080808080ull) != 0ull) {
         // a contig separator (0xFF) inside the chunk -- the only codes with bit 7: the extension ends there, column by column
 #pragma unroll

@@ -13,6 +13,7 @@
 #include <random>
 
 #include "mb_common.h"
+#define __builtin_memcpy memcpy
 
 // ---- the wave primitives of the kernel, emulated ----------------------------------------------------------------
 static inline unsigned emu_tid() { return emu::t_threadIdx.x; }
@@ -57,14 +58,27 @@ inline int wsdot4(uint32_t a, uint32_t b, int c) {
     for (int i = 0; i < 4; i++) c += (int)(int8_t)(a >> (8 * i)) * (int)(int8_t)(b >> (8 * i));
     return c;
 }
+inline int wreadlane(int v, int l) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu_tid(), w = tid >> 6;
+    g->slot[tid] = (unsigned long long)(unsigned)v;
+    pthread_barrier_wait(&g->wave[w]);
+    const int out = (int)(unsigned)g->slot[(tid & ~63u) | (unsigned)(l & 63)];
+    pthread_barrier_wait(&g->wave[w]);
+    return out;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned wsignin(unsigned acc, int d) { return (acc << 1) | ((unsigned)d >> 31); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 using std::max;
 using std::min;
 
 namespace mb {
-inline unsigned long long load8(const uint8_t *p) { unsigned long long v; memcpy(&v, p, 8); return v; }
+#include "mb_xdrop.h"
 #include "mb_ungapped_grp.h"
+#include "mb_ungapped_ux.h"
 }  // namespace mb
 
 // ---- the rule, sequentially ----------------------------------------------------------------------------------------
@@ -78,11 +92,12 @@ static int score_of(unsigned a, unsigned b) {
 struct Ref { std::vector<mb::DevHsp> hsps; std::vector<int32_t> extent; unsigned long long extended = 0, cols = 0; };
 
 static void reference(const std::vector<unsigned long long> &keys, const uint8_t *tc, const uint8_t *qc, int64_t qtot, int xdrop, int K,
-                      Ref &out) {
+                      int long_run, Ref &out) {
     for (size_t i = 0; i < keys.size();) {
         const uint32_t dq = (uint32_t)(keys[i] >> 32);
         int32_t ext = out.extent[dq];
         size_t j = i;
+        { size_t e = i; while (e < keys.size() && (uint32_t)(keys[e] >> 32) == dq) e++; if ((int)(e - i) > long_run) { i = e; continue; } }   // (a run of k_ungapped_long: not the kernels under test)
         for (; j < keys.size() && (uint32_t)(keys[j] >> 32) == dq; j++) {
             const int32_t q_end = (int32_t)(uint32_t)keys[j];
             if (q_end <= ext) continue;
@@ -127,6 +142,7 @@ static bool hsp_less(const mb::DevHsp &a, const mb::DevHsp &b) {
 int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
+    const bool use_ux = argc > 3 && !strcmp(argv[3], "ux");             // the level-synchronous pipeline instead of k_ungapped_grp
     int bad = 0;
     for (int cs = 0; cs < n_cases; cs++) {
         std::mt19937 rng(seed0 * 7919u + (unsigned)cs);
@@ -167,18 +183,20 @@ int main(int argc, char **argv) {
         const int64_t n_hits = (int64_t)keys.size();
         const int64_t ndiag = tn + qn + 2;
         std::vector<int32_t> extent0((size_t)ndiag, 0);
-        for (int s = 0; s < 20; s++) extent0[(size_t)rnd((int)ndiag)] = rnd((int)qn);       // extents left by an earlier q batch
+        const bool extent_clean = cs % 2 == 0;                              // (odd cases: extents left by an earlier q batch)
+        if (!extent_clean) for (int s = 0; s < 20; s++) extent0[(size_t)rnd((int)ndiag)] = rnd((int)qn);
         Ref ref; ref.extent = extent0;
-        reference(keys, tc, qc, qn, xdrop, K, ref);
+        const int long_run = 6 + rnd(27);
+        reference(keys, tc, qc, qn, xdrop, K, long_run, ref);
         // class lists as k_run_heads lays them out (every run is "short" here)
         const uint64_t n = (uint64_t)n_hits;
-        std::vector<unsigned> heads((size_t)(2 * n + n / 8 + 64), 0u);
+        std::vector<unsigned> heads((size_t)(2 * n + n / 4 + 64), 0u);
         unsigned n_heads[5] = {0, 0, 0, 0, 0};
         for (int64_t i = 0; i < n_hits;) {
             int64_t j = i; while (j < n_hits && (keys[j] >> 32) == (keys[i] >> 32)) j++;
             const int64_t len = j - i;
-            const int cls = len >= 8 ? 3 : len >= 4 ? 2 : len >= 2 ? 1 : 0;
-            const uint64_t off = cls == 0 ? 0 : cls == 1 ? n : cls == 2 ? n + n / 2 : n + n / 2 + n / 4;
+            const int cls = len > long_run ? 4 : len >= 8 ? 3 : len >= 4 ? 2 : len >= 2 ? 1 : 0;
+            const uint64_t off = cls == 0 ? 0 : cls == 1 ? n : cls == 2 ? n + n / 2 : cls == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
             heads[off + n_heads[cls]++] = (unsigned)i;
             i = j;
         }
@@ -186,9 +204,34 @@ int main(int argc, char **argv) {
         std::vector<mb::DevHsp> hsps((size_t)n_hits + 8);
         mb::UngappedCounters ctr = {0, 0, 0};
         const unsigned blocks = 1 + (unsigned)rnd(3);                    // few groups: every group walks many runs
-        hipLaunchKernelGGL(mb::k_ungapped_grp<5>, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, tc, qc, (int64_t)qn,
-                           extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), &ctr);
+        if (!use_ux) {
+            hipLaunchKernelGGL(mb::k_ungapped_grp<5>, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, tc, qc, (int64_t)qn,
+                               extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), &ctr);
+        } else {
+            std::vector<unsigned long long> rec((size_t)n_hits + 1, 0xdeadbeefdeadbeefull);
+            const unsigned cap = cs % 5 == 4 ? 3u : (unsigned)n_hits;      // (a tiny list: lanes finish their hits themselves)
+            std::vector<mb::UxEntry> entries(cap + 1);
+            const unsigned n_blk = (unsigned)((n_hits + 255) / 256);
+            std::vector<mb::UxEntry> blk_entries((size_t)n_blk * 16 + 1);
+            std::vector<unsigned> blk_cnt((size_t)n_blk * 2 + 1, 0u);
+            std::vector<uint32_t> bits((size_t)(ndiag + 31) / 32 + 1, 0u), dirty((size_t)(ndiag + 31) / 32 + 1, 0u);
+            unsigned n_entries[2] = {0, 0};
+            mb::UxScratch sc; sc.rec = rec.data(); sc.blk_entries = blk_entries.data(); sc.blk_cnt = blk_cnt.data(); sc.n_blk = n_blk; sc.entries = entries.data(); sc.entry_cap = cap; sc.n_entries = n_entries; sc.long_bits = bits.data(); sc.dirty_bits = dirty.data();
+            std::vector<unsigned> dirty_runs((size_t)n_hits + 1);
+            sc.dirty_runs = dirty_runs.data(); sc.dirty_cap = (unsigned)n_hits; sc.extent = extent.data(); sc.extent_live = extent_clean ? 0 : 1; sc.dbg = 0;
+            const unsigned *heads_long = heads.data() + (n + n / 2 + n / 4 + n / 8 + 8);
+            hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, bits.data());
+            hipLaunchKernelGGL(mb::k_ux_extend, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, tc, qc, (int64_t)qn, xdrop, K, sc,
+                               hsps.data(), (int64_t)hsps.size(), &ctr);
+            hipLaunchKernelGGL(mb::k_ux_tail, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, tc, qc, (int64_t)qn, xdrop, K, sc, hsps.data(), (int64_t)hsps.size(), &ctr);
+            hipLaunchKernelGGL(mb::k_ux_accept, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, extent.data(), sc, hsps.data(), &ctr);
+            hipLaunchKernelGGL(mb::k_ux_resolve, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, extent.data(), sc, hsps.data(), &ctr);
+            { size_t nd = 0; for (uint32_t w : dirty) nd += (size_t)__builtin_popcount(w); printf("  ux: %zu dirty diagonals\n", nd); }
+            hipLaunchKernelGGL(mb::k_ux_census, dim3(1), dim3(256), 0, nullptr, tc, qc, hsps.data(), (int64_t)hsps.size(), &ctr);
+            { unsigned nb = 0; for (unsigned v : blk_cnt) nb += v; printf("  ux: %u + %u of %lld hits left for the tail (block slots + list), %llu candidates, %u dirty runs\n", nb, n_entries[0], (long long)n_hits, ctr.hsps, n_entries[1]); }
+        }
         hsps.resize((size_t)ctr.hsps);
+        hsps.erase(std::remove_if(hsps.begin(), hsps.end(), [](const mb::DevHsp &d) { return d.score == INT32_MIN; }), hsps.end());
         std::sort(hsps.begin(), hsps.end(), hsp_less);
         std::sort(ref.hsps.begin(), ref.hsps.end(), hsp_less);
         bool ok = ctr.extended == ref.extended && ctr.cols == ref.cols && hsps.size() == ref.hsps.size() && extent == ref.extent;

@@ -35,6 +35,33 @@ def test_case_matches_oracle(gpu_ctx, olz, name, tf, qf, args):
         assert got.stats[k] == want["counters"][k], k
 
 
+@pytest.mark.parametrize("kernel", ["lane", "ux", "grp"])
+def test_every_ungapped_kernel_matches_oracle(gpu_ctx, olz, monkeypatch, kernel):
+    """The short diagonal runs have three interchangeable kernels (launch_ungapped: a run per lane; the level-synchronous
+    pipeline of mb_ungapped_ux.h that dense hit sets get by default; eight lanes per run).  Each is forced in turn on pairs
+    with busy diagonals, many contigs, chance hits only, soft-masked and N stretches, and on the q-batched path (MIBLAST_HIT_CAP)
+    where later batches start from the extents of earlier ones: HSP list in discovery order and every counter as the oracle's."""
+    from cases import DEFAULT, multi_contig, pair
+    from cactus_amd import gen
+    monkeypatch.setenv("MIBLAST_UNGAPPED", kernel)
+    t, q = gen.make_pair(150000, 17, homologous=False)
+    chance = (gen.fasta_bytes([("T|c0", t)]), gen.fasta_bytes([("Q|c0", q)]))
+    for (tf, qf), args, cap in ((pair(120000, 3), DEFAULT, None), (multi_contig(9), DEFAULT, None), (chance, ["--hspthresh=1500"], None),
+                                (pair(80000, 11, sub_rate=0.02), ["--step=1", "--hspthresh=2200"], "20000"), (chance, ["--hspthresh=1500", "--xdrop=300"], "3000")):
+        if cap is None:
+            monkeypatch.delenv("MIBLAST_HIT_CAP", raising=False)
+        else:
+            monkeypatch.setenv("MIBLAST_HIT_CAP", cap)
+        pm = _params(args)
+        T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+        got = gpu_ctx.align(T, Q, pm)
+        want = olz.align(tf, qf, _oracle_params(olz, pm))
+        assert got.hsps == want["hsps"]
+        assert got.paf == want["paf"]
+        for k in COUNTERS:
+            assert got.stats[k] == want["counters"][k], (k, args, cap)
+
+
 @pytest.mark.parametrize("step", [1, 2, 5])
 def test_seed_index_matches_oracle(gpu_ctx, olz, step):
     from cases import multi_contig, pair
