@@ -194,7 +194,7 @@ void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, c
 void launch_pack_segs(const TbSeg *segs, const unsigned long long *dst, int n, const uint32_t *ops, uint32_t *packed, hipStream_t s);
 void launch_verify(const VerifyJob *jobs, VerifyOut *res, int n, const uint8_t *snaps, int Y, int E, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
-void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int end_bit,
+void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int begin_bit, int end_bit,
                hipStream_t s);
 
 constexpr int kLdsRowCap = 2048;              // LDS ring columns per DP problem (power of two)

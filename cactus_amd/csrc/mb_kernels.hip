@@ -360,9 +360,11 @@ size_t sort_keys_temp_bytes(int64_t n, int end_bit) {
     return bytes;
 }
 
-void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int end_bit,
+// begin_bit = 32 when the keys already come in q order (k_seed_fill writes them so): the stable sort then only has to order
+// the diagonals -- three 8-bit passes instead of seven on an 8 Mb pair.
+void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int begin_bit, int end_bit,
                hipStream_t s) {
-    MB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, end_bit, s));
+    MB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, begin_bit, end_bit, s));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,38 +382,57 @@ constexpr int kLongRunMax = 32;
 
 constexpr int kRunClasses = 4;                // lane-per-run lists by run length: 1, 2-3, 4-7, 8..kLongRun (a wave then holds runs of similar length)
 
+constexpr int kHeadsPerThread = 4;            // keys per thread of k_run_heads: 4096 keys per block share one atomic per list
+
 __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
                                                     unsigned *__restrict__ heads, unsigned *__restrict__ n_heads /* [0..3] short classes, [4] long */) {
     // list c of the short classes starts at heads + off(c): class 0 at 0 (<= n runs), class 1 at n (<= n/2), class 2 at 3n/2 (<= n/4),
-    // class 3 at 7n/4 (<= n/8); the long-run list at 15n/8 + 8 (<= n/(kLongRun+1) <= n/5)
-    __shared__ unsigned cnt[kRunClasses + 1][16];
+    // class 3 at 7n/4 (<= n/8); the long-run list at 15n/8 + 8 (<= n/(kLongRun+1) <= n/5).
+    // (A returning atomic on one address costs ~7 ns whoever issues it: with one key per thread the five atomics of a 1024-key
+    //  block were the kernel's time.)
+    __shared__ unsigned cnt[kRunClasses + 1][16 * kHeadsPerThread];
     __shared__ unsigned base[kRunClasses + 1];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int cls = -1;
-    if (i < n_hits) {
-        const uint32_t d = (uint32_t)(keys[i] >> 32);
-        const bool head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != d);
-        auto same = [&](int k) -> bool { return (i + k < n_hits) && ((uint32_t)(keys[i + k] >> 32) == d); };
-        if (head) cls = same(kLongRun) ? kRunClasses : same(7) ? 3 : same(3) ? 2 : same(1) ? 1 : 0;
-    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long m[kRunClasses + 1];
+    int cls[kHeadsPerThread];
+    unsigned rank[kHeadsPerThread];
 #pragma unroll
-    for (int c = 0; c <= kRunClasses; c++) { m[c] = __ballot(cls == c); if (lane == 0) cnt[c][w] = (unsigned)__popcll(m[c]); }
+    for (int j = 0; j < kHeadsPerThread; j++) {
+        const int64_t i = ((int64_t)blockIdx.x * kHeadsPerThread + j) * blockDim.x + threadIdx.x;
+        cls[j] = -1;
+        if (i < n_hits) {
+            const uint32_t d = (uint32_t)(keys[i] >> 32);
+            const bool head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != d);
+            auto same = [&](int k) -> bool { return (i + k < n_hits) && ((uint32_t)(keys[i + k] >> 32) == d); };
+            if (head) cls[j] = same(kLongRun) ? kRunClasses : same(7) ? 3 : same(3) ? 2 : same(1) ? 1 : 0;
+        }
+        rank[j] = 0;
+#pragma unroll
+        for (int c = 0; c <= kRunClasses; c++) {
+            const unsigned long long m = __ballot(cls[j] == c);
+            if (lane == 0) cnt[c][16 * j + w] = (unsigned)__popcll(m);
+            if (cls[j] == c) rank[j] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        }
+    }
     __syncthreads();
     if (threadIdx.x <= kRunClasses) {
         const int c = threadIdx.x;
         unsigned t = 0;
-        for (int k = 0; k < 16; k++) { const unsigned v = cnt[c][k]; cnt[c][k] = t; t += v; }
+        for (int k = 0; k < 16 * kHeadsPerThread; k++) { const unsigned v = cnt[c][k]; cnt[c][k] = t; t += v; }
         base[c] = t ? atomicAdd(&n_heads[c], t) : 0u;
     }
     __syncthreads();
-    if (cls >= 0) {
-        const uint64_t n = (uint64_t)n_hits;
-        const uint64_t off = cls == 0 ? 0 : cls == 1 ? n : cls == 2 ? n + n / 2 : cls == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
-        heads[off + base[cls] + cnt[cls][w] + (unsigned)__popcll(m[cls] & ((1ull << lane) - 1ull))] = (unsigned)i;
+    const uint64_t n = (uint64_t)n_hits;
+#pragma unroll
+    for (int j = 0; j < kHeadsPerThread; j++) {
+        if (cls[j] < 0) continue;
+        const int c = cls[j];
+        const int64_t i = ((int64_t)blockIdx.x * kHeadsPerThread + j) * blockDim.x + threadIdx.x;
+        const uint64_t off = c == 0 ? 0 : c == 1 ? n : c == 2 ? n + n / 2 : c == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
+        heads[off + base[c] + cnt[c][16 * j + w] + rank[j]] = (unsigned)i;
     }
 }
+
+// One x-drop direction, 8 columns per load: see mb_xdrop.h.
 
 __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__restrict__ keys, int64_t n_hits,
                                                   const unsigned *__restrict__ heads, const unsigned *__restrict__ n_heads_p,
@@ -618,7 +639,8 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     const uint64_t n = (uint64_t)n_hits;
     unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
     (void)hipMemsetAsync(n_heads, 0, (kRunClasses + 1) * sizeof(unsigned), s);
-    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1023) / 1024)), dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
+    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1024 * kHeadsPerThread - 1) / (1024 * kHeadsPerThread))), dim3(1024), 0, s, keys, n_hits, kLongRun, heads,
+                       n_heads);
     const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
     // Short runs.  Three kernels give the same results:
     //   lane  k_ungapped: a run per lane (the default for sparse hit sets: the phase's 0.6 Mb pairs, where a launch is as long as

@@ -897,7 +897,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     if (!fits[strand] || !nh[strand]) continue;
                     MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
                     MB_HIP(hipEventRecord(w.sev[strand][2], s));
-                    sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], sort_bits, s);
+                    sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], 0, sort_bits, s);
                     MB_HIP(hipEventRecord(w.sev[strand][3], s));
                     MB_HIP(hipEventRecord(w.sev[strand][4], s));
                     const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2);   // (the unsorted keys are free now)
@@ -948,7 +948,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         std::vector<DevHsp> found;
         int rc_batch = MIBLAST_OK;
         // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
-        auto extend_batch = [&](unsigned long long nh, bool timed_fill) -> int {
+        auto extend_batch = [&](unsigned long long nh, bool timed_fill, bool q_ordered) -> int {
             if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one batch (unmasked repeat?)"); return MIBLAST_ELIMIT; }
             strand_hits[strand] += nh;
             st.seed_hits += (int64_t)nh;
@@ -959,7 +959,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev1, s));
-            sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, sort_bits, s);
+            sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, q_ordered ? 32 : 0, sort_bits, s);       // (k_seed_fill writes the keys in q order)
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
@@ -987,7 +987,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         // all hits of the strand; otherwise, or if they did not fit, the two-pass path below with exact sizes and q-batches.
         bool one_pass_done = false;
         const unsigned long long cap1 = std::min<unsigned long long>((unsigned long long)keys_a.n, (unsigned long long)hit_cap);
-        if (one_pass && cap1 > 0) {
+        // (a strand like the last one seeded with this workspace must fit, else the attempt costs a search for nothing: 1.6 ms on an
+        //  8 Mb pair)
+        if (one_pass && cap1 > 0 && w.last_strand_hits <= cap1) {
             qbsum.ensure(2);
             MB_HIP(hipMemsetAsync(qbsum.p, 0, 8, s));
             MB_HIP(hipEventRecord(ctx.ev0, s));
@@ -998,7 +1000,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             w.stage.done();
             if (total <= cap1) {
                 one_pass_done = true;
-                if (total) { rc_batch = extend_batch(total, true); if (rc_batch != MIBLAST_OK) return rc_batch; }
+                if (total) { rc_batch = extend_batch(total, true, false); if (rc_batch != MIBLAST_OK) return rc_batch; }
             }
         }
         if (!one_pass_done) {
@@ -1020,7 +1022,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev0, s));
             launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
             launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
-            rc_batch = extend_batch(nh, true);
+            rc_batch = extend_batch(nh, true, env_long("MIBLAST_SORT_DIAG_ONLY", 1) != 0);
             if (rc_batch != MIBLAST_OK) return rc_batch;
         }
         }
