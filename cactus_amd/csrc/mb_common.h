@@ -175,7 +175,8 @@ void launch_seed_count(const uint8_t *qcodes, int64_t qn, const uint32_t *offset
 void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qtot, const uint32_t *offsets,
                       const uint32_t *positions, int transitions, const uint32_t *hit_off, unsigned long long *keys,
                       hipStream_t s);
-void launch_bucket_bitmap(const uint32_t *offsets, uint32_t *occ, hipStream_t s);
+void launch_index_clear(const uint32_t *words, int64_t n_slots, uint32_t *cursor, hipStream_t s);
+void launch_scan_index(uint32_t *counts, uint32_t *offsets, unsigned long long *block_sums, uint32_t *occ, hipStream_t s);
 void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *occ, const uint32_t *positions, int transitions,
                         unsigned long long *keys, unsigned long long cap, unsigned long long *total, hipStream_t s);
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,

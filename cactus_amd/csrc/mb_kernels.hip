@@ -145,6 +145,21 @@ void launch_index_scatter(const uint32_t *words, int64_t n_slots, int step, int6
                        offsets, cursor, positions);
 }
 
+// the scatter's cursors (= the bucket counts again) back to zero for the next build: by the indexed words when they are few,
+// else with a memset of the 64 MiB
+__global__ void k_index_clear(const uint32_t *__restrict__ words, int64_t n_slots, uint32_t *__restrict__ cursor) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const uint32_t w = words[s];
+    if (w != 0xFFFFFFFFu) cursor[w] = 0u;
+}
+
+void launch_index_clear(const uint32_t *words, int64_t n_slots, uint32_t *cursor, hipStream_t s) {
+    if (n_slots <= 0) return;
+    if (n_slots > (2 << 20)) { (void)hipMemsetAsync(cursor, 0, ((size_t)kBuckets + 1) * 4, s); return; }
+    hipLaunchKernelGGL(k_index_clear, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, words, n_slots, cursor);
+}
+
 // ------------------------------------------------------------------------------------------------
 // exclusive scan of u32 (three launches: block totals, scan of totals, apply)
 constexpr int kScanBlock = 256;
@@ -193,8 +208,14 @@ __global__ void k_scan_bsums(unsigned long long *bsum, int64_t nb) {
     if (threadIdx.x == 0) bsum[nb] = carry_s;
 }
 
+// INDEX: the scan of the seed table's bucket counts.  The same pass leaves the counts zeroed (they are the scatter's cursors next,
+// and the next build's histogram after that: no 64 MiB memset between) and writes the occupancy bitmap of the buckets (bit b of
+// word w = bucket 32 w + b holds at least one position; 2 MiB, so it stays in L2 while the 64 MiB offset table does not:
+// k_seed_search asks it first).
+template <bool INDEX>
 __global__ void k_scan_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t n,
-                             const unsigned long long *__restrict__ bsum) {
+                             const unsigned long long *__restrict__ bsum, uint32_t *__restrict__ zero_in, uint32_t *__restrict__ occ,
+                             int64_t n_occ) {
     __shared__ uint32_t wsum[kScanBlock / 64];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread];
@@ -212,6 +233,19 @@ __global__ void k_scan_apply(const uint32_t *__restrict__ in, uint32_t *__restri
     uint32_t run = (uint32_t)bsum[blockIdx.x] + woff + incl - tsum;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (INDEX) {
+        static_assert(kScanPerThread == 8, "four threads make a bitmap word");
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; k++) {
+            m |= (v[k] != 0u ? 1u : 0u) << k;
+            if (v[k] != 0u) zero_in[base + k] = 0u;                       // (sparse: most buckets of a small target are empty already)
+        }
+        m <<= 8 * (lane & 3);
+        m |= __shfl_xor(m, 1);
+        m |= __shfl_xor(m, 2);
+        if ((lane & 3) == 0 && base < n_occ) occ[base >> 5] = m;          // (n_occ = kBuckets: a multiple of 32; the total slot behind it is not a bucket)
+    }
 }
 
 void launch_block_sums(const uint32_t *in, int64_t n, unsigned long long *block_sums, hipStream_t s) {
@@ -225,7 +259,16 @@ void launch_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, unsigned long
     int64_t nb = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, s, in, n, block_sums);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, s, block_sums, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanBlock), 0, s, in, out, n, block_sums);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3((unsigned)nb), dim3(kScanBlock), 0, s, in, out, n, block_sums, (uint32_t *)nullptr, (uint32_t *)nullptr, (int64_t)0);
+}
+
+// exclusive scan of the kBuckets + 1 bucket counts of the seed table -> offsets; the counts come out zeroed and the occupancy
+// bitmap of the buckets is written (k_scan_apply<true>)
+void launch_scan_index(uint32_t *counts, uint32_t *offsets, unsigned long long *block_sums, uint32_t *occ, hipStream_t s) {
+    const int64_t n = (int64_t)kBuckets + 1, nb = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, n, block_sums);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, s, block_sums, nb);
+    hipLaunchKernelGGL(k_scan_apply<true>, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, offsets, n, block_sums, counts, occ, (int64_t)kBuckets);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,22 +325,6 @@ void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qto
     if (q1 <= q0) return;
     hipLaunchKernelGGL(k_seed_fill, dim3((unsigned)((q1 - q0 + 255) / 256)), dim3(256), 0, s, qcodes, q0, q1, qtot, qtot,
                        offsets, positions, transitions ? 1 + kSeedWeight : 1, hit_off, keys);
-}
-
-// occupancy bitmap of the seed table: bit b of word w = bucket 32 w + b holds at least one position.  2 MiB for the 2^24
-// buckets, so it stays in L2 while the 64 MiB offset table does not: k_seed_search asks it first and only touches the
-// offset table for occupied buckets (a 1 Mb target occupies ~6 % of the buckets).
-__global__ void k_bucket_bitmap(const uint32_t *__restrict__ offsets, uint32_t *__restrict__ occ) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;            // one bucket per thread, one word per 32 lanes
-    if (b >= kBuckets) return;
-    const unsigned long long m = __ballot(offsets[b + 1] != offsets[b]);
-    const int lane = threadIdx.x & 63;
-    if (lane == 0) occ[b >> 5] = (uint32_t)m;
-    else if (lane == 32) occ[b >> 5] = (uint32_t)(m >> 32);
-}
-
-void launch_bucket_bitmap(const uint32_t *offsets, uint32_t *occ, hipStream_t s) {
-    hipLaunchKernelGGL(k_bucket_bitmap, dim3(kBuckets / 256), dim3(256), 0, s, offsets, occ);
 }
 
 // seed search in one pass: count, reserve and fill.  Every block counts the hits of its 256 query positions (the bucket

@@ -507,6 +507,7 @@ void release_seqset(SeqSet &s) {
 struct Workspace {                      // device buffers that persist across miblast_align() calls of one context
     // seed position table
     DevBuf<uint32_t> words, counts, offsets, positions, occ;
+    bool counts_zero = false;                 // `counts` is all zero (build_index leaves it so)
     DevBuf<unsigned long long> bsum;
     // seed search / ungapped
     DevBuf<uint8_t> rc;
@@ -594,13 +595,16 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     static const long spike_ms = env_long("MIBLAST_DEBUG_SPIKE", 0);
     const double t0 = now_s();
     if (spike_ms) MB_HIP(hipEventRecord(ctx.ev0, s));
-    MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
+    // the bucket counts are zero between builds: the scan zeroes what the histogram counted, and the scatter's cursors (the same
+    // array) are zeroed again by a pass over the indexed words -- 64 MiB memsets are most of a small target's build otherwise
+    if (!w.counts_zero) MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
+    w.counts_zero = false;                                              // (until the clearing pass below is queued: an error in between costs a memset)
     launch_index_words(T.dev(), T.total, step, first, w.words.p, n_slots, w.counts.p, s);
-    launch_scan_u32(w.counts.p, w.offsets.p, (int64_t)kBuckets + 1, w.bsum.p, s);
-    MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
-    launch_index_scatter(w.words.p, n_slots, step, first, w.offsets.p, w.counts.p, w.positions.p, s);
     w.occ.ensure((size_t)kBuckets / 32);
-    launch_bucket_bitmap(w.offsets.p, w.occ.p, s);
+    launch_scan_index(w.counts.p, w.offsets.p, w.bsum.p, w.occ.p, s);
+    launch_index_scatter(w.words.p, n_slots, step, first, w.offsets.p, w.counts.p, w.positions.p, s);
+    launch_index_clear(w.words.p, n_slots, w.counts.p, s);
+    w.counts_zero = true;
     if (spike_ms) MB_HIP(hipEventRecord(ctx.ev1, s));
     const double t1 = now_s();
     w.stage.d2h(&ix.n_positions, w.offsets.p + kBuckets, 4, s);
