@@ -170,9 +170,9 @@ void launch_index_scatter(const uint32_t *words, int64_t n_slots, int step, int6
 // ceil(n/2048)+1 entries and on return holds the exclusive prefix of the per-block totals, total last.
 void launch_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, unsigned long long *block_sums, hipStream_t s);
 void launch_block_sums(const uint32_t *in, int64_t n, unsigned long long *block_sums, hipStream_t s);
-void launch_seed_count(const uint8_t *qcodes, int64_t qn, const uint32_t *offsets, int transitions, uint32_t *qcnt,
+void launch_seed_count(const uint8_t *qcodes, int64_t qn, const uint32_t *offsets, const uint32_t *occ, int transitions, uint32_t *qcnt,
                        hipStream_t s);
-void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qtot, const uint32_t *offsets,
+void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
                       const uint32_t *positions, int transitions, const uint32_t *hit_off, unsigned long long *keys,
                       hipStream_t s);
 void launch_index_clear(const uint32_t *words, int64_t n_slots, uint32_t *cursor, hipStream_t s);

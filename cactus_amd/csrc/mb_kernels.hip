@@ -278,29 +278,31 @@ __device__ __forceinline__ uint32_t variant_word(uint32_t w, int v) {
     return v == 0 ? w : (w ^ (2u << (2 * (kSeedWeight - v))));
 }
 
+// (count and fill ask the 2 MiB occupancy bitmap before the 64 MiB offset table, like k_seed_search: most lookups of a sparse
+//  table end in L2)
 __global__ void k_seed_count(const uint8_t *__restrict__ qcodes, int64_t qn, const uint32_t *__restrict__ offsets,
-                             int nvar, uint32_t *__restrict__ qcnt) {
+                             const uint32_t *__restrict__ occ, int nvar, uint32_t *__restrict__ qcnt) {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= qn) return;
     uint32_t cnt = 0, w;
     if (q + kSeedSpan <= qn && window_word(qcodes, q, w)) {
         for (int v = 0; v < nvar; v++) {
             uint32_t wv = variant_word(w, v);
-            cnt += offsets[wv + 1] - offsets[wv];
+            if ((occ[wv >> 5] >> (wv & 31u)) & 1u) cnt += offsets[wv + 1] - offsets[wv];
         }
     }
     qcnt[q] = cnt;
 }
 
-void launch_seed_count(const uint8_t *qcodes, int64_t qn, const uint32_t *offsets, int transitions, uint32_t *qcnt,
+void launch_seed_count(const uint8_t *qcodes, int64_t qn, const uint32_t *offsets, const uint32_t *occ, int transitions, uint32_t *qcnt,
                        hipStream_t s) {
     if (qn <= 0) return;
-    hipLaunchKernelGGL(k_seed_count, dim3((unsigned)((qn + 255) / 256)), dim3(256), 0, s, qcodes, qn, offsets,
+    hipLaunchKernelGGL(k_seed_count, dim3((unsigned)((qn + 255) / 256)), dim3(256), 0, s, qcodes, qn, offsets, occ,
                        transitions ? 1 + kSeedWeight : 1, qcnt);
 }
 
 __global__ void k_seed_fill(const uint8_t *__restrict__ qcodes, int64_t q0, int64_t q1, int64_t qn, int64_t qtot,
-                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ positions, int nvar,
+                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ occ, const uint32_t *__restrict__ positions, int nvar,
                             const uint32_t *__restrict__ hit_off, unsigned long long *__restrict__ keys) {
     int64_t q = q0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= q1) return;
@@ -310,6 +312,7 @@ __global__ void k_seed_fill(const uint8_t *__restrict__ qcodes, int64_t q0, int6
     unsigned long long q_end = (unsigned long long)(q + kSeedSpan);
     for (int v = 0; v < nvar; v++) {
         uint32_t wv = variant_word(w, v);
+        if (!((occ[wv >> 5] >> (wv & 31u)) & 1u)) continue;
         uint32_t b0 = offsets[wv], b1 = offsets[wv + 1];
         for (uint32_t k = b0; k < b1; k++) {
             // diagonal d = t_end - q_end = p - q ; stored biased by qtot so it is non-negative
@@ -319,12 +322,12 @@ __global__ void k_seed_fill(const uint8_t *__restrict__ qcodes, int64_t q0, int6
     }
 }
 
-void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qtot, const uint32_t *offsets,
+void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
                       const uint32_t *positions, int transitions, const uint32_t *hit_off, unsigned long long *keys,
                       hipStream_t s) {
     if (q1 <= q0) return;
     hipLaunchKernelGGL(k_seed_fill, dim3((unsigned)((q1 - q0 + 255) / 256)), dim3(256), 0, s, qcodes, q0, q1, qtot, qtot,
-                       offsets, positions, transitions ? 1 + kSeedWeight : 1, hit_off, keys);
+                       offsets, occ, positions, transitions ? 1 + kSeedWeight : 1, hit_off, keys);
 }
 
 // seed search in one pass: count, reserve and fill.  Every block counts the hits of its 256 query positions (the bucket

@@ -1008,7 +1008,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             }
         }
         if (!one_pass_done) {
-        launch_seed_count(qc_d[strand], qtot, w.offsets.p, p.transitions, qcnt.p, s);
+        launch_seed_count(qc_d[strand], qtot, w.offsets.p, w.occ.p, p.transitions, qcnt.p, s);
         launch_block_sums(qcnt.p, qtot, qbsum.p, s);
         MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
         MB_HIP(hipStreamSynchronize(s));
@@ -1025,7 +1025,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             keys_a.ensure((size_t)nh);
             MB_HIP(hipEventRecord(ctx.ev0, s));
             launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
-            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
+            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
             rc_batch = extend_batch(nh, true, env_long("MIBLAST_SORT_DIAG_ONLY", 1) != 0);
             if (rc_batch != MIBLAST_OK) return rc_batch;
         }

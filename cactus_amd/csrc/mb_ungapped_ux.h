@@ -31,7 +31,7 @@ namespace ux {
 // Chance hits of the 12-of-19 seed under HOXD70 / x-drop 910 (simulation, 2 x 10^5 hits): the left walk looks at 40 columns on
 // average (the seed is 19 of them), P(> 48) = 0.14, P(> 72) = 0.005; the right walk at 21, P(> 32) = 0.09, P(> 56) = 0.003.
 constexpr int kL1 = 6, kR1 = 4;               // level 1: chunks to the left / right -- 80 % of the chance hits end here
-constexpr int kL2 = 4, kR2 = 4;               // level 2: further chunks per direction -- all but ~1 % of the rest
+constexpr int kL2 = 2, kR2 = 2;               // level 2: further chunks per direction -- all but ~2.5 % of the hits are done after it
 static_assert(kL1 % 2 == 0 && kR1 % 2 == 0 && kL2 % 2 == 0 && kR2 % 2 == 0, "chunks are loaded two at a time");
 constexpr int kBlock = 256;
 constexpr unsigned kSlots0 = 12, kSlots1 = 4;  // entry slots owned by wave 0 / wave 1 of a block of k_ux_extend (blk_entries, blk_cnt)
@@ -43,12 +43,13 @@ __device__ __forceinline__ bool on_long_diagonal(const uint32_t *__restrict__ bi
 // v_dot4c prefix of the signed score bytes; "best so far" is a running maximum of KEYS (score << 3 | 7 - column), so that the
 // first column of the best score comes with it; column m stops iff (score + xdrop) << 3 | 7 is below the key maximum before it
 // (carried best: best << 3 | 7, so an equal score never looks like an improvement).  What a sequential walk would not have
-// looked at lies behind the first stop and is masked out afterwards.  Same result as xdrop_chunk, which also serves the
-// chunks that hold a contig separator.
+// looked at lies behind the first stop and is masked out afterwards.  Same result as xdrop_chunk on chunks without a contig
+// separator; a hit with a separator inside the columns of a level skips that level (k_ux_tail's steps know separators).  Keeping
+// the column-by-column separator path out of here also keeps k_ux_extend's 18 chunk instances inside the instruction cache.
 template <int DIR, typename CNT>
 __device__ __forceinline__ void ux_chunk(const unsigned long long a8, const unsigned long long b8, const int c, const int xdrop,
                                          XState &x, CNT &ncols) {
-    if (((a8 | b8) & 0x8080808080808080ull) != 0ull) { xdrop_chunk<DIR>(a8, b8, c, xdrop, x, ncols); return; }
+    // (precondition: no contig separator in the chunk -- the callers hand such hits on untouched)
     // column m = byte m: to the left the bytes come reversed
     const uint32_t a_lo = DIR > 0 ? (uint32_t)a8 : wperm((uint32_t)(a8 >> 32), (uint32_t)a8, 0x04050607u);
     const uint32_t a_hi = DIR > 0 ? (uint32_t)(a8 >> 32) : wperm((uint32_t)(a8 >> 32), (uint32_t)a8, 0x00010203u);
@@ -168,14 +169,22 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
         for (int j = 0; j < kR1 / 2; j++) { load_right2(tc + t_end, j, aR[2 * j], aR[2 * j + 1]); load_right2(qc + q_end, j, bR[2 * j], bR[2 * j + 1]); }
         XState xl{0, 0, 0, true}, xr{0, 0, 0, true};
         uint32_t cols = 0;
+        unsigned long long seps = 0;
 #pragma unroll
-        for (int c = 0; c < kL1; c++) ux_chunk<-1>(aL[c], bL[c], c, xdrop, xl, cols);
+        for (int c = 0; c < kL1; c++) seps |= aL[c] | bL[c];
 #pragma unroll
-        for (int c = 0; c < kR1; c++) ux_chunk<+1>(aR[c], bR[c], c, xdrop, xr, cols);
+        for (int c = 0; c < kR1; c++) seps |= aR[c] | bR[c];
+        const bool clean = (seps & 0x8080808080808080ull) == 0ull;      // no contig separator within the level's columns
+        if (clean) {
+#pragma unroll
+            for (int c = 0; c < kL1; c++) ux_chunk<-1>(aL[c], bL[c], c, xdrop, xl, cols);
+#pragma unroll
+            for (int c = 0; c < kR1; c++) ux_chunk<+1>(aR[c], bR[c], c, xdrop, xr, cols);
+        }
         if (xl.live | xr.live) {
             // (a diagonal of k_ungapped_long: nobody reads this hit's record)
             unfinished = !on_long_diagonal(sc.long_bits, dq);
-            e.cl = xl.live ? kL1 : -1; e.cr = xr.live ? kR1 : -1;
+            e.cl = xl.live ? (clean ? kL1 : 0) : -1; e.cr = xr.live ? (clean ? kR1 : 0) : -1;
             e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos; e.cols = cols;
         } else {
             finish_hit((uint32_t)i, dq, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
@@ -211,12 +220,19 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
         for (int j = 0; j < kR2 / 2; j++) { load_right2(tc + t_end, cr0 / 2 + j, aR[2 * j], aR[2 * j + 1]); load_right2(qc + q_end, cr0 / 2 + j, bR[2 * j], bR[2 * j + 1]); }
         xl = XState{e.run_l, e.best_l, e.bpos_l, e.cl >= 0};
         xr = XState{e.run_r, e.best_r, e.bpos_r, e.cr >= 0};
+        unsigned long long seps = 0;
 #pragma unroll
-        for (int c = 0; c < kL2; c++) ux_chunk<-1>(aL[c], bL[c], cl0 + c, xdrop, xl, e.cols);
+        for (int c = 0; c < kL2; c++) seps |= aL[c] | bL[c];
 #pragma unroll
-        for (int c = 0; c < kR2; c++) ux_chunk<+1>(aR[c], bR[c], cr0 + c, xdrop, xr, e.cols);
-        e.cl = xl.live ? cl0 + kL2 : -1; e.cr = xr.live ? cr0 + kR2 : -1;
-        e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos;
+        for (int c = 0; c < kR2; c++) seps |= aR[c] | bR[c];
+        if ((seps & 0x8080808080808080ull) == 0ull) {
+#pragma unroll
+            for (int c = 0; c < kL2; c++) ux_chunk<-1>(aL[c], bL[c], cl0 + c, xdrop, xl, e.cols);
+#pragma unroll
+            for (int c = 0; c < kR2; c++) ux_chunk<+1>(aR[c], bR[c], cr0 + c, xdrop, xr, e.cols);
+            e.cl = xl.live ? cl0 + kL2 : -1; e.cr = xr.live ? cr0 + kR2 : -1;
+            e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos;
+        }                                                             // (else: a separator ahead -- the entry goes on as it came)
         spill = xl.live | xr.live;
         if (!spill) finish_hit(e.i, dq, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
     }
