@@ -169,10 +169,20 @@ constexpr int kScanTile = kScanBlock * kScanPerThread;    // 2048
 __global__ void k_block_sums(const uint32_t *__restrict__ in, int64_t n, unsigned long long *__restrict__ bsum) {
     __shared__ unsigned long long red[kScanBlock / 64];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPerThread;
+    // (thread sums in 64 bits; the wave total from three 20-bit slices summed with DPP scans: no LDS round trips)
     unsigned long long v = 0;
+    if (base + kScanPerThread <= n) {
+        const uint4 a = *(const uint4 *)(in + base), b = *(const uint4 *)(in + base + 4);      // (base is a multiple of 8: 16-byte aligned)
+        v = (unsigned long long)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; k++) if (base + k < n) v += in[base + k];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        for (int k = 0; k < kScanPerThread; k++) if (base + k < n) v += in[base + k];
+    }
+    {
+        const int s0 = dpp_scan_add((int)(v & 0xFFFFFu)), s1 = dpp_scan_add((int)((v >> 20) & 0xFFFFFu)), s2 = dpp_scan_add((int)(v >> 40));
+        v = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(s0, 63) + ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(s1, 63) << 20) +
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(s2, 63) << 40);
+    }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -220,19 +230,31 @@ __global__ void k_scan_apply(const uint32_t *__restrict__ in, uint32_t *__restri
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread];
     uint32_t tsum = 0;
+    if (base + kScanPerThread <= n) {
+        const uint4 a = *(const uint4 *)(in + base), b = *(const uint4 *)(in + base + 4);      // (base is a multiple of 8: 16-byte aligned)
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; k++) { v[k] = (base + k < n) ? in[base + k] : 0u; tsum += v[k]; }
-    // inclusive scan of tsum across the wave
-    uint32_t incl = tsum;
-    int lane = threadIdx.x & 63;
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        for (int k = 0; k < kScanPerThread; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) tsum += v[k];
+    // inclusive scan of tsum across the wave (DPP: no LDS round trips)
+    const int lane = threadIdx.x & 63;
+    const uint32_t incl = (uint32_t)dpp_scan_add((int)tsum);
     if (lane == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
     uint32_t woff = 0;
     for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += wsum[k];
     uint32_t run = (uint32_t)bsum[blockIdx.x] + woff + incl - tsum;
+    if (base + kScanPerThread <= n) {
+        uint4 a, b;
+        a.x = run; a.y = a.x + v[0]; a.z = a.y + v[1]; a.w = a.z + v[2]; b.x = a.w + v[3]; b.y = b.x + v[4]; b.z = b.y + v[5]; b.w = b.z + v[6];
+        *(uint4 *)(out + base) = a; *(uint4 *)(out + base + 4) = b;
+    } else {
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+        for (int k = 0; k < kScanPerThread; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    }
     if (INDEX) {
         static_assert(kScanPerThread == 8, "four threads make a bitmap word");
         uint32_t m = 0;
