@@ -124,7 +124,6 @@ struct UxScratch {                            // device scratch of one launch_un
     unsigned dirty_cap;
     const int32_t *extent;                    // extent[] of the launch, read by the first hit of a run when
     int extent_live;                          // ... an earlier q batch may have left extents (0: extent[] is all zero)
-    int dbg;                                  // MIBLAST_UX_DBG: timing experiments (results are wrong when set)
 };
 
 // ---- host-side sequence set --------------------------------------------------------------------

@@ -722,7 +722,6 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
         (void)hipMemsetAsync(ux->blk_cnt, 0, 2 * (size_t)ux->n_blk * sizeof(unsigned), s);
         UxScratch sc = *ux;
         sc.extent = extent; sc.extent_live = extent_clean ? 0 : 1;
-        { static const int dbg = [] { const char *e = getenv("MIBLAST_UX_DBG"); return e ? atoi(e) : 0; }(); sc.dbg = dbg; }
         ux = &sc;
         hipLaunchKernelGGL(k_ux_mark_long, dim3((unsigned)((max_long + 255) / 256)), dim3(256), 0, s, keys, heads_long, n_heads + kRunClasses, ux->long_bits);
         hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, tcodes, qcodes, qtot,

@@ -693,7 +693,7 @@ static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, in
     sc.entries = w.ux_entries.p + blk_slots; sc.entry_cap = (unsigned)std::min<size_t>(cap, 0x7fffffffu); sc.n_entries = w.ux_cnt.p;
     sc.long_bits = w.ux_bits.p; sc.dirty_bits = w.ux_bits.p + plane;
     sc.dirty_runs = (unsigned *)w.ux_entries.p; sc.dirty_cap = (unsigned)std::min<size_t>((blk_slots + cap) * (sizeof(UxEntry) / sizeof(unsigned)), 0x7fffffffu);
-    sc.extent = nullptr; sc.extent_live = 1; sc.dbg = 0;
+    sc.extent = nullptr; sc.extent_live = 1;
     return sc;
 }
 

@@ -111,11 +111,11 @@ __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, 
     // Does this walk reach the next hit of the diagonal -- or, in a later q batch, does an earlier batch's extent reach the run's
     // first hit?  Then the run needs the sequential rule (k_ux_resolve).
     bool dirty = false;
-    if (!(sc.dbg & 8) && (int64_t)i + 1 < n_hits) {
+    if ((int64_t)i + 1 < n_hits) {
         const unsigned long long nk = keys[i + 1];
         dirty = (uint32_t)(nk >> 32) == dq && q_end + br >= (int32_t)(uint32_t)nk;
     }
-    if (!(sc.dbg & 16) && sc.extent_live && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != dq)) dirty |= sc.extent[dq] >= q_end;
+    if (sc.extent_live && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != dq)) dirty |= sc.extent[dq] >= q_end;
     if (dirty) atomicOr(&sc.dirty_bits[dq >> 5], 1u << (dq & 31u));
     uint32_t x = cols;
     const int score = best_l + best_r;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
     // ---- still running: to k_ux_tail.  A returning atomic on one address costs ~7 ns whoever issues it, and nearly every block has
     //      a straggler or two: the first two waves of a block own 12 + 4 slots of the entry array (count stored, no atomic); only
     //      what does not fit there goes to the shared list (one atomic per wave).
-    const unsigned long long sm = wballot(spill && !(sc.dbg & 4));
+    const unsigned long long sm = wballot(spill);
     const unsigned my_pos = (unsigned)__popcll(sm & ((1ull << lane) - 1ull)), n_sp = (unsigned)__popcll(sm);
     const unsigned own = wv == 0 ? kSlots0 : wv == 1 ? kSlots1 : 0u;
     if (wv < 2 && lane == 0) sc.blk_cnt[2 * blockIdx.x + wv] = min(n_sp, own);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
         const unsigned long long nk = i + 1 < n_hits ? keys[i + 1] : ~0ull;
         const unsigned long long pk = i > 0 ? keys[i - 1] : ~0ull;
         const uint32_t dq = (uint32_t)(key >> 32);
-        const bool is_long = (sc.dbg & 2) ? false : (sc.long_bits[dq >> 5] >> (dq & 31u)) & 1u, is_dirty = (sc.dbg & 2) ? false : (sc.dirty_bits[dq >> 5] >> (dq & 31u)) & 1u;
+        const bool is_long = (sc.long_bits[dq >> 5] >> (dq & 31u)) & 1u, is_dirty = (sc.dirty_bits[dq >> 5] >> (dq & 31u)) & 1u;
         if (!is_long && !is_dirty) {
             const uint32_t x = (uint32_t)(rc >> 32);
             uint32_t cols = x;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
             }
             n_kept++; n_cols += cols;
             // the last hit of the run leaves the diagonal's extent
-            if (!(sc.dbg & 1) && (uint32_t)(nk >> 32) != dq) extent[dq] = (int32_t)(uint32_t)key + (int32_t)(uint32_t)rc;
+            if ((uint32_t)(nk >> 32) != dq) extent[dq] = (int32_t)(uint32_t)key + (int32_t)(uint32_t)rc;
         } else if (is_dirty && !is_long && (uint32_t)(pk >> 32) != dq) {
             const unsigned slot = atomicAdd(&n_dbuf, 1u);                // (LDS)
             if (slot < kDirtyBuf) dbuf[slot] = (unsigned)i;

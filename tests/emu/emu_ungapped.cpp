@@ -218,7 +218,7 @@ int main(int argc, char **argv) {
             unsigned n_entries[2] = {0, 0};
             mb::UxScratch sc; sc.rec = rec.data(); sc.blk_entries = blk_entries.data(); sc.blk_cnt = blk_cnt.data(); sc.n_blk = n_blk; sc.entries = entries.data(); sc.entry_cap = cap; sc.n_entries = n_entries; sc.long_bits = bits.data(); sc.dirty_bits = dirty.data();
             std::vector<unsigned> dirty_runs((size_t)n_hits + 1);
-            sc.dirty_runs = dirty_runs.data(); sc.dirty_cap = (unsigned)n_hits; sc.extent = extent.data(); sc.extent_live = extent_clean ? 0 : 1; sc.dbg = 0;
+            sc.dirty_runs = dirty_runs.data(); sc.dirty_cap = (unsigned)n_hits; sc.extent = extent.data(); sc.extent_live = extent_clean ? 0 : 1;
             const unsigned *heads_long = heads.data() + (n + n / 2 + n / 4 + n / 8 + 8);
             hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, bits.data());
             hipLaunchKernelGGL(mb::k_ux_extend, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, tc, qc, (int64_t)qn, xdrop, K, sc,
