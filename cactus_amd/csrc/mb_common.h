@@ -20,10 +20,11 @@ constexpr int32_t kNeg = -(1 << 29);
 constexpr int kDevPad = 128;                  // separator bytes around device code arrays (8-byte loads may overrun)
 
 // ---- device-side records ---------------------------------------------------------------------
-struct DevHsp {                               // written by k_ungapped for every HSP with score >= K
+struct DevHsp {                               // written by the ungapped kernels for every HSP with score >= K
     int32_t t_start, q_start, len, score;
     int32_t seed_t_end, seed_q_end;
     int32_t cnt[4];
+    int32_t anchor_off;                       // k_hsp_anchor: middle of the best-scoring 31-column window, first on ties
 };
 
 struct DpProb {                               // one one-sided Y-drop DP (SURVEY A.7 ONE_SIDED)

@@ -679,6 +679,47 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
 // ---- level-synchronous pipeline for dense hit sets ------------------------------------------------------------------
 #include "mb_ungapped_ux.h"
 
+// ---- anchors of the HSPs: the gapped stage starts an alignment in the middle of an HSP's best-scoring window of 31
+// columns, the first one on ties.  The host used to scan every column of every HSP for it (25 ms on a 30 Mb x 30 Mb pair at 1.3 %
+// divergence, where the HSPs hold 10^8 columns); here a lane walks an HSP, 8 columns per turn: the window gains the scores of
+// columns c + 30 .. c + 37 and loses those of c - 1 .. c + 6, both read as one unaligned 8-byte load per sequence.
+__global__ __launch_bounds__(256) void k_hsp_anchor(const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, DevHsp *__restrict__ hsps,
+                                                     const int64_t hsp_cap, const UngappedCounters *__restrict__ ctr) {
+    const unsigned long long n = min((unsigned long long)hsp_cap, ctr->hsps);
+    for (unsigned long long s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (unsigned long long)gridDim.x * blockDim.x) {
+        const int len = hsps[s].len;
+        if (hsps[s].score == -2147483647 - 1) continue;                  // (a candidate the suppression rule dropped)
+        int off = len / 2;
+        if (len > 31) {
+            const uint8_t *tp = tc + hsps[s].t_start, *qp = qc + hsps[s].q_start;
+            int sum = 0;
+            for (int k0 = 0; k0 < 32; k0 += 8) {                          // the first window: columns 0 .. 30
+                const unsigned long long a8 = load8(tp + k0), b8 = load8(qp + k0);
+                const uint32_t s_lo = scores4((uint32_t)a8, (uint32_t)b8), s_hi = scores4((uint32_t)(a8 >> 32), (uint32_t)(b8 >> 32));
+#pragma unroll
+                for (int m = 0; m < 8; m++)
+                    if (k0 + m < 31) sum += (int)(((m < 4 ? s_lo : s_hi) >> (8 * (m & 3))) & 0xFFu) - 128;
+            }
+            int bestsum = sum, bestc = 0;
+            for (int cc = 1; cc + 31 <= len; cc += 8) {                   // windows cc .. cc + 7
+                const unsigned long long a_in = load8(tp + cc + 30), b_in = load8(qp + cc + 30), a_out = load8(tp + cc - 1), b_out = load8(qp + cc - 1);
+                const uint32_t i_lo = scores4((uint32_t)a_in, (uint32_t)b_in), i_hi = scores4((uint32_t)(a_in >> 32), (uint32_t)(b_in >> 32));
+                const uint32_t o_lo = scores4((uint32_t)a_out, (uint32_t)b_out), o_hi = scores4((uint32_t)(a_out >> 32), (uint32_t)(b_out >> 32));
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int in = (int)(((m < 4 ? i_lo : i_hi) >> (8 * (m & 3))) & 0xFFu), out = (int)(((m < 4 ? o_lo : o_hi) >> (8 * (m & 3))) & 0xFFu);
+                    sum += in - out;
+                    const bool better = (cc + m + 31 <= len) & (sum > bestsum);
+                    bestsum = better ? sum : bestsum;
+                    bestc = better ? cc + m : bestc;
+                }
+            }
+            off = bestc + 15;
+        }
+        hsps[s].anchor_off = off;
+    }
+}
+
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
                      const uint8_t *qcodes, int64_t qtot, int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s) {
@@ -734,6 +775,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     }
     hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
                        tcodes, qcodes, qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+    hipLaunchKernelGGL(k_hsp_anchor, dim3(512), dim3(256), 0, s, tcodes, qcodes, hsps, hsp_cap, ctr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -185,7 +185,9 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
 
     // gap_q: how far apart in q two consecutive anchors of a group may lie; tol_d: how far apart their diagonals; a run of n_run
     // or more N between two anchors (in either sequence) ends the group as well: no extension survives it (N scores -100)
-    void index_anchors(int32_t gap_q, int32_t tol_d, const uint8_t *tc, const uint8_t *qc, int32_t n_run) {
+    // nt / nq: the runs of N bases of the target / of the searched strand of the query (n_runs_of), sorted; nullptr: none known
+    void index_anchors(int32_t gap_q, int32_t tol_d, const std::vector<std::pair<int32_t, int32_t>> *nt, const std::vector<std::pair<int32_t, int32_t>> *nq,
+                       int32_t n_run) {
         by_q.resize(anchors.size());
         for (size_t k = 0; k < by_q.size(); k++) by_q[k] = (uint32_t)k;
         parallel_sort(by_q.begin(), by_q.end(), [&](uint32_t x, uint32_t y) { return anchors[x].q != anchors[y].q ? anchors[x].q < anchors[y].q : x < y; });
@@ -206,13 +208,16 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
                 if (b.q - a.q > gap_q) break;
                 const int32_t dd = (b.t - b.q) - da;
                 if (dd >= -tol_d && dd <= tol_d) {
-                    auto n_between = [&](const uint8_t *c, int32_t lo, int32_t hi) -> bool {      // a run of >= n_run N inside [lo, hi)
-                        if (!c || hi - lo < n_run) return false;
-                        int32_t run = 0;
-                        for (int32_t x = lo; x < hi; x++) { run = (c[x] & 7u) == 4u ? run + 1 : 0; if (run >= n_run) return true; }
+                    // a run of >= n_run N inside [lo, hi): looked up in the sorted list of the sequence's N runs (scanning the bases
+                    // between every pair of linked anchors cost 24 ms on a 30 Mb x 30 Mb pair -- the whole of both sequences, on one thread)
+                    auto n_between = [&](const std::vector<std::pair<int32_t, int32_t>> *runs, int32_t lo, int32_t hi) -> bool {
+                        if (!runs || hi - lo < n_run) return false;
+                        auto it = std::lower_bound(runs->begin(), runs->end(), lo, [](const std::pair<int32_t, int32_t> &r, int32_t x) { return r.second <= x; });
+                        for (; it != runs->end() && it->first < hi; ++it)
+                            if (std::min(it->second, hi) - std::max(it->first, lo) >= n_run) return true;
                         return false;
                     };
-                    if (!n_between(qc, a.q, b.q) && !n_between(tc, a.t, b.t)) parent[find(by_q[p2])] = find(by_q[p]);
+                    if (!n_between(nq, a.q, b.q) && !n_between(nt, a.t, b.t)) parent[find(by_q[p2])] = find(by_q[p]);
                     break;
                 }
             }
@@ -673,6 +678,8 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     const uint8_t *qc_d[2] = {nullptr, nullptr};
     std::vector<miblast_hsp> strand_hsps[2];
     std::vector<DevHsp> found[2];         // HSPs as the device found them, per strand
+    std::vector<int32_t> strand_anchor[2];  // anchor offset (k_hsp_anchor) of every entry of strand_hsps[strand], same order
+    bool anchor_mismatch = false;           // MIBLAST_CHECK_ANCHORS: the host scan found a different offset
     struct HostOut { int64_t lookups = 0, pre = 0, kept = 0; double seconds = 0; } host_out[2];
     bool defer_host = false;              // batched calls run the host half of the seed stage on worker threads
     int64_t valid_windows = -1;           // seed windows of the '+' strand without N / soft-masked bases (counter seed_lookups)
@@ -737,6 +744,8 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
         });
         // entropy filter in IEEE double on the host, like lastz (hard part H4)
         std::vector<miblast_hsp> &hs = strand_hsps[strand];
+        std::vector<int32_t> &anc = job.strand_anchor[strand];
+        anc.clear();
         for (const Key &k : order) {
             const DevHsp &d = found[k.idx];
             bool keep = true;
@@ -759,6 +768,7 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
             h.strand = strand;
             h.q_contig = Q.contig_of(d.q_start);
             hs.push_back(h);
+            anc.push_back(d.anchor_off);
         }
         // --queryhsplimit=keep,nowarn:N: the search of a query stops at N HSPs and keeps them, i.e. the first N in found
         // order per query contig and strand (repeat-masker option set, cactus_progressive_config.xml:36)
@@ -766,23 +776,24 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
             std::vector<int64_t> seen(Q.starts.size() + 1, 0);
             size_t wr = 0;
             for (size_t k = 0; k < hs.size(); k++)
-                if (seen[(size_t)hs[k].q_contig]++ < p.queryhsplimit) hs[wr++] = hs[k];
-            hs.resize(wr);
+                if (seen[(size_t)hs[k].q_contig]++ < p.queryhsplimit) { anc[wr] = anc[k]; hs[wr++] = hs[k]; }
+            hs.resize(wr); anc.resize(wr);
         }
         // --queryhspbest=N per query contig and strand: N best scores, ties to the earlier found
         if (p.queryhspbest > 0) {
             std::vector<std::vector<size_t>> by_contig(Q.starts.size());
             for (size_t k = 0; k < hs.size(); k++) by_contig[(size_t)hs[k].q_contig].push_back(k);
             std::vector<miblast_hsp> kept;
+            std::vector<int32_t> kept_anc;
             for (std::vector<size_t> &idx : by_contig) {
                 if ((int64_t)idx.size() > p.queryhspbest) {
                     std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return hs[a].score > hs[b].score; });
                     idx.resize((size_t)p.queryhspbest);
                     std::sort(idx.begin(), idx.end());
                 }
-                for (size_t k : idx) kept.push_back(hs[k]);
+                for (size_t k : idx) { kept.push_back(hs[k]); kept_anc.push_back(anc[k]); }
             }
-            hs.swap(kept);
+            hs.swap(kept); anc.swap(kept_anc);
         }
         out.kept = (int64_t)hs.size();
         out.seconds = now_s() - t_h0;
@@ -1058,6 +1069,38 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
 }
 
 
+// the runs of at least min_len N bases (code 4, soft-masked or not) of codes[0, n), as [start, end) pairs in order: chunks on the
+// worker threads, runs that cross a chunk border stitched afterwards
+static std::vector<std::pair<int32_t, int32_t>> n_runs_of(const uint8_t *codes, int64_t n, int32_t min_len) {
+    const size_t kChunk = 1 << 18, parts = (size_t)((n + (int64_t)kChunk - 1) / (int64_t)kChunk);
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> found(parts);
+    parallel_for(parts, [&](size_t c) {
+        const int64_t lo = (int64_t)c * (int64_t)kChunk, hi = std::min<int64_t>(n, lo + (int64_t)kChunk);
+        int64_t x = lo;
+        while (x < hi) {
+            // (8 bases at a time while none is an N: bit 2 set and bit 7 clear -- a separator is not an N)
+            while (x + 8 <= hi) {
+                uint64_t w; memcpy(&w, codes + x, 8);
+                if ((w & ~(w >> 5) & 0x0404040404040404ull) != 0) break;
+                x += 8;
+            }
+            while (x < hi && (codes[x] & 7u) != 4u) x++;
+            if (x >= hi) break;
+            const int64_t s = x;
+            while (x < hi && (codes[x] & 7u) == 4u) x++;
+            found[c].push_back({(int32_t)s, (int32_t)x});
+        }
+    });
+    std::vector<std::pair<int32_t, int32_t>> runs;
+    for (size_t c = 0; c < parts; c++)
+        for (const auto &r : found[c]) {
+            if (!runs.empty() && runs.back().second == r.first) runs.back().second = r.second;      // the same run on both sides of a border
+            else runs.push_back(r);
+        }
+    runs.erase(std::remove_if(runs.begin(), runs.end(), [&](const std::pair<int32_t, int32_t> &r) { return r.second - r.first < min_len; }), runs.end());
+    return runs;
+}
+
 // anchors of one pair, one unit per (query contig, strand), sorted by (-score, t, q)  
 static void build_units(const miblast_params &p, PairJob &job, int pair, std::vector<Unit> &units) {
     const SeqSet &Q = *job.Q;
@@ -1076,6 +1119,14 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
             const std::vector<miblast_hsp> &hs = strand_hsps[strand];
             std::vector<int> offs(hs.size());
             const size_t kChunk = 256;
+            // (the device computed the offsets: k_hsp_anchor.  MIBLAST_HOST_ANCHORS=1 scans on the host instead, MIBLAST_CHECK_ANCHORS=1
+            //  does both and fails on a difference)
+            const bool host_anchors = env_long("MIBLAST_HOST_ANCHORS", 0) != 0, check_anchors = env_long("MIBLAST_CHECK_ANCHORS", 0) != 0;
+            const std::vector<int32_t> &dev_offs = job.strand_anchor[strand];
+            const bool have_dev = dev_offs.size() == hs.size();
+            if (have_dev && !host_anchors) for (size_t x = 0; x < hs.size(); x++) offs[x] = dev_offs[x];
+            if (!have_dev || host_anchors || check_anchors) {
+            std::atomic<long> n_bad{0};
             parallel_for((hs.size() + kChunk - 1) / kChunk, [&](size_t c) {
                 for (size_t x = c * kChunk; x < std::min(hs.size(), (c + 1) * kChunk); x++) {
                     const miblast_hsp &h = hs[x];
@@ -1096,9 +1147,12 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                         }
                         off = bestc + 15;
                     }
+                    if (have_dev && !host_anchors && off != offs[x]) n_bad++;
                     offs[x] = off;
                 }
             });
+            if (n_bad.load()) { set_error("k_hsp_anchor disagrees with the host scan on " + std::to_string(n_bad.load()) + " HSPs"); job.anchor_mismatch = true; }
+            }
             const double t_b1 = now_s();
             for (size_t x = 0; x < hs.size(); x++)
                 per[(size_t)hs[x].q_contig].push_back(Anchor{hs[x].t_start + offs[x], hs[x].q_start + offs[x], hs[x].score});
@@ -1113,8 +1167,13 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
             t_bu[0] += t_b1 - t_b0; t_bu[1] += now_s() - t_b1;
         }
         const double t_b2 = now_s();
+        const int32_t n_run = (int32_t)std::max(8l, env_long("MIBLAST_GROUP_NRUN", p.ydrop / 100));
+        std::vector<std::pair<int32_t, int32_t>> n_t, n_q[2];
+        bool have_nq[2] = {false, false};
+        if (units.size() > first_unit) n_t = n_runs_of(tc_h, job.T->total, n_run);
         for (size_t x = first_unit; x < units.size(); x++) {
             Unit &u = units[x];
+            if (!have_nq[u.strand]) { n_q[u.strand] = n_runs_of(qc_h[u.strand], Q.total, n_run); have_nq[u.strand] = true; }
             parallel_sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
                 if (a.score != b.score) return a.score > b.score;
                 if (a.t != b.t) return a.t < b.t;
@@ -1128,8 +1187,7 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
                 for (const Anchor &a : u.anchors) { q_min = std::min(q_min, a.q); q_max = std::max(q_max, a.q); }
                 group_gap = std::min(65536l, std::max(4096l, 48l * (long)(q_max - q_min) / (long)u.anchors.size()));
             }
-            u.index_anchors((int32_t)std::max(1l, group_gap), (int32_t)env_long("MIBLAST_GROUP_TOL", 64), tc_h, qc_h[u.strand],
-                            (int32_t)std::max(8l, env_long("MIBLAST_GROUP_NRUN", p.ydrop / 100)));
+            u.index_anchors((int32_t)std::max(1l, group_gap), (int32_t)env_long("MIBLAST_GROUP_TOL", 64), &n_t, &n_q[u.strand], n_run);
         }
         t_bu[2] = now_s() - t_b2;
         if (env_long("MIBLAST_DEBUG", 0) > 1) fprintf(stderr, "[miblast]   build_units: window scan %.2f ms, distribute %.2f ms, sorts %.2f ms\n", t_bu[0] * 1e3, t_bu[1] * 1e3, t_bu[2] * 1e3);
@@ -2226,6 +2284,8 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     }
     for (; waited < host_tasks.size(); waited++) host_tasks[waited].get();
     }
+    for (size_t k = 0; k < n; k++)
+        if (jobs[k]->anchor_mismatch) { set_error("MIBLAST_CHECK_ANCHORS: k_hsp_anchor disagrees with the host scan"); return MIBLAST_EHIP; }
     for (size_t k = 0; k < n; k++) {
         for (Unit &u : jobs[k]->units) units.push_back(std::move(u));
         jobs[k]->units.clear();

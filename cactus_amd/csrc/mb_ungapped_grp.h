@@ -1,7 +1,7 @@
 // mb_ungapped_grp.h -- k_ungapped_grp: ungapped x-drop extension with EIGHT LANES PER DIAGONAL RUN (gfx950, wave64).
 // Included by mb_kernels.hip inside namespace mb (and, with MB_EMU defined, by the host-side emulation test under tests/emu).
 //
-// Rule restated (SURVEY A.4 / A.5 / A.10 UNGAPPED, oracle/lastz_oracle.c:227-262, :508-521): the hits of a diagonal are
+// Rule restated (SURVEY A.4 / A.5 / A.10 UNGAPPED and SEARCH): the hits of a diagonal are
 // taken in q order; a hit with q_end <= extent[d] is skipped; otherwise the seed end is extended to the left and to the right,
 //     run += score; if (run > best) { best = run; pos = k } else if (run < best - xdrop) stop      (the stop column is counted)
 // a contig separator ends a direction before its column; extent[d] = q_end + pos_right; score = best_left + best_right.

@@ -120,6 +120,7 @@ static void reference(const std::vector<unsigned long long> &keys, const uint8_t
             ext = q_end + br;
             if (bestL + bestR >= K) {
                 mb::DevHsp h;
+                h.anchor_off = 0;                                       // (k_hsp_anchor: not under test here)
                 h.t_start = (int32_t)(t_end - bl); h.q_start = q_end - bl; h.len = bl + br; h.score = bestL + bestR;
                 h.seed_t_end = (int32_t)t_end; h.seed_q_end = q_end;
                 for (int c = 0; c < 4; c++) h.cnt[c] = 0;
@@ -232,6 +233,7 @@ int main(int argc, char **argv) {
         }
         hsps.resize((size_t)ctr.hsps);
         hsps.erase(std::remove_if(hsps.begin(), hsps.end(), [](const mb::DevHsp &d) { return d.score == INT32_MIN; }), hsps.end());
+        for (mb::DevHsp &d : hsps) d.anchor_off = 0;
         std::sort(hsps.begin(), hsps.end(), hsp_less);
         std::sort(ref.hsps.begin(), ref.hsps.end(), hsp_less);
         bool ok = ctr.extended == ref.extended && ctr.cols == ref.cols && hsps.size() == ref.hsps.size() && extent == ref.extent;
