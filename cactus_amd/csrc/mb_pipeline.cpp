@@ -915,7 +915,10 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], 0, sort_bits, s);
                     MB_HIP(hipEventRecord(w.sev[strand][3], s));
                     MB_HIP(hipEventRecord(w.sev[strand][4], s));
-                    const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2);   // (the unsorted keys are free now)
+                    // (sized for the larger strand before the first strand's kernels are queued: growing a buffer later would free
+                    //  memory that queued kernels still use; the strand's unsorted keys are free after its sort and hold the records)
+                    if (strand == 0 || !fits[0] || !nh[0]) (void)ux_scratch(w, nullptr, (size_t)nh_max, ttot + qtot + 2);
+                    const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2);
                     launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, ttot + qtot, extent.p, p.xdrop, p.hspthresh,
                                     d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, &uxs, true, s);
                     MB_HIP(hipEventRecord(w.sev[strand][5], s));
@@ -1380,13 +1383,16 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         const int nsides = (int)pend.size() * 2;
         // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
         // anyway, longer pieces waste less on warm-up overlap.
-        // Three regimes (measured on the bench workloads, scripts/gpu_r02_sched2.sh): a lone pair (few sides) -- 640-row pieces; a
+        // Regimes (measured on the bench workloads, scripts/gpu_r02_sched2.sh, gpu_r02_s2y.sh): a lone pair (few sides) -- 640-row pieces; a
         // batch of a few pairs (the evolver phase: hundreds of sides) -- 512-row pieces, still planted together with the heads: short
         // pieces balance the launch and a rejected hand-over costs one short retry; thousands of sides -- the GPU is full anyway,
         // long pieces waste less on warm-up and relays are only spent on sides that survive relay_s0 rows (16 x 1 Mb pairs, ~600
         // sides: 66 ms per call against 75 ms with the short pieces).
         const bool crowd = nsides > 400;
-        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides > 96 ? 512 : 640;
+        // (a handful of sides -- a trimmed outgroup call of the phase: every launch runs at lone-wave speed and most hand-overs are
+        //  retried; 448-row pieces: 19 -> 17 DP launches and 10.2 -> 9.4 ms of DP kernel time per phase; 320 and 256 need more launches)
+        const long relay_s_tiny = env_long("MIBLAST_RELAY_S_TINY", 448);
+        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides > 96 ? 512 : nsides > 16 ? 640 : relay_s_tiny;
         if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
         if (relay_w_env <= 0) relay_w = crowd ? 192 : 128;
         const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: unless thousands of sides are in flight, 2: always
