@@ -1394,7 +1394,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         const long relay_s_tiny = env_long("MIBLAST_RELAY_S_TINY", 448);
         if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides > 96 ? 512 : nsides > 16 ? 640 : relay_s_tiny;
         if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
-        if (relay_w_env <= 0) relay_w = crowd ? 192 : 128;
+        // (a handful of sides: 384 warm-up rows -- most hand-overs of such a call are rejected after 128, and a retry is a launch of
+        //  its own: 17 -> 11 DP launches per phase)
+        if (relay_w_env <= 0) relay_w = crowd ? 192 : nsides > 16 ? 128 : env_long("MIBLAST_RELAY_W_TINY", 384);
         const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: unless thousands of sides are in flight, 2: always
         const bool plant_at_once = plant_env == 2 || (!crowd && plant_env != 0);
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
