@@ -187,7 +187,7 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
                   unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s);
 void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena,
                    unsigned long long arena_bytes, unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir,
-                   uint8_t *snaps, hipStream_t s);
+                   uint8_t *snaps, const int *order, hipStream_t s);      // order: piece of block b (k_ydrop2 only), or nullptr
 void launch_trace_walk(TbWalk *walks, int n, const uint8_t *arena, unsigned long long arena_bytes,
                        const unsigned long long *rowdir, uint32_t *ops, uint32_t *recs, hipStream_t s);
 void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, const uint8_t *arena, unsigned long long arena_bytes,

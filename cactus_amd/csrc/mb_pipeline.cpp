@@ -538,6 +538,7 @@ struct Workspace {                      // device buffers that persist across mi
     std::vector<std::unique_ptr<RcSlot>> rc_pool;
     // gapped
     DevBuf<DpProb> probs;
+    DevBuf<int> dp_order;                     // a crowded DP launch: piece of block b (longest first)
     DevBuf<DpOut> outs;
     DevBuf<int32_t> grows;
     DevBuf<uint8_t> arena;
@@ -652,12 +653,31 @@ static void collect_dp_time(Ctx &ctx, miblast_stats &st) {             // after 
 }
 
 static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpProb *probs, DpOut *outs, int n,
-                            const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes, bool defer = false) {
+                            const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes, bool defer = false, const DpProb *host_probs = nullptr) {
     Workspace &g = *ctx.ws;
+    // A launch with more pieces than wave slots: the blocks take the pieces longest first (counting sort by the rows a piece will
+    // run at most), so that the launch ends with short pieces instead of a long one started late.  Scheduling only.
+    const int *order = nullptr;
+    if (kernel == kDpWave2x4 && host_probs && n > 4096 && env_long("MIBLAST_DP_LPT", 1) != 0) {
+        constexpr int kBins = 256;
+        std::vector<int> bin_of((size_t)n), start(kBins + 1, 0);
+        for (int x = 0; x < n; x++) {
+            const DpProb &pr = host_probs[x];
+            const long rows = std::max(0l, (long)(pr.stop_row > 0 ? pr.stop_row : pr.nb) - (long)pr.row_lo);
+            const int b = kBins - 1 - (int)std::min<long>(kBins - 1, rows / 16);          // bin 0: the longest
+            bin_of[(size_t)x] = b; start[(size_t)b + 1]++;
+        }
+        for (int b = 0; b < kBins; b++) start[(size_t)b + 1] += start[(size_t)b];
+        std::vector<int> ord((size_t)n);
+        for (int x = 0; x < n; x++) ord[(size_t)start[(size_t)bin_of[(size_t)x]]++] = x;
+        g.dp_order.ensure((size_t)n);
+        g.stage.h2d(g.dp_order.p, ord.data(), (size_t)n * sizeof(int), ctx.stream);
+        order = g.dp_order.p;
+    }
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     if (kernel == kDpWave2x4 || kernel == kDpWave4 || kernel == kDpWave8)
         launch_ydrop1(kernel, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.arena.p, (unsigned long long)g.arena.n - 64, g.arena_next.p,
-                      blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
+                      blk_bytes, g.rowdir.p, g.snaps.p, order, ctx.stream);
     else
         launch_ydrop(kernel == kDpHbm, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
                      (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
@@ -1641,7 +1661,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 MB_HIP(hipMemset2DAsync(g.snaps.p + launched * kSnapSlots * kSnapBytes, kSnapBytes, 0, sizeof(SnapHdr), n_new * kSnapSlots, s));
                 // DP launch, hand-over checks and the copies of both results: one synchronisation.  (Checks made on pieces that
                 // turn out to need a rerun are simply made again.)
-                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true);
+                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true, probs.data() + launched);
                 launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
                 g.stage.d2h(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), s);
                 g.stage.d2h(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), s);
