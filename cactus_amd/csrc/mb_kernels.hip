@@ -739,12 +739,12 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     //   lane  k_ungapped: a run per lane (the default for sparse hit sets: the phase's 0.6 Mb pairs, where a launch is as long as
     //         its longest chain of real extensions);
     //   ux    the level-synchronous pipeline of mb_ungapped_ux.h (the default for dense hit sets: a hit per four diagonals or more and at
-    //         least 2^20 hits, where the work is chance hits);
+    //         least 2^19 hits, where the work is chance hits -- the 1 Mb pair: 0.56 against 0.69 ms);
     //   grp   k_ungapped_grp: eight lanes per run (MIBLAST_UNGAPPED=grp only).
     // MIBLAST_UNGAPPED=lane|ux|grp forces one.
     const char *fe = getenv("MIBLAST_UNGAPPED");                                  // (read per launch: the tests switch it)
     const int forced = !fe ? 0 : !strcmp(fe, "lane") ? 1 : !strcmp(fe, "ux") ? 2 : !strcmp(fe, "grp") ? 3 : 0;
-    int mode = forced ? forced : (ux && n_hits >= n_diagonals / 4 && n_hits >= (1 << 20)) ? 2 : 1;
+    int mode = forced ? forced : (ux && n_hits >= n_diagonals / 4 && n_hits >= (1 << 19)) ? 2 : 1;
     if (mode == 2 && (!ux || xdrop >= (1 << 24))) mode = 1;
     if (mode == 1) {
         const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;               // upper bound: sum over classes of ceil(runs / 256)
