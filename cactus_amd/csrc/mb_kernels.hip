@@ -3,10 +3,11 @@
 // Stage map (SURVEY.md section 8a rows a6..a10, Appendix A.10 rules):
 //   k_revcomp            '-' strand of the query set (A.1)
 //   k_index_words/_scatter + scan kernels   target seed position table, CSR over 2^24 words (A.3, row a6)
-//   k_bucket_bitmap      occupancy bitmap of the seed table (keeps most lookups in L2)
+//   k_scan_apply<true>   ... whose last scan pass also writes the occupancy bitmap of the seed table (keeps most lookups in L2)
 //   k_seed_search        seed search in one pass: 12of19 word + 12 one-transition variants -> (diagonal,q) hit keys
-//                        (A.4, row a7); k_seed_count/_fill: the two-pass fallback with exact sizes
-//   k_run_heads, k_ungapped, k_ungapped_long   per-diagonal suppression + x-drop extension, HSP emission (A.4/A.5, row a8)
+//                        (A.4, row a7); k_seed_count/_fill: the two passes with exact sizes and q-ordered keys
+//   k_run_heads, k_ungapped / k_ux_* (mb_ungapped_ux.h) / k_ungapped_grp (mb_ungapped_grp.h), k_ungapped_long, k_hsp_anchor
+//                        per-diagonal suppression + x-drop extension, HSP emission, anchors (A.4/A.5/A.6, row a8)
 //   k_ydrop2, k_ydrop1<K>   one-sided Y-drop affine DP (A.7, row a10), ONE wave per piece, previous row in registers
 //   k_ydrop<HBM,...>     the same DP with four waves per piece and the row ring in LDS or HBM (wide windows)
 //   k_verify             relay hand-over check: exit state of a piece against the entry state of the next

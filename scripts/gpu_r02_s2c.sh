@@ -1,4 +1,5 @@
 #!/bin/bash
+# (MIBLAST_UNGAPPED_WAVES and the 8-wave build it selected were dropped after this run: 49 ms with spills)
 # session 2: where does k_ungapped_grp's time go (8 Mb random pair)?  variants + one SQ counter pass
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/s2c; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the MIBLAST_UX_PROTO prototype kernel this run timed became level 1 of k_ux_extend and was removed)
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/s2d; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/scripts/gpu_rand.py 8000000"
