@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_ungapped_grp.h (the eight-lanes-per-run ungapped extension kernel) on the
+// TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_runs.h, mb_ungapped_grp.h and mb_ungapped_ux.h (run heads, the ungapped extension kernels, anchors) on the
 // HOST -- one pthread per work-item, DPP / ballot exchanged through per-wave barriers (see hip/hip_runtime.h) -- against a
 // sequential restatement of the rule (oracle/lastz_oracle.c:227-262, :508-521) on random sequence sets with planted homology,
 // separators, N bases and busy diagonals.  Nothing of this is shipped or measured.
@@ -77,6 +77,7 @@ using std::min;
 
 namespace mb {
 #include "mb_xdrop.h"
+#include "mb_runs.h"
 #include "mb_ungapped_grp.h"
 #include "mb_ungapped_ux.h"
 }  // namespace mb
@@ -120,7 +121,7 @@ static void reference(const std::vector<unsigned long long> &keys, const uint8_t
             ext = q_end + br;
             if (bestL + bestR >= K) {
                 mb::DevHsp h;
-                h.anchor_off = 0;                                       // (k_hsp_anchor: not under test here)
+                h.anchor_off = 0;                                       // (checked separately against anchor_ref)
                 h.t_start = (int32_t)(t_end - bl); h.q_start = q_end - bl; h.len = bl + br; h.score = bestL + bestR;
                 h.seed_t_end = (int32_t)t_end; h.seed_q_end = q_end;
                 for (int c = 0; c < 4; c++) h.cnt[c] = 0;
@@ -134,6 +135,20 @@ static void reference(const std::vector<unsigned long long> &keys, const uint8_t
         out.extent[dq] = ext;
         i = j;
     }
+}
+
+// the anchor rule of SURVEY A.6, column by column: middle of the best-scoring 31-column window, first on ties
+static int anchor_ref(const mb::DevHsp &h, const uint8_t *tc, const uint8_t *qc) {
+    if (h.len <= 31) return h.len / 2;
+    const uint8_t *tp = tc + h.t_start, *qp = qc + h.q_start;
+    int sum = 0;
+    for (int k = 0; k < 31; k++) sum += score_of(tp[k], qp[k]);
+    int bestsum = sum, bestc = 0;
+    for (int cc = 1; cc + 31 <= h.len; cc++) {
+        sum += score_of(tp[cc + 30], qp[cc + 30]) - score_of(tp[cc - 1], qp[cc - 1]);
+        if (sum > bestsum) { bestsum = sum; bestc = cc; }
+    }
+    return bestc + 15;
 }
 
 static bool hsp_less(const mb::DevHsp &a, const mb::DevHsp &b) {
@@ -201,6 +216,23 @@ int main(int argc, char **argv) {
             heads[off + n_heads[cls]++] = (unsigned)i;
             i = j;
         }
+        {   // the lists as k_run_heads itself makes them: the same runs in every list (their order inside a list is free)
+            std::vector<unsigned> kheads(heads.size(), 0u);
+            unsigned kn[5] = {0, 0, 0, 0, 0};
+            hipLaunchKernelGGL(mb::k_run_heads, dim3((unsigned)((n_hits + 4095) / 4096)), dim3(1024), 0, nullptr, keys.data(), n_hits, long_run, kheads.data(), kn);
+            bool same = true;
+            for (int c = 0; c < 5 && same; c++) {
+                const uint64_t off = c == 0 ? 0 : c == 1 ? n : c == 2 ? n + n / 2 : c == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
+                same = kn[c] == n_heads[c];
+                if (same) {
+                    std::vector<unsigned> x(kheads.begin() + (long)off, kheads.begin() + (long)off + kn[c]), y(heads.begin() + (long)off, heads.begin() + (long)off + n_heads[c]);
+                    std::sort(x.begin(), x.end()); std::sort(y.begin(), y.end());
+                    same = x == y;
+                }
+            }
+            if (!same) { printf("case %d: k_run_heads lists differ from the host's  MISMATCH\n", cs); bad++; continue; }
+            heads = kheads;
+        }
         std::vector<int32_t> extent = extent0;
         std::vector<mb::DevHsp> hsps((size_t)n_hits + 8);
         mb::UngappedCounters ctr = {0, 0, 0};
@@ -231,12 +263,16 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(mb::k_ux_census, dim3(1), dim3(256), 0, nullptr, tc, qc, hsps.data(), (int64_t)hsps.size(), &ctr);
             { unsigned nb = 0; for (unsigned v : blk_cnt) nb += v; printf("  ux: %u + %u of %lld hits left for the tail (block slots + list), %llu candidates, %u dirty runs\n", nb, n_entries[0], (long long)n_hits, ctr.hsps, n_entries[1]); }
         }
+        hipLaunchKernelGGL(mb::k_hsp_anchor, dim3(1), dim3(256), 0, nullptr, tc, qc, hsps.data(), (int64_t)hsps.size(), &ctr);
+        bool anchors_ok = true;
+        for (unsigned long long s = 0; s < ctr.hsps; s++)
+            if (hsps[s].score != INT32_MIN && hsps[s].anchor_off != anchor_ref(hsps[s], tc, qc)) anchors_ok = false;
         hsps.resize((size_t)ctr.hsps);
         hsps.erase(std::remove_if(hsps.begin(), hsps.end(), [](const mb::DevHsp &d) { return d.score == INT32_MIN; }), hsps.end());
         for (mb::DevHsp &d : hsps) d.anchor_off = 0;
         std::sort(hsps.begin(), hsps.end(), hsp_less);
         std::sort(ref.hsps.begin(), ref.hsps.end(), hsp_less);
-        bool ok = ctr.extended == ref.extended && ctr.cols == ref.cols && hsps.size() == ref.hsps.size() && extent == ref.extent;
+        bool ok = anchors_ok && ctr.extended == ref.extended && ctr.cols == ref.cols && hsps.size() == ref.hsps.size() && extent == ref.extent;
         for (size_t i = 0; ok && i < hsps.size(); i++) ok = memcmp(&hsps[i], &ref.hsps[i], sizeof(mb::DevHsp)) == 0;
         printf("case %d: hits %lld runs %u xdrop %d K %d  hsps %zu/%zu extended %llu/%llu cols %llu/%llu  %s\n", cs, (long long)n_hits,
                n_heads[0] + n_heads[1] + n_heads[2] + n_heads[3], xdrop, K, hsps.size(), ref.hsps.size(), ctr.extended, ref.extended, ctr.cols,

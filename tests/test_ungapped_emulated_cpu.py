@@ -1,8 +1,9 @@
-"""Ungapped extension kernels without a GPU: the product's own kernel sources (cactus_amd/csrc/mb_ungapped_grp.h -- eight lanes per
-diagonal run -- and mb_ungapped_ux.h -- the level-synchronous pipeline for dense hit sets) built for the host against the stand-in
+"""Ungapped extension kernels without a GPU: the product's own kernel sources (cactus_amd/csrc/mb_runs.h -- run heads, anchors of the
+HSPs --, mb_ungapped_grp.h -- eight lanes per diagonal run -- and mb_ungapped_ux.h -- the level-synchronous pipeline for dense hit
+sets) built for the host against the stand-in
 HIP header of tests/emu (one pthread per work-item; DPP, ballot and readlane exchanged through per-wave barriers) and compared with
 a sequential restatement of the rule of oracle/lastz_oracle.c:227-262, :508-521 (suppression per diagonal, x-drop both ways,
-counters, extent[], HSP records) on random sequence sets with planted homology, separators, N bases, busy diagonals, extents left
+counters, extent[], HSP records, run-head lists, anchor offsets) on random sequence sets with planted homology, separators, N bases, busy diagonals, extents left
 by an earlier q batch and a tiny entry list.  The GPU parity tests proper are tests/test_parity_gpu.py (whole pipeline against the
 C oracle, every kernel choice forced in turn).  The emulation is test infrastructure: libmiblast.so has no CPU path."""
 import os
