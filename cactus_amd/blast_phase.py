@@ -243,6 +243,18 @@ def invert(paf: bytes) -> bytes:
 AlignBatch = Callable[[List[Tuple[bytes, bytes]], str], List[bytes]]
 
 
+_POOL = None
+
+
+def _phase_pool():
+    """Worker threads shared by every run of the phase in this process (starting eight threads per run cost a few ms each time)."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="blast-phase")
+    return _POOL
+
+
 def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_string: Callable[[float], str], align_batch: AlignBatch,
                     trim_min_size: int = 100, trim_flanking: int = 100, on_call=None) -> Dict[str, Dict[str, bytes]]:
     """Runs every call of the phase.  genomes: event name -> FASTA bytes.  align_batch(pairs, lastz_option_string) aligns a list
@@ -254,8 +266,7 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     query_fa: Dict[int, bytes] = {}
     current: Dict[Tuple[str, str], bytes] = {}                # (node, ingroup) -> what is left of the ingroup for the next outgroup
     last_paf: Dict[Tuple[str, str], Tuple[bytes, bytes]] = {}       # (node, ingroup) -> (query FASTA, raw PAF) of the previous level
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=8)          # the chains of a level are independent jobs (numpy / the library release the GIL)
+    pool = _phase_pool()                              # the chains of a level are independent jobs (numpy / the library release the GIL)
     finished: Dict[int, object] = {}
 
     def chain_share(paf: bytes, depth: int) -> bytes:
@@ -332,5 +343,4 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         for i in sorted(idx, key=lambda i: calls[i].level):
             if i in finished:
                 result[key[0]]["outgroup"] += finished[i].result()
-    pool.shutdown()
     return result
