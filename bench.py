@@ -24,6 +24,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import queue
 import socket
 import subprocess
 import sys
@@ -120,7 +121,9 @@ class EvolverPhase:
         # phase on the MI355X, but DP launches of two streams then share the GPU and their HIP-event durations -- the roofline's
         # denominator -- no longer measure one kernel; the default keeps the kernel figures clean.)
         self.contexts = [ctx] + [miblast.Context(ctx.device) for _ in range(max(0, int(os.environ.get("MIBLAST_BENCH_CONTEXTS", "2")) - 1))]
-        self.free_contexts = list(self.contexts)
+        self.free_contexts = queue.Queue()                     # align_batch blocks on it: never more calls in flight than contexts
+        for cx in self.contexts:
+            self.free_contexts.put(cx)
         self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
                          f"examples/evolverMammals.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 2001), ingroup trimming between outgroups, "
                          "option set per call by distance (1 x \"four\", rest \"default\")")
@@ -133,26 +136,28 @@ class EvolverPhase:
         lock = threading.Lock()
 
         def align_batch(pairs, opts):
+            cx = self.free_contexts.get()
+            try:
+                with lock:
+                    pm = self.params.get(opts)
+                    if pm is None:
+                        pm = self.params[opts] = self.miblast.params_from_args(opts.split())
+                sets = []
+                for tf, qf in pairs:
+                    s = []
+                    for fa in (tf, qf):
+                        h = self.resident.get(fa)
+                        if h is None:
+                            h = cx.seqset_from_fasta_bytes(fa)
+                            with lock:
+                                made.append(h)
+                        s.append(h)
+                    sets.append(tuple(s))
+                t0 = time.perf_counter()
+                rs = cx.align_pairs(sets, pm)
+            finally:
+                self.free_contexts.put(cx)
             with lock:
-                cx = self.free_contexts.pop()
-                pm = self.params.get(opts)
-                if pm is None:
-                    pm = self.params[opts] = self.miblast.params_from_args(opts.split())
-            sets = []
-            for tf, qf in pairs:
-                s = []
-                for fa in (tf, qf):
-                    h = self.resident.get(fa)
-                    if h is None:
-                        h = cx.seqset_from_fasta_bytes(fa)
-                        with lock:
-                            made.append(h)
-                    s.append(h)
-                sets.append(tuple(s))
-            t0 = time.perf_counter()
-            rs = cx.align_pairs(sets, pm)
-            with lock:
-                self.free_contexts.append(cx)
                 add_stats(agg, [r.stats for r in rs])
             if TIMELINE:
                 print(f"[bench] align_pairs of {len(pairs)} pairs: {(time.perf_counter() - t0) * 1e3:.2f} ms (since step start {(time.perf_counter() - t_step) * 1e3:.2f}); "

@@ -17,6 +17,7 @@ Data formats either side of a call come from cactus_amd.paf.
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -27,8 +28,9 @@ from cactus_amd.paf import chunking
 # /root/reference/examples/evolverMammals.txt:1 with the internal nodes named as progressive Cactus names them
 EVOLVER_MAMMALS_TREE = ("((simHuman_chr6:0.144018,(simMouse_chr6:0.084509,simRat_chr6:0.091589)mr:0.271974)Anc1:0.020593,"
                         "(simCow_chr6:0.18908,simDog_chr6:0.16303)Anc2:0.032898)Anc0;")
-# /root/reference/examples/evolverPrimates.txt:1
-EVOLVER_PRIMATES_TREE = "(((simHuman:0.006969,simChimp:0.009727)hc:0.025291,simGorilla:0.008640)hcg:0.050000,simOrang:0.020000)root;"
+# /root/reference/examples/evolverPrimates.txt:1, verbatim (the reference names cb and hcb itself; the unnamed root becomes Anc0).
+# Every pair of this tree is closer than divergence "one" (0.05), also after the ancestor up-weighting: set "one" everywhere.
+EVOLVER_PRIMATES_TREE = "(simOrang:0.00993,((simChimp:0.00272,simHuman:0.00269)cb:0.00415,simGorilla:0.00644)hcb:0.00046);"
 
 
 @dataclass(eq=False)
@@ -313,7 +315,14 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
                     halves.append((opts, idx))
             groups = halves
         if width > 1 and len(groups) > 1:
-            results = list(pool.map(lambda g: align_batch([(genomes[calls[i].target], query_fa[i]) for i in g[1]], g[0]), groups))
+            # never more than `width` calls in flight, however many option sets (and halves) a level has: the aligner owns that
+            # many contexts and no more
+            gate = threading.BoundedSemaphore(width)
+
+            def one(g):
+                with gate:
+                    return align_batch([(genomes[calls[i].target], query_fa[i]) for i in g[1]], g[0])
+            results = list(pool.map(one, groups))
         else:
             results = [align_batch([(genomes[calls[i].target], query_fa[i]) for i in idx], opts) for opts, idx in groups]
         for (opts, idx), outs in zip(groups, results):

@@ -143,17 +143,26 @@ int miblast_set_host_threads(int n) {
 }
 
 // $MIBLAST_DEVICE_MAP = "0,0,1": logical device k is HIP ordinal map[k] (several logical devices may share a GPU)
-static std::vector<int> device_map() {
+// An entry that does not parse or names a device that is not there makes the whole map invalid (*bad): dropping it would renumber
+// the logical devices behind the caller's back.  Without any device the map is empty, valid or not (there is no CPU path to map to).
+static std::vector<int> device_map(bool *bad = nullptr) {
     std::vector<int> m;
     int n = 0;
+    if (bad) *bad = false;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
     const char *e = getenv("MIBLAST_DEVICE_MAP");
     if (e && *e) {
+        if (n <= 0) return m;
         for (const char *p = e; *p;) {
             char *end = nullptr;
             long v = strtol(p, &end, 10);
-            if (end == p) break;
-            if (v >= 0 && v < n) m.push_back((int)v);
+            if (end == p || (*end && *end != ',') || v < 0 || v >= n) {
+                if (bad) *bad = true;
+                mb::set_error(std::string("MIBLAST_DEVICE_MAP=") + e + ": every entry must be a HIP device ordinal below " + std::to_string(n));
+                m.clear();
+                return m;
+            }
+            m.push_back((int)v);
             p = *end == ',' ? end + 1 : end;
         }
         return m;
@@ -162,13 +171,19 @@ static std::vector<int> device_map() {
     return m;
 }
 
-int miblast_device_count(void) { return (int)device_map().size(); }
+int miblast_device_count(void) {
+    bool bad = false;
+    const std::vector<int> m = device_map(&bad);
+    return bad ? (int)MIBLAST_EINVAL : (int)m.size();
+}
 
 int miblast_ctx_create(int device, miblast_ctx **out) {
     if (!out) return MIBLAST_EINVAL;
     *out = nullptr;
     return guarded([&]() -> int {
-        const std::vector<int> map = device_map();
+        bool bad_map = false;
+        const std::vector<int> map = device_map(&bad_map);
+        if (bad_map) return MIBLAST_ENODEV;                         // (message set by device_map)
         if (map.empty()) {
             mb::set_error("no HIP device visible: libmiblast has no CPU path");
             return MIBLAST_ENODEV;
@@ -373,7 +388,8 @@ int miblast_multi_create(int num_gpu, miblast_multi **out) {
     if (!out) return MIBLAST_EINVAL;
     *out = nullptr;
     const int n = miblast_device_count();
-    if (n <= 0) { mb::set_error("no HIP device visible: libmiblast has no CPU path"); return MIBLAST_ENODEV; }
+    if (n < 0) return MIBLAST_ENODEV;                               // invalid $MIBLAST_DEVICE_MAP (message set)
+    if (n == 0) { mb::set_error("no HIP device visible: libmiblast has no CPU path"); return MIBLAST_ENODEV; }
     if (num_gpu < 1 || num_gpu > n) { mb::set_error("num_gpu out of range: " + std::to_string(num_gpu) + " asked, " + std::to_string(n) + " visible"); return MIBLAST_ENODEV; }
     miblast_multi *m = new (std::nothrow) miblast_multi();
     if (!m) return MIBLAST_ELIMIT;

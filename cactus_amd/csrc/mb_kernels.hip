@@ -632,7 +632,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     // n_heads: five counters
     const uint64_t n = (uint64_t)n_hits;
     unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
-    (void)hipMemsetAsync(n_heads, 0, (kRunClasses + 1) * sizeof(unsigned), s);
+    MB_HIP(hipMemsetAsync(n_heads, 0, (kRunClasses + 1) * sizeof(unsigned), s));
     hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1024 * kHeadsPerThread - 1) / (1024 * kHeadsPerThread))), dim3(1024), 0, s, keys, n_hits, kLongRun, heads,
                        n_heads);
     const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
@@ -658,10 +658,10 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
         hipLaunchKernelGGL(k_ungapped_grp<5>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
                            qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
     } else {
-        (void)hipMemsetAsync(ux->long_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s);
-        (void)hipMemsetAsync(ux->dirty_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s);
-        (void)hipMemsetAsync(ux->n_entries, 0, 2 * sizeof(unsigned), s);
-        (void)hipMemsetAsync(ux->blk_cnt, 0, 2 * (size_t)ux->n_blk * sizeof(unsigned), s);
+        MB_HIP(hipMemsetAsync(ux->long_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
+        MB_HIP(hipMemsetAsync(ux->dirty_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
+        MB_HIP(hipMemsetAsync(ux->n_entries, 0, 2 * sizeof(unsigned), s));
+        MB_HIP(hipMemsetAsync(ux->blk_cnt, 0, 2 * (size_t)ux->n_blk * sizeof(unsigned), s));
         UxScratch sc = *ux;
         sc.extent = extent; sc.extent_live = extent_clean ? 0 : 1;
         ux = &sc;
@@ -677,6 +677,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
                        tcodes, qcodes, qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
     hipLaunchKernelGGL(k_hsp_anchor, dim3(512), dim3(256), 0, s, tcodes, qcodes, hsps, hsp_cap, ctr);
+    MB_HIP(hipGetLastError());                                                   // (a launch that was refused -- grid size, LDS -- must not pass as "no HSPs")
 }
 
 // ------------------------------------------------------------------------------------------------

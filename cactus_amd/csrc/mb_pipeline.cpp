@@ -118,6 +118,9 @@ struct Stager {
         MB_HIP(hipMemcpyAsync(b, dev, n, hipMemcpyDeviceToHost, s));
         pending.push_back({host, b, n});
     }
+    // A call that ended early (a HIP failure thrown between d2h() and done(), an early return) leaves `pending` entries whose
+    // destinations were locals of frames that are gone: every entry point drops them before it queues anything.
+    void abort() { pending.clear(); used = 0; }
     void done() {                                 // the stream is idle
         for (const Out &o : pending) memcpy(o.dst, o.src, o.n);
         pending.clear();
@@ -627,6 +630,7 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
 
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions) {
     MB_HIP(hipSetDevice(ctx.device));
+    ctx.ws->stage.abort();
     Index ix;
     build_index(ctx, T, step, ix);
     Workspace &w = *ctx.ws;
@@ -2232,6 +2236,8 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
     MB_HIP(hipSetDevice(ctx.device));
     Pool::Hot keep_workers_awake;
+    ctx.ws->stage.abort();
+    for (Ctx *lane : ctx.ws->lanes) lane->ws->stage.abort();
     miblast_params p = pin;
     if (p.diag_hash16 || p.walls) {
         set_error("diag=hash16 / walls are comparison modes of the CPU oracle only -- oracle only (SURVEY A.9 #4, #8): the MI355X path implements exact "

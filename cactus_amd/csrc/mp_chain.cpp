@@ -962,6 +962,7 @@ static bool dechunk_name(std::string &name, std::string &len, long long &start) 
 int mipaf_dechunk_text(const char *paf, size_t len, int32_t query_only, char **out_text, size_t *out_len) {
     if ((!paf && len) || !out_text || !out_len) return MIBLAST_EINVAL;
     *out_text = nullptr; *out_len = 0;
+    return mb::guarded([&]() -> int {                            // (whole-genome text: bad_alloc / length_error must not cross the C ABI)
     std::string out;
     out.reserve(len + 64);
     size_t line_no = 0;
@@ -1005,12 +1006,14 @@ int mipaf_dechunk_text(const char *paf, size_t len, int32_t query_only, char **o
     buf[out.size()] = 0;
     *out_text = buf; *out_len = out.size();
     return MIBLAST_OK;
+    });
 }
 
 int mipaf_unaligned_fasta(const char *paf, size_t paf_len, const char *fasta, size_t fasta_len, int64_t min_size, int64_t flank,
                           char **out_text, size_t *out_len) {
     if ((!paf && paf_len) || (!fasta && fasta_len) || !out_text || !out_len) return MIBLAST_EINVAL;
     *out_text = nullptr; *out_len = 0;
+    return mb::guarded([&]() -> int {
     // ---- records of the FASTA text: name = first word of the header, body = the lines up to the next '>' at a line start
     struct Rec { std::string name; size_t body, body_end; int64_t len; std::vector<std::pair<int64_t, int64_t>> spans; };
     std::vector<Rec> recs;
@@ -1044,7 +1047,11 @@ int mipaf_unaligned_fasta(const char *paf, size_t paf_len, const char *fasta, si
         pos = q;
     }
     std::unordered_map<std::string, size_t> by_name;
-    for (size_t k = 0; k < recs.size(); k++) by_name.emplace(recs[k].name, k);
+    for (size_t k = 0; k < recs.size(); k++)
+        if (!by_name.emplace(recs[k].name, k).second) {            // (Cactus's inputs have unique headers: checkUniqueHeaders.py; a repeat would lose spans silently)
+            mb::set_error("to_bed: sequence name " + recs[k].name + " occurs twice in the FASTA file");
+            return MIBLAST_EINVAL;
+        }
     // ---- query intervals of the alignments
     size_t line_no = 0;
     for (size_t pos = 0; pos < paf_len;) {
@@ -1112,6 +1119,7 @@ int mipaf_unaligned_fasta(const char *paf, size_t paf_len, const char *fasta, si
     buf[out.size()] = 0;
     *out_text = buf; *out_len = out.size();
     return MIBLAST_OK;
+    });
 }
 
 void mipaf_chain_params_default(mipaf_chain_params *p) {

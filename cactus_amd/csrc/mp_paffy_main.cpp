@@ -50,6 +50,9 @@ static int delegate(char **argv, bool required = true) {
         if (dir.empty()) continue;
         const std::string cand = dir + "/paffy";
         if (access(cand.c_str(), X_OK) != 0 || !realpath(cand.c_str(), other) || !strcmp(other, self)) continue;
+        // which implementation ran must be on record: one line per process (MIPAF_QUIET=1 silences it)
+        if (const char *q = getenv("MIPAF_QUIET"); !(q && *q && strcmp(q, "0") != 0))
+            fprintf(stderr, "paffy (mipaf): `%s` handed to %s%s\n", argv[1], other, required ? "" : " (MIPAF_NATIVE=1 runs the MI355X implementation instead)");
         execv(cand.c_str(), argv);
     }
     if (!required) return -1;

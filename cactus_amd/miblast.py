@@ -148,7 +148,10 @@ def params_from_args(args) -> Params:
 
 
 def device_count() -> int:
-    return load().miblast_device_count()
+    n = load().miblast_device_count()
+    if n < 0:                                  # an invalid $MIBLAST_DEVICE_MAP is an error, not a shorter device list
+        _check(n)
+    return n
 
 
 def set_host_threads(n: int = 0) -> int:

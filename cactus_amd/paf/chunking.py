@@ -97,6 +97,8 @@ def unaligned_intervals(paf_lines, seq_lens, min_size: int):
     (name, start, end) intervals of QUERY sequence no alignment covers, at least min_size long, in sequence order.  Works on the
     alignments' query intervals (sorted and merged), not on a per-base array: a whole-genome call has a handful of records."""
     spans = {name: [] for name, _ in seq_lens}
+    if len(spans) != len(seq_lens):
+        raise ValueError("to_bed: a sequence name occurs twice in the FASTA file")
     for line in paf_lines:
         if not line.strip():
             continue

@@ -75,7 +75,7 @@ int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const cha
 typedef struct miblast_ctx miblast_ctx;
 
 /* Replaces `count_nvidia_gpus` (/root/reference/src/cactus/shared/configWrapper.py:307).      */
-int miblast_device_count(void);
+int miblast_device_count(void);                                        /* < 0: $MIBLAST_DEVICE_MAP names a device that is not there */
 /* Host threads of this process that parse, sort anchors, merge traces and format PAF beside the GPU (the calling thread
  * included).  Replaces KegAlign's `--num_threads C`, which run_lastz sets to job.cores (local_alignment.py:58): a job
  * must not occupy cores the workflow engine gave to other jobs.  n = 0: automatic = min(16, cores of the affinity mask

@@ -51,7 +51,10 @@ def test_evolver_mammals_schedule_is_appendix_d():
     assert all(c.query == "simMouse_chr6" for c in mr_mouse)                                                              # outgroup = file A, ingroup = file B (:444-448)
     assert not [c for c in calls if c.node == "Anc0" and c.kind == "outgroup"]
     prim = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_PRIMATES_TREE))
-    assert len(prim) <= 21 and all(select_lastz_params(c.distance, cfg, 0).startswith("--step=2 ") for c in prim if c.kind == "ingroup" and c.node == "hc")
+    assert open("/root/reference/examples/evolverPrimates.txt").readline().strip() == bp.EVOLVER_PRIMATES_TREE if os.path.exists("/root/reference/examples/evolverPrimates.txt") else True
+    assert [c.node for c in prim if c.kind == "ingroup"] == ["cb", "hcb", "Anc0"] and len(prim) == 9 <= 21
+    # every pair of evolverPrimates is within divergence "one" -> --step=2 ... --notransition --queryhspbest=100000
+    assert all(select_lastz_params(c.distance, cfg, 0).startswith("--step=2 ") and "--notransition" in select_lastz_params(c.distance, cfg, 0) for c in prim)
 
 
 def test_phase_driver_data_flow_with_the_oracle(olz):
@@ -154,3 +157,33 @@ def test_bench_refuses_a_wrong_world_size_and_spawns_ranks():
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
         assert p.returncode != 0 and p.stderr.count("needs a GPU") == 2 and "{" not in p.stdout
+
+
+def test_calls_in_flight_never_exceed_the_aligners_width():
+    """a level with more option-set groups than the aligner has contexts (three sets, concurrent = 2, plus the split
+    halves) must not have more than `concurrent` align_batch calls in flight."""
+    import threading
+    import time
+    tree = bp.parse_newick("((a:0.01,b:0.01)x:0.01,(c:0.09,d:0.09)y:0.01,(e:0.2,f:0.2)z:0.01)r;")
+    calls = bp.blast_phase_calls(tree, max_outgroups=0)
+    fasta = {n.iD: b">%s\nACGT\n" % n.iD.encode() for n in tree.subtree()}
+    state = {"now": 0, "peak": 0, "free": ["ctx0", "ctx1"]}
+    lock = threading.Lock()
+
+    def align_batch(pairs, opts):
+        with lock:
+            state["free"].pop()                                     # IndexError here = the bug
+            state["now"] += 1
+            state["peak"] = max(state["peak"], state["now"])
+        time.sleep(0.05)
+        with lock:
+            state["now"] -= 1
+            state["free"].append("ctx")
+        return [b"" for _ in pairs]
+
+    align_batch.concurrent = 2
+    align_batch.split_above = 1
+    opts = lambda d: "set-%d" % (0 if d < 0.05 else 1 if d < 0.3 else 2)      # noqa: E731
+    assert len({opts(c.distance) for c in calls if c.level == 0}) == 3
+    bp.run_blast_phase(fasta, calls, opts, align_batch)
+    assert state["peak"] == 2

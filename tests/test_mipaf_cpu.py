@@ -134,5 +134,11 @@ def test_front_end_dechunks_and_hands_foreign_sub_commands_to_the_next_paffy(tmp
     env = dict(os.environ, PATH=BIN_DIR + os.pathsep + str(other) + os.pathsep + os.environ.get("PATH", ""))
     p = subprocess.run(["paffy", "view", "a.fa", "b.fa", "-i", "x.paf"], capture_output=True, env=env)
     assert p.returncode == 7 and p.stdout == b"real paffy got: view a.fa b.fa -i x.paf\n"
+    assert b"`view` handed to " + os.path.realpath(other / "paffy").encode() in p.stderr          # which implementation ran is on record
+    # ... and so do the sub-commands it does provide, unless MIPAF_NATIVE=1 asks for the MI355X implementation
+    p = subprocess.run(["paffy", "chain", "-i", "x.paf"], capture_output=True, env=dict(env, MIPAF_NATIVE="0"))
+    assert p.returncode == 7 and b"`chain` handed to " in p.stderr and b"MIPAF_NATIVE=1" in p.stderr
+    p = subprocess.run(["paffy", "chain", "-i", "x.paf"], capture_output=True, env=dict(env, MIPAF_NATIVE="0", MIPAF_QUIET="1"))
+    assert p.returncode == 7 and p.stderr == b""
     p = subprocess.run([PAFFY, "to_bed", "--binary"], capture_output=True, env=dict(os.environ, PATH=BIN_DIR + os.pathsep + "/usr/bin:/bin"))
     assert p.returncode == 2 and b"no other paffy is on PATH" in p.stderr
