@@ -25,6 +25,24 @@ struct DevHsp {                               // written by the ungapped kernels
     int32_t seed_t_end, seed_q_end;
     int32_t cnt[4];
     int32_t anchor_off;                       // k_hsp_anchor: middle of the best-scoring 31-column window, first on ties
+    int32_t unit;                             // seed unit (pair, strand) of the launch the HSP belongs to; coordinates are the unit's own
+};
+
+// A seed unit = one (chunk pair, query strand) of a seed-stage launch.  The ungapped kernels work on the sorted hit keys of ALL units
+// of a launch at once: unit u owns the diagonals [dbase, dbase + ttot + qtot + 2) of the launch's diagonal space (extent[], bit
+// planes), a hit of the unit has the key (dbase + t_end - q_end + qtot) << 32 | q_end with t_end / q_end in the unit's own
+// coordinates, and the units' ranges ascend with the unit index, so the sorted keys fall into one stretch per unit.
+struct SeedUnit {
+    const uint8_t *tc, *qc;                   // position 0 of the target / of the searched strand of the query
+    int32_t qtot, ttot;                       // bases (concatenated contigs) of the query / target set
+    uint32_t dbase;                           // first diagonal of the unit
+    int32_t index;                            // batched seed search: the unit's target index (SparseIndex table)
+    int64_t qpos0;                            // batched seed search: first slot of the unit's query positions in the launch's q space
+};
+struct UnitTab {                              // by value in the kernel arguments: a launch of ONE unit never touches memory for it
+    SeedUnit one;
+    const SeedUnit *tab;
+    int32_t n;
 };
 
 struct DpProb {                               // one one-sided Y-drop DP (SURVEY A.7 ONE_SIDED)
@@ -179,8 +197,10 @@ void launch_index_clear(const uint32_t *words, int64_t n_slots, uint32_t *cursor
 void launch_scan_index(uint32_t *counts, uint32_t *offsets, unsigned long long *block_sums, uint32_t *occ, hipStream_t s);
 void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *occ, const uint32_t *positions, int transitions,
                         unsigned long long *keys, unsigned long long cap, unsigned long long *total, hipStream_t s);
-void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
-                     const uint8_t *qcodes, int64_t qtot, int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
+// ut: the seed units of the launch (one for a strand of a pair, all (pair, strand) units of a batched call); ctr: one
+// UngappedCounters per unit -- extended / cols per unit, hsps of entry 0 = the slot counter of the whole launch
+void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const UnitTab &ut,
+                     int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s);      // ux: scratch of the level-synchronous pipeline, or nullptr; extent_clean: extent[] is all zero
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
                   int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
@@ -194,6 +214,29 @@ void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, c
                        const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, hipStream_t s);
 void launch_pack_segs(const TbSeg *segs, const unsigned long long *dst, int n, const uint32_t *ops, uint32_t *packed, hipStream_t s);
 void launch_verify(const VerifyJob *jobs, VerifyOut *res, int n, const uint8_t *snaps, int Y, int E, hipStream_t s);
+// ---- batched seed stage (mb_seed_batch.h) ----
+struct BatchTarget {                          // one distinct target of the call
+    const uint8_t *codes;                     // position 0
+    int64_t n;                                // bases
+    int32_t step, pad;
+    int64_t first;                            // slot s <-> position first + s * step  (--step phase of a block of a larger file)
+    int64_t n_slots;
+    int64_t slot0;                            // first slot in words[] / positions[]
+    int64_t cbase;                            // first entry in cnt[] / starts[] / cursor[]  (n_slots + 1 entries)
+    int64_t blk0;                             // first block of the per-slot kernels (256 slots per block)
+};
+constexpr int kBxWordsPerTarget = 1 << 18;    // 64-bit words of a target's bucket bitmap
+constexpr int kBxDirBlocks = 128;             // blocks per target of k_bx_popc / k_bx_dir: 2048 bitmap words each
+
+constexpr int kBsTile = 2048;                 // a unit's share of the q space of a batched seed search is a whole number of scan tiles
+void launch_batch_index(const BatchTarget *tg, int n_targets, int64_t slot_blocks, int64_t n_cnt, uint32_t *words, unsigned long long *bits,
+                        uint32_t *dir, uint32_t *bsum, uint32_t *cnt, uint32_t *starts, unsigned long long *scan_sums, uint32_t *positions, hipStream_t s);
+void launch_batch_seed_count(const SeedUnit *units, int n_units, const BatchTarget *tg, const unsigned long long *bits, const uint32_t *dir,
+                             const uint32_t *starts, int transitions, int64_t q_slots, uint32_t *qcnt, uint32_t *hit_off, unsigned long long *scan_sums,
+                             hipStream_t s);
+void launch_batch_seed_fill(const SeedUnit *units, int n_units, const BatchTarget *tg, const unsigned long long *bits, const uint32_t *dir,
+                            const uint32_t *starts, const uint32_t *positions, int transitions, int64_t q_slots, const uint32_t *hit_off,
+                            unsigned long long *keys, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int begin_bit, int end_bit,
                hipStream_t s);

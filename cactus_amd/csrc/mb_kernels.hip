@@ -25,22 +25,9 @@
 namespace mb {
 
 #include "mb_xdrop.h"
+#include "mb_units.h"
 
-__device__ __forceinline__ bool window_word(const uint8_t *codes, int64_t p, uint32_t &word) {
-    // care offsets of 1110100110010101111
-    unsigned bad = 0;
-    uint32_t w = 0;
-#pragma unroll
-    for (int k = 0; k < kSeedSpan; k++) {
-        unsigned c = codes[p + k];
-        bad |= c;                                  // any code >= 4 (N, lowercase bit 3, separator) sets bits 2..7
-        const bool care = (k == 0 || k == 1 || k == 2 || k == 4 || k == 7 || k == 8 || k == 11 || k == 13 || k == 15 ||
-                           k == 16 || k == 17 || k == 18);
-        if (care) w = (w << 2) | (c & 3u);
-    }
-    word = w;
-    return (bad & 0xFCu) == 0;
-}
+#include "mb_seedword.h"
 
 // Pointers read from a table in memory are generic for the compiler: it then emits FLAT loads and, because those may
 // complete out of order with LDS, waits for every outstanding memory operation around them.  The sequence pointers of
@@ -296,11 +283,6 @@ void launch_scan_index(uint32_t *counts, uint32_t *offsets, unsigned long long *
 
 // ------------------------------------------------------------------------------------------------
 // seed search
-__device__ __forceinline__ uint32_t variant_word(uint32_t w, int v) {
-    // v = 0 exact ; v = 1..12 transition (xor 2) at care position v-1, first care base most significant
-    return v == 0 ? w : (w ^ (2u << (2 * (kSeedWeight - v))));
-}
-
 // (count and fill ask the 2 MiB occupancy bitmap before the 64 MiB offset table, like k_seed_search: most lookups of a sparse
 //  table end in L2)
 __global__ void k_seed_count(const uint8_t *__restrict__ qcodes, int64_t qn, const uint32_t *__restrict__ offsets,
@@ -406,6 +388,46 @@ void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *off
                        transitions ? 1 + kSeedWeight : 1, keys, cap, total);
 }
 
+// ---- the seed stage of all pairs of a call in shared launches (mb_seed_batch.h) ------------------------------------------------
+#include "mb_seed_batch.h"
+
+// sparse seed position tables of the n_targets distinct targets of a call.  bits / dir: n_targets x 2^18 entries; words, positions:
+// one entry per slot; cnt, starts: n_cnt = slots + n_targets entries (cnt is scratch and ends as the zeroed cursor array);
+// bsum: n_targets x 128; scan_sums: ceil(n_cnt / 2048) + 2
+void launch_batch_index(const BatchTarget *tg, int n_targets, int64_t slot_blocks, int64_t n_cnt, uint32_t *words, unsigned long long *bits,
+                        uint32_t *dir, uint32_t *bsum, uint32_t *cnt, uint32_t *starts, unsigned long long *scan_sums, uint32_t *positions, hipStream_t s) {
+    MB_HIP(hipMemsetAsync(bits, 0, (size_t)n_targets * kBxWordsPerTarget * 8, s));
+    MB_HIP(hipMemsetAsync(cnt, 0, (size_t)n_cnt * 4, s));
+    if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_words, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits);
+    hipLaunchKernelGGL(k_bx_popc, dim3((unsigned)(n_targets * kBxDirBlocks)), dim3(256), 0, s, bits, bsum);
+    hipLaunchKernelGGL(k_bx_dir, dim3((unsigned)(n_targets * kBxDirBlocks)), dim3(256), 0, s, bits, bsum, dir);
+    if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_count, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits, dir, cnt);
+    launch_scan_u32(cnt, starts, n_cnt, scan_sums, s);
+    MB_HIP(hipMemsetAsync(cnt, 0, (size_t)n_cnt * 4, s));
+    if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_scatter, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits, dir, starts, cnt, positions);
+    MB_HIP(hipGetLastError());
+}
+
+// hits per query slot of every unit (q_slots = the launch's q space, a multiple of 2048), then their exclusive scan -> hit_off;
+// scan_sums[k] = hits before tile k (2048 slots), scan_sums[q_slots / 2048] = all hits
+void launch_batch_seed_count(const SeedUnit *units, int n_units, const BatchTarget *tg, const unsigned long long *bits, const uint32_t *dir,
+                             const uint32_t *starts, int transitions, int64_t q_slots, uint32_t *qcnt, uint32_t *hit_off, unsigned long long *scan_sums,
+                             hipStream_t s) {
+    if (q_slots <= 0) return;
+    hipLaunchKernelGGL(k_bs_count, dim3((unsigned)(q_slots / 256)), dim3(256), 0, s, units, n_units, tg, bits, dir, starts, transitions ? 1 + kSeedWeight : 1, qcnt);
+    launch_scan_u32(qcnt, hit_off, q_slots, scan_sums, s);
+    MB_HIP(hipGetLastError());
+}
+
+void launch_batch_seed_fill(const SeedUnit *units, int n_units, const BatchTarget *tg, const unsigned long long *bits, const uint32_t *dir,
+                            const uint32_t *starts, const uint32_t *positions, int transitions, int64_t q_slots, const uint32_t *hit_off,
+                            unsigned long long *keys, hipStream_t s) {
+    if (q_slots <= 0) return;
+    hipLaunchKernelGGL(k_bs_fill, dim3((unsigned)(q_slots / 256)), dim3(256), 0, s, units, n_units, tg, bits, dir, starts, positions,
+                       transitions ? 1 + kSeedWeight : 1, hit_off, keys);
+    MB_HIP(hipGetLastError());
+}
+
 size_t sort_keys_temp_bytes(int64_t n, int end_bit) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0,
@@ -430,10 +452,11 @@ void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned l
 
 __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__restrict__ keys, int64_t n_hits,
                                                   const unsigned *__restrict__ heads, const unsigned *__restrict__ n_heads_p,
-                                                  const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, int64_t qtot,
+                                                  const UnitTab ut,
                                                   int32_t *__restrict__ extent, int xdrop, int K, DevHsp *__restrict__ hsps,
                                                   int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     unsigned long long n_ext = 0, n_cols = 0;
+    int my_unit = 0;
     // The blocks are dealt to the run-length classes, longest runs first (they start early, and a wave holds runs of similar
     // length instead of waiting for its longest lane): class c owns ceil(n_c / 256) blocks.
     unsigned n_heads = 0;
@@ -459,11 +482,14 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
         int64_t k = heads[h];
         unsigned long long key = keys[k];
         const uint32_t dq = (uint32_t)(key >> 32);
+        const UnitRef un = unit_of(ut, dq);
+        const uint8_t *tc = un.tc, *qc = un.qc;
+        my_unit = un.id;
         int32_t ext = extent[dq];
         while (true) {
             const int32_t q_end = (int32_t)(uint32_t)key;
             if (q_end > ext) {
-                const int64_t t_end = (int64_t)dq - qtot + q_end;
+                const int64_t t_end = (int64_t)dq - un.qoff + q_end;
                 // Separators (0xFF) bound every contig on both sides; device buffers carry kDevPad pad bytes, so the
                 // 8-byte loads may overrun harmlessly.  Left covers the seed, then beyond; right starts at the seed end.
                 int bestL, bl, bestR, br;
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
                 ext = q_end + br;
                 const int score = bestL + bestR;
                 if (score >= K) {
-                    const unsigned long long slot = atomicAdd(&ctr->hsps, 1ull);
+                    const unsigned long long slot = atomicAdd(&ctr->hsps, 1ull);      // (the slot counter of the launch: unit 0's)
                     if ((int64_t)slot < hsp_cap) {
                         DevHsp hs;
                         hs.t_start = (int32_t)(t_end - bl);
@@ -486,6 +512,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
                         hs.score = score;
                         hs.seed_t_end = (int32_t)t_end;
                         hs.seed_q_end = q_end;
+                        hs.unit = un.id;
                         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
                         for (int kk = 0; kk < hs.len; kk += 8) {          // identical-base census, 8 columns per load
                             const unsigned long long a8 = load8(tc + hs.t_start + kk), b8 = load8(qc + hs.q_start + kk);
@@ -509,8 +536,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
         }
         extent[dq] = ext;
     }
-    for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_cols += __shfl_down(n_cols, o); }
-    if ((threadIdx.x & 63) == 0 && (n_ext | n_cols)) { atomicAdd(&ctr->extended, n_ext); atomicAdd(&ctr->cols, n_cols); }
+    unit_count(ctr, my_unit, n_ext, n_cols);
 }
 
 // ---- wave-per-run variant for busy diagonals --------------------------------------------------------------------
@@ -550,7 +576,7 @@ __device__ __forceinline__ void xdrop_dir_wave(const uint8_t *__restrict__ tp, c
 
 __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long *__restrict__ keys, int64_t n_hits,
                                                        const unsigned *__restrict__ heads, const unsigned *__restrict__ n_heads_p,
-                                                       const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, int64_t qtot,
+                                                       const UnitTab ut,
                                                        int32_t *__restrict__ extent, int xdrop, int K, DevHsp *__restrict__ hsps,
                                                        int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     const int lane = threadIdx.x & 63;
@@ -560,6 +586,8 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
     unsigned long long n_ext = 0, n_cols = 0;
     int64_t k0 = heads[h];
     const uint32_t dq = (uint32_t)(keys[k0] >> 32);
+    const UnitRef un = unit_of(ut, dq);                              // (one run per wave: uniform)
+    const uint8_t *tc = un.tc, *qc = un.qc;
     int32_t ext = extent[dq];
     bool run_done = false;
     while (!run_done) {
@@ -575,7 +603,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
             if (!todo) break;
             const int l = (int)__ffsll((long long)todo) - 1;            // next hit that is not inside an extended stretch
             const int32_t q_end = (int32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l);
-            const int64_t t_end = (int64_t)dq - qtot + q_end;
+            const int64_t t_end = (int64_t)dq - un.qoff + q_end;
             int bestL, bl, bestR, br;
             xdrop_dir_wave<-1>(tc + t_end, qc + q_end, xdrop, lane, bestL, bl, n_cols);
             xdrop_dir_wave<+1>(tc + t_end, qc + q_end, xdrop, lane, bestR, br, n_cols);
@@ -599,6 +627,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
                         hs.t_start = t_start; hs.q_start = q_start; hs.len = len; hs.score = score;
                         hs.seed_t_end = (int32_t)t_end; hs.seed_q_end = q_end;
                         hs.cnt[0] = c0; hs.cnt[1] = c1; hs.cnt[2] = c2; hs.cnt[3] = c3;
+                        hs.unit = un.id;
                         hsps[slot] = hs;
                     }
                 }
@@ -610,8 +639,8 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
     }
     if (lane == 0) {
         extent[dq] = ext;
-        atomicAdd(&ctr->extended, n_ext);
-        atomicAdd(&ctr->cols, n_cols);
+        atomicAdd(&ctr[un.id].extended, n_ext);
+        atomicAdd(&ctr[un.id].cols, n_cols);
     }
 }
 
@@ -621,8 +650,8 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
 // ---- level-synchronous pipeline for dense hit sets ------------------------------------------------------------------
 #include "mb_ungapped_ux.h"
 
-void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const uint8_t *tcodes,
-                     const uint8_t *qcodes, int64_t qtot, int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
+void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const UnitTab &ut,
+                     int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s) {
     if (n_hits <= 0) return;
     // runs longer than this go to the wave-per-run kernel: a few times the chance hits a diagonal holds on average
@@ -649,14 +678,14 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     if (mode == 2 && (!ux || xdrop >= (1 << 24))) mode = 1;
     if (mode == 1) {
         const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;               // upper bound: sum over classes of ceil(runs / 256)
-        hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
-                           qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+        hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, ut,
+                           extent, xdrop, K, hsps, hsp_cap, ctr);
     } else if (mode == 3) {
         // the groups are persistent: at most MIBLAST_UNGAPPED_BLOCKS blocks of 32 groups walk the runs in a strided order
         static const int64_t grp_blocks = [] { const char *e = getenv("MIBLAST_UNGAPPED_BLOCKS"); return e ? std::max(1, atoi(e)) : 4096; }();
         const int64_t blocks = std::min<int64_t>((n_hits + 31) / 32, grp_blocks); // (a run has at least one hit)
-        hipLaunchKernelGGL(k_ungapped_grp<5>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, tcodes, qcodes,
-                           qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
+        hipLaunchKernelGGL(k_ungapped_grp<5>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, ut,
+                           extent, xdrop, K, hsps, hsp_cap, ctr);
     } else {
         MB_HIP(hipMemsetAsync(ux->long_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
         MB_HIP(hipMemsetAsync(ux->dirty_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
@@ -666,17 +695,17 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
         sc.extent = extent; sc.extent_live = extent_clean ? 0 : 1;
         ux = &sc;
         hipLaunchKernelGGL(k_ux_mark_long, dim3((unsigned)((max_long + 255) / 256)), dim3(256), 0, s, keys, heads_long, n_heads + kRunClasses, ux->long_bits);
-        hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, tcodes, qcodes, qtot,
+        hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, ut,
                            xdrop, K, *ux, hsps, hsp_cap, ctr);
         const unsigned tail_blocks = (unsigned)std::min<int64_t>(2048, ((int64_t)ux->entry_cap + 2 * (int64_t)ux->n_blk + 31) / 32);
-        hipLaunchKernelGGL(k_ux_tail, dim3(tail_blocks), dim3(256), 0, s, keys, n_hits, tcodes, qcodes, qtot, xdrop, K, *ux, hsps, hsp_cap, ctr);
-        hipLaunchKernelGGL(k_ux_accept, dim3((unsigned)std::min<int64_t>(4096, (n_hits + 255) / 256)), dim3(256), 0, s, keys, n_hits, extent, *ux, hsps, ctr);
-        hipLaunchKernelGGL(k_ux_resolve, dim3(256), dim3(256), 0, s, keys, n_hits, extent, *ux, hsps, ctr);
-        hipLaunchKernelGGL(k_ux_census, dim3(256), dim3(256), 0, s, tcodes, qcodes, hsps, hsp_cap, ctr);
+        hipLaunchKernelGGL(k_ux_tail, dim3(tail_blocks), dim3(256), 0, s, keys, n_hits, ut, xdrop, K, *ux, hsps, hsp_cap, ctr);
+        hipLaunchKernelGGL(k_ux_accept, dim3((unsigned)std::min<int64_t>(4096, (n_hits + 255) / 256)), dim3(256), 0, s, keys, n_hits, ut, extent, *ux, hsps, ctr);
+        hipLaunchKernelGGL(k_ux_resolve, dim3(256), dim3(256), 0, s, keys, n_hits, ut, extent, *ux, hsps, ctr);
+        hipLaunchKernelGGL(k_ux_census, dim3(256), dim3(256), 0, s, ut, hsps, hsp_cap, ctr);
     }
     hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
-                       tcodes, qcodes, qtot, extent, xdrop, K, hsps, hsp_cap, ctr);
-    hipLaunchKernelGGL(k_hsp_anchor, dim3(512), dim3(256), 0, s, tcodes, qcodes, hsps, hsp_cap, ctr);
+                       ut, extent, xdrop, K, hsps, hsp_cap, ctr);
+    hipLaunchKernelGGL(k_hsp_anchor, dim3(512), dim3(256), 0, s, ut, hsps, hsp_cap, ctr);
     MB_HIP(hipGetLastError());                                                   // (a launch that was refused -- grid size, LDS -- must not pass as "no HSPs")
 }
 

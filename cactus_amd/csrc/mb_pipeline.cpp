@@ -539,6 +539,12 @@ struct Workspace {                      // device buffers that persist across mi
     Stager stage;
     struct RcSlot { DevBuf<uint8_t> d; PinBuf<uint8_t> h; };        // '-' strands of pairs 1.. of a batched call (device + pinned host copy)
     std::vector<std::unique_ptr<RcSlot>> rc_pool;
+    // batched seed stage (seed_phase_batched): sparse tables of the call's distinct targets, unit tables, per-unit counters
+    DevBuf<unsigned long long> bx_bits, bx_scan;
+    DevBuf<uint32_t> bx_dir, bx_bsum, bx_words, bx_cnt, bx_starts, bx_positions;
+    DevBuf<BatchTarget> bx_targets;
+    DevBuf<SeedUnit> bx_units;
+    PinBuf<unsigned long long> pin_scan;
     // gapped
     DevBuf<DpProb> probs;
     DevBuf<int> dp_order;                     // a crowded DP launch: piece of block b (longest first)
@@ -710,6 +716,15 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     std::vector<Unit> units;              // anchors of this pair (merged into the call's unit list in pair order)
     double t_begin = 0;
 };
+
+// a launch of the ungapped kernels over ONE seed unit: a strand of a pair (the table lives in the kernel arguments)
+static UnitTab one_unit(const uint8_t *tc, const uint8_t *qc, int64_t ttot, int64_t qtot) {
+    UnitTab ut;
+    memset(&ut, 0, sizeof ut);
+    ut.one.tc = tc; ut.one.qc = qc; ut.one.ttot = (int32_t)ttot; ut.one.qtot = (int32_t)qtot;
+    ut.tab = nullptr; ut.n = 1;
+    return ut;
+}
 
 // scratch of the level-synchronous ungapped pipeline for nh hits; rec = nh free 8-byte slots (the strand's unsorted keys)
 static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, int64_t n_diagonals) {
@@ -943,7 +958,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     //  memory that queued kernels still use; the strand's unsorted keys are free after its sort and hold the records)
                     if (strand == 0 || !fits[0] || !nh[0]) (void)ux_scratch(w, nullptr, (size_t)nh_max, ttot + qtot + 2);
                     const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2);
-                    launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, ttot + qtot, extent.p, p.xdrop, p.hspthresh,
+                    launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, extent.p, p.xdrop, p.hspthresh,
                                     d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, &uxs, true, s);
                     MB_HIP(hipEventRecord(w.sev[strand][5], s));
                     MB_HIP(hipMemcpyAsync(w.pin_ctr.p + strand, d_ctr.p + strand, sizeof(UngappedCounters), hipMemcpyDeviceToHost, s));
@@ -1006,7 +1021,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
             const UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2);               // (the unsorted keys are free now)
-            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, T.dev(), qc_d[strand], qtot, ttot + qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
+            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, &uxs, found.empty() && strand_hits[strand] == nh, s);     // (extent[] is all zero in the first batch only)
             MB_HIP(hipEventRecord(ctx.ev4, s));
             UngappedCounters hc;
@@ -1095,6 +1110,216 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     return MIBLAST_OK;
 }
 
+
+static void build_units(const miblast_params &p, PairJob &job, int pair, std::vector<Unit> &units);
+
+// ---- the seed stage of ALL pairs of a call in shared launches -----------------------------------------------------------------------
+// One sparse seed table per distinct target, one seed search over every (pair, strand) unit, ONE sort of all hit keys by diagonal,
+// one launch of the ungapped kernels, two synchronisations per call (hit totals; counters + HSPs) -- instead of ~25 launches and three
+// synchronisations per pair.  The pairs of a call are independent jobs (/root/reference/src/cactus/paf/local_alignment.py:395-405):
+// a unit's hits, diagonals and counters never meet another unit's (SeedUnit, mb_common.h), so the results are, pair by pair, those
+// of separate calls.  handled = false: the call does not fit this path (too many hits for one key buffer, coordinates beyond 32
+// bits) and goes pair by pair through seed_phase.
+static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, bool &handled) {
+    handled = false;
+    hipStream_t s = ctx.stream;
+    Workspace &w = *ctx.ws;
+    const size_t n = jobs.size();
+    const double t_begin = now_s();
+    // ---- does the call fit?  diagonals and q slots of all units in 31 bits, a bounded number of tables
+    int64_t n_diag = 0, q_slots = 0;
+    for (size_t k = 0; k < n; k++) {
+        const SeqSet &T = *jobs[k]->T, &Q = *jobs[k]->Q;
+        if (T.device != ctx.device || Q.device != ctx.device) { set_error("sequence set lives on another device"); return MIBLAST_EINVAL; }
+        if (T.total + Q.total + 4 >= (int64_t)0x7fffffff) return MIBLAST_OK;                 // (seed_phase reports it)
+        n_diag += 2 * (T.total + Q.total + 2);
+        q_slots += 2 * ((Q.total + kBsTile - 1) / kBsTile * kBsTile);
+    }
+    if (n_diag >= (int64_t)0x7fffffff || q_slots >= (int64_t)0x7fffffff) return MIBLAST_OK;
+    std::vector<const SeqSet *> targets;
+    std::vector<int> target_of(n);
+    for (size_t k = 0; k < n; k++) {
+        size_t t = 0;
+        while (t < targets.size() && targets[t] != jobs[k]->T) t++;
+        if (t == targets.size()) targets.push_back(jobs[k]->T);
+        target_of[k] = (int)t;
+    }
+    if (targets.size() > (size_t)env_long("MIBLAST_BATCH_TARGETS", 64)) return MIBLAST_OK;
+    const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
+
+    // ---- tables
+    std::vector<BatchTarget> tg(targets.size());
+    int64_t slots = 0, blocks = 0;
+    for (size_t t = 0; t < targets.size(); t++) {
+        const SeqSet &T = *targets[t];
+        BatchTarget &g = tg[t];
+        memset(&g, 0, sizeof g);
+        g.codes = T.dev(); g.n = T.total; g.step = p.step;
+        g.first = (p.step - T.origin % p.step) % p.step;                                      // (a block of a larger file keeps the file's --step phase)
+        g.n_slots = T.total > g.first ? (T.total - g.first + p.step - 1) / p.step : 0;
+        g.slot0 = slots; g.cbase = slots + (int64_t)t; g.blk0 = blocks;
+        slots += g.n_slots; blocks += (g.n_slots + 255) / 256;
+    }
+    const int64_t n_cnt = slots + (int64_t)targets.size();
+    if (n_cnt >= (int64_t)0x7fffffff) return MIBLAST_OK;
+    std::vector<SeedUnit> units(2 * n);
+    {
+        int64_t d0 = 0, q0 = 0;
+        for (size_t k = 0; k < n; k++)
+            for (int strand = 0; strand < 2; strand++) {
+                SeedUnit &u = units[2 * k + (size_t)strand];
+                memset(&u, 0, sizeof u);
+                u.qtot = (int32_t)jobs[k]->Q->total; u.ttot = (int32_t)jobs[k]->T->total;
+                u.dbase = (uint32_t)d0; u.index = target_of[k]; u.qpos0 = q0;
+                d0 += jobs[k]->T->total + jobs[k]->Q->total + 2;
+                q0 += (jobs[k]->Q->total + kBsTile - 1) / kBsTile * kBsTile;
+            }
+    }
+    handled = true;
+    for (size_t k = 0; k < n; k++) { memset(&jobs[k]->res->stats, 0, sizeof(miblast_stats)); jobs[k]->t_begin = t_begin; }
+
+    // ---- '-' strands (device + pinned host copy: discovery order, anchors, '='/'X' classification read it)
+    for (size_t k = 0; k < n; k++) {
+        PairJob &job = *jobs[k];
+        const SeqSet &T = *job.T, &Q = *job.Q;
+        const int64_t qtot = Q.total;
+        DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : *job.slot_rc;
+        d_rc.ensure((size_t)qtot + 2 * kDevPad);
+        MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
+        launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
+        PinBuf<uint8_t> &h_rc = job.use_ws_rc ? w.h_rc : *job.slot_h_rc;
+        h_rc.ensure((size_t)qtot + 2);
+        MB_HIP(hipMemcpyAsync(h_rc.p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
+        job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc.p + 1;
+        job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
+        job.strand_hsps[0].clear(); job.strand_hsps[1].clear();
+        for (int strand = 0; strand < 2; strand++) { units[2 * k + (size_t)strand].tc = T.dev(); units[2 * k + (size_t)strand].qc = job.qc_d[strand]; }
+    }
+
+    // ---- seed tables of the distinct targets
+    w.bx_bits.ensure(targets.size() * (size_t)kBxWordsPerTarget); w.bx_dir.ensure(targets.size() * (size_t)kBxWordsPerTarget);
+    w.bx_bsum.ensure(targets.size() * (size_t)kBxDirBlocks);
+    w.bx_words.ensure((size_t)std::max<int64_t>(1, slots)); w.bx_positions.ensure((size_t)std::max<int64_t>(1, slots));
+    w.bx_cnt.ensure((size_t)n_cnt + 8); w.bx_starts.ensure((size_t)n_cnt + 8);
+    const int64_t scan_tiles = std::max((n_cnt + kBsTile - 1) / kBsTile, q_slots / kBsTile) + 2;
+    w.bx_scan.ensure((size_t)scan_tiles);
+    w.bx_targets.ensure(tg.size()); w.bx_units.ensure(units.size());
+    w.stage.h2d(w.bx_targets.p, tg.data(), tg.size() * sizeof(BatchTarget), s);
+    w.stage.h2d(w.bx_units.p, units.data(), units.size() * sizeof(SeedUnit), s);
+    for (hipEvent_t &e : w.sev[0]) if (!e) MB_HIP(hipEventCreate(&e));
+    MB_HIP(hipEventRecord(w.sev[0][0], s));
+    launch_batch_index(w.bx_targets.p, (int)tg.size(), blocks, n_cnt, w.bx_words.p, w.bx_bits.p, w.bx_dir.p, w.bx_bsum.p, w.bx_cnt.p, w.bx_starts.p, w.bx_scan.p,
+                       w.bx_positions.p, s);
+    MB_HIP(hipEventRecord(w.sev[0][1], s));
+
+    // ---- hits per query position of every unit, their scan; the tile totals come back
+    const int64_t n_tiles = q_slots / kBsTile;
+    w.qcnt.ensure((size_t)std::max<int64_t>(1, q_slots)); w.hit_off.ensure((size_t)std::max<int64_t>(1, q_slots));
+    w.pin_scan.ensure((size_t)n_tiles + 2);
+    launch_batch_seed_count(w.bx_units.p, (int)units.size(), w.bx_targets.p, w.bx_bits.p, w.bx_dir.p, w.bx_starts.p, p.transitions, q_slots, w.qcnt.p, w.hit_off.p,
+                            w.bx_scan.p, s);
+    MB_HIP(hipEventRecord(w.sev[0][2], s));
+    unsigned long long total = 0;
+    if (q_slots > 0) {
+        MB_HIP(hipMemcpyAsync(w.pin_scan.p, w.bx_scan.p, ((size_t)n_tiles + 1) * 8, hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));                                           // (1) hits of every unit
+        total = w.pin_scan.p[n_tiles];
+    } else {
+        MB_HIP(hipStreamSynchronize(s));
+    }
+    const double t_index = now_s() - t_begin;
+    if (total > (unsigned long long)hit_cap || total >= (1ull << 31)) { handled = false; return MIBLAST_OK; }      // q batches: the per-pair path has them
+    std::vector<unsigned long long> unit_hits(units.size(), 0);
+    for (size_t u = 0; u < units.size(); u++) {
+        const unsigned long long lo = w.pin_scan.p[units[u].qpos0 / kBsTile];
+        const unsigned long long hi = u + 1 < units.size() ? w.pin_scan.p[units[u + 1].qpos0 / kBsTile] : total;
+        unit_hits[u] = hi - lo;
+    }
+
+    // ---- keys, ONE sort by diagonal (k_bs_fill writes a unit's keys in q order, the units in order), ungapped extension of all units
+    std::vector<UngappedCounters> hc(units.size());
+    size_t n_found = 0;
+    float ms_fill = 0, ms_sort = 0, ms_ung = 0, ms_index = 0, ms_count = 0;
+    if (total) {
+        const size_t nh = (size_t)total;
+        w.keys_a.ensure(nh); w.keys_b.ensure(nh);
+        w.hsps.ensure(nh);
+        w.heads.ensure(2 * nh + nh / 4 + 64); w.n_heads.ensure(8);
+        const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(n_diag + 2))));
+        const size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
+        w.sort_temp.ensure(tb + 16);
+        w.extent.ensure((size_t)n_diag + 2);
+        w.ctr.ensure(units.size());
+        MB_HIP(hipMemsetAsync(w.extent.p, 0, ((size_t)n_diag + 2) * 4, s));
+        MB_HIP(hipMemsetAsync(w.ctr.p, 0, units.size() * sizeof(UngappedCounters), s));
+        (void)ux_scratch(w, nullptr, nh, n_diag + 2);                               // (sized before anything is queued)
+        MB_HIP(hipEventRecord(w.sev[0][3], s));
+        launch_batch_seed_fill(w.bx_units.p, (int)units.size(), w.bx_targets.p, w.bx_bits.p, w.bx_dir.p, w.bx_starts.p, w.bx_positions.p, p.transitions, q_slots,
+                               w.hit_off.p, w.keys_a.p, s);
+        MB_HIP(hipEventRecord(w.sev[0][4], s));
+        sort_keys(w.sort_temp.p, tb, w.keys_a.p, w.keys_b.p, (int64_t)nh, env_long("MIBLAST_SORT_DIAG_ONLY", 1) != 0 ? 32 : 0, sort_bits, s);
+        MB_HIP(hipEventRecord(w.sev[0][5], s));
+        const UxScratch uxs = ux_scratch(w, w.keys_a.p, nh, n_diag + 2);            // (the unsorted keys are free now)
+        UnitTab ut;
+        ut.one = units[0]; ut.tab = w.bx_units.p; ut.n = (int32_t)units.size();
+        launch_ungapped(w.keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, ut, n_diag, w.extent.p, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, w.ctr.p, &uxs, true, s);
+        MB_HIP(hipEventRecord(ctx.ev0, s));
+        constexpr size_t kBlind = 1 << 16;                                          // HSPs copied back before their number is known
+        w.pin_ctr.ensure(units.size());
+        w.pin_hsps.ensure(kBlind);
+        const size_t blind = std::min(kBlind, nh);
+        MB_HIP(hipMemcpyAsync(w.pin_ctr.p, w.ctr.p, units.size() * sizeof(UngappedCounters), hipMemcpyDeviceToHost, s));
+        MB_HIP(hipMemcpyAsync(w.pin_hsps.p, w.hsps.p, blind * sizeof(DevHsp), hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));                                           // (2) counters + HSPs
+        for (size_t u = 0; u < units.size(); u++) hc[u] = w.pin_ctr.p[u];
+        n_found = (size_t)hc[0].hsps;                                              // (the slot counter of the launch)
+        if (n_found > nh) { set_error("HSP buffer overflow"); return MIBLAST_ELIMIT; }
+        MB_HIP(hipEventElapsedTime(&ms_fill, w.sev[0][3], w.sev[0][4]));
+        MB_HIP(hipEventElapsedTime(&ms_sort, w.sev[0][4], w.sev[0][5]));
+        MB_HIP(hipEventElapsedTime(&ms_ung, w.sev[0][5], ctx.ev0));
+        std::vector<DevHsp> rest;
+        if (n_found > blind) {
+            rest.resize(n_found - blind);
+            MB_HIP(hipMemcpy(rest.data(), w.hsps.p + blind, rest.size() * sizeof(DevHsp), hipMemcpyDeviceToHost));
+        }
+        for (size_t x = 0; x < n_found; x++) {
+            const DevHsp &d = x < blind ? w.pin_hsps.p[x] : rest[x - blind];
+            if (d.unit < 0 || (size_t)d.unit >= units.size()) { set_error("internal: HSP of an unknown seed unit"); return MIBLAST_EHIP; }
+            jobs[(size_t)d.unit / 2]->found[d.unit & 1].push_back(d);
+        }
+    }
+    MB_HIP(hipEventElapsedTime(&ms_index, w.sev[0][0], w.sev[0][1]));
+    MB_HIP(hipEventElapsedTime(&ms_count, w.sev[0][1], w.sev[0][2]));
+    const double t_dev = now_s() - t_begin;
+    // ---- per-pair counters; launch-level times are booked on the first pair (they add up over the pairs of a call)
+    for (size_t k = 0; k < n; k++) {
+        miblast_stats &st = jobs[k]->res->stats;
+        for (int strand = 0; strand < 2; strand++) {
+            const size_t u = 2 * k + (size_t)strand;
+            st.seed_hits += (int64_t)unit_hits[u];
+            st.hits_extended += (int64_t)hc[u].extended;
+            st.ungapped_cols += (int64_t)hc[u].cols;
+            if (unit_hits[u]) st.seed_batches++;
+        }
+    }
+    {
+        miblast_stats &st = jobs[0]->res->stats;
+        st.t_index = t_index; st.t_seed = t_dev - t_index;
+        st.t_seedfill_ms = ms_fill + ms_count; st.t_sort_ms = ms_sort; st.t_ungapped_kernel_ms = ms_ung; st.ungapped_kernel_launches = total ? 1 : 0;
+        (void)ms_index;
+    }
+    if (env_long("MIBLAST_DEBUG", 0))
+        fprintf(stderr, "[miblast] batched seed stage: %zu pairs, %zu targets, %llu hits, %zu HSP candidates; index %.2f ms (kernels %.2f), count %.2f, fill %.2f, sort %.2f, ungapped %.2f; device part %.2f ms\n",
+                n, targets.size(), total, n_found, t_index * 1e3, ms_index, ms_count, ms_fill, ms_sort, ms_ung, t_dev * 1e3);
+    // ---- host halves: discovery order, entropy filter, HSP limits, anchors -- pair by pair on the worker threads
+    parallel_for(n, [&](size_t k) {
+        PairJob &job = *jobs[k];
+        if (job.Q->total >= kSeedSpan) { seed_host(p, job, 0); seed_host(p, job, 1); }
+        seed_finish(job);
+        build_units(p, job, (int)k, job.units);
+    });
+    return MIBLAST_OK;
+}
 
 // the runs of at least min_len N bases (code 4, soft-masked or not) of codes[0, n), as [start, end) pairs in order: chunks on the
 // worker threads, runs that cross a chunk border stitched afterwards
@@ -2262,7 +2487,17 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         jobs.push_back(&j);
     }
     const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, env_long("MIBLAST_SEED_LANES", 12))) : 1;
-    if (n_lanes > 1) {
+    // MIBLAST_SEED_BATCHED: 1 (default) the seed stages of a call of several pairs share their launches (seed_phase_batched);
+    // 2: a single pair goes that way too (tests); 0: never -- pair by pair on the lanes below
+    const long batched_mode = env_long("MIBLAST_SEED_BATCHED", 1);
+    bool batched_done = false;
+    if (n >= 1 && (batched_mode >= 2 || (batched_mode == 1 && n > 1))) {
+        int rc = seed_phase_batched(ctx, p, jobs, batched_done);
+        if (rc != MIBLAST_OK) return rc;
+        if (!batched_done) for (PairJob *j : jobs) { j->found[0].clear(); j->found[1].clear(); j->units.clear(); }
+    }
+    if (batched_done) {
+    } else if (n_lanes > 1) {
         // Batched call: the pairs are dealt to a few lanes, each a host thread with its own stream and seed-stage buffers.  A
         // lane runs the device half of a pair's seed stage, then the host half (discovery order, entropy filter, anchors)
         // while the other lanes keep the device busy.  A pair's result does not depend on its lane.

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__
 // columns, the first one on ties.  The host used to scan every column of every HSP for it (25 ms on a 30 Mb x 30 Mb pair at 1.3 %
 // divergence, where the HSPs hold 10^8 columns); here a lane walks an HSP, 8 columns per turn: the window gains the scores of
 // columns c + 30 .. c + 37 and loses those of c - 1 .. c + 6, both read as one unaligned 8-byte load per sequence.
-__global__ __launch_bounds__(256) void k_hsp_anchor(const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, DevHsp *__restrict__ hsps,
+__global__ __launch_bounds__(256) void k_hsp_anchor(const UnitTab ut, DevHsp *__restrict__ hsps,
                                                      const int64_t hsp_cap, const UngappedCounters *__restrict__ ctr) {
     const unsigned long long n = min((unsigned long long)hsp_cap, ctr->hsps);
     for (unsigned long long s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (unsigned long long)gridDim.x * blockDim.x) {
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void k_hsp_anchor(const uint8_t *__restrict__ 
         if (hsps[s].score == -2147483647 - 1) continue;                  // (a candidate the suppression rule dropped)
         int off = len / 2;
         if (len > 31) {
-            const uint8_t *tp = tc + hsps[s].t_start, *qp = qc + hsps[s].q_start;
+            const UnitRef un = unit_by_id(ut, hsps[s].unit);
+            const uint8_t *tp = un.tc + hsps[s].t_start, *qp = un.qc + hsps[s].q_start;
             int sum = 0;
             for (int k0 = 0; k0 < 32; k0 += 8) {                          // the first window: columns 0 .. 30
                 const unsigned long long a8 = load8(tp + k0), b8 = load8(qp + k0);

@@ -178,7 +178,7 @@ __device__ __forceinline__ StepOut grp_step(const bool act, const bool left, con
 template <int kMinWaves>
 __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned long long *__restrict__ keys, int64_t n_hits,
                                                       const unsigned *__restrict__ heads, const unsigned *__restrict__ n_heads_p,
-                                                      const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, int64_t qtot,
+                                                      const UnitTab ut,
                                                       int32_t *__restrict__ extent, int xdrop, int K, DevHsp *__restrict__ hsps,
                                                       int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     using namespace ugrp;
@@ -205,6 +205,11 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
     int em_len = 0, em_score = 0, em_qend = 0;
     int64_t em_t = 0, em_q = 0, em_tend = 0;
     unsigned long long n_ext = 0, n_cols = 0;
+    // the unit of the current run (a group walks runs of several units of a batched launch: its counters go to the unit they belong
+    // to whenever the unit changes) and of the HSP waiting to be written
+    UnitRef un = unit_by_id(ut, 0);
+    const uint8_t *tc = un.tc, *qc = un.qc, *em_tc = un.tc, *em_qc = un.qc;
+    int em_unit = 0;
 
     auto advance = [&]() {                                            // to the next hit of the run, or the run is over
         if ((uint32_t)(nxt >> 32) == dq) {
@@ -231,6 +236,14 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
                     dq = (uint32_t)(cur >> 32);
                     ext = extent[dq];
                     need_run = false;
+                    if (ut.n > 1) {
+                        const UnitRef nu = unit_of(ut, dq);
+                        if (nu.id != un.id) {
+                            if (l8 == 0 && (n_ext | n_cols)) { atomicAdd(&ctr[un.id].extended, n_ext); atomicAdd(&ctr[un.id].cols, n_cols); }
+                            n_ext = 0; n_cols = 0;
+                            un = nu; tc = un.tc; qc = un.qc;
+                        }
+                    }
                 } else {
                     phase = 3;
                 }
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
             if (phase == 0) {
                 q_end = (int32_t)(uint32_t)cur;
                 if (q_end > ext) {
-                    t_end = (int64_t)dq - qtot + q_end;
+                    t_end = (int64_t)dq - un.qoff + q_end;
                     phase = 1; base = 0; runb = 0; best = 0; bpos = 0;
                 } else {
                     advance();
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
             if (score >= K) {
                 emit = true;
                 em_t = t_end - bl; em_q = (int64_t)q_end - bl; em_len = bl + br; em_score = score; em_tend = t_end; em_qend = q_end;
+                em_tc = tc; em_qc = qc; em_unit = un.id;
             }
             advance();
         }
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             for (int kk = 8 * l8; wballot(emit && kk < em_len); kk += 64) {
                 if (emit && kk < em_len) {
-                    const unsigned long long x8 = load8(tc + em_t + kk), y8 = load8(qc + em_q + kk);
+                    const unsigned long long x8 = load8(em_tc + em_t + kk), y8 = load8(em_qc + em_q + kk);
 #pragma unroll
                     for (int m = 0; m < 8; m++) {
                         const unsigned a = (unsigned)(x8 >> (8 * m)) & 7u, b = (unsigned)(y8 >> (8 * m)) & 7u;
@@ -296,6 +310,7 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
                     hs.t_start = (int32_t)em_t; hs.q_start = (int32_t)em_q; hs.len = em_len; hs.score = em_score;
                     hs.seed_t_end = (int32_t)em_tend; hs.seed_q_end = em_qend;
                     hs.cnt[0] = c0; hs.cnt[1] = c1; hs.cnt[2] = c2; hs.cnt[3] = c3;
+                    hs.unit = em_unit;
                     hsps[slot] = hs;
                 }
             }
@@ -303,5 +318,5 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
         }
     }
     // counters: the first lane of a group holds the group's numbers (a group lives for the whole launch: few atomics)
-    if (l8 == 0 && (n_ext | n_cols)) { atomicAdd(&ctr->extended, n_ext); atomicAdd(&ctr->cols, n_cols); }
+    if (l8 == 0 && (n_ext | n_cols)) { atomicAdd(&ctr[un.id].extended, n_ext); atomicAdd(&ctr[un.id].cols, n_cols); }
 }

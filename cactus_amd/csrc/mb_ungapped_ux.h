@@ -102,7 +102,7 @@ __device__ __forceinline__ void load_right2(const uint8_t *p_end, const int j, u
 }
 
 // a finished hit: its record and, if it scores, its candidate HSP (census later, only if the rule keeps the hit)
-__device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, const int32_t q_end, const int64_t t_end, const int best_l,
+__device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, const int unit, const int32_t q_end, const int64_t t_end, const int best_l,
                                            const int bl, const int best_r, const int br, const uint32_t cols, const int K,
                                            const unsigned long long *__restrict__ keys, const int64_t n_hits, const UxScratch &sc,
                                            DevHsp *__restrict__ hsps, const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
@@ -126,6 +126,7 @@ __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, 
             hs.t_start = (int32_t)(t_end - bl); hs.q_start = q_end - bl; hs.len = bl + br; hs.score = score;
             hs.seed_t_end = (int32_t)t_end; hs.seed_q_end = q_end;
             hs.cnt[0] = (int32_t)cols; hs.cnt[1] = 0; hs.cnt[2] = 0; hs.cnt[3] = 0;       // cnt[1]: set by k_ux_resolve when the rule keeps the hit
+            hs.unit = unit;
             hsps[slot] = hs;
             x = kCand | (uint32_t)slot;
         }
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_ux_mark_long(const unsigned long long *
 }
 
 __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long long *__restrict__ keys, const int64_t n_hits,
-                                                           const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, const int64_t qtot,
+                                                           const UnitTab ut,
                                                            const int xdrop, const int K, const UxScratch sc, DevHsp *__restrict__ hsps,
                                                            const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     using namespace ux;
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
         const unsigned long long key = keys[i];
         const uint32_t dq = (uint32_t)(key >> 32);
         const int32_t q_end = (int32_t)(uint32_t)key;
-        const int64_t t_end = (int64_t)dq - qtot + q_end;
+        const UnitRef un = unit_of(ut, dq);
+        const uint8_t *tc = un.tc, *qc = un.qc;
+        const int64_t t_end = (int64_t)dq - un.qoff + q_end;
         unsigned long long aL[kL1], bL[kL1], aR[kR1], bR[kR1];
 #pragma unroll
         for (int j = 0; j < kL1 / 2; j++) { load_left2(tc + t_end, j, aL[2 * j], aL[2 * j + 1]); load_left2(qc + q_end, j, bL[2 * j], bL[2 * j + 1]); }
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
             e.cl = xl.live ? (clean ? kL1 : 0) : -1; e.cr = xr.live ? (clean ? kR1 : 0) : -1;
             e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos; e.cols = cols;
         } else {
-            finish_hit((uint32_t)i, dq, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+            finish_hit((uint32_t)i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
         }
     }
     // ---- the unfinished hits of the block, packed at the front
@@ -205,12 +208,15 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
     bool spill = false;
     uint32_t dq = 0; int32_t q_end = 0; int64_t t_end = 0;
     XState xl{0, 0, 0, false}, xr{0, 0, 0, false};
+    UnitRef un = unit_by_id(ut, 0);
+    const uint8_t *tc = un.tc, *qc = un.qc;
     if (mine) {
         e = slots[tid];
         const unsigned long long key = keys[e.i];
         dq = (uint32_t)(key >> 32);
         q_end = (int32_t)(uint32_t)key;
-        t_end = (int64_t)dq - qtot + q_end;
+        un = unit_of(ut, dq); tc = un.tc; qc = un.qc;
+        t_end = (int64_t)dq - un.qoff + q_end;
         const int cl0 = max(e.cl, 0), cr0 = max(e.cr, 0);
         unsigned long long aL[kL2], bL[kL2], aR[kR2], bR[kR2];
         // (cl0 and cr0 are even: level 1 took an even number of chunks)
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
             e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos;
         }                                                             // (else: a separator ahead -- the entry goes on as it came)
         spill = xl.live | xr.live;
-        if (!spill) finish_hit(e.i, dq, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+        if (!spill) finish_hit(e.i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
     }
     // ---- still running: to k_ux_tail.  A returning atomic on one address costs ~7 ns whoever issues it, and nearly every block has
     //      a straggler or two: the first two waves of a block own 12 + 4 slots of the entry array (count stored, no atomic); only
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
                 // the list is full: this lane walks its hit to the end itself (slow and rare; same result)
                 while (xl.live) { xdrop_chunk<-1>(load8(tc + t_end - 8 * (e.cl + 1)), load8(qc + q_end - 8 * (e.cl + 1)), e.cl, xdrop, xl, e.cols); e.cl++; }
                 while (xr.live) { xdrop_chunk<+1>(load8(tc + t_end + 8 * e.cr), load8(qc + q_end + 8 * e.cr), e.cr, xdrop, xr, e.cols); e.cr++; }
-                finish_hit(e.i, dq, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+                finish_hit(e.i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
             }
         }
     }
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
 
 // The listed hits to the end: a group of 8 lanes per hit, 64 columns per step (the state machine of k_ungapped_grp with the
 // list in place of the runs).
-__global__ __launch_bounds__(256) void k_ux_tail(const unsigned long long *__restrict__ keys, const int64_t n_hits, const uint8_t *__restrict__ tc,
-                                                  const uint8_t *__restrict__ qc, const int64_t qtot, const int xdrop, const int K,
+__global__ __launch_bounds__(256) void k_ux_tail(const unsigned long long *__restrict__ keys, const int64_t n_hits, const UnitTab ut,
+                                                  const int xdrop, const int K,
                                                   const UxScratch sc, DevHsp *__restrict__ hsps, const int64_t hsp_cap,
                                                   UngappedCounters *__restrict__ ctr) {
     using namespace ugrp;
@@ -280,6 +286,8 @@ __global__ __launch_bounds__(256) void k_ux_tail(const unsigned long long *__res
     e.i = 0; e.cl = -1; e.cr = -1; e.run_l = 0; e.best_l = 0; e.bpos_l = 0; e.run_r = 0; e.best_r = 0; e.bpos_r = 0; e.cols = 0;
     uint32_t dq = 0; int32_t q_end = 0; int64_t t_end = 0;
     int base = 0, runb = 0, best = 0, bpos = 0;
+    UnitRef un = unit_by_id(ut, 0);
+    const uint8_t *tc = un.tc, *qc = un.qc;
     while (true) {
         if (phase == 0) {
             while (left == 0 && at < n_regions) {                       // (most block regions are empty)
@@ -297,7 +305,8 @@ __global__ __launch_bounds__(256) void k_ux_tail(const unsigned long long *__res
                 const unsigned long long key = keys[e.i];
                 dq = (uint32_t)(key >> 32);
                 q_end = (int32_t)(uint32_t)key;
-                t_end = (int64_t)dq - qtot + q_end;
+                un = unit_of(ut, dq); tc = un.tc; qc = un.qc;
+                t_end = (int64_t)dq - un.qoff + q_end;
                 if (e.cl >= 0) { phase = 1; base = 8 * e.cl; runb = e.run_l; best = e.best_l; bpos = e.bpos_l; }
                 else { phase = 2; base = 8 * e.cr; runb = e.run_r; best = e.best_r; bpos = e.bpos_r; }
             } else {
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256) void k_ux_tail(const unsigned long long *__res
                 phase = 4;
             }
             if (phase == 4) {
-                if (l8 == 0) ux::finish_hit(e.i, dq, q_end, t_end, e.best_l, e.bpos_l, e.best_r, e.bpos_r, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+                if (l8 == 0) ux::finish_hit(e.i, dq, un.id, q_end, t_end, e.best_l, e.bpos_l, e.best_r, e.bpos_r, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
                 phase = 0;
             }
         }
@@ -331,17 +340,26 @@ constexpr int kDirtyBuf = 2048;
 
 // Every hit of the clean short runs is kept: one hit per lane.  The first hit of a dirty short run puts the run on the list of
 // k_ux_resolve.
-__global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__restrict__ keys, const int64_t n_hits, int32_t *__restrict__ extent,
+__global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__restrict__ keys, const int64_t n_hits, const UnitTab ut, int32_t *__restrict__ extent,
                                                     const UxScratch sc, DevHsp *__restrict__ hsps, UngappedCounters *__restrict__ ctr) {
-    // (a grid-stride loop with the counters in registers: a pair of same-address atomics per wave of hits costs more than the rest)
+    // (every block takes one stretch of the sorted hits with the counters in registers: a pair of same-address atomics per wave of
+    //  hits costs more than the rest.  The hits of a unit are one stretch of the sorted keys, so a block sees a unit or two: a
+    //  thread's numbers go to their unit when the unit changes, and once per block at the end.)
     __shared__ unsigned dbuf[kDirtyBuf];                             // first hits of dirty runs found by this block, appended to the list at the end
-    __shared__ unsigned n_dbuf, dbase;
+    __shared__ unsigned n_dbuf, dbase, sh_unit1;
     __shared__ unsigned long long sh_kept, sh_cols;
-    if (threadIdx.x == 0) { n_dbuf = 0; sh_kept = 0; sh_cols = 0; }
+    if (threadIdx.x == 0) { n_dbuf = 0; sh_kept = 0; sh_cols = 0; sh_unit1 = 0; }
     __syncthreads();
     unsigned n_kept = 0;
     unsigned long long n_cols = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += (int64_t)gridDim.x * blockDim.x) {
+    int cur = 0;                                                     // unit of n_kept / n_cols
+    // (one unit: the grid strides over the hits, so that the list of dirty runs comes out interleaved -- k_ux_resolve's lanes then
+    //  walk runs from all over the diagonal space; several units: a stretch per block)
+    const bool strided = ut.n <= 1;
+    const int64_t per_blk = (((n_hits + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x) + (int64_t)blockDim.x - 1) / (int64_t)blockDim.x * (int64_t)blockDim.x;
+    const int64_t i_end = strided ? n_hits : min(n_hits, ((int64_t)blockIdx.x + 1) * per_blk);
+    const int64_t i_step = strided ? (int64_t)gridDim.x * blockDim.x : (int64_t)blockDim.x;
+    for (int64_t i = (strided ? (int64_t)blockIdx.x * blockDim.x : (int64_t)blockIdx.x * per_blk) + threadIdx.x; i < i_end; i += i_step) {
         // (everything that does not depend on the bit planes is requested first: one round trip + one dependent one per hit)
         const unsigned long long key = keys[i];
         const unsigned long long rc = sc.rec[i];
@@ -350,6 +368,13 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
         const uint32_t dq = (uint32_t)(key >> 32);
         const bool is_long = (sc.long_bits[dq >> 5] >> (dq & 31u)) & 1u, is_dirty = (sc.dirty_bits[dq >> 5] >> (dq & 31u)) & 1u;
         if (!is_long && !is_dirty) {
+            if (ut.n > 1) {
+                const int u = unit_index(ut, dq);
+                if (u != cur) {
+                    if (n_kept | n_cols) { atomicAdd(&ctr[cur].extended, (unsigned long long)n_kept); atomicAdd(&ctr[cur].cols, n_cols); }
+                    n_kept = 0; n_cols = 0; cur = u;
+                }
+            }
             const uint32_t x = (uint32_t)(rc >> 32);
             uint32_t cols = x;
             if (x & ux::kCand) {
@@ -369,9 +394,15 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
             }
         }
     }
+    if (n_kept | n_cols) atomicMax(&sh_unit1, (unsigned)cur + 1u);       // (LDS) the block's last unit takes the block-wide sum
     __syncthreads();
     const unsigned n_mine = min(n_dbuf, (unsigned)kDirtyBuf);
     if (threadIdx.x == 0 && n_mine) dbase = atomicAdd(sc.n_entries + 1, n_mine);
+    const int blk_unit = (int)sh_unit1 - 1;
+    if ((n_kept | n_cols) && cur != blk_unit) {                          // (a thread whose last hits belong to an earlier unit: few)
+        atomicAdd(&ctr[cur].extended, (unsigned long long)n_kept); atomicAdd(&ctr[cur].cols, n_cols);
+        n_kept = 0; n_cols = 0;
+    }
     __syncthreads();
     for (unsigned j = threadIdx.x; j < n_mine; j += blockDim.x)
         if (dbase + j < sc.dirty_cap) sc.dirty_runs[dbase + j] = dbuf[j];
@@ -388,19 +419,27 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
     }
     if ((threadIdx.x & 63) == 0 && kept) { atomicAdd(&sh_kept, kept); atomicAdd(&sh_cols, cols); }
     __syncthreads();
-    if (threadIdx.x == 0 && sh_kept) { atomicAdd(&ctr->extended, sh_kept); atomicAdd(&ctr->cols, sh_cols); }
+    if (threadIdx.x == 0 && sh_kept) { atomicAdd(&ctr[blk_unit].extended, sh_kept); atomicAdd(&ctr[blk_unit].cols, sh_cols); }
 }
 
 // The sequential rule over the records of the dirty short runs, one run per lane.
-__global__ __launch_bounds__(256) void k_ux_resolve(const unsigned long long *__restrict__ keys, const int64_t n_hits, int32_t *__restrict__ extent,
+__global__ __launch_bounds__(256) void k_ux_resolve(const unsigned long long *__restrict__ keys, const int64_t n_hits, const UnitTab ut, int32_t *__restrict__ extent,
                                                      const UxScratch sc, DevHsp *__restrict__ hsps, UngappedCounters *__restrict__ ctr) {
     const unsigned long long *__restrict__ rec = sc.rec;
     const unsigned total = min(sc.n_entries[1], sc.dirty_cap);
     unsigned long long n_ext = 0, n_cols = 0;
+    int cur = 0;                                                     // unit of n_ext / n_cols
     for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < total; r += gridDim.x * blockDim.x) {
         int64_t k = sc.dirty_runs[r];
         unsigned long long key = keys[k];
         const uint32_t dq = (uint32_t)(key >> 32);
+        if (ut.n > 1) {
+            const int u = unit_index(ut, dq);
+            if (u != cur) {
+                if (n_ext | n_cols) { atomicAdd(&ctr[cur].extended, n_ext); atomicAdd(&ctr[cur].cols, n_cols); }
+                n_ext = 0; n_cols = 0; cur = u;
+            }
+        }
         int32_t ext = extent[dq];
         while (true) {
             const int32_t q_end = (int32_t)(uint32_t)key;
@@ -424,16 +463,18 @@ __global__ __launch_bounds__(256) void k_ux_resolve(const unsigned long long *__
         }
         extent[dq] = ext;
     }
-    if (n_ext | n_cols) { atomicAdd(&ctr->extended, n_ext); atomicAdd(&ctr->cols, n_cols); }
+    unit_count(ctr, cur, n_ext, n_cols);                             // (one pair of atomics per wave)
 }
 
 // Candidates the rule kept get their identical-base census (SURVEY A.5 entropy filter input); the others are marked.
-__global__ __launch_bounds__(256) void k_ux_census(const uint8_t *__restrict__ tc, const uint8_t *__restrict__ qc, DevHsp *__restrict__ hsps,
+__global__ __launch_bounds__(256) void k_ux_census(const UnitTab ut, DevHsp *__restrict__ hsps,
                                                     const int64_t hsp_cap, const UngappedCounters *__restrict__ ctr) {
     const unsigned long long n = min((unsigned long long)hsp_cap, ctr->hsps);
     for (unsigned long long s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (unsigned long long)gridDim.x * blockDim.x) {
         DevHsp hs = hsps[s];
         if (hs.cnt[1] != 1) { hsps[s].score = -2147483647 - 1; continue; }
+        const UnitRef un = unit_by_id(ut, hs.unit);
+        const uint8_t *tc = un.tc, *qc = un.qc;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         for (int kk = 0; kk < hs.len; kk += 8) {
             const unsigned long long a8 = load8(tc + hs.t_start + kk), b8 = load8(qc + hs.q_start + kk);

@@ -77,6 +77,7 @@ using std::min;
 
 namespace mb {
 #include "mb_xdrop.h"
+#include "mb_units.h"
 #include "mb_runs.h"
 #include "mb_ungapped_grp.h"
 #include "mb_ungapped_ux.h"
@@ -121,7 +122,7 @@ static void reference(const std::vector<unsigned long long> &keys, const uint8_t
             ext = q_end + br;
             if (bestL + bestR >= K) {
                 mb::DevHsp h;
-                h.anchor_off = 0;                                       // (checked separately against anchor_ref)
+                h.anchor_off = 0; h.unit = 0;                           // (anchor checked separately against anchor_ref)
                 h.t_start = (int32_t)(t_end - bl); h.q_start = q_end - bl; h.len = bl + br; h.score = bestL + bestR;
                 h.seed_t_end = (int32_t)t_end; h.seed_q_end = q_end;
                 for (int c = 0; c < 4; c++) h.cnt[c] = 0;
@@ -163,47 +164,66 @@ int main(int argc, char **argv) {
     for (int cs = 0; cs < n_cases; cs++) {
         std::mt19937 rng(seed0 * 7919u + (unsigned)cs);
         auto rnd = [&](int n) { return (int)(rng() % (unsigned)n); };
-        const int64_t tn = 3000 + rnd(6000), qn = 3000 + rnd(6000);
+        // one to three seed units (chunk pair x strand) share the launch: unit u owns the diagonals [dbase, dbase + tn + qn + 2)
+        const int n_units = cs % 3 == 2 ? 1 : 1 + rnd(3);
         const int xdrop = cs % 3 == 0 ? 910 : cs % 3 == 1 ? 300 + rnd(400) : 1500 + rnd(3000);
         const int K = cs % 2 ? 3000 : 400 + rnd(1500);
-        std::vector<uint8_t> tb((size_t)tn + 2 * mb::kDevPad + 8, mb::kSep), qb((size_t)qn + 2 * mb::kDevPad + 8, mb::kSep);
-        uint8_t *tc = tb.data() + mb::kDevPad, *qc = qb.data() + mb::kDevPad;
-        for (int64_t i = 0; i < tn; i++) tc[i] = (uint8_t)rnd(4);
-        for (int64_t i = 0; i < qn; i++) qc[i] = (uint8_t)rnd(4);
-        // planted homology: stretches of Q copied from T with mutations
-        std::vector<std::pair<int64_t, int64_t>> diag_seeds;
-        for (int s = 0, ns = 3 + rnd(5); s < ns; s++) {
-            const int len = 50 + rnd(cs % 4 == 3 ? 1500 : 400);
-            const int64_t t0 = rnd((int)(tn - len)), q0 = rnd((int)(qn - len));
-            const int div = 2 + rnd(25);
-            for (int c = 0; c < len; c++) qc[q0 + c] = rnd(100) < div ? (uint8_t)rnd(4) : tc[t0 + c];
-            for (int h = 0, nhh = 1 + rnd(20); h < nhh; h++) { const int c = 1 + rnd(len - 1); diag_seeds.push_back({t0 + c, q0 + c}); }
-        }
-        // N bases, soft-mask bits, contig separators
-        for (int s = 0; s < 12; s++) { tc[rnd((int)tn)] = 4; qc[rnd((int)qn)] = 4; }
-        for (int s = 0; s < 200; s++) { tc[rnd((int)tn)] |= 8; qc[rnd((int)qn)] |= 8; }
-        for (int s = 0, ns = rnd(4); s < ns; s++) { tc[1 + rnd((int)tn - 2)] = mb::kSep; qc[1 + rnd((int)qn - 2)] = mb::kSep; }
-        // hits: (t_end, q_end) with the base before either end inside a contig; chance hits, hits on the planted diagonals, a busy diagonal
-        std::vector<unsigned long long> keys;
-        auto add = [&](int64_t t_end, int64_t q_end) {
-            if (t_end < 1 || t_end > tn || q_end < 1 || q_end > qn) return;
-            if (tc[t_end - 1] == mb::kSep || qc[q_end - 1] == mb::kSep) return;
-            const uint64_t d = (uint64_t)(t_end - q_end + qn);
-            keys.push_back((d << 32) | (uint64_t)(uint32_t)q_end);
-        };
-        for (int h = 0, nhh = 300 + rnd(1200); h < nhh; h++) add(1 + rnd((int)tn), 1 + rnd((int)qn));
-        for (auto &ds : diag_seeds) add(ds.first, ds.second);
-        { const int64_t d0 = rnd((int)tn / 2); for (int h = 0, nhh = rnd(40); h < nhh; h++) { const int q = 1 + rnd((int)std::min(qn, tn - d0) - 1); add(d0 + q, q); } }
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-        const int64_t n_hits = (int64_t)keys.size();
-        const int64_t ndiag = tn + qn + 2;
-        std::vector<int32_t> extent0((size_t)ndiag, 0);
-        const bool extent_clean = cs % 2 == 0;                              // (odd cases: extents left by an earlier q batch)
-        if (!extent_clean) for (int s = 0; s < 20; s++) extent0[(size_t)rnd((int)ndiag)] = rnd((int)qn);
-        Ref ref; ref.extent = extent0;
         const int long_run = 6 + rnd(27);
-        reference(keys, tc, qc, qn, xdrop, K, long_run, ref);
+        const bool extent_clean = cs % 2 == 0;                              // (odd cases: extents left by an earlier q batch)
+        struct Unit { int64_t tn, qn; std::vector<uint8_t> tb, qb; uint8_t *tc, *qc; uint32_t dbase; std::vector<unsigned long long> keys; Ref ref; };
+        std::vector<Unit> units((size_t)n_units);
+        std::vector<unsigned long long> keys;
+        uint32_t dnext = 0;
+        for (Unit &u : units) {
+            const int64_t tn = u.tn = (n_units > 1 ? 1500 : 3000) + rnd(6000), qn = u.qn = (n_units > 1 ? 1500 : 3000) + rnd(6000);
+            u.tb.assign((size_t)tn + 2 * mb::kDevPad + 8, mb::kSep); u.qb.assign((size_t)qn + 2 * mb::kDevPad + 8, mb::kSep);
+            uint8_t *tc = u.tc = u.tb.data() + mb::kDevPad, *qc = u.qc = u.qb.data() + mb::kDevPad;
+            u.dbase = dnext; dnext += (uint32_t)(tn + qn + 2);
+            for (int64_t i = 0; i < tn; i++) tc[i] = (uint8_t)rnd(4);
+            for (int64_t i = 0; i < qn; i++) qc[i] = (uint8_t)rnd(4);
+            // planted homology: stretches of Q copied from T with mutations
+            std::vector<std::pair<int64_t, int64_t>> diag_seeds;
+            for (int s = 0, ns = 3 + rnd(5); s < ns; s++) {
+                const int len = 50 + rnd(cs % 4 == 3 ? 1500 : 400);
+                const int64_t t0 = rnd((int)(tn - len)), q0 = rnd((int)(qn - len));
+                const int div = 2 + rnd(25);
+                for (int c = 0; c < len; c++) qc[q0 + c] = rnd(100) < div ? (uint8_t)rnd(4) : tc[t0 + c];
+                for (int h = 0, nhh = 1 + rnd(20); h < nhh; h++) { const int c = 1 + rnd(len - 1); diag_seeds.push_back({t0 + c, q0 + c}); }
+            }
+            // N bases, soft-mask bits, contig separators
+            for (int s = 0; s < 12; s++) { tc[rnd((int)tn)] = 4; qc[rnd((int)qn)] = 4; }
+            for (int s = 0; s < 200; s++) { tc[rnd((int)tn)] |= 8; qc[rnd((int)qn)] |= 8; }
+            for (int s = 0, ns = rnd(4); s < ns; s++) { tc[1 + rnd((int)tn - 2)] = mb::kSep; qc[1 + rnd((int)qn - 2)] = mb::kSep; }
+            // hits: (t_end, q_end) with the base before either end inside a contig; chance hits, hits on the planted diagonals, a busy diagonal
+            auto add = [&](int64_t t_end, int64_t q_end) {
+                if (t_end < 1 || t_end > tn || q_end < 1 || q_end > qn) return;
+                if (tc[t_end - 1] == mb::kSep || qc[q_end - 1] == mb::kSep) return;
+                const uint64_t d = (uint64_t)(t_end - q_end + qn);
+                u.keys.push_back((d << 32) | (uint64_t)(uint32_t)q_end);
+            };
+            for (int h = 0, nhh = 300 + rnd(1200); h < nhh; h++) add(1 + rnd((int)tn), 1 + rnd((int)qn));
+            for (auto &ds : diag_seeds) add(ds.first, ds.second);
+            { const int64_t d0 = rnd((int)tn / 2); for (int h = 0, nhh = rnd(40); h < nhh; h++) { const int q = 1 + rnd((int)std::min(qn, tn - d0) - 1); add(d0 + q, q); } }
+            std::sort(u.keys.begin(), u.keys.end());
+            u.keys.erase(std::unique(u.keys.begin(), u.keys.end()), u.keys.end());
+            u.ref.extent.assign((size_t)(tn + qn + 2), 0);
+            if (!extent_clean) for (int s = 0; s < 20; s++) u.ref.extent[(size_t)rnd((int)(tn + qn + 2))] = rnd((int)qn);
+            for (unsigned long long k : u.keys) keys.push_back(k + ((unsigned long long)u.dbase << 32));       // the launch's keys: sorted, one stretch per unit
+        }
+        const int64_t n_hits = (int64_t)keys.size();
+        const int64_t ndiag = (int64_t)dnext;
+        std::vector<int32_t> extent0((size_t)ndiag, 0);
+        for (Unit &u : units) {
+            std::copy(u.ref.extent.begin(), u.ref.extent.end(), extent0.begin() + (long)u.dbase);
+            reference(u.keys, u.tc, u.qc, u.qn, xdrop, K, long_run, u.ref);
+        }
+        std::vector<mb::SeedUnit> tab((size_t)n_units);
+        for (int x = 0; x < n_units; x++) {
+            memset(&tab[(size_t)x], 0, sizeof(mb::SeedUnit));
+            tab[(size_t)x].tc = units[(size_t)x].tc; tab[(size_t)x].qc = units[(size_t)x].qc; tab[(size_t)x].qtot = (int32_t)units[(size_t)x].qn; tab[(size_t)x].ttot = (int32_t)units[(size_t)x].tn;
+            tab[(size_t)x].dbase = units[(size_t)x].dbase;
+        }
+        mb::UnitTab ut; ut.one = tab[0]; ut.tab = tab.data(); ut.n = n_units;
         // class lists as k_run_heads lays them out (every run is "short" here)
         const uint64_t n = (uint64_t)n_hits;
         std::vector<unsigned> heads((size_t)(2 * n + n / 4 + 64), 0u);
@@ -235,11 +255,12 @@ int main(int argc, char **argv) {
         }
         std::vector<int32_t> extent = extent0;
         std::vector<mb::DevHsp> hsps((size_t)n_hits + 8);
-        mb::UngappedCounters ctr = {0, 0, 0};
+        std::vector<mb::UngappedCounters> ctrs((size_t)n_units, mb::UngappedCounters{0, 0, 0});
+        mb::UngappedCounters *ctr = ctrs.data();
         const unsigned blocks = 1 + (unsigned)rnd(3);                    // few groups: every group walks many runs
         if (!use_ux) {
-            hipLaunchKernelGGL(mb::k_ungapped_grp<5>, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, tc, qc, (int64_t)qn,
-                               extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), &ctr);
+            hipLaunchKernelGGL(mb::k_ungapped_grp<5>, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, ut,
+                               extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), ctr);
         } else {
             std::vector<unsigned long long> rec((size_t)n_hits + 1, 0xdeadbeefdeadbeefull);
             const unsigned cap = cs % 5 == 4 ? 3u : (unsigned)n_hits;      // (a tiny list: lanes finish their hits themselves)
@@ -254,41 +275,52 @@ int main(int argc, char **argv) {
             sc.dirty_runs = dirty_runs.data(); sc.dirty_cap = (unsigned)n_hits; sc.extent = extent.data(); sc.extent_live = extent_clean ? 0 : 1;
             const unsigned *heads_long = heads.data() + (n + n / 2 + n / 4 + n / 8 + 8);
             hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, bits.data());
-            hipLaunchKernelGGL(mb::k_ux_extend, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, tc, qc, (int64_t)qn, xdrop, K, sc,
-                               hsps.data(), (int64_t)hsps.size(), &ctr);
-            hipLaunchKernelGGL(mb::k_ux_tail, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, tc, qc, (int64_t)qn, xdrop, K, sc, hsps.data(), (int64_t)hsps.size(), &ctr);
-            hipLaunchKernelGGL(mb::k_ux_accept, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, extent.data(), sc, hsps.data(), &ctr);
-            hipLaunchKernelGGL(mb::k_ux_resolve, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, extent.data(), sc, hsps.data(), &ctr);
+            hipLaunchKernelGGL(mb::k_ux_extend, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc,
+                               hsps.data(), (int64_t)hsps.size(), ctr);
+            hipLaunchKernelGGL(mb::k_ux_tail, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc, hsps.data(), (int64_t)hsps.size(), ctr);
+            // (few blocks: a block's stretch of the sorted hits then spans several units)
+            hipLaunchKernelGGL(mb::k_ux_accept, dim3(cs % 2 ? 1u + (unsigned)rnd(2) : (unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, ut, extent.data(), sc, hsps.data(), ctr);
+            hipLaunchKernelGGL(mb::k_ux_resolve, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, ut, extent.data(), sc, hsps.data(), ctr);
             { size_t nd = 0; for (uint32_t w : dirty) nd += (size_t)__builtin_popcount(w); printf("  ux: %zu dirty diagonals\n", nd); }
-            hipLaunchKernelGGL(mb::k_ux_census, dim3(1), dim3(256), 0, nullptr, tc, qc, hsps.data(), (int64_t)hsps.size(), &ctr);
-            { unsigned nb = 0; for (unsigned v : blk_cnt) nb += v; printf("  ux: %u + %u of %lld hits left for the tail (block slots + list), %llu candidates, %u dirty runs\n", nb, n_entries[0], (long long)n_hits, ctr.hsps, n_entries[1]); }
+            hipLaunchKernelGGL(mb::k_ux_census, dim3(1), dim3(256), 0, nullptr, ut, hsps.data(), (int64_t)hsps.size(), ctr);
+            { unsigned nb = 0; for (unsigned v : blk_cnt) nb += v; printf("  ux: %u + %u of %lld hits left for the tail (block slots + list), %llu candidates, %u dirty runs\n", nb, n_entries[0], (long long)n_hits, ctr[0].hsps, n_entries[1]); }
         }
-        hipLaunchKernelGGL(mb::k_hsp_anchor, dim3(1), dim3(256), 0, nullptr, tc, qc, hsps.data(), (int64_t)hsps.size(), &ctr);
-        bool anchors_ok = true;
-        for (unsigned long long s = 0; s < ctr.hsps; s++)
-            if (hsps[s].score != INT32_MIN && hsps[s].anchor_off != anchor_ref(hsps[s], tc, qc)) anchors_ok = false;
-        hsps.resize((size_t)ctr.hsps);
-        hsps.erase(std::remove_if(hsps.begin(), hsps.end(), [](const mb::DevHsp &d) { return d.score == INT32_MIN; }), hsps.end());
-        for (mb::DevHsp &d : hsps) d.anchor_off = 0;
-        std::sort(hsps.begin(), hsps.end(), hsp_less);
-        std::sort(ref.hsps.begin(), ref.hsps.end(), hsp_less);
-        bool ok = anchors_ok && ctr.extended == ref.extended && ctr.cols == ref.cols && hsps.size() == ref.hsps.size() && extent == ref.extent;
-        for (size_t i = 0; ok && i < hsps.size(); i++) ok = memcmp(&hsps[i], &ref.hsps[i], sizeof(mb::DevHsp)) == 0;
-        printf("case %d: hits %lld runs %u xdrop %d K %d  hsps %zu/%zu extended %llu/%llu cols %llu/%llu  %s\n", cs, (long long)n_hits,
-               n_heads[0] + n_heads[1] + n_heads[2] + n_heads[3], xdrop, K, hsps.size(), ref.hsps.size(), ctr.extended, ref.extended, ctr.cols,
-               ref.cols, ok ? "ok" : "MISMATCH");
-        if (!ok) {
-            bad++;
-            for (size_t i = 0; i < std::min(hsps.size(), ref.hsps.size()); i++)
-                if (memcmp(&hsps[i], &ref.hsps[i], sizeof(mb::DevHsp)) != 0) {
-                    printf("  first differing hsp %zu: got t %d q %d len %d score %d seed %d/%d | want t %d q %d len %d score %d seed %d/%d\n", i, hsps[i].t_start,
-                           hsps[i].q_start, hsps[i].len, hsps[i].score, hsps[i].seed_t_end, hsps[i].seed_q_end, ref.hsps[i].t_start, ref.hsps[i].q_start,
-                           ref.hsps[i].len, ref.hsps[i].score, ref.hsps[i].seed_t_end, ref.hsps[i].seed_q_end);
-                    break;
-                }
-            for (size_t d = 0; d < extent.size(); d++)
-                if (extent[d] != ref.extent[d]) { printf("  first differing extent: diagonal %zu got %d want %d\n", d, extent[d], ref.extent[d]); break; }
+        hipLaunchKernelGGL(mb::k_hsp_anchor, dim3(1), dim3(256), 0, nullptr, ut, hsps.data(), (int64_t)hsps.size(), ctr);
+        hsps.resize((size_t)ctr[0].hsps);
+        bool all_ok = true;
+        size_t total_hsps = 0, total_ref = 0;
+        for (int x = 0; x < n_units; x++) {
+            Unit &u = units[(size_t)x];
+            std::vector<mb::DevHsp> mine;
+            bool anchors_ok = true;
+            for (const mb::DevHsp &d : hsps)
+                if (d.unit == x && d.score != INT32_MIN) { if (d.anchor_off != anchor_ref(d, u.tc, u.qc)) anchors_ok = false; mine.push_back(d); }
+            for (mb::DevHsp &d : mine) { d.anchor_off = 0; d.unit = 0; }
+            for (mb::DevHsp &d : u.ref.hsps) d.unit = 0;
+            std::sort(mine.begin(), mine.end(), hsp_less);
+            std::sort(u.ref.hsps.begin(), u.ref.hsps.end(), hsp_less);
+            const std::vector<int32_t> ext(extent.begin() + (long)u.dbase, extent.begin() + (long)u.dbase + (long)(u.tn + u.qn + 2));
+            bool ok = anchors_ok && ctr[x].extended == u.ref.extended && ctr[x].cols == u.ref.cols && mine.size() == u.ref.hsps.size() && ext == u.ref.extent;
+            for (size_t i = 0; ok && i < mine.size(); i++) ok = memcmp(&mine[i], &u.ref.hsps[i], sizeof(mb::DevHsp)) == 0;
+            total_hsps += mine.size(); total_ref += u.ref.hsps.size();
+            if (!ok) {
+                all_ok = false;
+                printf("  unit %d of %d: hsps %zu/%zu extended %llu/%llu cols %llu/%llu anchors %d\n", x, n_units, mine.size(), u.ref.hsps.size(), ctr[x].extended, u.ref.extended,
+                       ctr[x].cols, u.ref.cols, (int)anchors_ok);
+                for (size_t i = 0; i < std::min(mine.size(), u.ref.hsps.size()); i++)
+                    if (memcmp(&mine[i], &u.ref.hsps[i], sizeof(mb::DevHsp)) != 0) {
+                        printf("  first differing hsp %zu: got t %d q %d len %d score %d seed %d/%d | want t %d q %d len %d score %d seed %d/%d\n", i, mine[i].t_start,
+                               mine[i].q_start, mine[i].len, mine[i].score, mine[i].seed_t_end, mine[i].seed_q_end, u.ref.hsps[i].t_start, u.ref.hsps[i].q_start,
+                               u.ref.hsps[i].len, u.ref.hsps[i].score, u.ref.hsps[i].seed_t_end, u.ref.hsps[i].seed_q_end);
+                        break;
+                    }
+                for (size_t d = 0; d < ext.size(); d++)
+                    if (ext[d] != u.ref.extent[d]) { printf("  first differing extent: diagonal %zu got %d want %d\n", d, ext[d], u.ref.extent[d]); break; }
+            }
         }
+        printf("case %d: %d unit(s) hits %lld runs %u xdrop %d K %d  hsps %zu/%zu  %s\n", cs, n_units, (long long)n_hits,
+               n_heads[0] + n_heads[1] + n_heads[2] + n_heads[3], xdrop, K, total_hsps, total_ref, all_ok ? "ok" : "MISMATCH");
+        if (!all_ok) bad++;
     }
     return bad ? 1 : 0;
 }

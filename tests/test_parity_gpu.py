@@ -63,6 +63,59 @@ def test_every_ungapped_kernel_matches_oracle(gpu_ctx, olz, monkeypatch, kernel)
             assert got.stats[k] == want["counters"][k], (k, args, cap)
 
 
+@pytest.mark.parametrize("name,tf,qf,args", CASES, ids=CASE_IDS)
+def test_case_matches_oracle_through_the_batched_seed_stage(gpu_ctx, olz, monkeypatch, name, tf, qf, args):
+    """The seed stage that the pairs of a batched call share (seed_phase_batched: sparse seed tables, one seed search, one sort, one
+    launch of the ungapped kernels over all (pair, strand) units) forced on every single case: same bytes, HSP list in discovery
+    order and counters as the oracle's."""
+    monkeypatch.setenv("MIBLAST_SEED_BATCHED", "2")
+    monkeypatch.setenv("MIBLAST_CHECK_ANCHORS", "1")
+    pm = _params(args)
+    T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+    got = gpu_ctx.align(T, Q, pm)
+    want = olz.align(tf, qf, _oracle_params(olz, pm))
+    assert got.hsps == want["hsps"]
+    assert got.paf == want["paf"]
+    assert got.alns == want["alns"] and got.ops == want["ops"]
+    for k in COUNTERS:
+        assert got.stats[k] == want["counters"][k], k
+
+
+@pytest.mark.parametrize("kernel", ["lane", "ux", "grp"])
+@pytest.mark.parametrize("batched", ["1", "0"])
+def test_batched_call_with_every_ungapped_kernel_matches_oracle(gpu_ctx, olz, monkeypatch, kernel, batched):
+    """Several pairs in one call -- shared targets, a pair without a hit, an empty query, many contigs, two pairs of one genome
+    against itself -- with each short-run kernel forced in turn, through the shared seed stage and (MIBLAST_SEED_BATCHED=0) pair by
+    pair on the lanes: every pair's bytes, HSPs and counters are the oracle's for that pair alone."""
+    from cases import DEFAULT, multi_contig, pair
+    from cactus_amd import gen
+    monkeypatch.setenv("MIBLAST_UNGAPPED", kernel)
+    monkeypatch.setenv("MIBLAST_SEED_BATCHED", batched)
+    monkeypatch.setenv("MIBLAST_CHECK_ANCHORS", "1")
+    a, b, c = pair(60000, 3), pair(40000, 5, sub_rate=0.05), multi_contig(9)
+    t, q = gen.make_pair(50000, 17, homologous=False)
+    chance = (gen.fasta_bytes([("T|c0", t)]), gen.fasta_bytes([("Q|c0", q)]))
+    fastas = [a, (a[0], b[1]), c, chance, (b[0], b""), (a[0], a[0]), b, (c[0], a[1])]
+    for args in (DEFAULT, ["--step=2", "--notransition", "--ydrop=3000"]):
+        pm = _params(args)
+        cache = {}
+        sets = []
+        for tf, qf in fastas:
+            for fa in (tf, qf):
+                if fa not in cache:
+                    cache[fa] = gpu_ctx.seqset_from_fasta_bytes(fa)
+            sets.append((cache[tf], cache[qf]))
+        got = gpu_ctx.align_pairs(sets, pm, details=True)
+        for (tf, qf), r in zip(fastas, got):
+            want = olz.align(tf, qf, _oracle_params(olz, pm))
+            assert r.hsps == want["hsps"]
+            assert r.paf == want["paf"]
+            for k in COUNTERS:
+                assert r.stats[k] == want["counters"][k], (k, args)
+        for h in cache.values():
+            h.close()
+
+
 @pytest.mark.parametrize("step", [1, 2, 5])
 def test_seed_index_matches_oracle(gpu_ctx, olz, step):
     from cases import multi_contig, pair

@@ -27,3 +27,14 @@ def test_emulated_ungapped_kernels_match_the_sequential_rule(mode, seed, cases):
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()
     assert out.count(" ok\n") == cases and "MISMATCH" not in out, out
+
+
+def test_emulated_batched_seed_stage_matches_the_rule():
+    """cactus_amd/csrc/mb_seed_batch.h on the host: the sparse seed tables of several targets (bitmap + rank directory + CSR) hold
+    exactly the positions SURVEY A.3 indexes, and the seed search over all (pair, strand) units of a call writes, unit by unit in
+    q order, exactly the hits of SURVEY A.4 (every word variant, every position of its bucket)."""
+    subprocess.run(["make", "-C", EMU_DIR, "emu_seed_batch"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_seed_batch"), "11", "3"], capture_output=True, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert out.count(" ok\n") == 3 and "MISMATCH" not in out, out
