@@ -146,7 +146,7 @@ class EvolverPhase:
                 for tf, qf in pairs:
                     s = []
                     for fa in (tf, qf):
-                        h = self.resident.get(fa)
+                        h = fa if isinstance(fa, self.miblast.SeqSet) else self.resident.get(fa)      # (a trimmed query is a resident set already)
                         if h is None:
                             h = cx.seqset_from_fasta_bytes(fa)
                             with lock:
@@ -164,6 +164,18 @@ class EvolverPhase:
                       f"t_gapped {rs[0].stats['t_gapped'] * 1e3:.2f}, dp {rs[0].stats['t_dp_kernel_ms']:.2f}, max t_seed+index {max(r.stats['t_seed'] + r.stats['t_index'] for r in rs) * 1e3:.2f}", file=sys.stderr)
             return [r.paf for r in rs]
 
+        def trim_resident(items, min_size, flank):
+            """what is left of every chain's ingroup after its previous call, cut out on the device (miblast_seqsets_unaligned)"""
+            t0 = time.perf_counter()
+            qs = [q if isinstance(q, self.miblast.SeqSet) else self.resident[q] for q, _ in items]
+            outs = self.contexts[0].seqsets_unaligned(qs, [paf for _, paf in items], min_size, flank)
+            made.extend(o for o in outs if o is not None)
+            if TIMELINE:
+                print(f"[bench] trim_resident of {len(items)} chains: {(time.perf_counter() - t0) * 1e3:.2f} ms", file=sys.stderr)
+            return outs
+
+        if os.environ.get("MIBLAST_BENCH_TEXT_TRIM", "0") == "0":
+            align_batch.trim_resident = trim_resident
         align_batch.concurrent = len(self.contexts)
         align_batch.split_above = int(os.environ.get("MIBLAST_BENCH_SPLIT", "0")) if len(self.contexts) > 1 else 0
         res = self.bp.run_blast_phase(self.fasta, self.calls, self.options, align_batch, *self.trim,

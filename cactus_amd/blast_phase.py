@@ -245,6 +245,12 @@ def invert(paf: bytes) -> bytes:
 AlignBatch = Callable[[List[Tuple[bytes, bytes]], str], List[bytes]]
 
 
+def as_fasta(query) -> bytes:
+    """FASTA bytes of a query of the phase: the bytes themselves, or the text of a resident set of the aligner's (a handle made by
+    align_batch.trim_resident; anything with fasta_bytes())"""
+    return query if isinstance(query, (bytes, bytearray)) else query.fasta_bytes()
+
+
 _POOL = None
 
 
@@ -263,7 +269,10 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     of (target FASTA, query FASTA) with ONE option set and returns their PAF bytes in order -- calls of one dependency level
     that share an option set are handed over together (they are independent Toil jobs in the reference; a GPU runs them as one
     batched call).  Returns per node {"ingroup": PAF of the ingroup pairs, "outgroup": the inverted ingroup->outgroup PAF
-    (make_ingroup_to_outgroup_alignments_0)}.  on_call(call, target_fa, query_fa, paf) sees every single call (parity checks)."""
+    (make_ingroup_to_outgroup_alignments_0)}.  on_call(call, target_fa, query_fa, paf) sees every single call (parity checks).
+    An aligner that keeps its sequences resident may offer align_batch.trim_resident(items, min_size, flank) -- items = [(query
+    of the chain's previous call, its PAF)] -- and return, per item, a handle of its own for what is left of the query (falsy:
+    nothing); such a handle comes back as the query of the chain's next pair and must offer fasta_bytes() for on_call."""
     raw: Dict[int, bytes] = {}
     query_fa: Dict[int, bytes] = {}
     current: Dict[Tuple[str, str], bytes] = {}                # (node, ingroup) -> what is left of the ingroup for the next outgroup
@@ -280,7 +289,15 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         trimmed = {}
         if level > 0:
             idx = [i for i, c in enumerate(calls) if c.level == level and c.kind != "ingroup"]
-            outs = pool.map(lambda i: unaligned_fasta(last_paf[calls[i].chain][1], last_paf[calls[i].chain][0], trim_min_size, trim_flanking), idx)
+            trim_resident = getattr(align_batch, "trim_resident", None)
+            if trim_resident is not None:
+                # the aligner keeps the sequences on its device: what is left of every chain's ingroup is cut out there, all chains
+                # of the level in one call (miblast_seqsets_unaligned); a query is then a handle of the aligner's, not FASTA bytes
+                live = [i for i in idx if last_paf[calls[i].chain][0]]                        # (a chain with nothing left stays empty)
+                got = dict(zip(live, trim_resident([last_paf[calls[i].chain] for i in live], trim_min_size, trim_flanking))) if live else {}
+                outs = [got.get(i) for i in idx]
+            else:
+                outs = pool.map(lambda i: unaligned_fasta(last_paf[calls[i].chain][1], last_paf[calls[i].chain][0], trim_min_size, trim_flanking), idx)
             trimmed = dict(zip(idx, outs))                                                      # make_ingroup_to_outgroup_alignments_2
         for i, c in enumerate(calls):
             if c.level != level:
@@ -334,7 +351,7 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
                     # now: it runs beside the next level's calls instead of after the last one
                     finished[i] = pool.submit(chain_share, paf, level)
                 if on_call is not None:
-                    on_call(calls[i], genomes[calls[i].target], query_fa[i], paf)
+                    on_call(calls[i], genomes[calls[i].target], as_fasta(query_fa[i]), paf)
     # assemble: outgroup chains are merged innermost first (each level's sub-sequence coordinates fixed by dechunk --query,
     # make_ingroup_to_outgroup_alignments_3), then inverted so that the ingroup is the target
     result: Dict[str, Dict[str, bytes]] = {}

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <fstream>
 #include <new>
 #include <unistd.h>
@@ -281,6 +282,57 @@ int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_s
     return guarded([&]() -> int {
         int rc = read_fasta_file(path, data);
         return rc != MIBLAST_OK ? rc : miblast_seqset_from_fasta_mem(ctx, data.data(), data.size(), out);
+    });
+}
+
+int miblast_seqsets_unaligned(miblast_ctx *ctx, size_t n, const miblast_seqset *const *queries, const char *const *pafs, const size_t *paf_lens,
+                              int64_t min_size, int64_t flank, miblast_seqset **out) {
+    if (!ctx || !out || (n && (!queries || !pafs || !paf_lens))) return MIBLAST_EINVAL;
+    for (size_t k = 0; k < n; k++) { out[k] = nullptr; if (!queries[k] || (!pafs[k] && paf_lens[k])) return MIBLAST_EINVAL; }
+    return guarded([&]() -> int {
+        std::vector<const mb::SeqSet *> qs(n);
+        std::vector<miblast_seqset *> made(n, nullptr);
+        std::vector<mb::SeqSet *> outs(n);
+        std::unique_ptr<bool[]> none(new bool[n + 1]);
+        for (size_t k = 0; k < n; k++) { qs[k] = &queries[k]->s; made[k] = new miblast_seqset(); outs[k] = &made[k]->s; }
+        int rc;
+        try {
+            rc = mb::seqset_unaligned(ctx->c, n, qs.data(), pafs, paf_lens, min_size, flank, outs.data(), none.get());
+        } catch (...) {
+            for (miblast_seqset *m : made) delete m;
+            throw;
+        }
+        for (size_t k = 0; k < n; k++) {
+            if (rc == MIBLAST_OK && !none[k]) out[k] = made[k];
+            else { if (made[k]->s.d_buf) mb::release_seqset(made[k]->s); delete made[k]; }
+        }
+        return rc;
+    });
+}
+
+int miblast_seqset_fasta(const miblast_seqset *s, char **text, size_t *len) {
+    if (!s || !text || !len) return MIBLAST_EINVAL;
+    *text = nullptr; *len = 0;
+    return guarded([&]() -> int {
+        static const char kLetter[16] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N', 'a', 'c', 'g', 't', 'n', 'n', 'n', 'n'};
+        const mb::SeqSet &q = s->s;
+        std::string out;
+        out.reserve((size_t)q.total + (size_t)q.total / 60 + 64 * q.names.size() + 16);
+        for (size_t k = 0; k < q.names.size(); k++) {
+            out += '>'; out += q.names[k]; out += '\n';
+            const uint8_t *c = q.host() + q.starts[k];
+            for (int64_t x = 0; x < q.lens[k]; x += 60) {
+                const int64_t w = std::min<int64_t>(60, q.lens[k] - x);
+                for (int64_t y = 0; y < w; y++) out += kLetter[c[x + y] & 15u];
+                out += '\n';
+            }
+        }
+        char *buf = (char *)malloc(out.size() + 1);
+        if (!buf) { mb::set_error("out of host memory"); return MIBLAST_ELIMIT; }
+        memcpy(buf, out.data(), out.size());
+        buf[out.size()] = 0;
+        *text = buf; *len = out.size();
+        return MIBLAST_OK;
     });
 }
 

@@ -237,6 +237,9 @@ void launch_batch_seed_count(const SeedUnit *units, int n_units, const BatchTarg
 void launch_batch_seed_fill(const SeedUnit *units, int n_units, const BatchTarget *tg, const unsigned long long *bits, const uint32_t *dir,
                             const uint32_t *starts, const uint32_t *positions, int transitions, int64_t q_slots, const uint32_t *hit_off,
                             unsigned long long *keys, hipStream_t s);
+void launch_cov_mark(const long long *spans, int n, uint32_t *diff, hipStream_t s);
+void launch_cov_edges(const uint32_t *depth, const uint8_t *codes, int64_t total, unsigned *n_edges, long long *first, long long *last, unsigned cap, hipStream_t s);
+void launch_gather_stretches(const uint8_t *src, uint8_t *dst, const long long *iv, int n_iv, int64_t total, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int begin_bit, int end_bit,
                hipStream_t s);

@@ -428,6 +428,53 @@ void launch_batch_seed_fill(const SeedUnit *units, int n_units, const BatchTarge
     MB_HIP(hipGetLastError());
 }
 
+// ---- outgroup trimming on the device (/root/reference/src/cactus/paf/local_alignment.py:460-499) -------------------
+// Per-base coverage of a query set by the query intervals of a call's alignments, kept on the device between two blast calls: the
+// intervals are marked as +1 / -1 in a difference array, its prefix sum is the depth of every base, and the maximal uncovered
+// stretches come out as their first and last+1 positions (unordered; the handful of them is sorted on the host).
+__global__ __launch_bounds__(256) void k_cov_mark(const long long *__restrict__ spans, const int n, uint32_t *__restrict__ diff) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    atomicAdd(&diff[spans[2 * k]], 1u);
+    atomicAdd(&diff[spans[2 * k + 1]], 0xFFFFFFFFu);                     // -1 (the prefix sums never go below zero)
+}
+
+// depth[p + 1] = number of intervals over base p (exclusive scan of diff, one entry further on)
+__global__ __launch_bounds__(256) void k_cov_edges(const uint32_t *__restrict__ depth, const uint8_t *__restrict__ codes, const long long total,
+                                                    unsigned *__restrict__ n_edges, long long *__restrict__ first, long long *__restrict__ last,
+                                                    const unsigned cap) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    auto open = [&](long long x) -> bool { return x >= 0 && x < total && depth[x + 1] == 0u && codes[x] != kSep; };
+    if (!open(p)) return;
+    if (!open(p - 1)) { const unsigned at = atomicAdd(&n_edges[0], 1u); if (at < cap) first[at] = p; }
+    if (!open(p + 1)) { const unsigned at = atomicAdd(&n_edges[1], 1u); if (at < cap) last[at] = p + 1; }
+}
+
+// the bases of the kept stretches, one after the other with a separator between two stretches: iv = (dst, src, len) triples by dst
+__global__ __launch_bounds__(256) void k_gather_stretches(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const long long *__restrict__ iv,
+                                                           const int n_iv, const long long total) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    int lo = 0, hi = n_iv - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (iv[3 * mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const long long off = p - iv[3 * lo];
+    dst[p] = off < iv[3 * lo + 2] ? src[iv[3 * lo + 1] + off] : kSep;
+}
+
+void launch_cov_mark(const long long *spans, int n, uint32_t *diff, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_cov_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spans, n, diff);
+}
+void launch_cov_edges(const uint32_t *depth, const uint8_t *codes, int64_t total, unsigned *n_edges, long long *first, long long *last, unsigned cap, hipStream_t s) {
+    if (total > 0) hipLaunchKernelGGL(k_cov_edges, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, depth, codes, (long long)total, n_edges, first, last, cap);
+}
+void launch_gather_stretches(const uint8_t *src, uint8_t *dst, const long long *iv, int n_iv, int64_t total, hipStream_t s) {
+    if (total > 0 && n_iv > 0) hipLaunchKernelGGL(k_gather_stretches, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, iv, n_iv, (long long)total);
+}
+
 size_t sort_keys_temp_bytes(int64_t n, int end_bit) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0,
@@ -674,7 +721,9 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     // MIBLAST_UNGAPPED=lane|ux|grp forces one.
     const char *fe = getenv("MIBLAST_UNGAPPED");                                  // (read per launch: the tests switch it)
     const int forced = !fe ? 0 : !strcmp(fe, "lane") ? 1 : !strcmp(fe, "ux") ? 2 : !strcmp(fe, "grp") ? 3 : 0;
-    int mode = forced ? forced : (ux && n_hits >= n_diagonals / 4 && n_hits >= (1 << 19)) ? 2 : 1;
+    // (the pooled hits of a batched call -- several units -- are dense enough for the pipeline whenever they are many: the 9-pair call
+    //  of the evolver phase, 4.9 x 10^6 hits on 2.2 x 10^7 diagonals, 1.28 ms against 2.08 ms with a run per lane)
+    int mode = forced ? forced : (ux && n_hits >= (1 << 19) && (ut.n > 1 || n_hits >= n_diagonals / 4)) ? 2 : 1;
     if (mode == 2 && (!ux || xdrop >= (1 << 24))) mode = 1;
     if (mode == 1) {
         const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;               // upper bound: sum over classes of ceil(runs / 256)

@@ -246,26 +246,31 @@ struct Unit {                  // one (pair, query contig, strand): anchors are 
 };
 
 // independent work items on a few persistent host threads (merging traces, formatting PAF, anchors: all embarrassingly
-// parallel).  The caller takes part; nested calls run inline.
+// parallel).  The caller takes part; nested calls run inline.  Several parallel regions may be open at a time (the gapped stages of
+// two groups of a call's pairs, calls on several contexts): the workers serve whichever has items left.
 class Pool {
+    struct Job {
+        const std::function<void(size_t)> *fn;
+        size_t n;
+        std::atomic<size_t> next{0}, done{0};
+        std::atomic<int> refs{0};                 // workers that hold a pointer to the job
+    };
     std::vector<std::thread> th;
-    std::mutex m, run_m;
-    std::condition_variable cv, done_cv;
-    const std::function<void(size_t)> *fn = nullptr;
-    size_t n = 0;
-    std::atomic<size_t> next{0};
-    size_t busy = 0;
-    size_t sleepers = 0;                      // workers blocked on cv (under m)
-    unsigned long long gen = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<Job *> open_jobs;                // under m
+    size_t sleepers = 0;                          // workers blocked on cv (under m)
+    unsigned long long gen = 0;                   // bumped with every new job (under m)
     std::atomic<unsigned long long> gen_a{0};
-    std::atomic<int> hot_a{0};                // > 0 while a job is in flight: idle workers spin instead of sleeping
+    std::atomic<int> hot_a{0};                    // > 0 while an alignment call is in flight: idle workers spin a little before they sleep
     std::atomic<bool> stop_a{false};
     bool stop = false;
+    std::atomic<int> regions{0};                  // parallel regions open right now
     void worker() {
         unsigned long long seen = 0;
         for (;;) {
-            // While a job is in flight an idle worker spins for a few tens of microseconds (the parallel regions of a job follow
-            // each other closely), then sleeps: a job is mostly GPU waits, and workers that spin through them burn the CPU quota
+            // While a call is in flight an idle worker spins for a few tens of microseconds (the parallel regions of a call follow
+            // each other closely), then sleeps: a call is mostly GPU waits, and workers that spin through them burn the CPU quota
             // of the container (a 16-CPU cgroup throttled the process for 10 ms every few calls with 15 spinning workers).
             for (unsigned spins = 0;;) {
                 if (gen_a.load(std::memory_order_acquire) != seen || stop_a.load(std::memory_order_relaxed)) break;
@@ -276,20 +281,18 @@ class Pool {
                 sleepers--;
                 spins = 0;
             }
-            const std::function<void(size_t)> *f;
-            size_t cnt;
-            {
-                std::lock_guard<std::mutex> lk(m);
-                if (stop) return;
-                if (gen == seen) continue;
-                seen = gen; f = fn; cnt = n;
-                if (!f) continue;                                   // the region is already over
-                busy++;
-            }
-            for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < cnt;) (*f)(i);
-            {
-                std::lock_guard<std::mutex> lk(m);
-                if (--busy == 0) done_cv.notify_all();
+            for (;;) {                                               // serve the open jobs until none has an item left
+                Job *j = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    if (stop) return;
+                    seen = gen;
+                    for (Job *c : open_jobs)
+                        if (c->next.load(std::memory_order_relaxed) < c->n) { j = c; j->refs.fetch_add(1, std::memory_order_relaxed); break; }
+                }
+                if (!j) break;
+                for (size_t i; (i = j->next.fetch_add(1, std::memory_order_relaxed)) < j->n;) { (*j->fn)(i); j->done.fetch_add(1, std::memory_order_release); }
+                j->refs.fetch_sub(1, std::memory_order_release);
             }
         }
     }
@@ -328,47 +331,50 @@ public:
     void spawn(unsigned total) {                                   // `total` threads including the caller
         for (unsigned t = 1; t < total; t++) th.emplace_back([this] { worker(); });
     }
-    // change the number of threads (caller included); refused while a job keeps the workers awake
+    // change the number of threads (caller included); refused while a call keeps the workers awake or a region is open
     bool resize(unsigned total) {
-        std::unique_lock<std::mutex> one(run_m, std::try_to_lock);
-        if (!one.owns_lock() || hot_a.load() > 0) return false;
+        if (hot_a.load() > 0 || regions.load() > 0) return false;
         if (total == 0) total = default_threads();
         total = std::min(64u, std::max(1u, total));
         if (total == threads()) return true;
         join_all();
-        {
-            std::lock_guard<std::mutex> lk(m);                      // a fresh generation: new workers start in step with it
-            fn = nullptr; n = 0;
-        }
         spawn(total);
         return true;
     }
-    struct Hot {                              // keeps the workers awake for the duration of a job
+    struct Hot {                              // keeps the workers awake for the duration of a call
         Hot() { Pool &p = get(); p.hot_a++; }
         ~Hot() { get().hot_a--; }
     };
     void run(size_t count, const std::function<void(size_t)> &f) {
         static thread_local bool inside = false;
         if (count <= 1 || th.empty() || inside) { for (size_t i = 0; i < count; i++) f(i); return; }
-        std::unique_lock<std::mutex> one(run_m, std::try_to_lock);      // one parallel region at a time; others run inline
-        if (!one.owns_lock()) { for (size_t i = 0; i < count; i++) f(i); return; }
         inside = true;
+        regions++;
+        Job job;
+        job.fn = &f; job.n = count;
         bool wake;
         {
             std::lock_guard<std::mutex> lk(m);
-            fn = &f; n = count; next.store(0, std::memory_order_relaxed); gen++; busy++;
+            open_jobs.push_back(&job);
+            gen++;
             gen_a.store(gen, std::memory_order_release);
             wake = sleepers > 0;
         }
         if (wake) cv.notify_all();
-        for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count;) f(i);
-        for (bool first = true;; first = false) {                       // the stragglers finish within microseconds: spin
-            std::unique_lock<std::mutex> lk(m);
-            if (first) --busy;
-            if (busy == 0) { fn = nullptr; n = 0; break; }
-            lk.unlock();
-            __builtin_ia32_pause();
+        try {
+            for (size_t i; (i = job.next.fetch_add(1, std::memory_order_relaxed)) < count;) { f(i); job.done.fetch_add(1, std::memory_order_release); }
+        } catch (...) {
+            // (the items are not supposed to throw; if one does, the job still has to leave the list before the stack unwinds)
+            job.next.store(count, std::memory_order_relaxed);
+            { std::lock_guard<std::mutex> lk(m); open_jobs.erase(std::find(open_jobs.begin(), open_jobs.end(), &job)); }
+            while (job.refs.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+            regions--; inside = false;
+            throw;
         }
+        { std::lock_guard<std::mutex> lk(m); open_jobs.erase(std::find(open_jobs.begin(), open_jobs.end(), &job)); }
+        // the stragglers finish within microseconds: spin
+        while (job.done.load(std::memory_order_acquire) < count || job.refs.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+        regions--;
         inside = false;
     }
 };
@@ -545,6 +551,10 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<BatchTarget> bx_targets;
     DevBuf<SeedUnit> bx_units;
     PinBuf<unsigned long long> pin_scan;
+    // outgroup trimming on the device (seqset_unaligned)
+    DevBuf<uint32_t> cov_diff, cov_depth;
+    DevBuf<long long> cov_spans, cov_first, cov_last, cov_iv;
+    DevBuf<unsigned> cov_n;
     // gapped
     DevBuf<DpProb> probs;
     DevBuf<int> dp_order;                     // a crowded DP launch: piece of block b (longest first)
@@ -591,6 +601,175 @@ void workspace_destroy(Workspace *w) {
         delete c;
     }
     delete w;
+}
+
+// ---- outgroup trimming between two blast calls, on the device --------------------------------------------------
+// `paffy to_bed --excludeAligned --minSize N` + `faffy extract --flank F` (/root/reference/src/cactus/paf/local_alignment.py:460-499)
+// without the round trip PAF text -> BED -> FASTA text -> parse -> upload: the per-base coverage of the resident query set by the
+// alignments' query intervals is taken on the device (difference array, prefix sum), the maximal uncovered stretches come back as
+// a few numbers, the rule of the reference's two tools is applied to them (at least min_size long; widened by flank; widened
+// stretches that touch are one), and the kept stretches are gathered on the device into a new resident set whose records are named
+// NAME|SEQLEN|START like faffy's.  Same set -- names, lengths, codes -- as mipaf_unaligned_fasta + miblast_seqset_from_fasta_mem.
+// The chains of a dependency level are trimmed in ONE call: every item's kernels are queued before the first of the two
+// synchronisations (edges back; gathers done).
+int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *const *pafs, const size_t *paf_lens, int64_t min_size, int64_t flank,
+                     SeqSet *const *outs, bool *nothing_left) {
+    MB_HIP(hipSetDevice(ctx.device));
+    Workspace &w = *ctx.ws;
+    hipStream_t s = ctx.stream;
+    w.stage.abort();
+    struct Item {
+        std::vector<long long> spans, first, last, iv;
+        unsigned cap = 0, n_edges[2] = {0, 0};
+        size_t off_depth = 0, off_spans = 0, off_edges = 0, off_iv = 0;      // the item's share of the workspace arrays
+        int rc = MIBLAST_OK;
+        std::string err;
+    };
+    std::vector<Item> items(n);
+    // ---- query intervals of the alignments, in each set's concatenated coordinates (text work: on the worker threads)
+    parallel_for(n, [&](size_t k) {
+        Item &it = items[k];
+        const SeqSet &Q = *Qs[k];
+        nothing_left[k] = true;
+        if (Q.device != ctx.device) { it.rc = MIBLAST_EINVAL; it.err = "sequence set lives on another device"; return; }
+        std::unordered_map<std::string, size_t> by_name;
+        for (size_t c = 0; c < Q.names.size(); c++)
+            if (!by_name.emplace(Q.names[c], c).second) { it.rc = MIBLAST_EINVAL; it.err = "to_bed: sequence name " + Q.names[c] + " occurs twice in the query set"; return; }
+        const char *paf = pafs[k];
+        const size_t paf_len = paf_lens[k];
+        size_t line_no = 0;
+        for (size_t pos = 0; pos < paf_len;) {
+            const char *nl = (const char *)memchr(paf + pos, '\n', paf_len - pos);
+            const size_t end = nl ? (size_t)(nl - paf) : paf_len;
+            line_no++;
+            const size_t p0 = pos;
+            pos = end + 1;
+            bool blank = true;
+            for (size_t x = p0; x < end && blank; x++) blank = paf[x] == ' ' || paf[x] == '\t' || paf[x] == '\r';
+            if (blank) continue;
+            const char *t[4];
+            bool ok = true;
+            size_t c = p0;
+            for (int f = 0; f < 4 && ok; f++) {
+                t[f] = (const char *)memchr(paf + c, '\t', end - c);
+                if (!t[f]) ok = false; else c = (size_t)(t[f] - paf) + 1;
+            }
+            if (!ok) { it.rc = MIBLAST_EINVAL; it.err = "to_bed: PAF line " + std::to_string(line_no) + " has fewer than 5 columns"; return; }
+            const std::string name(paf + p0, (size_t)(t[0] - (paf + p0)));
+            const auto f = by_name.find(name);
+            if (f == by_name.end()) { it.rc = MIBLAST_EINVAL; it.err = "to_bed: PAF line " + std::to_string(line_no) + ": query " + name + " is not in the query set"; return; }
+            const int64_t len = Q.lens[f->second];
+            const int64_t s0 = std::min(len, std::max<int64_t>(0, strtoll(t[1] + 1, nullptr, 10))), e0 = std::min(len, std::max<int64_t>(0, strtoll(t[2] + 1, nullptr, 10)));
+            if (e0 > s0) { it.spans.push_back(Q.starts[f->second] + s0); it.spans.push_back(Q.starts[f->second] + e0); }
+        }
+        it.cap = (unsigned)std::min<size_t>(it.spans.size() / 2 + Q.names.size() + 2, 0x7fffffffu);
+    });
+    for (const Item &it : items) if (it.rc != MIBLAST_OK) { set_error(it.err); return it.rc; }
+    // ---- coverage on the device, edges of the uncovered stretches back
+    size_t n_depth = 0, n_sp = 0, n_ed = 0, scan_tiles = 0;
+    for (size_t k = 0; k < n; k++) {
+        Item &it = items[k];
+        it.off_depth = n_depth; it.off_spans = n_sp; it.off_edges = n_ed;
+        n_depth += (((size_t)Qs[k]->total + 2) + 7) & ~(size_t)7;                 // (16-byte aligned shares: the scan loads uint4)
+        n_sp += it.spans.size() + 2; n_ed += it.cap;
+        scan_tiles = std::max(scan_tiles, (size_t)((Qs[k]->total + 2 + 2047) / 2048) + 2);
+    }
+    w.cov_diff.ensure(n_depth + 8); w.cov_depth.ensure(n_depth + 8);
+    w.cov_spans.ensure(n_sp + 2); w.cov_first.ensure(n_ed + 1); w.cov_last.ensure(n_ed + 1); w.cov_n.ensure(2 * n + 2);
+    w.bx_scan.ensure(n * scan_tiles + 2);
+    MB_HIP(hipMemsetAsync(w.cov_diff.p, 0, (n_depth + 8) * 4, s));
+    MB_HIP(hipMemsetAsync(w.cov_n.p, 0, (2 * n + 2) * sizeof(unsigned), s));
+    for (size_t k = 0; k < n; k++) {
+        Item &it = items[k];
+        const int64_t total = Qs[k]->total;
+        if (total <= 0) continue;
+        it.first.resize(it.cap); it.last.resize(it.cap);
+        w.stage.h2d(w.cov_spans.p + it.off_spans, it.spans.data(), it.spans.size() * sizeof(long long), s);
+        launch_cov_mark(w.cov_spans.p + it.off_spans, (int)(it.spans.size() / 2), w.cov_diff.p + it.off_depth, s);
+        launch_scan_u32(w.cov_diff.p + it.off_depth, w.cov_depth.p + it.off_depth, total + 2, w.bx_scan.p + k * scan_tiles, s);
+        launch_cov_edges(w.cov_depth.p + it.off_depth, Qs[k]->dev(), total, w.cov_n.p + 2 * k, w.cov_first.p + it.off_edges, w.cov_last.p + it.off_edges, it.cap, s);
+        w.stage.d2h(it.n_edges, w.cov_n.p + 2 * k, 8, s);
+        w.stage.d2h(it.first.data(), w.cov_first.p + it.off_edges, (size_t)it.cap * sizeof(long long), s);
+        w.stage.d2h(it.last.data(), w.cov_last.p + it.off_edges, (size_t)it.cap * sizeof(long long), s);
+    }
+    MB_HIP(hipStreamSynchronize(s));                                           // (1) the edges of every item
+    w.stage.done();
+    // ---- the rule of the two tools on the uncovered stretches, contig by contig; host images of the new sets
+    struct Iv { size_t contig; int64_t s, e; };
+    std::vector<std::vector<Iv>> keeps(n);
+    for (size_t k = 0; k < n; k++) {
+        Item &it = items[k];
+        const SeqSet &Q = *Qs[k];
+        if (it.n_edges[0] != it.n_edges[1] || it.n_edges[0] > it.cap) { set_error("internal: coverage edges do not pair up"); return MIBLAST_EHIP; }
+        it.first.resize(it.n_edges[0]); it.last.resize(it.n_edges[0]);
+        std::sort(it.first.begin(), it.first.end()); std::sort(it.last.begin(), it.last.end());
+        std::vector<Iv> &keep = keeps[k];
+        for (size_t x = 0; x < it.first.size(); x++) {
+            const int cg = Q.contig_of(it.first[x]);
+            if (cg < 0) continue;
+            const int64_t c0 = Q.starts[(size_t)cg], len = Q.lens[(size_t)cg];
+            int64_t a = it.first[x] - c0, b = it.last[x] - c0;
+            if (b - a < min_size || b <= a) continue;
+            a = std::max<int64_t>(0, a - flank); b = std::min(len, b + flank);
+            if (!keep.empty() && keep.back().contig == (size_t)cg && a <= keep.back().e) keep.back().e = std::max(keep.back().e, b);
+            else keep.push_back(Iv{(size_t)cg, a, b});
+        }
+    }
+    size_t n_iv = 0;
+    for (size_t k = 0; k < n; k++) { items[k].off_iv = n_iv; n_iv += 3 * keeps[k].size(); }
+    w.cov_iv.ensure(n_iv + 3);
+    parallel_for(n, [&](size_t k) {
+        const std::vector<Iv> &keep = keeps[k];
+        if (keep.empty()) return;
+        const SeqSet &Q = *Qs[k];
+        SeqSet &out = *outs[k];
+        out.names.clear(); out.starts.clear(); out.lens.clear(); out.codes.clear();
+        out.view = nullptr; out.origin = 0;
+        int64_t new_total = 0;
+        for (size_t x = 0; x < keep.size(); x++) new_total += (keep[x].e - keep[x].s) + (x ? 1 : 0);
+        out.codes.resize((size_t)new_total + 2);
+        out.codes[0] = kSep;
+        std::vector<long long> &iv = items[k].iv;
+        iv.resize(3 * keep.size());
+        int64_t at = 0;
+        for (size_t x = 0; x < keep.size(); x++) {
+            const Iv &v = keep[x];
+            if (x) out.codes[(size_t)(1 + at++)] = kSep;
+            out.names.push_back(Q.names[v.contig] + "|" + std::to_string(Q.lens[v.contig]) + "|" + std::to_string(v.s));
+            out.starts.push_back(at); out.lens.push_back(v.e - v.s);
+            iv[3 * x] = at; iv[3 * x + 1] = Q.starts[v.contig] + v.s; iv[3 * x + 2] = v.e - v.s;
+            memcpy(out.codes.data() + 1 + at, Q.host() + Q.starts[v.contig] + v.s, (size_t)(v.e - v.s));
+            at += v.e - v.s;
+        }
+        out.codes[(size_t)new_total + 1] = kSep;
+        out.total = new_total;
+    });
+    // ---- device images gathered from the resident sets
+    bool any = false;
+    try {
+        for (size_t k = 0; k < n; k++) {
+            if (keeps[k].empty()) continue;
+            any = true;
+            nothing_left[k] = false;
+            SeqSet &out = *outs[k];
+            out.device = ctx.device;
+            const size_t nc = out.starts.size();
+            const size_t seq_bytes = ((size_t)out.total + 2 * kDevPad + 255) & ~(size_t)255, image = seq_bytes + 2 * nc * sizeof(int64_t);
+            out.d_buf = (uint8_t *)device_blocks().take(ctx.device, image, out.d_cap);
+            out.d_starts = (int64_t *)(out.d_buf + seq_bytes);
+            out.d_lens = out.d_starts + nc;
+            MB_HIP(hipMemsetAsync(out.d_buf, 0xFF, seq_bytes, s));
+            w.stage.h2d(w.cov_iv.p + items[k].off_iv, items[k].iv.data(), items[k].iv.size() * sizeof(long long), s);
+            launch_gather_stretches(Qs[k]->dev(), out.d_buf + kDevPad, w.cov_iv.p + items[k].off_iv, (int)keeps[k].size(), out.total, s);
+            w.stage.h2d(out.d_starts, out.starts.data(), nc * sizeof(int64_t), s);
+            w.stage.h2d(out.d_lens, out.lens.data(), nc * sizeof(int64_t), s);
+        }
+        if (any) { MB_HIP(hipStreamSynchronize(s)); w.stage.done(); }         // (2) the new sets are resident
+    } catch (...) {
+        for (size_t k = 0; k < n; k++) if (outs[k]->d_buf) release_seqset(*outs[k]);
+        throw;
+    }
+    return MIBLAST_OK;
 }
 
 struct Index { uint32_t n_positions = 0; };
@@ -1448,12 +1627,15 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
 
 // score-ordered gapped extension of every unit of every pair of the batch: all speculative one-sided DPs of a round
 // share one k_ydrop launch, so several chunk pairs fill the GPU together
-static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, std::vector<Unit> &units) {
+// `members`: the pairs whose units are in `units` (nullptr: all pairs of `jobs`) -- a large call runs the gapped stages of two
+// groups of its pairs side by side, each on a stream and workspace of its own (align_pairs)
+static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, std::vector<Unit> &units, const std::vector<size_t> *members = nullptr) {
     const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 4096);
     const long shadow_q0 = env_long("MIBLAST_SHADOW_Q", 1 << 16);        // spatial thinning of speculative anchors
     // anchors per round the thinning aims at: a lone pair is probed generously (an idle GPU, rounds cost latency); in a batch every
     // pair brings its own heads and further heads on the same alignment only duplicate relay pieces
-    const long spec_target = env_long("MIBLAST_SPEC_TARGET", jobs.size() > 1 ? 6 : 24) * (long)std::max<size_t>(1, jobs.size());
+    const size_t n_members = members ? members->size() : jobs.size();
+    const long spec_target = env_long("MIBLAST_SPEC_TARGET", jobs.size() > 1 ? 6 : 24) * (long)std::max<size_t>(1, n_members);
     const long shadow_d = env_long("MIBLAST_SHADOW_D", 2 * (p.ydrop / std::max(1, p.gap_extend)) + 64);
     const unsigned kBlk = 64u << 10, kBlkWide = 4u << 20;
     // relay hand-over (see the DP section below): first stop, relay spacing, warm-up rows, diagonal tolerance, relays per side
@@ -1527,20 +1709,29 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // new anchor per (diagonal band, query neighbourhood).  The neighbourhood is the smallest of a 4x ladder that
         // keeps the batch within `spec_target` anchors, so an idle GPU is filled with probes in the first round (a
         // single one-sided DP is a row-sequential chain: rounds cost latency, parallel probes cost almost nothing).
-        for (Unit &u : units) {
+        parallel_for(units.size(), [&](size_t ui) {
+            Unit &u = units[ui];
             std::fill(u.tent.begin(), u.tent.end(), 0);
             for (const auto &kv : u.cache) {
                 const Cached &c = kv.second;
                 if (c.accepted) u.mark(u.tent, c.t_lo, c.t_hi, c.q_lo, c.q_hi, c.dmin, c.dmax);
             }
-        }
+        });
         std::vector<Pending> pend;
         long shadow_q = shadow_q0;
+        // (the units are independent: every unit's candidates are picked on the worker threads and strung together in unit order)
+        auto gather = [&](std::vector<std::vector<Pending>> &per, std::vector<Pending> &out) {
+            size_t total = 0;
+            for (const auto &v : per) total += v.size();
+            out.clear(); out.reserve(total);
+            for (const auto &v : per) out.insert(out.end(), v.begin(), v.end());
+        };
         // First round: one head per colinear group of anchors (Unit::index_anchors) -- the best anchor of the group that is still
         // open; its relay chain covers the rest of the group.  Whatever is left uncovered after that round (groups that bridge a
         // stretch the extension does not survive) goes through the spatial thinning below, many at a time.
         if (round == 0 && chain_heads && relay_s0_env != 0) {
-            for (size_t ui = 0; ui < units.size(); ui++) {
+            std::vector<std::vector<Pending>> per(units.size());
+            parallel_for(units.size(), [&](size_t ui) {
                 Unit &u = units[ui];
                 std::vector<uint8_t> taken(u.n_comp, 0);
                 size_t n_taken = 0;
@@ -1549,14 +1740,16 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     if (k != u.next && (u.tent[k] || taken[u.comp[k]])) continue;
                     taken[u.comp[k]] = 1;
                     n_taken++;
-                    pend.push_back(Pending{ui, k});
+                    per[ui].push_back(Pending{ui, k});
                 }
-            }
+            });
+            gather(per, pend);
         }
         for (int level = 0; level < 6 && !(round == 0 && chain_heads && relay_s0_env != 0); level++) {
             std::vector<Pending> cand;
             const long sq = std::max(64l, shadow_q0 >> (2 * level));
-            for (size_t ui = 0; ui < units.size(); ui++) {
+            std::vector<std::vector<Pending>> per(units.size());
+            parallel_for(units.size(), [&](size_t ui) {
                 Unit &u = units[ui];
                 // taken anchors are bucketed on a (diagonal band, query neighbourhood) grid: the shadow test looks at 3x3 cells
                 std::unordered_map<long long, std::vector<Anchor>> grid;
@@ -1582,9 +1775,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     }
                     grid[cell(a, 0, 0)].push_back(a);
                     n_taken++;
-                    cand.push_back(Pending{ui, k});
+                    per[ui].push_back(Pending{ui, k});
                 }
-            }
+            });
+            gather(per, cand);
             if (level > 0 && (long)cand.size() > spec_target) break;      // keep the previous (coarser) level
             pend.swap(cand);
             shadow_q = sq;
@@ -1637,15 +1831,17 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // pieces balance the launch and a rejected hand-over costs one short retry; thousands of sides -- the GPU is full anyway,
         // long pieces waste less on warm-up and relays are only spent on sides that survive relay_s0 rows (16 x 1 Mb pairs, ~600
         // sides: 66 ms per call against 75 ms with the short pieces).
-        const bool crowd = nsides > 400;
+        // (a group of a split call shares the GPU with the other group: the regime follows the sides of the whole call)
+        const long nsides_call = (long)nsides * (long)jobs.size() / (long)std::max<size_t>(1, n_members);
+        const bool crowd = nsides_call > 400;
         // (a handful of sides -- a trimmed outgroup call of the phase: every launch runs at lone-wave speed and most hand-overs are
         //  retried; 448-row pieces: 19 -> 17 DP launches and 10.2 -> 9.4 ms of DP kernel time per phase; 320 and 256 need more launches)
         const long relay_s_tiny = env_long("MIBLAST_RELAY_S_TINY", 448);
-        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides > 96 ? 512 : nsides > 16 ? 640 : relay_s_tiny;
+        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides_call > 96 ? 512 : nsides_call > 16 ? 640 : relay_s_tiny;
         if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
         // (a handful of sides: 384 warm-up rows -- most hand-overs of such a call are rejected after 128, and a retry is a launch of
         //  its own: 17 -> 11 DP launches per phase)
-        if (relay_w_env <= 0) relay_w = crowd ? 192 : nsides > 16 ? 128 : env_long("MIBLAST_RELAY_W_TINY", 384);
+        if (relay_w_env <= 0) relay_w = crowd ? 192 : nsides_call > 16 ? 128 : env_long("MIBLAST_RELAY_W_TINY", 384);
         const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: unless thousands of sides are in flight, 2: always
         const bool plant_at_once = plant_env == 2 || (!crowd && plant_env != 0);
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
@@ -2323,7 +2519,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                            round, tm[0] * 1e3, tm[1] * 1e3, tm[2] * 1e3, tm[3] * 1e3, tm[4] * 1e3);
     }
     st.t_gapped = now_s() - t_g0;
-    for (PairJob *j : jobs) {                // launch-level figures are shared by the pairs that were in flight together
+    for (size_t jk = 0; jk < n_members; jk++) {      // launch-level figures are shared by the pairs that were in flight together
+        PairJob *j = jobs[members ? (*members)[jk] : jk];
         miblast_stats &d = j->res->stats;
         d.t_gapped = st.t_gapped; d.gapped_rounds = st.gapped_rounds; d.dp_sides_run = st.dp_sides_run; d.dp_cells_run = st.dp_cells_run;
         d.dp_rows_run = st.dp_rows_run; d.t_dp_kernel_ms = st.t_dp_kernel_ms; d.dp_kernel_launches = st.dp_kernel_launches;
@@ -2566,7 +2763,90 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         ctx.ws->pair_ptrs.ensure(n);
         ctx.ws->stage.h2d(ctx.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), ctx.stream);          // (in stream order before the first DP launch)
     }
-    int rc = gapped_phase(ctx, p, jobs, units);
+    // A call of several pairs with enough work: the gapped stages of two groups of its pairs run side by side, each on a stream and
+    // workspace of its own -- the host work of one group (relay planting, commits, traceback merge) overlaps the kernels of the
+    // other, and their latency-bound tail launches share the GPU.  Pairs are independent jobs: results do not depend on the split.
+    const size_t gapped_lanes = (size_t)std::min<long>(8, std::max(1l, env_long("MIBLAST_GAPPED_LANES", 2)));
+    size_t total_anchors = 0;
+    for (const Unit &u : units) total_anchors += u.anchors.size();
+    int rc = MIBLAST_OK;
+    if (gapped_lanes > 1 && n >= 4 && total_anchors >= (size_t)env_long("MIBLAST_GAPPED_LANES_MIN_ANCHORS", 4096)) {
+        // pairs dealt to the groups heaviest first (anchors as the weight)
+        const size_t L = std::min(gapped_lanes, n / 2);
+        std::vector<size_t> weight(n, 0), order(n);
+        for (const Unit &u : units) weight[(size_t)u.pair] += u.anchors.size();
+        for (size_t k = 0; k < n; k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+        std::vector<std::vector<size_t>> members(L);
+        std::vector<size_t> load(L, 0);
+        std::vector<size_t> group_of(n, 0);
+        for (size_t k : order) {
+            size_t gsel = 0;
+            for (size_t x = 1; x < L; x++) if (load[x] < load[gsel]) gsel = x;
+            members[gsel].push_back(k); load[gsel] += weight[k] + 1; group_of[k] = gsel;
+        }
+        for (auto &m : members) std::sort(m.begin(), m.end());
+        std::vector<std::vector<Unit>> gunits(L);
+        for (Unit &u : units) gunits[group_of[(size_t)u.pair]].push_back(std::move(u));
+        units.clear();
+        Workspace &w0 = *ctx.ws;
+        while (w0.lanes.size() + 1 < L) w0.lanes.push_back(lane_create(ctx.device));
+        std::vector<PairPtrs> pp(n);
+        for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }
+        std::vector<int> lane_rc(L, MIBLAST_OK);
+        std::vector<std::string> lane_err(L);
+        std::vector<std::future<void>> others;
+        for (size_t x = 1; x < L; x++) {
+            Ctx &lane = *w0.lanes[x - 1];
+            lane.ws->stage.abort();
+            lane.ws->pair_ptrs.ensure(n);
+            lane.ws->stage.h2d(lane.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), lane.stream);
+            others.push_back(std::async(std::launch::async, [&, x] {
+                try {
+                    MB_HIP(hipSetDevice(ctx.device));
+                    lane_rc[x] = gapped_phase(*w0.lanes[x - 1], p, jobs, gunits[x], &members[x]);
+                    if (lane_rc[x] != MIBLAST_OK) lane_err[x] = last_error_text();
+                } catch (const HipFailure &e) {
+                    lane_rc[x] = MIBLAST_EHIP;
+                    lane_err[x] = std::string("HIP call did not succeed: ") + e.what + " -> " + hipGetErrorString(e.code);
+                } catch (const std::exception &e) {
+                    lane_rc[x] = MIBLAST_EHIP;
+                    lane_err[x] = std::string("internal: ") + e.what();
+                }
+            }));
+        }
+        try {
+            rc = gapped_phase(ctx, p, jobs, gunits[0], &members[0]);
+        } catch (...) {
+            for (auto &f : others) f.get();
+            throw;
+        }
+        for (auto &f : others) f.get();
+        for (size_t x = 1; x < L && rc == MIBLAST_OK; x++) if (lane_rc[x] != MIBLAST_OK) { set_error(lane_err[x]); rc = lane_rc[x]; }
+        for (auto &gu : gunits) for (Unit &u : gu) units.push_back(std::move(u));
+        if (rc == MIBLAST_OK) {
+            // launch-level figures of the call = all groups together (wall time: the longest one)
+            miblast_stats sum;
+            memset(&sum, 0, sizeof sum);
+            for (size_t x = 0; x < L; x++) {
+                const miblast_stats &a = jobs[members[x][0]]->res->stats;
+                sum.t_gapped = std::max(sum.t_gapped, a.t_gapped); sum.gapped_rounds = std::max(sum.gapped_rounds, a.gapped_rounds);
+                sum.dp_sides_run += a.dp_sides_run; sum.dp_cells_run += a.dp_cells_run; sum.dp_rows_run += a.dp_rows_run;
+                sum.t_dp_kernel_ms += a.t_dp_kernel_ms; sum.dp_kernel_launches += a.dp_kernel_launches;
+                sum.relay_accepted += a.relay_accepted; sum.relay_rejected += a.relay_rejected; sum.dp_reruns += a.dp_reruns;
+                sum.t_traceback_ms += a.t_traceback_ms; sum.t_merge_ms += a.t_merge_ms;
+            }
+            for (PairJob *j : jobs) {
+                miblast_stats &d = j->res->stats;
+                d.t_gapped = sum.t_gapped; d.gapped_rounds = sum.gapped_rounds; d.dp_sides_run = sum.dp_sides_run; d.dp_cells_run = sum.dp_cells_run;
+                d.dp_rows_run = sum.dp_rows_run; d.t_dp_kernel_ms = sum.t_dp_kernel_ms; d.dp_kernel_launches = sum.dp_kernel_launches;
+                d.relay_accepted = sum.relay_accepted; d.relay_rejected = sum.relay_rejected; d.dp_reruns = sum.dp_reruns;
+                d.t_traceback_ms = sum.t_traceback_ms; d.t_merge_ms = sum.t_merge_ms;
+            }
+        }
+    } else {
+        rc = gapped_phase(ctx, p, jobs, units);
+    }
     if (rc != MIBLAST_OK) return rc;
     const double t_o = now_s();
     parallel_for(n, [&](size_t k) { output_phase(p, *jobs[k], (int)k, units); });

@@ -32,6 +32,10 @@ struct Result {
 
 void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
+// outgroup trimming on the device (mb_pipeline.cpp): what no alignment of `paf` covers of the resident query set, as a new resident set
+// (n items in one call; outs[k] is left empty and nothing_left[k] set when every base of Qs[k] is covered)
+int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *const *pafs, const size_t *paf_lens, int64_t min_size, int64_t flank,
+                     SeqSet *const *outs, bool *nothing_left);
 int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &p, Result &res);
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &p, Result **results);
 // mb_multi.cpp: n_pairs (target, query) sets parsed on the host (not uploaded), cut into blocks of whole contigs, the block pairs

@@ -81,6 +81,8 @@ def load() -> C.CDLL:
         "miblast_seqset_from_fasta_file": (C.c_int, [vp, cp, P(vp)]),
         "miblast_seqset_from_fasta_mem": (C.c_int, [vp, cp, C.c_size_t, P(vp)]),
         "miblast_seqset_free": (None, [vp]),
+        "miblast_seqsets_unaligned": (C.c_int, [vp, C.c_size_t, P(vp), P(cp), P(C.c_size_t), i64, i64, P(vp)]),
+        "miblast_seqset_fasta": (C.c_int, [vp, P(vp), P(C.c_size_t)]),
         "miblast_seqset_n_contigs": (i32, [vp]),
         "miblast_seqset_total": (i64, [vp]),
         "miblast_seqset_name": (cp, [vp, i32]),
@@ -115,7 +117,7 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_set_host_threads",
                     "miblast_ctx_create",
                     "miblast_ctx_destroy", "miblast_seqset_from_fasta_file", "miblast_seqset_from_fasta_mem",
-                    "miblast_seqset_free", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
+                    "miblast_seqset_free", "miblast_seqsets_unaligned", "miblast_seqset_fasta", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
                     "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_align_pairs", "miblast_result_free",
                     "miblast_result_paf", "miblast_result_stats", "miblast_result_hsps", "miblast_result_alns",
                     "miblast_result_ops", "miblast_align_files", "miblast_multi_create", "miblast_multi_destroy", "miblast_multi_num_gpu",
@@ -185,6 +187,16 @@ class SeqSet:
         return [(lib.miblast_seqset_name(self._h, i).decode(), lib.miblast_seqset_start(self._h, i), lib.miblast_seqset_len(self._h, i))
                 for i in range(lib.miblast_seqset_n_contigs(self._h))]
 
+    def fasta_bytes(self) -> bytes:
+        """FASTA text of the set (60 columns per line): what `faffy extract` would have written for a trimmed set."""
+        lib = load()
+        text, n = C.c_void_p(), C.c_size_t()
+        _check(lib.miblast_seqset_fasta(self._h, C.byref(text), C.byref(n)))
+        try:
+            return C.string_at(text, n.value)
+        finally:
+            lib.miblast_free(text)
+
     def close(self):
         if self._h:
             load().miblast_seqset_free(self._h)
@@ -210,6 +222,18 @@ class Context:
         h = C.c_void_p()
         _check(load().miblast_seqset_from_fasta_mem(self._h, data, len(data), C.byref(h)))
         return SeqSet(self, h)
+
+    def seqsets_unaligned(self, queries, pafs, min_size: int, flank: int):
+        """Outgroup trimming on the device (include/miblast.h miblast_seqsets_unaligned; local_alignment.py:460-499): for every
+        (resident query set, PAF bytes of its alignments) the part no alignment covers, as a new resident set -- or None when
+        nothing is left.  One call for all chains of a dependency level."""
+        n = len(queries)
+        qs = (C.c_void_p * n)(*[q._h for q in queries])
+        ps = (C.c_char_p * n)(*pafs)
+        ls = (C.c_size_t * n)(*[len(p) for p in pafs])
+        outs = (C.c_void_p * n)()
+        _check(load().miblast_seqsets_unaligned(self._h, n, qs, ps, ls, int(min_size), int(flank), outs))
+        return [SeqSet(self, C.c_void_p(outs[i])) if outs[i] else None for i in range(n)]
 
     def seqset_from_fasta_file(self, path: str) -> SeqSet:
         h = C.c_void_p()

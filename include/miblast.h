@@ -95,6 +95,18 @@ typedef struct miblast_seqset miblast_seqset;
 int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_seqset **out);
 int miblast_seqset_from_fasta_mem(miblast_ctx *ctx, const char *buf, size_t len, miblast_seqset **out);
 void miblast_seqset_free(miblast_seqset *s);
+/* Outgroup trimming between two blast calls, on the device.  Replaces, for the n ingroup -> outgroup chains of a dependency level at
+ * once, the pipe `paffy to_bed --excludeAligned --binary --minSize N` | `faffy extract --flank F` and the re-reading of its output
+ * (/root/reference/src/cactus/paf/local_alignment.py:460-499, trimMinSize / trimFlanking of cactus_progressive_config.xml:116-117):
+ * the per-base coverage of the RESIDENT query set queries[k] by the query intervals of the alignments in pafs[k] is taken on the
+ * device; what no alignment covers -- stretches of at least min_size bases, widened by flank on both sides, touching ones merged --
+ * is gathered on the device into a new resident set whose records are named NAME|SEQLEN|START (faffy's sub-sequence names, undone
+ * by `paffy dechunk --query`).  out[k] = that set, or NULL when nothing is left.  Same names, lengths and bases as
+ * mipaf_unaligned_fasta + miblast_seqset_from_fasta_mem on the same inputs.  A PAF query name that is not in the set: MIBLAST_EINVAL. */
+int miblast_seqsets_unaligned(miblast_ctx *ctx, size_t n, const miblast_seqset *const *queries, const char *const *pafs, const size_t *paf_lens,
+                              int64_t min_size, int64_t flank, miblast_seqset **out);
+/* FASTA text of a set (60 columns per line; ACGTN, lower case where soft-masked): free with miblast_free.                          */
+int miblast_seqset_fasta(const miblast_seqset *s, char **text, size_t *len);
 int32_t miblast_seqset_n_contigs(const miblast_seqset *s);
 int64_t miblast_seqset_total(const miblast_seqset *s);           /* concatenated length */
 const char *miblast_seqset_name(const miblast_seqset *s, int32_t i);

@@ -435,6 +435,99 @@ def test_batched_pairs_equal_single_calls(gpu_ctx, monkeypatch, lanes):
             assert a.stats[k] == b.stats[k], (name, k)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_outgroup_trimming_on_the_device_equals_the_text_path_and_the_oracle(gpu_ctx, tmp_path, seed):
+    """miblast_seqsets_unaligned (per-base coverage, uncovered stretches, gather -- all on the resident set) against
+    oracle/paffy_text_oracle.c (`paffy to_bed --excludeAligned --minSize N | faffy extract --flank F` restated with per-base
+    counters) and against the product's own text path: same records, names, lengths and bases; several items per call; a second
+    round on an already trimmed set (nested NAME|LEN|START names); nothing left -> no set."""
+    from test_text_oracle_cpu import random_case, oracle, built      # noqa: F401  (the oracle is built on demand)
+    import subprocess, os
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), "oracle_paffy_text"], check=True, capture_output=True)
+    from cactus_amd import mipaf
+    fa, paf, recs = random_case(seed, n_contigs=1 + seed % 5, nested=seed % 3 == 2)
+    (tmp_path / "q.fa").write_bytes(fa)
+    (tmp_path / "a.paf").write_bytes(paf)
+    Q = gpu_ctx.seqset_from_fasta_bytes(fa)
+    settings = ((100, 100), (1, 0), (37, 5), (5000, 10), (10, 3000))
+    for min_size, flank in settings:
+        want = oracle("to_bed_extract", tmp_path / "a.paf", tmp_path / "q.fa", min_size, flank)
+        got = gpu_ctx.seqsets_unaligned([Q, Q], [paf, b""], min_size, flank)                   # (an item without alignments: everything >= min_size is left)
+        if not want:
+            assert got[0] is None
+        else:
+            assert got[0].fasta_bytes() == want == mipaf.unaligned_fasta(paf, fa, min_size, flank)
+            ref = gpu_ctx.seqset_from_fasta_bytes(want)
+            assert got[0].contigs == ref.contigs and got[0].total == ref.total
+            # second round on the trimmed set: what a later outgroup leaves of it
+            inner = []
+            for name, start, n in got[0].contigs:
+                if n > 30:
+                    inner.append(f"{name}\t{n}\t{n // 4}\t{n // 2}\t+\tid=T|x\t9999\t0\t{n // 2 - n // 4}\t1\t1\t255\n")
+            paf2 = "".join(inner).encode()
+            (tmp_path / "q2.fa").write_bytes(want)
+            (tmp_path / "a2.paf").write_bytes(paf2)
+            want2 = oracle("to_bed_extract", tmp_path / "a2.paf", tmp_path / "q2.fa", 8, 3)
+            got2 = gpu_ctx.seqsets_unaligned([got[0]], [paf2], 8, 3)[0]
+            assert (got2.fasta_bytes() if got2 is not None else b"") == want2
+            ref.close()
+        empty = tmp_path / "none.paf"
+        empty.write_bytes(b"")
+        want_all = oracle("to_bed_extract", empty, tmp_path / "q.fa", min_size, flank)
+        assert (got[1].fasta_bytes() if got[1] is not None else b"") == want_all
+    from cactus_amd import miblast
+    with pytest.raises(miblast.MiblastError):
+        gpu_ctx.seqsets_unaligned([Q], [b"nobody\t10\t0\t5\t+\tt\t10\t0\t5\t5\t5\t255\n"], 1, 0)
+    Q.close()
+
+
+def test_evolver_phase_with_trimming_on_the_device_equals_the_oracle_call_by_call(gpu_ctx, olz):
+    """The phase as bench.py runs it -- genomes resident, every chain's leftover cut out on the device between the outgroup calls
+    (align_batch.trim_resident -> miblast_seqsets_unaligned) -- at a tenth of the size: every call's bytes and counters are the
+    oracle's on the FASTA text of what the device left over, and the assembled files equal those of the text path."""
+    from cactus_amd import blast_phase as bp, gen, miblast
+    from cactus_amd.paf.local_alignment import select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE))
+    genomes = gen.make_tree_genomes(60_000, 2001, ancestors=True)
+    fasta = {k: gen.fasta_bytes([("id=%s|%s" % (k, k), v)]) for k, v in genomes.items()}
+    resident = {fa: gpu_ctx.seqset_from_fasta_bytes(fa) for fa in fasta.values()}
+    made, seen = [], []
+
+    def align_batch(pairs, opts):
+        pm = miblast.params_from_args(opts.split())
+        sets = [(resident[t], q if isinstance(q, miblast.SeqSet) else resident[q]) for t, q in pairs]
+        return [r.paf for r in gpu_ctx.align_pairs(sets, pm)]
+
+    def trim_resident(items, min_size, flank):
+        outs = gpu_ctx.seqsets_unaligned([q if isinstance(q, miblast.SeqSet) else resident[q] for q, _ in items], [p for _, p in items], min_size, flank)
+        made.extend(o for o in outs if o is not None)
+        return outs
+
+    options = lambda d: select_lastz_params(d, cfg, 0)      # noqa: E731
+    align_batch.trim_resident = trim_resident
+    res = bp.run_blast_phase(fasta, calls, options, align_batch, on_call=lambda c, tf, qf, paf: seen.append((c, tf, qf, paf)))
+    assert len(seen) == 20 and made
+    for c, tf, qf, paf in seen:
+        pm = miblast.params_from_args(options(c.distance).split())
+        want = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}), details=False)
+        assert paf == want["paf"], (c.node, c.kind, c.level)
+
+    def text_batch(pairs, opts):
+        pm = miblast.params_from_args(opts.split())
+        out = []
+        for t, q in pairs:
+            T, Q = gpu_ctx.seqset_from_fasta_bytes(t), gpu_ctx.seqset_from_fasta_bytes(q)
+            out.append(gpu_ctx.align(T, Q, pm, details=False).paf)
+            T.close(); Q.close()
+        return out
+
+    assert bp.run_blast_phase(fasta, calls, options, text_batch) == res
+    for h in list(resident.values()) + made:
+        h.close()
+
+
 def test_full_size_chunk_pair_equals_the_oracle_digest(gpu_ctx):
     """One chunk pair at Cactus's full chunk size (30 Mb x 30 Mb, 1.3 % divergence, half soft-masked, parameter
     set "one"): PAF bytes and counters equal the CPU oracle's, which takes a minute on this input and is therefore committed as a

@@ -1,0 +1,101 @@
+"""CPU tests of the text steps either side of the blast call against oracle/paffy_text_oracle.c --
+a third, independently built restatement (per-base counters instead of interval merging; written from the reference's call sites,
+/root/reference/src/cactus/paf/local_alignment.py:352, 378-387, 460-488): the Python cores of cactus_amd/paf/chunking.py and the
+native text code of libmiblast (mipaf_dechunk_text, mipaf_unaligned_fasta) must write the oracle's bytes.  (The device
+implementation, miblast_seqsets_unaligned, is diffed against the same oracle in tests/test_parity_gpu.py.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cactus_amd import gen
+from cactus_amd.paf import chunking
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle", "oracle_paffy_text")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle_paffy_text"], check=True, capture_output=True)
+
+
+def oracle(*args):
+    p = subprocess.run([ORACLE, *[str(a) for a in args]], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout
+
+
+def random_case(seed, n_contigs=4, max_len=3000, n_aln=12, nested=False):
+    """A FASTA file (ragged contigs, soft-masked and N stretches; NAME|LEN|START names when nested) and PAF lines whose query
+    intervals overlap, touch, repeat, reach the contig ends or leave a contig untouched."""
+    rng = np.random.default_rng(seed)
+    recs = []
+    for k in range(n_contigs):
+        n = int(rng.integers(1, max_len))
+        s = gen.random_sequence(n, rng)
+        if n > 40:                                                   # a soft-masked stretch and a few N (Cactus's alphabet is ACGTNacgtn)
+            a = int(rng.integers(0, n - 20))
+            s = s.copy()
+            s[a:a + 20] = np.frombuffer(bytes(s[a:a + 20]).lower(), dtype=np.uint8)
+            s[int(rng.integers(0, n))] = ord("N")
+        name = f"id=Q|c{k}" + (f"|{n + 500}|{int(rng.integers(0, 400))}" if nested else "")
+        recs.append((name, s))
+    lines = []
+    for _ in range(n_aln):
+        k = int(rng.integers(0, n_contigs - 1)) if n_contigs > 1 else 0          # the last contig stays unaligned
+        n = len(recs[k][1])
+        a = int(rng.integers(0, n))
+        b = int(min(n, a + rng.integers(0, max(2, n // 3))))
+        if rng.random() < 0.2:
+            a = 0
+        if rng.random() < 0.2:
+            b = n
+        lines.append(f"{recs[k][0]}\t{n}\t{a}\t{b}\t{'+-'[int(rng.integers(0, 2))]}\tid=T|x\t9999\t5\t{5 + b - a}\t{b - a}\t{b - a}\t255\tAS:i:7\tcg:Z:{max(1, b - a)}=\n")
+    return gen.fasta_bytes(recs), "".join(lines).encode(), recs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_unaligned_parts_text_implementations_write_the_oracles_bytes(tmp_path, seed):
+    from cactus_amd import blast_phase as bp, mipaf
+    fa, paf, _ = random_case(seed, n_contigs=1 + seed % 5, nested=seed % 3 == 2)
+    (tmp_path / "q.fa").write_bytes(fa)
+    (tmp_path / "a.paf").write_bytes(paf)
+    for min_size, flank in ((100, 100), (1, 0), (37, 5), (5000, 10), (10, 3000)):
+        want = oracle("to_bed_extract", tmp_path / "a.paf", tmp_path / "q.fa", min_size, flank)
+        assert mipaf.unaligned_fasta(paf, fa, min_size, flank) == want, (seed, min_size, flank)           # native text code
+        assert bp.unaligned_fasta_py(paf, fa, min_size, flank) == want, (seed, min_size, flank)           # Python cores
+    empty = tmp_path / "none.paf"
+    empty.write_bytes(b"")
+    assert mipaf.unaligned_fasta(b"", fa, 100, 100) == oracle("to_bed_extract", empty, tmp_path / "q.fa", 100, 100)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dechunk_text_implementations_write_the_oracles_bytes(tmp_path, seed):
+    from cactus_amd import mipaf
+    rng = np.random.default_rng(100 + seed)
+    lines = []
+    for k in range(20):
+        qn, tn = f"id=Q|c{k % 3}|{int(rng.integers(1000, 9000))}|{int(rng.integers(0, 500))}", f"id=T|x|y{k % 2}|{int(rng.integers(1000, 9000))}|{int(rng.integers(0, 500))}"
+        a, b = sorted(int(x) for x in rng.integers(0, 900, 2))
+        c, d = sorted(int(x) for x in rng.integers(0, 900, 2))
+        tags = "\tAS:i:%d\tcg:Z:%d=" % (k, b - a + 1) if k % 4 else ""
+        lines.append(f"{qn}\t1000\t{a}\t{b}\t{'+-'[k % 2]}\t{tn}\t1000\t{c}\t{d}\t{b - a}\t{b - a}\t255{tags}\n")
+    text = "".join(lines)
+    path = tmp_path / "c.paf"
+    path.write_text(text)
+    for query_only in (False, True):
+        want = oracle("dechunk", path, *(["--query"] if query_only else []))
+        assert mipaf.dechunk_text(text.encode(), query_only=query_only) == want
+        assert "".join(chunking.paf_dechunk_line(l, query_only) for l in lines).encode() == want
+
+
+@pytest.mark.parametrize("seed,chunk,overlap", [(1, 1000, 100), (2, 700, 0), (3, 5000, 50), (4, 123, 45)])
+def test_fasta_chunker_writes_the_oracles_files(tmp_path, seed, chunk, overlap):
+    fa, _, _ = random_case(200 + seed, n_contigs=5, max_len=4000)
+    src = tmp_path / "g.fa"
+    src.write_bytes(fa)
+    files = chunking.fasta_chunk(str(src), str(tmp_path / "chunks"), chunk, overlap)
+    got = b"".join(b"== file %d\n" % k + open(f, "rb").read() for k, f in enumerate(files))
+    assert got == oracle("chunk", src, chunk, overlap)
