@@ -1855,27 +1855,17 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         std::vector<VerifyOut> vres;
         struct RelayPt { int unit; int32_t t, q, dir; int piece; int tail; };   // origin of a relay; piece = its fresh DP (-1: not queued yet); tail = virtual relays since the last anchor
         std::vector<RelayPt> relay_pts;
-        std::unordered_map<unsigned long long, int> relay_id;          // (unit, direction, t, q) -> index into relay_pts
+        // relay points are looked up per (unit, direction) -- chains never leave theirs --: group 2 * unit + (dir > 0), key (t, q),
+        // value = index into relay_pts minus the group's base (the parallel planting below numbers a group's points locally)
+        std::vector<std::unordered_map<unsigned long long, int>> relay_id(2 * units.size());
+        std::vector<int> relay_base(2 * units.size(), 0);
         bool arena_full = false;
         long n_verify_ok = 0, n_verify_bad = 0, n_subrounds = 0;
+        auto relay_key = [](int32_t t, int32_t q) -> unsigned long long { return ((unsigned long long)(uint32_t)t << 32) | (uint32_t)q; };
         auto relay_at = [&](int unit, int32_t dir, int32_t t, int32_t q) -> int {
-            // (t, q) identify the point inside a unit and direction; units of a batch are told apart by the upper bits
-            const unsigned long long key = ((unsigned long long)(unsigned)unit << 52) ^ ((unsigned long long)(unsigned)t << 21) ^ ((unsigned long long)(unsigned)q << 1) ^ (dir > 0 ? 1ull : 0ull);
-            auto it = relay_id.find(key);
-            if (it != relay_id.end()) {
-                const RelayPt &r = relay_pts[(size_t)it->second];
-                if (r.unit == unit && r.t == t && r.q == q && r.dir == dir) return it->second;
-                // (hash collision of two different points: keep them apart with a linear probe on the key)
-                unsigned long long k2 = key;
-                while (true) {
-                    k2 = k2 * 6364136223846793005ull + 1442695040888963407ull;
-                    auto i2 = relay_id.find(k2);
-                    if (i2 == relay_id.end()) { relay_id[k2] = (int)relay_pts.size(); relay_pts.push_back(RelayPt{unit, t, q, dir, -1, 0}); return (int)relay_pts.size() - 1; }
-                    const RelayPt &r2 = relay_pts[(size_t)i2->second];
-                    if (r2.unit == unit && r2.t == t && r2.q == q && r2.dir == dir) return i2->second;
-                }
-            }
-            relay_id[key] = (int)relay_pts.size();
+            const size_t gi = 2 * (size_t)unit + (dir > 0 ? 1 : 0);
+            auto ins = relay_id[gi].emplace(relay_key(t, q), (int)relay_pts.size() - relay_base[gi]);
+            if (!ins.second) return relay_base[gi] + ins.first->second;
             relay_pts.push_back(RelayPt{unit, t, q, dir, -1, 0});
             return (int)relay_pts.size() - 1;
         };
@@ -1967,7 +1957,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 side_base[2 * k + (size_t)sdn] = b;
             }
         }
-        if (relay_s0 > 0 && plant_at_once && env_long("MIBLAST_PLANT_THREADS", 1) != 0) {
+        // MIBLAST_PLANT_THREADS: 1 (default) the chains of every (unit, direction) are planted on the worker threads, group by group,
+        // and strung together afterwards; 2: only the lattice steps are walked ahead in parallel (chain_memo), planting is serial; 0: serial
+        const long plant_threads = env_long("MIBLAST_PLANT_THREADS", 1);
+        const bool plant_parallel = relay_s0 > 0 && plant_at_once && plant_threads == 1;
+        if (relay_s0 > 0 && plant_at_once && plant_threads == 2) {
             chain_memo.assign(2 * units.size(), {});
             std::vector<std::vector<size_t>> group(2 * units.size());     // sides of a (unit, direction), in planting order
             for (size_t si = 0; si < (size_t)nsides; si++) group[2 * pend[si / 2].unit + (side_base[si].dir > 0 ? 1 : 0)].push_back(si);
@@ -1996,8 +1990,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         }
         while (true) {                                   // retried with a larger arena if the trace does not fit
             sides.assign((size_t)nsides, SideRun());
-            pieces.clear(); probs.clear(); outs.clear(); vjobs.clear(); vres.clear(); relay_pts.clear(); relay_id.clear();
-            pieces.reserve(4096); probs.reserve(4096); vjobs.reserve(4096); relay_pts.reserve(4096); relay_id.reserve(8192);
+            pieces.clear(); probs.clear(); outs.clear(); vjobs.clear(); vres.clear(); relay_pts.clear();
+            for (auto &m : relay_id) m.clear();
+            std::fill(relay_base.begin(), relay_base.end(), 0);
+            pieces.reserve(4096); probs.reserve(4096); vjobs.reserve(4096); relay_pts.reserve(4096);
             arena_full = false;
             uint64_t dir_entries = 0;
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
@@ -2043,7 +2039,109 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     a = nx;
                 }
             };
-            for (size_t k = 0; k < pend.size(); k++) {
+            if (plant_parallel) {
+                // ---- every (unit, direction) plants its heads and their relay chains into tables of its own (the same steps as the
+                //      serial code below, with local numbers); the tables are then strung together group by group.  Which number a
+                //      piece gets is scheduling only.
+                struct Plant {
+                    std::vector<Piece> pieces; std::vector<DpProb> probs; std::vector<VerifyJob> vjobs; std::vector<RelayPt> pts;
+                    std::unordered_map<unsigned long long, int> id;
+                    uint64_t dir_entries = 0;
+                    std::vector<std::pair<size_t, int>> heads;              // (side, its head piece)
+                };
+                std::vector<std::vector<size_t>> group(2 * units.size());     // sides of a (unit, direction), in planting order
+                for (size_t si = 0; si < (size_t)nsides; si++) group[2 * pend[si / 2].unit + (side_base[si].dir > 0 ? 1 : 0)].push_back(si);
+                std::vector<size_t> busy;
+                for (size_t gi = 0; gi < group.size(); gi++) if (!group[gi].empty()) busy.push_back(gi);
+                std::vector<Plant> plants(busy.size());
+                parallel_for(busy.size(), [&](size_t bi) {
+                    const size_t gi = busy[bi];
+                    const int unit = (int)(gi / 2);
+                    Plant &pl = plants[bi];
+                    auto l_relay_at = [&](int32_t dir, int32_t t, int32_t q) -> int {
+                        auto ins = pl.id.emplace(relay_key(t, q), (int)pl.pts.size());
+                        if (ins.second) pl.pts.push_back(RelayPt{unit, t, q, dir, -1, 0});
+                        return ins.first->second;
+                    };
+                    auto l_next_relay = [&](const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) -> int {
+                        const NextPt np = next_point(unit, b, t, q, min_dq, from_tail);
+                        if (!np.ok) return -1;
+                        const int id = l_relay_at(b.dir, np.t, np.q);
+                        if (np.set_tail >= 0) pl.pts[(size_t)id].tail = np.set_tail;
+                        return id;
+                    };
+                    auto l_add_piece = [&](const DpProb &base, int32_t ot, int32_t oq, int32_t stop_row, int32_t snap_row, int target) -> int {
+                        const int id = (int)pl.pieces.size();
+                        DpProb pr = base;
+                        const int32_t dr = (oq - base.q0) * base.dir, dc = (ot - base.t0) * base.dir;
+                        pr.t0 = ot; pr.q0 = oq; pr.na = base.na - dc; pr.nb = base.nb - dr;
+                        pr.row_lo = 0; pr.stop_row = stop_row; pr.snap_row = snap_row;
+                        pr.snap_row2 = pr.snap_row3 = 0;
+                        if (snap_row > 0 && relay_ckpt) {
+                            if (stop_row == 0 || 2 * snap_row < stop_row) pr.snap_row2 = 2 * snap_row;
+                            if (stop_row == 0 || 4 * snap_row < stop_row) pr.snap_row3 = 4 * snap_row;
+                        }
+                        pr.init_snap = -1; pr.snap_idx = id;                  // (local number: kSnapSlots x the global one when the tables are strung together)
+                        pr.row_off = pl.dir_entries;
+                        const int64_t last = stop_row > 0 ? stop_row : pr.nb;
+                        pl.dir_entries += (uint64_t)(last / 4096) + 2;
+                        pl.probs.push_back(pr);
+                        pl.pieces.push_back(Piece{unit, ot, oq, base.dir, 0, snap_row > 0 ? (int32_t)relay_w : -1, stop_row, target, 0, -1, -1, -1});
+                        if (target >= 0) {
+                            const RelayPt ta = pl.pts[(size_t)target];
+                            pl.pieces.back().vjob = (int)pl.vjobs.size();
+                            pl.vjobs.push_back(VerifyJob{id, -1, (ta.t - ot) * base.dir, (ta.q - oq) * base.dir});      // eslot: local piece for now
+                        }
+                        return id;
+                    };
+                    for (size_t si : group[gi]) {
+                        const DpProb b = side_base[si];
+                        int aim = l_next_relay(b, b.t0, b.q0, (int32_t)(relay_s / 2), 0);
+                        int32_t stop = (int32_t)(relay_end_steps * relay_s);
+                        if (aim >= 0) {
+                            int a = aim;
+                            for (long n = 0; a >= 0 && n < relay_max; n++) {            // plant_chain
+                                if (pl.pts[(size_t)a].piece >= 0) break;
+                                const RelayPt c = pl.pts[(size_t)a];
+                                int nx = l_next_relay(b, c.t, c.q, (int32_t)(relay_s / 2), c.tail);
+                                int32_t cstop = nx >= 0 ? (pl.pts[(size_t)nx].q - c.q) * b.dir + (int32_t)relay_w : (int32_t)(relay_end_steps * relay_s + relay_w);
+                                if (nx >= 0 && n + 1 == relay_max) { nx = -1; cstop = (int32_t)(relay_s + relay_w); }
+                                const int id = l_add_piece(b, c.t, c.q, cstop, (int32_t)relay_w, nx);
+                                pl.pts[(size_t)a].piece = id;
+                                a = nx;
+                            }
+                            stop = (pl.pts[(size_t)aim].q - b.q0) * b.dir + (int32_t)relay_w;
+                        }
+                        pl.heads.emplace_back(si, l_add_piece(b, b.t0, b.q0, stop, 0, aim));
+                    }
+                });
+                for (size_t bi = 0; bi < busy.size(); bi++) {
+                    Plant &pl = plants[bi];
+                    const size_t gi = busy[bi];
+                    const int pb = (int)pieces.size(), rb = (int)relay_pts.size(), vb = (int)vjobs.size();
+                    relay_base[gi] = rb;
+                    relay_id[gi].swap(pl.id);
+                    for (RelayPt &r : pl.pts) { if (r.piece >= 0) r.piece += pb; relay_pts.push_back(r); }
+                    for (size_t x = 0; x < pl.pieces.size(); x++) {
+                        Piece pc = pl.pieces[x];
+                        DpProb pr = pl.probs[x];
+                        if (pc.target >= 0) pc.target += rb;
+                        if (pc.vjob >= 0) pc.vjob += vb;
+                        pr.snap_idx = kSnapSlots * (pb + (int)x);
+                        pr.row_off += dir_entries;
+                        pieces.push_back(pc); probs.push_back(pr);
+                    }
+                    for (VerifyJob v : pl.vjobs) { v.eslot = kSnapSlots * (pb + v.eslot) + 1; vjobs.push_back(v); }
+                    dir_entries += pl.dir_entries;
+                    for (const auto &h : pl.heads) {
+                        SideRun &sd = sides[h.first];
+                        sd.base = side_base[h.first]; sd.unit = (int)pend[h.first / 2].unit;
+                        const int id = pb + h.second;
+                        sd.cur.push_back(id); sd.chain.push_back(id); sd.chain_floor.push_back(-1);
+                    }
+                }
+            }
+            for (size_t k = 0; k < pend.size() && !plant_parallel; k++) {
                 for (int sdn = 0; sdn < 2; sdn++) {
                     const DpProb b = side_base[2 * k + (size_t)sdn];
                     SideRun &sd = sides[2 * k + (size_t)sdn];
@@ -2390,22 +2488,27 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 const size_t nR = (size_t)(coff[2 * x + 1] - coff[2 * x]), nL = (size_t)(coff[2 * x + 2] - coff[2 * x + 1]);
                 return run < nL ? Lops[run] : Rops[nR - 1 - (run - nL)];
             };
-            for (size_t x = 0; x < acc.size(); x++) {
+            // (the prefix walk of every alignment on the worker threads, the task lists strung together afterwards)
+            std::vector<std::vector<MergeTask>> per(acc.size());
+            parallel_for(acc.size(), [&](size_t x) {
                 const Cached &c = *cptr[x];
                 const size_t nruns = (size_t)(coff[2 * x + 2] - coff[2 * x]);
                 int64_t tt = c.t_lo, qq = c.q_lo;
-                task_range[x].first = tasks.size();
                 for (size_t r0 = 0; r0 < nruns || r0 == 0; r0 += kRunsPerTask) {
                     const size_t r1 = std::min(nruns, r0 + kRunsPerTask);
-                    tasks.push_back(MergeTask{x, r0, r1, tt, qq, {}, 0x7fffffff, -0x7fffffff - 1});
+                    per[x].push_back(MergeTask{x, r0, r1, tt, qq, {}, 0x7fffffff, -0x7fffffff - 1});
                     for (size_t r = r0; r < r1; r++) {
                         const uint32_t e = run_at(x, r), o = e & 3u, len = e >> 2;
                         if (o == 0) { tt += len; qq += len; } else if (o == 2) qq += len; else tt += len;
                     }
                     if (r1 >= nruns) break;
                 }
-                task_range[x].second = tasks.size();
                 reached[x] = {tt, qq};
+            });
+            for (size_t x = 0; x < acc.size(); x++) {
+                task_range[x].first = tasks.size();
+                for (MergeTask &t : per[x]) tasks.push_back(std::move(t));
+                task_range[x].second = tasks.size();
             }
             const double t_mg1 = now_s();
             parallel_for(tasks.size(), [&](size_t ti) {
@@ -2656,6 +2759,7 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
 }
 
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
+    const double t_call0 = now_s();
     MB_HIP(hipSetDevice(ctx.device));
     Pool::Hot keep_workers_awake;
     ctx.ws->stage.abort();
@@ -2750,6 +2854,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     }
     for (; waited < host_tasks.size(); waited++) host_tasks[waited].get();
     }
+    const double t_call1 = now_s();
     for (size_t k = 0; k < n; k++)
         if (jobs[k]->anchor_mismatch) { set_error("MIBLAST_CHECK_ANCHORS: k_hsp_anchor disagrees with the host scan"); return MIBLAST_EHIP; }
     for (size_t k = 0; k < n; k++) {
@@ -2850,7 +2955,9 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     if (rc != MIBLAST_OK) return rc;
     const double t_o = now_s();
     parallel_for(n, [&](size_t k) { output_phase(p, *jobs[k], (int)k, units); });
-    if (env_long("MIBLAST_DEBUG", 0) && n == 1) fprintf(stderr, "[miblast] output phase %.2f ms\n", (now_s() - t_o) * 1e3);
+    if (env_long("MIBLAST_DEBUG", 0))
+        fprintf(stderr, "[miblast] call of %zu pairs: seed stages %.2f ms, gapped stage %.2f ms, output %.2f ms, all %.2f ms\n", n, (t_call1 - t_call0) * 1e3, (t_o - t_call1) * 1e3,
+                (now_s() - t_o) * 1e3, (now_s() - t_call0) * 1e3);
     return MIBLAST_OK;
 }
 

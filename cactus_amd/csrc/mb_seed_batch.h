@@ -140,6 +140,33 @@ __device__ __forceinline__ void bs_lookup(const unsigned long long *__restrict__
     b0 = starts[r]; b1 = starts[r + 1];
 }
 
+// (every variant's bitmap word is requested before the first one is looked at, then every directory entry, then every pair of
+//  bucket bounds: three rounds of independent loads per thread instead of thirteen dependent chains)
+__device__ __forceinline__ void bs_lookup_all(const unsigned long long *__restrict__ bits, const uint32_t *__restrict__ dir, const uint32_t *__restrict__ starts,
+                                              const int t, const int64_t cbase, const uint32_t w, const int nvar, uint32_t (&b0)[1 + kSeedWeight],
+                                              uint32_t (&b1)[1 + kSeedWeight]) {
+    unsigned long long m[1 + kSeedWeight];
+    uint32_t wv[1 + kSeedWeight], d[1 + kSeedWeight];
+#pragma unroll
+    for (int v = 0; v < 1 + kSeedWeight; v++) {
+        wv[v] = variant_word(w, v);
+        m[v] = v < nvar ? bits[(size_t)t * kBxWordsPerTarget + (wv[v] >> 6)] : 0ull;
+    }
+#pragma unroll
+    for (int v = 0; v < 1 + kSeedWeight; v++) {
+        const bool hit = (m[v] >> (wv[v] & 63u)) & 1ull;
+        d[v] = hit ? dir[(size_t)t * kBxWordsPerTarget + (wv[v] >> 6)] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int v = 0; v < 1 + kSeedWeight; v++) {
+        b0[v] = b1[v] = 0;
+        if (d[v] != 0xFFFFFFFFu) {
+            const int64_t r = cbase + d[v] + (uint32_t)__popcll(m[v] & ((1ull << (wv[v] & 63u)) - 1ull));
+            b0[v] = starts[r]; b1[v] = starts[r + 1];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bs_count(const SeedUnit *__restrict__ units, const int n_units, const BatchTarget *__restrict__ tg,
                                                    const unsigned long long *__restrict__ bits, const uint32_t *__restrict__ dir,
                                                    const uint32_t *__restrict__ starts, const int nvar, uint32_t *__restrict__ qcnt) {
@@ -149,12 +176,10 @@ __global__ __launch_bounds__(256) void k_bs_count(const SeedUnit *__restrict__ u
     const int64_t q = slot - su.qpos0;
     uint32_t cnt = 0, w;
     if (q + kSeedSpan <= su.qtot && window_word(unit_glob(su.qc), q, w)) {
-        const int64_t cbase = tg[su.index].cbase;
-        for (int v = 0; v < nvar; v++) {
-            uint32_t b0, b1;
-            bs_lookup(bits, dir, starts, su.index, cbase, variant_word(w, v), b0, b1);
-            cnt += b1 - b0;
-        }
+        uint32_t b0[1 + kSeedWeight], b1[1 + kSeedWeight];
+        bs_lookup_all(bits, dir, starts, su.index, tg[su.index].cbase, w, nvar, b0, b1);
+#pragma unroll
+        for (int v = 0; v < 1 + kSeedWeight; v++) cnt += b1[v] - b0[v];
     }
     qcnt[slot] = cnt;
 }
@@ -169,13 +194,12 @@ __global__ __launch_bounds__(256) void k_bs_fill(const SeedUnit *__restrict__ un
     const int64_t q = slot - su.qpos0;
     uint32_t w;
     if (!(q + kSeedSpan <= su.qtot && window_word(unit_glob(su.qc), q, w))) return;
-    const int64_t cbase = tg[su.index].cbase;
+    uint32_t b0[1 + kSeedWeight], b1[1 + kSeedWeight];
+    bs_lookup_all(bits, dir, starts, su.index, tg[su.index].cbase, w, nvar, b0, b1);
     uint32_t o = hit_off[slot];
     const unsigned long long q_end = (unsigned long long)(q + kSeedSpan);
     const int64_t dq0 = (int64_t)su.dbase + su.qtot - q;                          // diagonal of target position 0 against this q
-    for (int v = 0; v < nvar; v++) {
-        uint32_t b0, b1;
-        bs_lookup(bits, dir, starts, su.index, cbase, variant_word(w, v), b0, b1);
-        for (uint32_t k = b0; k < b1; k++) keys[o++] = ((unsigned long long)(dq0 + (int64_t)positions[k]) << 32) | q_end;
-    }
+#pragma unroll
+    for (int v = 0; v < 1 + kSeedWeight; v++)
+        for (uint32_t k = b0[v]; k < b1[v]; k++) keys[o++] = ((unsigned long long)(dq0 + (int64_t)positions[k]) << 32) | q_end;
 }
