@@ -50,8 +50,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("evolver", "pair"), default="evolver",
-                    help="evolver: BASELINE configs[2] stand-in (default); pair: configs[1], one synthetic chunk pair per GPU")
+    ap.add_argument("--workload", choices=("evolver", "pair", "chr20"), default="evolver",
+                    help="evolver: BASELINE configs[2] stand-in (default; weak scaling: every GPU its own phase); pair: configs[1], one synthetic "
+                         "chunk pair per GPU; chr20: configs[3], ONE genome pair whose chunk pairs are dealt to the GPUs (strong scaling)")
+    ap.add_argument("--chr20-bases", type=int, default=64_444_167, help="chr20 workload: bases of the synthetic chromosome (SURVEY 8d config 4)")
+    ap.add_argument("--chr20-chunk", type=int, default=30_000_000,
+                    help="chr20 workload: chunkSize (cactus_progressive_config.xml:90; overlap 10 000, :92).  A finer chunking gives more pairs to deal "
+                         "but is not bit-comparable to the CPU path's 30 Mb chunks")
+    ap.add_argument("--primates-leg", type=int, default=1, help="evolver workload: also time the evolverPrimates stand-in, BASELINE configs[0] (0 = skip); reported under primates")
     ap.add_argument("--ancestor", type=int, default=600_000, help="ancestor length of the evolverMammals stand-in (SURVEY 8d config 3: 600 kb)")
     ap.add_argument("--size", type=int, default=1_000_000, help="bases per chunk of the pair workload / pair leg (config 2: 1 Mb)")
     ap.add_argument("--seed", type=int, default=42)
@@ -94,10 +100,16 @@ def add_stats(agg, stats_list):
         agg[k] = agg.get(k, 0) + stats_list[0][k]
 
 
-class EvolverPhase:
-    """BASELINE configs[2] stand-in on one GPU (see the module docstring)."""
+def newick_to_gen_tree(node):
+    """cactus_amd.blast_phase.Node -> the nested tuples cactus_amd.gen.make_tree_genomes walks"""
+    return (node.iD, node.distance, [newick_to_gen_tree(c) for c in node.children])
 
-    def __init__(self, a, ctx, rank):
+
+class EvolverPhase:
+    """The blast phase of a whole progressive run on one GPU: BASELINE configs[2] (evolverMammals, the headline) or configs[0]
+    (evolverPrimates) -- see the module docstring."""
+
+    def __init__(self, a, ctx, rank, which="mammals"):
         from cactus_amd import blast_phase as bp, gen, miblast
         from cactus_amd.paf.local_alignment import select_lastz_params
         from cactus_amd.shared.configWrapper import load_config
@@ -107,8 +119,15 @@ class EvolverPhase:
         blast = cfg.find("blast")
         self.trim = (int(blast.attrib["trimMinSize"]), int(blast.attrib["trimFlanking"]))
         max_div = float(cfg.find("constants").find("divergences").attrib["five"])
-        self.calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE), max_div=max_div, max_outgroups=3)
-        genomes = gen.make_tree_genomes(a.ancestor, 2001, ancestors=True)
+        if which == "mammals":
+            tree = bp.parse_newick(bp.EVOLVER_MAMMALS_TREE)
+            genomes = gen.make_tree_genomes(a.ancestor, 2001, ancestors=True)
+        else:
+            # "primates-like" set, 600 kb ancestor, the leaves at the tree distances of examples/evolverPrimates.txt:1, seed 1001
+            tree = bp.parse_newick(bp.EVOLVER_PRIMATES_TREE)
+            t = newick_to_gen_tree(tree)
+            genomes = gen.make_tree_genomes(a.ancestor, 1001, tree=("root", t[2]), ancestors=True)
+        self.calls = bp.blast_phase_calls(tree, max_div=max_div, max_outgroups=3)
         # every rank runs the same phase (weak scaling with per-GPU work held exactly constant); only the names differ
         self.fasta = {k: gen.fasta_bytes([("id=%s|%s_r%d" % (k, k, rank), v)]) for k, v in genomes.items()}
         self.resident = {fa: ctx.seqset_from_fasta_bytes(fa) for fa in self.fasta.values()}      # genomes resident in HBM before the timed region
@@ -117,16 +136,18 @@ class EvolverPhase:
         self.params = {}
         # the option sets of a dependency level are independent jobs too (1 x "four" beside 9 x "default" at level 0): each gets its
         # own context (stream + workspace) on this GPU and they run concurrently, as Toil runs independent jobs of a node.
-        # (MIBLAST_BENCH_CONTEXTS=3 MIBLAST_BENCH_SPLIT=6 also runs a large group as two concurrent calls: 41 instead of 50 ms per
-        # phase on the MI355X, but DP launches of two streams then share the GPU and their HIP-event durations -- the roofline's
-        # denominator -- no longer measure one kernel; the default keeps the kernel figures clean.)
         self.contexts = [ctx] + [miblast.Context(ctx.device) for _ in range(max(0, int(os.environ.get("MIBLAST_BENCH_CONTEXTS", "2")) - 1))]
         self.free_contexts = queue.Queue()                     # align_batch blocks on it: never more calls in flight than contexts
         for cx in self.contexts:
             self.free_contexts.put(cx)
-        self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
-                         f"examples/evolverMammals.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 2001), ingroup trimming between outgroups, "
-                         "option set per call by distance (1 x \"four\", rest \"default\")")
+        sets = sorted({self.options(c.distance).split()[0] + " ..." for c in self.calls})
+        if which == "mammals":
+            self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
+                             f"examples/evolverMammals.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 2001), ingroup trimming between outgroups "
+                             "on the device, option set per call by distance (1 x \"four\", rest \"default\")")
+        else:
+            self.describe = (f"evolverPrimates blast phase stand-in (BASELINE configs[0], SURVEY 8d config 1): {len(self.calls)} lastz calls over the guide tree of "
+                             f"examples/evolverPrimates.txt:1, synthetic genomes from a {a.ancestor} bp ancestor (seed 1001), every call option set \"one\" ({', '.join(sets)})")
 
     def step(self, keep=None):
         agg = {}
@@ -214,6 +235,64 @@ class PairWorkload:
         return agg, b"".join(r.paf for r in rs)
 
 
+class Chr20Workload:
+    """BASELINE configs[3]: ONE genome pair -- a synthetic chr20 against a 1.3 % diverged, half soft-masked copy --
+    chunked exactly as the CPU path chunks it (faffy chunk -c chunkSize -o 10000: cactus_progressive_config.xml:90-92,
+    /root/reference/src/cactus/paf/local_alignment.py:378-387), every (target chunk, query chunk) pair an independent job (:395-405)
+    with the option set of divergence "one".  The chunk pairs are dealt to the ranks longest first (cactus_amd.multigpu.assign_pairs);
+    a rank aligns its share in ONE batched call; the only exchange is the gather of the framed PAFs to rank 0, which strings them
+    together in chunk-pair order -- the bytes do not depend on the number of GPUs.  Total work is fixed: STRONG scaling."""
+
+    OPTIONS = "--step=2 --ambiguous=iupac,100,100 --ydrop=3000 --notransition --queryhspbest=100000"      # set "one", cactus_progressive_config.xml:131
+
+    def __init__(self, a, ctx, rank, world):
+        from cactus_amd import gen, miblast
+        from cactus_amd.multigpu import assign_pairs
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.pm = miblast.params_from_args(self.OPTIONS.split())
+        n, chunk, overlap = a.chr20_bases, a.chr20_chunk, 10_000
+        t, q = gen.make_pair(n, 3001, sub_rate=0.013, indel_rate=0.002, mask_frac=0.5)
+
+        def chunks(name, seq):                    # faffy chunk: records NAME|SEQLEN|START of chunkSize + overlapSize bases, one file per chunkSize bases
+            return [gen.fasta_bytes([(f"{name}|{len(seq)}|{s0}", seq[s0:s0 + chunk + overlap])]) for s0 in range(0, len(seq), chunk)]
+
+        self.tfa, self.qfa = chunks("id=simT|chr20", t), chunks("id=simQ|chr20", q)
+        self.pairs = [(i, j) for i in range(len(self.tfa)) for j in range(len(self.qfa))]
+        self.weights = [float(len(self.tfa[i])) * float(len(self.qfa[j])) for i, j in self.pairs]
+        self.mine = assign_pairs(self.weights, world)[rank]
+        need_t, need_q = sorted({self.pairs[k][0] for k in self.mine}), sorted({self.pairs[k][1] for k in self.mine})
+        self.T = {i: ctx.seqset_from_fasta_bytes(self.tfa[i]) for i in need_t}                 # only this rank's chunks go to its HBM
+        self.Q = {j: ctx.seqset_from_fasta_bytes(self.qfa[j]) for j in need_q}
+        self.describe = (f"synthetic chr20 x chr20 (BASELINE configs[3], SURVEY 8d config 4): {len(t)} x {len(q)} bp at 1.3 % divergence, half soft-masked, seed 3001; "
+                         f"chunkSize {chunk} + overlap {overlap} -> {len(self.tfa)} x {len(self.qfa)} chunk pairs, option set \"one\", dealt longest first to {world} GPU(s)")
+
+    def step(self, keep=None):
+        from cactus_amd.multigpu import _frame
+        agg = {}
+        blob = b""
+        if self.mine:
+            sets = [(self.T[self.pairs[k][0]], self.Q[self.pairs[k][1]]) for k in self.mine]
+            rs = self.ctx.align_pairs(sets, self.pm) if len(sets) > 1 else [self.ctx.align(*sets[0], self.pm, details=False)]
+            add_stats(agg, [r.stats for r in rs])
+            blob = b"".join(_frame(k, r.paf) for k, r in zip(self.mine, rs))
+            if keep is not None:
+                keep.extend((self.tfa[self.pairs[k][0]], self.qfa[self.pairs[k][1]], self.OPTIONS, r.paf) for k, r in zip(self.mine, rs))
+        else:
+            for k in PER_PAIR + PER_BATCH:
+                agg[k] = 0
+        return agg, blob
+
+    def assemble(self, gathered):
+        """rank 0: the ranks' framed PAFs -> one PAF in chunk-pair order"""
+        from cactus_amd.multigpu import _unframe
+        by_index = {}
+        for part in gathered:
+            for idx, paf in _unframe(part):
+                by_index[idx] = paf
+        assert sorted(by_index) == list(range(len(self.pairs))), "a chunk pair is missing from the gather"
+        return b"".join(by_index[k] for k in range(len(self.pairs)))
+
+
 def cpu_throttle_state():
     """(nr_throttled, throttled_usec) of this container's CPU cgroup -- the bench box runs under a CPU quota; a process whose threads
     exceed it is frozen for the rest of the 100 ms period, which shows up as outlier steps"""
@@ -299,12 +378,14 @@ def run_rank(a):
     host_threads = share_host_cores(int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else miblast.set_host_threads(0)
     ctx = miblast.Context(local_rank)
     coll_dev = torch.device("cuda", local_rank) if coll_backend != "gloo" else torch.device("cpu")
-    work = EvolverPhase(a, ctx, rank) if a.workload == "evolver" else PairWorkload(a, ctx, rank)
+    work = EvolverPhase(a, ctx, rank) if a.workload == "evolver" else Chr20Workload(a, ctx, rank, world) if a.workload == "chr20" else PairWorkload(a, ctx, rank)
     gathered = {}
 
     def gather(paf: bytes):
-        """final hit list -> rank 0 (RCCL over xGMI)"""
+        """final hit list -> rank 0 (RCCL over xGMI); the sharded workload strings the ranks' shares together there"""
         gathered["last"] = gather_bytes(paf, dist, rank, world, coll_dev)
+        if a.workload == "chr20" and rank == 0:
+            gathered["paf"] = work.assemble(gathered["last"])
 
     def sync():
         if dist is not None:
@@ -324,16 +405,19 @@ def run_rank(a):
     tot = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
 
     if rank == 0:
-        per = a.steps * world
+        per = a.steps * (1 if a.workload == "chr20" else world)      # per-step figures: of one rank's phase (weak) / of the whole sharded job (strong)
         out = {
             "metric": "gapped X-drop Gcell/s (blast phase, whole job)",
             "value": tot["dp_cells"] / elapsed / 1e9,
             "unit": "Gcell/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if a.workload == "chr20" else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": work.describe, "sharding": "every GPU runs its own copy of the phase (chunk pairs are independent jobs); gather of the PAF to rank 0",
+            "config": {"workload": work.describe,
+                       "sharding": ("the chunk pairs of ONE genome pair dealt longest first to the GPUs (independent jobs, no data-path collective); framed PAFs "
+                                    "gathered to rank 0 and strung together in chunk-pair order") if a.workload == "chr20" else
+                                   "every GPU runs its own copy of the phase (chunk pairs are independent jobs); gather of the PAF to rank 0",
                        "collective_backend": coll_backend, "host_threads_per_rank": host_threads,
                        "paf_bytes_gathered_per_step": sum(len(x) for x in gathered["last"]) if gathered.get("last") else 0},
             "seeds_per_s": tot["seed_hits"] / elapsed,
@@ -366,6 +450,16 @@ def run_rank(a):
                                        "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9}
         except Exception as e:                               # noqa: BLE001  (never lose the line over a device-property quirk)
             out["roofline"]["valu"] = {"error": str(e)}
+        if a.workload == "chr20":
+            import hashlib
+            out["config"]["paf_md5"] = hashlib.md5(gathered["paf"]).hexdigest()
+            out["config"]["paf_bytes"] = len(gathered["paf"])
+            out["config"]["chunk_pairs_per_rank"] = [len(x) for x in __import__("cactus_amd.multigpu", fromlist=["assign_pairs"]).assign_pairs(work.weights, world)]
+        out["roofline"]["overlap_note"] = ("a call of several pairs runs the gapped stages of two groups of its pairs on two streams (MIBLAST_GAPPED_LANES=2): their DP launches "
+                                           "share the GPU, so a launch's HIP-event duration -- the denominator here -- is longer than it would be alone, and the "
+                                           "durations add up to more than the wall time they cover")
+        if a.workload == "evolver" and a.primates_leg > 0:
+            out["primates"] = primates_leg(a, ctx)
         if a.workload == "evolver" and a.pair_leg > 0:
             out["pair_1mb"] = pair_leg(a, ctx)
         if a.batch_leg > 1:
@@ -375,7 +469,13 @@ def run_rank(a):
         if a.chain_leg > 0:
             out["chain_stage"] = chain_stage_leg(a, ctx)
         if a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / per, work.describe)
+            if a.workload == "chr20":
+                # the oracle needs a minute per 30 Mb x 30 Mb chunk pair: the bounded sample is the smallest pair of rank 0's share
+                if keep:
+                    small = min(keep, key=lambda c: len(c[0]) * len(c[1]))
+                    out["cpu_baseline"] = cpu_baseline([small], None, "the smallest chunk pair of rank 0's share of: " + work.describe)
+            else:
+                out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / per, work.describe)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -400,6 +500,24 @@ def pair_leg(a, ctx):
         out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / a.steps, w.describe)
     for t, q in w.sets:
         t.close(); q.close()
+    return out
+
+
+def primates_leg(a, ctx):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): the blast phase of the evolverPrimates run -- every pair within
+    divergence "one" -- on the same terms as the headline: whole phase per step, genomes resident, oracle diff of every call."""
+    w = EvolverPhase(a, ctx, 0, which="primates")
+    elapsed, tot, keep = timed_steps(w, max(3, a.steps // 2), 2, lambda: None, lambda paf: None)
+    steps = max(3, a.steps // 2)
+    out = {"workload": w.describe, "ms_per_step": 1e3 * elapsed / steps, "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s", "calls": len(w.calls),
+           "seeds_per_s": tot["seed_hits"] / elapsed, "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
+           "dp_cells_per_step": tot["dp_cells"] / steps, "alignments_per_step": tot["alignments"] / steps,
+           "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / steps, "ungapped": tot["t_ungapped_kernel_ms"] / steps,
+                                        "sort": tot["t_sort_ms"] / steps, "seed_fill": tot["t_seedfill_ms"] / steps}}
+    if a.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / steps, w.describe)
+    for h in w.resident.values():
+        h.close()
     return out
 
 
@@ -497,8 +615,11 @@ def chain_stage_leg(a, ctx):
 
 
 def cpu_baseline(kept_calls, dp_cells_gpu, describe):
-    """CPU oracle (kind "port": the in-repo C restatement, 1 thread like a lastz job) on the lastz calls of the last timed step --
-    the same FASTA bytes and option strings, call by call -- timed on this box's host cores, every PAF compared with the GPU's."""
+    """CPU oracle (kind "port": the in-repo C restatement) on the lastz calls of the last timed step -- the same FASTA bytes and
+    option strings, call by call -- timed on this box's host cores, every PAF compared with the GPU's.  Two figures: one core,
+    the calls one after the other (1 thread like a lastz job; this run makes the byte diff), and SURVEY 8d's CPU throughput model
+    -- min(calls, cores) single-threaded oracle processes at a time, each pinned to a core with taskset, as Toil schedules lastz
+    jobs on a node (defaultCpu="1", cactus_progressive_config.xml:4)."""
     from cactus_amd import miblast
     from oracle import olz
     cells = hits = 0
@@ -513,10 +634,56 @@ def cpu_baseline(kept_calls, dp_cells_gpu, describe):
             same = False
             n_diff += 1
     dt = time.perf_counter() - t0
-    return {"value": cells / dt / 1e9, "unit": "Gcell/s", "cores": 1, "kind": "port",
-            "sample": f"all {len(kept_calls)} lastz calls of one step of: {describe} ({dt:.1f} s of CPU work, one after the other on one core)",
-            "seeds_per_s": hits / dt, "seconds": dt, "calls": len(kept_calls),
-            "same_bytes": same, "calls_differing": n_diff, "same_dp_cells": int(cells) == int(round(dp_cells_gpu))}
+    out = {"value": cells / dt / 1e9, "unit": "Gcell/s", "cores": 1, "kind": "port",
+           "sample": f"all {len(kept_calls)} lastz calls of one step of: {describe} ({dt:.1f} s of CPU work, one after the other on one core)",
+           "seeds_per_s": hits / dt, "seconds": dt, "calls": len(kept_calls),
+           "same_bytes": same, "calls_differing": n_diff,
+           "same_dp_cells": None if dp_cells_gpu is None else int(cells) == int(round(dp_cells_gpu))}
+    try:
+        out["node"] = cpu_baseline_concurrent(kept_calls, cells, hits)
+    except Exception as e:                                   # noqa: BLE001  (the figure above stands on its own)
+        out["node"] = {"error": str(e)}
+    return out
+
+
+def cpu_baseline_concurrent(kept_calls, cells, hits):
+    """min(calls, cores) oracle processes at a time (oracle/oracle_lastz, the lastz-argv front end of the same restatement), one core
+    each: wall time of the whole list, longest calls first."""
+    import shutil
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "oracle_lastz")
+    if not os.path.exists(exe):
+        raise RuntimeError("oracle/oracle_lastz is not built")
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    width = max(1, min(len(kept_calls), len(cores)))
+    work = tempfile.mkdtemp(prefix="miblast_cpu_")
+    try:
+        jobs = []
+        for k, (tf, qf, opts, paf) in enumerate(kept_calls):
+            tp, qp = os.path.join(work, f"{k}.t.fa"), os.path.join(work, f"{k}.q.fa")
+            open(tp, "wb").write(tf); open(qp, "wb").write(qf)
+            jobs.append((len(tf) * len(qf), k, [exe, tp + "[multiple][nameparse=darkspace]", qp + "[nameparse=darkspace]", "--format=paf:wfmash"] + opts.split(), paf))
+        jobs.sort(key=lambda x: (-x[0], x[1]))
+        taskset = shutil.which("taskset")
+        free, running, same = list(cores[:width]), [], True
+        t0 = time.perf_counter()
+        pending = list(jobs)
+        while pending or running:
+            while pending and free:
+                _, k, cmd, paf = pending.pop(0)
+                core = free.pop(0)
+                p = subprocess.Popen(([taskset, "-c", str(core)] if taskset else []) + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                running.append((p, core, paf))
+            p, core, paf = running.pop(0)                     # (the longest were started first: waiting in start order costs nothing)
+            got = p.communicate()[0]
+            same = same and p.returncode == 0 and got == paf
+            free.append(core)
+        wall = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return {"value": cells / wall / 1e9, "unit": "Gcell/s", "seeds_per_s": hits / wall, "cores": width, "cores_available": len(cores), "seconds_wall": wall,
+            "pinned_with_taskset": bool(taskset), "same_bytes": same,
+            "model": "SURVEY 8d: min(calls, cores) single-threaded processes at a time, one lastz job per core"}
 
 
 def main():

@@ -34,8 +34,10 @@ def share_host_cores(local_world_size: int) -> int:
 
 
 def gather_bytes(payload: bytes, dist, rank: int, world_size: int, device) -> Optional[List[bytes]]:
-    """Variable-length gather to rank 0: all_gather of the byte counts, then one padded gather
-    (the 'gatherv' of SURVEY 8e; payload is small next to xGMI bandwidth, so latency matters, not size)."""
+    """Variable-length gather to rank 0 (the 'gatherv' of SURVEY 8e): all_gather of the byte counts, then every peer sends its
+    bytes straight to rank 0 (point-to-point: over xGMI every peer has a link of its own to GPU 0) into a tensor of exactly that
+    size -- nothing is padded to the largest payload, nothing of size world x max is ever allocated (a human-mouse run gathers
+    gigabytes)."""
     import torch
     if world_size == 1:
         return [payload]
@@ -43,15 +45,19 @@ def gather_bytes(payload: bytes, dist, rank: int, world_size: int, device) -> Op
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world_size)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
-    mx = max(1, max(sizes))
-    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-    if payload:
-        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-    out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world_size)] if rank == 0 else None
-    dist.gather(buf, out, dst=0)
     if rank != 0:
+        if payload:
+            dist.send(torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device), dst=0)
         return None
-    return [bytes(o[:s].cpu().numpy()) for o, s in zip(out, sizes)]
+    parts = [payload]
+    for src in range(1, world_size):
+        if sizes[src] == 0:
+            parts.append(b"")
+            continue
+        buf = torch.empty(sizes[src], dtype=torch.uint8, device=device)
+        dist.recv(buf, src=src)
+        parts.append(buf.cpu().numpy().tobytes())
+    return parts
 
 
 def _frame(index: int, paf: bytes) -> bytes:

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0", "--pair-leg", "0", "--batch-leg", "0"]
+SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0", "--pair-leg", "0", "--batch-leg", "0", "--primates-leg", "0"]
 
 
 def _bench(args, **env):
@@ -45,6 +45,39 @@ def test_bench_gpus_2_really_runs_two_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL], capture_output=True, text=True,
                        env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr                   # a launcher that started the wrong number of ranks is an error
+
+
+def test_primates_leg_and_the_node_wide_cpu_baseline():
+    out = _bench([x if x != "0" or prev != "--primates-leg" else "1" for prev, x in zip([""] + SMALL, SMALL)])
+    pr = out["primates"]
+    assert "evolverPrimates" in pr["workload"] and "configs[0]" in pr["workload"] and pr["calls"] == 9
+    assert pr["cpu_baseline"]["same_bytes"] is True and pr["cpu_baseline"]["same_dp_cells"] is True
+    node = out["cpu_baseline"]["node"]
+    assert node["same_bytes"] is True and node["cores"] >= 1 and node["value"] > 0 and "min(calls, cores)" in node["model"]
+
+
+def test_chr20_workload_shards_one_genome_pair_and_the_bytes_do_not_depend_on_the_ranks(olz):
+    """BASELINE configs[3] at a two-hundredth of the size: the chunk pairs of ONE genome pair dealt over 1, 2 and 3 ranks (all on
+    this box's GPU, gloo) -- strong scaling, the assembled PAF identical for every world size and equal to the oracle's per-pair
+    outputs strung together in chunk-pair order."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    from cactus_amd import gen, miblast
+    args = ["--workload", "chr20", "--chr20-bases", "300000", "--chr20-chunk", "120000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0",
+            "--batch-leg", "0", "--cpu-sample", "0"]
+    one = _bench(args)
+    assert one["scaling"] == "strong" and "configs[3]" in one["config"]["workload"] and one["config"]["chunk_pairs_per_rank"] == [9]
+    t, q = gen.make_pair(300000, 3001, sub_rate=0.013, indel_rate=0.002, mask_frac=0.5)
+    chunks = lambda name, seq: [gen.fasta_bytes([(f"{name}|{len(seq)}|{s0}", seq[s0:s0 + 130000])]) for s0 in range(0, len(seq), 120000)]      # noqa: E731
+    pm = miblast.params_from_args("--step=2 --ambiguous=iupac,100,100 --ydrop=3000 --notransition --queryhspbest=100000".split())
+    po = olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_})
+    want = b"".join(olz.align(tf, qf, po, details=False)["paf"] for tf in chunks("id=simT|chr20", t) for qf in chunks("id=simQ|chr20", q))
+    assert one["config"]["paf_md5"] == hashlib.md5(want).hexdigest() and one["config"]["paf_bytes"] == len(want) > 1000
+    for n in (2, 3):
+        many = _bench(args + ["--gpus", str(n)], MIBLAST_BENCH_SINGLE_DEVICE="1", MIBLAST_BENCH_BACKEND="gloo")
+        assert many["n_gpus"] == n and many["scaling"] == "strong" and sum(many["config"]["chunk_pairs_per_rank"]) == 9 and len(many["config"]["chunk_pairs_per_rank"]) == n
+        assert many["config"]["paf_md5"] == one["config"]["paf_md5"]
+        assert many["dp_cells_per_step"] == one["dp_cells_per_step"]                     # the whole job's work, whoever did it
 
 
 def _rank_main(rank, world, port, out_path):

@@ -528,6 +528,57 @@ def test_evolver_phase_with_trimming_on_the_device_equals_the_oracle_call_by_cal
         h.close()
 
 
+def test_evolver_primates_phase_at_full_size_equals_the_oracle_call_by_call(gpu_ctx, olz):
+    """BASELINE configs[0] as a parity test: the evolverPrimates stand-in of SURVEY 8d config 1 (600 kb ancestor, seed 1001, the guide
+    tree of /root/reference/examples/evolverPrimates.txt:1) -- nine lastz calls, every one with option set "one" -- through the
+    batched calls and the device trimming the bench uses, every call diffed byte for byte and counter for counter."""
+    from cactus_amd import blast_phase as bp, gen, miblast
+    from cactus_amd.paf.local_alignment import select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    tree = bp.parse_newick(bp.EVOLVER_PRIMATES_TREE)
+    calls = bp.blast_phase_calls(tree)
+
+    def nested(n):
+        return (n.iD, n.distance, [nested(c) for c in n.children])
+
+    genomes = gen.make_tree_genomes(600_000, 1001, tree=("root", nested(tree)[2]), ancestors=True)
+    assert set(genomes) == {"simOrang", "simChimp", "simHuman", "simGorilla", "cb", "hcb", "Anc0"}
+    fasta = {k: gen.fasta_bytes([("id=%s|%s" % (k, k), v)]) for k, v in genomes.items()}
+    resident = {fa: gpu_ctx.seqset_from_fasta_bytes(fa) for fa in fasta.values()}
+    made, seen = [], []
+
+    def align_batch(pairs, opts):
+        assert opts.startswith("--step=2 ") and "--notransition" in opts                      # set "one" everywhere
+        pm = miblast.params_from_args(opts.split())
+        sets = [(resident[t], q if isinstance(q, miblast.SeqSet) else resident[q]) for t, q in pairs]
+        rs = gpu_ctx.align_pairs(sets, pm)
+        seen.extend((opts, r.stats) for r in rs)
+        return [r.paf for r in rs]
+
+    def trim_resident(items, min_size, flank):
+        outs = gpu_ctx.seqsets_unaligned([q if isinstance(q, miblast.SeqSet) else resident[q] for q, _ in items], [p for _, p in items], min_size, flank)
+        made.extend(o for o in outs if o is not None)
+        return outs
+
+    align_batch.trim_resident = trim_resident
+    checked = []
+
+    def on_call(c, tf, qf, paf):
+        pm = miblast.params_from_args(select_lastz_params(c.distance, cfg, 0).split())
+        want = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}), details=False)
+        assert paf == want["paf"], (c.node, c.kind, c.level)
+        checked.append(want["counters"])
+
+    bp.run_blast_phase(fasta, calls, lambda d: select_lastz_params(d, cfg, 0), align_batch, on_call=on_call)
+    assert len(checked) == 9 == len(seen)
+    for k in ("seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_cells", "alignments"):
+        assert sum(c[k] for c in checked) == sum(st[k] for _, st in seen), k
+    assert sum(c["dp_cells"] for c in checked) > 3e8
+    for h in list(resident.values()) + made:
+        h.close()
+
+
 def test_full_size_chunk_pair_equals_the_oracle_digest(gpu_ctx):
     """One chunk pair at Cactus's full chunk size (30 Mb x 30 Mb, 1.3 % divergence, half soft-masked, parameter
     set "one"): PAF bytes and counters equal the CPU oracle's, which takes a minute on this input and is therefore committed as a
