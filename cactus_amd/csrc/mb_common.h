@@ -240,6 +240,10 @@ void launch_batch_seed_fill(const SeedUnit *units, int n_units, const BatchTarge
 void launch_cov_mark(const long long *spans, int n, uint32_t *diff, hipStream_t s);
 void launch_cov_edges(const uint32_t *depth, const uint8_t *codes, int64_t total, unsigned *n_edges, long long *first, long long *last, unsigned cap, hipStream_t s);
 void launch_gather_stretches(const uint8_t *src, uint8_t *dst, const long long *iv, int n_iv, int64_t total, hipStream_t s);
+size_t sort_pairs_temp_bytes(int64_t n);
+void launch_ungapped_hash16(const unsigned long long *keys, int64_t n_hits, const UnitTab &ut, int64_t n_diagonals, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
+                            UngappedCounters *ctr, const UxScratch *ux, unsigned long long *ka, unsigned long long *kb, uint32_t *va, uint32_t *vb, void *temp,
+                            size_t temp_bytes, int32_t *extent, hipStream_t s);
 size_t sort_keys_temp_bytes(int64_t n, int end_bit);
 void sort_keys(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, int64_t n, int begin_bit, int end_bit,
                hipStream_t s);

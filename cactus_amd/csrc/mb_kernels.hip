@@ -758,6 +758,42 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     MB_HIP(hipGetLastError());                                                   // (a launch that was refused -- grid size, LDS -- must not pass as "no HSPs")
 }
 
+// ---- diagonal suppression through the 16-bit diagonal hash (miblast_params.diag_hash16) ------------------------------------------
+#include "mb_hash16.h"
+
+size_t sort_pairs_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (size_t)n, 0, 64, (hipStream_t)0);
+    return bytes;
+}
+
+// every hit extended (level-synchronous pipeline without long diagonals), then the rule per (unit, hash class) in generation order.
+// ka / kb: n_hits u64 each, va / vb: n_hits u32 each, temp: sort_pairs_temp_bytes(n_hits)
+void launch_ungapped_hash16(const unsigned long long *keys, int64_t n_hits, const UnitTab &ut, int64_t n_diagonals, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
+                            UngappedCounters *ctr, const UxScratch *ux, unsigned long long *ka, unsigned long long *kb, uint32_t *va, uint32_t *vb, void *temp,
+                            size_t temp_bytes, int32_t *extent, hipStream_t s) {
+    if (n_hits <= 0) return;
+    MB_HIP(hipMemsetAsync(ux->long_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
+    MB_HIP(hipMemsetAsync(ux->dirty_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
+    MB_HIP(hipMemsetAsync(ux->n_entries, 0, 2 * sizeof(unsigned), s));
+    MB_HIP(hipMemsetAsync(ux->blk_cnt, 0, 2 * (size_t)ux->n_blk * sizeof(unsigned), s));
+    UxScratch sc = *ux;
+    sc.extent = extent; sc.extent_live = 0;
+    hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, ut, xdrop, K, sc, hsps, hsp_cap, ctr);
+    const unsigned tail_blocks = (unsigned)std::min<int64_t>(2048, ((int64_t)sc.entry_cap + 2 * (int64_t)sc.n_blk + 31) / 32);
+    hipLaunchKernelGGL(k_ux_tail, dim3(tail_blocks), dim3(256), 0, s, keys, n_hits, ut, xdrop, K, sc, hsps, hsp_cap, ctr);
+    const unsigned blocks = (unsigned)((n_hits + 255) / 256);
+    hipLaunchKernelGGL(k_h16_tkeys, dim3(blocks), dim3(256), 0, s, keys, n_hits, ut, ka, va);
+    MB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, ka, kb, va, vb, (size_t)n_hits, 0, 31, s));
+    hipLaunchKernelGGL(k_h16_ckeys, dim3(blocks), dim3(256), 0, s, keys, n_hits, ut, vb, ka);
+    MB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, ka, kb, vb, va, (size_t)n_hits, 0, 59, s));
+    hipLaunchKernelGGL(k_h16_resolve, dim3(blocks), dim3(256), 0, s, kb, va, n_hits, sc.rec, hsps, ctr);
+    hipLaunchKernelGGL(k_ux_census, dim3(256), dim3(256), 0, s, ut, hsps, hsp_cap, ctr);
+    hipLaunchKernelGGL(k_hsp_anchor, dim3(512), dim3(256), 0, s, ut, hsps, hsp_cap, ctr);
+    MB_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------
 // One-sided Y-drop DP (A.7 / A.10 ONE_SIDED), single pass with trace.
 //

@@ -113,7 +113,9 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
     const int n_dev = (int)ctxs.size();
     if (n_dev <= 0 || n_pairs == 0) { set_error("align_blocked: nothing to do"); return MIBLAST_EINVAL; }
     const int64_t cap = std::min<int64_t>(kBlockCap, std::max<int64_t>(64, env_ll("MIBLAST_BLOCK_BASES", kBlockCap)));
-    const bool one_block_only = p.format != 0 || p.markend;          // one header / end marker per job: not assembled from blocks
+    // one header / end marker per job, suppression state shared by diagonals 65536 apart (diag=hash16), earlier alignments as walls
+    // for later ones: such jobs are not assembled from blocks
+    const bool one_block_only = p.format != 0 || p.markend || p.diag_hash16 || p.walls;
     const int step = std::max(1, p.step);
 
     // ---- blocks and the job grid ---------------------------------------------------------------------------------
@@ -135,7 +137,7 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
         if (rc == MIBLAST_OK) rc = partition(Q, cap, one_block_only ? cap : q_limit, qblk[k]);
         if (rc != MIBLAST_OK) return rc;
         if (one_block_only && (tblk[k].size() > 1 || qblk[k].size() > 1)) {
-            set_error("--format=general / --markend jobs are not assembled from blocks: input longer than 2^30 bases");
+            set_error("--format=general / --markend / --miblast-diag=hash16 / --miblast-walls jobs are not assembled from blocks: input longer than 2^30 bases");
             return MIBLAST_ELIMIT;
         }
         if (tblk[k].size() > 1 && (p.queryhspbest > 0 || p.queryhsplimit > 0)) {

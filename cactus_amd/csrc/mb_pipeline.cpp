@@ -548,6 +548,8 @@ struct Workspace {                      // device buffers that persist across mi
     // batched seed stage (seed_phase_batched): sparse tables of the call's distinct targets, unit tables, per-unit counters
     DevBuf<unsigned long long> bx_bits, bx_scan;
     DevBuf<uint32_t> bx_dir, bx_bsum, bx_words, bx_cnt, bx_starts, bx_positions;
+    DevBuf<unsigned long long> h16_ka, h16_kb;               // diag_hash16: sort keys and values of the resolve pass
+    DevBuf<uint32_t> h16_va, h16_vb;
     DevBuf<BatchTarget> bx_targets;
     DevBuf<SeedUnit> bx_units;
     PinBuf<unsigned long long> pin_scan;
@@ -1324,6 +1326,7 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         target_of[k] = (int)t;
     }
     if (targets.size() > (size_t)env_long("MIBLAST_BATCH_TARGETS", 64)) return MIBLAST_OK;
+    if (p.diag_hash16 && 2 * n > 256) return MIBLAST_OK;                                      // (the class keys of mb_hash16.h hold 8 bits of unit)
     const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
 
     // ---- tables
@@ -1426,7 +1429,9 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         w.heads.ensure(2 * nh + nh / 4 + 64); w.n_heads.ensure(8);
         const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(n_diag + 2))));
         const size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
-        w.sort_temp.ensure(tb + 16);
+        const size_t pb = p.diag_hash16 ? sort_pairs_temp_bytes((int64_t)nh) : 0;
+        w.sort_temp.ensure(std::max(tb, pb) + 16);
+        if (p.diag_hash16) { w.h16_ka.ensure(nh); w.h16_kb.ensure(nh); w.h16_va.ensure(nh); w.h16_vb.ensure(nh); }
         w.extent.ensure((size_t)n_diag + 2);
         w.ctr.ensure(units.size());
         MB_HIP(hipMemsetAsync(w.extent.p, 0, ((size_t)n_diag + 2) * 4, s));
@@ -1441,6 +1446,11 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         const UxScratch uxs = ux_scratch(w, w.keys_a.p, nh, n_diag + 2);            // (the unsorted keys are free now)
         UnitTab ut;
         ut.one = units[0]; ut.tab = w.bx_units.p; ut.n = (int32_t)units.size();
+        if (p.diag_hash16) {
+            // lastz's 16-bit diagonal hash: every hit extended, the rule per hash class afterwards (mb_hash16.h)
+            launch_ungapped_hash16(w.keys_b.p, (int64_t)nh, ut, n_diag, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, w.ctr.p, &uxs, w.h16_ka.p, w.h16_kb.p, w.h16_va.p,
+                                   w.h16_vb.p, w.sort_temp.p, pb, w.extent.p, s);
+        } else
         launch_ungapped(w.keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, ut, n_diag, w.extent.p, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, w.ctr.p, &uxs, true, s);
         MB_HIP(hipEventRecord(ctx.ev0, s));
         constexpr size_t kBlind = 1 << 16;                                          // HSPs copied back before their number is known
@@ -2765,9 +2775,8 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     ctx.ws->stage.abort();
     for (Ctx *lane : ctx.ws->lanes) lane->ws->stage.abort();
     miblast_params p = pin;
-    if (p.diag_hash16 || p.walls) {
-        set_error("diag=hash16 / walls are comparison modes of the CPU oracle only -- oracle only (SURVEY A.9 #4, #8): the MI355X path implements exact "
-                  "per-diagonal suppression and no walls");
+    if (p.walls) {
+        set_error("walls (SURVEY A.9 #8) is a comparison mode of the CPU oracle only: the MI355X path implements the covered-anchor rule without walls");
         return MIBLAST_EINVAL;
     }
     if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
@@ -2790,12 +2799,16 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, env_long("MIBLAST_SEED_LANES", 12))) : 1;
     // MIBLAST_SEED_BATCHED: 1 (default) the seed stages of a call of several pairs share their launches (seed_phase_batched);
     // 2: a single pair goes that way too (tests); 0: never -- pair by pair on the lanes below
-    const long batched_mode = env_long("MIBLAST_SEED_BATCHED", 1);
+    const long batched_mode = p.diag_hash16 ? 2 : env_long("MIBLAST_SEED_BATCHED", 1);      // (diag=hash16 lives in the shared seed stage only)
     bool batched_done = false;
     if (n >= 1 && (batched_mode >= 2 || (batched_mode == 1 && n > 1))) {
         int rc = seed_phase_batched(ctx, p, jobs, batched_done);
         if (rc != MIBLAST_OK) return rc;
         if (!batched_done) for (PairJob *j : jobs) { j->found[0].clear(); j->found[1].clear(); j->units.clear(); }
+    }
+    if (p.diag_hash16 && !batched_done) {
+        set_error("diag=hash16: the call does not fit one seed batch (more hits than MIBLAST_HIT_CAP, more than 128 pairs, or coordinates beyond 31 bits)");
+        return MIBLAST_ELIMIT;
     }
     if (batched_done) {
     } else if (n_lanes > 1) {

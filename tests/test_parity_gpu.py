@@ -656,16 +656,59 @@ def test_chunked_genome_pair_through_the_job_functions(gpu_ctx, olz, tmp_path):
         a.close(); b.close()
 
 
-def test_oracle_only_comparison_switches_are_refused_not_ignored(gpu_ctx):
-    """diag=hash16 / walls exist in the oracle for the day a lastz binary can be compared; the MI355X path
-    implements the default reading only and must say so rather than silently compute something else."""
+@pytest.mark.parametrize("name,tf,qf,args", CASES, ids=CASE_IDS)
+def test_case_matches_oracle_with_the_16_bit_diagonal_hash(gpu_ctx, olz, monkeypatch, name, tf, qf, args):
+    """--miblast-diag=hash16 (lastz keys its suppression state by (t_end - q_end) & 0xFFFF, so a hit can be
+    dropped because of an extension on a diagonal 65536 away): the MI355X path extends every hit and applies the rule per hash class
+    in generation order (mb_hash16.h); bytes, HSPs in discovery order and counters as the oracle's in the same mode."""
+    monkeypatch.setenv("MIBLAST_CHECK_ANCHORS", "1")
+    pm = _params(list(args) + ["--miblast-diag=hash16"])
+    assert pm.diag_hash16 == 1
+    T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+    got = gpu_ctx.align(T, Q, pm)
+    want = olz.align(tf, qf, _oracle_params(olz, pm))
+    assert got.hsps == want["hsps"]
+    assert got.paf == want["paf"]
+    assert got.alns == want["alns"] and got.ops == want["ops"]
+    for k in COUNTERS:
+        assert got.stats[k] == want["counters"][k], k
+
+
+def test_the_16_bit_diagonal_hash_drops_hits_across_diagonals_like_the_oracle(gpu_ctx, olz):
+    """Sequences long enough for diagonals 65536 apart to collide (tandem copies of one segment 65536 bases apart, a batched call of
+    several such pairs): the hash mode differs from the exact mode, and the MI355X path follows the oracle in both."""
+    import numpy as np
+    from cactus_amd import gen
+    rng = np.random.default_rng(5)
+    unit = gen.random_sequence(65536, rng)
+    t = np.concatenate([unit, gen.mutate(unit, np.random.default_rng(6), 0.02, 0.0), unit[:30000]])
+    q = np.concatenate([gen.mutate(unit[:50000], np.random.default_rng(7), 0.03, 0.001), gen.random_sequence(20000, rng)])
+    fastas = [(gen.fasta_bytes([("T|a", t)]), gen.fasta_bytes([("Q|a", q)])), (gen.fasta_bytes([("T|b", t[::-1].copy()), ("T|c", unit)]), gen.fasta_bytes([("Q|b", q), ("Q|c", unit[1000:40000])]))]
+    differs = 0
+    for extra in ([], ["--miblast-diag=hash16"]):
+        pm = _params(["--step=1", "--hspthresh=2200", "--gappedthresh=2400", "--ydrop=4000", "--ambiguous=iupac,100,100"] + extra)
+        sets = [(gpu_ctx.seqset_from_fasta_bytes(a), gpu_ctx.seqset_from_fasta_bytes(b)) for a, b in fastas]
+        got = gpu_ctx.align_pairs(sets, pm, details=True)
+        for (a, b), r in zip(fastas, got):
+            want = olz.align(a, b, _oracle_params(olz, pm))
+            assert r.hsps == want["hsps"] and r.paf == want["paf"]
+            for k in COUNTERS:
+                assert r.stats[k] == want["counters"][k], (k, extra)
+            differs += want["counters"]["hits_extended"] * (1 if extra else -1)
+        for x, y in sets:
+            x.close(); y.close()
+    assert differs != 0                                          # the collision really happens on these inputs: the modes extend different numbers of hits
+
+
+def test_walls_switch_is_refused_not_ignored(gpu_ctx):
+    """walls exists in the oracle for the day a lastz binary can be compared; the MI355X path implements the
+    covered-anchor rule without walls and must say so rather than silently compute something else."""
     from cactus_amd import miblast
     from cases import pair, KEG_DEFAULT
     tf, qf = pair(5000, 3)
     T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
-    for extra in (["--miblast-diag=hash16"], ["--miblast-walls"]):
-        with pytest.raises(miblast.MiblastError, match="oracle only"):
-            gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + extra))
+    with pytest.raises(miblast.MiblastError, match="oracle only"):
+        gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + ["--miblast-walls"]))
     assert gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + ["--miblast-diag=exact"])).paf
 
 
