@@ -202,9 +202,12 @@ void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *off
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const UnitTab &ut,
                      int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                      UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s);      // ux: scratch of the level-synchronous pipeline, or nullptr; extent_clean: extent[] is all zero
+// wsegs / walns / wref: walls mode (miblast_params.walls) -- WallSeg runs of the earlier alignments, int2 run ranges per alignment, int2
+// alignment ranges per problem; nullptr without walls
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
                   int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
-                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s);
+                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s,
+                  const void *wsegs = nullptr, const void *walns = nullptr, const void *wref = nullptr, uint8_t *wflags = nullptr);
 void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena,
                    unsigned long long arena_bytes, unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir,
                    uint8_t *snaps, const int *order, hipStream_t s);      // order: piece of block b (k_ydrop2 only), or nullptr

@@ -836,6 +836,11 @@ struct YdShared {                            // LDS of one DP problem (LDS-ring 
     int iv_last, cp_last;                    // last column of a pass, for the next pass of a wide row
     unsigned long long blk, chunk; int fail; // arena allocations made by thread 0
     unsigned long long smax;                 // best cell of the exit row (score, column) packed for atomicMax
+    // walls (miblast_params.walls): one flag per ring column -- the column lies, in this row, on the path of an earlier alignment --,
+    // their number in the row, and the 64-bit (cuts, value) scan slots of the horizontal-gap chain
+    int n_blocked;
+    uint8_t wflag[2048];
+    unsigned long long scanx[kYdThreads];
 };
 
 // One workgroup (4 waves) per problem; a row is evaluated 256 columns per pass, wave w taking columns
@@ -847,14 +852,48 @@ struct YdShared {                            // LDS of one DP problem (LDS-ring 
 //   B2  after the y-drop test: each wave publishes {first break, first alive, last alive, best candidate};
 //       all waves reduce the four records identically, so no third barrier is needed.
 // C/D of the previous row live in an LDS ring of int2 indexed by column, overwritten in place.
-template <bool GLOBAL, bool PROF>
+// WALLS (miblast_params.walls): a cell that pairs a target base with a query base lying on the path of an
+// earlier alignment of the unit is dead, and neither gap state survives it (oracle/lastz_oracle.c one_sided(): Cv = Dv = Iv = NEG).
+// The earlier alignments come as their gap-free runs (WallSeg, sorted by q inside an alignment); a thread follows up to kWallPerThread
+// alignments with a cursor each while the rows advance and flags the column a path crosses the row in (at most one per alignment).
+// A dead cell cuts the horizontal-gap chain of the row.  The max-plus scan therefore runs on 64-bit keys (blocked columns up to and
+// including this one) << 32 | value: the candidates behind the last blocked column left of a lane always win -- the blocked column
+// itself is among them, with a dead value -- so what a lane reads is exactly the oracle's chain restarted after every dead cell,
+// however many a row holds.  Rows without a flagged column (nearly all) take the plain 32-bit scan.
+struct WallSeg { int32_t q0, t0, len; };      // cells (t0 + k, q0 + k), k < len, in the coordinates of the searched strand
+constexpr int kWallPerThread = 4;             // alignments per thread: a unit may hold 4 x 256 earlier alignments
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned long long dpp_max64_step(const unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROWS, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROWS, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long dpp_scan_max64(unsigned long long v) {      // inclusive prefix max over the wave (keys >= 0: 0 is the identity)
+    v = dpp_max64_step<0x111, 0xf>(v); v = dpp_max64_step<0x112, 0xf>(v); v = dpp_max64_step<0x114, 0xf>(v);
+    v = dpp_max64_step<0x118, 0xf>(v); v = dpp_max64_step<0x142, 0xa>(v); v = dpp_max64_step<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned long long dpp_shr1_64(unsigned long long v, unsigned long long fill) {      // lane l <- lane l-1, lane 0 <- fill
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)fill, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(fill >> 32), (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wall_key(int cuts, int x) { return ((unsigned long long)(unsigned)cuts << 32) | (unsigned)(x ^ (int)0x80000000); }
+__device__ __forceinline__ int wall_val(unsigned long long k) { return (int)((unsigned)k ^ 0x80000000u); }
+
+template <bool GLOBAL, bool PROF, bool WALLS>
 __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const gbytes tc,
                                            const gbytes qc, const int O, const int E, const int Y,
                                            int2 *CD, uint8_t *Tb, const int cap, YdShared *sh,
                                            uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                                            unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
-                                           unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps) {
+                                           unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps,
+                                           const WallSeg *__restrict__ wsegs = nullptr, const int2 *__restrict__ walns = nullptr, const int wa0 = 0, const int wa1 = 0,
+                                           uint8_t *__restrict__ gflags = nullptr) {
     const int tid = threadIdx.x;
+    uint8_t *const wflag = WALLS ? (GLOBAL ? gflags : sh->wflag) : nullptr;       // one flag per ring column (HBM ring: zeroed by the host)
     const int lane = tid & 63;
     const int wv = uni(tid >> 6);
     const int mask = cap - 1;
@@ -934,6 +973,18 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
     __syncthreads();
     int i = row_lo + 1;
     int stopped = 0, exit_j = 0;
+    // walls: this thread's alignment (threads beyond the unit's alignments have none), its runs [ws0, ws1) and the cursor
+    int ws0[kWallPerThread], ws1[kWallPerThread], wcur[kWallPerThread], wjb[kWallPerThread];
+    if (WALLS) {
+        if (wa1 - wa0 > kWallPerThread * kYdThreads) overflow = 4;   // (more earlier alignments in a unit than this mode covers)
+#pragma unroll
+        for (int m = 0; m < kWallPerThread; m++) {
+            ws0[m] = ws1[m] = wcur[m] = 0; wjb[m] = -1;
+            const int a = wa0 + tid + m * kYdThreads;
+            if (!overflow && a < wa1) { const int2 al = walns[a]; ws0[m] = al.x; ws1[m] = al.y; wcur[m] = dir > 0 ? ws0[m] : ws1[m] - 1; }
+        }
+        if (!GLOBAL) for (int j = tid; j < 2048; j += kYdThreads) sh->wflag[j] = 0;
+    }
     for (; i <= nb && !overflow; i++) {
         if (PROF) pt = clock64();
         const int rho = i - row_lo;
@@ -971,6 +1022,29 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
             __syncthreads();
         }
         if (lane == (rho & 63)) { const unsigned long long ro = blk_off + blk_used; rb_lo = (unsigned)ro; rb_hi = (unsigned)(ro >> 32); rb_ly = (unsigned)LY; }
+        int n_blk_row = 0;
+        if (WALLS) {
+            if (tid == 0) sh->n_blocked = 0;
+            __syncthreads();                                             // (also: the flags of the previous row are cleared by now)
+            const int qrow = (int)(dir > 0 ? q0 + i - 1 : q0 - i);
+#pragma unroll
+            for (int m = 0; m < kWallPerThread; m++) {
+                wjb[m] = -1;
+                if (ws1[m] <= ws0[m]) continue;
+                bool hit;
+                int c = wcur[m];
+                if (dir > 0) { while (c < ws1[m] && wsegs[c].q0 + wsegs[c].len <= qrow) c++; hit = c < ws1[m] && wsegs[c].q0 <= qrow; }
+                else { while (c >= ws0[m] && wsegs[c].q0 > qrow) c--; hit = c >= ws0[m] && qrow < wsegs[c].q0 + wsegs[c].len; }
+                wcur[m] = c;
+                if (hit) {
+                    const int tcol = wsegs[c].t0 + (qrow - wsegs[c].q0);
+                    const int jb = (int)(dir > 0 ? tcol - t0 + 1 : t0 - tcol);
+                    if (jb >= max(LY, 1) && jb <= reach) { wjb[m] = jb; wflag[jb & mask] = 1; atomicAdd(&sh->n_blocked, 1); }
+                }
+            }
+            __syncthreads();
+            n_blk_row = uni(sh->n_blocked);
+        }
         MB_TICK(0);
         int carry_x = kNeg2, carry_m = best, carry_iv = kNeg, carry_cp = kNeg;   // pass-level carries (wave-uniform)
         int row_best = best, first_alive = -1, last_alive = -1, nrow = 0;
@@ -988,15 +1062,34 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
             cpl = (j - 1 >= LY && j - 1 < RY) ? cpl : kNeg;
             if (base != LY && tid == 0) cpl = carry_cp;                   // column base-1 was overwritten by the previous pass
             const unsigned at = (j <= na && j >= 1) ? t : 4u;
-            const int diag = cpl + lut_score(lut, at);
+            // walls: is this column blocked in this row; how many blocked columns of the pass lie left of it, in the whole pass, and
+            // left of the column before this one (every wave reads the flags of all four waves' columns)
+            bool wblocked = false;
+            int wbefore = 0;
+            if (WALLS && n_blk_row) {
+                unsigned long long fb[kYdWaves];
+#pragma unroll
+                for (int v = 0; v < kYdWaves; v++) fb[v] = __ballot(wflag[(base + 64 * v + lane) & mask] != 0);
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int v = 0; v < kYdWaves; v++) {
+                    const int c = (int)__popcll(fb[v]);
+                    if (v < wv) wbefore += c;
+                    if (v == wv) { wbefore += (int)__popcll(fb[v] & below); wblocked = (fb[v] >> lane) & 1ull; }
+                }
+            }
+            const int diag = wblocked ? kNeg : cpl + lut_score(lut, at);
             const int de = dp - E, dn = cp - OE;
-            const int Dv = max(de, dn);
+            const int Dv = wblocked ? kNeg : max(de, dn);
             const int dext = de >= dn ? 4 : 0;
             const int M = max(diag, Dv);
             const int rel = tidE + uni((base - LY) * E);
-            const int PX = dpp_scan_max(M + rel);
+            const bool wrow = WALLS && n_blk_row;                         // (uniform) a row with dead cells: the chain runs on (cuts, value) keys
+            const unsigned long long PX64 = wrow ? dpp_scan_max64(wall_key(wbefore + (wblocked ? 1 : 0), M + rel)) : 0ull;
+            const int PX = wrow ? 0 : dpp_scan_max(M + rel);
             const int PM = dpp_scan_max(j <= na ? M : kNeg);
             sh->scan[tid] = make_int2(PX, PM);
+            if (wrow) sh->scanx[tid] = PX64;
             MB_TICK(1);
             __syncthreads();                                            // ---- B1
             MB_TICK(2);
@@ -1007,16 +1100,30 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
             const int cm = max(max(carry_m, wv > 0 ? t0s.y : kNeg2), max(wv > 1 ? t1s.y : kNeg2, wv > 2 ? t2s.y : kNeg2));
             const int allm = max(max(carry_m, t0s.y), max(max(t1s.y, t2s.y), t3s.y));
             const int allx = max(max(carry_x, t0s.x), max(max(t1s.x, t2s.x), t3s.x));
-            const int ivl0 = wv == 0 ? carry_iv : max(cxm1, x62) - O - (rel - tidE + (64 * wv - 1) * E);
+            int ivl0 = wv == 0 ? carry_iv : max(cxm1, x62) - O - (rel - tidE + (64 * wv - 1) * E);
             const int pex = max(dpp_shr1(PX, kNeg2), cx);
-            const int Iv = pex - O - rel;
+            int Iv = pex - O - rel;
+            unsigned long long allx64 = 0;
+            if (wrow) {
+                // the same combination on the keys: totals of the waves before this one, the carry of the passes before (no cut yet)
+                const unsigned long long k0 = sh->scanx[63], k1 = sh->scanx[127], k2 = sh->scanx[191], k3 = sh->scanx[255];
+                const unsigned long long kc = wall_key(0, carry_x);
+                auto mx = [](unsigned long long a, unsigned long long b) { return a > b ? a : b; };
+                const unsigned long long cx64 = mx(mx(kc, wv > 0 ? k0 : 0ull), mx(wv > 1 ? k1 : 0ull, wv > 2 ? k2 : 0ull));
+                const unsigned long long cxm64 = mx(kc, mx(wv > 1 ? k0 : 0ull, wv > 2 ? k1 : 0ull));
+                const unsigned long long k62 = sh->scanx[(64 * wv + 254) & 255];
+                allx64 = mx(mx(kc, k0), mx(mx(k1, k2), k3));
+                const unsigned long long pex64 = mx(dpp_shr1_64(PX64, 0ull), cx64);
+                Iv = wblocked ? kNeg : wall_val(pex64) - O - rel;            // (the winning keys carry exactly this lane's count of cuts)
+                if (wv > 0) ivl0 = wall_val(mx(cxm64, k62)) - O - (rel - tidE + (64 * wv - 1) * E);
+            }
             const int ivl = dpp_shr1(Iv, ivl0);
             const int iext = (Iv == ivl - E) ? 8 : 0;
             const int gmax = max(Dv, Iv);
             const int Cv = max(diag, gmax);
             const int src = diag >= gmax ? 0 : (Dv >= Iv ? 1 : 2);       // tie preference diag > D > I
             const int best_at = max(PM, cm);                             // running best, row-major, incl. this cell
-            const bool alive = (j <= na) & (Cv >= best_at - Y);
+            const bool alive = (j <= na) & (Cv >= best_at - Y) & !wblocked;
             const unsigned long long am = __ballot(alive);
             const unsigned long long bm = __ballot(((j >= RY) & !alive) | (j > na));
             const unsigned long long wm = __ballot((j <= na) & (Cv == allm));
@@ -1053,8 +1160,12 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
                 if (!(tid & 1) && tid < nvalid) arena[blk_off + blk_used + (unsigned)((nrow + tid) >> 1)] = (uint8_t)(code | (next << 4));
             }
             nrow += nvalid;
-            if (!done) { carry_x = uni(allx); carry_m = uni(allm); carry_iv = uni(sh->iv_last); carry_cp = uni(sh->cp_last); }
+            if (!done) { carry_x = wrow ? uni(wall_val(allx64)) : uni(allx); carry_m = uni(allm); carry_iv = uni(sh->iv_last); carry_cp = uni(sh->cp_last); }
             MB_TICK(5);
+        }
+        if (WALLS && n_blk_row) {
+#pragma unroll
+            for (int m = 0; m < kWallPerThread; m++) if (wjb[m] >= 0) wflag[wjb[m] & mask] = 0;      // (the next row's barrier orders this before its flags)
         }
         blk_used += (unsigned)(nrow + 1) >> 1;
         cells += nrow;
@@ -1095,12 +1206,14 @@ __device__ __forceinline__ void ydrop_body(const DpProb &pr, DpOut *out, const g
     }
 }
 
-template <bool GLOBAL_ROWS, bool PROF>
+template <bool GLOBAL_ROWS, bool PROF, bool WALLS>
 __global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
                                                       const PairPtrs *__restrict__ pairs, int O, int E, int Y, int32_t *grows,
                                                       uint8_t *__restrict__ arena, unsigned long long arena_bytes,
                                                       unsigned long long *__restrict__ arena_next, unsigned blk_bytes,
-                                                      unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps) {
+                                                      unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps,
+                                                      const WallSeg *__restrict__ wsegs, const int2 *__restrict__ walns, const int2 *__restrict__ wref,
+                                                      uint8_t *__restrict__ wflags) {
     int pi = blockIdx.x;
     if (pi >= n) return;
     DpProb pr = probs[pi];
@@ -1108,27 +1221,36 @@ __global__ __launch_bounds__(kYdThreads) void k_ydrop(const DpProb *__restrict__
     const gbytes tc = as_global(pp.tc);
     const gbytes qc = as_global(pr.strand ? pp.qr : pp.qf);
     __shared__ YdShared sh;
+    const int2 wr = WALLS ? wref[pi] : make_int2(0, 0);
     if (GLOBAL_ROWS) {
         int2 *CD = (int2 *)(grows + (size_t)pi * 2 * kGlobalRowCap);
-        ydrop_body<true, PROF>(pr, &outs[pi], tc, qc, O, E, Y, CD, nullptr, kGlobalRowCap, &sh, arena, arena_bytes, arena_next,
-                               blk_bytes, rowdir, snaps);
+        ydrop_body<true, PROF, WALLS>(pr, &outs[pi], tc, qc, O, E, Y, CD, nullptr, kGlobalRowCap, &sh, arena, arena_bytes, arena_next,
+                                      blk_bytes, rowdir, snaps, wsegs, walns, wr.x, wr.y, WALLS ? wflags + (size_t)pi * kGlobalRowCap : nullptr);
     } else {
         __shared__ int2 sCD[kLdsRowCap];
         __shared__ uint8_t sT[kLdsRowCap];
-        ydrop_body<false, PROF>(pr, &outs[pi], tc, qc, O, E, Y, sCD, sT, kLdsRowCap, &sh, arena, arena_bytes, arena_next,
-                                blk_bytes, rowdir, snaps);
+        ydrop_body<false, PROF, WALLS>(pr, &outs[pi], tc, qc, O, E, Y, sCD, sT, kLdsRowCap, &sh, arena, arena_bytes, arena_next,
+                                       blk_bytes, rowdir, snaps, wsegs, walns, wr.x, wr.y);
     }
 }
 
+// walls: the gap-free runs of the earlier alignments (wsegs), per alignment its runs [x, y) (walns), per problem the alignments
+// [x, y) of its unit (wref, indexed like probs), with the HBM ring n x kGlobalRowCap zeroed flag bytes (wflags); all nullptr without walls
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
                   int O, int E, int Y, int32_t *grows, uint8_t *arena, unsigned long long arena_bytes,
-                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s) {
+                  unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, hipStream_t s,
+                  const void *wsegs, const void *walns, const void *wref, uint8_t *wflags) {
     if (n <= 0) return;
     dim3 g((unsigned)n), b(kYdThreads);
     static const bool prof = getenv("MIBLAST_DP_PROFILE") != nullptr;
-    if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
-    else if (prof) hipLaunchKernelGGL((k_ydrop<false, true>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
-    else hipLaunchKernelGGL((k_ydrop<false, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    const WallSeg *ws = (const WallSeg *)wsegs; const int2 *wa = (const int2 *)walns, *wr = (const int2 *)wref;
+    if (wref) {
+        if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false, true>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, ws, wa, wr, wflags);
+        else hipLaunchKernelGGL((k_ydrop<false, false, true>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, ws, wa, wr, wflags);
+    }
+    else if (global_rows) hipLaunchKernelGGL((k_ydrop<true, false, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, ws, wa, wr, wflags);
+    else if (prof) hipLaunchKernelGGL((k_ydrop<false, true, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, ws, wa, wr, wflags);
+    else hipLaunchKernelGGL((k_ydrop<false, false, false>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, grows, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, ws, wa, wr, wflags);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -163,6 +163,7 @@ struct Anchor { int32_t t, q, score; };
 struct Cached {                // result of one anchor's two one-sided DPs
     bool accepted = false;
     bool traced = false;       // ops / dmin / dmax are valid (an accepted result is traced unless an earlier one of its unit covers it)
+    size_t epoch = 0;          // walls mode: alignments the unit had committed when the DPs ran (they were its walls)
     int32_t score = 0, t_lo = 0, t_hi = 0, q_lo = 0, q_hi = 0, dmin = 0, dmax = 0;
     int64_t cells = 0, rows = 0;
     std::vector<uint32_t> ops;           // merged run-length ops, forward order
@@ -576,6 +577,9 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<VerifyJob> vjobs;
     DevBuf<VerifyOut> vres;
     DevBuf<PairPtrs> pair_ptrs;
+    DevBuf<int32_t> wall_segs;                // walls mode: WallSeg runs (3 x int32), run ranges per alignment and alignment ranges per piece (int2 each)
+    DevBuf<int32_t> wall_alns, wall_ref;
+    DevBuf<uint8_t> wall_flags;               // ... and, for DPs on the HBM ring, one flag byte per ring column
     // batched calls: extra lanes (own stream, events and seed-stage buffers) so that the seed stages of several pairs are on
     // the device at the same time
     std::vector<Ctx *> lanes;
@@ -844,7 +848,8 @@ static void collect_dp_time(Ctx &ctx, miblast_stats &st) {             // after 
 }
 
 static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpProb *probs, DpOut *outs, int n,
-                            const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes, bool defer = false, const DpProb *host_probs = nullptr) {
+                            const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes, bool defer = false, const DpProb *host_probs = nullptr,
+                            const int32_t *wall_ref = nullptr) {
     Workspace &g = *ctx.ws;
     // A launch with more pieces than wave slots: the blocks take the pieces longest first (counting sort by the rows a piece will
     // run at most), so that the launch ends with short pieces instead of a long one started late.  Scheduling only.
@@ -865,13 +870,18 @@ static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpPro
         g.stage.h2d(g.dp_order.p, ord.data(), (size_t)n * sizeof(int), ctx.stream);
         order = g.dp_order.p;
     }
+    if (wall_ref && kernel == kDpHbm) {                                  // walls on the HBM ring: one zeroed flag byte per ring column and problem
+        g.wall_flags.ensure((size_t)n * (size_t)kGlobalRowCap);
+        MB_HIP(hipMemsetAsync(g.wall_flags.p, 0, (size_t)n * (size_t)kGlobalRowCap, ctx.stream));
+    }
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     if (kernel == kDpWave2x4 || kernel == kDpWave4 || kernel == kDpWave8)
         launch_ydrop1(kernel, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.arena.p, (unsigned long long)g.arena.n - 64, g.arena_next.p,
                       blk_bytes, g.rowdir.p, g.snaps.p, order, ctx.stream);
     else
         launch_ydrop(kernel == kDpHbm, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
-                     (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream);
+                     (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream,
+                     wall_ref ? g.wall_segs.p : nullptr, wall_ref ? g.wall_alns.p : nullptr, wall_ref, wall_ref && kernel == kDpHbm ? g.wall_flags.p : nullptr);
     MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     if (defer) return;                                                  // the caller synchronises once for several things
     MB_HIP(hipEventSynchronize(ctx.ev1));
@@ -1669,6 +1679,12 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long win_typ = (p.ydrop > p.gap_open ? (p.ydrop - p.gap_open) / std::max(1, p.gap_extend) : 0) * 5 / 4 + 32;
     const long dp_kernel_env = env_long("MIBLAST_DP_KERNEL", 0);         // 4 / 8: columns per lane of the one-wave kernel, 100: 4-wave LDS kernel
     const bool debug = env_long("MIBLAST_DEBUG", 0) != 0;
+    // walls (miblast_params.walls): base pairs on the path of an earlier alignment of the unit are dead cells of
+    // later DPs.  The DPs of a round run against the alignments their unit has COMMITTED by then (the 4-wave kernel's WALLS variant);
+    // a cached result is only good while its unit commits nothing new -- the commit loop drops what went stale and the anchors are
+    // evaluated again, against the new walls.  Relays, continuations and the traceback work as they are: every piece of a round sees
+    // the same walls, so equal states still evolve identically.
+    const bool walls = p.walls != 0;
     Workspace &g = *ctx.ws;
     hipStream_t s = ctx.stream;
     miblast_stats st;                        // launch-level counters shared by all pairs of the batch
@@ -1695,6 +1711,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 auto it = u.cache.find(u.next);
                 if (it == u.cache.end()) break;
                 Cached &c = it->second;
+                if (walls && c.epoch != u.kept.size()) { u.cache.erase(it); break; }     // ran against fewer walls than the unit has now: evaluate it again
                 if (c.accepted && !c.traced) { u.cache.erase(it); break; }    // predicted covered, but is not: evaluate it again
                 PS(u).dp_sides += 2; PS(u).dp_cells += c.cells; PS(u).dp_rows += c.rows;
                 if (c.accepted) {
@@ -1712,6 +1729,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 u.cache.erase(it);
                 u.next++;
             }
+            if (walls)                                                       // what ran against fewer walls is stale: drop it now, so that it is nominated again
+                for (auto it = u.cache.begin(); it != u.cache.end();) it = it->second.epoch != u.kept.size() ? u.cache.erase(it) : std::next(it);
         }
         // Nomination of the next speculative batch is a pure scheduling heuristic: results never depend on it because
         // anchors are committed strictly in order above.  The first unresolved anchor of every unit is always nominated
@@ -1856,9 +1875,47 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         const bool plant_at_once = plant_env == 2 || (!crowd && plant_env != 0);
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
-        const int dp_kernel = dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : win_typ <= 224 ? kDpWave2x4 : kDpWave8;
+        const int dp_kernel = walls ? kDpLds : dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : win_typ <= 224 ? kDpWave2x4 : kDpWave8;
+        // walls of the round: the gap-free runs of every unit's committed alignments, in the strand's coordinates
+        std::vector<int32_t> wall_segs, wall_alns;                          // WallSeg = 3 x int32; run range per alignment = 2 x int32
+        std::vector<std::pair<int32_t, int32_t>> unit_walls(units.size(), {0, 0});      // alignments [first, last) of a unit
+        if (walls) {
+            for (size_t ui = 0; ui < units.size(); ui++) {
+                const Unit &u = units[ui];
+                unit_walls[ui].first = (int32_t)(wall_alns.size() / 2);
+                for (const miblast_aln &A : u.kept) {
+                    const int32_t s0 = (int32_t)(wall_segs.size() / 3);
+                    int32_t tt = A.t_lo, qq = A.q_lo;
+                    for (int64_t k = 0; k < A.n_ops; k++) {
+                        const uint32_t e = u.unit_ops[(size_t)(A.ops_off + k)], o = e & 3u, len = e >> 2;
+                        if (o <= 1u) {                                       // '=' or 'X': aligned pairs
+                            const size_t nseg = wall_segs.size() / 3;
+                            if ((int32_t)nseg > s0 && wall_segs[3 * (nseg - 1)] + wall_segs[3 * (nseg - 1) + 2] == qq && wall_segs[3 * (nseg - 1) + 1] + wall_segs[3 * (nseg - 1) + 2] == tt)
+                                wall_segs[3 * (nseg - 1) + 2] += (int32_t)len;             // '=' and 'X' runs of one gap-free stretch
+                            else { wall_segs.push_back(qq); wall_segs.push_back(tt); wall_segs.push_back((int32_t)len); }
+                            tt += (int32_t)len; qq += (int32_t)len;
+                        } else if (o == 2u) qq += (int32_t)len;
+                        else tt += (int32_t)len;
+                    }
+                    wall_alns.push_back(s0); wall_alns.push_back((int32_t)(wall_segs.size() / 3));
+                }
+                unit_walls[ui].second = (int32_t)(wall_alns.size() / 2);
+            }
+            g.wall_segs.ensure(wall_segs.size() + 3); g.wall_alns.ensure(wall_alns.size() + 2);
+            g.stage.h2d(g.wall_segs.p, wall_segs.data(), wall_segs.size() * 4, s);
+            g.stage.h2d(g.wall_alns.p, wall_alns.data(), wall_alns.size() * 4, s);
+        }
         std::vector<SideRun> sides;
         std::vector<Piece> pieces;
+        // per piece the alignments of its unit (uploaded with the pieces of a launch)
+        auto upload_wall_refs = [&](size_t first, size_t last) -> const int32_t * {
+            if (!walls) return nullptr;
+            std::vector<int32_t> ref(2 * (last - first));
+            for (size_t x = first; x < last; x++) { ref[2 * (x - first)] = unit_walls[(size_t)pieces[x].unit].first; ref[2 * (x - first) + 1] = unit_walls[(size_t)pieces[x].unit].second; }
+            g.wall_ref.ensure_keep(2 * last + 2);
+            g.stage.h2d(g.wall_ref.p + 2 * first, ref.data(), ref.size() * 4, s);
+            return g.wall_ref.p + 2 * first;
+        };
         std::vector<DpProb> probs;
         std::vector<DpOut> outs;
         std::vector<VerifyJob> vjobs;
@@ -2194,7 +2251,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 MB_HIP(hipMemset2DAsync(g.snaps.p + launched * kSnapSlots * kSnapBytes, kSnapBytes, 0, sizeof(SnapHdr), n_new * kSnapSlots, s));
                 // DP launch, hand-over checks and the copies of both results: one synchronisation.  (Checks made on pieces that
                 // turn out to need a rerun are simply made again.)
-                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true, probs.data() + launched);
+                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true, probs.data() + launched,
+                                upload_wall_refs(launched, pieces.size()));
                 launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
                 g.stage.d2h(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), s);
                 g.stage.d2h(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), s);
@@ -2227,6 +2285,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     }
                 }
                 for (size_t x = launched; x < pieces.size(); x++) arena_full |= outs[x].overflow == 3;
+                for (size_t x = launched; x < pieces.size(); x++)
+                    if (outs[x].overflow == 4) {
+                        set_error("walls: a unit holds more than 1024 earlier alignments: beyond what the walls mode of the MI355X path covers");
+                        return MIBLAST_ELIMIT;
+                    }
                 if (arena_full) break;
                 for (size_t x = launched; x < pieces.size(); x++) {
                     st.dp_sides_run++;
@@ -2356,13 +2419,14 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     outs.resize(pieces.size());
                     g.grows.ensure(n_new * 2 * (size_t)kGlobalRowCap);
                     g.stage.h2d(g.probs.p + first, probs.data() + first, n_new * sizeof(DpProb), s);
-                    run_ydrop_timed(ctx, st, kDpHbm, g.probs.p + first, g.outs.p + first, (int)n_new, g.pair_ptrs.p, p, kBlkWide);
+                    run_ydrop_timed(ctx, st, kDpHbm, g.probs.p + first, g.outs.p + first, (int)n_new, g.pair_ptrs.p, p, kBlkWide, false, nullptr, upload_wall_refs(first, pieces.size()));
                     g.stage.d2h(outs.data() + first, g.outs.p + first, n_new * sizeof(DpOut), s);
                     MB_HIP(hipStreamSynchronize(s));
                     g.stage.done();
                     for (size_t x = first; x < pieces.size(); x++) {
                         const DpOut &o = outs[x];
                         if (o.overflow == 1) { set_error("DP row wider than 2^20 columns"); return MIBLAST_ELIMIT; }
+                        if (o.overflow == 4) { set_error("walls: a unit holds more than 1024 earlier alignments: beyond what the walls mode of the MI355X path covers"); return MIBLAST_ELIMIT; }
                         if (o.overflow == 3) { arena_full = true; continue; }
                         SideRun &sd = sides[(size_t)owner[x - first]];
                         sd.gbest = o.best; sd.gbi = o.bi; sd.gbj = o.bj; sd.best_piece = (int)x;
@@ -2401,6 +2465,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             c.t_lo = a.t - L.gbj; c.t_hi = a.t + R.gbj; c.q_lo = a.q - L.gbi; c.q_hi = a.q + R.gbi;
             c.accepted = c.score >= p.gappedthresh;
             c.traced = false;
+            c.epoch = u.kept.size();
             c.dmin = 0x7fffffff; c.dmax = -0x7fffffff - 1;          // set by the merge; until then covers nothing
             cres[k] = &u.cache.emplace(pend[k].anchor, std::move(c)).first->second;      // (references into an unordered_map stay valid)
         }
@@ -2775,10 +2840,6 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     ctx.ws->stage.abort();
     for (Ctx *lane : ctx.ws->lanes) lane->ws->stage.abort();
     miblast_params p = pin;
-    if (p.walls) {
-        set_error("walls (SURVEY A.9 #8) is a comparison mode of the CPU oracle only: the MI355X path implements the covered-anchor rule without walls");
-        return MIBLAST_EINVAL;
-    }
     if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
     if (p.step < 1) p.step = 1;
     std::vector<std::unique_ptr<PairJob>> store;
@@ -2888,7 +2949,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     size_t total_anchors = 0;
     for (const Unit &u : units) total_anchors += u.anchors.size();
     int rc = MIBLAST_OK;
-    if (gapped_lanes > 1 && n >= 4 && total_anchors >= (size_t)env_long("MIBLAST_GAPPED_LANES_MIN_ANCHORS", 4096)) {
+    if (gapped_lanes > 1 && !p.walls && n >= 4 && total_anchors >= (size_t)env_long("MIBLAST_GAPPED_LANES_MIN_ANCHORS", 4096)) {
         // pairs dealt to the groups heaviest first (anchors as the weight)
         const size_t L = std::min(gapped_lanes, n / 2);
         std::vector<size_t> weight(n, 0), order(n);

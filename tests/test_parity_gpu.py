@@ -700,16 +700,61 @@ def test_the_16_bit_diagonal_hash_drops_hits_across_diagonals_like_the_oracle(gp
     assert differs != 0                                          # the collision really happens on these inputs: the modes extend different numbers of hits
 
 
-def test_walls_switch_is_refused_not_ignored(gpu_ctx):
-    """walls exists in the oracle for the day a lastz binary can be compared; the MI355X path implements the
-    covered-anchor rule without walls and must say so rather than silently compute something else."""
-    from cactus_amd import miblast
-    from cases import pair, KEG_DEFAULT
-    tf, qf = pair(5000, 3)
+@pytest.mark.parametrize("extra", [["--miblast-walls"], ["--miblast-walls", "--miblast-diag=hash16"]], ids=["walls", "walls+hash16"])
+@pytest.mark.parametrize("name,tf,qf,args", CASES, ids=CASE_IDS)
+def test_case_matches_oracle_with_walls(gpu_ctx, olz, name, tf, qf, args, extra):
+    """--miblast-walls (base pairs on the path of an earlier alignment of the unit are dead cells of later DPs),
+    alone and together with the 16-bit diagonal hash: the DPs of a round run against the alignments their unit has committed (the
+    WALLS variant of the 4-wave kernel: flagged ring columns, the horizontal-gap chain cut at every dead cell), results that ran
+    against fewer walls are evaluated again.  Bytes, records, ops and counters as the oracle's in the same mode -- including the two
+    low-complexity cases, where hundreds of earlier alignments cross a DP's rows and the mode changes the output."""
+    pm = _params(list(args) + extra)
+    assert pm.walls == 1
     T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
-    with pytest.raises(miblast.MiblastError, match="oracle only"):
-        gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + ["--miblast-walls"]))
-    assert gpu_ctx.align(T, Q, miblast.params_from_args(KEG_DEFAULT + ["--miblast-diag=exact"])).paf
+    got = gpu_ctx.align(T, Q, pm)
+    want = olz.align(tf, qf, _oracle_params(olz, pm))
+    assert got.paf == want["paf"]
+    assert got.hsps == want["hsps"] and got.alns == want["alns"] and got.ops == want["ops"]
+    for k in COUNTERS:
+        assert got.stats[k] == want["counters"][k], k
+
+
+@pytest.mark.parametrize("env", [{"MIBLAST_RELAY_S0": "0"}, {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "3"},
+                                 {"MIBLAST_GAPPED_BATCH_MAX": "1"}], ids=["no-relays", "short-relays-rejected", "one-anchor-per-round"])
+def test_walls_do_not_depend_on_relays_or_speculation(gpu_ctx, olz, monkeypatch, env):
+    """Walls with the relay hand-overs switched off, cut short with forced rejections, and with one anchor per round, on pairs whose
+    alignments run across each other (tandem copies), in a batched call: the oracle's bytes and counters every time."""
+    import numpy as np
+    from cactus_amd import gen
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    def tandem(seed, period, copies, div):
+        rng = np.random.default_rng(seed)
+        unit = gen.random_sequence(period, rng)
+
+        def rep(s2):
+            r = np.random.default_rng(s2)
+            return np.concatenate([gen.mutate(unit, r, div, 0.004) for _ in range(copies)])
+        t = np.concatenate([gen.random_sequence(2000, rng), rep(seed + 1), gen.random_sequence(2000, rng)])
+        q = np.concatenate([gen.random_sequence(1500, rng), rep(seed + 2), gen.random_sequence(1500, rng)])
+        return gen.fasta_bytes([("T|s%d" % seed, t)]), gen.fasta_bytes([("Q|s%d" % seed, q)])
+
+    # tandem copies with a period shorter than a DP window: later alignments run beside and across the paths of earlier ones
+    fastas = [tandem(21, 60, 40, 0.05), tandem(22, 97, 30, 0.04)]
+    pm = _params(["--step=1", "--hspthresh=2200", "--gappedthresh=2400", "--ydrop=4000", "--ambiguous=iupac,100,100", "--miblast-walls"])
+    sets = [(gpu_ctx.seqset_from_fasta_bytes(a), gpu_ctx.seqset_from_fasta_bytes(b)) for a, b in fastas]
+    got = gpu_ctx.align_pairs(sets, pm, details=True)
+    plain = _params(["--step=1", "--hspthresh=2200", "--gappedthresh=2400", "--ydrop=4000", "--ambiguous=iupac,100,100"])
+    changed = False
+    for (a, b), r in zip(fastas, got):
+        want = olz.align(a, b, _oracle_params(olz, pm))
+        assert r.paf == want["paf"] and r.alns == want["alns"] and r.ops == want["ops"]
+        for k in COUNTERS:
+            assert r.stats[k] == want["counters"][k], k
+        changed |= olz.align(a, b, _oracle_params(olz, plain), details=False)["counters"]["dp_cells"] != want["counters"]["dp_cells"]
+    assert changed                                               # the walls matter on these inputs: dead cells change what the DPs evaluate
+    for x, y in sets:
+        x.close(); y.close()
 
 
 def test_evolver_mammals_phase_at_full_size_equals_the_oracle_call_by_call(gpu_ctx, olz):
