@@ -332,8 +332,10 @@ def dp_roofline(tot, profile_name):
     launches = max(1.0, tot["dp_kernel_launches"])
     cells, rows = tot["dp_cells_run"] / launches, tot["dp_rows_run"] / launches
     dp_ms = tot["t_dp_kernel_ms"] / launches
-    algo = cells * TRACE_BYTES_PER_CELL + rows * 18.0
+    algo = cells * TRACE_BYTES_PER_CELL                        # SURVEY 8d, strictly: 0.5 B of trace per evaluated cell, nothing else
+    algo_rows = algo + rows * 18.0                             # ... + what the kernel also moves per row: the 16-byte row record and ~2 sequence bytes
     achieved = algo / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+    achieved_rows = algo_rows / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
     traffic, note = None, "no committed PMC summary for this workload"
     path = os.path.join(ROOT, "profiles", profile_name)
     if os.path.exists(path):
@@ -348,6 +350,8 @@ def dp_roofline(tot, profile_name):
     return {"bound": "hbm", "kernel": "k_ydrop2 (one-sided Y-drop DP, one wave per piece; k_ydrop1 / k_ydrop for wider windows)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "bytes_per_cell": TRACE_BYTES_PER_CELL, "bytes_per_cell_written": TRACE_BYTES_WRITTEN, "cells_per_launch": cells, "rows_per_launch": rows,
+            "with_row_records": {"achieved": achieved_rows, "frac": achieved_rows / HBM_PEAK_GBS, "bytes_per_launch": algo_rows,
+                                 "note": "the same plus 18 B per DP row (16-byte row record + sequence bytes); frac above is SURVEY 8d's 0.5 B per evaluated cell alone"},
             "launch_ms": dp_ms, "traffic_note": note,
             "note": "the DP is bound by instruction issue and latency per row, not by HBM (SURVEY 8d caveat): see roofline.valu for its meaningful ceiling"}
 
@@ -447,7 +451,10 @@ def run_rank(a):
             peak_ops = prop.multi_processor_count * 4 * 32 * clock_hz
             cells_per_s = tot["dp_cells_run"] / max(1e-12, tot["t_dp_kernel_ms"] * 1e-3 / world)
             out["roofline"]["valu"] = {"cells_evaluated_per_s_per_gpu": cells_per_s, "min_int_ops_per_cell": 10, "peak_lane_ops_per_s": peak_ops,
-                                       "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9}
+                                       "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9,
+                                       "peak_measured_lane_ops_per_s": peak_ops / 2, "frac_of_measured_peak": cells_per_s * 10 / (peak_ops / 2),
+                                       "peak_note": "peak = CUs x 4 SIMD-32 x 32 lanes x clock (one int32 VALU instruction per SIMD and 2 cycles); measured on this chip an int32 "
+                                                    "VALU instruction of a wave64 takes ~4 cycles (DESIGN.md section 5): half that peak, given as peak_measured"}
         except Exception as e:                               # noqa: BLE001  (never lose the line over a device-property quirk)
             out["roofline"]["valu"] = {"error": str(e)}
         if a.workload == "chr20":

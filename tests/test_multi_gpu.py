@@ -172,3 +172,36 @@ def test_blocked_equals_unblocked_at_chunk_scale(monkeypatch):
     assert blocked == whole
     for k in ("seed_hits", "hsps", "dp_cells", "alignments"):
         assert st0[k] == st1[k], k
+
+
+def test_blocked_path_at_megabase_blocks_equals_one_oracle_run(olz, monkeypatch):
+    """The blocked / multi-device path pinned to the ORACLE at a realistic block size (not only to the unblocked product): a
+    multi-contig pair of 3.2 Mb cut into blocks of at most 1 Mb, dealt to two logical devices, against ONE oracle run over the
+    whole files (seconds of CPU): bytes and counters."""
+    import numpy as np
+    from cactus_amd import gen, miblast
+    rng = np.random.default_rng(77)
+    trecs, qrecs = [], []
+    for k in range(5):
+        n = 400_000 + 90_000 * k
+        t = gen.random_sequence(n, rng)
+        q = gen.mutate(t, rng, 0.05, 0.004)
+        if k == 1:
+            q = gen.revcomp(q)
+        trecs.append(("id=T|chr%d" % k, gen.soft_mask(t, rng, 0.2)))
+        qrecs.append(("id=Q|chr%d" % k, gen.soft_mask(q, rng, 0.2)))
+    tf, qf = gen.fasta_bytes(trecs), gen.fasta_bytes([qrecs[i] for i in (3, 1, 4, 0, 2)])
+    args = "--step=2 --ambiguous=iupac,100,100 --ydrop=3500 --hspthresh=2800".split()
+    pm = miblast.params_from_args(args)
+    want = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}), details=False)
+    assert want["paf"].count(b"\n") >= 5
+    monkeypatch.setenv("MIBLAST_BLOCK_BASES", "1000000")
+    monkeypatch.setenv("MIBLAST_DEVICE_MAP", "0,0")
+    m = miblast.Multi(2)
+    try:
+        got, st = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert got == want["paf"]
+    for k in ("seed_hits", "hits_extended", "hsps", "dp_cells", "alignments"):
+        assert st[k] == want["counters"][k], k

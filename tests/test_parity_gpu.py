@@ -208,11 +208,11 @@ def test_relay_handover_matches_oracle(gpu_ctx, olz, monkeypatch, env):
                 assert got.stats["relay_rejected"] > 0
 
 
-def test_full_size_properties_1mb(gpu_ctx, monkeypatch):
-    """BASELINE config 2 at full size (1 Mb x 1 Mb): too slow to diff against the oracle in a unit test, so
-    check size-independent properties: every record passes the caf walk (pinchIterator.c:59-121) and its AS
-    score re-derives from the sequences; the run is reproducible; aligning the reverse-complemented query
-    yields the same alignments with the strand flipped."""
+def test_full_size_properties_1mb(gpu_ctx, olz, monkeypatch):
+    """BASELINE config 2 at full size (1 Mb x 1 Mb): the oracle's bytes and counters (1.6 s of CPU), and size-independent
+    properties: every record passes the caf walk (pinchIterator.c:59-121) and its AS score re-derives from the
+    sequences; the run is reproducible; aligning the reverse-complemented query yields the same alignments with the
+    strand flipped."""
     from cactus_amd import gen, pafcheck
     from cases import DEFAULT
     t, q = gen.make_pair(1_000_000, 42)
@@ -224,6 +224,10 @@ def test_full_size_properties_1mb(gpu_ctx, monkeypatch):
     r1 = gpu_ctx.align(T, Q, pm, details=False)
     r2 = gpu_ctx.align(T, Q, pm, details=False)
     assert r1.paf == r2.paf
+    want = olz.align(tf, qf, _oracle_params(olz, pm), details=False)
+    assert r1.paf == want["paf"]
+    for k in COUNTERS:
+        assert r1.stats[k] == want["counters"][k], k
     n = pafcheck.check_paf(r1.paf.decode(), pafcheck.read_fasta(tf), pafcheck.read_fasta(qf))
     assert n == r1.stats["alignments"] and n > 5
     rr = gpu_ctx.align(T, QR, pm, details=False)
