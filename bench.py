@@ -41,7 +41,7 @@ TIMELINE = bool(os.environ.get("MIBLAST_BENCH_TIMELINE"))       # per-call wall 
 TRACE_BYTES_WRITTEN = 0.5      # what the DP kernels store per evaluated cell: 4-bit trace codes, two columns per byte
 PER_PAIR = ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_sides", "dp_cells", "dp_rows", "alignments",
             "t_index", "t_seed", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms")
-PER_BATCH = ("t_gapped", "gapped_rounds", "dp_sides_run", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms", "dp_kernel_launches",
+PER_BATCH = ("t_gapped", "gapped_rounds", "dp_sides_run", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms", "t_dp_busy_ms", "dp_kernel_launches",
              "relay_accepted", "relay_rejected", "t_traceback_ms", "t_merge_ms", "dp_reruns")
 
 
@@ -347,7 +347,13 @@ def dp_roofline(tot, profile_name):
             traffic = pmc / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None
             note = ("PMC bytes per DP launch (corrected FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/%s: %.1f MB averaged over the %d "
                     "launches profiled) / this run's average launch duration" % (profile_name, pmc / 1e6, calls))
-    return {"bound": "hbm", "kernel": "k_ydrop2 (one-sided Y-drop DP, one wave per piece; k_ydrop1 / k_ydrop for wider windows)",
+    busy_ms = tot.get("t_dp_busy_ms", 0.0)
+    busy = {"achieved": tot["dp_cells_run"] * TRACE_BYTES_PER_CELL / (busy_ms * 1e-3) / 1e9, "busy_ms": busy_ms,
+            "note": "all launches' algorithmic bytes / the time at least one DP launch was running (union of the HIP-event intervals): what the kernel "
+                    "moves per second of its own time when launches of two streams overlap"} if busy_ms > 0 else None
+    if busy:
+        busy["frac"] = busy["achieved"] / HBM_PEAK_GBS
+    return {"bound": "hbm", "kernel": "k_ydrop2 (one-sided Y-drop DP, one wave per piece; k_ydrop1 / k_ydrop for wider windows)", "over_busy_time": busy,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "bytes_per_cell": TRACE_BYTES_PER_CELL, "bytes_per_cell_written": TRACE_BYTES_WRITTEN, "cells_per_launch": cells, "rows_per_launch": rows,
             "with_row_records": {"achieved": achieved_rows, "frac": achieved_rows / HBM_PEAK_GBS, "bytes_per_launch": algo_rows,
@@ -430,13 +436,16 @@ def run_rank(a):
             "stage_seconds_per_step": {k: tot[k] / per for k in ("t_index", "t_seed", "t_gapped")},
             "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / per, "ungapped": tot["t_ungapped_kernel_ms"] / per,
                                          "sort": tot["t_sort_ms"] / per, "seed_fill": tot["t_seedfill_ms"] / per},
-            "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3 / world) / 1e9,
+            # evaluated cells (speculative ones included) per second of DP kernel time: over the time at least one DP launch was running
+            # (union of the launches' HIP-event intervals), and over the sum of the launch durations (launches of two streams overlap)
+            "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3 / world) / 1e9,
+            "gapped_gcells_per_s_sum_of_launches": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3 / world) / 1e9,
             "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
             "relay": {"pieces_per_step": tot["dp_sides_run"] / per, "dp_launches_per_step": tot["dp_kernel_launches"] / per,
                       "handovers_accepted_per_step": tot["relay_accepted"] / per, "handovers_rejected_per_step": tot["relay_rejected"] / per,
                       "reruns_per_step": tot["dp_reruns"] / per,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / per, "merge_ms_per_step": tot["t_merge_ms"] / per},
-            "roofline": dp_roofline(tot, "r02_hbm_traffic_pmc.json" if a.workload == "evolver" else "r02_pair_hbm_traffic_pmc.json"),
+            "roofline": dp_roofline(tot, "r03_hbm_traffic_pmc.json" if a.workload == "evolver" else "r03_pair_hbm_traffic_pmc.json"),
             "host": {"cpu_seconds_per_step": tot["host_cpu_seconds"] / per, "busy_threads_avg": tot["host_cpu_seconds"] / world / max(1e-9, elapsed),
                      "cgroup_throttled_periods": tot["host_throttled_periods"], "cgroup_throttled_ms": tot["host_throttled_ms"],
                      "note": "all ranks; a CPU-quota container freezes the process when its threads exceed the quota (outlier steps)"},
@@ -449,7 +458,7 @@ def run_rank(a):
             prop = torch.cuda.get_device_properties(local_rank)
             clock_hz = float(getattr(prop, "clock_rate", 2_400_000)) * 1e3
             peak_ops = prop.multi_processor_count * 4 * 32 * clock_hz
-            cells_per_s = tot["dp_cells_run"] / max(1e-12, tot["t_dp_kernel_ms"] * 1e-3 / world)
+            cells_per_s = tot["dp_cells_run"] / max(1e-12, tot["t_dp_busy_ms"] * 1e-3 / world)
             out["roofline"]["valu"] = {"cells_evaluated_per_s_per_gpu": cells_per_s, "min_int_ops_per_cell": 10, "peak_lane_ops_per_s": peak_ops,
                                        "frac": cells_per_s * 10 / peak_ops, "cus": prop.multi_processor_count, "clock_ghz": clock_hz / 1e9,
                                        "peak_measured_lane_ops_per_s": peak_ops / 2, "frac_of_measured_peak": cells_per_s * 10 / (peak_ops / 2),
@@ -496,10 +505,10 @@ def pair_leg(a, ctx):
     b = types.SimpleNamespace(size=a.size, seed=a.seed, random_pair=False, lastz_args=DEFAULT_ARGS, pairs_per_gpu=1)
     w = PairWorkload(b, ctx, 0)
     elapsed, tot, keep = timed_steps(w, a.steps, a.warmup, lambda: None, lambda paf: None)
-    r = dp_roofline(tot, "r02_pair_hbm_traffic_pmc.json")
+    r = dp_roofline(tot, "r03_pair_hbm_traffic_pmc.json")
     out = {"workload": w.describe, "ms_per_step": 1e3 * elapsed / a.steps, "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
            "seeds_per_s": tot["seed_hits"] / elapsed, "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
-           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3) / 1e9,
+           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3) / 1e9,
            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / a.steps, "ungapped": tot["t_ungapped_kernel_ms"] / a.steps,
                                         "sort": tot["t_sort_ms"] / a.steps, "seed_fill": tot["t_seedfill_ms"] / a.steps},
            "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "launch_ms", "cells_per_launch")}}
@@ -539,7 +548,7 @@ def batch_leg(a, ctx):
     r = dp_roofline(tot, "none")
     out = {"workload": w.describe, "ms_per_call": 1e3 * elapsed / 3, "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
            "seeds_per_s": tot["seed_hits"] / elapsed, "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
-           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3) / 1e9,
+           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3) / 1e9,
            "dp_launches_per_call": tot["dp_kernel_launches"] / 3, "pieces_per_call": tot["dp_sides_run"] / 3,
            "roofline": {k: r[k] for k in ("achieved", "frac", "launch_ms", "cells_per_launch")}}
     for t, q in w.sets:

@@ -853,7 +853,7 @@ struct YdShared {                            // LDS of one DP problem (LDS-ring 
 //       all waves reduce the four records identically, so no third barrier is needed.
 // C/D of the previous row live in an LDS ring of int2 indexed by column, overwritten in place.
 // WALLS (miblast_params.walls): a cell that pairs a target base with a query base lying on the path of an
-// earlier alignment of the unit is dead, and neither gap state survives it (oracle/lastz_oracle.c one_sided(): Cv = Dv = Iv = NEG).
+// earlier alignment of the unit is dead, and neither gap state survives it (SURVEY A.10 ONE_SIDED with the walls switch: C = D = I = -inf).
 // The earlier alignments come as their gap-free runs (WallSeg, sorted by q inside an alignment); a thread follows up to kWallPerThread
 // alignments with a cursor each while the rows advance and flags the column a path crosses the row in (at most one per alignment).
 // A dead cell cuts the horizontal-gap chain of the row.  The max-plus scan therefore runs on 64-bit keys (blocked columns up to and

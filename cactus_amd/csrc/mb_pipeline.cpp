@@ -538,6 +538,7 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<unsigned> ux_cnt;                  // their counter,
     DevBuf<uint32_t> ux_bits;                 // two bit planes, one bit per diagonal each (runs of k_ungapped_long; runs that need the sequential rule)
     // both strands of a pair in one go (seed_phase, fused path): events per strand, pinned read-back areas
+    hipEvent_t ev_base = nullptr;             // start of the current call (DpSpans::base)
     hipEvent_t sev[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
     unsigned long long last_strand_hits = 0;  // hits of the larger strand of the last pair seeded with this workspace
     PinBuf<unsigned long long> pin_u64;
@@ -600,6 +601,7 @@ static Ctx *lane_create(int device) {
 void workspace_destroy(Workspace *w) {
     if (!w) return;
     for (auto &row : w->sev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+    if (w->ev_base) (void)hipEventDestroy(w->ev_base);
     for (Ctx *c : w->lanes) {
         for (hipEvent_t e : {c->ev0, c->ev1, c->ev2, c->ev3, c->ev4}) if (e) (void)hipEventDestroy(e);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -840,11 +842,33 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
 // LDS ring (windows up to ~1400 columns), or the 4-wave kernel with the ring in HBM (any width)
 enum DpKernel { kDpWave2x4 = 2, kDpWave4 = 4, kDpWave8 = 8, kDpLds = 100, kDpHbm = 101 };
 
+struct DpSpans {
+    std::mutex m;
+    hipEvent_t base = nullptr;
+    std::vector<std::pair<float, float>> v;
+    double busy_ms() {                                                 // length of the union of the intervals
+        std::sort(v.begin(), v.end());
+        double busy = 0, end = -1e30;
+        for (const auto &iv : v) {
+            if (iv.first > end) { busy += iv.second - iv.first; end = iv.second; }
+            else if (iv.second > end) { busy += iv.second - end; end = iv.second; }
+        }
+        return busy;
+    }
+};
+
 static void collect_dp_time(Ctx &ctx, miblast_stats &st) {             // after the stream has been synchronised
     float ms = 0;
     MB_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
     st.t_dp_kernel_ms += ms;
     st.dp_kernel_launches++;
+    if (ctx.spans && ctx.spans->base) {
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, ctx.spans->base, ctx.ev0) == hipSuccess && hipEventElapsedTime(&b, ctx.spans->base, ctx.ev1) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(ctx.spans->m);
+            ctx.spans->v.emplace_back(a, b);
+        } else (void)hipGetLastError();
+    }
 }
 
 static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpProb *probs, DpOut *outs, int n,
@@ -2839,6 +2863,15 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     Pool::Hot keep_workers_awake;
     ctx.ws->stage.abort();
     for (Ctx *lane : ctx.ws->lanes) lane->ws->stage.abort();
+    DpSpans spans;
+    if (!ctx.ws->ev_base) MB_HIP(hipEventCreate(&ctx.ws->ev_base));
+    spans.base = ctx.ws->ev_base;
+    MB_HIP(hipEventRecord(spans.base, ctx.stream));
+    struct SpanScope {                                                  // the contexts of the call report to `spans` while it lives
+        Ctx &c;
+        SpanScope(Ctx &cx, DpSpans *sp) : c(cx) { c.spans = sp; for (Ctx *l : c.ws->lanes) l->spans = sp; }
+        ~SpanScope() { c.spans = nullptr; for (Ctx *l : c.ws->lanes) l->spans = nullptr; }
+    } span_scope(ctx, &spans);
     miblast_params p = pin;
     if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
     if (p.step < 1) p.step = 1;
@@ -2878,6 +2911,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         // while the other lanes keep the device busy.  A pair's result does not depend on its lane.
         Workspace &w = *ctx.ws;
         while (w.lanes.size() < n_lanes) w.lanes.push_back(lane_create(ctx.device));
+        for (Ctx *l : w.lanes) l->spans = ctx.spans;
         std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
         std::vector<std::string> lane_err(n_lanes);
         std::vector<std::future<void>> lane_threads;
@@ -2970,6 +3004,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         units.clear();
         Workspace &w0 = *ctx.ws;
         while (w0.lanes.size() + 1 < L) w0.lanes.push_back(lane_create(ctx.device));
+        for (Ctx *l : w0.lanes) l->spans = ctx.spans;
         std::vector<PairPtrs> pp(n);
         for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }
         std::vector<int> lane_rc(L, MIBLAST_OK);
@@ -3027,6 +3062,11 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         rc = gapped_phase(ctx, p, jobs, units);
     }
     if (rc != MIBLAST_OK) return rc;
+    {
+        for (Ctx *l : ctx.ws->lanes) l->spans = &spans;                  // (lanes created during the call)
+        const double busy = spans.busy_ms();
+        for (PairJob *j : jobs) j->res->stats.t_dp_busy_ms = busy;
+    }
     const double t_o = now_s();
     parallel_for(n, [&](size_t k) { output_phase(p, *jobs[k], (int)k, units); });
     if (env_long("MIBLAST_DEBUG", 0))

@@ -11,12 +11,17 @@ struct Workspace;
 Workspace *workspace_create();
 void workspace_destroy(Workspace *w);
 
+// HIP-event intervals of the DP launches of one align_pairs call (the groups of its pairs launch on streams of their own): start and
+// end of every launch in ms after `base`, collected from all streams; their union is miblast_stats.t_dp_busy_ms
+struct DpSpans;
+
 struct Ctx {
     int device = 0;
     Workspace *ws = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
     void *chain_cache = nullptr;        // device buffers the chaining stage keeps between calls (mp_chain.cpp)
+    DpSpans *spans = nullptr;           // where this context's DP launches report their intervals during a call (mb_pipeline.cpp)
 };
 void chain_cache_destroy(void *cache);  // mp_chain.cpp
 

@@ -146,6 +146,9 @@ typedef struct miblast_stats {          /* counters defined by SURVEY.md section
     int64_t relay_accepted, relay_rejected; /* hand-overs between concurrently evaluated pieces of long DPs */
     double  t_traceback_ms, t_merge_ms;     /* host wall time of the traceback (kernels + copies) and of the trace merge  */
     int64_t dp_reruns;                      /* pieces rerun with a wider DP kernel (window outgrew the one-wave kernel)    */
+    double  t_dp_busy_ms;                   /* time during which at least one DP launch of the call was running: the union of the launches'
+                                             * HIP-event intervals (the groups of a call's pairs launch on streams of their own and overlap;
+                                             * t_dp_kernel_ms is the SUM of the launch durations)                            */
 } miblast_stats;
 
 typedef struct miblast_result miblast_result;

@@ -5,7 +5,7 @@
 TAG=${1:-rXX}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --seed-leg 0 --chain-leg 0 --pair-leg 0 --batch-leg 0"
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --seed-leg 0 --chain-leg 0 --pair-leg 0 --batch-leg 0 --primates-leg 0"
 PCMD="python $ROOT/bench.py --workload pair --steps 3 --warmup 1 --cpu-sample 0 --seed-leg 0 --chain-leg 0 --batch-leg 0"
 ( cd $ROOT && python bench.py > $OUT/bench.json 2> $OUT/bench.err )
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
@@ -16,7 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/ppmc_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/ppmc_write -- $PCMD > /dev/null 2> $OUT/ppmc_write.log
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 find $OUT/pstats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/pair_kernel_stats.csv
-python $ROOT/scripts/pmc_summary.py "$OUT/pmc_fetch/**/*counter_collection.csv" "$OUT/pmc_write/**/*counter_collection.csv" "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over \`python bench.py --steps 3 --warmup 1 --cpu-sample 0 --seed-leg 0 --chain-leg 0 --pair-leg 0 --batch-leg 0\` (evolverMammals stand-in), MI355X, $TAG" > $OUT/hbm_traffic_pmc.json
+python $ROOT/scripts/pmc_summary.py "$OUT/pmc_fetch/**/*counter_collection.csv" "$OUT/pmc_write/**/*counter_collection.csv" "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over \`python bench.py --steps 3 --warmup 1 --cpu-sample 0 --seed-leg 0 --chain-leg 0 --pair-leg 0 --batch-leg 0 --primates-leg 0\` (evolverMammals stand-in), MI355X, $TAG" > $OUT/hbm_traffic_pmc.json
 python $ROOT/scripts/pmc_summary.py "$OUT/ppmc_fetch/**/*counter_collection.csv" "$OUT/ppmc_write/**/*counter_collection.csv" "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over \`python bench.py --workload pair --steps 3 --warmup 1 --cpu-sample 0 --seed-leg 0 --chain-leg 0 --batch-leg 0\` (1 Mb x 1 Mb pair), MI355X, $TAG" > $OUT/pair_hbm_traffic_pmc.json
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*.db" -delete
