@@ -434,7 +434,7 @@ def run_rank(a):
             "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
             "dp_cells_per_step": tot["dp_cells"] / per, "seed_hits_per_step": tot["seed_hits"] / per, "alignments_per_step": tot["alignments"] / per,
             "stage_seconds_per_step": {k: tot[k] / per for k in ("t_index", "t_seed", "t_gapped")},
-            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / per, "ungapped": tot["t_ungapped_kernel_ms"] / per,
+            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / per, "ydrop_busy": tot["t_dp_busy_ms"] / per, "ungapped": tot["t_ungapped_kernel_ms"] / per,
                                          "sort": tot["t_sort_ms"] / per, "seed_fill": tot["t_seedfill_ms"] / per},
             # evaluated cells (speculative ones included) per second of DP kernel time: over the time at least one DP launch was running
             # (union of the launches' HIP-event intervals), and over the sum of the launch durations (launches of two streams overlap)

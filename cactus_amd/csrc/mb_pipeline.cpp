@@ -512,7 +512,10 @@ void upload_seqset(SeqSet &s, int device) {
     }
 }
 
+void forget_n_runs(const SeqSet &S);
+
 void release_seqset(SeqSet &s) {
+    forget_n_runs(s);
     if (s.d_buf) device_blocks().give(s.device, s.d_buf, s.d_cap);
     s.d_buf = nullptr; s.d_starts = nullptr; s.d_lens = nullptr; s.d_cap = 0;
 }
@@ -1576,6 +1579,48 @@ static std::vector<std::pair<int32_t, int32_t>> n_runs_of(const uint8_t *codes, 
     return runs;
 }
 
+// The N runs of a resident set are found once and kept for as long as the set lives (the genomes of a phase take part in call after
+// call; scanning target and both strands of the query was a third of a pair's host half): all runs, per set, keyed by the set's host
+// image; the '-' strand's runs are the '+' strand's mirrored contig by contig.
+namespace {
+struct NRunCache {
+    std::mutex mu;
+    std::unordered_map<const uint8_t *, std::shared_ptr<const std::vector<std::pair<int32_t, int32_t>>>> runs;
+};
+NRunCache &n_run_cache() { static NRunCache *c = new NRunCache(); return *c; }
+}  // namespace
+
+static std::shared_ptr<const std::vector<std::pair<int32_t, int32_t>>> n_runs_cached(const SeqSet &S) {
+    NRunCache &c = n_run_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.runs.find(S.host());
+        if (it != c.runs.end()) return it->second;
+    }
+    auto made = std::make_shared<const std::vector<std::pair<int32_t, int32_t>>>(n_runs_of(S.host(), S.total, 1));
+    std::lock_guard<std::mutex> lk(c.mu);
+    return c.runs.emplace(S.host(), made).first->second;
+}
+void forget_n_runs(const SeqSet &S) {
+    NRunCache &c = n_run_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.runs.erase(S.host());
+}
+// runs of at least min_len bases; mirrored = in the coordinates of the contig-wise reverse complement
+static std::vector<std::pair<int32_t, int32_t>> n_runs_for(const SeqSet &S, int32_t min_len, bool mirrored) {
+    const auto all = n_runs_cached(S);
+    std::vector<std::pair<int32_t, int32_t>> out;
+    for (const auto &r : *all) {
+        if (r.second - r.first < min_len) continue;
+        if (!mirrored) { out.push_back(r); continue; }
+        const int cg = S.contig_of(r.first);
+        const int32_t c0 = (int32_t)S.starts[(size_t)cg], c1 = c0 + (int32_t)S.lens[(size_t)cg];
+        out.push_back({c0 + (c1 - r.second), c0 + (c1 - r.first)});
+    }
+    if (mirrored) std::sort(out.begin(), out.end());
+    return out;
+}
+
 // anchors of one pair, one unit per (query contig, strand), sorted by (-score, t, q)  
 static void build_units(const miblast_params &p, PairJob &job, int pair, std::vector<Unit> &units) {
     const SeqSet &Q = *job.Q;
@@ -1645,10 +1690,10 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
         const int32_t n_run = (int32_t)std::max(8l, env_long("MIBLAST_GROUP_NRUN", p.ydrop / 100));
         std::vector<std::pair<int32_t, int32_t>> n_t, n_q[2];
         bool have_nq[2] = {false, false};
-        if (units.size() > first_unit) n_t = n_runs_of(tc_h, job.T->total, n_run);
+        if (units.size() > first_unit) n_t = n_runs_for(*job.T, n_run, false);
         for (size_t x = first_unit; x < units.size(); x++) {
             Unit &u = units[x];
-            if (!have_nq[u.strand]) { n_q[u.strand] = n_runs_of(qc_h[u.strand], Q.total, n_run); have_nq[u.strand] = true; }
+            if (!have_nq[u.strand]) { n_q[u.strand] = n_runs_for(Q, n_run, u.strand == 1); have_nq[u.strand] = true; }
             parallel_sort(u.anchors.begin(), u.anchors.end(), [](const Anchor &a, const Anchor &b) {
                 if (a.score != b.score) return a.score > b.score;
                 if (a.t != b.t) return a.t < b.t;
@@ -1880,7 +1925,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
         // anyway, longer pieces waste less on warm-up overlap.
         // Regimes (measured on the bench workloads, scripts/gpu_r02_sched2.sh, gpu_r02_s2y.sh): a lone pair (few sides) -- 640-row pieces; a
-        // batch of a few pairs (the evolver phase: hundreds of sides) -- 512-row pieces, still planted together with the heads: short
+        // batch of a few pairs (the evolver phase: hundreds of sides) -- 768-row pieces (round 3: 512 -> 768 takes the speculation factor of the phase
+        // from 1.51 to 1.39 -- a relay's warm-up rows are evaluated twice -- and ~0.8 ms off a step), still planted together with the heads: short
         // pieces balance the launch and a rejected hand-over costs one short retry; thousands of sides -- the GPU is full anyway,
         // long pieces waste less on warm-up and relays are only spent on sides that survive relay_s0 rows (16 x 1 Mb pairs, ~600
         // sides: 66 ms per call against 75 ms with the short pieces).
@@ -1890,7 +1936,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // (a handful of sides -- a trimmed outgroup call of the phase: every launch runs at lone-wave speed and most hand-overs are
         //  retried; 448-row pieces: 19 -> 17 DP launches and 10.2 -> 9.4 ms of DP kernel time per phase; 320 and 256 need more launches)
         const long relay_s_tiny = env_long("MIBLAST_RELAY_S_TINY", 448);
-        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides_call > 96 ? 512 : nsides_call > 16 ? 640 : relay_s_tiny;
+        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides_call > 96 ? env_long("MIBLAST_RELAY_S_MID", 768) : nsides_call > 16 ? 640 : relay_s_tiny;
         if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
         // (a handful of sides: 384 warm-up rows -- most hand-overs of such a call are rejected after 128, and a retry is a launch of
         //  its own: 17 -> 11 DP launches per phase)
