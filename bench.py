@@ -134,9 +134,10 @@ class EvolverPhase:
         for fa in self.fasta.values():
             bp.parsed_records(fa, keep=True)                                                     # ... and parsed once on the host, like their upload
         self.params = {}
-        # the option sets of a dependency level are independent jobs too (1 x "four" beside 9 x "default" at level 0): each gets its
-        # own context (stream + workspace) on this GPU and they run concurrently, as Toil runs independent jobs of a node.
-        self.contexts = [ctx] + [miblast.Context(ctx.device) for _ in range(max(0, int(os.environ.get("MIBLAST_BENCH_CONTEXTS", "2")) - 1))]
+        # the option sets of a dependency level are independent jobs too (1 x "four" beside 9 x "default" at level 0), and so are the
+        # ingroup pairs nothing waits for beside the chains of outgroup calls: each job in flight gets its own context (stream +
+        # workspace) on this GPU and they run concurrently, as Toil runs independent jobs of a node.
+        self.contexts = [ctx] + [miblast.Context(ctx.device) for _ in range(max(0, int(os.environ.get("MIBLAST_BENCH_CONTEXTS", "3")) - 1))]
         self.free_contexts = queue.Queue()                     # align_batch blocks on it: never more calls in flight than contexts
         for cx in self.contexts:
             self.free_contexts.put(cx)
@@ -189,7 +190,11 @@ class EvolverPhase:
             """what is left of every chain's ingroup after its previous call, cut out on the device (miblast_seqsets_unaligned)"""
             t0 = time.perf_counter()
             qs = [q if isinstance(q, self.miblast.SeqSet) else self.resident[q] for q, _ in items]
-            outs = self.contexts[0].seqsets_unaligned(qs, [paf for _, paf in items], min_size, flank)
+            cx = self.free_contexts.get()                      # (a context serves one call at a time, and jobs nothing waits for may be out)
+            try:
+                outs = cx.seqsets_unaligned(qs, [paf for _, paf in items], min_size, flank)
+            finally:
+                self.free_contexts.put(cx)
             made.extend(o for o in outs if o is not None)
             if TIMELINE:
                 print(f"[bench] trim_resident of {len(items)} chains: {(time.perf_counter() - t0) * 1e3:.2f} ms", file=sys.stderr)

@@ -284,7 +284,26 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         for _ in range(depth):
             paf = dechunk_query(paf) if paf else paf
         return invert(paf)
-    for level in range(max(c.level for c in calls) + 1):
+    last_level = max(c.level for c in calls)
+    gate = threading.BoundedSemaphore(max(1, int(getattr(align_batch, "concurrent", 1))))
+    free_jobs = []                                    # (option set, calls, future): jobs nothing waits for, collected at the end
+
+    def gated(pairs, opts):
+        with gate:
+            return align_batch(pairs, opts)
+
+    def take(opts, idx, outs):
+        for i, paf in zip(idx, outs):
+            raw[i] = paf
+            if calls[i].chain is not None:
+                last_paf[calls[i].chain] = (query_fa[i], paf)
+                # its share of the chain's final file is a job of its own (dechunk and invert work record by record), started
+                # now: it runs beside the next level's calls instead of after the last one
+                finished[i] = pool.submit(chain_share, paf, calls[i].level)
+            if on_call is not None:
+                on_call(calls[i], genomes[calls[i].target], as_fasta(query_fa[i]), paf)
+
+    for level in range(last_level + 1):
         todo: List[int] = []
         trimmed = {}
         if level > 0:
@@ -320,6 +339,22 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         # (align_batch.concurrent = how many calls it accepts at a time; each call still gets ONE option set)
         groups = list(by_opts.items())
         width = int(getattr(align_batch, "concurrent", 1))
+        if width > 2 and level < last_level:
+            # Calls nothing waits for -- the ingroup pairs of the nodes: only the final files take their output -- are jobs of their own
+            # that need not hold up the next level: they are handed over now and collected at the end of the phase, while the chains
+            # (an ingroup against its outgroups, one after the other) go on.  Toil does the same with its independent jobs.
+            held = []
+            for opts, idx in groups:
+                free_idx = [i for i in idx if calls[i].chain is None]
+                rest = [i for i in idx if calls[i].chain is not None]
+                if free_idx and rest:
+                    free_jobs.append((opts, free_idx, pool.submit(gated, [(genomes[calls[i].target], query_fa[i]) for i in free_idx], opts)))
+                    held.append((opts, rest))
+                elif free_idx and any(calls[i].chain is not None for _, ix in groups for i in ix):
+                    free_jobs.append((opts, free_idx, pool.submit(gated, [(genomes[calls[i].target], query_fa[i]) for i in free_idx], opts)))
+                else:
+                    held.append((opts, idx))
+            groups = held
         split = int(getattr(align_batch, "split_above", 0))
         if width > 1 and split > 0:
             # a large group is handed over in two halves (two concurrent batched calls: their host-side work -- relay planting,
@@ -334,24 +369,13 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         if width > 1 and len(groups) > 1:
             # never more than `width` calls in flight, however many option sets (and halves) a level has: the aligner owns that
             # many contexts and no more
-            gate = threading.BoundedSemaphore(width)
-
-            def one(g):
-                with gate:
-                    return align_batch([(genomes[calls[i].target], query_fa[i]) for i in g[1]], g[0])
-            results = list(pool.map(one, groups))
+            results = list(pool.map(lambda g: gated([(genomes[calls[i].target], query_fa[i]) for i in g[1]], g[0]), groups))
         else:
             results = [align_batch([(genomes[calls[i].target], query_fa[i]) for i in idx], opts) for opts, idx in groups]
         for (opts, idx), outs in zip(groups, results):
-            for i, paf in zip(idx, outs):
-                raw[i] = paf
-                if calls[i].chain is not None:
-                    last_paf[calls[i].chain] = (query_fa[i], paf)
-                    # its share of the chain's final file is a job of its own (dechunk and invert work record by record), started
-                    # now: it runs beside the next level's calls instead of after the last one
-                    finished[i] = pool.submit(chain_share, paf, level)
-                if on_call is not None:
-                    on_call(calls[i], genomes[calls[i].target], as_fasta(query_fa[i]), paf)
+            take(opts, idx, outs)
+    for opts, idx, fut in free_jobs:
+        take(opts, idx, fut.result())
     # assemble: outgroup chains are merged innermost first (each level's sub-sequence coordinates fixed by dechunk --query,
     # make_ingroup_to_outgroup_alignments_3), then inverted so that the ingroup is the target
     result: Dict[str, Dict[str, bytes]] = {}

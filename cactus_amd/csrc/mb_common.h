@@ -240,9 +240,14 @@ void launch_batch_seed_count(const SeedUnit *units, int n_units, const BatchTarg
 void launch_batch_seed_fill(const SeedUnit *units, int n_units, const BatchTarget *tg, const unsigned long long *bits, const uint32_t *dir,
                             const uint32_t *starts, const uint32_t *positions, int transitions, int64_t q_slots, const uint32_t *hit_off,
                             unsigned long long *keys, hipStream_t s);
+struct RcItem { const uint8_t *src; const int64_t *starts, *lens; long long total, grid_off; int n_contigs, pad; };
+void launch_revcomp_sets(const RcItem *items, int n_items, int64_t grid_bytes, uint8_t *dst, hipStream_t s);
+// outgroup trimming (k_cov_*, k_gather_stretches): the query sets of one call share every launch
+struct CovItem { const uint8_t *codes; long long total, off_depth, off_edges; unsigned cap, pad; };     // off_depth: a multiple of 256
+struct GatherItem { const uint8_t *src; uint8_t *dst; int64_t *d_starts, *d_lens; long long grid_off, seq_bytes, total, iv_off; int n_iv, pad; };
 void launch_cov_mark(const long long *spans, int n, uint32_t *diff, hipStream_t s);
-void launch_cov_edges(const uint32_t *depth, const uint8_t *codes, int64_t total, unsigned *n_edges, long long *first, long long *last, unsigned cap, hipStream_t s);
-void launch_gather_stretches(const uint8_t *src, uint8_t *dst, const long long *iv, int n_iv, int64_t total, hipStream_t s);
+void launch_cov_edges(const uint32_t *depth, const CovItem *items, int n_items, int64_t n_depth, unsigned *n_edges, long long *first, long long *last, hipStream_t s);
+void launch_gather_stretches(const GatherItem *items, int n_items, int64_t grid_bytes, const long long *iv, hipStream_t s);
 size_t sort_pairs_temp_bytes(int64_t n);
 void launch_ungapped_hash16(const unsigned long long *keys, int64_t n_hits, const UnitTab &ut, int64_t n_diagonals, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
                             UngappedCounters *ctr, const UxScratch *ux, unsigned long long *ka, unsigned long long *kb, uint32_t *va, uint32_t *vb, void *temp,

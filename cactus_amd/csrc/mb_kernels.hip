@@ -93,6 +93,36 @@ void launch_revcomp(const uint8_t *src, uint8_t *dst, const int64_t *starts, con
     hipLaunchKernelGGL(k_revcomp, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, starts, lens, n_contigs, total);
 }
 
+// the '-' strands of all distinct query sets of a call in one launch, separator bytes around each included: set k owns the bytes
+// [grid_off, grid_off + span) of dst (span = total + 2 kDevPad rounded up to whole blocks), its strand begins kDevPad bytes in
+__global__ __launch_bounds__(256) void k_revcomp_sets(const RcItem *__restrict__ items, const int n_items, uint8_t *__restrict__ dst) {
+    const long long g = (long long)blockIdx.x * blockDim.x;
+    int k = 0;
+    while (k + 1 < n_items && items[k + 1].grid_off <= g) k++;
+    const RcItem it = items[k];
+    const long long at = g + threadIdx.x;
+    const long long pos = at - it.grid_off - kDevPad;
+    uint8_t v = kSep;
+    if (pos >= 0 && pos < it.total) {
+        int lo = 0, hi = it.n_contigs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (it.starts[mid] <= pos) lo = mid; else hi = mid - 1;
+        }
+        const long long st = it.starts[lo], n = it.lens[lo];
+        if (pos < st + n) {
+            unsigned b = it.src[st + n - 1 - (pos - st)];
+            if ((b & 7u) < 4u) b = (b & 8u) | (3u - (b & 7u));
+            v = (uint8_t)b;
+        }
+    }
+    dst[at] = v;
+}
+
+void launch_revcomp_sets(const RcItem *items, int n_items, int64_t grid_bytes, uint8_t *dst, hipStream_t s) {
+    if (grid_bytes > 0 && n_items > 0) hipLaunchKernelGGL(k_revcomp_sets, dim3((unsigned)((grid_bytes + 255) / 256)), dim3(256), 0, s, items, n_items, dst);
+}
+
 // ------------------------------------------------------------------------------------------------
 // seed index
 __global__ void k_index_words(const uint8_t *__restrict__ codes, int64_t n, int step, int64_t first, uint32_t *__restrict__ words,
@@ -439,40 +469,60 @@ __global__ __launch_bounds__(256) void k_cov_mark(const long long *__restrict__ 
     atomicAdd(&diff[spans[2 * k + 1]], 0xFFFFFFFFu);                     // -1 (the prefix sums never go below zero)
 }
 
-// depth[p + 1] = number of intervals over base p (exclusive scan of diff, one entry further on)
-__global__ __launch_bounds__(256) void k_cov_edges(const uint32_t *__restrict__ depth, const uint8_t *__restrict__ codes, const long long total,
-                                                    unsigned *__restrict__ n_edges, long long *__restrict__ first, long long *__restrict__ last,
-                                                    const unsigned cap) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// depth[p + 1] = number of intervals over base p (exclusive scan of diff, one entry further on).  All query sets of a trimming call
+// in one launch: their depth arrays lie one after the other in shares of whole blocks (CovItem::off_depth), a block finds its set.
+__global__ __launch_bounds__(256) void k_cov_edges(const uint32_t *__restrict__ depth_all, const CovItem *__restrict__ items, const int n_items,
+                                                    unsigned *__restrict__ n_edges_all, long long *__restrict__ first_all,
+                                                    long long *__restrict__ last_all) {
+    const long long g = (long long)blockIdx.x * blockDim.x;
+    int k = 0;
+    while (k + 1 < n_items && items[k + 1].off_depth <= g) k++;
+    const CovItem it = items[k];
+    const long long total = it.total;
+    const long long p = g - it.off_depth + threadIdx.x;
     if (p >= total) return;
+    const uint32_t *depth = depth_all + it.off_depth;
+    const uint8_t *codes = it.codes;
     auto open = [&](long long x) -> bool { return x >= 0 && x < total && depth[x + 1] == 0u && codes[x] != kSep; };
     if (!open(p)) return;
-    if (!open(p - 1)) { const unsigned at = atomicAdd(&n_edges[0], 1u); if (at < cap) first[at] = p; }
-    if (!open(p + 1)) { const unsigned at = atomicAdd(&n_edges[1], 1u); if (at < cap) last[at] = p + 1; }
+    if (!open(p - 1)) { const unsigned at = atomicAdd(&n_edges_all[2 * k], 1u); if (at < it.cap) first_all[it.off_edges + at] = p; }
+    if (!open(p + 1)) { const unsigned at = atomicAdd(&n_edges_all[2 * k + 1], 1u); if (at < it.cap) last_all[it.off_edges + at] = p + 1; }
 }
 
-// the bases of the kept stretches, one after the other with a separator between two stretches: iv = (dst, src, len) triples by dst
-__global__ __launch_bounds__(256) void k_gather_stretches(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const long long *__restrict__ iv,
-                                                           const int n_iv, const long long total) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total) return;
-    int lo = 0, hi = n_iv - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (iv[3 * mid] <= p) lo = mid; else hi = mid - 1;
+// The device images of the new sets, all sets of a call in one launch (a set's image = a share of whole blocks of the grid): the
+// bases of the kept stretches one after the other with a separator between two stretches (iv = (dst, src, len) triples by dst),
+// separator bytes around them, and the contig tables behind the codes (start and length of stretch x = iv[3x] and iv[3x + 2]).
+__global__ __launch_bounds__(256) void k_gather_stretches(const GatherItem *__restrict__ items, const int n_items, const long long *__restrict__ iv_all) {
+    const long long g = (long long)blockIdx.x * blockDim.x;
+    int k = 0;
+    while (k + 1 < n_items && items[k + 1].grid_off <= g) k++;
+    const GatherItem it = items[k];
+    const long long at = g - it.grid_off + threadIdx.x;                  // byte of the image
+    if (at >= it.seq_bytes) return;
+    const long long *iv = iv_all + it.iv_off;
+    if (at < it.n_iv) { it.d_starts[at] = iv[3 * at]; it.d_lens[at] = iv[3 * at + 2]; }
+    const long long p = at - kDevPad;
+    uint8_t v = kSep;
+    if (p >= 0 && p < it.total) {
+        int lo = 0, hi = it.n_iv - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (iv[3 * mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        const long long off = p - iv[3 * lo];
+        if (off < iv[3 * lo + 2]) v = it.src[iv[3 * lo + 1] + off];
     }
-    const long long off = p - iv[3 * lo];
-    dst[p] = off < iv[3 * lo + 2] ? src[iv[3 * lo + 1] + off] : kSep;
+    it.dst[at] = v;
 }
 
 void launch_cov_mark(const long long *spans, int n, uint32_t *diff, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_cov_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spans, n, diff);
 }
-void launch_cov_edges(const uint32_t *depth, const uint8_t *codes, int64_t total, unsigned *n_edges, long long *first, long long *last, unsigned cap, hipStream_t s) {
-    if (total > 0) hipLaunchKernelGGL(k_cov_edges, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, depth, codes, (long long)total, n_edges, first, last, cap);
+void launch_cov_edges(const uint32_t *depth, const CovItem *items, int n_items, int64_t n_depth, unsigned *n_edges, long long *first, long long *last, hipStream_t s) {
+    if (n_depth > 0 && n_items > 0) hipLaunchKernelGGL(k_cov_edges, dim3((unsigned)((n_depth + 255) / 256)), dim3(256), 0, s, depth, items, n_items, n_edges, first, last);
 }
-void launch_gather_stretches(const uint8_t *src, uint8_t *dst, const long long *iv, int n_iv, int64_t total, hipStream_t s) {
-    if (total > 0 && n_iv > 0) hipLaunchKernelGGL(k_gather_stretches, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, iv, n_iv, (long long)total);
+void launch_gather_stretches(const GatherItem *items, int n_items, int64_t grid_bytes, const long long *iv, hipStream_t s) {
+    if (grid_bytes > 0 && n_items > 0) hipLaunchKernelGGL(k_gather_stretches, dim3((unsigned)((grid_bytes + 255) / 256)), dim3(256), 0, s, items, n_items, iv);
 }
 
 size_t sort_keys_temp_bytes(int64_t n, int end_bit) {
@@ -1581,6 +1631,9 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
     const int64_t t0 = pr.t0, q0 = pr.q0;
     const int row_lo = pr.row_lo;
     const long long clk0 = clock64();
+    // the piece's own snapshot slots start out invalid (nothing reads them before this launch is over: the hand-over checks and the
+    // continuations that start from them come after it in stream order)
+    if (pr.snap_idx >= 0 && lane < kSnapSlots) ((SnapHdr *)(snaps + (size_t)(pr.snap_idx + lane) * kSnapBytes))->valid = 0;
     const int OE = O + E;
     const int grow = (Y >= O ? (Y - O) / E : 0) + 2;          // a row can outgrow the previous window by at most this
     int overflow = 0;

@@ -118,6 +118,24 @@ struct Stager {
         MB_HIP(hipMemcpyAsync(b, dev, n, hipMemcpyDeviceToHost, s));
         pending.push_back({host, b, n});
     }
+    // two host arrays that lie one behind the other on the device (the second behind(na) bytes in): ONE copy each way
+    static size_t behind(size_t n) { return (n + 255) & ~(size_t)255; }
+    void h2d2(void *dev, const void *a, size_t na, const void *b, size_t nb, hipStream_t s) {
+        const size_t off_b = behind(na), n = nb ? off_b + nb : na;
+        if (!n) return;
+        char *buf = take(n);
+        if (na) memcpy(buf, a, na);
+        if (nb) memcpy(buf + off_b, b, nb);
+        MB_HIP(hipMemcpyAsync(dev, buf, n, hipMemcpyHostToDevice, s));
+    }
+    void d2h2(void *a, size_t na, void *b, size_t nb, const void *dev, hipStream_t s) {
+        const size_t off_b = behind(na), n = nb ? off_b + nb : na;
+        if (!n) return;
+        char *buf = take(n);
+        MB_HIP(hipMemcpyAsync(buf, dev, n, hipMemcpyDeviceToHost, s));
+        if (na) pending.push_back({a, buf, na});
+        if (nb) pending.push_back({b, buf + off_b, nb});
+    }
     // A call that ended early (a HIP failure thrown between d2h() and done(), an early return) leaves `pending` entries whose
     // destinations were locals of frames that are gone: every entry point drops them before it queues anything.
     void abort() { pending.clear(); used = 0; }
@@ -530,6 +548,7 @@ struct Workspace {                      // device buffers that persist across mi
     // seed search / ungapped
     DevBuf<uint8_t> rc;
     PinBuf<uint8_t> h_rc;
+    DevBuf<RcItem> rc_items;
     DevBuf<int32_t> extent;
     DevBuf<uint32_t> qcnt, hit_off;
     DevBuf<unsigned long long> qbsum, scan_scratch, keys_a, keys_b;
@@ -560,8 +579,7 @@ struct Workspace {                      // device buffers that persist across mi
     PinBuf<unsigned long long> pin_scan;
     // outgroup trimming on the device (seqset_unaligned)
     DevBuf<uint32_t> cov_diff, cov_depth;
-    DevBuf<long long> cov_spans, cov_first, cov_last, cov_iv;
-    DevBuf<unsigned> cov_n;
+    DevBuf<long long> cov_spans, cov_first, cov_iv;
     // gapped
     DevBuf<DpProb> probs;
     DevBuf<int> dp_order;                     // a crowded DP launch: piece of block b (longest first)
@@ -573,13 +591,10 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<uint32_t> ops, ops_packed;
     DevBuf<unsigned long long> coff;
     PinBuf<uint32_t> hops;
-    DevBuf<TbSide> tb_sides;
-    DevBuf<TbWalk> tb_walks;
-    DevBuf<TbSeg> tb_segs;
+    DevBuf<char> tb_blk;                      // traceback tables (walks, sides, segments) one behind the other
     DevBuf<uint32_t> recs;
     DevBuf<uint8_t> snaps;
-    DevBuf<VerifyJob> vjobs;
-    DevBuf<VerifyOut> vres;
+    DevBuf<char> dp_up, dp_down;             // a DP launch's pieces + hand-over checks / their results: one copy each way
     DevBuf<PairPtrs> pair_ptrs;
     DevBuf<int32_t> wall_segs;                // walls mode: WallSeg runs (3 x int32), run ranges per alignment and alignment ranges per piece (int2 each)
     DevBuf<int32_t> wall_alns, wall_ref;
@@ -676,35 +691,45 @@ int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *co
         it.cap = (unsigned)std::min<size_t>(it.spans.size() / 2 + Q.names.size() + 2, 0x7fffffffu);
     });
     for (const Item &it : items) if (it.rc != MIBLAST_OK) { set_error(it.err); return it.rc; }
-    // ---- coverage on the device, edges of the uncovered stretches back
-    size_t n_depth = 0, n_sp = 0, n_ed = 0, scan_tiles = 0;
+    // ---- coverage on the device, edges of the uncovered stretches back: one difference array, one scan, one edge search for all
+    //      items (an item's difference array sums to zero, so the running depth is zero where the next item's share begins)
+    static_assert(sizeof(CovItem) == 5 * sizeof(long long) && sizeof(GatherItem) == 9 * sizeof(long long), "tables travel as long long");
+    size_t n_depth = 0, n_sp = 0, n_ed = 0;
     for (size_t k = 0; k < n; k++) {
         Item &it = items[k];
         it.off_depth = n_depth; it.off_spans = n_sp; it.off_edges = n_ed;
-        n_depth += (((size_t)Qs[k]->total + 2) + 7) & ~(size_t)7;                 // (16-byte aligned shares: the scan loads uint4)
-        n_sp += it.spans.size() + 2; n_ed += it.cap;
-        scan_tiles = std::max(scan_tiles, (size_t)((Qs[k]->total + 2 + 2047) / 2048) + 2);
+        n_depth += (((size_t)std::max<int64_t>(0, Qs[k]->total) + 2) + 255) & ~(size_t)255;       // (shares of whole blocks: k_cov_edges)
+        n_sp += it.spans.size(); n_ed += it.cap;
     }
-    w.cov_diff.ensure(n_depth + 8); w.cov_depth.ensure(n_depth + 8);
-    w.cov_spans.ensure(n_sp + 2); w.cov_first.ensure(n_ed + 1); w.cov_last.ensure(n_ed + 1); w.cov_n.ensure(2 * n + 2);
-    w.bx_scan.ensure(n * scan_tiles + 2);
-    MB_HIP(hipMemsetAsync(w.cov_diff.p, 0, (n_depth + 8) * 4, s));
-    MB_HIP(hipMemsetAsync(w.cov_n.p, 0, (2 * n + 2) * sizeof(unsigned), s));
+    std::vector<long long> up(5 * n + n_sp);                                   // CovItem table, then every item's spans at its share of the array
     for (size_t k = 0; k < n; k++) {
         Item &it = items[k];
-        const int64_t total = Qs[k]->total;
-        if (total <= 0) continue;
-        it.first.resize(it.cap); it.last.resize(it.cap);
-        w.stage.h2d(w.cov_spans.p + it.off_spans, it.spans.data(), it.spans.size() * sizeof(long long), s);
-        launch_cov_mark(w.cov_spans.p + it.off_spans, (int)(it.spans.size() / 2), w.cov_diff.p + it.off_depth, s);
-        launch_scan_u32(w.cov_diff.p + it.off_depth, w.cov_depth.p + it.off_depth, total + 2, w.bx_scan.p + k * scan_tiles, s);
-        launch_cov_edges(w.cov_depth.p + it.off_depth, Qs[k]->dev(), total, w.cov_n.p + 2 * k, w.cov_first.p + it.off_edges, w.cov_last.p + it.off_edges, it.cap, s);
-        w.stage.d2h(it.n_edges, w.cov_n.p + 2 * k, 8, s);
-        w.stage.d2h(it.first.data(), w.cov_first.p + it.off_edges, (size_t)it.cap * sizeof(long long), s);
-        w.stage.d2h(it.last.data(), w.cov_last.p + it.off_edges, (size_t)it.cap * sizeof(long long), s);
+        CovItem ci{Qs[k]->d_buf ? Qs[k]->dev() : nullptr, std::max<int64_t>(0, Qs[k]->total), (long long)it.off_depth, (long long)it.off_edges, it.cap, 0};
+        memcpy(&up[5 * k], &ci, sizeof ci);
+        for (size_t x = 0; x < it.spans.size(); x++) up[5 * n + it.off_spans + x] = it.spans[x] + (long long)it.off_depth;
     }
+    std::vector<long long> edges(2 * n_ed + 1);
+    std::vector<unsigned> counts(2 * n + 2);
+    w.cov_diff.ensure(n_depth + 2 * n + 8); w.cov_depth.ensure(n_depth + 8);
+    w.cov_spans.ensure(up.size() + 2); w.cov_first.ensure(2 * n_ed + 1);
+    w.bx_scan.ensure((n_depth + 2047) / 2048 + 2);
+    unsigned *d_counts = w.cov_diff.p + n_depth;                                  // (zeroed with the difference array)
+    MB_HIP(hipMemsetAsync(w.cov_diff.p, 0, (n_depth + 2 * n + 8) * 4, s));
+    w.stage.h2d(w.cov_spans.p, up.data(), up.size() * sizeof(long long), s);
+    launch_cov_mark(w.cov_spans.p + 5 * n, (int)(n_sp / 2), w.cov_diff.p, s);
+    launch_scan_u32(w.cov_diff.p, w.cov_depth.p, (int64_t)n_depth, w.bx_scan.p, s);
+    launch_cov_edges(w.cov_depth.p, (const CovItem *)w.cov_spans.p, (int)n, (int64_t)n_depth, d_counts, w.cov_first.p, w.cov_first.p + n_ed, s);
+    w.stage.d2h(counts.data(), d_counts, 2 * n * sizeof(unsigned), s);
+    if (n_ed) w.stage.d2h(edges.data(), w.cov_first.p, 2 * n_ed * sizeof(long long), s);
     MB_HIP(hipStreamSynchronize(s));                                           // (1) the edges of every item
     w.stage.done();
+    for (size_t k = 0; k < n; k++) {
+        Item &it = items[k];
+        it.n_edges[0] = counts[2 * k]; it.n_edges[1] = counts[2 * k + 1];
+        const size_t got = std::min<size_t>(it.cap, std::max(it.n_edges[0], it.n_edges[1]));
+        it.first.assign(edges.begin() + (long)it.off_edges, edges.begin() + (long)(it.off_edges + got));
+        it.last.assign(edges.begin() + (long)(n_ed + it.off_edges), edges.begin() + (long)(n_ed + it.off_edges + got));
+    }
     // ---- the rule of the two tools on the uncovered stretches, contig by contig; host images of the new sets
     struct Iv { size_t contig; int64_t s, e; };
     std::vector<std::vector<Iv>> keeps(n);
@@ -728,7 +753,6 @@ int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *co
     }
     size_t n_iv = 0;
     for (size_t k = 0; k < n; k++) { items[k].off_iv = n_iv; n_iv += 3 * keeps[k].size(); }
-    w.cov_iv.ensure(n_iv + 3);
     parallel_for(n, [&](size_t k) {
         const std::vector<Iv> &keep = keeps[k];
         if (keep.empty()) return;
@@ -755,12 +779,15 @@ int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *co
         out.codes[(size_t)new_total + 1] = kSep;
         out.total = new_total;
     });
-    // ---- device images gathered from the resident sets
-    bool any = false;
+    // ---- device images gathered from the resident sets: one table, one launch
+    std::vector<size_t> live;
+    for (size_t k = 0; k < n; k++) if (!keeps[k].empty()) live.push_back(k);
+    if (live.empty()) return MIBLAST_OK;
     try {
-        for (size_t k = 0; k < n; k++) {
-            if (keeps[k].empty()) continue;
-            any = true;
+        std::vector<long long> tab(9 * live.size() + n_iv);
+        long long grid = 0, iv_at = 0;
+        for (size_t x = 0; x < live.size(); x++) {
+            const size_t k = live[x];
             nothing_left[k] = false;
             SeqSet &out = *outs[k];
             out.device = ctx.device;
@@ -769,13 +796,16 @@ int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *co
             out.d_buf = (uint8_t *)device_blocks().take(ctx.device, image, out.d_cap);
             out.d_starts = (int64_t *)(out.d_buf + seq_bytes);
             out.d_lens = out.d_starts + nc;
-            MB_HIP(hipMemsetAsync(out.d_buf, 0xFF, seq_bytes, s));
-            w.stage.h2d(w.cov_iv.p + items[k].off_iv, items[k].iv.data(), items[k].iv.size() * sizeof(long long), s);
-            launch_gather_stretches(Qs[k]->dev(), out.d_buf + kDevPad, w.cov_iv.p + items[k].off_iv, (int)keeps[k].size(), out.total, s);
-            w.stage.h2d(out.d_starts, out.starts.data(), nc * sizeof(int64_t), s);
-            w.stage.h2d(out.d_lens, out.lens.data(), nc * sizeof(int64_t), s);
+            GatherItem gi{Qs[k]->dev(), out.d_buf, out.d_starts, out.d_lens, grid, (long long)seq_bytes, out.total, iv_at, (int)keeps[k].size(), 0};
+            memcpy(&tab[9 * x], &gi, sizeof gi);
+            std::copy(items[k].iv.begin(), items[k].iv.end(), tab.begin() + (long)(9 * live.size()) + iv_at);
+            grid += (long long)seq_bytes; iv_at += (long long)items[k].iv.size();
         }
-        if (any) { MB_HIP(hipStreamSynchronize(s)); w.stage.done(); }         // (2) the new sets are resident
+        w.cov_iv.ensure(tab.size() + 3);
+        w.stage.h2d(w.cov_iv.p, tab.data(), tab.size() * sizeof(long long), s);
+        launch_gather_stretches((const GatherItem *)w.cov_iv.p, (int)live.size(), grid, w.cov_iv.p + 9 * live.size(), s);
+        MB_HIP(hipStreamSynchronize(s));                                       // (2) the new sets are resident
+        w.stage.done();
     } catch (...) {
         for (size_t k = 0; k < n; k++) if (outs[k]->d_buf) release_seqset(*outs[k]);
         throw;
@@ -1397,22 +1427,39 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
     handled = true;
     for (size_t k = 0; k < n; k++) { memset(&jobs[k]->res->stats, 0, sizeof(miblast_stats)); jobs[k]->t_begin = t_begin; }
 
-    // ---- '-' strands (device + pinned host copy: discovery order, anchors, '='/'X' classification read it)
-    for (size_t k = 0; k < n; k++) {
-        PairJob &job = *jobs[k];
-        const SeqSet &T = *job.T, &Q = *job.Q;
-        const int64_t qtot = Q.total;
-        DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : *job.slot_rc;
-        d_rc.ensure((size_t)qtot + 2 * kDevPad);
-        MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
-        launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
-        PinBuf<uint8_t> &h_rc = job.use_ws_rc ? w.h_rc : *job.slot_h_rc;
-        h_rc.ensure((size_t)qtot + 2);
-        MB_HIP(hipMemcpyAsync(h_rc.p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
-        job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc.p + 1;
-        job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
-        job.strand_hsps[0].clear(); job.strand_hsps[1].clear();
-        for (int strand = 0; strand < 2; strand++) { units[2 * k + (size_t)strand].tc = T.dev(); units[2 * k + (size_t)strand].qc = job.qc_d[strand]; }
+    // ---- '-' strands (device + pinned host copy: discovery order, anchors, '='/'X' classification read it): one buffer, one launch and
+    //      one copy back for the distinct query sets of the call
+    {
+        std::vector<const SeqSet *> qsets;
+        std::vector<RcItem> rc_items;
+        std::vector<size_t> q_of(n);
+        long long grid = 0;
+        for (size_t k = 0; k < n; k++) {
+            const SeqSet *Q = jobs[k]->Q;
+            size_t x = 0;
+            while (x < qsets.size() && qsets[x] != Q) x++;
+            if (x == qsets.size()) {
+                qsets.push_back(Q);
+                rc_items.push_back(RcItem{Q->dev(), Q->d_starts, Q->d_lens, Q->total, grid, (int)Q->starts.size(), 0});
+                grid += (long long)(((size_t)Q->total + 2 * kDevPad + 255) & ~(size_t)255);
+            }
+            q_of[k] = x;
+        }
+        w.rc.ensure((size_t)grid + 16);
+        w.h_rc.ensure((size_t)grid + 16);
+        w.rc_items.ensure(rc_items.size());
+        w.stage.h2d(w.rc_items.p, rc_items.data(), rc_items.size() * sizeof(RcItem), s);
+        launch_revcomp_sets(w.rc_items.p, (int)rc_items.size(), grid, w.rc.p, s);
+        MB_HIP(hipMemcpyAsync(w.h_rc.p, w.rc.p, (size_t)grid, hipMemcpyDeviceToHost, s));
+        for (size_t k = 0; k < n; k++) {
+            PairJob &job = *jobs[k];
+            const SeqSet &T = *job.T, &Q = *job.Q;
+            const long long off = rc_items[q_of[k]].grid_off + kDevPad;
+            job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = w.h_rc.p + off;
+            job.qc_d[0] = Q.dev(); job.qc_d[1] = w.rc.p + off;
+            job.strand_hsps[0].clear(); job.strand_hsps[1].clear();
+            for (int strand = 0; strand < 2; strand++) { units[2 * k + (size_t)strand].tc = T.dev(); units[2 * k + (size_t)strand].qc = job.qc_d[strand]; }
+        }
     }
 
     // ---- seed tables of the distinct targets
@@ -2309,23 +2356,27 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             while (launched < pieces.size() && !arena_full) {
                 n_subrounds++;
                 const size_t n_new = pieces.size() - launched, v_new = vjobs.size() - vlaunched;
-                g.probs.ensure_keep(pieces.size()); g.outs.ensure_keep(pieces.size()); g.rowdir.ensure_keep((size_t)dir_entries + 1);
+                g.rowdir.ensure_keep((size_t)dir_entries + 1);
                 g.snaps.ensure_keep(pieces.size() * kSnapSlots * kSnapBytes);
-                g.vjobs.ensure(v_new + 1); g.vres.ensure(v_new + 1);
                 outs.resize(pieces.size()); vres.resize(vjobs.size());
                 for (size_t x = launched; x < pieces.size(); x++)
                     if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = kSnapSlots * relay_pts[(size_t)pieces[x].target].piece + (pieces[x].ckpt == 0 ? 0 : pieces[x].ckpt + 1);
-                g.stage.h2d(g.probs.p + launched, probs.data() + launched, n_new * sizeof(DpProb), s);
-                g.stage.h2d(g.vjobs.p, vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), s);
-                // valid = 0 in every header of the new pieces' slots (the headers only: the slots are 16 KiB apart)
-                MB_HIP(hipMemset2DAsync(g.snaps.p + launched * kSnapSlots * kSnapBytes, kSnapBytes, 0, sizeof(SnapHdr), n_new * kSnapSlots, s));
+                // the launch's pieces with its hand-over checks behind them travel in one copy, and so do both kinds of results
+                const size_t up_v = Stager::behind(n_new * sizeof(DpProb)), down_v = Stager::behind(n_new * sizeof(DpOut));
+                g.dp_up.ensure(up_v + v_new * sizeof(VerifyJob) + 256); g.dp_down.ensure(down_v + v_new * sizeof(VerifyOut) + 256);
+                DpProb *const d_probs = (DpProb *)g.dp_up.p;
+                VerifyJob *const d_vjobs = (VerifyJob *)(g.dp_up.p + up_v);
+                DpOut *const d_outs = (DpOut *)g.dp_down.p;
+                VerifyOut *const d_vres = (VerifyOut *)(g.dp_down.p + down_v);
+                g.stage.h2d2(g.dp_up.p, probs.data() + launched, n_new * sizeof(DpProb), vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), s);
+                // valid = 0 in every header of the new pieces' slots (the headers only: the slots are 16 KiB apart); k_ydrop2 does it itself
+                if (dp_kernel != kDpWave2x4) MB_HIP(hipMemset2DAsync(g.snaps.p + launched * kSnapSlots * kSnapBytes, kSnapBytes, 0, sizeof(SnapHdr), n_new * kSnapSlots, s));
                 // DP launch, hand-over checks and the copies of both results: one synchronisation.  (Checks made on pieces that
                 // turn out to need a rerun are simply made again.)
-                run_ydrop_timed(ctx, st, dp_kernel, g.probs.p + launched, g.outs.p + launched, (int)n_new, g.pair_ptrs.p, p, kBlk, true, probs.data() + launched,
+                run_ydrop_timed(ctx, st, dp_kernel, d_probs, d_outs, (int)n_new, g.pair_ptrs.p, p, kBlk, true, probs.data() + launched,
                                 upload_wall_refs(launched, pieces.size()));
-                launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
-                g.stage.d2h(outs.data() + launched, g.outs.p + launched, n_new * sizeof(DpOut), s);
-                g.stage.d2h(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), s);
+                launch_verify(d_vjobs, d_vres, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
+                g.stage.d2h2(outs.data() + launched, n_new * sizeof(DpOut), vres.data() + vlaunched, v_new * sizeof(VerifyOut), g.dp_down.p, s);
                 MB_HIP(hipStreamSynchronize(s));
                 g.stage.done();
                 collect_dp_time(ctx, st);
@@ -2338,18 +2389,18 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     if (!again.empty()) {
                         std::vector<DpProb> sub(again.size());
                         for (size_t y = 0; y < again.size(); y++) sub[y] = probs[again[y]];
-                        g.probs.ensure_keep(pieces.size() + again.size()); g.outs.ensure_keep(pieces.size() + again.size());
-                        g.stage.h2d(g.probs.p + pieces.size(), sub.data(), sub.size() * sizeof(DpProb), s);
-                        run_ydrop_timed(ctx, st, kDpLds, g.probs.p + pieces.size(), g.outs.p + pieces.size(), (int)again.size(), g.pair_ptrs.p, p, kBlk);
+                        g.probs.ensure(again.size()); g.outs.ensure(again.size());
+                        g.stage.h2d(g.probs.p, sub.data(), sub.size() * sizeof(DpProb), s);
+                        run_ydrop_timed(ctx, st, kDpLds, g.probs.p, g.outs.p, (int)again.size(), g.pair_ptrs.p, p, kBlk);
                         std::vector<DpOut> so(again.size());
-                        g.stage.d2h(so.data(), g.outs.p + pieces.size(), so.size() * sizeof(DpOut), s);
+                        g.stage.d2h(so.data(), g.outs.p, so.size() * sizeof(DpOut), s);
                         MB_HIP(hipStreamSynchronize(s));
                         g.stage.done();
                         for (size_t y = 0; y < again.size(); y++) outs[again[y]] = so[y];
                         st.dp_reruns += (int64_t)again.size();
                         if (debug) fprintf(stderr, "[miblast]   %zu of %zu pieces outgrew the one-wave kernel and were rerun (dp kernel total %.2f ms)\n", again.size(), n_new, st.t_dp_kernel_ms);
-                        launch_verify(g.vjobs.p, g.vres.p, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
-                        g.stage.d2h(vres.data() + vlaunched, g.vres.p, v_new * sizeof(VerifyOut), s);
+                        launch_verify(d_vjobs, d_vres, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
+                        g.stage.d2h(vres.data() + vlaunched, d_vres, v_new * sizeof(VerifyOut), s);
                         MB_HIP(hipStreamSynchronize(s));
                         g.stage.done();
                     }
@@ -2580,16 +2631,19 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         const double t_tb0 = now_s();
         std::vector<unsigned long long> coff;           // first packed run of every side (+ total)
         if (!acc.empty()) {
-            g.tb_sides.ensure(tbs.size()); g.tb_walks.ensure(tbw.size()); g.tb_segs.ensure((size_t)soff + 1);
+            // walks, sides and segments lie one behind the other: walks + sides go up in one copy, sides + segments come back in one
+            const size_t at_sides = Stager::behind(tbw.size() * sizeof(TbWalk)), at_segs = at_sides + Stager::behind(tbs.size() * sizeof(TbSide));
+            g.tb_blk.ensure(at_segs + ((size_t)soff + 1) * sizeof(TbSeg) + 256);
+            TbWalk *const d_walks = (TbWalk *)g.tb_blk.p;
+            TbSide *const d_sides = (TbSide *)(g.tb_blk.p + at_sides);
+            TbSeg *const d_segs = (TbSeg *)(g.tb_blk.p + at_segs);
             g.ops.ensure((size_t)ooff + 64); g.recs.ensure((size_t)roff + 64);
-            g.stage.h2d(g.tb_sides.p, tbs.data(), tbs.size() * sizeof(TbSide), s);
-            g.stage.h2d(g.tb_walks.p, tbw.data(), tbw.size() * sizeof(TbWalk), s);
-            launch_trace_walk(g.tb_walks.p, (int)tbw.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, s);
-            launch_trace_join(g.tb_sides.p, (int)tbs.size(), g.tb_walks.p, g.tb_segs.p, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p,
+            g.stage.h2d2(g.tb_blk.p, tbw.data(), tbw.size() * sizeof(TbWalk), tbs.data(), tbs.size() * sizeof(TbSide), s);
+            launch_trace_walk(d_walks, (int)tbw.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, s);
+            launch_trace_join(d_sides, (int)tbs.size(), d_walks, d_segs, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p,
                               g.ops.p, g.recs.p, s);
             std::vector<TbSeg> segs((size_t)soff + 1);
-            g.stage.d2h(tbs.data(), g.tb_sides.p, tbs.size() * sizeof(TbSide), s);
-            g.stage.d2h(segs.data(), g.tb_segs.p, (size_t)soff * sizeof(TbSeg), s);
+            g.stage.d2h2(tbs.data(), tbs.size() * sizeof(TbSide), segs.data(), (size_t)soff * sizeof(TbSeg), d_sides, s);
             MB_HIP(hipStreamSynchronize(s));
             g.stage.done();
             // only the run slots actually used travel: the segments are packed on the device in walk order, then one copy
@@ -2605,10 +2659,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
             }
             coff[tbs.size()] = ctot;
-            g.tb_segs.ensure(flat.size() + 1); g.coff.ensure(dst.size() + 1); g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
-            g.stage.h2d(g.tb_segs.p, flat.data(), flat.size() * sizeof(TbSeg), s);
-            g.stage.h2d(g.coff.p, dst.data(), dst.size() * sizeof(unsigned long long), s);
-            launch_pack_segs(g.tb_segs.p, g.coff.p, (int)flat.size(), g.ops.p, g.ops_packed.p, s);
+            const size_t at_dst = Stager::behind(flat.size() * sizeof(TbSeg));
+            g.tb_blk.ensure(at_dst + (dst.size() + 1) * sizeof(unsigned long long) + 256);
+            g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
+            g.stage.h2d2(g.tb_blk.p, flat.data(), flat.size() * sizeof(TbSeg), dst.data(), dst.size() * sizeof(unsigned long long), s);
+            launch_pack_segs((const TbSeg *)g.tb_blk.p, (const unsigned long long *)(g.tb_blk.p + at_dst), (int)flat.size(), g.ops.p, g.ops_packed.p, s);
             if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
             MB_HIP(hipStreamSynchronize(s));
             g.stage.done();

@@ -187,3 +187,40 @@ def test_calls_in_flight_never_exceed_the_aligners_width():
     assert len({opts(c.distance) for c in calls if c.level == 0}) == 3
     bp.run_blast_phase(fasta, calls, opts, align_batch)
     assert state["peak"] == 2
+
+
+def test_jobs_nothing_waits_for_run_beside_the_chains(olz):
+    """An aligner that takes three calls at a time: the ingroup pairs (only the final files take their output) are handed over as
+    jobs of their own and level 1 starts before they are back; the phase's files equal those of the one-call-at-a-time run."""
+    import threading
+    from cactus_amd import miblast
+    from cactus_amd.paf.local_alignment import select_lastz_params
+    from cactus_amd.shared.configWrapper import load_config
+    cfg = load_config()
+    calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE))
+    genomes = gen.make_tree_genomes(6_000, 2002, ancestors=True)
+    fasta = {k: gen.fasta_bytes([("id=%s|%s" % (k, k), v)]) for k, v in genomes.items()}
+    ingroup_only = threading.Event()            # set when a call made of ingroup pairs alone has returned
+    log, lock = [], threading.Lock()
+    by_pair = {(fasta[c.target], fasta[c.query]): c for c in calls if c.level == 0}
+
+    def align_batch(pairs, opts):
+        kinds = {by_pair[(t, q)].kind if (t, q) in by_pair else "later" for t, q in pairs}
+        if kinds == {"ingroup"} and len(pairs) > 1:
+            assert ingroup_only.wait(60)                                  # held until a level-1 call has been seen
+        if "later" in kinds:
+            ingroup_only.set()
+        with lock:
+            log.append(sorted(kinds))
+        pm = miblast.params_from_args(opts.split())
+        po = olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_})
+        return [olz.align(t, q, po, details=False)["paf"] for t, q in pairs]
+
+    choose = lambda d: select_lastz_params(d, cfg, 0)      # noqa: E731
+    plain = bp.run_blast_phase(fasta, calls, choose, align_batch)
+    assert ["ingroup", "outgroup"] in log                                 # width 1: a level is one call per option set
+    del log[:]
+    ingroup_only.clear()
+    align_batch.concurrent = 3
+    wide = bp.run_blast_phase(fasta, calls, choose, align_batch)
+    assert ["ingroup"] in log and ["ingroup", "outgroup"] not in log and wide == plain
