@@ -315,14 +315,18 @@ def timed_steps(work, steps, warmup, sync, gather):
     thr0, cpu0 = cpu_throttle_state(), time.process_time()
     t0 = time.perf_counter()
     tot, keep = {}, None
+    marks = [t0]
     for k in range(steps):
         keep = [] if k == steps - 1 else None          # the calls of the last timed step are kept for the byte diff with the oracle
         agg, paf = work.step(keep)
         gather(paf)
         for key, v in agg.items():
             tot[key] = tot.get(key, 0) + v
+        marks.append(time.perf_counter())              # (a step ends with its PAF on the host: the spread of the steps, for the record)
     sync()
     elapsed = time.perf_counter() - t0
+    each = sorted((b - a) * 1e3 for a, b in zip(marks, marks[1:]))
+    timed_steps.last_spread = {"min": each[0], "median": each[len(each) // 2], "max": each[-1]} if each else {}      # (of this rank)
     thr1 = cpu_throttle_state()
     tot["host_cpu_seconds"] = time.process_time() - cpu0
     tot["host_throttled_periods"] = thr1[0] - thr0[0]
@@ -410,6 +414,7 @@ def run_rank(a):
             dist.barrier()
 
     elapsed, tot, keep = timed_steps(work, a.steps, a.warmup, sync, gather)
+    step_spread = dict(timed_steps.last_spread, note="wall time of the single steps of the timed region on rank 0 (ms_per_step is their mean over all ranks' barrier-to-barrier time)")
     keys = sorted(tot)
     vec = torch.tensor([float(tot[k]) for k in keys] + [elapsed], dtype=torch.float64, device=coll_dev)
     if dist is not None:
@@ -426,7 +431,7 @@ def run_rank(a):
             "value": tot["dp_cells"] / elapsed / 1e9,
             "unit": "Gcell/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps,
+            "ms_per_step": 1e3 * elapsed / a.steps, "step_ms_spread": step_spread,
             "higher_is_better": True, "scaling": "strong" if a.workload == "chr20" else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": work.describe,

@@ -143,7 +143,11 @@ struct UxScratch {                            // device scratch of one launch_un
     unsigned dirty_cap;
     const int32_t *extent;                    // extent[] of the launch, read by the first hit of a run when
     int extent_live;                          // ... an earlier q batch may have left extents (0: extent[] is all zero)
+    // what a launch zeroes first: the two bit planes lie one behind the other from long_bits on, the counters (n_entries, blk_cnt) from
+    // n_entries on; byte counts in multiples of 16 (a fill of any other size is two launches)
+    unsigned long long zero_bits_bytes, zero_cnt_bytes;
 };
+inline size_t up16(size_t bytes) { return (bytes + 15) & ~(size_t)15; }
 
 // ---- host-side sequence set --------------------------------------------------------------------
 struct SeqSet {

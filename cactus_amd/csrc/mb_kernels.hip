@@ -427,13 +427,13 @@ void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *off
 void launch_batch_index(const BatchTarget *tg, int n_targets, int64_t slot_blocks, int64_t n_cnt, uint32_t *words, unsigned long long *bits,
                         uint32_t *dir, uint32_t *bsum, uint32_t *cnt, uint32_t *starts, unsigned long long *scan_sums, uint32_t *positions, hipStream_t s) {
     MB_HIP(hipMemsetAsync(bits, 0, (size_t)n_targets * kBxWordsPerTarget * 8, s));
-    MB_HIP(hipMemsetAsync(cnt, 0, (size_t)n_cnt * 4, s));
+    MB_HIP(hipMemsetAsync(cnt, 0, up16((size_t)n_cnt * 4), s));
     if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_words, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits);
     hipLaunchKernelGGL(k_bx_popc, dim3((unsigned)(n_targets * kBxDirBlocks)), dim3(256), 0, s, bits, bsum);
     hipLaunchKernelGGL(k_bx_dir, dim3((unsigned)(n_targets * kBxDirBlocks)), dim3(256), 0, s, bits, bsum, dir);
     if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_count, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits, dir, cnt);
     launch_scan_u32(cnt, starts, n_cnt, scan_sums, s);
-    MB_HIP(hipMemsetAsync(cnt, 0, (size_t)n_cnt * 4, s));
+    MB_HIP(hipMemsetAsync(cnt, 0, up16((size_t)n_cnt * 4), s));
     if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_scatter, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits, dir, starts, cnt, positions);
     MB_HIP(hipGetLastError());
 }
@@ -758,7 +758,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     // n_heads: five counters
     const uint64_t n = (uint64_t)n_hits;
     unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
-    MB_HIP(hipMemsetAsync(n_heads, 0, (kRunClasses + 1) * sizeof(unsigned), s));
+    MB_HIP(hipMemsetAsync(n_heads, 0, up16((kRunClasses + 1) * sizeof(unsigned)), s));      // (n_heads: 8 counters)
     hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1024 * kHeadsPerThread - 1) / (1024 * kHeadsPerThread))), dim3(1024), 0, s, keys, n_hits, kLongRun, heads,
                        n_heads);
     const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
@@ -786,10 +786,8 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
         hipLaunchKernelGGL(k_ungapped_grp<5>, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, ut,
                            extent, xdrop, K, hsps, hsp_cap, ctr);
     } else {
-        MB_HIP(hipMemsetAsync(ux->long_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
-        MB_HIP(hipMemsetAsync(ux->dirty_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
-        MB_HIP(hipMemsetAsync(ux->n_entries, 0, 2 * sizeof(unsigned), s));
-        MB_HIP(hipMemsetAsync(ux->blk_cnt, 0, 2 * (size_t)ux->n_blk * sizeof(unsigned), s));
+        MB_HIP(hipMemsetAsync(ux->long_bits, 0, (size_t)ux->zero_bits_bytes, s));
+        MB_HIP(hipMemsetAsync(ux->n_entries, 0, (size_t)ux->zero_cnt_bytes, s));
         UxScratch sc = *ux;
         sc.extent = extent; sc.extent_live = extent_clean ? 0 : 1;
         ux = &sc;
@@ -824,10 +822,8 @@ void launch_ungapped_hash16(const unsigned long long *keys, int64_t n_hits, cons
                             UngappedCounters *ctr, const UxScratch *ux, unsigned long long *ka, unsigned long long *kb, uint32_t *va, uint32_t *vb, void *temp,
                             size_t temp_bytes, int32_t *extent, hipStream_t s) {
     if (n_hits <= 0) return;
-    MB_HIP(hipMemsetAsync(ux->long_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
-    MB_HIP(hipMemsetAsync(ux->dirty_bits, 0, (size_t)((n_diagonals + 31) / 32) * 4, s));
-    MB_HIP(hipMemsetAsync(ux->n_entries, 0, 2 * sizeof(unsigned), s));
-    MB_HIP(hipMemsetAsync(ux->blk_cnt, 0, 2 * (size_t)ux->n_blk * sizeof(unsigned), s));
+    MB_HIP(hipMemsetAsync(ux->long_bits, 0, (size_t)ux->zero_bits_bytes, s));
+    MB_HIP(hipMemsetAsync(ux->n_entries, 0, (size_t)ux->zero_cnt_bytes, s));
     UxScratch sc = *ux;
     sc.extent = extent; sc.extent_live = 0;
     hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, ut, xdrop, K, sc, hsps, hsp_cap, ctr);

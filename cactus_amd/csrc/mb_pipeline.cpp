@@ -714,7 +714,7 @@ int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *co
     w.cov_spans.ensure(up.size() + 2); w.cov_first.ensure(2 * n_ed + 1);
     w.bx_scan.ensure((n_depth + 2047) / 2048 + 2);
     unsigned *d_counts = w.cov_diff.p + n_depth;                                  // (zeroed with the difference array)
-    MB_HIP(hipMemsetAsync(w.cov_diff.p, 0, (n_depth + 2 * n + 8) * 4, s));
+    MB_HIP(hipMemsetAsync(w.cov_diff.p, 0, up16((n_depth + 2 * n + 4) * 4), s));
     w.stage.h2d(w.cov_spans.p, up.data(), up.size() * sizeof(long long), s);
     launch_cov_mark(w.cov_spans.p + 5 * n, (int)(n_sp / 2), w.cov_diff.p, s);
     launch_scan_u32(w.cov_diff.p, w.cov_depth.p, (int64_t)n_depth, w.bx_scan.p, s);
@@ -980,8 +980,9 @@ static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, in
     // unfinished hits: 16 slots per block of 256 hits + a shared list of nh / 16 + 4096 (40-byte entries: 5 bytes per hit); the same
     // memory later holds the list of dirty runs (4-byte entries: room for 1.25 per hit)
     const size_t n_blk = (nh + 255) / 256, blk_slots = n_blk * 16, cap = nh / 16 + 4096;
-    w.ux_entries.ensure(blk_slots + cap); w.ux_cnt.ensure(4 + 2 * n_blk);
-    const size_t plane = (size_t)((n_diagonals + 31) / 32) + 1; w.ux_bits.ensure(2 * plane);
+    w.ux_entries.ensure(blk_slots + cap); w.ux_cnt.ensure(4 + 2 * n_blk + 4);
+    const size_t plane = ((size_t)((n_diagonals + 31) / 32) + 1 + 3) & ~(size_t)3; w.ux_bits.ensure(2 * plane);
+    sc.zero_bits_bytes = 2 * plane * 4; sc.zero_cnt_bytes = up16((4 + 2 * n_blk) * 4);
     sc.rec = rec;
     sc.blk_entries = w.ux_entries.p; sc.blk_cnt = w.ux_cnt.p + 4; sc.n_blk = (unsigned)n_blk;
     sc.entries = w.ux_entries.p + blk_slots; sc.entry_cap = (unsigned)std::min<size_t>(cap, 0x7fffffffu); sc.n_entries = w.ux_cnt.p;
@@ -1141,7 +1142,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     const bool one_pass = env_long("MIBLAST_SEED_ONE_PASS", 1) != 0;
     const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
     DevBuf<int32_t> &extent = w.extent;
-    extent.ensure((size_t)(ttot + qtot + 2));
+    extent.ensure((size_t)(ttot + qtot + 8));
     DevBuf<uint32_t> &qcnt = w.qcnt, &hit_off = w.hit_off;
     qcnt.ensure((size_t)std::max<int64_t>(1, qtot));
     int64_t n_qblk = (qtot + 2047) / 2048;
@@ -1150,7 +1151,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     DevBuf<char> &sort_temp = w.sort_temp;
     DevBuf<DevHsp> &d_hsps = w.hsps;
     DevBuf<UngappedCounters> &d_ctr = w.ctr;
-    d_ctr.ensure(1);
+    d_ctr.ensure(2);
     std::vector<unsigned long long> h_qbsum((size_t)n_qblk + 2);
     std::vector<miblast_hsp> *strand_hsps = job.strand_hsps;
     strand_hsps[0].clear(); strand_hsps[1].clear();
@@ -1197,7 +1198,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                 w.pin_hsps.ensure(2 * kBlind);
                 for (int strand = 0; strand < 2; strand++) {
                     if (!fits[strand] || !nh[strand]) continue;
-                    MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
+                    MB_HIP(hipMemsetAsync(extent.p, 0, up16((size_t)(ttot + qtot + 2) * 4), s));
                     MB_HIP(hipEventRecord(w.sev[strand][2], s));
                     sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], 0, sort_bits, s);
                     MB_HIP(hipEventRecord(w.sev[strand][3], s));
@@ -1249,7 +1250,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             continue;
         }
         const double t0 = now_s();
-        MB_HIP(hipMemsetAsync(extent.p, 0, (size_t)(ttot + qtot + 2) * 4, s));
+        MB_HIP(hipMemsetAsync(extent.p, 0, up16((size_t)(ttot + qtot + 2) * 4), s));
         std::vector<DevHsp> found;
         int rc_batch = MIBLAST_OK;
         // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
@@ -1266,7 +1267,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev1, s));
             sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, q_ordered ? 32 : 0, sort_bits, s);       // (k_seed_fill writes the keys in q order)
             MB_HIP(hipEventRecord(ctx.ev2, s));
-            MB_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(UngappedCounters), s));
+            MB_HIP(hipMemsetAsync(d_ctr.p, 0, up16(sizeof(UngappedCounters)), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
             const UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2);               // (the unsorted keys are free now)
             launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
@@ -1296,7 +1297,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         //  8 Mb pair)
         if (one_pass && cap1 > 0 && w.last_strand_hits <= cap1) {
             qbsum.ensure(2);
-            MB_HIP(hipMemsetAsync(qbsum.p, 0, 8, s));
+            MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
             MB_HIP(hipEventRecord(ctx.ev0, s));
             launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
             unsigned long long total = 0;
@@ -1516,10 +1517,10 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         const size_t pb = p.diag_hash16 ? sort_pairs_temp_bytes((int64_t)nh) : 0;
         w.sort_temp.ensure(std::max(tb, pb) + 16);
         if (p.diag_hash16) { w.h16_ka.ensure(nh); w.h16_kb.ensure(nh); w.h16_va.ensure(nh); w.h16_vb.ensure(nh); }
-        w.extent.ensure((size_t)n_diag + 2);
-        w.ctr.ensure(units.size());
-        MB_HIP(hipMemsetAsync(w.extent.p, 0, ((size_t)n_diag + 2) * 4, s));
-        MB_HIP(hipMemsetAsync(w.ctr.p, 0, units.size() * sizeof(UngappedCounters), s));
+        w.extent.ensure((size_t)n_diag + 8);
+        w.ctr.ensure(units.size() + 1);
+        MB_HIP(hipMemsetAsync(w.extent.p, 0, up16(((size_t)n_diag + 2) * 4), s));
+        MB_HIP(hipMemsetAsync(w.ctr.p, 0, up16(units.size() * sizeof(UngappedCounters)), s));
         (void)ux_scratch(w, nullptr, nh, n_diag + 2);                               // (sized before anything is queued)
         MB_HIP(hipEventRecord(w.sev[0][3], s));
         launch_batch_seed_fill(w.bx_units.p, (int)units.size(), w.bx_targets.p, w.bx_bits.p, w.bx_dir.p, w.bx_starts.p, w.bx_positions.p, p.transitions, q_slots,

@@ -10,7 +10,7 @@ for path in sys.argv[1:]:
         print(path, "unreadable:", e)
         continue
     r = d["roofline"]
-    print(f"{path}: {d['n_gpus']} GPU, {d['ms_per_step']:.2f} ms/step, {d['value']:.2f} {d['unit']}, spec {d.get('speculation_factor', 0):.2f}, "
+    print(f"{path}: {d['n_gpus']} GPU, {d['ms_per_step']:.2f} ms/step (steps {d.get('step_ms_spread', {}).get('min', 0):.1f} / {d.get('step_ms_spread', {}).get('median', 0):.1f} / {d.get('step_ms_spread', {}).get('max', 0):.1f}), {d['value']:.2f} {d['unit']}, spec {d.get('speculation_factor', 0):.2f}, "
           f"kernel {d.get('gapped_gcells_per_s_kernel', 0):.0f} Gc/s, frac {r['frac']:.5f}, valu {r.get('valu', {}).get('frac', 0):.4f}")
     print("  stage kernel ms:", {k: round(v, 2) for k, v in d.get("stage_kernel_ms_per_step", {}).items()}, "relay:", {k: round(v, 2) for k, v in d.get("relay", {}).items()})
     print("  host:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.get("host", {}).items() if k != "note"})

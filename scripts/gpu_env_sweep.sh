@@ -12,7 +12,8 @@ for setting in "$@"; do
 import json, sys
 try:
     d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-    print("%-60s %.2f ms/step  dp busy %.2f  launches %.0f  spec %.2f" % (sys.argv[1] or "(defaults)", d["ms_per_step"], d["stage_kernel_ms_per_step"]["ydrop_busy"], d["relay"]["dp_launches_per_step"], d["speculation_factor"]))
+    sp = d.get("step_ms_spread", {})
+    print("%-60s %.2f ms/step (min %.1f median %.1f)  dp busy %.2f  launches %.0f  spec %.2f" % (sys.argv[1] or "(defaults)", d["ms_per_step"], sp.get("min", 0), sp.get("median", 0), d["stage_kernel_ms_per_step"]["ydrop_busy"], d["relay"]["dp_launches_per_step"], d["speculation_factor"]))
 except Exception as e:
     print(sys.argv[1], "failed:", e)
 PY
