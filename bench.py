@@ -137,10 +137,15 @@ class EvolverPhase:
         # the option sets of a dependency level are independent jobs too (1 x "four" beside 9 x "default" at level 0), and so are the
         # ingroup pairs nothing waits for beside the chains of outgroup calls: each job in flight gets its own context (stream +
         # workspace) on this GPU and they run concurrently, as Toil runs independent jobs of a node.
-        self.contexts = [ctx] + [miblast.Context(ctx.device) for _ in range(max(0, int(os.environ.get("MIBLAST_BENCH_CONTEXTS", "3")) - 1))]
+        self.contexts = [ctx] + [miblast.Context(ctx.device) for _ in range(max(0, int(os.environ.get("MIBLAST_BENCH_CONTEXTS", "4")) - 1))]
         self.free_contexts = queue.Queue()                     # align_batch blocks on it: never more calls in flight than contexts
-        for cx in self.contexts:
-            self.free_contexts.put(cx)
+        self.background_contexts = queue.Queue()               # ... those of the jobs nothing waits for: their launches yield to the chains'
+        n_bg = min(len(self.contexts) - 1, int(os.environ.get("MIBLAST_BENCH_BACKGROUND", "2"))) if len(self.contexts) > 2 else 0
+        for k, cx in enumerate(self.contexts):
+            if k >= len(self.contexts) - n_bg:
+                self.background_contexts.put(cx.set_priority(-1))
+            else:
+                self.free_contexts.put(cx)
         sets = sorted({self.options(c.distance).split()[0] + " ..." for c in self.calls})
         if which == "mammals":
             self.describe = (f"evolverMammals blast phase stand-in (BASELINE configs[2], SURVEY 8d config 3): {len(self.calls)} lastz calls over the guide tree of "
@@ -157,8 +162,9 @@ class EvolverPhase:
 
         lock = threading.Lock()
 
-        def align_batch(pairs, opts):
-            cx = self.free_contexts.get()
+        def align_batch(pairs, opts, pool=None):
+            pool = pool or self.free_contexts
+            cx = pool.get()
             try:
                 with lock:
                     pm = self.params.get(opts)
@@ -178,7 +184,7 @@ class EvolverPhase:
                 t0 = time.perf_counter()
                 rs = cx.align_pairs(sets, pm)
             finally:
-                self.free_contexts.put(cx)
+                pool.put(cx)
             with lock:
                 add_stats(agg, [r.stats for r in rs])
             if TIMELINE:
@@ -202,6 +208,8 @@ class EvolverPhase:
 
         if os.environ.get("MIBLAST_BENCH_TEXT_TRIM", "0") == "0":
             align_batch.trim_resident = trim_resident
+        if not self.background_contexts.empty():
+            align_batch.background = lambda pairs, opts: align_batch(pairs, opts, self.background_contexts)
         align_batch.concurrent = len(self.contexts)
         align_batch.split_above = int(os.environ.get("MIBLAST_BENCH_SPLIT", "0")) if len(self.contexts) > 1 else 0
         res = self.bp.run_blast_phase(self.fasta, self.calls, self.options, align_batch, *self.trim,
@@ -326,6 +334,8 @@ def timed_steps(work, steps, warmup, sync, gather):
     sync()
     elapsed = time.perf_counter() - t0
     each = sorted((b - a) * 1e3 for a, b in zip(marks, marks[1:]))
+    if os.environ.get("MIBLAST_BENCH_STEP_TIMES"):
+        print("[bench] step times (ms): " + " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(marks, marks[1:])), file=sys.stderr)
     timed_steps.last_spread = {"min": each[0], "median": each[len(each) // 2], "max": each[-1]} if each else {}      # (of this rank)
     thr1 = cpu_throttle_state()
     tot["host_cpu_seconds"] = time.process_time() - cpu0

@@ -288,9 +288,11 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     gate = threading.BoundedSemaphore(max(1, int(getattr(align_batch, "concurrent", 1))))
     free_jobs = []                                    # (option set, calls, future): jobs nothing waits for, collected at the end
 
-    def gated(pairs, opts):
+    def gated(pairs, opts, free=False):
         with gate:
-            return align_batch(pairs, opts)
+            # (an aligner may serve the jobs nothing waits for differently -- align_batch.background: on contexts whose launches
+            #  yield to those of the chains)
+            return (getattr(align_batch, "background", None) or align_batch)(pairs, opts) if free else align_batch(pairs, opts)
 
     def take(opts, idx, outs):
         for i, paf in zip(idx, outs):
@@ -348,10 +350,10 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
                 free_idx = [i for i in idx if calls[i].chain is None]
                 rest = [i for i in idx if calls[i].chain is not None]
                 if free_idx and rest:
-                    free_jobs.append((opts, free_idx, pool.submit(gated, [(genomes[calls[i].target], query_fa[i]) for i in free_idx], opts)))
+                    free_jobs.append((opts, free_idx, pool.submit(gated, [(genomes[calls[i].target], query_fa[i]) for i in free_idx], opts, True)))
                     held.append((opts, rest))
                 elif free_idx and any(calls[i].chain is not None for _, ix in groups for i in ix):
-                    free_jobs.append((opts, free_idx, pool.submit(gated, [(genomes[calls[i].target], query_fa[i]) for i in free_idx], opts)))
+                    free_jobs.append((opts, free_idx, pool.submit(gated, [(genomes[calls[i].target], query_fa[i]) for i in free_idx], opts, True)))
                 else:
                     held.append((opts, idx))
             groups = held

@@ -209,6 +209,11 @@ int miblast_ctx_create(int device, miblast_ctx **out) {
     });
 }
 
+int miblast_ctx_set_priority(miblast_ctx *ctx, int level) {
+    if (!ctx) return MIBLAST_EINVAL;
+    return guarded([&]() -> int { return mb::ctx_set_priority(ctx->c, level); });
+}
+
 void miblast_ctx_destroy(miblast_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->c.device);

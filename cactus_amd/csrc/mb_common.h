@@ -100,8 +100,11 @@ struct TbWalk {
     uint64_t ops_off;                         // run buffer of the walk
     uint64_t rec_off;                         // one record (3 x u32: column, runs written, pending length << 2 | state) per entered row
     int32_t n_runs, ei, ej, estate;           // out: runs written; cell and state on reaching the floor
-    int32_t pad[2];
+    int32_t pad[2];                           // the piece's share of the side's join buffer: first run slot (64 bit; all ones: head of its side)
 };
+// k_trace_prejoin's join walk of a piece: made from the PREDICTED entry (pi, pj, pstate); n_runs runs (-1: none made), then either the
+// guessed walk's runs from its run nr on (the first shortened by sub) if the two met, or the cell and state it reached the floor with
+struct TbJoin { int32_t pi, pj, pstate, n_runs, joined, ei, ej, estate, nr, sub; };
 struct TbSeg { uint64_t src; int32_t n_runs, first_sub; };       // n_runs runs from ops[src], the first one shortened by first_sub
 struct TbSide {
     int32_t first_walk, n_walks;              // walkers from the best cell's piece back to the head
@@ -217,8 +220,10 @@ void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtr
                    uint8_t *snaps, const int *order, hipStream_t s);      // order: piece of block b (k_ydrop2 only), or nullptr
 void launch_trace_walk(TbWalk *walks, int n, const uint8_t *arena, unsigned long long arena_bytes,
                        const unsigned long long *rowdir, uint32_t *ops, uint32_t *recs, hipStream_t s);
+void launch_trace_prejoin(const TbWalk *walks, int n, TbJoin *joins, const uint8_t *arena, unsigned long long arena_bytes,
+                          const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, int poison, hipStream_t s);
 void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, const uint8_t *arena, unsigned long long arena_bytes,
-                       const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, hipStream_t s);
+                       const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, const TbJoin *joins, hipStream_t s);
 void launch_pack_segs(const TbSeg *segs, const unsigned long long *dst, int n, const uint32_t *ops, uint32_t *packed, hipStream_t s);
 void launch_verify(const VerifyJob *jobs, VerifyOut *res, int n, const uint8_t *snaps, int Y, int E, hipStream_t s);
 // ---- batched seed stage (mb_seed_batch.h) ----

@@ -2096,11 +2096,49 @@ __global__ __launch_bounds__(64) void k_trace_walk(TbWalk *__restrict__ walks, i
     if (lane == 0) { walks[slot].n_runs = ro.n_runs; walks[slot].ei = i; walks[slot].ej = j; walks[slot].estate = state; }
 }
 
-// one wave per side: stitches the walks of the side's pieces (see TbWalk)
+// One wave per piece that is not the head of its side: the join walk of the piece, made BEFORE the side is stitched, from the cell the
+// true path enters it through if the walk of the piece before it ends where the true path does -- which it does whenever that walk and
+// the true path have met inside the piece, i.e. nearly always.  k_trace_join then only compares: a prediction that turns out wrong
+// (the cell it reaches the piece with is another one) makes it walk itself, as it would without this kernel.  What is saved is the
+// chain of dependent memory round trips of a side's join walks, one after the other in one wave.
+// TbWalk::pad holds the piece's share of the side's join buffer (first run slot, 64 bit; all ones: head of a side, no join walk).
+__global__ __launch_bounds__(64) void k_trace_prejoin(const TbWalk *__restrict__ walks, int n, TbJoin *__restrict__ joins,
+                                                      const uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
+                                                      const unsigned long long *__restrict__ rowdir, uint32_t *__restrict__ ops,
+                                                      const uint32_t *__restrict__ recs, const int poison) {
+    const int slot = blockIdx.x;
+    if (slot >= n) return;
+    const int lane = threadIdx.x & 63;
+    const TbWalk W = walks[slot];
+    unsigned long long jo;
+    __builtin_memcpy(&jo, W.pad, 8);
+    TbJoin J;
+    J.pi = (int32_t)0x80000000; J.pj = 0; J.pstate = 0; J.n_runs = -1; J.joined = 0; J.ei = J.ej = J.estate = 0; J.nr = J.sub = 0;
+    if (jo != ~0ull) {
+        const TbWalk Wp = walks[slot - 1];
+        int i = uni(Wp.ei + Wp.dr), j = uni(Wp.ej + Wp.dc), state = uni(Wp.estate);
+        if (poison && (slot & 1)) j = uni(j + 1);                         // (tests: a wrong prediction must cost nothing but time)
+        J.pi = i; J.pj = j; J.pstate = state;
+        if (!(i == W.si && j == W.sj && state == 0)) {
+            RunOut ro{ops + jo, 0, -1, 0};
+            const bool joined = walk_piece<1>(W, i, j, state, ro, const_cast<uint32_t *>(recs) + W.rec_off, arena, arena_bytes, rowdir);
+            ro.emit(-2, 0, lane);
+            J.n_runs = ro.n_runs; J.joined = joined ? 1 : 0; J.ei = i; J.ej = j; J.estate = state;
+            if (joined) {
+                const uint32_t *q = recs + W.rec_off + 3ull * (unsigned)(W.si - i);
+                J.nr = (int32_t)q[1]; J.sub = (int32_t)(q[2] >> 2);
+            }
+        }
+    }
+    if (lane == 0) joins[slot] = J;
+}
+
+// one wave per side: stitches the walks of the side's pieces (see TbWalk); joins: k_trace_prejoin's walks (nullptr: none were made)
 __global__ __launch_bounds__(64) void k_trace_join(TbSide *__restrict__ sides, int n, const TbWalk *__restrict__ walks,
                                                    TbSeg *__restrict__ segs, const uint8_t *__restrict__ arena,
                                                    const unsigned long long arena_bytes, const unsigned long long *__restrict__ rowdir,
-                                                   uint32_t *__restrict__ ops, const uint32_t *__restrict__ recs) {
+                                                   uint32_t *__restrict__ ops, const uint32_t *__restrict__ recs,
+                                                   const TbJoin *__restrict__ joins) {
     const int slot = blockIdx.x;
     if (slot >= n) return;
     const TbSide sd = sides[slot];
@@ -2115,31 +2153,44 @@ __global__ __launch_bounds__(64) void k_trace_join(TbSide *__restrict__ sides, i
     const TbWalk W0 = walks[sd.first_walk];
     push_seg(W0.ops_off, W0.n_runs, 0);
     int i = uni(W0.ei + W0.dr), j = uni(W0.ej + W0.dc), state = uni(W0.estate);
-    unsigned long long jp = sd.jops_off;                          // next free slot of the join walk's own runs
-    // The guessed start of a piece is usually the cell the true path enters it through: then the whole guessed walk is spliced
-    // and nothing has to be read but the walker's record.  The records of 64 walkers are fetched at once (one per lane), so
-    // that chain of hand-overs costs no memory latency.
+    // The guessed start of a piece is sometimes the cell the true path enters it through: then the whole guessed walk is spliced.
+    // Otherwise the join walk k_trace_prejoin made from its predicted entry is spliced if the prediction holds.  Either way nothing
+    // has to be read but the records of the walker: those of 64 walkers are fetched at once (one per lane), so the chain of
+    // hand-overs costs no memory latency.
     for (int k0 = 1; k0 < sd.n_walks; k0 += 64) {
         const int kk = k0 + lane;
         TbWalk Wl;
-        if (kk < sd.n_walks) Wl = walks[sd.first_walk + kk];
-        else { Wl.si = -1; Wl.sj = -1; Wl.dr = Wl.dc = 0; Wl.ops_off = 0; Wl.n_runs = 0; Wl.ei = Wl.ej = Wl.estate = 0; }
+        TbJoin Jl;
+        Jl.pi = (int32_t)0x80000000; Jl.pj = 0; Jl.pstate = 0; Jl.n_runs = -1; Jl.joined = 0; Jl.ei = Jl.ej = Jl.estate = 0; Jl.nr = Jl.sub = 0;
+        if (kk < sd.n_walks) { Wl = walks[sd.first_walk + kk]; if (joins) Jl = joins[sd.first_walk + kk]; }
+        else { Wl.si = -1; Wl.sj = -1; Wl.dr = Wl.dc = 0; Wl.ops_off = 0; Wl.n_runs = 0; Wl.ei = Wl.ej = Wl.estate = 0; Wl.pad[0] = Wl.pad[1] = 0; }
         const int cnt = min(64, sd.n_walks - k0);
         for (int t = 0; t < cnt; t++) {
             const int si = __builtin_amdgcn_readlane(Wl.si, t), sj = __builtin_amdgcn_readlane(Wl.sj, t);
             const int wdr = __builtin_amdgcn_readlane(Wl.dr, t), wdc = __builtin_amdgcn_readlane(Wl.dc, t);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)Wl.ops_off, t);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(Wl.ops_off >> 32), t);
+            const unsigned long long w_ops = ((unsigned long long)hi << 32) | lo;
+            const unsigned long long jo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(Wl.pad[1], t) << 32) | (unsigned)__builtin_amdgcn_readlane(Wl.pad[0], t);
             if (i == si && j == sj && state == 0) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)Wl.ops_off, t);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(Wl.ops_off >> 32), t);
-                push_seg(((unsigned long long)hi << 32) | lo, __builtin_amdgcn_readlane(Wl.n_runs, t), 0);
+                push_seg(w_ops, __builtin_amdgcn_readlane(Wl.n_runs, t), 0);
                 i = __builtin_amdgcn_readlane(Wl.ei, t); j = __builtin_amdgcn_readlane(Wl.ej, t); state = __builtin_amdgcn_readlane(Wl.estate, t);
+            } else if (__builtin_amdgcn_readlane(Jl.n_runs, t) >= 0 && i == __builtin_amdgcn_readlane(Jl.pi, t) && j == __builtin_amdgcn_readlane(Jl.pj, t) &&
+                       state == __builtin_amdgcn_readlane(Jl.pstate, t)) {
+                push_seg(jo, __builtin_amdgcn_readlane(Jl.n_runs, t), 0);
+                if (__builtin_amdgcn_readlane(Jl.joined, t)) {
+                    const int nr = __builtin_amdgcn_readlane(Jl.nr, t);
+                    push_seg(w_ops + (unsigned)nr, __builtin_amdgcn_readlane(Wl.n_runs, t) - nr, __builtin_amdgcn_readlane(Jl.sub, t));
+                    i = __builtin_amdgcn_readlane(Wl.ei, t); j = __builtin_amdgcn_readlane(Wl.ej, t); state = __builtin_amdgcn_readlane(Wl.estate, t);
+                } else {
+                    i = __builtin_amdgcn_readlane(Jl.ei, t); j = __builtin_amdgcn_readlane(Jl.ej, t); state = __builtin_amdgcn_readlane(Jl.estate, t);
+                }
             } else {
                 const TbWalk W = walks[sd.first_walk + k0 + t];
-                RunOut ro{ops + jp, 0, -1, 0};
+                RunOut ro{ops + jo, 0, -1, 0};
                 const bool joined = walk_piece<1>(W, i, j, state, ro, const_cast<uint32_t *>(recs) + W.rec_off, arena, arena_bytes, rowdir);
                 ro.emit(-2, 0, lane);
-                push_seg(jp, ro.n_runs, 0);
-                jp += (unsigned)ro.n_runs;
+                push_seg(jo, ro.n_runs, 0);
                 if (joined) {
                     const uint32_t *q = recs + W.rec_off + 3ull * (unsigned)(W.si - i);
                     const int nr = (int)q[1], sub = (int)(q[2] >> 2);
@@ -2158,10 +2209,15 @@ void launch_trace_walk(TbWalk *walks, int n, const uint8_t *arena, unsigned long
     if (n <= 0) return;
     hipLaunchKernelGGL(k_trace_walk, dim3((unsigned)n), dim3(64), 0, s, walks, n, arena, arena_bytes, rowdir, ops, recs);
 }
-void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, const uint8_t *arena, unsigned long long arena_bytes,
-                       const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, hipStream_t s) {
+void launch_trace_prejoin(const TbWalk *walks, int n, TbJoin *joins, const uint8_t *arena, unsigned long long arena_bytes,
+                          const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, int poison, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_trace_join, dim3((unsigned)n), dim3(64), 0, s, sides, n, walks, segs, arena, arena_bytes, rowdir, ops, recs);
+    hipLaunchKernelGGL(k_trace_prejoin, dim3((unsigned)n), dim3(64), 0, s, walks, n, joins, arena, arena_bytes, rowdir, ops, recs, poison);
+}
+void launch_trace_join(TbSide *sides, int n, const TbWalk *walks, TbSeg *segs, const uint8_t *arena, unsigned long long arena_bytes,
+                       const unsigned long long *rowdir, uint32_t *ops, const uint32_t *recs, const TbJoin *joins, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_trace_join, dim3((unsigned)n), dim3(64), 0, s, sides, n, walks, segs, arena, arena_bytes, rowdir, ops, recs, joins);
 }
 
 // relay hand-over check: the upstream piece's state after its exit row against the relay's state after the same row.

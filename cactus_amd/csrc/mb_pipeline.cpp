@@ -606,27 +606,50 @@ struct Workspace {                      // device buffers that persist across mi
 
 Workspace *workspace_create() { return new Workspace(); }
 
-static Ctx *lane_create(int device) {
+static Ctx *lane_create(int device, int priority) {
     Ctx *c = new Ctx();
     c->device = device;
+    c->priority = priority;
     c->ws = workspace_create();
-    MB_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MB_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority));
     MB_HIP(hipEventCreate(&c->ev0)); MB_HIP(hipEventCreate(&c->ev1)); MB_HIP(hipEventCreate(&c->ev2));
     MB_HIP(hipEventCreate(&c->ev3)); MB_HIP(hipEventCreate(&c->ev4));
     return c;
 }
 
-void workspace_destroy(Workspace *w) {
-    if (!w) return;
-    for (auto &row : w->sev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
-    if (w->ev_base) (void)hipEventDestroy(w->ev_base);
+static void lanes_destroy(Workspace *w) {
     for (Ctx *c : w->lanes) {
         for (hipEvent_t e : {c->ev0, c->ev1, c->ev2, c->ev3, c->ev4}) if (e) (void)hipEventDestroy(e);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         workspace_destroy(c->ws);
         delete c;
     }
+    w->lanes.clear();
+}
+
+void workspace_destroy(Workspace *w) {
+    if (!w) return;
+    for (auto &row : w->sev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+    if (w->ev_base) (void)hipEventDestroy(w->ev_base);
+    lanes_destroy(w);
     delete w;
+}
+
+// The context's launches yield to (level < 0) or go before (level > 0) those of other contexts on the device: its stream, and the
+// streams of the lanes its batched calls open, are made anew at the lowest / highest priority the device offers (0: the default).
+int ctx_set_priority(Ctx &ctx, int level) {
+    MB_HIP(hipSetDevice(ctx.device));
+    int least = 0, greatest = 0;
+    MB_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int priority = level < 0 ? least : level > 0 ? greatest : 0;
+    MB_HIP(hipStreamSynchronize(ctx.stream));
+    lanes_destroy(ctx.ws);
+    hipStream_t fresh = nullptr;
+    MB_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, priority));
+    (void)hipStreamDestroy(ctx.stream);
+    ctx.stream = fresh;
+    ctx.priority = priority;
+    return MIBLAST_OK;
 }
 
 // ---- outgroup trimming between two blast calls, on the device --------------------------------------------------
@@ -2625,6 +2648,10 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     }
                     ts.n_walks = (int32_t)tbw.size() - ts.first_walk;
                     ts.jops_off = ooff; ooff += side_slots;                  // the join walk can at worst repeat every walk
+                    for (size_t x = (size_t)ts.first_walk; x < tbw.size(); x++) {          // ... each piece's in its own share
+                        const unsigned long long jo = x == (size_t)ts.first_walk ? ~0ull : ts.jops_off + (tbw[x].ops_off - tbw[(size_t)ts.first_walk].ops_off);
+                        memcpy(tbw[x].pad, &jo, 8);
+                    }
                     ts.seg_off = soff; soff += 2 * (uint64_t)ts.n_walks + 1;
                     tbs.push_back(ts);
                 }
@@ -2634,15 +2661,21 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (!acc.empty()) {
             // walks, sides and segments lie one behind the other: walks + sides go up in one copy, sides + segments come back in one
             const size_t at_sides = Stager::behind(tbw.size() * sizeof(TbWalk)), at_segs = at_sides + Stager::behind(tbs.size() * sizeof(TbSide));
-            g.tb_blk.ensure(at_segs + ((size_t)soff + 1) * sizeof(TbSeg) + 256);
+            const size_t at_joins = at_segs + Stager::behind(((size_t)soff + 1) * sizeof(TbSeg));
+            g.tb_blk.ensure(at_joins + tbw.size() * sizeof(TbJoin) + 256);
             TbWalk *const d_walks = (TbWalk *)g.tb_blk.p;
             TbSide *const d_sides = (TbSide *)(g.tb_blk.p + at_sides);
             TbSeg *const d_segs = (TbSeg *)(g.tb_blk.p + at_segs);
+            TbJoin *const d_joins = (TbJoin *)(g.tb_blk.p + at_joins);
             g.ops.ensure((size_t)ooff + 64); g.recs.ensure((size_t)roff + 64);
             g.stage.h2d2(g.tb_blk.p, tbw.data(), tbw.size() * sizeof(TbWalk), tbs.data(), tbs.size() * sizeof(TbSide), s);
             launch_trace_walk(d_walks, (int)tbw.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, s);
+            // the join walks of all pieces at once, from predicted entries (MIBLAST_TRACE_PREJOIN=0: none, the sides walk themselves;
+            // 2: every other prediction is made wrong on purpose -- both for the tests)
+            const long prejoin = env_long("MIBLAST_TRACE_PREJOIN", 1);
+            if (prejoin) launch_trace_prejoin(d_walks, (int)tbw.size(), d_joins, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, prejoin == 2, s);
             launch_trace_join(d_sides, (int)tbs.size(), d_walks, d_segs, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p,
-                              g.ops.p, g.recs.p, s);
+                              g.ops.p, g.recs.p, prejoin ? d_joins : nullptr, s);
             std::vector<TbSeg> segs((size_t)soff + 1);
             g.stage.d2h2(tbs.data(), tbs.size() * sizeof(TbSide), segs.data(), (size_t)soff * sizeof(TbSeg), d_sides, s);
             MB_HIP(hipStreamSynchronize(s));
@@ -2834,8 +2867,17 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
 
 }
 
-// PAF (or the general HSP format) of one pair, in the reference's output order
-static void output_phase(const miblast_params &p, PairJob &job, int pair, std::vector<Unit> &units) {
+// PAF (or the general HSP format) of a call's pairs, in the reference's output order.  Three passes over the pairs, so that the
+// cigar text of ALL pairs' alignments is formatted in one parallel region (a pair's own region would run inline inside the pairs'):
+// collect (alignments and ops in output order, the list of text chunks), format the chunks, lay the lines out.
+struct CigarTask { size_t aln; int64_t k0, k1; std::string text; int64_t nmatch, alen; size_t at; };
+struct OutputJob {
+    std::vector<CigarTask> ctasks;
+    std::vector<size_t> cfirst;
+    double t_out0 = 0;
+};
+
+static void output_collect(PairJob &job, int pair, std::vector<Unit> &units, OutputJob &oj) {
     const SeqSet &T = *job.T, &Q = *job.Q;
     Result &res = *job.res;
     miblast_stats &st = res.stats;
@@ -2853,12 +2895,46 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
                 }
             }
     st.alignments = (int64_t)res.alns.size();
-    const double t_out0 = now_s();
+    oj.t_out0 = now_s();
     {
         size_t reserve = 0;
         for (const miblast_aln &A : res.alns) reserve += 256 + Q.names[(size_t)A.q_contig].size() + T.names[(size_t)A.t_contig].size() + (size_t)A.n_ops * 9;
         res.paf.reserve(reserve);
     }
+    // the cigar text of long alignments is formatted in chunks on several threads
+    std::vector<CigarTask> &ctasks = oj.ctasks;
+    std::vector<size_t> &cfirst = oj.cfirst;
+    ctasks.clear();
+    cfirst.assign(res.alns.size() + 1, 0);
+    const int64_t kOpsPerTask = 4096;
+    for (size_t x = 0; x < res.alns.size(); x++) {
+        cfirst[x] = ctasks.size();
+        for (int64_t k0 = 0; k0 < res.alns[x].n_ops; k0 += kOpsPerTask) ctasks.push_back(CigarTask{x, k0, std::min(res.alns[x].n_ops, k0 + kOpsPerTask), {}, 0, 0, 0});
+    }
+    cfirst[res.alns.size()] = ctasks.size();
+}
+
+static void output_cigar_chunk(const Result &res, CigarTask &t) {
+    const miblast_aln &A = res.alns[t.aln];
+    t.text.reserve((size_t)(t.k1 - t.k0) * 5);
+    for (int64_t k = t.k0; k < t.k1; k++) {
+        const uint32_t o = res.ops[(size_t)(A.ops_off + k)];
+        t.alen += o >> 2;
+        if ((o & 3u) == 0) t.nmatch += o >> 2;
+        char buf[12]; int n = 0;
+        uint32_t u = o >> 2;
+        do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        while (n) t.text.push_back(buf[--n]);
+        t.text.push_back("=XID"[o & 3u]);
+    }
+}
+
+static void output_layout(const miblast_params &p, PairJob &job, OutputJob &oj) {
+    const SeqSet &T = *job.T, &Q = *job.Q;
+    Result &res = *job.res;
+    miblast_stats &st = res.stats;
+    std::vector<CigarTask> &ctasks = oj.ctasks;
+    const std::vector<size_t> &cfirst = oj.cfirst;
     auto put_num = [&](long long v) {                   // decimal formatting without snprintf (hundreds of thousands of cigar ops)
         char buf[24]; int n = 0;
         unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
@@ -2866,32 +2942,7 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         if (v < 0) buf[n++] = '-';
         while (n) res.paf.push_back(buf[--n]);
     };
-    // the cigar text of long alignments is formatted in chunks on several threads
-    struct CigarTask { size_t aln; int64_t k0, k1; std::string text; int64_t nmatch, alen; size_t at; };
-    std::vector<CigarTask> ctasks;
-    std::vector<size_t> cfirst(res.alns.size() + 1, 0);
-    const int64_t kOpsPerTask = 16384;
-    for (size_t x = 0; x < res.alns.size(); x++) {
-        cfirst[x] = ctasks.size();
-        for (int64_t k0 = 0; k0 < res.alns[x].n_ops; k0 += kOpsPerTask) ctasks.push_back(CigarTask{x, k0, std::min(res.alns[x].n_ops, k0 + kOpsPerTask), {}, 0, 0, 0});
-    }
-    cfirst[res.alns.size()] = ctasks.size();
-    parallel_for(ctasks.size(), [&](size_t ti) {
-        CigarTask &t = ctasks[ti];
-        const miblast_aln &A = res.alns[t.aln];
-        t.text.reserve((size_t)(t.k1 - t.k0) * 5);
-        for (int64_t k = t.k0; k < t.k1; k++) {
-            const uint32_t o = res.ops[(size_t)(A.ops_off + k)];
-            t.alen += o >> 2;
-            if ((o & 3u) == 0) t.nmatch += o >> 2;
-            char buf[12]; int n = 0;
-            uint32_t u = o >> 2;
-            do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-            while (n) t.text.push_back(buf[--n]);
-            t.text.push_back("=XID"[o & 3u]);
-        }
-    });
-    // line heads first (short), then every piece of text is copied to its place on the worker threads
+    // line heads first (short), then every piece of text is copied to its place
     std::vector<std::string> heads(res.alns.size());
     size_t total = res.paf.size();
     const size_t paf0 = total;
@@ -2930,7 +2981,7 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         }
         res.line_off.push_back(at);
     }
-    parallel_for(ctasks.size(), [&](size_t ti) { if (!ctasks[ti].text.empty()) memcpy(&res.paf[ctasks[ti].at], ctasks[ti].text.data(), ctasks[ti].text.size()); });
+    for (const CigarTask &t : ctasks) if (!t.text.empty()) memcpy(&res.paf[t.at], t.text.data(), t.text.size());
     if (p.format == 1) {
         // --format=general:name1,zstart1,end1,name2,zstart2+,end2+ (cactus_lastzRepeatMask.py:104): one line per HSP
         res.paf += "#name1\tzstart1\tend1\tname2\tzstart2+\tend2+\n";
@@ -2955,7 +3006,7 @@ static void output_phase(const miblast_params &p, PairJob &job, int pair, std::v
         }
     }
     if (p.markend) res.paf += "# lastz end-of-file\n";
-    if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast] PAF formatting: %.2f ms; index %.2f ms, seed %.2f ms, gapped %.2f ms\n", (now_s() - t_out0) * 1e3, st.t_index * 1e3, st.t_seed * 1e3, st.t_gapped * 1e3);
+    if (env_long("MIBLAST_DEBUG", 0)) fprintf(stderr, "[miblast] PAF formatting: %.2f ms; index %.2f ms, seed %.2f ms, gapped %.2f ms\n", (now_s() - oj.t_out0) * 1e3, st.t_index * 1e3, st.t_seed * 1e3, st.t_gapped * 1e3);
     st.t_total = now_s() - job.t_begin;
 }
 
@@ -3012,7 +3063,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         // lane runs the device half of a pair's seed stage, then the host half (discovery order, entropy filter, anchors)
         // while the other lanes keep the device busy.  A pair's result does not depend on its lane.
         Workspace &w = *ctx.ws;
-        while (w.lanes.size() < n_lanes) w.lanes.push_back(lane_create(ctx.device));
+        while (w.lanes.size() < n_lanes) w.lanes.push_back(lane_create(ctx.device, ctx.priority));
         for (Ctx *l : w.lanes) l->spans = ctx.spans;
         std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
         std::vector<std::string> lane_err(n_lanes);
@@ -3105,7 +3156,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         for (Unit &u : units) gunits[group_of[(size_t)u.pair]].push_back(std::move(u));
         units.clear();
         Workspace &w0 = *ctx.ws;
-        while (w0.lanes.size() + 1 < L) w0.lanes.push_back(lane_create(ctx.device));
+        while (w0.lanes.size() + 1 < L) w0.lanes.push_back(lane_create(ctx.device, ctx.priority));
         for (Ctx *l : w0.lanes) l->spans = ctx.spans;
         std::vector<PairPtrs> pp(n);
         for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }
@@ -3170,7 +3221,14 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         for (PairJob *j : jobs) j->res->stats.t_dp_busy_ms = busy;
     }
     const double t_o = now_s();
-    parallel_for(n, [&](size_t k) { output_phase(p, *jobs[k], (int)k, units); });
+    {
+        std::vector<OutputJob> ojs(n);
+        parallel_for(n, [&](size_t k) { output_collect(*jobs[k], (int)k, units, ojs[k]); });
+        std::vector<std::pair<size_t, size_t>> chunks;                   // (pair, chunk of its cigar text)
+        for (size_t k = 0; k < n; k++) for (size_t ti = 0; ti < ojs[k].ctasks.size(); ti++) chunks.emplace_back(k, ti);
+        parallel_for(chunks.size(), [&](size_t x) { output_cigar_chunk(*jobs[chunks[x].first]->res, ojs[chunks[x].first].ctasks[chunks[x].second]); });
+        parallel_for(n, [&](size_t k) { output_layout(p, *jobs[k], ojs[k]); });
+    }
     if (env_long("MIBLAST_DEBUG", 0))
         fprintf(stderr, "[miblast] call of %zu pairs: seed stages %.2f ms, gapped stage %.2f ms, output %.2f ms, all %.2f ms\n", n, (t_call1 - t_call0) * 1e3, (t_o - t_call1) * 1e3,
                 (now_s() - t_o) * 1e3, (now_s() - t_call0) * 1e3);

@@ -17,6 +17,7 @@ struct DpSpans;
 
 struct Ctx {
     int device = 0;
+    int priority = 0;                   // HIP priority of the context's streams (ctx_set_priority)
     Workspace *ws = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
@@ -35,6 +36,7 @@ struct Result {
     std::vector<size_t> line_off;            // PAF line k of alns[k] = paf[line_off[k], line_off[k+1])
 };
 
+int ctx_set_priority(Ctx &ctx, int level);
 void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
 // outgroup trimming on the device (mb_pipeline.cpp): what no alignment of `paf` covers of the resident query set, as a new resident set

@@ -78,6 +78,7 @@ def load() -> C.CDLL:
         "miblast_device_count": (C.c_int, []),
         "miblast_set_host_threads": (C.c_int, [C.c_int]),
         "miblast_ctx_create": (C.c_int, [C.c_int, P(vp)]),
+        "miblast_ctx_set_priority": (C.c_int, [vp, C.c_int]),
         "miblast_ctx_destroy": (None, [vp]),
         "miblast_seqset_from_fasta_file": (C.c_int, [vp, cp, P(vp)]),
         "miblast_seqset_from_fasta_mem": (C.c_int, [vp, cp, C.c_size_t, P(vp)]),
@@ -116,7 +117,7 @@ def load() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_set_host_threads",
-                    "miblast_ctx_create",
+                    "miblast_ctx_create", "miblast_ctx_set_priority",
                     "miblast_ctx_destroy", "miblast_seqset_from_fasta_file", "miblast_seqset_from_fasta_mem",
                     "miblast_seqset_free", "miblast_seqsets_unaligned", "miblast_seqset_fasta", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
                     "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_align_pairs", "miblast_result_free",
@@ -218,6 +219,11 @@ class Context:
         _check(load().miblast_ctx_create(device, C.byref(h)))
         self._h = h
         self.device = device
+
+    def set_priority(self, level: int):
+        """< 0: this context's launches yield to those of the device's other contexts (jobs nothing waits for); > 0: they go first."""
+        _check(load().miblast_ctx_set_priority(self._h, int(level)))
+        return self
 
     def seqset_from_fasta_bytes(self, data: bytes) -> SeqSet:
         h = C.c_void_p()

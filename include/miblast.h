@@ -84,6 +84,11 @@ int miblast_device_count(void);                                        /* < 0: $
 int miblast_set_host_threads(int n);
 /* One context per process per GPU (ordinal after HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES). */
 int miblast_ctx_create(int device, miblast_ctx **ctx);
+/* Several contexts on one GPU serve independent lastz jobs at the same time (a Toil node runs as many as its cores allow,
+ * local_alignment.py:395-405).  level < 0: this context's launches yield to those of the other contexts on the device -- for jobs
+ * nothing waits for, beside a chain of jobs that depend on one another (an ingroup against its outgroups, :460-526); level > 0: they
+ * go first; 0: the default.  Not while a call is running on the context.                                              */
+int miblast_ctx_set_priority(miblast_ctx *ctx, int level);
 void miblast_ctx_destroy(miblast_ctx *ctx);
 
 /* ---- sequence sets ------------------------------------------------------------------------

@@ -7,7 +7,7 @@ mkdir -p gpurun_out/$TAG
 k=0
 for setting in "$@"; do
   k=$((k+1))
-  env $setting timeout 300 python bench.py --steps 12 --warmup 4 --pair-leg 0 --batch-leg 0 --chain-leg 0 --seed-leg 0 --primates-leg 0 --cpu-sample 0 > gpurun_out/$TAG/b$k.json 2> gpurun_out/$TAG/b$k.err
+  env $setting timeout 300 python bench.py --steps ${SWEEP_STEPS:-40} --warmup 5 --pair-leg 0 --batch-leg 0 --chain-leg 0 --seed-leg 0 --primates-leg 0 --cpu-sample 0 > gpurun_out/$TAG/b$k.json 2> gpurun_out/$TAG/b$k.err
   python - "$setting" gpurun_out/$TAG/b$k.json <<'PY'
 import json, sys
 try:

@@ -147,6 +147,9 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
                 {"MIBLAST_SEED_FUSED": "0"},                    # strands one after the other instead of both in one go
                 {"MIBLAST_LONG_RUN": "4"}, {"MIBLAST_LONG_RUN": "32"},      # which diagonal runs go to the wave-per-run ungapped kernel
                 {"MIBLAST_RELAY_CKPT": "0"},                    # rejected hand-overs continue to the next relay instead of retrying at a later snapshot
+                # traceback: no join walks from predicted entries (the sides walk themselves) / every other prediction made wrong on purpose
+                {"MIBLAST_TRACE_PREJOIN": "0"}, {"MIBLAST_TRACE_PREJOIN": "2"},
+                {"MIBLAST_TRACE_PREJOIN": "2", "MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64"},
                 {"MIBLAST_CHAIN_HEADS": "0"},                   # first-round nomination by spatial thinning instead of one head per colinear anchor group
                 {"MIBLAST_GROUP_GAP": "200", "MIBLAST_GROUP_TOL": "8"}, {"MIBLAST_GROUP_GAP": "1000000", "MIBLAST_GROUP_TOL": "100000"},
                 {"MIBLAST_DP_KERNEL": "4", "MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "3"}):
@@ -174,6 +177,10 @@ RELAY_CONFIGS = [
     # retries at the relays' later entry snapshots switched off / forced through all three checkpoints
     {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "512", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_FORCE_REJECT": "2", "MIBLAST_RELAY_CKPT": "0"},
     {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "768", "MIBLAST_RELAY_W": "48", "MIBLAST_RELAY_FORCE_REJECT": "2"},
+    # traceback: the join walks k_trace_prejoin makes from predicted entries switched off / half of the predictions made wrong
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_TRACE_PREJOIN": "0"},
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_TRACE_PREJOIN": "2"},
+    {"MIBLAST_RELAY_S0": "32", "MIBLAST_RELAY_S": "300", "MIBLAST_RELAY_W": "70", "MIBLAST_RELAY_FORCE_REJECT": "3", "MIBLAST_TRACE_PREJOIN": "2"},
 ]
 
 
