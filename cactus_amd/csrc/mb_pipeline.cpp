@@ -611,7 +611,8 @@ static Ctx *lane_create(int device, int priority) {
     c->device = device;
     c->priority = priority;
     c->ws = workspace_create();
-    MB_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority));
+    if (priority == 0) MB_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));      // (the default: as every other stream of the library)
+    else MB_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority));
     MB_HIP(hipEventCreate(&c->ev0)); MB_HIP(hipEventCreate(&c->ev1)); MB_HIP(hipEventCreate(&c->ev2));
     MB_HIP(hipEventCreate(&c->ev3)); MB_HIP(hipEventCreate(&c->ev4));
     return c;
@@ -2906,7 +2907,7 @@ static void output_collect(PairJob &job, int pair, std::vector<Unit> &units, Out
     std::vector<size_t> &cfirst = oj.cfirst;
     ctasks.clear();
     cfirst.assign(res.alns.size() + 1, 0);
-    const int64_t kOpsPerTask = 4096;
+    const int64_t kOpsPerTask = env_long("MIBLAST_OUTPUT_CHUNK", 4096);
     for (size_t x = 0; x < res.alns.size(); x++) {
         cfirst[x] = ctasks.size();
         for (int64_t k0 = 0; k0 < res.alns[x].n_ops; k0 += kOpsPerTask) ctasks.push_back(CigarTask{x, k0, std::min(res.alns[x].n_ops, k0 + kOpsPerTask), {}, 0, 0, 0});
