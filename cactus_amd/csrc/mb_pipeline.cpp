@@ -147,6 +147,17 @@ struct Stager {
     }
 };
 
+// bit k set iff t[k] and q[k] are the same base of A, C, G, T (codes 0..3 in the low three bits; 4 = N, bit 3 = soft-masked)
+inline unsigned match_bits8(const uint8_t *t, const uint8_t *q) {
+    uint64_t a, b;
+    memcpy(&a, t, 8); memcpy(&b, q, 8);
+    a &= 0x0707070707070707ull; b &= 0x0707070707070707ull;
+    const uint64_t x = a ^ b;
+    const uint64_t eq = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);      // 0x80 where the byte of x is zero
+    const uint64_t acgt = (~a & 0x0404040404040404ull) << 5;                                                      // 0x80 where the code is below 4
+    return (unsigned)((((eq & acgt) >> 7) * 0x0102040810204080ull) >> 56);                                         // byte k -> bit k
+}
+
 // host substitution score (HOXD70 + N = -100)
 struct HostScoreTable {                     // 8 x 8 by the low three code bits: branch-free lookups in the anchor window scan
     int8_t s[64];
@@ -2768,7 +2779,19 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         const int32_t d = (int32_t)(tt - qq);
                         dmin = std::min(dmin, d); dmax = std::max(dmax, d);
                         const uint8_t *tp = tc_h + tt, *qp = qc + qq;
-                        for (uint32_t m = 0; m < len; m++) {
+                        // '=' iff both bases are the same of A, C, G, T.  Eight columns per step: the matching columns of the
+                        // eight as a bit mask, then whole runs of equal bits at a time (a run of '=' is dozens of columns long)
+                        uint32_t m = 0;
+                        for (; m + 8 <= len; m += 8) {
+                            unsigned bits = match_bits8(tp + m, qp + m), left = 8;
+                            while (left) {
+                                const unsigned one = bits & 1u;
+                                const unsigned n = std::min(left, (unsigned)__builtin_ctz((one ? ~bits : bits) | 0x100u));
+                                push(one ? 0u : 1u, n);
+                                bits >>= n; left -= n;
+                            }
+                        }
+                        for (; m < len; m++) {
                             const unsigned a = tp[m] & 7u, b = qp[m] & 7u;
                             push((a < 4u && a == b) ? 0u : 1u, 1);
                         }
@@ -3224,11 +3247,16 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     const double t_o = now_s();
     {
         std::vector<OutputJob> ojs(n);
+        const double t_o0 = now_s();
         parallel_for(n, [&](size_t k) { output_collect(*jobs[k], (int)k, units, ojs[k]); });
+        const double t_o1 = now_s();
         std::vector<std::pair<size_t, size_t>> chunks;                   // (pair, chunk of its cigar text)
         for (size_t k = 0; k < n; k++) for (size_t ti = 0; ti < ojs[k].ctasks.size(); ti++) chunks.emplace_back(k, ti);
         parallel_for(chunks.size(), [&](size_t x) { output_cigar_chunk(*jobs[chunks[x].first]->res, ojs[chunks[x].first].ctasks[chunks[x].second]); });
+        const double t_o2 = now_s();
         parallel_for(n, [&](size_t k) { output_layout(p, *jobs[k], ojs[k]); });
+        if (env_long("MIBLAST_DEBUG", 0))
+            fprintf(stderr, "[miblast] output: collect %.2f ms, %zu chunks of cigar text %.2f ms, layout %.2f ms\n", (t_o1 - t_o0) * 1e3, chunks.size(), (t_o2 - t_o1) * 1e3, (now_s() - t_o2) * 1e3);
     }
     if (env_long("MIBLAST_DEBUG", 0))
         fprintf(stderr, "[miblast] call of %zu pairs: seed stages %.2f ms, gapped stage %.2f ms, output %.2f ms, all %.2f ms\n", n, (t_call1 - t_call0) * 1e3, (t_o - t_call1) * 1e3,
