@@ -810,3 +810,33 @@ def test_evolver_mammals_phase_at_full_size_equals_the_oracle_call_by_call(gpu_c
             full[name] = seq.tobytes().decode()
     checked = sum(pafcheck.check_paf(parts[kind].decode(), full, full) for parts in res.values() for kind in ("ingroup", "outgroup") if parts[kind])
     assert checked >= 100
+
+
+@pytest.mark.gpu
+def test_contexts_of_any_priority_give_the_same_bytes(olz):
+    """miblast_ctx_set_priority: a context whose launches yield to (or go before) those of the device's other contexts, with the lanes
+    of its batched calls, computes what every context computes -- also while a call runs on another context of the device."""
+    import threading
+    from cases import DEFAULT, pair
+    from cactus_amd import miblast
+    pm = _params(DEFAULT)
+    cases = [pair(40000, 31), pair(60000, 33), pair(30000, 35), pair(50000, 37)]
+    want = [olz.align(tf, qf, _oracle_params(olz, pm))["paf"] for tf, qf in cases]
+    low, high = miblast.Context(0).set_priority(-1), miblast.Context(0).set_priority(1)
+    got = {}
+
+    def run(name, cx):
+        sets = [(cx.seqset_from_fasta_bytes(tf), cx.seqset_from_fasta_bytes(qf)) for tf, qf in cases]
+        got[name] = [r.paf for r in cx.align_pairs(sets, pm)] + [cx.align(sets[0][0], sets[0][1], pm).paf]
+        for t, q in sets:
+            t.close(); q.close()
+    th = [threading.Thread(target=run, args=(n, c)) for n, c in (("low", low), ("high", high))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got["low"] == want + [want[0]] and got["high"] == want + [want[0]]
+    low.set_priority(0)
+    run("again", low)
+    assert got["again"] == want + [want[0]]
+    low.close(); high.close()
