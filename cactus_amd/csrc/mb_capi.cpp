@@ -204,6 +204,7 @@ int miblast_ctx_create(int device, miblast_ctx **out) {
         MB_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
         MB_HIP(hipEventCreate(&c->c.ev0)); MB_HIP(hipEventCreate(&c->c.ev1)); MB_HIP(hipEventCreate(&c->c.ev2));
         MB_HIP(hipEventCreate(&c->c.ev3)); MB_HIP(hipEventCreate(&c->c.ev4));
+        mb::ctx_pair_streams(c->c);
         *out = c;
         return MIBLAST_OK;
     });

@@ -647,6 +647,22 @@ void workspace_destroy(Workspace *w) {
     delete w;
 }
 
+// The runtime deals a process's streams to a few hardware queues in the order of their first use, and two streams on one queue run
+// their kernels one after the other.  The stream of a context and that of the lane its batched calls run their second group of pairs
+// on must overlap (16 x 1 Mb pairs in one call: 31 ms side by side, 34 ms one after the other), so they are made and used for
+// the first time together, one right after the other: neighbours in that order never share a queue.
+void ctx_pair_streams(Ctx &ctx) {
+    if (env_long("MIBLAST_PAIR_STREAMS", 1) == 0) return;
+    MB_HIP(hipSetDevice(ctx.device));
+    Workspace &w = *ctx.ws;
+    const size_t gapped_lanes = (size_t)std::min<long>(8, std::max(1l, env_long("MIBLAST_GAPPED_LANES", 2)));
+    while (w.lanes.size() + 1 < gapped_lanes) w.lanes.push_back(lane_create(ctx.device, ctx.priority));
+    MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+    for (Ctx *l : w.lanes) MB_HIP(hipEventRecord(l->ev0, l->stream));
+    MB_HIP(hipStreamSynchronize(ctx.stream));
+    for (Ctx *l : w.lanes) MB_HIP(hipStreamSynchronize(l->stream));
+}
+
 // The context's launches yield to (level < 0) or go before (level > 0) those of other contexts on the device: its stream, and the
 // streams of the lanes its batched calls open, are made anew at the lowest / highest priority the device offers (0: the default).
 int ctx_set_priority(Ctx &ctx, int level) {
@@ -661,6 +677,7 @@ int ctx_set_priority(Ctx &ctx, int level) {
     (void)hipStreamDestroy(ctx.stream);
     ctx.stream = fresh;
     ctx.priority = priority;
+    ctx_pair_streams(ctx);
     return MIBLAST_OK;
 }
 

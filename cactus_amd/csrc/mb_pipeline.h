@@ -37,6 +37,7 @@ struct Result {
 };
 
 int ctx_set_priority(Ctx &ctx, int level);
+void ctx_pair_streams(Ctx &ctx);     // the context's stream and its lanes' on hardware queues of their own
 void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
 // outgroup trimming on the device (mb_pipeline.cpp): what no alignment of `paf` covers of the resident query set, as a new resident set
