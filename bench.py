@@ -505,6 +505,10 @@ def run_rank(a):
             out["pair_1mb"] = pair_leg(a, ctx)
         if a.batch_leg > 1:
             out["batched_pairs"] = batch_leg(a, ctx)
+            # the dominant kernel on launches that fill the GPU (16 pairs in one call): the like-for-like figure across rounds
+            sat = out["batched_pairs"].get("roofline") or {}
+            out["roofline"]["saturated"] = dict(sat, source="batched_pairs leg: 16 x (1 Mb x 1 Mb) in one miblast_align_pairs call",
+                                                gapped_gcells_per_s_kernel=out["batched_pairs"].get("gapped_gcells_per_s_kernel"))
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, ctx)
         if a.chain_leg > 0:
