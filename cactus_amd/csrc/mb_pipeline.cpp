@@ -510,9 +510,12 @@ struct UploadStage {                               // pinned staging of set imag
 UploadStage &upload_stage() { static UploadStage *u = new UploadStage(); return *u; }
 }  // namespace
 
+void note_n_runs(const SeqSet &S);
+
 void upload_seqset(SeqSet &s, int device) {
     MB_HIP(hipSetDevice(device));
     s.device = device;
+    note_n_runs(s);                                                       // (part of making the set resident: see n_runs_cached)
     const size_t nc = std::max<size_t>(1, s.starts.size());
     const size_t seq_bytes = ((size_t)s.total + 2 * kDevPad + 255) & ~(size_t)255, image = seq_bytes + 2 * nc * sizeof(int64_t);
     s.d_buf = (uint8_t *)device_blocks().take(device, image, s.d_cap);
@@ -1679,8 +1682,9 @@ static std::vector<std::pair<int32_t, int32_t>> n_runs_of(const uint8_t *codes, 
     return runs;
 }
 
-// The N runs of a resident set are found once and kept for as long as the set lives (the genomes of a phase take part in call after
-// call; scanning target and both strands of the query was a third of a pair's host half): all runs, per set, keyed by the set's host
+// The N runs of a resident set are found once, when the set is made resident (upload_seqset; a set the device cuts out of another one --
+// seqset_unaligned -- at its first call), and kept for as long as the set lives: the genomes of a phase take part in call after call,
+// and scanning target and both strands of the query was a third of a pair's host half.  All runs, per set, keyed by the set's host
 // image; the '-' strand's runs are the '+' strand's mirrored contig by contig.
 namespace {
 struct NRunCache {
@@ -1701,6 +1705,7 @@ static std::shared_ptr<const std::vector<std::pair<int32_t, int32_t>>> n_runs_ca
     std::lock_guard<std::mutex> lk(c.mu);
     return c.runs.emplace(S.host(), made).first->second;
 }
+void note_n_runs(const SeqSet &S) { if (S.total > 0) (void)n_runs_cached(S); }
 void forget_n_runs(const SeqSet &S) {
     NRunCache &c = n_run_cache();
     std::lock_guard<std::mutex> lk(c.mu);

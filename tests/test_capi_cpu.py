@@ -96,6 +96,12 @@ def test_host_threads_follow_num_threads():
     assert out.stdout.strip() == "5", out.stderr
 
 
+def test_context_calls_refuse_a_null_handle():
+    lib = miblast.load()
+    assert lib.miblast_ctx_set_priority(None, -1) < 0
+    lib.miblast_ctx_destroy(None)                                                # (a no-op, like free)
+
+
 def test_no_device_means_loud_refusal_not_cpu_fallback():
     if not _no_gpu():
         pytest.skip("a GPU is visible here")
