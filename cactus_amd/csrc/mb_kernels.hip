@@ -1631,7 +1631,6 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
     // continuations that start from them come after it in stream order)
     if (pr.snap_idx >= 0 && lane < kSnapSlots) ((SnapHdr *)(snaps + (size_t)(pr.snap_idx + lane) * kSnapBytes))->valid = 0;
     const int OE = O + E;
-    const int grow = (Y >= O ? (Y - O) / E : 0) + 2;          // a row can outgrow the previous window by at most this
     int overflow = 0;
     int R0 = 0;
     if (Y >= O) { R0 = (Y - O) / E; if (R0 > na) R0 = na; }
@@ -1725,7 +1724,18 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
         for (int k = 0; k < K; k++) asm volatile("" : "+v"(C[g][k]), "+v"(D[g][k]));
     int i = row_lo + 1;
     int stopped = 0, exit_j = 0;
-    for (; i <= nb && !overflow; i++) {
+    // the next row after which a snapshot is due (entry snapshots of a relay, the exit snapshot at stop_row): one comparison per row
+    auto next_event = [&](int after) -> int {
+        int e = 0x7fffffff;
+        if (pr.snap_row > after) e = min(e, pr.snap_row);
+        if (pr.stop_row > after) e = min(e, pr.stop_row);
+        if (pr.snap_row2 > after) e = min(e, pr.snap_row2);
+        if (pr.snap_row3 > after) e = min(e, pr.snap_row3);
+        return e;
+    };
+    int evt = uni(next_event(row_lo));
+    if (overflow) i = nb + 1;                                             // (nothing to evaluate: straight to the epilogue)
+    for (; i <= nb; i++) {                                                // (whatever sets `overflow` inside leaves the loop at once)
         const int rho = i - row_lo;
         if (i - qblk0 >= 256) { qblk0 += 256; qv = load_q(qblk0); asm volatile("" : "+v"(qv)); }      // (every 256 rows: waited for on the spot)
         const unsigned qword = (unsigned)__builtin_amdgcn_readlane((int)qv, (i - qblk0) >> 2);
@@ -1748,17 +1758,19 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
             }
         }
         if (RY - jb + K > kCap) { overflow = 1; break; }
-        const int reach = min(min(na, RY + grow), jb + kCap - 1);
-        const int need = reach - jb + 1 + 2 * K;
-        const bool new_blk = blk_used + (unsigned)need > blk_bytes;
-        const bool new_chunk = (rho & (kRowChunk - 1)) == 0;
-        if ((rho & 63) == 0) flush_rows(rho - 1);
-        if (new_blk || new_chunk) {
-            const unsigned nblk = (new_blk ? 1u : 0u) + (new_chunk ? 1u : 0u);
-            unsigned long long o1 = arena_take(nblk);
-            if (o1 == ~0ull) { overflow = 3; break; }
-            if (new_blk) { blk_off = o1; blk_used = 0; o1 += blk_bytes; }
-            if (new_chunk) { chunk_off = o1; if (lane == 0) rowdir[pr.row_off + (unsigned)(rho / kRowChunk)] = chunk_off; }
+        // Rarely: every 64 rows the buffered row records go out, a full chunk of them (every kRowChunk rows) or a trace block that may
+        // not hold another row (the widest a row can be: kCap columns + padding) is replaced.  One test per row for all of it.
+        const bool blk_full = blk_used + (unsigned)(kCap + 2 * K) > blk_bytes;
+        if (__builtin_expect(((rho & 63) == 0) | blk_full, 0)) {
+            const bool new_chunk = (rho & (kRowChunk - 1)) == 0;
+            if ((rho & 63) == 0) flush_rows(rho - 1);
+            if (blk_full || new_chunk) {
+                const unsigned nblk = (blk_full ? 1u : 0u) + (new_chunk ? 1u : 0u);
+                unsigned long long o1 = arena_take(nblk);
+                if (o1 == ~0ull) { overflow = 3; break; }
+                if (blk_full) { blk_off = o1; blk_used = 0; o1 += blk_bytes; }
+                if (new_chunk) { chunk_off = o1; if (lane == 0) rowdir[pr.row_off + (unsigned)(rho / kRowChunk)] = chunk_off; }
+            }
         }
         if (lane == (rho & 63)) { const unsigned long long ro = blk_off + blk_used; rb_lo = (unsigned)ro; rb_hi = (unsigned)(ro >> 32); rb_ly = (unsigned)jb; }
         // ---- one group of 256 columns; carries: cpl0 = old C of the column left of the group, cx / cm = max X / running best left of it,
@@ -1850,23 +1862,34 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
         else group(std::integral_constant<int, 0>{}, std::false_type{}, kNeg, kNeg2, best, 0);
         const unsigned long long blA = __ballot(bmg[0] != 0u);
         const bool need_b = (RY - jb > kHalf) || !blA;                    // the old window reaches into B, or no break inside A
-        unsigned long long blB = 0;
-        if (need_b) {
+        int allm, pbrk, first_alive, last_alive;                           // row maximum; first break (relative to jb); first / last alive column (-1: none)
+        if (__builtin_expect(!need_b, 1)) {
+            // the row lies inside group A (nearly every row): a break exists there, no column of B is or becomes alive.  Straight-line
+            // scalar code -- for a lone wave every branch of the bookkeeping is a stall.
+            allm = totm[0];
+            const int lb = (int)__ffsll((long long)blA) - 1;
+            pbrk = K * lb + (__ffs(__builtin_amdgcn_readlane((int)bmg[0], lb)) - 1);
+            const unsigned long long alA = __ballot(amg[0] != 0u);
+            const int lf = ((int)__ffsll((long long)alA) - 1) & 63, ll = (63 - (int)__clzll((long long)alA)) & 63;      // (alA == 0: any lane, masked below)
+            const int fa = jb + K * lf + (__ffs(__builtin_amdgcn_readlane((int)amg[0], lf)) - 1);
+            const int la = jb + K * ll + (31 - __clz(__builtin_amdgcn_readlane((int)amg[0], ll)));
+            first_alive = alA ? fa : -1;
+            last_alive = alA ? la : -1;
+        } else {
             group(std::integral_constant<int, 1>{}, std::true_type{}, cplB0, totx[0], totm[0], flast[0]);   // (rare: always the masking form)
-            blB = __ballot(bmg[1] != 0u);
+            const unsigned long long blB = __ballot(bmg[1] != 0u);
             if (!blA && !blB) { overflow = 1; break; }                    // every column up to the last lane is still alive
+            allm = totm[1];                                               // (carries make the last total the overall one)
+            if (blA) { const int lb = (int)__ffsll((long long)blA) - 1; pbrk = K * lb + (__ffs(__builtin_amdgcn_readlane((int)bmg[0], lb)) - 1); }
+            else { const int lb = (int)__ffsll((long long)blB) - 1; pbrk = kHalf + K * lb + (__ffs(__builtin_amdgcn_readlane((int)bmg[1], lb)) - 1); }
+            first_alive = -1; last_alive = -1;
+            const unsigned long long alA = __ballot(amg[0] != 0u), alB = __ballot(amg[1] != 0u);
+            if (alA) { const int lf = (int)__ffsll((long long)alA) - 1; first_alive = jb + K * lf + (__ffs(__builtin_amdgcn_readlane((int)amg[0], lf)) - 1); }
+            else if (alB) { const int lf = (int)__ffsll((long long)alB) - 1; first_alive = jb + kHalf + K * lf + (__ffs(__builtin_amdgcn_readlane((int)amg[1], lf)) - 1); }
+            if (alB) { const int ll = 63 - (int)__clzll((long long)alB); last_alive = jb + kHalf + K * ll + (31 - __clz(__builtin_amdgcn_readlane((int)amg[1], ll))); }
+            else if (alA) { const int ll = 63 - (int)__clzll((long long)alA); last_alive = jb + K * ll + (31 - __clz(__builtin_amdgcn_readlane((int)amg[0], ll))); }
         }
-        const int allm = need_b ? totm[1] : totm[0];                      // (carries make the last total the overall one)
-        int pbrk;                                                         // first break, relative to jb
-        if (blA) { const int lb = (int)__ffsll((long long)blA) - 1; pbrk = K * lb + (__ffs(__builtin_amdgcn_readlane((int)bmg[0], lb)) - 1); }
-        else { const int lb = (int)__ffsll((long long)blB) - 1; pbrk = kHalf + K * lb + (__ffs(__builtin_amdgcn_readlane((int)bmg[1], lb)) - 1); }
         const int nvalid = min(pbrk + ((jb + pbrk) <= na ? 1 : 0), kCap);
-        int first_alive = -1, last_alive = -1;
-        const unsigned long long alA = __ballot(amg[0] != 0u), alB = need_b ? __ballot(amg[1] != 0u) : 0ull;
-        if (alA) { const int lf = (int)__ffsll((long long)alA) - 1; first_alive = jb + K * lf + (__ffs(__builtin_amdgcn_readlane((int)amg[0], lf)) - 1); }
-        else if (alB) { const int lf = (int)__ffsll((long long)alB) - 1; first_alive = jb + kHalf + K * lf + (__ffs(__builtin_amdgcn_readlane((int)amg[1], lf)) - 1); }
-        if (alB) { const int ll = 63 - (int)__clzll((long long)alB); last_alive = jb + kHalf + K * ll + (31 - __clz(__builtin_amdgcn_readlane((int)amg[1], ll))); }
-        else if (alA) { const int ll = 63 - (int)__clzll((long long)alA); last_alive = jb + K * ll + (31 - __clz(__builtin_amdgcn_readlane((int)amg[0], ll))); }
         if (allm > best) {
             // the first cell of the row that reaches the new best
             unsigned wmA = 0, wmB = 0;
@@ -1889,7 +1912,8 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
         if (first_alive < 0) { i++; break; }
         LY = first_alive;
         RY = last_alive + 1;
-        if (i == pr.snap_row || i == pr.stop_row || i == pr.snap_row2 || i == pr.snap_row3) {
+        if (__builtin_expect(i == evt, 0)) {
+            evt = uni(next_event(i));
             // state after row i
             uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : i == pr.snap_row ? 0 : i == pr.snap_row2 ? 2 : 3)) * kSnapBytes;
             int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
