@@ -1945,8 +1945,9 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
 }
 
 // The piece evaluator needs about 100 VGPRs when the compiler is left alone: 4 waves per SIMD (k_ydrop2).  k_ydrop2_w5 is the same
-// instruction stream held to 96 VGPRs = 5 waves per SIMD; it is launched when the pieces outnumber the 4 x 1024 wave slots of
-// k_ydrop2 (MIBLAST_DP_WAVES=4 / 5 forces one of them).  (Before the trace codes were collected as sign bits the evaluator
+// instruction stream held to 96 VGPRs = 5 waves per SIMD.  It used to be launched when the pieces outnumbered the 4 x 1024 wave
+// slots of k_ydrop2; since the row bookkeeping became straight-line code the squeezed build spills inside the row loop and loses
+// (16 x 1 Mb pairs in one call: 33.5 ms against 31.3 ms, 315 against 357 Gcell/s in the kernel): MIBLAST_DP_WAVES=5 only.  (Before the trace codes were collected as sign bits the evaluator
 // took 129 VGPRs, 3 waves per SIMD, and the squeezed build 128.)
 __global__ __launch_bounds__(64)
 void k_ydrop2(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
@@ -1970,7 +1971,7 @@ void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtr
     dim3 g((unsigned)n), b(64);
     const char *we = getenv("MIBLAST_DP_WAVES");
     const int waves = we ? atoi(we) : 0;
-    const bool five = waves == 5 || (waves != 4 && n > 4 * 1024);
+    const bool five = waves == 5;                                       // (round 3: the 4-wave build is the faster one at every size, see above)
     if (K == 2 && five) hipLaunchKernelGGL(k_ydrop2_w5, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
     else if (K == 2) hipLaunchKernelGGL(k_ydrop2, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
     else if (K == 4) hipLaunchKernelGGL((k_ydrop1<4>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);

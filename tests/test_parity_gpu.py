@@ -142,7 +142,7 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
                 # DP kernel: one wave per piece with 2 x 4, 4 or 8 columns per lane (windows that outgrow the lanes are rerun with
                 # the 4-wave LDS-ring kernel), or the 4-wave kernel from the start
                 {"MIBLAST_DP_KERNEL": "2"}, {"MIBLAST_DP_KERNEL": "4"}, {"MIBLAST_DP_KERNEL": "8"}, {"MIBLAST_DP_KERNEL": "100"},
-                {"MIBLAST_DP_WAVES": "4"}, {"MIBLAST_DP_WAVES": "3"},    # the 128-VGPR build of the one-wave DP kernel (4 waves per SIMD) / the default
+                {"MIBLAST_DP_WAVES": "4"}, {"MIBLAST_DP_WAVES": "5"},    # the two builds of the one-wave DP kernel: 4 waves per SIMD (the default) / held to 96 VGPRs = 5 waves
                 {"MIBLAST_SEED_ONE_PASS": "0"},                 # two-pass seed search (count, scan, fill) instead of the fused one
                 {"MIBLAST_SEED_FUSED": "0"},                    # strands one after the other instead of both in one go
                 {"MIBLAST_LONG_RUN": "4"}, {"MIBLAST_LONG_RUN": "32"},      # which diagonal runs go to the wave-per-run ungapped kernel
