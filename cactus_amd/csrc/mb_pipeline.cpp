@@ -2961,18 +2961,29 @@ static void output_collect(PairJob &job, int pair, std::vector<Unit> &units, Out
 }
 
 static void output_cigar_chunk(const Result &res, CigarTask &t) {
+    // (nearly every run length has one or two digits: those come from a table, straight into a buffer sized for the worst case)
+    static const char two[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                              "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
     const miblast_aln &A = res.alns[t.aln];
-    t.text.reserve((size_t)(t.k1 - t.k0) * 5);
+    std::unique_ptr<char[]> room(new char[(size_t)(t.k1 - t.k0) * 11 + 1]);    // (30 bits of length: at most 10 digits and the op; not zeroed)
+    char *const w0 = room.get();
+    char *w = w0;
+    const uint32_t *ops = res.ops.data() + A.ops_off;
     for (int64_t k = t.k0; k < t.k1; k++) {
-        const uint32_t o = res.ops[(size_t)(A.ops_off + k)];
-        t.alen += o >> 2;
-        if ((o & 3u) == 0) t.nmatch += o >> 2;
-        char buf[12]; int n = 0;
+        const uint32_t o = ops[k];
         uint32_t u = o >> 2;
-        do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-        while (n) t.text.push_back(buf[--n]);
-        t.text.push_back("=XID"[o & 3u]);
+        t.alen += u;
+        if ((o & 3u) == 0) t.nmatch += u;
+        if (u < 10) *w++ = (char)('0' + u);
+        else if (u < 100) { *w++ = two[2 * u]; *w++ = two[2 * u + 1]; }
+        else {
+            char buf[12]; int n = 0;
+            do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+            while (n) *w++ = buf[--n];
+        }
+        *w++ = "=XID"[o & 3u];
     }
+    t.text.assign(w0, (size_t)(w - w0));
 }
 
 static void output_layout(const miblast_params &p, PairJob &job, OutputJob &oj) {
