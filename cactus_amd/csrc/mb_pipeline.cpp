@@ -1047,6 +1047,22 @@ static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, in
     return sc;
 }
 
+// seed windows of a strand without N or soft-masked bases (the counter seed_lookups = this x the word variants).  Eight bases at a time
+// while all of them are unmasked A, C, G, T: a stretch of x such bases holds max(0, x - 18) windows.
+static int64_t valid_seed_windows(const uint8_t *qc, int64_t qtot) {
+    auto held = [](int64_t x) -> int64_t { return x >= kSeedSpan ? x - kSeedSpan + 1 : 0; };
+    int64_t run = 0, valid = 0, i = 0;
+    while (i < qtot) {
+        if (i + 8 <= qtot) {
+            uint64_t w8; memcpy(&w8, qc + i, 8);
+            if ((w8 & 0xFCFCFCFCFCFCFCFCull) == 0) { valid += held(run + 8) - held(run); run += 8; i += 8; continue; }
+        }
+        const int64_t stop = std::min(qtot, i + 8);
+        for (; i < stop; i++) { run = qc[i] < 4 ? run + 1 : 0; valid += run >= kSeedSpan; }
+    }
+    return valid;
+}
+
 // host half of the seed stage of one strand: lookup counter, discovery order, entropy filter, --queryhsplimit/--queryhspbest.
 // Touches only the strand's own fields of the job, so it can run beside the device half of the other strand or pair.
 static void seed_host(const miblast_params &p, PairJob &job, int strand) {
@@ -1061,12 +1077,9 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
         // number of seed word lookups = valid query windows x variants (counter only)
         {
             // (the '-' strand is the contig-wise mirror image of the '+' strand: same number of valid windows)
-            int64_t valid = strand == 1 ? job.valid_windows : -1;
+            int64_t valid = job.valid_windows;                         // (the shared seed stage counts them once per pair before the strands' halves)
             if (valid < 0) {
-                int64_t run = 0;
-                valid = 0;
-                const uint8_t *qc = qc_h[strand];
-                for (int64_t i = 0; i < qtot; i++) { run = qc[i] < 4 ? run + 1 : 0; valid += run >= kSeedSpan; }
+                valid = valid_seed_windows(qc_h[strand], qtot);
                 if (strand == 0) job.valid_windows = valid;
             }
             out.lookups = valid * (p.transitions ? 1 + kSeedWeight : 1);
@@ -1641,12 +1654,21 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         fprintf(stderr, "[miblast] batched seed stage: %zu pairs, %zu targets, %llu hits, %zu HSP candidates; index %.2f ms (kernels %.2f), count %.2f, fill %.2f, sort %.2f, ungapped %.2f; device part %.2f ms\n",
                 n, targets.size(), total, n_found, t_index * 1e3, ms_index, ms_count, ms_fill, ms_sort, ms_ung, t_dev * 1e3);
     // ---- host halves: discovery order, entropy filter, HSP limits, anchors -- pair by pair on the worker threads
+    const double t_h0 = now_s();
+    parallel_for(n, [&](size_t k) { if (jobs[k]->Q->total >= kSeedSpan) jobs[k]->valid_windows = valid_seed_windows(jobs[k]->qc_h[0], jobs[k]->Q->total); });
+    const double t_h1 = now_s();
+    parallel_for(2 * n, [&](size_t ks) {                                  // (a strand's half touches only the strand's own fields of the job)
+        PairJob &job = *jobs[ks / 2];
+        if (job.Q->total >= kSeedSpan) seed_host(p, job, (int)(ks & 1));
+    });
+    const double t_h2 = now_s();
     parallel_for(n, [&](size_t k) {
         PairJob &job = *jobs[k];
-        if (job.Q->total >= kSeedSpan) { seed_host(p, job, 0); seed_host(p, job, 1); }
         seed_finish(job);
         build_units(p, job, (int)k, job.units);
     });
+    if (env_long("MIBLAST_DEBUG", 0))
+        fprintf(stderr, "[miblast] host halves of the seed stage: window count %.2f ms, strands %.2f ms, anchors %.2f ms\n", (t_h1 - t_h0) * 1e3, (t_h2 - t_h1) * 1e3, (now_s() - t_h2) * 1e3);
     return MIBLAST_OK;
 }
 
