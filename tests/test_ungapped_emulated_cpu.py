@@ -38,3 +38,13 @@ def test_emulated_batched_seed_stage_matches_the_rule():
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()
     assert out.count(" ok\n") == 3 and "MISMATCH" not in out, out
+
+
+def test_emulated_set_kernels_match_plain_loops():
+    """cactus_amd/csrc/mb_sets.h on the host (tests/emu/emu_sets.cpp): the '-' strands of a call's query sets, and outgroup trimming
+    between two calls -- interval marks, edges of the uncovered stretches, the gathered device image of the new set with its contig
+    tables -- all sets of a call in one launch, against plain loops over every set."""
+    subprocess.run(["make", "-C", EMU_DIR, "emu_sets"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_sets"), "5", "60"], capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    assert b"60 cases, 0 differences" in p.stdout
