@@ -208,7 +208,8 @@ void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *off
 // UngappedCounters per unit -- extended / cols per unit, hsps of entry 0 = the slot counter of the whole launch
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const UnitTab &ut,
                      int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
-                     UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s);      // ux: scratch of the level-synchronous pipeline, or nullptr; extent_clean: extent[] is all zero
+                     UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s,        // ux: scratch of the level-synchronous pipeline, or nullptr; extent_clean: extent[] is all zero
+                     bool n_heads_clean = false);                                                      // n_heads_clean: the caller has zeroed the 8 counters of n_heads
 // wsegs / walns / wref: walls mode (miblast_params.walls) -- WallSeg runs of the earlier alignments, int2 run ranges per alignment, int2
 // alignment ranges per problem; nullptr without walls
 void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs,
@@ -242,7 +243,8 @@ constexpr int kBxDirBlocks = 128;             // blocks per target of k_bx_popc 
 
 constexpr int kBsTile = 2048;                 // a unit's share of the q space of a batched seed search is a whole number of scan tiles
 void launch_batch_index(const BatchTarget *tg, int n_targets, int64_t slot_blocks, int64_t n_cnt, uint32_t *words, unsigned long long *bits,
-                        uint32_t *dir, uint32_t *bsum, uint32_t *cnt, uint32_t *starts, unsigned long long *scan_sums, uint32_t *positions, hipStream_t s);
+                        uint32_t *dir, uint32_t *bsum, uint32_t *cnt, uint32_t *cursor, uint32_t *starts, unsigned long long *scan_sums, uint32_t *positions,
+                        hipStream_t s);
 void launch_batch_seed_count(const SeedUnit *units, int n_units, const BatchTarget *tg, const unsigned long long *bits, const uint32_t *dir,
                              const uint32_t *starts, int transitions, int64_t q_slots, uint32_t *qcnt, uint32_t *hit_off, unsigned long long *scan_sums,
                              hipStream_t s);

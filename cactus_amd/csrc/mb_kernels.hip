@@ -400,17 +400,24 @@ void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *off
 // sparse seed position tables of the n_targets distinct targets of a call.  bits / dir: n_targets x 2^18 entries; words, positions:
 // one entry per slot; cnt, starts: n_cnt = slots + n_targets entries (cnt is scratch and ends as the zeroed cursor array);
 // bsum: n_targets x 128; scan_sums: ceil(n_cnt / 2048) + 2
+// cnt: the positions per occupied bucket; cursor: as many zeroed counters again for the scatter.  When the two lie right behind the
+// bitmaps (cnt = end of bits, cursor = cnt + n_cnt rounded up to 4 entries: the pipeline's layout) ONE fill zeroes all three.
 void launch_batch_index(const BatchTarget *tg, int n_targets, int64_t slot_blocks, int64_t n_cnt, uint32_t *words, unsigned long long *bits,
-                        uint32_t *dir, uint32_t *bsum, uint32_t *cnt, uint32_t *starts, unsigned long long *scan_sums, uint32_t *positions, hipStream_t s) {
-    MB_HIP(hipMemsetAsync(bits, 0, (size_t)n_targets * kBxWordsPerTarget * 8, s));
-    MB_HIP(hipMemsetAsync(cnt, 0, up16((size_t)n_cnt * 4), s));
+                        uint32_t *dir, uint32_t *bsum, uint32_t *cnt, uint32_t *cursor, uint32_t *starts, unsigned long long *scan_sums, uint32_t *positions,
+                        hipStream_t s) {
+    const size_t bits_bytes = (size_t)n_targets * kBxWordsPerTarget * 8, cnt_bytes = up16((size_t)n_cnt * 4);
+    if ((uint8_t *)cnt == (uint8_t *)bits + bits_bytes && (uint8_t *)cursor == (uint8_t *)cnt + cnt_bytes) MB_HIP(hipMemsetAsync(bits, 0, bits_bytes + 2 * cnt_bytes, s));
+    else {
+        MB_HIP(hipMemsetAsync(bits, 0, bits_bytes, s));
+        MB_HIP(hipMemsetAsync(cnt, 0, cnt_bytes, s));
+        MB_HIP(hipMemsetAsync(cursor, 0, cnt_bytes, s));
+    }
     if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_words, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits);
     hipLaunchKernelGGL(k_bx_popc, dim3((unsigned)(n_targets * kBxDirBlocks)), dim3(256), 0, s, bits, bsum);
     hipLaunchKernelGGL(k_bx_dir, dim3((unsigned)(n_targets * kBxDirBlocks)), dim3(256), 0, s, bits, bsum, dir);
     if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_count, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits, dir, cnt);
     launch_scan_u32(cnt, starts, n_cnt, scan_sums, s);
-    MB_HIP(hipMemsetAsync(cnt, 0, up16((size_t)n_cnt * 4), s));
-    if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_scatter, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits, dir, starts, cnt, positions);
+    if (slot_blocks > 0) hipLaunchKernelGGL(k_bx_scatter, dim3((unsigned)slot_blocks), dim3(256), 0, s, tg, n_targets, words, bits, dir, starts, cursor, positions);
     MB_HIP(hipGetLastError());
 }
 
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
 
 void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *heads, unsigned *n_heads, const UnitTab &ut,
                      int64_t n_diagonals, int32_t *extent, int xdrop, int K, DevHsp *hsps, int64_t hsp_cap,
-                     UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s) {
+                     UngappedCounters *ctr, const UxScratch *ux, bool extent_clean, hipStream_t s, bool n_heads_clean) {
     if (n_hits <= 0) return;
     // runs longer than this go to the wave-per-run kernel: a few times the chance hits a diagonal holds on average
     int kLongRun = (int)std::min<int64_t>(kLongRunMax, 6 + 4 * n_hits / std::max<int64_t>(1, n_diagonals));
@@ -677,7 +684,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     // n_heads: five counters
     const uint64_t n = (uint64_t)n_hits;
     unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
-    MB_HIP(hipMemsetAsync(n_heads, 0, up16((kRunClasses + 1) * sizeof(unsigned)), s));      // (n_heads: 8 counters)
+    if (!n_heads_clean) MB_HIP(hipMemsetAsync(n_heads, 0, up16((kRunClasses + 1) * sizeof(unsigned)), s));      // (n_heads: 8 counters)
     hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1024 * kHeadsPerThread - 1) / (1024 * kHeadsPerThread))), dim3(1024), 0, s, keys, n_hits, kLongRun, heads,
                        n_heads);
     const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits

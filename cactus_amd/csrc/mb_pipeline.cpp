@@ -585,7 +585,7 @@ struct Workspace {                      // device buffers that persist across mi
     std::vector<std::unique_ptr<RcSlot>> rc_pool;
     // batched seed stage (seed_phase_batched): sparse tables of the call's distinct targets, unit tables, per-unit counters
     DevBuf<unsigned long long> bx_bits, bx_scan;
-    DevBuf<uint32_t> bx_dir, bx_bsum, bx_words, bx_cnt, bx_starts, bx_positions;
+    DevBuf<uint32_t> bx_dir, bx_bsum, bx_words, bx_starts, bx_positions;
     DevBuf<unsigned long long> h16_ka, h16_kb;               // diag_hash16: sort keys and values of the resolve pass
     DevBuf<uint32_t> h16_va, h16_vb;
     DevBuf<BatchTarget> bx_targets;
@@ -1532,10 +1532,13 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
     }
 
     // ---- seed tables of the distinct targets
-    w.bx_bits.ensure(targets.size() * (size_t)kBxWordsPerTarget); w.bx_dir.ensure(targets.size() * (size_t)kBxWordsPerTarget);
+    // (bitmaps, bucket counts and the scatter's cursors lie one behind the other: one fill zeroes them)
+    const size_t bx_cnt_words = up16((size_t)n_cnt * 4) / 4;
+    w.bx_bits.ensure(targets.size() * (size_t)kBxWordsPerTarget + bx_cnt_words + 8); w.bx_dir.ensure(targets.size() * (size_t)kBxWordsPerTarget);
+    uint32_t *const bx_cnt = (uint32_t *)(w.bx_bits.p + targets.size() * (size_t)kBxWordsPerTarget), *const bx_cursor = bx_cnt + bx_cnt_words;
     w.bx_bsum.ensure(targets.size() * (size_t)kBxDirBlocks);
     w.bx_words.ensure((size_t)std::max<int64_t>(1, slots)); w.bx_positions.ensure((size_t)std::max<int64_t>(1, slots));
-    w.bx_cnt.ensure((size_t)n_cnt + 8); w.bx_starts.ensure((size_t)n_cnt + 8);
+    w.bx_starts.ensure((size_t)n_cnt + 8);
     const int64_t scan_tiles = std::max((n_cnt + kBsTile - 1) / kBsTile, q_slots / kBsTile) + 2;
     w.bx_scan.ensure((size_t)scan_tiles);
     w.bx_targets.ensure(tg.size()); w.bx_units.ensure(units.size());
@@ -1543,7 +1546,7 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
     w.stage.h2d(w.bx_units.p, units.data(), units.size() * sizeof(SeedUnit), s);
     for (hipEvent_t &e : w.sev[0]) if (!e) MB_HIP(hipEventCreate(&e));
     MB_HIP(hipEventRecord(w.sev[0][0], s));
-    launch_batch_index(w.bx_targets.p, (int)tg.size(), blocks, n_cnt, w.bx_words.p, w.bx_bits.p, w.bx_dir.p, w.bx_bsum.p, w.bx_cnt.p, w.bx_starts.p, w.bx_scan.p,
+    launch_batch_index(w.bx_targets.p, (int)tg.size(), blocks, n_cnt, w.bx_words.p, w.bx_bits.p, w.bx_dir.p, w.bx_bsum.p, bx_cnt, bx_cursor, w.bx_starts.p, w.bx_scan.p,
                        w.bx_positions.p, s);
     MB_HIP(hipEventRecord(w.sev[0][1], s));
 
@@ -1585,10 +1588,12 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         const size_t pb = p.diag_hash16 ? sort_pairs_temp_bytes((int64_t)nh) : 0;
         w.sort_temp.ensure(std::max(tb, pb) + 16);
         if (p.diag_hash16) { w.h16_ka.ensure(nh); w.h16_kb.ensure(nh); w.h16_va.ensure(nh); w.h16_vb.ensure(nh); }
-        w.extent.ensure((size_t)n_diag + 8);
-        w.ctr.ensure(units.size() + 1);
-        MB_HIP(hipMemsetAsync(w.extent.p, 0, up16(((size_t)n_diag + 2) * 4), s));
-        MB_HIP(hipMemsetAsync(w.ctr.p, 0, up16(units.size() * sizeof(UngappedCounters)), s));
+        // extent[], the units' counters and the run-list counters lie one behind the other: one fill
+        const size_t ext_bytes = up16(((size_t)n_diag + 2) * 4), ctr_bytes = up16(units.size() * sizeof(UngappedCounters)), nh_bytes = 32;
+        w.extent.ensure((ext_bytes + ctr_bytes + nh_bytes) / 4 + 8);
+        UngappedCounters *const d_ctr = (UngappedCounters *)((uint8_t *)w.extent.p + ext_bytes);
+        unsigned *const d_n_heads = (unsigned *)((uint8_t *)w.extent.p + ext_bytes + ctr_bytes);
+        MB_HIP(hipMemsetAsync(w.extent.p, 0, ext_bytes + ctr_bytes + nh_bytes, s));
         (void)ux_scratch(w, nullptr, nh, n_diag + 2);                               // (sized before anything is queued)
         MB_HIP(hipEventRecord(w.sev[0][3], s));
         launch_batch_seed_fill(w.bx_units.p, (int)units.size(), w.bx_targets.p, w.bx_bits.p, w.bx_dir.p, w.bx_starts.p, w.bx_positions.p, p.transitions, q_slots,
@@ -1601,16 +1606,16 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         ut.one = units[0]; ut.tab = w.bx_units.p; ut.n = (int32_t)units.size();
         if (p.diag_hash16) {
             // lastz's 16-bit diagonal hash: every hit extended, the rule per hash class afterwards (mb_hash16.h)
-            launch_ungapped_hash16(w.keys_b.p, (int64_t)nh, ut, n_diag, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, w.ctr.p, &uxs, w.h16_ka.p, w.h16_kb.p, w.h16_va.p,
+            launch_ungapped_hash16(w.keys_b.p, (int64_t)nh, ut, n_diag, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, d_ctr, &uxs, w.h16_ka.p, w.h16_kb.p, w.h16_va.p,
                                    w.h16_vb.p, w.sort_temp.p, pb, w.extent.p, s);
         } else
-        launch_ungapped(w.keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, ut, n_diag, w.extent.p, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, w.ctr.p, &uxs, true, s);
+        launch_ungapped(w.keys_b.p, (int64_t)nh, w.heads.p, d_n_heads, ut, n_diag, w.extent.p, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, d_ctr, &uxs, true, s, true);
         MB_HIP(hipEventRecord(ctx.ev0, s));
         constexpr size_t kBlind = 1 << 16;                                          // HSPs copied back before their number is known
         w.pin_ctr.ensure(units.size());
         w.pin_hsps.ensure(kBlind);
         const size_t blind = std::min(kBlind, nh);
-        MB_HIP(hipMemcpyAsync(w.pin_ctr.p, w.ctr.p, units.size() * sizeof(UngappedCounters), hipMemcpyDeviceToHost, s));
+        MB_HIP(hipMemcpyAsync(w.pin_ctr.p, d_ctr, units.size() * sizeof(UngappedCounters), hipMemcpyDeviceToHost, s));
         MB_HIP(hipMemcpyAsync(w.pin_hsps.p, w.hsps.p, blind * sizeof(DevHsp), hipMemcpyDeviceToHost, s));
         MB_HIP(hipStreamSynchronize(s));                                           // (2) counters + HSPs
         for (size_t u = 0; u < units.size(); u++) hc[u] = w.pin_ctr.p[u];
@@ -3123,11 +3128,18 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         jobs.push_back(&j);
     }
     const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, env_long("MIBLAST_SEED_LANES", 12))) : 1;
-    // MIBLAST_SEED_BATCHED: 1 (default) the seed stages of a call of several pairs share their launches (seed_phase_batched);
-    // 2: a single pair goes that way too (tests); 0: never -- pair by pair on the lanes below
+    // MIBLAST_SEED_BATCHED: 1 (default) the seed stages of a call of several pairs share their launches (seed_phase_batched), and so does
+    // a single pair that will fit one key buffer with room to spare (half the launches of the pair-by-pair path; chance hits expected
+    // from the sizes: 2 strands x word variants x |T| x |Q| / 4^12 -- an 8 Mb pair would count its 10^8 hits only to be sent back);
+    // 2: every single pair goes that way (tests); 0: never -- pair by pair on the lanes below
     const long batched_mode = p.diag_hash16 ? 2 : env_long("MIBLAST_SEED_BATCHED", 1);      // (diag=hash16 lives in the shared seed stage only)
+    bool small_single = false;
+    if (n == 1) {
+        const double expected = 2.0 * (p.transitions ? 1 + kSeedWeight : 1) * (double)Ts[0]->total * (double)Qs[0]->total / (double)kBuckets;
+        small_single = expected <= (double)env_long("MIBLAST_HIT_CAP", 32l << 20) / 8.0;
+    }
     bool batched_done = false;
-    if (n >= 1 && (batched_mode >= 2 || (batched_mode == 1 && n > 1))) {
+    if (n >= 1 && (batched_mode >= 2 || (batched_mode == 1 && (n > 1 || small_single)))) {
         int rc = seed_phase_batched(ctx, p, jobs, batched_done);
         if (rc != MIBLAST_OK) return rc;
         if (!batched_done) for (PairJob *j : jobs) { j->found[0].clear(); j->found[1].clear(); j->units.clear(); }

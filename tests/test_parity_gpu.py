@@ -21,7 +21,10 @@ def _oracle_params(olz, pm):
 
 
 @pytest.mark.parametrize("name,tf,qf,args", CASES, ids=CASE_IDS)
-def test_case_matches_oracle(gpu_ctx, olz, name, tf, qf, args):
+def test_case_matches_oracle(gpu_ctx, olz, monkeypatch, name, tf, qf, args):
+    """Every case pair by pair (the path of a pair too large for the shared seed stage: dense seed table, seed search and sort per
+    strand); small single pairs take the shared seed stage by default -- the test after the next one runs every case through it."""
+    monkeypatch.setenv("MIBLAST_SEED_BATCHED", "0")
     pm = _params(args)
     T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
     got = gpu_ctx.align(T, Q, pm)
@@ -44,6 +47,7 @@ def test_every_ungapped_kernel_matches_oracle(gpu_ctx, olz, monkeypatch, kernel)
     from cases import DEFAULT, multi_contig, pair
     from cactus_amd import gen
     monkeypatch.setenv("MIBLAST_UNGAPPED", kernel)
+    monkeypatch.setenv("MIBLAST_SEED_BATCHED", "0")             # (pair by pair: the q-batched path lives there; the shared seed stage has its own tests)
     monkeypatch.setenv("MIBLAST_CHECK_ANCHORS", "1")             # k_hsp_anchor against the host's column-by-column scan (the call fails on a difference)
     t, q = gen.make_pair(150000, 17, homologous=False)
     chance = (gen.fasta_bytes([("T|c0", t)]), gen.fasta_bytes([("Q|c0", q)]))
@@ -138,13 +142,14 @@ def test_deterministic_across_runs_and_batch_sizes(gpu_ctx, monkeypatch):
     base = gpu_ctx.align(T, Q, pm)
     assert base.paf.count(b"\n") >= 3
     for env in ({"MIBLAST_GAPPED_BATCH_MAX": "1"}, {"MIBLAST_SHADOW_Q": "0", "MIBLAST_SHADOW_D": "0"},
-                {"MIBLAST_SHADOW_Q": "100000000"}, {"MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_ARENA_MB": "1"},
+                {"MIBLAST_SHADOW_Q": "100000000"}, {"MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_SEED_BATCHED": "0", "MIBLAST_HIT_CAP": "3000"}, {"MIBLAST_ARENA_MB": "1"},
                 # DP kernel: one wave per piece with 2 x 4, 4 or 8 columns per lane (windows that outgrow the lanes are rerun with
                 # the 4-wave LDS-ring kernel), or the 4-wave kernel from the start
                 {"MIBLAST_DP_KERNEL": "2"}, {"MIBLAST_DP_KERNEL": "4"}, {"MIBLAST_DP_KERNEL": "8"}, {"MIBLAST_DP_KERNEL": "100"},
                 {"MIBLAST_DP_WAVES": "4"}, {"MIBLAST_DP_WAVES": "5"},    # the two builds of the one-wave DP kernel: 4 waves per SIMD (the default) / held to 96 VGPRs = 5 waves
-                {"MIBLAST_SEED_ONE_PASS": "0"},                 # two-pass seed search (count, scan, fill) instead of the fused one
-                {"MIBLAST_SEED_FUSED": "0"},                    # strands one after the other instead of both in one go
+                {"MIBLAST_SEED_BATCHED": "0"},                  # pair by pair instead of the shared seed stage (the default for a pair this small)
+                {"MIBLAST_SEED_BATCHED": "0", "MIBLAST_SEED_ONE_PASS": "0"},      # ... with the two-pass seed search (count, scan, fill) instead of the fused one
+                {"MIBLAST_SEED_BATCHED": "0", "MIBLAST_SEED_FUSED": "0"},         # ... strands one after the other instead of both in one go
                 {"MIBLAST_LONG_RUN": "4"}, {"MIBLAST_LONG_RUN": "32"},      # which diagonal runs go to the wave-per-run ungapped kernel
                 {"MIBLAST_RELAY_CKPT": "0"},                    # rejected hand-overs continue to the next relay instead of retrying at a later snapshot
                 # traceback: no join walks from predicted entries (the sides walk themselves) / every other prediction made wrong on purpose
