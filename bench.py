@@ -325,6 +325,10 @@ def timed_steps(work, steps, warmup, sync, gather):
     for _ in range(warmup):
         gather(work.step()[1])
     sync()
+    import gc
+    nogc = os.environ.get("MIBLAST_BENCH_NOGC", "1") != "0"           # the harness's own garbage collector stays out of the timed steps (as timeit keeps it)
+    if nogc:
+        gc.collect(); gc.disable()
     thr0, cpu0 = cpu_throttle_state(), time.process_time()
     t0 = time.perf_counter()
     tot, keep = {}, None
@@ -338,6 +342,8 @@ def timed_steps(work, steps, warmup, sync, gather):
         marks.append(time.perf_counter())              # (a step ends with its PAF on the host: the spread of the steps, for the record)
     sync()
     elapsed = time.perf_counter() - t0
+    if nogc:
+        gc.enable()
     each = sorted((b - a) * 1e3 for a, b in zip(marks, marks[1:]))
     if os.environ.get("MIBLAST_BENCH_STEP_TIMES"):
         print("[bench] step times (ms): " + " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(marks, marks[1:])), file=sys.stderr)
@@ -429,7 +435,8 @@ def run_rank(a):
             dist.barrier()
 
     elapsed, tot, keep = timed_steps(work, a.steps, a.warmup, sync, gather)
-    step_spread = dict(timed_steps.last_spread, note="wall time of the single steps of the timed region on rank 0 (ms_per_step is their mean over all ranks' barrier-to-barrier time)")
+    step_spread = dict(timed_steps.last_spread, note="wall time of the single steps of the timed region on rank 0 (ms_per_step is their mean over all ranks' barrier-to-barrier time); "
+                                                     "Python's cyclic garbage collector is switched off for the timed steps, as timeit does (MIBLAST_BENCH_NOGC=0 leaves it on)")
     keys = sorted(tot)
     vec = torch.tensor([float(tot[k]) for k in keys] + [elapsed], dtype=torch.float64, device=coll_dev)
     if dist is not None:
