@@ -506,6 +506,13 @@ def run_rank(a):
         out["roofline"]["overlap_note"] = ("a call of several pairs runs the gapped stages of two groups of its pairs on two streams (MIBLAST_GAPPED_LANES=2): their DP launches "
                                            "share the GPU, so a launch's HIP-event duration -- the denominator here -- is longer than it would be alone, and the "
                                            "durations add up to more than the wall time they cover")
+        if world > 1:
+            # the extra legs and the CPU baseline are single-GPU figures: measured at N = 1 only (the ranks of a scaling run do not wait
+            # for rank 0 to time them)
+            a.primates_leg = a.pair_leg = a.batch_leg = a.seed_leg = a.chain_leg = 0
+            if a.workload != "chr20":
+                a.cpu_sample = 0
+            out["legs_note"] = "primates / pair_1mb / batched_pairs / seed_stage / chain_stage / cpu_baseline are measured at --gpus 1 only"
         if a.workload == "evolver" and a.primates_leg > 0:
             out["primates"] = primates_leg(a, ctx)
         if a.workload == "evolver" and a.pair_leg > 0:
