@@ -223,7 +223,7 @@ class EvolverPhase:
             h.close()
         if TIMELINE:
             print(f"[bench] step total {(time.perf_counter() - t_step) * 1e3:.2f} ms", file=sys.stderr)
-        paf = b"".join(v["ingroup"] + v["outgroup"] for v in res.values())
+        paf = b"".join(part for v in res.values() for part in (v["ingroup"], v["outgroup"]))
         return agg, paf
 
 

@@ -380,11 +380,11 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
         take(opts, idx, fut.result())
     # assemble: outgroup chains are merged innermost first (each level's sub-sequence coordinates fixed by dechunk --query,
     # make_ingroup_to_outgroup_alignments_3), then inverted so that the ingroup is the target
-    result: Dict[str, Dict[str, bytes]] = {}
+    parts: Dict[str, Dict[str, List[bytes]]] = {}     # (pieces first, ONE join per file: the files of a phase are megabytes)
     for i, c in enumerate(calls):
-        node = result.setdefault(c.node, {"ingroup": b"", "outgroup": b""})
+        node = parts.setdefault(c.node, {"ingroup": [], "outgroup": []})
         if c.kind == "ingroup":
-            node["ingroup"] += raw[i]
+            node["ingroup"].append(raw[i])
     chains: Dict[Tuple[str, str], List[int]] = {}
     for i, c in enumerate(calls):
         if c.chain is not None:
@@ -394,5 +394,5 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
     for key, idx in chains.items():
         for i in sorted(idx, key=lambda i: calls[i].level):
             if i in finished:
-                result[key[0]]["outgroup"] += finished[i].result()
-    return result
+                parts[key[0]]["outgroup"].append(finished[i].result())
+    return {node: {kind: b"".join(p) for kind, p in files.items()} for node, files in parts.items()}
