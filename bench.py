@@ -42,7 +42,22 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # results, traceback), each time for a millisecond or less.  The ROCm runtime wakes a waiting thread through an interrupt by
 # default; polling the completion signal instead takes ~25 us off every wait (19.1 -> 18.3 ms per step) at the price of a
 # spinning core per waiting thread -- the library's host threads spin between their tasks anyway.  Caller's setting wins.
-os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+def _cores_per_rank():
+    ranks = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+    if not ranks and "--gpus" in sys.argv[1:-1]:
+        try:
+            ranks = int(sys.argv[sys.argv.index("--gpus") + 1])
+        except ValueError:
+            ranks = 0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return cores / max(1, ranks)
+
+
+if _cores_per_rank() >= 24:                       # (a rank keeps about twenty threads busy then: not on a node that has fewer per GPU)
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 DEFAULT_ARGS = "--step=1 --ambiguous=iupac,100,100 --ydrop=4000 --hspthresh=2200 --gappedthresh=2400 --queryhspbest=100000"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
