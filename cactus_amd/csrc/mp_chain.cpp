@@ -219,16 +219,28 @@ int parse_line(PafSet &set, const char *b, const char *e, std::string &err) {
             else if (!memcmp(p, "cg:Z:", 5)) {
                 r.has_cg = 1;
                 r.ops_off = set.ops.size();
+                // (an op is two characters at least: room for the most there can be, written through a pointer, trimmed afterwards)
+                const size_t room = (size_t)(te - val) / 2 + 1;
+                if (set.ops.capacity() - set.ops.size() < room) set.ops.reserve(std::max(2 * set.ops.capacity(), set.ops.size() + room));
+                set.ops.resize(r.ops_off + room);
+                uint32_t *w = set.ops.data() + r.ops_off;
+                static const struct OpCode { uint8_t of[256]; OpCode() { memset(of, 99, sizeof of); of[(int)'='] = kOpEq; of[(int)'X'] = kOpX; of[(int)'M'] = kOpM; of[(int)'I'] = kOpI; of[(int)'D'] = kOpD; } } op_code;
+                const char *why = nullptr;
                 for (const char *c = val; c < te;) {
-                    uint64_t len = 0;
-                    if (*c < '0' || *c > '9') return bad("cigar: a length is expected");
-                    while (c < te && *c >= '0' && *c <= '9') { len = len * 10 + (uint64_t)(*c++ - '0'); if (len >= (1u << 28)) return bad("cigar: op longer than 2^28"); }
-                    if (c == te) return bad("cigar: op letter missing");
-                    uint32_t code = *c == '=' ? kOpEq : *c == 'X' ? kOpX : *c == 'M' ? kOpM : *c == 'I' ? kOpI : *c == 'D' ? kOpD : 99u;
-                    if (code == 99u || len == 0) return bad("cigar: unknown op or zero length");
+                    unsigned d = (unsigned)(*c - '0');
+                    if (d > 9u) { why = "cigar: a length is expected"; break; }
+                    uint64_t len = d;
                     c++;
-                    set.ops.push_back((uint32_t)(len << 3) | code);
+                    while (c < te && (d = (unsigned)(*c - '0')) <= 9u) { len = len * 10 + d; c++; if (len >= (1u << 28)) break; }
+                    if (len >= (1u << 28)) { why = "cigar: op longer than 2^28"; break; }
+                    if (c == te) { why = "cigar: op letter missing"; break; }
+                    const uint32_t code = op_code.of[(unsigned char)*c];
+                    if (code == 99u || len == 0) { why = "cigar: unknown op or zero length"; break; }
+                    c++;
+                    *w++ = (uint32_t)(len << 3) | code;
                 }
+                set.ops.resize((size_t)(w - set.ops.data()));
+                if (why) return bad(why);
                 r.n_ops = (uint32_t)(set.ops.size() - r.ops_off);
             }
         }
@@ -327,11 +339,27 @@ void format_rec(const PafSet &set, const PafRec &r, std::string &out) {
     if (r.s1 != -1) { out += "\ts1:i:"; put_i64(out, r.s1); }
     if (r.has_cg) {
         out += "\tcg:Z:";
+        // (the cigars of whole-chunk alignments run to hundreds of thousands of ops, nearly all of one or two digits: those come
+        //  from a table, a few thousand characters at a time into the string)
+        static const char two[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                                  "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+        char buf[4096];
+        size_t at = 0;
+        const uint32_t *ops = set.ops.data() + r.ops_off;
         for (uint32_t k = 0; k < r.n_ops; k++) {
-            const uint32_t o = set.ops[r.ops_off + k];
-            put_i64(out, (int64_t)(o >> 3));
-            out += kOpCh[o & 7u];
+            if (at + 16 > sizeof buf) { out.append(buf, at); at = 0; }
+            const uint32_t o = ops[k];
+            uint32_t u = o >> 3;
+            if (u < 10) buf[at++] = (char)('0' + u);
+            else if (u < 100) { buf[at++] = two[2 * u]; buf[at++] = two[2 * u + 1]; }
+            else {
+                char d[12]; int n = 0;
+                do { d[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+                while (n) buf[at++] = d[--n];
+            }
+            buf[at++] = kOpCh[o & 7u];
         }
+        out.append(buf, at);
     }
     out += '\n';
 }
