@@ -744,18 +744,22 @@ def cpu_baseline_concurrent(kept_calls, cells, hits):
             jobs.append((len(tf) * len(qf), k, [exe, tp + "[multiple][nameparse=darkspace]", qp + "[nameparse=darkspace]", "--format=paf:wfmash"] + opts.split(), paf))
         jobs.sort(key=lambda x: (-x[0], x[1]))
         taskset = shutil.which("taskset")
-        free, running, same = list(cores[:width]), [], True
+        free, running, same = list(cores[:width]), {}, True
         t0 = time.perf_counter()
         pending = list(jobs)
         while pending or running:
             while pending and free:
                 _, k, cmd, paf = pending.pop(0)
                 core = free.pop(0)
-                p = subprocess.Popen(([taskset, "-c", str(core)] if taskset else []) + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-                running.append((p, core, paf))
-            p, core, paf = running.pop(0)                     # (the longest were started first: waiting in start order costs nothing)
-            got = p.communicate()[0]
-            same = same and p.returncode == 0 and got == paf
+                outp = os.path.join(work, f"{k}.paf")            # (to a file: a finished job never waits on a full pipe)
+                p = subprocess.Popen(([taskset, "-c", str(core)] if taskset else []) + cmd, stdout=open(outp, "wb"), stderr=subprocess.DEVNULL)
+                running[p.pid] = (p, core, paf, outp)
+            pid, status = os.wait()                              # whichever job ends first gives its core to the next one
+            if pid not in running:
+                continue
+            p, core, paf, outp = running.pop(pid)
+            p.returncode = os.waitstatus_to_exitcode(status)
+            same = same and p.returncode == 0 and open(outp, "rb").read() == paf
             free.append(core)
         wall = time.perf_counter() - t0
     finally:

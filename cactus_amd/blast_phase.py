@@ -305,7 +305,7 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
             if on_call is not None:
                 on_call(calls[i], genomes[calls[i].target], as_fasta(query_fa[i]), paf)
 
-    for level in range(last_level + 1):
+    def run_level(level):
         todo: List[int] = []
         trimmed = {}
         if level > 0:
@@ -315,7 +315,10 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
                 # the aligner keeps the sequences on its device: what is left of every chain's ingroup is cut out there, all chains
                 # of the level in one call (miblast_seqsets_unaligned); a query is then a handle of the aligner's, not FASTA bytes
                 live = [i for i in idx if last_paf[calls[i].chain][0]]                        # (a chain with nothing left stays empty)
-                got = dict(zip(live, trim_resident([last_paf[calls[i].chain] for i in live], trim_min_size, trim_flanking))) if live else {}
+                got = {}
+                if live:
+                    with gate:                        # (a trimming call occupies a context of the aligner like any other call)
+                        got = dict(zip(live, trim_resident([last_paf[calls[i].chain] for i in live], trim_min_size, trim_flanking)))
                 outs = [got.get(i) for i in idx]
             else:
                 outs = pool.map(lambda i: unaligned_fasta(last_paf[calls[i].chain][1], last_paf[calls[i].chain][0], trim_min_size, trim_flanking), idx)
@@ -373,9 +376,23 @@ def run_blast_phase(genomes: Dict[str, bytes], calls: Sequence[Call], option_str
             # many contexts and no more
             results = list(pool.map(lambda g: gated([(genomes[calls[i].target], query_fa[i]) for i in g[1]], g[0]), groups))
         else:
-            results = [align_batch([(genomes[calls[i].target], query_fa[i]) for i in idx], opts) for opts, idx in groups]
+            # (through the gate as well: jobs nothing waits for may be out on the aligner's other contexts)
+            results = [gated([(genomes[calls[i].target], query_fa[i]) for i in idx], opts) for opts, idx in groups]
         for (opts, idx), outs in zip(groups, results):
             take(opts, idx, outs)
+
+    try:
+        for level in range(last_level + 1):
+            run_level(level)
+    except BaseException:
+        for _, _, fut in free_jobs:                   # a level raised: nothing of this run stays in flight on the aligner's contexts
+            fut.cancel()
+        for _, _, fut in free_jobs:
+            try:
+                fut.result()
+            except BaseException:                     # noqa: BLE001
+                pass
+        raise
     for opts, idx, fut in free_jobs:
         take(opts, idx, fut.result())
     # assemble: outgroup chains are merged innermost first (each level's sub-sequence coordinates fixed by dechunk --query,

@@ -291,26 +291,27 @@ int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_s
     });
 }
 
+void miblast_drop_derived(void) {
+    try { mb::drop_derived(); } catch (...) {}
+}
+
 int miblast_seqsets_unaligned(miblast_ctx *ctx, size_t n, const miblast_seqset *const *queries, const char *const *pafs, const size_t *paf_lens,
                               int64_t min_size, int64_t flank, miblast_seqset **out) {
     if (!ctx || !out || (n && (!queries || !pafs || !paf_lens))) return MIBLAST_EINVAL;
     for (size_t k = 0; k < n; k++) { out[k] = nullptr; if (!queries[k] || (!pafs[k] && paf_lens[k])) return MIBLAST_EINVAL; }
     return guarded([&]() -> int {
         std::vector<const mb::SeqSet *> qs(n);
-        std::vector<miblast_seqset *> made(n, nullptr);
+        std::vector<std::unique_ptr<miblast_seqset>> made(n);          // (owned here until handed out: nothing leaks when an allocation throws half way)
         std::vector<mb::SeqSet *> outs(n);
         std::unique_ptr<bool[]> none(new bool[n + 1]);
-        for (size_t k = 0; k < n; k++) { qs[k] = &queries[k]->s; made[k] = new miblast_seqset(); outs[k] = &made[k]->s; }
-        int rc;
-        try {
-            rc = mb::seqset_unaligned(ctx->c, n, qs.data(), pafs, paf_lens, min_size, flank, outs.data(), none.get());
-        } catch (...) {
-            for (miblast_seqset *m : made) delete m;
-            throw;
-        }
         for (size_t k = 0; k < n; k++) {
-            if (rc == MIBLAST_OK && !none[k]) out[k] = made[k];
-            else { if (made[k]->s.d_buf) mb::release_seqset(made[k]->s); delete made[k]; }
+            if (queries[k]->s.device != ctx->c.device) { mb::set_error("a query set lives on another device than the context"); return MIBLAST_EINVAL; }
+            qs[k] = &queries[k]->s; made[k].reset(new miblast_seqset()); outs[k] = &made[k]->s;
+        }
+        const int rc = mb::seqset_unaligned(ctx->c, n, qs.data(), pafs, paf_lens, min_size, flank, outs.data(), none.get());
+        for (size_t k = 0; k < n; k++) {
+            if (rc == MIBLAST_OK && !none[k]) out[k] = made[k].release();
+            else if (made[k]->s.d_buf) mb::release_seqset(made[k]->s);
         }
         return rc;
     });

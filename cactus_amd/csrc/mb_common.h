@@ -199,8 +199,19 @@ void launch_seed_count(const uint8_t *qcodes, int64_t qn, const uint32_t *offset
                        hipStream_t s);
 void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
                       const uint32_t *positions, int transitions, const uint32_t *hit_off, unsigned long long *keys,
-                      hipStream_t s);
+                      hipStream_t s, uint32_t hmul = 1u, uint32_t hmask = 0xFFFFFFFFu);      // key diagonal = (d * hmul) & hmask (mb_seed_dense.h)
 void launch_index_clear(const uint32_t *words, int64_t n_slots, uint32_t *cursor, hipStream_t s);
+// ---- seed stage of a large pair (mb_seed_dense.h) ----
+inline size_t packed_words2(int64_t n) { return (size_t)((n + 31) / 32 + 2); }      // u64 words of the 2-bit plane / of the mask plane of n bases
+inline size_t packed_wordsm(int64_t n) { return (size_t)((n + 63) / 64 + 2); }
+void launch_pack2bit(const uint8_t *codes, int64_t n, unsigned long long *p2, unsigned long long *pm, hipStream_t s);
+void launch_index_words_packed(const unsigned long long *p2, const unsigned long long *pm, int64_t n, int step, int64_t first, uint32_t *words, int64_t n_slots,
+                               uint32_t *counts, hipStream_t s);
+int64_t seed_ord_state_words(int64_t qtot);
+void launch_seed_search_ord(const uint8_t *qcodes, const unsigned long long *p2, const unsigned long long *pm, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
+                            const uint32_t *positions, int transitions, uint32_t hmul, uint32_t hmask, unsigned long long *keys, unsigned long long cap,
+                            unsigned long long *state, hipStream_t s);
+void launch_keys_unhash(unsigned long long *keys, int64_t n, uint32_t hinv, uint32_t hmask, hipStream_t s);
 void launch_scan_index(uint32_t *counts, uint32_t *offsets, unsigned long long *block_sums, uint32_t *occ, hipStream_t s);
 void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *occ, const uint32_t *positions, int transitions,
                         unsigned long long *keys, unsigned long long cap, unsigned long long *total, hipStream_t s);

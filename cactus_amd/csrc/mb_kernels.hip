@@ -314,7 +314,7 @@ void launch_seed_count(const uint8_t *qcodes, int64_t qn, const uint32_t *offset
 
 __global__ void k_seed_fill(const uint8_t *__restrict__ qcodes, int64_t q0, int64_t q1, int64_t qn, int64_t qtot,
                             const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ occ, const uint32_t *__restrict__ positions, int nvar,
-                            const uint32_t *__restrict__ hit_off, unsigned long long *__restrict__ keys) {
+                            const uint32_t *__restrict__ hit_off, unsigned long long *__restrict__ keys, const uint32_t hmul, const uint32_t hmask) {
     int64_t q = q0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= q1) return;
     uint32_t w;
@@ -326,19 +326,19 @@ __global__ void k_seed_fill(const uint8_t *__restrict__ qcodes, int64_t q0, int6
         if (!((occ[wv >> 5] >> (wv & 31u)) & 1u)) continue;
         uint32_t b0 = offsets[wv], b1 = offsets[wv + 1];
         for (uint32_t k = b0; k < b1; k++) {
-            // diagonal d = t_end - q_end = p - q ; stored biased by qtot so it is non-negative
-            unsigned long long dq = (unsigned long long)((int64_t)positions[k] - q + qtot);
-            keys[o++] = (dq << 32) | q_end;
+            // diagonal d = t_end - q_end = p - q ; stored biased by qtot so it is non-negative, scrambled for the sort (mb_seed_dense.h)
+            const uint32_t dq = (uint32_t)((int64_t)positions[k] - q + qtot);
+            keys[o++] = ((unsigned long long)((dq * hmul) & hmask) << 32) | q_end;
         }
     }
 }
 
 void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
                       const uint32_t *positions, int transitions, const uint32_t *hit_off, unsigned long long *keys,
-                      hipStream_t s) {
+                      hipStream_t s, uint32_t hmul, uint32_t hmask) {
     if (q1 <= q0) return;
     hipLaunchKernelGGL(k_seed_fill, dim3((unsigned)((q1 - q0 + 255) / 256)), dim3(256), 0, s, qcodes, q0, q1, qtot, qtot,
-                       offsets, occ, positions, transitions ? 1 + kSeedWeight : 1, hit_off, keys);
+                       offsets, occ, positions, transitions ? 1 + kSeedWeight : 1, hit_off, keys, hmul, hmask);
 }
 
 // seed search in one pass: count, reserve and fill.  Every block counts the hits of its 256 query positions (the bucket
@@ -392,6 +392,43 @@ void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *off
     if (qtot <= 0) return;
     hipLaunchKernelGGL(k_seed_search, dim3((unsigned)((qtot + 255) / 256)), dim3(256), 0, s, qcodes, qtot, qtot, offsets, occ, positions,
                        transitions ? 1 + kSeedWeight : 1, keys, cap, total);
+}
+
+// ---- the seed stage of a large pair: packed strands, q-ordered one-pass search, scrambled diagonals (mb_seed_dense.h) ------------
+#include "mb_seed_dense.h"
+
+void launch_pack2bit(const uint8_t *codes, int64_t n, unsigned long long *p2, unsigned long long *pm, hipStream_t s) {
+    const int64_t nm = (int64_t)packed_wordsm(n);
+    hipLaunchKernelGGL(k_pack2bit_mask, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, codes, n, p2, pm, nm);
+}
+
+void launch_index_words_packed(const unsigned long long *p2, const unsigned long long *pm, int64_t n, int step, int64_t first, uint32_t *words, int64_t n_slots,
+                               uint32_t *counts, hipStream_t s) {
+    if (n_slots <= 0) return;
+    hipLaunchKernelGGL(k_index_words_packed, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, p2, pm, n, step, first, words, n_slots, counts);
+}
+
+// (tiles of 4096 positions with one word variant, of 1024 with thirteen: the state is sized for the smaller tile)
+int64_t seed_ord_state_words(int64_t qtot) { return 2 + (qtot + kOrdThreads - 1) / kOrdThreads; }
+
+// state: seed_ord_state_words(qtot) zeroed words; state[1] = hits of the strand afterwards (also when they did not fit `cap`)
+void launch_seed_search_ord(const uint8_t *qcodes, const unsigned long long *p2, const unsigned long long *pm, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
+                            const uint32_t *positions, int transitions, uint32_t hmul, uint32_t hmask, unsigned long long *keys, unsigned long long cap,
+                            unsigned long long *state, hipStream_t s) {
+    if (qtot <= 0) return;
+    const int per_tile = kOrdThreads * (transitions ? 1 : 4);
+    const int n_tiles = (int)((qtot + per_tile - 1) / per_tile);
+    const unsigned grid = (unsigned)std::min(n_tiles, 512);             // two blocks of 1024 threads per CU
+#define MB_ORD(P, R, NV) hipLaunchKernelGGL((k_seed_search_ord<P, R, NV>), dim3(grid), dim3(kOrdThreads), 0, s, qcodes, p2, pm, qtot, qtot, offsets, occ, positions, hmul, hmask, keys, cap, state, n_tiles)
+    if (transitions) { if (p2) MB_ORD(true, 1, 1 + kSeedWeight); else MB_ORD(false, 1, 1 + kSeedWeight); }
+    else { if (p2) MB_ORD(true, 4, 1); else MB_ORD(false, 4, 1); }
+#undef MB_ORD
+    MB_HIP(hipGetLastError());
+}
+
+void launch_keys_unhash(unsigned long long *keys, int64_t n, uint32_t hinv, uint32_t hmask, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_keys_unhash, dim3((unsigned)(((n + 1) / 2 + 255) / 256)), dim3(256), 0, s, keys, n, hinv, hmask);
 }
 
 // ---- the seed stage of all pairs of a call in shared launches (mb_seed_batch.h) ------------------------------------------------
@@ -508,7 +545,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
         const UnitRef un = unit_of(ut, dq);
         const uint8_t *tc = un.tc, *qc = un.qc;
         my_unit = un.id;
-        int32_t ext = extent[dq];
+        int32_t ext = extent_get(extent, dq);
         while (true) {
             const int32_t q_end = (int32_t)(uint32_t)key;
             if (q_end > ext) {
@@ -557,7 +594,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
             key = keys[k];
             if ((uint32_t)(key >> 32) != dq) break;
         }
-        extent[dq] = ext;
+        extent_put(extent, dq, ext);
     }
     unit_count(ctr, my_unit, n_ext, n_cols);
 }
@@ -611,7 +648,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
     const uint32_t dq = (uint32_t)(keys[k0] >> 32);
     const UnitRef un = unit_of(ut, dq);                              // (one run per wave: uniform)
     const uint8_t *tc = un.tc, *qc = un.qc;
-    int32_t ext = extent[dq];
+    int32_t ext = extent_get(extent, dq);
     bool run_done = false;
     while (!run_done) {
         // 64 hits of the run at a time; all suppressed hits of the block are skipped with one ballot
@@ -661,7 +698,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
         k0 += 64;
     }
     if (lane == 0) {
-        extent[dq] = ext;
+        extent_put(extent, dq, ext);
         atomicAdd(&ctr[un.id].extended, n_ext);
         atomicAdd(&ctr[un.id].cols, n_cols);
     }
@@ -699,7 +736,9 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     const int forced = !fe ? 0 : !strcmp(fe, "lane") ? 1 : !strcmp(fe, "ux") ? 2 : !strcmp(fe, "grp") ? 3 : 0;
     // (the pooled hits of a batched call -- several units -- are dense enough for the pipeline whenever they are many: the 9-pair call
     //  of the evolver phase, 4.9 x 10^6 hits on 2.2 x 10^7 diagonals, 1.28 ms against 2.08 ms with a run per lane)
-    int mode = forced ? forced : (ux && n_hits >= (1 << 19) && (ut.n > 1 || n_hits >= n_diagonals / 4)) ? 2 : 1;
+    // (and for the millions of hits of a chunk pair whatever their density: a 30 Mb x 30 Mb pair without homology, 1.5 x 10^7 chance hits per
+    //  strand on 6 x 10^7 diagonals, 1.7 ms against 4.8 ms with a run per lane)
+    int mode = forced ? forced : (ux && n_hits >= (1 << 19) && (ut.n > 1 || n_hits >= n_diagonals / 4 || n_hits >= (1 << 22))) ? 2 : 1;
     if (mode == 2 && (!ux || xdrop >= (1 << 24))) mode = 1;
     if (mode == 1) {
         const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;               // upper bound: sum over classes of ceil(runs / 256)

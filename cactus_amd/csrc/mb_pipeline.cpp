@@ -22,6 +22,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -463,7 +464,7 @@ struct DeviceBlocks {
     std::mutex mu;
     std::vector<Block> free_list;
     size_t cached = 0;
-    static constexpr size_t kKeep = (size_t)1 << 30;
+    static constexpr size_t kKeep = (size_t)8 << 30;        // (of 288 GB: the derived data of a genome pair's chunks comes and goes with every step of a bench)
     void *take(int device, size_t bytes, size_t &cap) {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -510,6 +511,70 @@ struct UploadStage {                               // pinned staging of set imag
 UploadStage &upload_stage() { static UploadStage *u = new UploadStage(); return *u; }
 }  // namespace
 
+// device memory out of the block cache (no hipMalloc / hipFree -- the latter waits for the device -- when a size comes round again)
+template <typename T>
+struct PoolBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    int device = 0;
+    PoolBuf() = default;
+    PoolBuf(const PoolBuf &) = delete;
+    PoolBuf &operator=(const PoolBuf &) = delete;
+    ~PoolBuf() { release(); }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        release();
+        MB_HIP(hipGetDevice(&device));
+        p = (T *)device_blocks().take(device, count * sizeof(T), cap);
+        n = cap / sizeof(T);
+    }
+    void release() { if (p) device_blocks().give(device, p, cap); p = nullptr; n = 0; cap = 0; }
+};
+namespace {
+struct PinnedBlocks {                              // the same for pinned host memory (hipHostMalloc / hipHostFree of 30 MB cost milliseconds)
+    struct Block { void *p; size_t cap; };
+    std::mutex mu;
+    std::vector<Block> free_list;
+    void *take(size_t bytes, size_t &cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].cap >= bytes && free_list[i].cap <= 2 * bytes + 4096) {
+                    Block b = free_list[i];
+                    free_list.erase(free_list.begin() + (long)i);
+                    cap = b.cap;
+                    return b.p;
+                }
+        }
+        void *p = nullptr;
+        cap = (bytes + 4095) & ~(size_t)4095;
+        MB_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
+        return p;
+    }
+    void give(void *p, size_t cap) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (free_list.size() < 64) { free_list.push_back({p, cap}); return; }
+        (void)hipHostFree(p);
+    }
+};
+PinnedBlocks &pinned_blocks() { static PinnedBlocks *b = new PinnedBlocks(); return *b; }
+}  // namespace
+template <typename T>
+struct PoolPin {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    PoolPin() = default;
+    PoolPin(const PoolPin &) = delete;
+    PoolPin &operator=(const PoolPin &) = delete;
+    ~PoolPin() { if (p) pinned_blocks().give(p, cap); }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        if (p) pinned_blocks().give(p, cap);
+        p = (T *)pinned_blocks().take(count * sizeof(T), cap);
+        n = cap / sizeof(T);
+    }
+};
+
 void note_n_runs(const SeqSet &S);
 
 void upload_seqset(SeqSet &s, int device) {
@@ -545,19 +610,32 @@ void upload_seqset(SeqSet &s, int device) {
 }
 
 void forget_n_runs(const SeqSet &S);
+static void forget_derived(const SeqSet &S);
 
 void release_seqset(SeqSet &s) {
     forget_n_runs(s);
+    if (s.d_buf) forget_derived(s);
     if (s.d_buf) device_blocks().give(s.device, s.d_buf, s.d_cap);
     s.d_buf = nullptr; s.d_starts = nullptr; s.d_lens = nullptr; s.d_cap = 0;
 }
 
 
 // --------------------------------------------------------------------------------------------------
+// seed position table of a target (CSR over the 2^24 seed words + occupancy bitmap of the buckets) and the packed form of a strand
+// (mb_seed_dense.h); both live with the set they are derived from (SetDerived below) or, as scratch, in a context's workspace
+struct SeedTable {
+    int step = 0; int64_t first = 0, n_slots = 0; uint32_t n_positions = 0;
+    PoolBuf<uint32_t> offsets, occ, positions;
+};
+struct PackedStrand { PoolBuf<unsigned long long> p2, pm; bool ready = false; };
+
 struct Workspace {                      // device buffers that persist across miblast_align() calls of one context
     // seed position table
-    DevBuf<uint32_t> words, counts, offsets, positions, occ;
+    DevBuf<uint32_t> words, counts;
     bool counts_zero = false;                 // `counts` is all zero (build_index leaves it so)
+    PackedStrand pack_t;                      // the packed target of the build in progress (scratch)
+    std::shared_ptr<SeedTable> own_table;     // MIBLAST_RESIDENT_TABLES=0: the table of the call in progress
+    DevBuf<unsigned long long> ord_state;     // q-ordered seed search: ticket, total and look-back words of both strands
     DevBuf<unsigned long long> bsum;
     // seed search / ungapped
     DevBuf<uint8_t> rc;
@@ -581,8 +659,6 @@ struct Workspace {                      // device buffers that persist across mi
     PinBuf<UngappedCounters> pin_ctr;
     PinBuf<DevHsp> pin_hsps;
     Stager stage;
-    struct RcSlot { DevBuf<uint8_t> d; PinBuf<uint8_t> h; };        // '-' strands of pairs 1.. of a batched call (device + pinned host copy)
-    std::vector<std::unique_ptr<RcSlot>> rc_pool;
     // batched seed stage (seed_phase_batched): sparse tables of the call's distinct targets, unit tables, per-unit counters
     DevBuf<unsigned long long> bx_bits, bx_scan;
     DevBuf<uint32_t> bx_dir, bx_bsum, bx_words, bx_starts, bx_positions;
@@ -870,16 +946,68 @@ int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *co
 
 struct Index { uint32_t n_positions = 0; };
 
-static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
+// ---- data derived from a resident set, kept with it (SURVEY 8e "target-major": a target chunk's seed table is built once and stays
+// resident while the query chunks stream through it; the '-' strand and the packed form of a query chunk likewise serve every target
+// chunk it meets).  Keyed by the set's device image; dropped with the set (release_seqset) or on request (drop_derived: bench.py does
+// so at the start of every step, so that a step pays for every table it uses once).  A chunk pair of the reference's CPU path
+// (30 Mb + 10 kb) holds 64 MiB + 2 MiB + 4 B per indexed position of table, 30 MB of '-' strand and 23 MB of packed strands: three
+// target and three query chunks of a chr20 pair are half a gigabyte of the 288.
+struct SetDerived {
+    std::mutex mu;                                  // a lane that needs something another lane is building waits here
+    std::map<std::pair<int, int64_t>, std::shared_ptr<SeedTable>> tables;      // by (step, first)
+    bool rc_ready = false;
+    PoolBuf<uint8_t> d_rc;                          // '-' strand, kDevPad separator bytes either side
+    PoolPin<uint8_t> h_rc;                          // ... and its host copy ([SEP] codes [SEP])
+    PackedStrand packed[2];
+};
+namespace {
+struct DerivedCache {
+    std::mutex mu;
+    std::unordered_map<const uint8_t *, std::shared_ptr<SetDerived>> sets;     // by SeqSet::d_buf
+};
+DerivedCache &derived_cache() { static DerivedCache *c = new DerivedCache(); return *c; }
+}  // namespace
+static std::shared_ptr<SetDerived> derived_of(const SeqSet &S) {
+    DerivedCache &c = derived_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    std::shared_ptr<SetDerived> &e = c.sets[S.d_buf];
+    if (!e) e = std::make_shared<SetDerived>();
+    return e;
+}
+static void forget_derived(const SeqSet &S) {
+    std::shared_ptr<SetDerived> gone;                // (freed outside the lock: hipFree waits for the device)
+    DerivedCache &c = derived_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.sets.find(S.d_buf);
+    if (it != c.sets.end()) { gone = it->second; c.sets.erase(it); }
+}
+void drop_derived() {
+    std::vector<std::shared_ptr<SetDerived>> gone;
+    DerivedCache &c = derived_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (auto &kv : c.sets) gone.push_back(kv.second);
+    c.sets.clear();
+}
+
+// the packed form (2 bits + 1 mask bit per base, mb_seed_dense.h) of n code bytes
+static void pack_strand(const uint8_t *codes, int64_t n, PackedStrand &ps, hipStream_t s) {
+    ps.p2.ensure(packed_words2(n)); ps.pm.ensure(packed_wordsm(n));
+    launch_pack2bit(codes, n, ps.p2.p, ps.pm.p, s);
+    ps.ready = true;
+}
+
+// seed position table of T into tab (the scratch of the build -- words, bucket counts, scan sums, the packed target -- is the context's)
+static void build_index(Ctx &ctx, const SeqSet &T, int step, SeedTable &tab) {
     hipStream_t s = ctx.stream;
     Workspace &w = *ctx.ws;
     // indexed positions are those with (origin + p) % step == 0: a block of a larger file keeps the file's phase
     const int64_t first = (step - T.origin % step) % step;
     int64_t n_slots = T.total > first ? (T.total - first + step - 1) / step : 0;
+    tab.step = step; tab.first = first; tab.n_slots = n_slots;
     w.words.ensure((size_t)std::max<int64_t>(1, n_slots));
     w.counts.ensure((size_t)kBuckets + 1);
-    w.offsets.ensure((size_t)kBuckets + 1);
-    w.positions.ensure((size_t)std::max<int64_t>(1, n_slots));
+    tab.offsets.ensure((size_t)kBuckets + 1);
+    tab.positions.ensure((size_t)std::max<int64_t>(1, n_slots));
     int64_t nblk = ((int64_t)kBuckets + 1 + 2047) / 2048;
     w.bsum.ensure((size_t)nblk + 2);
     static const long spike_ms = env_long("MIBLAST_DEBUG_SPIKE", 0);
@@ -889,15 +1017,21 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     // array) are zeroed again by a pass over the indexed words -- 64 MiB memsets are most of a small target's build otherwise
     if (!w.counts_zero) MB_HIP(hipMemsetAsync(w.counts.p, 0, ((size_t)kBuckets + 1) * 4, s));
     w.counts_zero = false;                                              // (until the clearing pass below is queued: an error in between costs a memset)
+    const long packed_mode = env_long("MIBLAST_SEED_PACKED", 1);       // 0: words from the code bytes; 1: from the packed form for sets of 64 kb and more; 2: always (tests)
+    if (packed_mode == 2 || (packed_mode == 1 && T.total >= (1 << 16))) {
+        // words from the packed target: 0.375 B per base read once instead of 19 code bytes per window
+        pack_strand(T.dev(), T.total, w.pack_t, s);
+        launch_index_words_packed(w.pack_t.p2.p, w.pack_t.pm.p, T.total, step, first, w.words.p, n_slots, w.counts.p, s);
+    } else
     launch_index_words(T.dev(), T.total, step, first, w.words.p, n_slots, w.counts.p, s);
-    w.occ.ensure((size_t)kBuckets / 32);
-    launch_scan_index(w.counts.p, w.offsets.p, w.bsum.p, w.occ.p, s);
-    launch_index_scatter(w.words.p, n_slots, step, first, w.offsets.p, w.counts.p, w.positions.p, s);
+    tab.occ.ensure((size_t)kBuckets / 32);
+    launch_scan_index(w.counts.p, tab.offsets.p, w.bsum.p, tab.occ.p, s);
+    launch_index_scatter(w.words.p, n_slots, step, first, tab.offsets.p, w.counts.p, tab.positions.p, s);
     launch_index_clear(w.words.p, n_slots, w.counts.p, s);
     w.counts_zero = true;
     if (spike_ms) MB_HIP(hipEventRecord(ctx.ev1, s));
     const double t1 = now_s();
-    w.stage.d2h(&ix.n_positions, w.offsets.p + kBuckets, 4, s);
+    w.stage.d2h(&tab.n_positions, tab.offsets.p + kBuckets, 4, s);
     const double t2 = now_s();
     MB_HIP(hipStreamSynchronize(s));
     w.stage.done();
@@ -909,16 +1043,61 @@ static void build_index(Ctx &ctx, const SeqSet &T, int step, Index &ix) {
     }
 }
 
+// the table of (T, step): the resident one (built by the first lane that asks, under the set's lock), or -- MIBLAST_RESIDENT_TABLES=0, or
+// a set that is a view of a parsed file -- one of the context's own, built for this call
+static std::shared_ptr<SeedTable> acquire_table(Ctx &ctx, const SeqSet &T, int step, bool &built) {
+    built = false;
+    const int64_t first = (step - T.origin % step) % step;
+    if (env_long("MIBLAST_RESIDENT_TABLES", 1) == 0 || !T.d_buf) {
+        if (!ctx.ws->own_table) ctx.ws->own_table = std::make_shared<SeedTable>();
+        build_index(ctx, T, step, *ctx.ws->own_table);
+        built = true;
+        return ctx.ws->own_table;
+    }
+    std::shared_ptr<SetDerived> d = derived_of(T);
+    std::lock_guard<std::mutex> lk(d->mu);
+    std::shared_ptr<SeedTable> &t = d->tables[{step, first}];
+    if (!t) {
+        auto fresh = std::make_shared<SeedTable>();
+        build_index(ctx, T, step, *fresh);                              // (synchronises the stream: the table is complete when the lock goes)
+        t = fresh;
+        built = true;
+    }
+    return t;
+}
+
+// '-' strand of Q (device + pinned host copy) and, on request, the packed form of both strands: resident with the set
+static std::shared_ptr<SetDerived> acquire_strands(Ctx &ctx, const SeqSet &Q, bool packed) {
+    std::shared_ptr<SetDerived> d = derived_of(Q);
+    std::lock_guard<std::mutex> lk(d->mu);
+    hipStream_t s = ctx.stream;
+    const int64_t qtot = Q.total;
+    bool queued = false;
+    if (!d->rc_ready) {
+        d->d_rc.ensure((size_t)qtot + 2 * kDevPad);
+        MB_HIP(hipMemsetAsync(d->d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
+        launch_revcomp(Q.dev(), d->d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
+        d->h_rc.ensure((size_t)qtot + 2);
+        MB_HIP(hipMemcpyAsync(d->h_rc.p, d->d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
+        d->rc_ready = true; queued = true;
+    }
+    if (packed && qtot > 0) {
+        if (!d->packed[0].ready) { pack_strand(Q.dev(), qtot, d->packed[0], s); queued = true; }
+        if (!d->packed[1].ready) { pack_strand(d->d_rc.p + kDevPad, qtot, d->packed[1], s); queued = true; }
+    }
+    if (queued) MB_HIP(hipStreamSynchronize(s));                        // (complete before another lane's stream reads them)
+    return d;
+}
+
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions) {
     MB_HIP(hipSetDevice(ctx.device));
     ctx.ws->stage.abort();
-    Index ix;
+    SeedTable ix;
     build_index(ctx, T, step, ix);
-    Workspace &w = *ctx.ws;
     uint32_t *off = (uint32_t *)malloc(((size_t)kBuckets + 1) * 4);
     uint32_t *pos = (uint32_t *)malloc(((size_t)ix.n_positions + 1) * 4);
-    MB_HIP(hipMemcpy(off, w.offsets.p, ((size_t)kBuckets + 1) * 4, hipMemcpyDeviceToHost));
-    if (ix.n_positions) MB_HIP(hipMemcpy(pos, w.positions.p, (size_t)ix.n_positions * 4, hipMemcpyDeviceToHost));
+    MB_HIP(hipMemcpy(off, ix.offsets.p, ((size_t)kBuckets + 1) * 4, hipMemcpyDeviceToHost));
+    if (ix.n_positions) MB_HIP(hipMemcpy(pos, ix.positions.p, (size_t)ix.n_positions * 4, hipMemcpyDeviceToHost));
     // the device scatter fills a bucket in arrival order; the exported table is canonical (ascending)
     for (uint32_t b = 0; b < kBuckets; b++)
         if (off[b + 1] - off[b] > 1) std::sort(pos + off[b], pos + off[b + 1]);
@@ -1003,9 +1182,6 @@ static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpPro
 struct PairJob {                          // one chunk pair of a (possibly batched) call
     const SeqSet *T = nullptr, *Q = nullptr;
     Result *res = nullptr;
-    bool use_ws_rc = true;                // pair 0 keeps its '-' strand in the persistent workspace
-    DevBuf<uint8_t> *slot_rc = nullptr;   // other pairs of a batch: a slot of the calling context's pool (Workspace::rc_pool)
-    PinBuf<uint8_t> *slot_h_rc = nullptr;
     const uint8_t *tc_h = nullptr;
     const uint8_t *qc_h[2] = {nullptr, nullptr};
     const uint8_t *qc_d[2] = {nullptr, nullptr};
@@ -1018,6 +1194,8 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     int64_t valid_windows = -1;           // seed windows of the '+' strand without N / soft-masked bases (counter seed_lookups)
     std::vector<Unit> units;              // anchors of this pair (merged into the call's unit list in pair order)
     double t_begin = 0;
+    std::shared_ptr<SeedTable> table;     // the target's seed table and the query's derived strands, held for the call (seed_phase)
+    std::shared_ptr<SetDerived> strands;
 };
 
 // a launch of the ungapped kernels over ONE seed unit: a strand of a pair (the table lives in the kernel arguments)
@@ -1184,33 +1362,39 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
 
     // ---- seed position table ------------------------------------------------------------------
     Workspace &w = *ctx.ws;
-    Index ix;
-    build_index(ctx, T, p.step, ix);
-    st.t_index = now_s() - t_begin;
+    bool table_built = false;
+    job.table = acquire_table(ctx, T, p.step, table_built);            // resident with the target: built by the first pair that meets it
+    const SeedTable &tab = *job.table;
+    st.t_index = table_built ? now_s() - t_begin : 0.0;
     double tp[8] = {t_begin, now_s(), 0, 0, 0, 0, 0, 0};          // MIBLAST_DEBUG_SPIKE: where a slow seed phase spent its time
 
-    // ---- '-' strand of the query -----------------------------------------------------------------
-    DevBuf<uint8_t> &d_rc = job.use_ws_rc ? w.rc : *job.slot_rc;
-    d_rc.ensure((size_t)qtot + 2 * kDevPad);
-    MB_HIP(hipMemsetAsync(d_rc.p, 0xFF, (size_t)qtot + 2 * kDevPad, s));
-    launch_revcomp(Q.dev(), d_rc.p + kDevPad, Q.d_starts, Q.d_lens, (int)Q.starts.size(), qtot, s);
-    // host copy of the '-' strand (discovery order, anchors, '='/'X' classification) in pinned memory -- the context's buffer for
-    // pair 0 of a call, a pooled slot for the other pairs of a batch: the copy is asynchronous and is complete long before the
-    // first host read (the host half of strand '-' comes after several synchronisations of this stream).
-    PinBuf<uint8_t> &h_rc = job.use_ws_rc ? w.h_rc : *job.slot_h_rc;
-    h_rc.ensure((size_t)qtot + 2);
-    uint8_t *h_rc_p = h_rc.p;
-    MB_HIP(hipMemcpyAsync(h_rc_p, d_rc.p + kDevPad - 1, (size_t)qtot + 2, hipMemcpyDeviceToHost, s));
-    job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = h_rc_p + 1;
-    job.qc_d[0] = Q.dev(); job.qc_d[1] = d_rc.p + kDevPad;
+    // ---- '-' strand of the query (device + pinned host copy: discovery order, anchors, '='/'X' classification read it) and the packed
+    //      form of both strands: resident with the query set, made by the first pair that meets it
+    const bool ordered = env_long("MIBLAST_SEED_ORDERED", 1) != 0;     // q-ordered one-pass search (mb_seed_dense.h); 0: k_seed_search + whole-key sort
+    const long packed_mode = env_long("MIBLAST_SEED_PACKED", 1);
+    const bool packed = ordered && (packed_mode == 2 || (packed_mode == 1 && qtot >= (1 << 16)));
+    job.strands = acquire_strands(ctx, Q, packed);
+    const SetDerived &qs = *job.strands;
+    job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = qs.h_rc.p + 1;
+    job.qc_d[0] = Q.dev(); job.qc_d[1] = qs.d_rc.p + kDevPad;
     const uint8_t *const *qc_d = job.qc_d;
+    // the diagonal of a key is scrambled for the sort: (d * hmul) mod 2^B, B = bits of the diagonal space; k_keys_unhash undoes it
+    const int diag_bits = std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
+    const bool scramble = env_long("MIBLAST_DIAG_SCRAMBLE", 1) != 0;
+    const uint32_t hmask = diag_bits >= 32 ? 0xFFFFFFFFu : ((1u << diag_bits) - 1u);
+    const uint32_t hmul = scramble ? 0x9E3779B1u : 1u;
+    uint32_t hinv = 1u;
+    for (int it = 0; it < 5; it++) hinv *= 2u - hmul * hinv;           // Newton: hmul * hinv = 1 mod 2^32 (hmul odd)
 
     // ---- seed search + ungapped extension, per strand ----------------------------------------------
-    const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
+    // hits per q batch of a strand.  A large pair's strand is ONE batch whenever it can be (no extent[] then, one sort, one launch of the
+    // ungapped kernels): 2^27 hits = 1 GiB of keys per buffer, sized for the 288 GB of an MI355X -- a 30 Mb x 30 Mb chunk pair of the
+    // human-mouse kind has ~10^8 hits per strand.  MIBLAST_HIT_CAP (the shared seed stage's limit, and the tests' way of forcing batches)
+    // wins when it is set.
+    const int64_t hit_cap = getenv("MIBLAST_HIT_CAP") ? env_long("MIBLAST_HIT_CAP", 32l << 20) : env_long("MIBLAST_DENSE_HIT_CAP", 128l << 20);
     const bool one_pass = env_long("MIBLAST_SEED_ONE_PASS", 1) != 0;
     const int sort_bits = 32 + std::max(1, (int)std::ceil(std::log2((double)(ttot + qtot + 2))));
-    DevBuf<int32_t> &extent = w.extent;
-    extent.ensure((size_t)(ttot + qtot + 8));
+    DevBuf<int32_t> &extent = w.extent;                            // (only a strand whose hits need several q batches has one: extent_get / extent_put)
     DevBuf<uint32_t> &qcnt = w.qcnt, &hit_off = w.hit_off;
     qcnt.ensure((size_t)std::max<int64_t>(1, qtot));
     int64_t n_qblk = (qtot + 2047) / 2048;
@@ -1238,12 +1422,22 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             const double t0 = now_s();
             for (auto &row : w.sev) for (hipEvent_t &e : row) if (!e) MB_HIP(hipEventCreate(&e));
             qbsum.ensure(4); w.pin_u64.ensure(16); w.pin_ctr.ensure(2); d_ctr.ensure(2);
-            MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
+            const int64_t ord_words = seed_ord_state_words(qtot);
+            if (ordered) { w.ord_state.ensure(2 * (size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16(2 * (size_t)ord_words * 8), s)); }
+            else MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
             for (int strand = 0; strand < 2; strand++) {
                 MB_HIP(hipEventRecord(w.sev[strand][0], s));
-                launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, keys_a.p + (size_t)strand * capH, capH, qbsum.p + strand, s);
+                if (ordered)
+                    launch_seed_search_ord(qc_d[strand], packed ? qs.packed[strand].p2.p : nullptr, packed ? qs.packed[strand].pm.p : nullptr, qtot, tab.offsets.p, tab.occ.p,
+                                           tab.positions.p, p.transitions, hmul, hmask, keys_a.p + (size_t)strand * capH, capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, s);
+                else
+                    launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p + (size_t)strand * capH, capH, qbsum.p + strand, s);
                 MB_HIP(hipEventRecord(w.sev[strand][1], s));
             }
+            if (ordered) {
+                for (int strand = 0; strand < 2; strand++)
+                    MB_HIP(hipMemcpyAsync(w.pin_u64.p + strand, w.ord_state.p + (size_t)strand * (size_t)ord_words + 1, 8, hipMemcpyDeviceToHost, s));
+            } else
             MB_HIP(hipMemcpyAsync(w.pin_u64.p, qbsum.p, 16, hipMemcpyDeviceToHost, s));
             tp[2] = now_s();
             MB_HIP(hipStreamSynchronize(s));                                       // (1) hits per strand
@@ -1266,16 +1460,17 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                 w.pin_hsps.ensure(2 * kBlind);
                 for (int strand = 0; strand < 2; strand++) {
                     if (!fits[strand] || !nh[strand]) continue;
-                    MB_HIP(hipMemsetAsync(extent.p, 0, up16((size_t)(ttot + qtot + 2) * 4), s));
                     MB_HIP(hipEventRecord(w.sev[strand][2], s));
-                    sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], 0, sort_bits, s);
+                    // (q-ordered keys: a stable sort by the diagonal bits alone)
+                    sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], ordered ? 32 : 0, sort_bits, s);
+                    if (ordered && hmul != 1u) launch_keys_unhash(keys_b.p, (int64_t)nh[strand], hinv, hmask, s);
                     MB_HIP(hipEventRecord(w.sev[strand][3], s));
                     MB_HIP(hipEventRecord(w.sev[strand][4], s));
                     // (sized for the larger strand before the first strand's kernels are queued: growing a buffer later would free
                     //  memory that queued kernels still use; the strand's unsorted keys are free after its sort and hold the records)
                     if (strand == 0 || !fits[0] || !nh[0]) (void)ux_scratch(w, nullptr, (size_t)nh_max, ttot + qtot + 2);
                     const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2);
-                    launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, extent.p, p.xdrop, p.hspthresh,
+                    launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, nullptr, p.xdrop, p.hspthresh,
                                     d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, &uxs, true, s);
                     MB_HIP(hipEventRecord(w.sev[strand][5], s));
                     MB_HIP(hipMemcpyAsync(w.pin_ctr.p + strand, d_ctr.p + strand, sizeof(UngappedCounters), hipMemcpyDeviceToHost, s));
@@ -1318,11 +1513,11 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             continue;
         }
         const double t0 = now_s();
-        MB_HIP(hipMemsetAsync(extent.p, 0, up16((size_t)(ttot + qtot + 2) * 4), s));
+        int32_t *ext_p = nullptr;                                       // set when the strand turns out to need several batches
         std::vector<DevHsp> found;
         int rc_batch = MIBLAST_OK;
         // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
-        auto extend_batch = [&](unsigned long long nh, bool timed_fill, bool q_ordered) -> int {
+        auto extend_batch = [&](unsigned long long nh, bool timed_fill, bool q_ordered, bool hashed) -> int {
             if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one batch (unmasked repeat?)"); return MIBLAST_ELIMIT; }
             strand_hits[strand] += nh;
             st.seed_hits += (int64_t)nh;
@@ -1334,11 +1529,12 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev1, s));
             sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, q_ordered ? 32 : 0, sort_bits, s);       // (k_seed_fill writes the keys in q order)
+            if (hashed && hmul != 1u) launch_keys_unhash(keys_b.p, (int64_t)nh, hinv, hmask, s);
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, up16(sizeof(UngappedCounters)), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
             const UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2);               // (the unsorted keys are free now)
-            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, extent.p, p.xdrop, p.hspthresh, d_hsps.p,
+            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, ext_p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, &uxs, found.empty() && strand_hits[strand] == nh, s);     // (extent[] is all zero in the first batch only)
             MB_HIP(hipEventRecord(ctx.ev4, s));
             UngappedCounters hc;
@@ -1365,23 +1561,38 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         //  8 Mb pair)
         if (one_pass && cap1 > 0 && w.last_strand_hits <= cap1) {
             qbsum.ensure(2);
-            MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
+            const int64_t ord_words = seed_ord_state_words(qtot);
+            if (ordered) { w.ord_state.ensure((size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16((size_t)ord_words * 8), s)); }
+            else MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
             MB_HIP(hipEventRecord(ctx.ev0, s));
-            launch_seed_search(qc_d[strand], qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
+            if (ordered)
+                launch_seed_search_ord(qc_d[strand], packed ? qs.packed[strand].p2.p : nullptr, packed ? qs.packed[strand].pm.p : nullptr, qtot, tab.offsets.p, tab.occ.p,
+                                       tab.positions.p, p.transitions, hmul, hmask, keys_a.p, cap1, w.ord_state.p, s);
+            else
+                launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
             unsigned long long total = 0;
-            w.stage.d2h(&total, qbsum.p, 8, s);
+            w.stage.d2h(&total, ordered ? w.ord_state.p + 1 : qbsum.p, 8, s);
             MB_HIP(hipStreamSynchronize(s));
             w.stage.done();
             if (total <= cap1) {
                 one_pass_done = true;
-                if (total) { rc_batch = extend_batch(total, true, false); if (rc_batch != MIBLAST_OK) return rc_batch; }
+                if (total) { rc_batch = extend_batch(total, true, ordered, ordered); if (rc_batch != MIBLAST_OK) return rc_batch; }
             }
         }
         if (!one_pass_done) {
-        launch_seed_count(qc_d[strand], qtot, w.offsets.p, w.occ.p, p.transitions, qcnt.p, s);
+        launch_seed_count(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, p.transitions, qcnt.p, s);
         launch_block_sums(qcnt.p, qtot, qbsum.p, s);
         MB_HIP(hipMemcpyAsync(h_qbsum.data(), qbsum.p, (size_t)n_qblk * 8, hipMemcpyDeviceToHost, s));
         MB_HIP(hipStreamSynchronize(s));
+        {
+            unsigned long long all = 0;
+            for (int64_t b = 0; b < n_qblk; b++) all += h_qbsum[(size_t)b];
+            if (all > (unsigned long long)hit_cap) {                    // several q batches: the diagonals' extents go from one to the next
+                extent.ensure((size_t)(ttot + qtot + 8));
+                MB_HIP(hipMemsetAsync(extent.p, 0, up16((size_t)(ttot + qtot + 2) * 4), s));
+                ext_p = extent.p;
+            }
+        }
         int64_t b0 = 0;
         while (b0 < n_qblk) {
             // greedy batch of whole 2048-position blocks with at most hit_cap hits
@@ -1395,8 +1606,8 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             keys_a.ensure((size_t)nh);
             MB_HIP(hipEventRecord(ctx.ev0, s));
             launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
-            launch_seed_fill(qc_d[strand], q0, q1, qtot, w.offsets.p, w.occ.p, w.positions.p, p.transitions, hit_off.p, keys_a.p, s);
-            rc_batch = extend_batch(nh, true, env_long("MIBLAST_SORT_DIAG_ONLY", 1) != 0);
+            launch_seed_fill(qc_d[strand], q0, q1, qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, hit_off.p, keys_a.p, s, hmul, hmask);
+            rc_batch = extend_batch(nh, true, env_long("MIBLAST_SORT_DIAG_ONLY", 1) != 0, true);
             if (rc_batch != MIBLAST_OK) return rc_batch;
         }
         }
@@ -1588,8 +1799,9 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         const size_t pb = p.diag_hash16 ? sort_pairs_temp_bytes((int64_t)nh) : 0;
         w.sort_temp.ensure(std::max(tb, pb) + 16);
         if (p.diag_hash16) { w.h16_ka.ensure(nh); w.h16_kb.ensure(nh); w.h16_va.ensure(nh); w.h16_vb.ensure(nh); }
-        // extent[], the units' counters and the run-list counters lie one behind the other: one fill
-        const size_t ext_bytes = up16(((size_t)n_diag + 2) * 4), ctr_bytes = up16(units.size() * sizeof(UngappedCounters)), nh_bytes = 32;
+        // the units' counters and the run-list counters lie one behind the other: one fill.  (No extent[]: the hits of the call are ONE
+        // batch, so no diagonal carries an extent from an earlier one -- the kernels take nullptr for "all zero, nothing kept".)
+        const size_t ext_bytes = 0, ctr_bytes = up16(units.size() * sizeof(UngappedCounters)), nh_bytes = 32;
         w.extent.ensure((ext_bytes + ctr_bytes + nh_bytes) / 4 + 8);
         UngappedCounters *const d_ctr = (UngappedCounters *)((uint8_t *)w.extent.p + ext_bytes);
         unsigned *const d_n_heads = (unsigned *)((uint8_t *)w.extent.p + ext_bytes + ctr_bytes);
@@ -1607,9 +1819,9 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         if (p.diag_hash16) {
             // lastz's 16-bit diagonal hash: every hit extended, the rule per hash class afterwards (mb_hash16.h)
             launch_ungapped_hash16(w.keys_b.p, (int64_t)nh, ut, n_diag, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, d_ctr, &uxs, w.h16_ka.p, w.h16_kb.p, w.h16_va.p,
-                                   w.h16_vb.p, w.sort_temp.p, pb, w.extent.p, s);
+                                   w.h16_vb.p, w.sort_temp.p, pb, nullptr, s);
         } else
-        launch_ungapped(w.keys_b.p, (int64_t)nh, w.heads.p, d_n_heads, ut, n_diag, w.extent.p, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, d_ctr, &uxs, true, s, true);
+        launch_ungapped(w.keys_b.p, (int64_t)nh, w.heads.p, d_n_heads, ut, n_diag, nullptr, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, d_ctr, &uxs, true, s, true);
         MB_HIP(hipEventRecord(ctx.ev0, s));
         constexpr size_t kBlind = 1 << 16;                                          // HSPs copied back before their number is known
         w.pin_ctr.ensure(units.size());
@@ -1712,11 +1924,17 @@ static std::vector<std::pair<int32_t, int32_t>> n_runs_of(const uint8_t *codes, 
 // The N runs of a resident set are found once, when the set is made resident (upload_seqset; a set the device cuts out of another one --
 // seqset_unaligned -- at its first call), and kept for as long as the set lives: the genomes of a phase take part in call after call,
 // and scanning target and both strands of the query was a third of a pair's host half.  All runs, per set, keyed by the set's host
-// image; the '-' strand's runs are the '+' strand's mirrored contig by contig.
+// image AND its length (a block view of a parsed file shares its parent's pointer -- block 0 -- but not its length); the '-' strand's
+// runs are the '+' strand's mirrored contig by contig.
 namespace {
+struct NRunKey {
+    const uint8_t *host; int64_t total;
+    bool operator==(const NRunKey &o) const { return host == o.host && total == o.total; }
+};
+struct NRunKeyHash { size_t operator()(const NRunKey &k) const { return std::hash<const void *>()(k.host) ^ (std::hash<int64_t>()(k.total) * 0x9E3779B97F4A7C15ull); } };
 struct NRunCache {
     std::mutex mu;
-    std::unordered_map<const uint8_t *, std::shared_ptr<const std::vector<std::pair<int32_t, int32_t>>>> runs;
+    std::unordered_map<NRunKey, std::shared_ptr<const std::vector<std::pair<int32_t, int32_t>>>, NRunKeyHash> runs;
 };
 NRunCache &n_run_cache() { static NRunCache *c = new NRunCache(); return *c; }
 }  // namespace
@@ -1725,25 +1943,25 @@ static std::shared_ptr<const std::vector<std::pair<int32_t, int32_t>>> n_runs_ca
     NRunCache &c = n_run_cache();
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.runs.find(S.host());
+        auto it = c.runs.find(NRunKey{S.host(), S.total});
         if (it != c.runs.end()) return it->second;
     }
     auto made = std::make_shared<const std::vector<std::pair<int32_t, int32_t>>>(n_runs_of(S.host(), S.total, 1));
     std::lock_guard<std::mutex> lk(c.mu);
-    return c.runs.emplace(S.host(), made).first->second;
+    return c.runs.emplace(NRunKey{S.host(), S.total}, made).first->second;
 }
 void note_n_runs(const SeqSet &S) { if (S.total > 0) (void)n_runs_cached(S); }
 void forget_n_runs(const SeqSet &S) {
     NRunCache &c = n_run_cache();
     std::lock_guard<std::mutex> lk(c.mu);
-    c.runs.erase(S.host());
+    c.runs.erase(NRunKey{S.host(), S.total});
 }
 // runs of at least min_len bases; mirrored = in the coordinates of the contig-wise reverse complement
 static std::vector<std::pair<int32_t, int32_t>> n_runs_for(const SeqSet &S, int32_t min_len, bool mirrored) {
     const auto all = n_runs_cached(S);
     std::vector<std::pair<int32_t, int32_t>> out;
     for (const auto &r : *all) {
-        if (r.second - r.first < min_len) continue;
+        if (r.second - r.first < min_len || r.first < 0 || (int64_t)r.second > S.total) continue;      // (runs lie inside [0, total) by construction)
         if (!mirrored) { out.push_back(r); continue; }
         const int cg = S.contig_of(r.first);
         const int32_t c0 = (int32_t)S.starts[(size_t)cg], c1 = c0 + (int32_t)S.lens[(size_t)cg];
@@ -3118,12 +3336,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     for (size_t k = 0; k < n; k++) {
         store.emplace_back(new PairJob());
         PairJob &j = *store.back();
-        j.T = Ts[k]; j.Q = Qs[k]; j.res = results[k]; j.use_ws_rc = (k == 0);
-        if (k > 0) {
-            Workspace &w0 = *ctx.ws;
-            while (w0.rc_pool.size() < k) w0.rc_pool.emplace_back(new Workspace::RcSlot());
-            j.slot_rc = &w0.rc_pool[k - 1]->d; j.slot_h_rc = &w0.rc_pool[k - 1]->h;
-        }
+        j.T = Ts[k]; j.Q = Qs[k]; j.res = results[k];
         j.defer_host = n > 1;
         jobs.push_back(&j);
     }

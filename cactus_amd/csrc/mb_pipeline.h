@@ -40,6 +40,7 @@ int ctx_set_priority(Ctx &ctx, int level);
 void ctx_pair_streams(Ctx &ctx);     // the context's stream and its lanes' on hardware queues of their own
 void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
+void drop_derived();                 // frees what the library keeps with resident sets: seed tables, '-' strands, packed strands (made again on demand)
 // outgroup trimming on the device (mb_pipeline.cpp): what no alignment of `paf` covers of the resident query set, as a new resident set
 // (n items in one call; outs[k] is left empty and nothing_left[k] set when every base of Qs[k] is covered)
 int seqset_unaligned(Ctx &ctx, size_t n, const SeqSet *const *Qs, const char *const *pafs, const size_t *paf_lens, int64_t min_size, int64_t flank,

@@ -115,7 +115,7 @@ __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, 
         const unsigned long long nk = keys[i + 1];
         dirty = (uint32_t)(nk >> 32) == dq && q_end + br >= (int32_t)(uint32_t)nk;
     }
-    if (sc.extent_live && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != dq)) dirty |= sc.extent[dq] >= q_end;
+    if (sc.extent_live && sc.extent && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != dq)) dirty |= sc.extent[dq] >= q_end;
     if (dirty) atomicOr(&sc.dirty_bits[dq >> 5], 1u << (dq & 31u));
     uint32_t x = cols;
     const int score = best_l + best_r;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
             }
             n_kept++; n_cols += cols;
             // the last hit of the run leaves the diagonal's extent
-            if ((uint32_t)(nk >> 32) != dq) extent[dq] = (int32_t)(uint32_t)key + (int32_t)(uint32_t)rc;
+            if ((uint32_t)(nk >> 32) != dq) extent_put(extent, dq, (int32_t)(uint32_t)key + (int32_t)(uint32_t)rc);
         } else if (is_dirty && !is_long && (uint32_t)(pk >> 32) != dq) {
             const unsigned slot = atomicAdd(&n_dbuf, 1u);                // (LDS)
             if (slot < kDirtyBuf) dbuf[slot] = (unsigned)i;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void k_ux_resolve(const unsigned long long *__
                 n_ext = 0; n_cols = 0; cur = u;
             }
         }
-        int32_t ext = extent[dq];
+        int32_t ext = extent_get(extent, dq);
         while (true) {
             const int32_t q_end = (int32_t)(uint32_t)key;
             if (q_end > ext) {
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_ux_resolve(const unsigned long long *__
             key = keys[k];
             if ((uint32_t)(key >> 32) != dq) break;
         }
-        extent[dq] = ext;
+        extent_put(extent, dq, ext);
     }
     unit_count(ctr, cur, n_ext, n_cols);                             // (one pair of atomics per wave)
 }

@@ -19,6 +19,12 @@ __device__ __forceinline__ const SeedUnit *unit_table(const UnitTab &ut) {
 inline const SeedUnit *unit_table(const UnitTab &ut) { return ut.tab; }
 #endif
 
+// extent[] of a launch -- the right end of the last extension on a diagonal, carried from one q-ordered batch of a strand's hits to the
+// next.  A strand whose hits are ONE batch needs none: the pipeline passes nullptr (every diagonal starts at 0, nothing is kept), which
+// saves the fill of 4 B per diagonal (240 MB per strand of a 30 Mb x 30 Mb chunk pair) and a random read + write per diagonal run.
+__device__ __forceinline__ int32_t extent_get(const int32_t *__restrict__ extent, const uint32_t dq) { return extent ? extent[dq] : 0; }
+__device__ __forceinline__ void extent_put(int32_t *__restrict__ extent, const uint32_t dq, const int32_t v) { if (extent) extent[dq] = v; }
+
 struct UnitRef {
     const uint8_t *tc, *qc;
     int64_t qoff;                             // t_end = (int64_t)dq - qoff + q_end      (qoff = dbase + qtot)

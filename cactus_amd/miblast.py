@@ -83,6 +83,7 @@ def load() -> C.CDLL:
         "miblast_seqset_from_fasta_file": (C.c_int, [vp, cp, P(vp)]),
         "miblast_seqset_from_fasta_mem": (C.c_int, [vp, cp, C.c_size_t, P(vp)]),
         "miblast_seqset_free": (None, [vp]),
+        "miblast_drop_derived": (None, []),
         "miblast_seqsets_unaligned": (C.c_int, [vp, C.c_size_t, P(vp), P(cp), P(C.c_size_t), i64, i64, P(vp)]),
         "miblast_seqset_fasta": (C.c_int, [vp, P(vp), P(C.c_size_t)]),
         "miblast_seqset_n_contigs": (i32, [vp]),
@@ -119,7 +120,7 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_set_host_threads",
                     "miblast_ctx_create", "miblast_ctx_set_priority",
                     "miblast_ctx_destroy", "miblast_seqset_from_fasta_file", "miblast_seqset_from_fasta_mem",
-                    "miblast_seqset_free", "miblast_seqsets_unaligned", "miblast_seqset_fasta", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
+                    "miblast_seqset_free", "miblast_drop_derived", "miblast_seqsets_unaligned", "miblast_seqset_fasta", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",
                     "miblast_seqset_start", "miblast_seqset_len", "miblast_align", "miblast_align_pairs", "miblast_result_free",
                     "miblast_result_paf", "miblast_result_stats", "miblast_result_hsps", "miblast_result_alns",
                     "miblast_result_ops", "miblast_align_files", "miblast_multi_create", "miblast_multi_destroy", "miblast_multi_num_gpu",
@@ -156,6 +157,11 @@ def device_count() -> int:
     if n < 0:                                  # an invalid $MIBLAST_DEVICE_MAP is an error, not a shorter device list
         _check(n)
     return n
+
+
+def drop_derived() -> None:
+    """Frees what the library keeps with resident sets (seed tables per --step, '-' strands, packed strands): made again on demand."""
+    load().miblast_drop_derived()
 
 
 def set_host_threads(n: int = 0) -> int:

@@ -49,15 +49,12 @@ def gather_bytes(payload: bytes, dist, rank: int, world_size: int, device) -> Op
         if payload:
             dist.send(torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device), dst=0)
         return None
-    parts = [payload]
-    for src in range(1, world_size):
-        if sizes[src] == 0:
-            parts.append(b"")
-            continue
-        buf = torch.empty(sizes[src], dtype=torch.uint8, device=device)
-        dist.recv(buf, src=src)
-        parts.append(buf.cpu().numpy().tobytes())
-    return parts
+    # all receives are posted before any is waited for: the peers' transfers overlap (each has a link of its own to GPU 0)
+    bufs = {src: torch.empty(sizes[src], dtype=torch.uint8, device=device) for src in range(1, world_size) if sizes[src]}
+    reqs = [dist.irecv(buf, src=src) for src, buf in bufs.items()]
+    for r in reqs:
+        r.wait()
+    return [payload] + [bufs[src].cpu().numpy().tobytes() if src in bufs else b"" for src in range(1, world_size)]
 
 
 def _frame(index: int, paf: bytes) -> bytes:

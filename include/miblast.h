@@ -100,6 +100,12 @@ typedef struct miblast_seqset miblast_seqset;
 int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_seqset **out);
 int miblast_seqset_from_fasta_mem(miblast_ctx *ctx, const char *buf, size_t len, miblast_seqset **out);
 void miblast_seqset_free(miblast_seqset *s);
+/* What the library derives from a resident set stays resident with it: the seed position table of a target per --step (SURVEY 8e:
+ * "index built once per owned target chunk, stays resident" while the query chunks of make_chunked_alignments' job list stream
+ * through it, /root/reference/src/cactus/paf/local_alignment.py:395-405), the '-' strand and the packed form of a query.  They go
+ * with the set (miblast_seqset_free); this call frees all of them at once -- they are made again by the next job that needs them
+ * (a benchmark step that must pay for its tables calls it first).  Not while an alignment call is running.                       */
+void miblast_drop_derived(void);
 /* Outgroup trimming between two blast calls, on the device.  Replaces, for the n ingroup -> outgroup chains of a dependency level at
  * once, the pipe `paffy to_bed --excludeAligned --binary --minSize N` | `faffy extract --flank F` and the re-reading of its output
  * (/root/reference/src/cactus/paf/local_alignment.py:460-499, trimMinSize / trimFlanking of cactus_progressive_config.xml:116-117):

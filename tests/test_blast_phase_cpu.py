@@ -189,6 +189,69 @@ def test_calls_in_flight_never_exceed_the_aligners_width():
     assert state["peak"] == 2
 
 
+def test_width_holds_with_free_jobs_in_flight_and_trimming():
+    """with concurrent >= 3 the ingroup pairs go out as jobs nothing waits for; the chains' single-group levels and the
+    trim_resident calls must pass the same gate -- never more than `concurrent` calls on the aligner at a time -- and a level that
+    raises must not leave free jobs behind."""
+    import threading
+    import time
+    calls = bp.blast_phase_calls(bp.parse_newick(bp.EVOLVER_MAMMALS_TREE))
+    fasta = {n: b">%s\nACGT\n" % n.encode() for n in {c.target for c in calls} | {c.query for c in calls}}
+    width = 3
+    state = {"now": 0, "peak": 0, "free": ["ctx"] * width, "trims": 0}
+    lock = threading.Lock()
+
+    def enter():
+        with lock:
+            state["free"].pop()                                     # IndexError here = more calls than contexts
+            state["now"] += 1
+            state["peak"] = max(state["peak"], state["now"])
+
+    def leave():
+        with lock:
+            state["now"] -= 1
+            state["free"].append("ctx")
+
+    def align_batch(pairs, opts):
+        enter()
+        time.sleep(0.03 if any(q == b"left" for _, q in pairs) else 0.12)     # (ingroup / level-0 calls are the slow ones: still out when level 1 starts)
+        leave()
+        return [b"x" for _ in pairs]
+
+    class Left(bytes):
+        def fasta_bytes(self):
+            return bytes(self)
+
+    def trim_resident(items, min_size, flank):
+        enter()
+        state["trims"] += 1
+        time.sleep(0.03)
+        leave()
+        return [Left(b"left") for _ in items]
+
+    align_batch.concurrent = width
+    align_batch.trim_resident = trim_resident
+    opts = lambda d: "set-%d" % (0 if d < 0.2 else 1)      # noqa: E731
+    import cactus_amd.blast_phase as mod
+    saved = (mod.invert, mod.dechunk_query)
+    mod.invert = mod.dechunk_query = lambda paf: paf       # (the text steps are not under test: the PAFs here are not PAF)
+    try:
+        bp.run_blast_phase(fasta, calls, opts, align_batch)
+        assert state["trims"] >= 2 and state["peak"] <= width and state["now"] == 0
+
+        def failing(pairs, opts):
+            if any(q == b"left" for _, q in pairs):
+                raise RuntimeError("boom")
+            return align_batch(pairs, opts)
+        failing.concurrent = width
+        failing.trim_resident = trim_resident
+        with pytest.raises(RuntimeError):
+            bp.run_blast_phase(fasta, calls, opts, failing)
+        assert state["now"] == 0                                    # nothing of the failed run is still on the aligner
+    finally:
+        mod.invert, mod.dechunk_query = saved
+
+
 def test_jobs_nothing_waits_for_run_beside_the_chains(olz):
     """An aligner that takes three calls at a time: the ingroup pairs (only the final files take their output) are handed over as
     jobs of their own and level 1 starts before they are back; the phase's files equal those of the one-call-at-a-time run."""

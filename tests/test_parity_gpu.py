@@ -38,6 +38,37 @@ def test_case_matches_oracle(gpu_ctx, olz, monkeypatch, name, tf, qf, args):
         assert got.stats[k] == want["counters"][k], k
 
 
+@pytest.mark.parametrize("env", [
+    {"MIBLAST_SEED_PACKED": "2"},                                       # seed words of target and both strands from the packed form (2 bits + mask bit), whatever the size
+    {"MIBLAST_SEED_PACKED": "0"},                                       # ... from the code bytes
+    {"MIBLAST_SEED_PACKED": "2", "MIBLAST_SEED_FUSED": "0"},            # strands one after the other
+    {"MIBLAST_SEED_ORDERED": "0"},                                      # round 3's search: keys in arrival order, sorted as whole keys
+    {"MIBLAST_DIAG_SCRAMBLE": "0"},                                     # keys sorted by the plain diagonal
+    {"MIBLAST_RESIDENT_TABLES": "0"},                                   # a table per call in the context's own memory
+    {"MIBLAST_SEED_PACKED": "2", "MIBLAST_HIT_CAP": "3000"},            # q batches (two-pass path, extent[] carried from batch to batch)
+], ids=lambda e: ",".join(f"{k[8:].lower()}={v}" for k, v in e.items()))
+def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
+    """The seed stage of a large pair (mb_seed_dense.h: packed strands, q-ordered one-pass search with LDS-staged keys, scrambled
+    diagonals, tables and '-' strands resident with their sets) on every case, with each of its switches: same bytes, HSP list in
+    discovery order and counters as the oracle's.  Every case runs twice on the same resident sets, so the second call takes the
+    both-strands-in-one-go path with the tables of the first."""
+    monkeypatch.setenv("MIBLAST_SEED_BATCHED", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, tf, qf, args in CASES:
+        pm = _params(args)
+        T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+        want = olz.align(tf, qf, _oracle_params(olz, pm))
+        for rep in range(2):
+            got = gpu_ctx.align(T, Q, pm)
+            assert got.paf == want["paf"], (name, rep)
+            assert got.hsps == want["hsps"], (name, rep)
+            assert got.alns == want["alns"] and got.ops == want["ops"], (name, rep)
+            for k in COUNTERS:
+                assert got.stats[k] == want["counters"][k], (name, rep, k)
+        T.close(); Q.close()
+
+
 @pytest.mark.parametrize("kernel", ["lane", "ux", "grp"])
 def test_every_ungapped_kernel_matches_oracle(gpu_ctx, olz, monkeypatch, kernel):
     """The short diagonal runs have three interchangeable kernels (launch_ungapped: a run per lane; the level-synchronous
