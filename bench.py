@@ -75,9 +75,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("evolver", "pair", "chr20"), default="evolver",
+    ap.add_argument("--workload", choices=("evolver", "pair", "chr20", "hm"), default="evolver",
                     help="evolver: BASELINE configs[2] stand-in (default; weak scaling: every GPU its own phase); pair: configs[1], one synthetic "
-                         "chunk pair per GPU; chr20: configs[3], ONE genome pair whose chunk pairs are dealt to the GPUs (strong scaling)")
+                         "chunk pair per GPU; chr20: configs[3], ONE genome pair whose chunk pairs are dealt to the GPUs (strong scaling); hm: the "
+                         "scaled human-mouse stand-in of configs[4], same sharding")
+    ap.add_argument("--chunk-legs", type=int, default=1, help="evolver workload: also time the chunk-scale configurations chr20 (configs[3]) and hm (configs[4] stand-in) "
+                                                              "on this GPU, every chunk pair checked against its oracle digest (0 = skip); reported under chr20 / hm")
     ap.add_argument("--chr20-bases", type=int, default=64_444_167, help="chr20 workload: bases of the synthetic chromosome (SURVEY 8d config 4)")
     ap.add_argument("--chr20-chunk", type=int, default=30_000_000,
                     help="chr20 workload: chunkSize (cactus_progressive_config.xml:90; overlap 10 000, :92).  A finer chunking gives more pairs to deal "
@@ -273,46 +276,51 @@ class PairWorkload:
         return agg, b"".join(r.paf for r in rs)
 
 
-class Chr20Workload:
-    """BASELINE configs[3]: ONE genome pair -- a synthetic chr20 against a 1.3 % diverged, half soft-masked copy --
-    chunked exactly as the CPU path chunks it (faffy chunk -c chunkSize -o 10000: cactus_progressive_config.xml:90-92,
-    /root/reference/src/cactus/paf/local_alignment.py:378-387), every (target chunk, query chunk) pair an independent job (:395-405)
-    with the option set of divergence "one".  The chunk pairs are dealt to the ranks longest first (cactus_amd.multigpu.assign_pairs);
-    a rank aligns its share in ONE batched call; the only exchange is the gather of the framed PAFs to rank 0, which strings them
-    together in chunk-pair order -- the bytes do not depend on the number of GPUs.  Total work is fixed: STRONG scaling."""
+class ChunkWorkload:
+    """The chunk-scale configurations (cactus_amd/workloads.py): `chr20` = BASELINE configs[3], `hm` = the scaled
+    stand-in for configs[4] (config 5).  ONE genome pair, chunked exactly as the CPU path chunks it (faffy chunk -c chunkSize -o 10000:
+    cactus_progressive_config.xml:90-92, /root/reference/src/cactus/paf/local_alignment.py:378-387), every (target chunk, query chunk)
+    pair an independent job (:395-405) with the option set of its divergence.  The work units -- chunk pairs, or with --split-pairs
+    (chunk pair, query half) -- are dealt to the ranks longest first (cactus_amd.multigpu); a rank aligns its share in ONE batched call,
+    target-major: a target chunk's seed table is built once per step and stays resident while the query chunks stream through it (SURVEY
+    8e; the library keeps it with the set, miblast_drop_derived at the start of every step makes the step pay for it).  The only exchange
+    is the gather of the framed PAFs to rank 0, which strings them together in chunk-pair order -- the bytes do not depend on the number
+    of GPUs.  Total work is fixed: STRONG scaling."""
 
-    OPTIONS = "--step=2 --ambiguous=iupac,100,100 --ydrop=3000 --notransition --queryhspbest=100000"      # set "one", cactus_progressive_config.xml:131
-
-    def __init__(self, a, ctx, rank, world):
-        from cactus_amd import gen, miblast
+    def __init__(self, a, ctx, rank, world, which):
+        from cactus_amd import miblast, workloads
         from cactus_amd.multigpu import assign_pairs
-        self.ctx, self.rank, self.world = ctx, rank, world
-        self.pm = miblast.params_from_args(self.OPTIONS.split())
-        n, chunk, overlap = a.chr20_bases, a.chr20_chunk, 10_000
-        t, q = gen.make_pair(n, 3001, sub_rate=0.013, indel_rate=0.002, mask_frac=0.5)
-
-        def chunks(name, seq):                    # faffy chunk: records NAME|SEQLEN|START of chunkSize + overlapSize bases, one file per chunkSize bases
-            return [gen.fasta_bytes([(f"{name}|{len(seq)}|{s0}", seq[s0:s0 + chunk + overlap])]) for s0 in range(0, len(seq), chunk)]
-
-        self.tfa, self.qfa = chunks("id=simT|chr20", t), chunks("id=simQ|chr20", q)
-        self.pairs = [(i, j) for i in range(len(self.tfa)) for j in range(len(self.qfa))]
-        self.weights = [float(len(self.tfa[i])) * float(len(self.qfa[j])) for i, j in self.pairs]
+        self.ctx, self.rank, self.world, self.miblast = ctx, rank, world, miblast
+        kw = {}
+        if which == "chr20" and (a.chr20_bases, a.chr20_chunk) != (64_444_167, 30_000_000):
+            kw = dict(bases=a.chr20_bases, chunk=a.chr20_chunk)
+        self.w = w = workloads.by_name(which, **kw)
+        self.OPTIONS = w.options
+        self.pm = miblast.params_from_args(w.options.split())
+        self.tfa, self.qfa, self.pairs = w.tfa, w.qfa, w.pairs
+        self.weights = w.weights()
         self.mine = assign_pairs(self.weights, world)[rank]
         need_t, need_q = sorted({self.pairs[k][0] for k in self.mine}), sorted({self.pairs[k][1] for k in self.mine})
         self.T = {i: ctx.seqset_from_fasta_bytes(self.tfa[i]) for i in need_t}                 # only this rank's chunks go to its HBM
         self.Q = {j: ctx.seqset_from_fasta_bytes(self.qfa[j]) for j in need_q}
-        self.describe = (f"synthetic chr20 x chr20 (BASELINE configs[3], SURVEY 8d config 4): {len(t)} x {len(q)} bp at 1.3 % divergence, half soft-masked, seed 3001; "
-                         f"chunkSize {chunk} + overlap {overlap} -> {len(self.tfa)} x {len(self.qfa)} chunk pairs, option set \"one\", dealt longest first to {world} GPU(s)")
+        self.describe = w.describe + f", dealt longest first to {world} GPU(s)"
+        self.last = {}                                     # pair index -> PAF of the last step (digest check)
+
+    def close(self):
+        for h in list(self.T.values()) + list(self.Q.values()):
+            h.close()
 
     def step(self, keep=None):
         from cactus_amd.multigpu import _frame
         agg = {}
         blob = b""
+        self.miblast.drop_derived()                        # a step builds every seed table, '-' strand and packed strand it uses (once)
         if self.mine:
             sets = [(self.T[self.pairs[k][0]], self.Q[self.pairs[k][1]]) for k in self.mine]
             rs = self.ctx.align_pairs(sets, self.pm) if len(sets) > 1 else [self.ctx.align(*sets[0], self.pm, details=False)]
             add_stats(agg, [r.stats for r in rs])
             blob = b"".join(_frame(k, r.paf) for k, r in zip(self.mine, rs))
+            self.last = {k: r.paf for k, r in zip(self.mine, rs)}
             if keep is not None:
                 keep.extend((self.tfa[self.pairs[k][0]], self.qfa[self.pairs[k][1]], self.OPTIONS, r.paf) for k, r in zip(self.mine, rs))
         else:
@@ -321,14 +329,70 @@ class Chr20Workload:
         return agg, blob
 
     def assemble(self, gathered):
-        """rank 0: the ranks' framed PAFs -> one PAF in chunk-pair order"""
+        """rank 0: the ranks' framed PAFs -> {pair index: PAF} and one PAF in chunk-pair order"""
         from cactus_amd.multigpu import _unframe
         by_index = {}
         for part in gathered:
             for idx, paf in _unframe(part):
                 by_index[idx] = paf
         assert sorted(by_index) == list(range(len(self.pairs))), "a chunk pair is missing from the gather"
+        self.by_index = by_index
         return b"".join(by_index[k] for k in range(len(self.pairs)))
+
+    def digest_check(self, by_index):
+        """every chunk pair's PAF against the CPU oracle's digest of that pair (tests/golden/<key>_pairs.json, written by
+        scripts/oracle_chunk_digests.py: the oracle needs 1 to 60 s per pair, so its runs are committed, not repeated in the bench)"""
+        import hashlib
+        path = os.path.join(ROOT, "tests", "golden", f"{self.w.key}_pairs.json")
+        if not os.path.exists(path):
+            return {"same_bytes": None, "note": f"no committed oracle digests for this variant of the workload ({os.path.basename(path)})"}
+        gold = json.load(open(path))
+        if gold.get("fasta_md5") != hashlib.md5(b"".join(self.tfa + self.qfa)).hexdigest():
+            return {"same_bytes": None, "note": "the committed digests were made from other FASTA bytes (numpy version?)"}
+        bad = [k for k in range(len(self.pairs)) if gold["pairs"][k] is None or hashlib.md5(by_index[k]).hexdigest() != gold["pairs"][k]["paf_md5"]]
+        return {"same_bytes": not bad, "pairs_checked": len(self.pairs), "pairs_differing": len(bad), "kind": "md5 of every chunk pair's PAF against the CPU oracle's (tests/golden/%s)" % os.path.basename(path),
+                "oracle_cpu_seconds_all_pairs": sum(p["oracle_seconds"] for p in gold["pairs"] if p),
+                "oracle_dp_cells": sum(p["dp_cells"] for p in gold["pairs"] if p), "oracle_seed_hits": sum(p["seed_hits"] for p in gold["pairs"] if p)}
+
+    def cpu_sample(self, by_index, budget_s=25.0):
+        """the bounded CPU sample of a chunk-scale workload: the chunk pairs the oracle is quickest on (by its committed run times),
+        as many as fit ~25 s, run live on this box and diffed byte for byte"""
+        path = os.path.join(ROOT, "tests", "golden", f"{self.w.key}_pairs.json")
+        order = list(range(len(self.pairs)))
+        if os.path.exists(path):
+            gold = json.load(open(path))["pairs"]
+            order.sort(key=lambda k: gold[k]["oracle_seconds"] if gold[k] else 1e9)
+            pick, t = [], 0.0
+            for k in order:
+                sec = gold[k]["oracle_seconds"] if gold[k] else 60.0
+                if pick and t + sec > budget_s:
+                    break
+                pick.append(k); t += sec
+        else:
+            pick = [min(order, key=lambda k: self.weights[k])]
+        calls = [(self.tfa[self.pairs[k][0]], self.qfa[self.pairs[k][1]], self.OPTIONS, by_index[k]) for k in pick]
+        out = cpu_baseline(calls, None, f"{len(pick)} of the {len(self.pairs)} chunk pairs (the quickest for the oracle: pairs {pick}) of: " + self.describe, node=False)
+        out["sample_pairs"] = pick
+        return out
+
+    def b_read(self, tot, per, elapsed_step_s):
+        """SURVEY 8d's algorithmic READ bytes of one step, per stage and whole-leg, against the HBM roof.  T, Q in bases; a target's table is
+        built once per step (target-major), a query's strands are packed once."""
+        step, nvar = self.pm.step, (13 if self.pm.transitions else 1)
+        t_bases = sum(len(x) for x in self.tfa) * 60 / 61.0        # (FASTA bytes -> bases: 60 columns + newline)
+        q_bases = sum(len(x) for x in self.qfa) * 60 / 61.0
+        look, hits, cols, rows = tot["seed_lookups"] / per, tot["seed_hits"] / per, tot["ungapped_cols"] / per, tot["dp_rows"] / per
+        stages = {
+            "index": 1.375 * t_bases,                                         # 1 B/base codes in, 0.375 B/base packed read back for the words
+            "seed_search": 0.375 * q_bases * 2 * len(self.tfa) + 8.0 * look + 4.0 * hits,      # packed strands streamed per target chunk, two bucket bounds per look-up, a position per hit
+            "ungapped": 8.0 * hits + 0.5 * cols,                              # the hit keys + 2 x 0.25 B per column
+            "gapped": 0.75 * rows,                                           # 2 x 0.375 B per DP row (both sequences); the traceback's read-back is of the same order
+        }
+        total = sum(stages.values())
+        return {"bytes_per_step": {k: float(v) for k, v in stages.items()}, "bytes_total": float(total),
+                "achieved_GBps": total / elapsed_step_s / 1e9, "peak_GBps": HBM_PEAK_GBS * self.world, "frac": total / elapsed_step_s / 1e9 / (HBM_PEAK_GBS * self.world),
+                "note": "SURVEY 8d read terms only, nothing padded; the gapped DP is VALU / issue bound (its bytes are negligible), so a step in which it is "
+                        "a third of the time cannot come near the roof: see per-stage kernel times"}
 
 
 def cpu_throttle_state():
@@ -438,13 +502,14 @@ def run_rank(a):
     host_threads = share_host_cores(int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else miblast.set_host_threads(0)
     ctx = miblast.Context(local_rank)
     coll_dev = torch.device("cuda", local_rank) if coll_backend != "gloo" else torch.device("cpu")
-    work = EvolverPhase(a, ctx, rank) if a.workload == "evolver" else Chr20Workload(a, ctx, rank, world) if a.workload == "chr20" else PairWorkload(a, ctx, rank)
+    sharded = a.workload in ("chr20", "hm")
+    work = EvolverPhase(a, ctx, rank) if a.workload == "evolver" else ChunkWorkload(a, ctx, rank, world, a.workload) if sharded else PairWorkload(a, ctx, rank)
     gathered = {}
 
     def gather(paf: bytes):
         """final hit list -> rank 0 (RCCL over xGMI); the sharded workload strings the ranks' shares together there"""
         gathered["last"] = gather_bytes(paf, dist, rank, world, coll_dev)
-        if a.workload == "chr20" and rank == 0:
+        if sharded and rank == 0:
             gathered["paf"] = work.assemble(gathered["last"])
 
     def sync():
@@ -467,18 +532,18 @@ def run_rank(a):
     tot = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
 
     if rank == 0:
-        per = a.steps * (1 if a.workload == "chr20" else world)      # per-step figures: of one rank's phase (weak) / of the whole sharded job (strong)
+        per = a.steps * (1 if sharded else world)      # per-step figures: of one rank's phase (weak) / of the whole sharded job (strong)
         out = {
             "metric": "gapped X-drop Gcell/s (blast phase, whole job)",
             "value": tot["dp_cells"] / elapsed / 1e9,
             "unit": "Gcell/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "step_ms_spread": step_spread,
-            "higher_is_better": True, "scaling": "strong" if a.workload == "chr20" else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": work.describe,
                        "sharding": ("the chunk pairs of ONE genome pair dealt longest first to the GPUs (independent jobs, no data-path collective); framed PAFs "
-                                    "gathered to rank 0 and strung together in chunk-pair order") if a.workload == "chr20" else
+                                    "gathered to rank 0 and strung together in chunk-pair order") if sharded else
                                    "every GPU runs its own copy of the phase (chunk pairs are independent jobs); gather of the PAF to rank 0",
                        "collective_backend": coll_backend, "host_threads_per_rank": host_threads,
                        "paf_bytes_gathered_per_step": sum(len(x) for x in gathered["last"]) if gathered.get("last") else 0},
@@ -518,19 +583,23 @@ def run_rank(a):
                                                     "VALU instruction of a wave64 takes ~4 cycles (DESIGN.md section 5): half that peak, given as peak_measured"}
         except Exception as e:                               # noqa: BLE001  (never lose the line over a device-property quirk)
             out["roofline"]["valu"] = {"error": str(e)}
-        if a.workload == "chr20":
+        if sharded:
             import hashlib
             out["config"]["paf_md5"] = hashlib.md5(gathered["paf"]).hexdigest()
             out["config"]["paf_bytes"] = len(gathered["paf"])
             out["config"]["chunk_pairs_per_rank"] = [len(x) for x in __import__("cactus_amd.multigpu", fromlist=["assign_pairs"]).assign_pairs(work.weights, world)]
+            out["parity"] = work.digest_check(work.by_index)
+            out["hbm_read"] = work.b_read(tot, per, elapsed / a.steps)
+            out["config"]["residency"] = ("chunks resident in HBM before the timed region (parse + upload excluded); seed tables, '-' strands and packed strands "
+                                          "are dropped at the start of every step and built once per step and chunk (target-major, SURVEY 8e)")
         out["roofline"]["overlap_note"] = ("a call of several pairs runs the gapped stages of two groups of its pairs on two streams (MIBLAST_GAPPED_LANES=2): their DP launches "
                                            "share the GPU, so a launch's HIP-event duration -- the denominator here -- is longer than it would be alone, and the "
                                            "durations add up to more than the wall time they cover")
         if world > 1:
             # the extra legs and the CPU baseline are single-GPU figures: measured at N = 1 only (the ranks of a scaling run do not wait
             # for rank 0 to time them)
-            a.primates_leg = a.pair_leg = a.batch_leg = a.seed_leg = a.chain_leg = 0
-            if a.workload != "chr20":
+            a.primates_leg = a.pair_leg = a.batch_leg = a.seed_leg = a.chain_leg = a.chunk_legs = 0
+            if not sharded:
                 a.cpu_sample = 0
             out["legs_note"] = "primates / pair_1mb / batched_pairs / seed_stage / chain_stage / cpu_baseline are measured at --gpus 1 only"
         if a.workload == "evolver" and a.primates_leg > 0:
@@ -545,14 +614,14 @@ def run_rank(a):
                                                 gapped_gcells_per_s_kernel=out["batched_pairs"].get("gapped_gcells_per_s_kernel"))
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, ctx)
+        if a.workload == "evolver" and a.chunk_legs > 0:
+            for which in ("chr20", "hm"):
+                out[which] = chunk_leg(a, ctx, which)
         if a.chain_leg > 0:
             out["chain_stage"] = chain_stage_leg(a, ctx)
         if a.cpu_sample > 0:
-            if a.workload == "chr20":
-                # the oracle needs a minute per 30 Mb x 30 Mb chunk pair: the bounded sample is the smallest pair of rank 0's share
-                if keep:
-                    small = min(keep, key=lambda c: len(c[0]) * len(c[1]))
-                    out["cpu_baseline"] = cpu_baseline([small], None, "the smallest chunk pair of rank 0's share of: " + work.describe)
+            if sharded:
+                out["cpu_baseline"] = work.cpu_sample(work.by_index)
             else:
                 out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / per, work.describe)
         print(json.dumps(out), flush=True)
@@ -616,6 +685,34 @@ def batch_leg(a, ctx):
            "roofline": {k: r[k] for k in ("achieved", "frac", "launch_ms", "cells_per_launch")}}
     for t, q in w.sets:
         t.close(); q.close()
+    return out
+
+
+def chunk_leg(a, ctx, which):
+    """A chunk-scale configuration as a leg of the default line (N = 1): configs[3] (chr20) or the configs[4] stand-in (hm), on the same
+    terms as `--workload chr20|hm`: every chunk pair of the genome pair in one batched call per step, target-major, every pair's PAF
+    checked against the oracle's digest, a bounded live CPU sample, SURVEY 8d's read bytes against the HBM roof."""
+    import hashlib
+    w = ChunkWorkload(a, ctx, 0, 1, which)
+    steps, warm = (3, 1) if which == "chr20" else (3, 1)
+    elapsed, tot, _ = timed_steps(w, steps, warm, lambda: None, lambda paf: None)
+    by_index = dict(w.last)
+    paf = b"".join(by_index[k] for k in range(len(w.pairs)))
+    r = dp_roofline(tot, "none")
+    out = {"workload": w.describe, "chunk_pairs": len(w.pairs), "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
+           "seeds_per_s": tot["seed_hits"] / elapsed, "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
+           "dp_cells_per_step": tot["dp_cells"] / steps, "seed_hits_per_step": tot["seed_hits"] / steps, "alignments_per_step": tot["alignments"] / steps,
+           "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
+           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3) / 1e9,
+           "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / steps, "ydrop_busy": tot["t_dp_busy_ms"] / steps, "ungapped": tot["t_ungapped_kernel_ms"] / steps,
+                                        "sort": tot["t_sort_ms"] / steps, "seed_search": tot["t_seedfill_ms"] / steps,
+                                        "note": "HIP-event durations summed over the pairs of the call; the seed stages of up to twelve pairs share the GPU, so the sums exceed the wall time they cover"},
+           "paf_md5": hashlib.md5(paf).hexdigest(), "paf_bytes": len(paf),
+           "parity": w.digest_check(by_index), "hbm_read": w.b_read(tot, steps, elapsed / steps),
+           "roofline_dp": {k: r[k] for k in ("achieved", "frac", "launch_ms", "cells_per_launch")}}
+    if a.cpu_sample > 0:
+        out["cpu_baseline"] = w.cpu_sample(by_index)
+    w.close()
     return out
 
 
@@ -693,7 +790,7 @@ def chain_stage_leg(a, ctx):
                              "sample": "the same text through the oracle's six piped processes", "same_bytes": p.returncode == 0 and p.stdout.decode() == out}}
 
 
-def cpu_baseline(kept_calls, dp_cells_gpu, describe):
+def cpu_baseline(kept_calls, dp_cells_gpu, describe, node=True):
     """CPU oracle (kind "port": the in-repo C restatement) on the lastz calls of the last timed step -- the same FASTA bytes and
     option strings, call by call -- timed on this box's host cores, every PAF compared with the GPU's.  Two figures: one core,
     the calls one after the other (1 thread like a lastz job; this run makes the byte diff), and SURVEY 8d's CPU throughput model
@@ -718,6 +815,8 @@ def cpu_baseline(kept_calls, dp_cells_gpu, describe):
            "seeds_per_s": hits / dt, "seconds": dt, "calls": len(kept_calls),
            "same_bytes": same, "calls_differing": n_diff,
            "same_dp_cells": None if dp_cells_gpu is None else int(cells) == int(round(dp_cells_gpu))}
+    if not node:
+        return out
     try:
         out["node"] = cpu_baseline_concurrent(kept_calls, cells, hits)
     except Exception as e:                                   # noqa: BLE001  (the figure above stands on its own)

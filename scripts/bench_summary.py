@@ -17,7 +17,7 @@ for path in sys.argv[1:]:
     if "cpu_baseline" in d:
         c = d["cpu_baseline"]
         print("  cpu_baseline:", {k: c[k] for k in c if k not in ("sample",)})
-    for leg in ("pair_1mb", "batched_pairs", "seed_stage", "chain_stage", "primates", "chr20"):
+    for leg in ("pair_1mb", "batched_pairs", "seed_stage", "chain_stage", "primates", "chr20", "hm"):
         if leg in d:
             x = d[leg]
             print(f"  {leg}:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in x.items() if k not in ("workload", "bytes_note", "cpu_baseline", "note")},
