@@ -24,7 +24,7 @@ class Stats(C.Structure):
 
 
 EXPORTED_SYMBOLS = ("mipaf_set_from_mem", "mipaf_set_from_file", "mipaf_set_free", "mipaf_set_size", "mipaf_set_text", "mipaf_set_write",
-                    "mipaf_invert", "mipaf_dechunk_text", "mipaf_unaligned_fasta", "mipaf_chain_params_default", "mipaf_chain", "mipaf_tile", "mipaf_trim", "mipaf_filter",
+                    "mipaf_invert", "mipaf_dechunk_text", "mipaf_unaligned_fasta", "mipaf_to_bed_text", "mipaf_fasta_extract_text", "mipaf_upconvert_text", "mipaf_fasta_chunk_files", "mipaf_chain_params_default", "mipaf_chain", "mipaf_tile", "mipaf_trim", "mipaf_filter",
                     "mipaf_split_by_query", "mipaf_chain_tile_trim_filter")
 
 _bound = False
@@ -45,6 +45,10 @@ def _lib() -> C.CDLL:
             "mipaf_invert": (C.c_int, [vp]),
             "mipaf_dechunk_text": (C.c_int, [cp, C.c_size_t, C.c_int32, P(vp), P(C.c_size_t)]),
             "mipaf_unaligned_fasta": (C.c_int, [cp, C.c_size_t, cp, C.c_size_t, C.c_int64, C.c_int64, P(vp), P(C.c_size_t)]),
+            "mipaf_to_bed_text": (C.c_int, [cp, C.c_size_t, cp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int64, P(vp), P(C.c_size_t)]),
+            "mipaf_fasta_extract_text": (C.c_int, [cp, C.c_size_t, cp, C.c_size_t, C.c_int64, C.c_int64, C.c_int32, P(vp), P(C.c_size_t)]),
+            "mipaf_upconvert_text": (C.c_int, [cp, C.c_size_t, P(cp), P(C.c_size_t), C.c_size_t, P(vp), P(C.c_size_t)]),
+            "mipaf_fasta_chunk_files": (C.c_int, [cp, C.c_size_t, cp, C.c_int64, C.c_int64, P(C.c_int32)]),
             "mipaf_chain_params_default": (None, [P(ChainParams)]),
             "mipaf_chain": (C.c_int, [vp, vp, P(ChainParams), P(Stats)]),
             "mipaf_tile": (C.c_int, [vp, vp, C.c_int32, P(Stats)]),
@@ -82,6 +86,42 @@ def dechunk_text(paf: bytes, query_only: bool = False) -> bytes:
         return C.string_at(out, n.value) if n.value else b""
     finally:
         lib.miblast_free(out)
+
+
+def _text_out(call) -> bytes:
+    lib = _lib()
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(call(lib, C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value) if n.value else b""
+    finally:
+        lib.miblast_free(out)
+
+
+def to_bed_text(paf: bytes, fasta: bytes = None, exclude_aligned: bool = False, exclude_unaligned: bool = False, include_inverted: bool = False,
+                min_size: int = 0) -> bytes:
+    """`paffy to_bed --binary ...` on text (include/mipaf.h mipaf_to_bed_text)"""
+    return _text_out(lambda lib, o, n: lib.mipaf_to_bed_text(paf, len(paf), fasta, len(fasta) if fasta else 0, int(exclude_aligned), int(exclude_unaligned),
+                                                             int(include_inverted), min_size, o, n))
+
+
+def fasta_extract_text(bed: bytes, fasta: bytes, flank: int = 0, min_size: int = 1, skip_missing: bool = False) -> bytes:
+    """`faffy extract -i bed fa [--flank F] [--minSize N] [--skipMissing]` on text (mipaf_fasta_extract_text)"""
+    return _text_out(lambda lib, o, n: lib.mipaf_fasta_extract_text(bed, len(bed), fasta, len(fasta), flank, min_size, int(skip_missing), o, n))
+
+
+def upconvert_text(paf: bytes, fastas) -> bytes:
+    """`paffy upconvert -i paf trimmed_1.fa ...` on text (mipaf_upconvert_text)"""
+    arr = (C.c_char_p * len(fastas))(*fastas)
+    lens = (C.c_size_t * len(fastas))(*[len(f) for f in fastas])
+    return _text_out(lambda lib, o, n: lib.mipaf_upconvert_text(paf, len(paf), arr, lens, len(fastas), o, n))
+
+
+def fasta_chunk_files(fasta: bytes, out_dir: str, chunk_size: int, overlap: int) -> int:
+    """`faffy chunk -c C -o O --dir D` (mipaf_fasta_chunk_files): writes D/chunk_<k>.fa, returns the number of files"""
+    n = C.c_int32()
+    _check(_lib().mipaf_fasta_chunk_files(fasta, len(fasta), out_dir.encode(), chunk_size, overlap, C.byref(n)))
+    return n.value
 
 
 def unaligned_fasta(paf: bytes, fasta: bytes, min_size: int, flank: int) -> bytes:

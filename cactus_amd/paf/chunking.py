@@ -155,3 +155,94 @@ def fasta_extract(bed, fasta_path: str, out_path: str, flank: int):
             out.write(">{}\n".format(name))
             for i in range(0, len(piece), 100):
                 out.write(piece[i:i + 100] + "\n")
+
+
+# ---- trimming the sequences to what is aligned (second half; local_alignment.py:861-904) ---------------------
+def aligned_intervals(paf_lines, include_inverted: bool = True):
+    """Core of `paffy to_bed --binary --excludeUnaligned [--includeInverted] -i paf` (local_alignment.py:878): the (name, start, end)
+    intervals of sequence covered by at least one alignment -- by their query intervals and, with --includeInverted, by their
+    target intervals too (the alignment read the other way round).  No FASTA file is given at this call site: sequences come in
+    order of first appearance in the PAF (query before target within a line).  Sorted and merged intervals, not a per-base array."""
+    spans, order = {}, []
+
+    def add(name, s, e):
+        if name not in spans:
+            spans[name] = []
+            order.append(name)
+        if e > s:
+            spans[name].append((s, e))
+    for line in paf_lines:
+        if not line.strip():
+            continue
+        t = line.split("\t", 9)
+        add(t[0], int(t[2]), int(t[3]))
+        if include_inverted:
+            add(t[5], int(t[7]), int(t[8]))
+    out = []
+    for name in order:
+        cur = None
+        for s, e in sorted(spans[name]):
+            if cur is not None and s <= cur[1]:
+                cur[1] = max(cur[1], e)
+            else:
+                if cur is not None:
+                    out.append((name, cur[0], cur[1]))
+                cur = [s, e]
+        if cur is not None:
+            out.append((name, cur[0], cur[1]))
+    return out
+
+
+def extract_records_skip_missing(bed, records, flank: int, min_size: int = 1):
+    """Core of `faffy extract -i bed fa --skipMissing --minSize N --flank F` (local_alignment.py:890-892): like extract_records, but
+    BED lines that name a sequence which is not in this file are passed over (the BED of trim_unaligned_sequences covers the sequences
+    of ALL files), and intervals shorter than min_size are dropped before they are widened."""
+    have = {name for name, _ in records}
+    return extract_records([(n, s, e) for n, s, e in bed if n in have and e - s >= min_size], records, flank)
+
+
+def paf_upconvert_lines(paf_lines, record_names):
+    """Core of `paffy upconvert -i paf trimmed_1.fa trimmed_2.fa ...` (local_alignment.py:899-900): the alignments rewritten to refer to
+    the extracted sub-sequences -- the inverse of dechunk.  record_names: [(NAME|SEQLEN|START, length)] of every record of every trimmed
+    file.  A query (target) interval lies inside exactly one record of its sequence: the name becomes the record's, the length the
+    record's, start / end are shifted by -START; every other column and tag passes through.  A sequence none of whose records is in the
+    files keeps its coordinates."""
+    import bisect
+    by = {}
+    for full, n in record_names:
+        base, seq_len, start = _split_chunk_name(full)
+        by.setdefault(base, []).append((start, start + n, full))
+    for v in by.values():
+        v.sort()
+    out = []
+
+    def conv(name, s, e):
+        recs = by.get(name)
+        if recs is None:
+            return None
+        k = bisect.bisect_right(recs, (s, float("inf"), "")) - 1
+        if k < 0 or not (recs[k][0] <= s and e <= recs[k][1]):
+            raise ValueError("upconvert: {}:{}-{} lies in no extracted record".format(name, s, e))
+        return recs[k]
+    for line in paf_lines:
+        if not line.strip():
+            continue
+        f = line.rstrip("\n").split("\t")
+        q = conv(f[0], int(f[2]), int(f[3]))
+        if q is not None:
+            f[0], f[1], f[2], f[3] = q[2], str(q[1] - q[0]), str(int(f[2]) - q[0]), str(int(f[3]) - q[0])
+        t = conv(f[5], int(f[7]), int(f[8]))
+        if t is not None:
+            f[5], f[6], f[7], f[8] = t[2], str(t[1] - t[0]), str(int(f[7]) - t[0]), str(int(f[8]) - t[0])
+        out.append("\t".join(f) + "\n")
+    return out
+
+
+def trim_to_aligned(paf_text: str, fastas, flank: int, min_size: int = 1):
+    """The three steps of trim_unaligned_sequences (local_alignment.py:861-904) on text: fastas = [[(name, sequence)]] per file.
+    Returns ([[(NAME|SEQLEN|START, piece)]] per file, upconverted PAF text)."""
+    lines = paf_text.splitlines(True)
+    bed = aligned_intervals(lines, include_inverted=True)
+    trimmed = [extract_records_skip_missing(bed, recs, flank, min_size) for recs in fastas]
+    names = [(n, len(s)) for recs in trimmed for n, s in recs]
+    return trimmed, "".join(paf_upconvert_lines(lines, names))

@@ -8,6 +8,7 @@ reference's callers:
     combine_chunks            :336-356  dechunk + concatenate
     chain_alignments          :607-657  merge, add the inverted copies, split by query contig when large
     chain_tile_trim_filter_one_contig :660-727  paffy chain | tile | trim | filter | chain | filter
+    trim_unaligned_sequences  :861-904  paffy to_bed | faffy extract | paffy upconvert (second half)
 
 What differs, on purpose: the `lastz` / `run_kegalign` found on PATH are the MI355X front ends in
 <repo>/bin (or, with MIBLAST_INPROCESS=1, the same code through the C ABI via ctypes), AMD GPUs are
@@ -236,6 +237,31 @@ def make_ingroup_to_outgroup_alignments_3(job, ingroup_event, ingroup_seq_file, 
     chunking.paf_dechunk(a2, merged, query_only=True, append=True)
     job.fileStore.deleteGlobalFile(ingroup_seq_file)
     return job.fileStore.writeGlobalFile(merged)
+
+
+def trim_unaligned_sequences(job, sequences, alignments, params, has_resources=False):
+    """:861-904 -- the genomes cut down to what the blast alignments cover (+ trimOutgroupFlanking), and the alignments rewritten to
+    those sub-sequences.  The three tools run as the reference runs them -- bin/paffy to_bed / upconvert and bin/faffy extract are the
+    native text code of libmiblast (mp_text.cpp); the same steps in process: cactus_amd.paf.chunking.trim_to_aligned."""
+    work_dir = job.fileStore.getLocalTempDir()
+    alignments_file = os.path.join(work_dir, 'alignments.paf')
+    job.fileStore.readGlobalFile(alignments, alignments_file)
+    bed_file = alignments_file + '.bed'
+    cactus_call(parameters=['paffy', 'to_bed', "--binary", "--excludeUnaligned", "--includeInverted",
+                            '-i', alignments_file, "--logLevel", getLogLevelString()], outfile=bed_file, returnStdErr=True, job_memory=job.memory)
+    trimmed_sequence_files = []
+    for i, sequence in enumerate(sequences):
+        seq_file = os.path.join(work_dir, '{}.fa'.format(i))
+        job.fileStore.readGlobalFile(sequence, seq_file)
+        trimmed_seq_file = seq_file + '.trim'
+        cactus_call(parameters=['faffy', 'extract', "-i", bed_file, seq_file, "--skipMissing", "--minSize", "1",
+                                "--flank", params.find("blast").attrib["trimOutgroupFlanking"], "--logLevel", getLogLevelString()],
+                    outfile=trimmed_seq_file, returnStdErr=True, job_memory=job.memory)
+        trimmed_sequence_files.append(trimmed_seq_file)
+    trimmed_alignments = alignments_file + '.trim'
+    cactus_call(parameters=['paffy', 'upconvert', "-i", alignments_file, "--logLevel", getLogLevelString()] + trimmed_sequence_files,
+                outfile=trimmed_alignments, returnStdErr=True)
+    return [job.fileStore.writeGlobalFile(i) for i in trimmed_sequence_files], job.fileStore.writeGlobalFile(trimmed_alignments)
 
 
 # ---- chaining stage (local_alignment.py:594-734): chain -> tile -> trim -> filter -> chain -> filter ---------------------------

@@ -55,6 +55,27 @@ int mipaf_dechunk_text(const char *paf, size_t len, int32_t query_only, char **o
 int mipaf_unaligned_fasta(const char *paf, size_t paf_len, const char *fasta, size_t fasta_len, int64_t min_size, int64_t flank,
                           char **out, size_t *out_len);
 
+/* ---- the other text steps of the blast phase (mp_text.cpp; front ends bin/paffy to_bed|upconvert, bin/faffy chunk|extract) ----------
+ * `paffy to_bed --binary {--excludeAligned|--excludeUnaligned} [--includeInverted] [--minSize N] -i paf [--queryFastaFile fa]`
+ * (local_alignment.py:191-204, :476-480, :878-880): BED lines NAME<tab>START<tab>END of the stretches no alignment covers
+ * (exclude_aligned) or of the stretches some alignment covers (exclude_unaligned), at least min_size long.  Coverage is by the query
+ * intervals and, with include_inverted, by the target intervals as well.  With a FASTA text its sequences are reported in its order
+ * (a query that is not in it is an error); without one (fasta NULL) the sequences of the PAF in order of first appearance, lengths
+ * from the PAF.  *out is freed with miblast_free.                                                                                  */
+int mipaf_to_bed_text(const char *paf, size_t paf_len, const char *fasta, size_t fasta_len, int32_t exclude_aligned, int32_t exclude_unaligned,
+                      int32_t include_inverted, int64_t min_size, char **out, size_t *out_len);
+/* `faffy extract -i bed fa [--flank F] [--minSize N] [--skipMissing]` (:208-216, :485-488, :890-893): the BED intervals of at least
+ * min_size bases, widened by flank (widened intervals that touch are one), as FASTA records NAME|SEQLEN|START with 60 columns per line,
+ * in file order.  skip_missing: BED lines naming a sequence that is not in `fasta` are passed over instead of being an error.       */
+int mipaf_fasta_extract_text(const char *bed, size_t bed_len, const char *fasta, size_t fasta_len, int64_t flank, int64_t min_size, int32_t skip_missing,
+                             char **out, size_t *out_len);
+/* `paffy upconvert -i paf trimmed_1.fa trimmed_2.fa ...` (:899-900): the alignments rewritten to refer to the extracted sub-sequences
+ * (records NAME|SEQLEN|START of the given FASTA texts) -- the inverse of dechunk; other columns and tags pass through.              */
+int mipaf_upconvert_text(const char *paf, size_t paf_len, const char *const *fastas, const size_t *fasta_lens, size_t n_fastas, char **out, size_t *out_len);
+/* `faffy chunk -c chunkSize -o overlapSize --dir D fa` (:378-387): records NAME|SEQLEN|START of chunkSize + overlapSize bases, 100
+ * columns per line, packed into files D/chunk_<k>.fa of about chunkSize bases; *n_files (may be NULL) = files written.             */
+int mipaf_fasta_chunk_files(const char *fasta, size_t fasta_len, const char *out_dir, int64_t chunk_size, int64_t overlap, int32_t *n_files);
+
 typedef struct mipaf_chain_params {     /* `paffy chain` options (local_alignment.py:672-677, values xml:108-111)  */
     int64_t max_gap_length;             /* --maxGapLength  (chainMaxGapLength 1000000)                            */
     int64_t gap_open;                   /* --chainGapOpen  (chainGapOpen 5000)                                    */

@@ -11,6 +11,9 @@
  *   dechunk PAF [--query]                      `paffy dechunk -i PAF [--query]`  (:352, :515)
  *   chunk FASTA CHUNKSIZE OVERLAP              `faffy chunk -c C -o O --dir D FASTA` (:378-387) as one listing: a line "== file k"
  *                                              before the records of every chunk file
+ *   trim_aligned PAF FLANK FASTA...            trim_unaligned_sequences (:861-904): `paffy to_bed --binary --excludeUnaligned
+ *                                              --includeInverted` | `faffy extract --skipMissing --minSize 1 --flank F` per file |
+ *                                              `paffy upconvert`, as one listing
  *
  * PARITY UNPINNED: the paffy submodule is empty in the reference tree; the record naming
  * NAME|SEQLEN|START is SURVEY Appendix B's [MEMORY] of the tool.  What this file pins is that the product's two implementations
@@ -200,10 +203,116 @@ static int cmd_chunk(const char *fa_path, int64_t chunk, int64_t overlap) {
     return 0;
 }
 
+/* trim_unaligned_sequences (/root/reference/src/cactus/paf/local_alignment.py:861-904) in one go:
+ *   paffy to_bed --binary --excludeUnaligned --includeInverted -i PAF          -> coverage of every sequence by query AND target intervals
+ *   faffy extract -i BED FASTA_k --skipMissing --minSize 1 --flank F           -> per file, the covered stretches widened by F
+ *   paffy upconvert -i PAF trimmed_1 trimmed_2 ...                             -> the PAF in the coordinates of the extracted records
+ * Output: "== file k" before the records of every trimmed file, "== paf" before the converted alignments.  Per-base counters and a
+ * per-base keep mask; an alignment finds its record by walking the mask from its own first base. */
+static int cmd_trim_aligned(const char *paf_path, int64_t flank, int n_files, char **paths) {
+    rec_t **files = (rec_t **)malloc((size_t)n_files * sizeof *files);
+    int *n_recs = (int *)malloc((size_t)n_files * sizeof *n_recs);
+    uint8_t ***keep = (uint8_t ***)malloc((size_t)n_files * sizeof *keep);
+    uint16_t ***cnt = (uint16_t ***)malloc((size_t)n_files * sizeof *cnt);
+    for (int f = 0; f < n_files; f++) {
+        files[f] = read_fasta(paths[f], &n_recs[f]);
+        keep[f] = (uint8_t **)malloc(((size_t)n_recs[f] + 1) * sizeof **keep);
+        cnt[f] = (uint16_t **)malloc(((size_t)n_recs[f] + 1) * sizeof **cnt);
+        for (int k = 0; k < n_recs[f]; k++) { keep[f][k] = (uint8_t *)calloc((size_t)files[f][k].len + 1, 1); cnt[f][k] = (uint16_t *)calloc((size_t)files[f][k].len + 1, 2); }
+    }
+    size_t len;
+    char *paf = slurp(paf_path, &len);
+    char *copy = (char *)malloc(len + 1);
+    memcpy(copy, paf, len + 1);
+    /* pass 1: counters */
+    for (char *line = paf; line < paf + len;) {
+        char *eol = memchr(line, '\n', (size_t)(paf + len - line));
+        if (!eol) eol = paf + len;
+        *eol = 0;
+        char qn[4096], tn[4096], strand[8];
+        long long ql, qs, qe, tl, ts, te;
+        if (sscanf(line, "%4095[^\t]\t%lld\t%lld\t%lld\t%7[^\t]\t%4095[^\t]\t%lld\t%lld\t%lld", qn, &ql, &qs, &qe, strand, tn, &tl, &ts, &te) == 9) {
+            for (int side = 0; side < 2; side++) {
+                const char *nm = side ? tn : qn;
+                long long s0 = side ? ts : qs, e0 = side ? te : qe;
+                for (int f = 0; f < n_files; f++) for (int k = 0; k < n_recs[f]; k++) if (!strcmp(files[f][k].name, nm))
+                    for (long long p = s0 < 0 ? 0 : s0; p < e0 && p < files[f][k].len; p++) if (cnt[f][k][p] != 0xFFFF) cnt[f][k][p]++;
+            }
+        } else {
+            int blank = 1;
+            for (char *c = line; *c; c++) if (*c != ' ' && *c != '\t' && *c != '\r') blank = 0;
+            if (!blank) die("PAF line with fewer than 9 columns");
+        }
+        line = eol + 1;
+    }
+    /* the records */
+    for (int f = 0; f < n_files; f++) {
+        printf("== file %d\n", f);
+        for (int k = 0; k < n_recs[f]; k++) {
+            const int64_t L = files[f][k].len;
+            for (int64_t p = 0; p < L;) {
+                if (!cnt[f][k][p]) { p++; continue; }
+                int64_t e = p;
+                while (e < L && cnt[f][k][e]) e++;
+                for (int64_t x = (p - flank < 0 ? 0 : p - flank); x < (e + flank > L ? L : e + flank); x++) keep[f][k][x] = 1;
+                p = e;
+            }
+            for (int64_t p = 0; p < L;) {
+                if (!keep[f][k][p]) { p++; continue; }
+                int64_t e = p;
+                while (e < L && keep[f][k][e]) e++;
+                put_record(files[f][k].name, L, p, files[f][k].seq + p, e - p, 60);
+                p = e;
+            }
+        }
+    }
+    /* pass 2: the alignments in the records' coordinates */
+    printf("== paf\n");
+    for (char *line = copy; line < copy + len;) {
+        char *eol = memchr(line, '\n', (size_t)(copy + len - line));
+        if (!eol) eol = copy + len;
+        *eol = 0;
+        if (eol > line && eol[-1] == '\r') eol[-1] = 0;
+        char *col[10];
+        int nc = 0;
+        char *c = line;
+        while (nc < 9 && c) {
+            col[nc++] = c;
+            char *t = strchr(c, '\t');
+            if (!t) { c = NULL; break; }
+            *t = 0; c = t + 1;
+        }
+        if (nc == 9) {
+            long long v[2][3] = {{atoll(col[1]), atoll(col[2]), atoll(col[3])}, {atoll(col[6]), atoll(col[7]), atoll(col[8])}};
+            char name[2][4200];
+            for (int side = 0; side < 2; side++) {
+                const char *nm = col[side ? 5 : 0];
+                snprintf(name[side], sizeof name[side], "%s", nm);
+                for (int f = 0; f < n_files; f++) for (int k = 0; k < n_recs[f]; k++) if (!strcmp(files[f][k].name, nm)) {
+                    const int64_t L = files[f][k].len;
+                    int64_t a = v[side][1], b = v[side][1];
+                    if (a >= L || !keep[f][k][a]) die("an alignment starts outside every extracted record");
+                    while (a > 0 && keep[f][k][a - 1]) a--;
+                    while (b < L && keep[f][k][b]) b++;
+                    if (v[side][2] > b) die("an alignment ends outside its extracted record");
+                    snprintf(name[side], sizeof name[side], "%s|%lld|%lld", nm, (long long)L, (long long)a);
+                    v[side][0] = b - a; v[side][1] -= a; v[side][2] -= a;
+                }
+            }
+            printf("%s\t%lld\t%lld\t%lld\t%s\t%s\t%lld\t%lld\t%lld", name[0], v[0][0], v[0][1], v[0][2], col[4], name[1], v[1][0], v[1][1], v[1][2]);
+            if (c) printf("\t%s", c);
+            fputc('\n', stdout);
+        }
+        line = eol + 1;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 6 && !strcmp(argv[1], "to_bed_extract")) return cmd_to_bed_extract(argv[2], argv[3], atoll(argv[4]), atoll(argv[5]));
     if (argc >= 3 && !strcmp(argv[1], "dechunk")) return cmd_dechunk(argv[2], argc > 3 && !strcmp(argv[3], "--query"));
     if (argc >= 5 && !strcmp(argv[1], "chunk")) return cmd_chunk(argv[2], atoll(argv[3]), atoll(argv[4]));
-    die("usage: to_bed_extract PAF FASTA MINSIZE FLANK | dechunk PAF [--query] | chunk FASTA CHUNKSIZE OVERLAP");
+    if (argc >= 5 && !strcmp(argv[1], "trim_aligned")) return cmd_trim_aligned(argv[2], atoll(argv[3]), argc - 4, argv + 4);
+    die("usage: to_bed_extract PAF FASTA MINSIZE FLANK | dechunk PAF [--query] | chunk FASTA CHUNKSIZE OVERLAP | trim_aligned PAF FLANK FASTA...");
     return 2;
 }

@@ -99,3 +99,93 @@ def test_fasta_chunker_writes_the_oracles_files(tmp_path, seed, chunk, overlap):
     files = chunking.fasta_chunk(str(src), str(tmp_path / "chunks"), chunk, overlap)
     got = b"".join(b"== file %d\n" % k + open(f, "rb").read() for k, f in enumerate(files))
     assert got == oracle("chunk", src, chunk, overlap)
+
+
+def two_genome_case(seed):
+    """Two FASTA files (genomes A and B, several contigs each, one contig of B untouched) and alignments between them whose query
+    and target intervals overlap, touch, nest and reach the contig ends -- the input of trim_unaligned_sequences."""
+    rng = np.random.default_rng(seed)
+    files = []
+    for g in "AB":
+        recs = []
+        for k in range(2 + seed % 3):
+            n = int(rng.integers(200, 6000))
+            recs.append((f"id={g}|chr{k}", gen.random_sequence(n, rng)))
+        files.append(recs)
+    lines = []
+    for _ in range(10 + seed):
+        qa, ta = files[0][int(rng.integers(0, len(files[0])))], files[1][int(rng.integers(0, len(files[1]) - 1))]
+        span = int(rng.integers(1, 150))
+        qs, ts = int(rng.integers(0, len(qa[1]) - span + 1)), int(rng.integers(0, len(ta[1]) - span + 1))
+        if rng.random() < 0.15:
+            qs = 0
+        if rng.random() < 0.15:
+            ts = len(ta[1]) - span
+        tags = f"\tAS:i:{span * 90}\tcg:Z:{span}=" if rng.random() < 0.8 else ""
+        lines.append(f"{qa[0]}\t{len(qa[1])}\t{qs}\t{qs + span}\t{'+-'[int(rng.integers(0, 2))]}\t{ta[0]}\t{len(ta[1])}\t{ts}\t{ts + span}\t{span}\t{span}\t255{tags}\n")
+    return files, "".join(lines)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_trim_to_aligned_four_implementations_write_the_oracles_bytes(tmp_path, seed):
+    """trim_unaligned_sequences (local_alignment.py:861-904): the Python cores, the native text code through the C ABI, the CLI faces
+    bin/paffy to_bed | bin/faffy extract | bin/paffy upconvert driven by the job function, and the oracle's per-base restatement."""
+    import sys
+    import xml.etree.ElementTree as ET
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from localjob import LocalJob
+    from cactus_amd import mipaf
+    from cactus_amd.paf.local_alignment import trim_unaligned_sequences
+    files, paf = two_genome_case(seed)
+    flank = (0, 7, 60, 2000)[seed % 4]
+    paths = []
+    for k, recs in enumerate(files):
+        p = tmp_path / f"g{k}.fa"
+        p.write_bytes(gen.fasta_bytes(recs))
+        paths.append(p)
+    (tmp_path / "a.paf").write_text(paf)
+    want = oracle("trim_aligned", tmp_path / "a.paf", flank, *paths).decode()
+    sections = want.split("== ")
+    want_files = [s.split("\n", 1)[1] for s in sections if s.startswith("file ")]
+    want_paf = [s.split("\n", 1)[1] for s in sections if s.startswith("paf")][0]
+    # Python cores
+    trimmed, up = chunking.trim_to_aligned(paf, [[(n, s.tobytes().decode()) for n, s in recs] for recs in files], flank)
+    got_files = [gen.fasta_bytes([(n, np.frombuffer(s.encode(), dtype=np.uint8)) for n, s in recs]).decode() for recs in trimmed]
+    assert got_files == want_files and up == want_paf
+    # native text code (C ABI)
+    bed = mipaf.to_bed_text(paf.encode(), exclude_unaligned=True, include_inverted=True)
+    assert bed.decode() == "".join(f"{n}\t{s}\t{e}\n" for n, s, e in chunking.aligned_intervals(paf.splitlines(True)))
+    native = [mipaf.fasta_extract_text(bed, p.read_bytes(), flank, 1, True) for p in paths]
+    assert [x.decode() for x in native] == want_files
+    assert mipaf.upconvert_text(paf.encode(), native).decode() == want_paf
+    # the job function over the CLI faces (argv of the reference)
+    job = LocalJob()
+    params = ET.fromstring(f'<cactusWorkflowConfig><blast trimOutgroupFlanking="{flank}"/></cactusWorkflowConfig>')
+    seq_ids, paf_id = trim_unaligned_sequences(job, [job.fileStore.writeGlobalFile(str(p)) for p in paths], job.fileStore.writeGlobalFile(str(tmp_path / "a.paf")), params)
+    assert [open(str(i)).read() for i in seq_ids] == want_files and open(str(paf_id)).read() == want_paf
+    # dechunk undoes upconvert
+    assert mipaf.dechunk_text(want_paf.encode()) == paf.encode()
+
+
+def test_to_bed_and_extract_general_forms(tmp_path):
+    """the forms of the other call sites (local_alignment.py:191-216, :476-489): --excludeAligned with a FASTA file equals the
+    first-half implementation; an unknown BED name is an error without --skipMissing; faffy chunk through the CLI equals the oracle"""
+    from cactus_amd import mipaf
+    fa, paf, _ = random_case(5, n_contigs=4)
+    bed = mipaf.to_bed_text(paf, fasta=fa, exclude_aligned=True, min_size=37)
+    want = chunking.unaligned_intervals(paf.decode().splitlines(True), [(n.split()[0], len(s)) for n, s in
+                                        ((n, s) for n, s in [(r[0], r[1]) for r in __import__("cactus_amd.blast_phase", fromlist=["x"]).parse_fasta_bytes(fa)])], 37)
+    assert bed.decode() == "".join(f"{n}\t{s}\t{e}\n" for n, s, e in want)
+    assert mipaf.fasta_extract_text(bed, fa, 5, 1, False) == mipaf.unaligned_fasta(paf, fa, 37, 5)
+    with pytest.raises(Exception):
+        mipaf.fasta_extract_text(b"nosuch\t0\t5\n", fa, 0, 1, False)
+    assert mipaf.fasta_extract_text(b"nosuch\t0\t5\n", fa, 0, 1, True) == b""
+    src = tmp_path / "g.fa"
+    src.write_bytes(fa)
+    out = tmp_path / "chunks"
+    out.mkdir()
+    p = subprocess.run([os.path.join(ROOT, "bin", "faffy"), "chunk", "-c", "700", "-o", "50", "--dir", str(out), str(src)], capture_output=True)
+    assert p.returncode == 0, p.stderr
+    files = sorted(os.listdir(out), key=lambda f: int(f.split("_")[1].split(".")[0]))
+    got = b"".join(b"== file %d\n" % k + (out / f).read_bytes() for k, f in enumerate(files))
+    assert got == oracle("chunk", src, 700, 50)
