@@ -9,7 +9,9 @@
 //   * exit code != 0 on any problem (common.py:962-988); on success stderr stays EMPTY, because the
 //     GPU branch greps it for terminate/error/fail/assert/signal/abort/... (local_alignment.py:75-83).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "../../include/miblast.h"
 
@@ -28,6 +30,19 @@ int main(int argc, char **argv) {
     if (miblast_params_from_argv(argc, argv, &p, files, &num_gpu, &num_threads) != MIBLAST_OK) {
         fprintf(stderr, "lastz (miblast): %s\n", miblast_last_error());
         return 2;
+    }
+    // private, never set by Cactus: MIBLAST_PARSE_ONLY=1 stops after the command line has been accepted and both files could be opened
+    // (tests drive the reference's unmodified job functions against this front end on a box without a GPU: tests/refjobs.py)
+    if (const char *po = getenv("MIBLAST_PARSE_ONLY"); po && *po && strcmp(po, "0") != 0) {
+        for (int k = 0; k < 2; k++) {
+            std::string path(files[k]);
+            const size_t br = path.find('[');                          // file.fa[multiple][nameparse=darkspace]
+            if (br != std::string::npos) path.resize(br);
+            FILE *f = fopen(path.c_str(), "rb");
+            if (!f) { fprintf(stderr, "lastz (miblast): cannot open %s\n", path.c_str()); return 1; }
+            fclose(f);
+        }
+        return 0;
     }
     bool threads_given = false;
     for (int i = 1; i < argc; i++) threads_given |= !strcmp(argv[i], "--num_threads");

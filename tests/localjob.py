@@ -75,3 +75,8 @@ class LocalJob:
         return _Promise(fn(child, *args, **kw))
 
     addFollowOnJobFn = addChildJobFn
+
+    def addChild(self, other):
+        """the reference hangs sub-graphs off a bare Job() (local_alignment.py:432-433): it works in its parent's file store"""
+        other.fileStore, other.cores, other.memory = self.fileStore, self.cores, self.memory
+        return other

@@ -1,7 +1,11 @@
 """-m gpu : the parity tests proper.  Every case goes through the C ABI of libmiblast.so on a real
 MI355X and is compared with the CPU oracle on the same bytes -- bit-exact: PAF text, HSP records,
 alignment records, run-length ops and every oracle-defined counter (integer scoring)."""
+import os
+
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from cases import CASES, CASE_IDS
 
@@ -67,6 +71,32 @@ def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
             for k in COUNTERS:
                 assert got.stats[k] == want["counters"][k], (name, rep, k)
         T.close(); Q.close()
+
+
+def _ref_argv():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "ref_argv.json")))["run_lastz"]
+
+
+@pytest.mark.parametrize("rec", _ref_argv(), ids=lambda r: f"d{r['distance']}-gpu{r['gpu']}")
+def test_command_lines_built_by_the_reference_run_on_the_front_ends(olz, tmp_path, monkeypatch, rec):
+    """tests/golden/ref_argv.json holds the argv that the REFERENCE's unmodified run_lastz builds for every divergence class, CPU and
+    GPU branch (written by tests/golden/make_ref_argv.py in the build container, where /root/reference exists; the same functions are
+    run end to end there by tests/test_reference_jobs_cpu.py).  Here the recorded command lines run against the real bin/lastz and
+    bin/run_kegalign on the MI355X, from a work directory like the job's: PAF on stdout equal to the oracle's, empty stderr."""
+    import subprocess
+    from cases import pair
+    tf, qf = pair(40000, 77)
+    (tmp_path / "A.fa").write_bytes(tf); (tmp_path / "B.fa").write_bytes(qf)
+    argv = list(rec["argv"])
+    env = dict(os.environ, PATH=os.path.join(ROOT, "bin") + os.pathsep + os.environ.get("PATH", ""))
+    if rec["gpu"] > 1:
+        env["MIBLAST_DEVICE_MAP"] = ",".join(["0"] * rec["gpu"])       # (a one-GPU box: the job's logical devices all map to it)
+    p = subprocess.run(argv, cwd=str(tmp_path), env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0 and p.stderr == b"", p.stderr.decode()
+    pm = _params([a for a in argv[4:] if a.startswith("--") and not a.startswith("--num_")])
+    want = olz.align(tf, qf, _oracle_params(olz, pm), details=False)["paf"]
+    assert p.stdout == want and want.count(b"\n") >= 1
 
 
 @pytest.mark.parametrize("kernel", ["lane", "ux", "grp"])
