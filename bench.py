@@ -395,6 +395,19 @@ class ChunkWorkload:
                         "a third of the time cannot come near the roof: see per-stage kernel times"}
 
 
+def reduce_totals(tot, elapsed, dist, coll_dev):
+    """counters summed over the ranks, the barrier-to-barrier time as the maximum over the ranks"""
+    import torch
+    keys = sorted(tot)
+    vec = torch.tensor([float(tot[k]) for k in keys] + [elapsed], dtype=torch.float64, device=coll_dev)
+    if dist is not None:
+        tmax = vec[-1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax.item())
+    return elapsed, {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
+
+
 def cpu_throttle_state():
     """(nr_throttled, throttled_usec) of this container's CPU cgroup -- the bench box runs under a CPU quota; a process whose threads
     exceed it is frozen for the rest of the 100 ms period, which shows up as outlier steps"""
@@ -522,14 +535,12 @@ def run_rank(a):
     elapsed, tot, keep = timed_steps(work, a.steps, a.warmup, sync, gather)
     step_spread = dict(timed_steps.last_spread, note="wall time of the single steps of the timed region on rank 0 (ms_per_step is their mean over all ranks' barrier-to-barrier time); "
                                                      "Python's cyclic garbage collector is switched off for the timed steps, as timeit does (MIBLAST_BENCH_NOGC=0 leaves it on)")
-    keys = sorted(tot)
-    vec = torch.tensor([float(tot[k]) for k in keys] + [elapsed], dtype=torch.float64, device=coll_dev)
-    if dist is not None:
-        tmax = vec[-1:].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax.item())
-    tot = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
+    elapsed, tot = reduce_totals(tot, elapsed, dist, coll_dev)
+    # the chunk-scale configurations, sharded over ALL ranks (strong scaling; at N = 1 the same legs on one GPU): every rank takes part
+    sharded_legs = {}
+    if a.workload == "evolver" and a.chunk_legs > 0:
+        for which in ("chr20", "hm"):
+            sharded_legs[which] = chunk_leg(a, ctx, which, rank, world, dist, coll_dev, sync)
 
     if rank == 0:
         per = a.steps * (1 if sharded else world)      # per-step figures: of one rank's phase (weak) / of the whole sharded job (strong)
@@ -598,10 +609,11 @@ def run_rank(a):
         if world > 1:
             # the extra legs and the CPU baseline are single-GPU figures: measured at N = 1 only (the ranks of a scaling run do not wait
             # for rank 0 to time them)
-            a.primates_leg = a.pair_leg = a.batch_leg = a.seed_leg = a.chain_leg = a.chunk_legs = 0
+            a.primates_leg = a.pair_leg = a.batch_leg = a.seed_leg = a.chain_leg = 0
             if not sharded:
                 a.cpu_sample = 0
-            out["legs_note"] = "primates / pair_1mb / batched_pairs / seed_stage / chain_stage / cpu_baseline are measured at --gpus 1 only"
+            out["legs_note"] = ("primates / pair_1mb / batched_pairs / seed_stage / chain_stage / cpu_baseline are measured at --gpus 1 only; chr20 / hm are the "
+                                "SHARDED chunk-scale configurations at every N (strong scaling: the chunk pairs of one genome pair dealt over the ranks, framed PAFs gathered)")
         if a.workload == "evolver" and a.primates_leg > 0:
             out["primates"] = primates_leg(a, ctx)
         if a.workload == "evolver" and a.pair_leg > 0:
@@ -614,9 +626,8 @@ def run_rank(a):
                                                 gapped_gcells_per_s_kernel=out["batched_pairs"].get("gapped_gcells_per_s_kernel"))
         if a.seed_leg > 0 and not a.random_pair:
             out["seed_stage"] = seed_stage_leg(a, ctx)
-        if a.workload == "evolver" and a.chunk_legs > 0:
-            for which in ("chr20", "hm"):
-                out[which] = chunk_leg(a, ctx, which)
+        for which, leg in sharded_legs.items():
+            out[which] = leg
         if a.chain_leg > 0:
             out["chain_stage"] = chain_stage_leg(a, ctx)
         if a.cpu_sample > 0:
@@ -688,29 +699,46 @@ def batch_leg(a, ctx):
     return out
 
 
-def chunk_leg(a, ctx, which):
-    """A chunk-scale configuration as a leg of the default line (N = 1): configs[3] (chr20) or the configs[4] stand-in (hm), on the same
-    terms as `--workload chr20|hm`: every chunk pair of the genome pair in one batched call per step, target-major, every pair's PAF
-    checked against the oracle's digest, a bounded live CPU sample, SURVEY 8d's read bytes against the HBM roof."""
+def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=None):
+    """A chunk-scale configuration as a leg of the default line: configs[3] (chr20) or the configs[4] stand-in (hm), on the same terms as
+    `--workload chr20|hm` -- the chunk pairs of ONE genome pair dealt over the `world` ranks (every rank calls this; strong scaling: the
+    work is fixed, ms_per_step is the maximum over the ranks, barrier to barrier, gather included), each rank its share in one batched
+    call per step, target-major, every pair's PAF checked against the oracle's digest on rank 0, a bounded live CPU sample at N = 1,
+    SURVEY 8d's read bytes against the HBM roof of the GPUs in use.  Returns the leg on rank 0, None elsewhere."""
     import hashlib
-    w = ChunkWorkload(a, ctx, 0, 1, which)
-    steps, warm = (3, 1) if which == "chr20" else (3, 1)
-    elapsed, tot, _ = timed_steps(w, steps, warm, lambda: None, lambda paf: None)
-    by_index = dict(w.last)
-    paf = b"".join(by_index[k] for k in range(len(w.pairs)))
+    from cactus_amd.multigpu import gather_bytes
+    w = ChunkWorkload(a, ctx, rank, world, which)
+    steps, warm = 3, 1
+    box = {}
+
+    def gather(paf):
+        box["last"] = gather_bytes(paf, dist, rank, world, coll_dev) if world > 1 else [paf]
+    elapsed, tot, _ = timed_steps(w, steps, warm, sync or (lambda: None), gather)
+    if world > 1:
+        elapsed, tot = reduce_totals(tot, elapsed, dist, coll_dev)
+    if rank != 0:
+        w.close()
+        return None
+    paf = w.assemble(box["last"])
+    by_index = w.by_index
     r = dp_roofline(tot, "none")
-    out = {"workload": w.describe, "chunk_pairs": len(w.pairs), "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
+    from cactus_amd.multigpu import assign_pairs
+    shares = assign_pairs(w.weights, world)
+    load = [sum(w.weights[k] for k in sh) for sh in shares]
+    out = {"workload": w.describe, "chunk_pairs": len(w.pairs), "n_gpus": world, "scaling": "strong", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+           "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
+           "chunk_pairs_per_rank": [len(sh) for sh in shares], "balance_by_weight": (sum(load) / len(load)) / max(load) if max(load) > 0 else 1.0,
            "seeds_per_s": tot["seed_hits"] / elapsed, "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
            "dp_cells_per_step": tot["dp_cells"] / steps, "seed_hits_per_step": tot["seed_hits"] / steps, "alignments_per_step": tot["alignments"] / steps,
            "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
-           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3) / 1e9,
+           "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3 / world) / 1e9,
            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / steps, "ydrop_busy": tot["t_dp_busy_ms"] / steps, "ungapped": tot["t_ungapped_kernel_ms"] / steps,
                                         "sort": tot["t_sort_ms"] / steps, "seed_search": tot["t_seedfill_ms"] / steps,
-                                        "note": "HIP-event durations summed over the pairs of the call; the seed stages of up to twelve pairs share the GPU, so the sums exceed the wall time they cover"},
+                                        "note": "HIP-event durations summed over the pairs of the call (all ranks); the seed stages of up to twelve pairs share a GPU, so the sums exceed the wall time they cover"},
            "paf_md5": hashlib.md5(paf).hexdigest(), "paf_bytes": len(paf),
            "parity": w.digest_check(by_index), "hbm_read": w.b_read(tot, steps, elapsed / steps),
            "roofline_dp": {k: r[k] for k in ("achieved", "frac", "launch_ms", "cells_per_launch")}}
-    if a.cpu_sample > 0:
+    if a.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = w.cpu_sample(by_index)
     w.close()
     return out
@@ -730,6 +758,7 @@ def seed_stage_leg(a, ctx):
     T = ctx.seqset_from_fasta_bytes(gen.fasta_bytes([("id=randT|chr1", t)]))
     Q = ctx.seqset_from_fasta_bytes(gen.fasta_bytes([("id=randQ|chr1", q)]))
     ctx.align(T, Q, pm, details=False)
+    miblast.drop_derived()                                  # (the timed job builds its seed table, '-' strand and packed strands like the first one did)
     t0 = time.perf_counter()
     r = ctx.align(T, Q, pm, details=False)
     dt = time.perf_counter() - t0

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0", "--pair-leg", "0", "--batch-leg", "0", "--primates-leg", "0"]
+SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0", "--pair-leg", "0", "--batch-leg", "0", "--primates-leg", "0", "--chunk-legs", "0"]
 
 
 def _bench(args, **env):
@@ -134,3 +134,17 @@ def test_two_ranks_of_the_real_library_gather_the_oracle_bytes(olz, tmp_path):
     want = b"".join(olz.align(c[1], c[2], po, details=False)["paf"]
                     for c in CASES if c[0] in ("homolog_20k_default", "random_50k", "multi_contig_ragged", "tandem_repeats", "empty_query", "revcomp_query"))
     assert outs[1] == outs[2] == want and want.count(b"\n") > 5
+
+
+def test_chunk_scale_legs_are_sharded_over_the_ranks_and_every_pair_equals_its_oracle_digest():
+    """The default line's chr20 (BASELINE configs[3]) and hm (configs[4] stand-in) legs at N = 2 (two ranks on this box's GPU, gloo):
+    the chunk pairs of each genome pair dealt over the ranks, framed PAFs gathered to rank 0, and EVERY chunk pair's PAF equal to
+    the CPU oracle's committed digest (tests/golden/chr20_pairs.json, hm_pairs.json) -- the bytes do not depend on the number of ranks."""
+    args = [x if x != "0" or prev != "--chunk-legs" else "1" for prev, x in zip([""] + SMALL, SMALL)] + ["--cpu-sample", "0", "--gpus", "2"]
+    out = _bench(args, MIBLAST_BENCH_SINGLE_DEVICE="1", MIBLAST_BENCH_BACKEND="gloo")
+    for which, n_pairs in (("chr20", 9), ("hm", 42)):
+        leg = out[which]
+        assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["chunk_pairs"] == n_pairs and sum(leg["chunk_pairs_per_rank"]) == n_pairs
+        assert leg["parity"]["same_bytes"] is True and leg["parity"]["pairs_checked"] == n_pairs and leg["parity"]["pairs_differing"] == 0
+        assert leg["dp_cells_per_step"] == leg["parity"]["oracle_dp_cells"] and leg["seed_hits_per_step"] == leg["parity"]["oracle_seed_hits"]
+        assert 0 < leg["hbm_read"]["frac"] < 1
