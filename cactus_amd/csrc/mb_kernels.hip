@@ -109,7 +109,7 @@ __global__ void k_index_words(const uint8_t *__restrict__ codes, int64_t n, int 
     uint32_t w = 0xFFFFFFFFu;
     if (p + kSeedSpan <= n) {
         uint32_t ww;
-        if (window_word(codes, p, ww)) { w = ww; atomicAdd(&counts[ww], 1u); }
+        if (window_word(codes, p, ww)) { w = dense_bucket(ww); atomicAdd(&counts[w], 1u); }
     }
     words[s] = w;
 }
@@ -297,8 +297,9 @@ __global__ void k_seed_count(const uint8_t *__restrict__ qcodes, int64_t qn, con
     if (q >= qn) return;
     uint32_t cnt = 0, w;
     if (q + kSeedSpan <= qn && window_word(qcodes, q, w)) {
+        const uint32_t b = dense_bucket(w);
         for (int v = 0; v < nvar; v++) {
-            uint32_t wv = variant_word(w, v);
+            uint32_t wv = dense_variant(b, v);
             if ((occ[wv >> 5] >> (wv & 31u)) & 1u) cnt += offsets[wv + 1] - offsets[wv];
         }
     }
@@ -321,8 +322,9 @@ __global__ void k_seed_fill(const uint8_t *__restrict__ qcodes, int64_t q0, int6
     if (!(q + kSeedSpan <= qn && window_word(qcodes, q, w))) return;
     uint32_t o = hit_off[q - q0];
     unsigned long long q_end = (unsigned long long)(q + kSeedSpan);
+    const uint32_t bkt = dense_bucket(w);
     for (int v = 0; v < nvar; v++) {
-        uint32_t wv = variant_word(w, v);
+        uint32_t wv = dense_variant(bkt, v);
         if (!((occ[wv >> 5] >> (wv & 31u)) & 1u)) continue;
         uint32_t b0 = offsets[wv], b1 = offsets[wv + 1];
         for (uint32_t k = b0; k < b1; k++) {
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void k_seed_search(const uint8_t *__restrict__
     for (int v = 0; v < 1 + kSeedWeight; v++) {
         b0[v] = b1[v] = 0;
         if (valid && v < nvar) {
-            const uint32_t wvv = variant_word(w, v);
+            const uint32_t wvv = dense_variant(dense_bucket(w), v);
             if ((occ[wvv >> 5] >> (wvv & 31u)) & 1u) { b0[v] = offsets[wvv]; b1[v] = offsets[wvv + 1]; cnt += b1[v] - b0[v]; }
         }
     }
@@ -408,20 +410,20 @@ void launch_index_words_packed(const unsigned long long *p2, const unsigned long
     hipLaunchKernelGGL(k_index_words_packed, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, p2, pm, n, step, first, words, n_slots, counts);
 }
 
-// (tiles of 4096 positions with one word variant, of 1024 with thirteen: the state is sized for the smaller tile)
-int64_t seed_ord_state_words(int64_t qtot) { return 2 + (qtot + kOrdThreads - 1) / kOrdThreads; }
+// (tiles of 4096 positions with one word variant, of 512 with thirteen: the state is sized for the smaller tile)
+int64_t seed_ord_state_words(int64_t qtot) { return 2 + (qtot + kOrdThreadsMin - 1) / kOrdThreadsMin; }
 
 // state: seed_ord_state_words(qtot) zeroed words; state[1] = hits of the strand afterwards (also when they did not fit `cap`)
 void launch_seed_search_ord(const uint8_t *qcodes, const unsigned long long *p2, const unsigned long long *pm, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
                             const uint32_t *positions, int transitions, uint32_t hmul, uint32_t hmask, unsigned long long *keys, unsigned long long cap,
                             unsigned long long *state, hipStream_t s) {
     if (qtot <= 0) return;
-    const int per_tile = kOrdThreads * (transitions ? 1 : 4);
+    const int threads = transitions ? 512 : 1024, per_tile = threads * (transitions ? 1 : 4);
     const int n_tiles = (int)((qtot + per_tile - 1) / per_tile);
-    const unsigned grid = (unsigned)std::min(n_tiles, 512);             // two blocks of 1024 threads per CU
-#define MB_ORD(P, R, NV) hipLaunchKernelGGL((k_seed_search_ord<P, R, NV>), dim3(grid), dim3(kOrdThreads), 0, s, qcodes, p2, pm, qtot, qtot, offsets, occ, positions, hmul, hmask, keys, cap, state, n_tiles)
-    if (transitions) { if (p2) MB_ORD(true, 1, 1 + kSeedWeight); else MB_ORD(false, 1, 1 + kSeedWeight); }
-    else { if (p2) MB_ORD(true, 4, 1); else MB_ORD(false, 4, 1); }
+    const unsigned grid = (unsigned)std::min(n_tiles, transitions ? 768 : 512);      // what a GPU holds at a time: three blocks of 512 / two of 1024 threads per CU
+#define MB_ORD(P, R, NV, T) hipLaunchKernelGGL((k_seed_search_ord<P, R, NV, T>), dim3(grid), dim3(T), 0, s, qcodes, p2, pm, qtot, qtot, offsets, occ, positions, hmul, hmask, keys, cap, state, n_tiles)
+    if (transitions) { if (p2) MB_ORD(true, 1, 1 + kSeedWeight, 512); else MB_ORD(false, 1, 1 + kSeedWeight, 512); }
+    else { if (p2) MB_ORD(true, 4, 1, 1024); else MB_ORD(false, 4, 1, 1024); }
 #undef MB_ORD
     MB_HIP(hipGetLastError());
 }

@@ -1098,10 +1098,25 @@ int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32
     uint32_t *pos = (uint32_t *)malloc(((size_t)ix.n_positions + 1) * 4);
     MB_HIP(hipMemcpy(off, ix.offsets.p, ((size_t)kBuckets + 1) * 4, hipMemcpyDeviceToHost));
     if (ix.n_positions) MB_HIP(hipMemcpy(pos, ix.positions.p, (size_t)ix.n_positions * 4, hipMemcpyDeviceToHost));
-    // the device scatter fills a bucket in arrival order; the exported table is canonical (ascending)
-    for (uint32_t b = 0; b < kBuckets; b++)
-        if (off[b + 1] - off[b] > 1) std::sort(pos + off[b], pos + off[b + 1]);
-    *offsets = off; *positions = pos;
+    // The device numbers the buckets of the dense table by dense_bucket(word) (mb_seedword.h: the word's low base bits above its high ones)
+    // and fills a bucket in arrival order; the exported table is the canonical one: buckets by word, positions ascending.
+    auto dense_bucket_h = [](uint32_t w) -> uint32_t {
+        uint32_t e = 0, o = 0;
+        for (int i = 0; i < kSeedWeight; i++) { e |= ((w >> (2 * i)) & 1u) << i; o |= ((w >> (2 * i + 1)) & 1u) << i; }
+        return (e << 12) | o;
+    };
+    uint32_t *off_w = (uint32_t *)malloc(((size_t)kBuckets + 1) * 4);
+    uint32_t *pos_w = (uint32_t *)malloc(((size_t)ix.n_positions + 1) * 4);
+    uint32_t at = 0;
+    for (uint32_t w = 0; w < kBuckets; w++) {
+        const uint32_t b = dense_bucket_h(w);
+        off_w[w] = at;
+        for (uint32_t k = off[b]; k < off[b + 1]; k++) pos_w[at++] = pos[k];
+        if (at - off_w[w] > 1) std::sort(pos_w + off_w[w], pos_w + at);
+    }
+    off_w[kBuckets] = at;
+    free(off); free(pos);
+    *offsets = off_w; *positions = pos_w;
     return 0;
 }
 

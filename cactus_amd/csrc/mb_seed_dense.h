@@ -78,13 +78,14 @@ __global__ __launch_bounds__(256) void k_index_words_packed(const unsigned long 
     uint32_t w = 0xFFFFFFFFu;
     if (p + kSeedSpan <= n) {
         uint32_t ww;
-        if (packed_window_word(p2, pm, p, ww)) { w = ww; atomicAdd(&counts[ww], 1u); }
+        if (packed_window_word(p2, pm, p, ww)) { w = dense_bucket(ww); atomicAdd(&counts[w], 1u); }
     }
     words[s] = w;
 }
 
 // ---- q-ordered one-pass seed search ---------------------------------------------------------------------------------------------
-constexpr int kOrdThreads = 1024;             // threads per block; a tile = kOrdThreads x R query positions (R consecutive ones per thread)
+constexpr int kOrdThreadsMin = 512;           // threads per block: 1024 with one word variant, 512 with thirteen (74 VGPRs: three blocks of 8 waves per CU instead of one of 16);
+                                              // a tile = threads x R query positions (R consecutive ones per thread)
 constexpr int kOrdStage = 6144;               // keys a tile puts together in LDS (48 KiB); a tile with more writes them one by one
 constexpr unsigned long long kOrdFlagA = 1ull << 62, kOrdFlagP = 2ull << 62, kOrdValue = (1ull << 62) - 1ull;
 
@@ -97,8 +98,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // state: [0] ticket, [1] total hits of the strand (written by the last tile), [2 + t] look-back word of tile t -- all zero before the launch.
 // NV word variants per position (1 with --notransition, else 13); R positions per thread (4 with one variant: a quarter of the tiles --
 // tickets, block scans, look-backs -- for the 3 x 10^7 positions of a chunk's strand).
-template <bool PACKED, int R, int NV>
-__global__ __launch_bounds__(kOrdThreads) void k_seed_search_ord(const uint8_t *__restrict__ qcodes, const unsigned long long *__restrict__ p2,
+template <bool PACKED, int R, int NV, int kOrdThreads>
+__global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_search_ord(const uint8_t *__restrict__ qcodes, const unsigned long long *__restrict__ p2,
                                                                   const unsigned long long *__restrict__ pm, const int64_t qn, const int64_t qtot,
                                                                   const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ occ,
                                                                   const uint32_t *__restrict__ positions, const uint32_t hmul, const uint32_t hmask,
@@ -124,11 +125,12 @@ __global__ __launch_bounds__(kOrdThreads) void k_seed_search_ord(const uint8_t *
             uint32_t w = 0;
             bool valid = q + kSeedSpan <= qn;
             if (valid) valid = PACKED ? packed_window_word(p2, pm, q, w) : window_word(qcodes, q, w);
+            const uint32_t bkt = dense_bucket(w);                     // (mb_seedword.h: the 13 variants lie within one stretch of 4096 buckets)
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 b0[r * NV + v] = b1[r * NV + v] = 0;
                 if (valid) {
-                    const uint32_t wvv = variant_word(w, v);
+                    const uint32_t wvv = dense_variant(bkt, v);
                     if ((occ[wvv >> 5] >> (wvv & 31u)) & 1u) { b0[r * NV + v] = offsets[wvv]; b1[r * NV + v] = offsets[wvv + 1]; cnt += b1[r * NV + v] - b0[r * NV + v]; }
                 }
             }
