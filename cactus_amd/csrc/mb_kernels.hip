@@ -411,7 +411,7 @@ void launch_index_words_packed(const unsigned long long *p2, const unsigned long
 }
 
 // (tiles of 4096 positions with one word variant, of 512 with thirteen: the state is sized for the smaller tile)
-int64_t seed_ord_state_words(int64_t qtot) { return 2 + (qtot + kOrdThreadsMin - 1) / kOrdThreadsMin; }
+int64_t seed_ord_state_words(int64_t qtot) { return 2 + (qtot + kOrdThreadsMin - 1) / kOrdThreadsMin + 8; }      // (+ 8: the lab build's phase clocks)
 
 // state: seed_ord_state_words(qtot) zeroed words; state[1] = hits of the strand afterwards (also when they did not fit `cap`)
 void launch_seed_search_ord(const uint8_t *qcodes, const unsigned long long *p2, const unsigned long long *pm, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,

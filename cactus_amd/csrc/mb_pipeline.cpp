@@ -1452,6 +1452,15 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             if (ordered) {
                 for (int strand = 0; strand < 2; strand++)
                     MB_HIP(hipMemcpyAsync(w.pin_u64.p + strand, w.ord_state.p + (size_t)strand * (size_t)ord_words + 1, 8, hipMemcpyDeviceToHost, s));
+#ifdef MB_ORD_PROF
+                {
+                    const int per_tile = p.transitions ? 512 : 4096;
+                    const int64_t nt = (qtot + per_tile - 1) / per_tile;
+                    unsigned long long pc[5];
+                    MB_HIP(hipMemcpy(pc, w.ord_state.p + 2 + nt, sizeof pc, hipMemcpyDeviceToHost));
+                    if (pc[4]) fprintf(stderr, "[miblast] k_seed_search_ord, block 0 of strand +: %llu tiles; clocks per tile: lookups %llu, scan %llu, look-back %llu, keys %llu\n", pc[4], pc[0] / pc[4], pc[1] / pc[4], pc[2] / pc[4], pc[3] / pc[4]);
+                }
+#endif
             } else
             MB_HIP(hipMemcpyAsync(w.pin_u64.p, qbsum.p, 16, hipMemcpyDeviceToHost, s));
             tp[2] = now_s();

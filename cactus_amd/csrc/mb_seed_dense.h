@@ -98,6 +98,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // state: [0] ticket, [1] total hits of the strand (written by the last tile), [2 + t] look-back word of tile t -- all zero before the launch.
 // NV word variants per position (1 with --notransition, else 13); R positions per thread (4 with one variant: a quarter of the tiles --
 // tickets, block scans, look-backs -- for the 3 x 10^7 positions of a chunk's strand).
+#ifdef MB_ORD_PROF            // (lab build: shader clocks of a tile's phases, summed over the tiles of block 0 into the words behind the look-back words)
+#define MB_ORD_T(k) const long long ordt##k = (tid == 0) ? (long long)__builtin_readcyclecounter() : 0
+#define MB_ORD_FLUSH() do { if (tid == 0 && blockIdx.x == 0) { unsigned long long *pp = state + 2 + n_tiles; atomicAdd(pp + 0, (unsigned long long)(ordt1 - ordt0)); atomicAdd(pp + 1, (unsigned long long)(ordt2 - ordt1)); \
+    atomicAdd(pp + 2, (unsigned long long)(ordt3 - ordt2)); atomicAdd(pp + 3, (unsigned long long)(ordt4 - ordt3)); atomicAdd(pp + 4, 1ull); } } while (0)
+#else
+#define MB_ORD_T(k) do { } while (0)
+#define MB_ORD_FLUSH() do { } while (0)
+#endif
 template <bool PACKED, int R, int NV, int kOrdThreads>
 __global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_search_ord(const uint8_t *__restrict__ qcodes, const unsigned long long *__restrict__ p2,
                                                                   const unsigned long long *__restrict__ pm, const int64_t qn, const int64_t qtot,
@@ -116,6 +124,7 @@ __global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_search_or
         __syncthreads();
         const int tile = s_tile;
         if (tile >= n_tiles) return;
+        MB_ORD_T(0);
         const int64_t q0 = (int64_t)tile * kTile + (int64_t)tid * R;
         uint32_t b0[R * NV], b1[R * NV];
         unsigned cnt = 0;
@@ -135,9 +144,11 @@ __global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_search_or
                 }
             }
         }
+        MB_ORD_T(1);
         const unsigned incl = (unsigned)dpp_scan_add((int)cnt);
         if (lane == 63) wave_sum[wv] = incl;
         __syncthreads();
+        MB_ORD_T(2);
         unsigned before = 0, all = 0;
 #pragma unroll
         for (int k = 0; k < kOrdThreads / 64; k++) { const unsigned ws = wave_sum[k]; all += ws; before += k < wv ? ws : 0u; }
@@ -168,31 +179,57 @@ __global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_search_or
             }
         }
         __syncthreads();
+        MB_ORD_T(3);
         const unsigned long long excl = s_excl;
         if (excl + all <= cap && all) {                                 // (does not fit: the host makes room and searches again; the totals still come out)
             unsigned o = before + (incl - cnt);
             const bool staged = all <= (unsigned)kOrdStage;
             unsigned long long *const out = keys + excl;
+            if (staged && NV > 1) {
+                // a position's hits are listed in LDS first -- (slot in the table's position array, position's offset in the tile): no memory
+                // access in the lanes' serial loops -- and the tile's threads then fetch the target positions of ALL hits side by side and
+                // write the keys in order, whole cache lines at a time
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int64_t q = q0 + r;
-                const unsigned long long q_end = (unsigned long long)(q + kSeedSpan);
+                for (int r = 0; r < R; r++) {
+                    const unsigned long long qrel = (unsigned long long)(unsigned)(tid * R + r) << 32;
 #pragma unroll
-                for (int v = 0; v < NV; v++)
-                    for (uint32_t k = b0[r * NV + v]; k < b1[r * NV + v]; k++) {
-                        // diagonal d = t_end - q_end = p - q, biased by qtot so that it is not negative, then scrambled (see the head of the file)
-                        const uint32_t dq = (uint32_t)((int64_t)positions[k] - q + qtot);
-                        const unsigned long long key = ((unsigned long long)((dq * hmul) & hmask) << 32) | q_end;
-                        if (staged) stage[o] = key; else out[o] = key;
-                        o++;
-                    }
-            }
-            if (staged) {
+                    for (int v = 0; v < NV; v++)
+                        for (uint32_t k = b0[r * NV + v]; k < b1[r * NV + v]; k++) stage[o++] = qrel | k;
+                }
                 __syncthreads();
-                for (unsigned i = tid; i < all; i += kOrdThreads) out[i] = stage[i];
+                const int64_t qbase = (int64_t)tile * kTile;
+                for (unsigned i = tid; i < all; i += kOrdThreads) {
+                    const unsigned long long e = stage[i];
+                    const int64_t q = qbase + (int64_t)(e >> 32);
+                    const uint32_t dq = (uint32_t)((int64_t)positions[(uint32_t)e] - q + qtot);
+                    out[i] = ((unsigned long long)((dq * hmul) & hmask) << 32) | (unsigned long long)(q + kSeedSpan);
+                }
+            } else {
+                // (one word variant: a position has a hit or two, the lanes' loops are short -- the keys are made where the bounds are and only
+                //  pass through LDS to leave in whole cache lines)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int64_t q = q0 + r;
+                    const unsigned long long q_end = (unsigned long long)(q + kSeedSpan);
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+                        for (uint32_t k = b0[r * NV + v]; k < b1[r * NV + v]; k++) {
+                            // diagonal d = t_end - q_end = p - q, biased by qtot so that it is not negative, then scrambled (see the head of the file)
+                            const uint32_t dq = (uint32_t)((int64_t)positions[k] - q + qtot);
+                            const unsigned long long key = ((unsigned long long)((dq * hmul) & hmask) << 32) | q_end;
+                            if (staged) stage[o] = key; else out[o] = key;
+                            o++;
+                        }
+                }
+                if (staged) {
+                    __syncthreads();
+                    for (unsigned i = tid; i < all; i += kOrdThreads) out[i] = stage[i];
+                }
             }
         }
         __syncthreads();                                                // (stage, s_tile and s_excl are reused by the next tile)
+        MB_ORD_T(4);
+        MB_ORD_FLUSH();
     }
 }
 
