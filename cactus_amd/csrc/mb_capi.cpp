@@ -112,7 +112,7 @@ int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const cha
             // "has no effect when --ungapped is passed" (cactus_lastzRepeatMask.py:100); accepted for that case only
             if (!val || strncmp(val, "keep,nowarn:", 12) || !parse_int(val + 12, v) || v < 1) return bad(a, "unsupported --querydepth form");
             querydepth_seen = true;
-        } else if (key == "--miblast-diag") {                  // oracle comparison switches: parsed so that one argv serves both, refused at run time
+        } else if (key == "--miblast-diag") {                  // the oracle's comparison switches: one argv serves both implementations
             if (!val || (strcmp(val, "exact") && strcmp(val, "hash16"))) return bad(a, "unsupported --miblast-diag form");
             p->diag_hash16 = !strcmp(val, "hash16");
         } else if (key == "--miblast-walls" && !val) p->walls = 1;

@@ -56,8 +56,9 @@ typedef struct miblast_params {
     int32_t markend;       /* --markend: terminate the output with "# lastz end-of-file"                  */
     int32_t queryhsplimit; /* --queryhsplimit=keep,nowarn:N : per query sequence and strand keep only the first N HSPs found; 0 = off */
     /* The oracle's named comparison switches (oracle/lastz_oracle.h), kept in the same place so that the
-     * two structs stay copy-compatible.  The MI355X path implements the default reading only: a non-zero value is refused
-     * with MIBLAST_EINVAL, never ignored.                                                                                  */
+     * two structs stay copy-compatible.  The MI355X path implements both (mb_hash16.h; the WALLS variant of the 4-wave DP kernel) and
+     * gives the oracle's bytes with each; a call they cannot serve (diag=hash16 beyond one seed batch, more than 1 024 earlier
+     * alignments per unit with walls, blocked inputs) is refused with MIBLAST_ELIMIT, never answered in the default reading.     */
     int32_t diag_hash16;   /* --miblast-diag=hash16 */
     int32_t walls;         /* --miblast-walls       */
 } miblast_params;
