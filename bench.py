@@ -79,6 +79,9 @@ def parse_args():
                     help="evolver: BASELINE configs[2] stand-in (default; weak scaling: every GPU its own phase); pair: configs[1], one synthetic "
                          "chunk pair per GPU; chr20: configs[3], ONE genome pair whose chunk pairs are dealt to the GPUs (strong scaling); hm: the "
                          "scaled human-mouse stand-in of configs[4], same sharding")
+    ap.add_argument("--split-strands", default="auto", choices=("auto", "0", "1"),
+                    help="chunk-scale workloads: deal (chunk pair, query strand) units instead of whole chunk pairs (exact: miblast_params.strands; the halves of a "
+                         "pair are put together on rank 0) -- auto: when there are fewer than four chunk pairs per GPU")
     ap.add_argument("--chunk-legs", type=int, default=1, help="evolver workload: also time the chunk-scale configurations chr20 (configs[3]) and hm (configs[4] stand-in) "
                                                               "on this GPU, every chunk pair checked against its oracle digest (0 = skip); reported under chr20 / hm")
     ap.add_argument("--chr20-bases", type=int, default=64_444_167, help="chr20 workload: bases of the synthetic chromosome (SURVEY 8d config 4)")
@@ -298,13 +301,17 @@ class ChunkWorkload:
         self.OPTIONS = w.options
         self.pm = miblast.params_from_args(w.options.split())
         self.tfa, self.qfa, self.pairs = w.tfa, w.qfa, w.pairs
-        self.weights = w.weights()
+        # work units: whole chunk pairs (strand code 0), or -- few pairs per GPU -- (chunk pair, query strand): 1 '+', 2 '-'
+        mode = getattr(a, "split_strands", "auto")
+        self.split = mode == "1" or (mode == "auto" and world > 1 and len(w.pairs) < 4 * world)
+        self.units = [(k, sc) for k in range(len(w.pairs)) for sc in ((1, 2) if self.split else (0,))]
+        self.weights = [w.weights()[k] * (0.5 if sc else 1.0) for k, sc in self.units]
         self.mine = assign_pairs(self.weights, world)[rank]
-        need_t, need_q = sorted({self.pairs[k][0] for k in self.mine}), sorted({self.pairs[k][1] for k in self.mine})
+        self.pm_strand = {sc: miblast.params_from_args(w.options.split() + ([] if sc == 0 else ["--strand=" + ("plus" if sc == 1 else "minus")])) for sc in (0, 1, 2)}
+        need_t, need_q = sorted({self.pairs[self.units[u][0]][0] for u in self.mine}), sorted({self.pairs[self.units[u][0]][1] for u in self.mine})
         self.T = {i: ctx.seqset_from_fasta_bytes(self.tfa[i]) for i in need_t}                 # only this rank's chunks go to its HBM
         self.Q = {j: ctx.seqset_from_fasta_bytes(self.qfa[j]) for j in need_q}
         self.describe = w.describe + f", dealt longest first to {world} GPU(s)"
-        self.last = {}                                     # pair index -> PAF of the last step (digest check)
 
     def close(self):
         for h in list(self.T.values()) + list(self.Q.values()):
@@ -316,13 +323,21 @@ class ChunkWorkload:
         blob = b""
         self.miblast.drop_derived()                        # a step builds every seed table, '-' strand and packed strand it uses (once)
         if self.mine:
-            sets = [(self.T[self.pairs[k][0]], self.Q[self.pairs[k][1]]) for k in self.mine]
-            rs = self.ctx.align_pairs(sets, self.pm) if len(sets) > 1 else [self.ctx.align(*sets[0], self.pm, details=False)]
-            add_stats(agg, [r.stats for r in rs])
-            blob = b"".join(_frame(k, r.paf) for k, r in zip(self.mine, rs))
-            self.last = {k: r.paf for k, r in zip(self.mine, rs)}
-            if keep is not None:
-                keep.extend((self.tfa[self.pairs[k][0]], self.qfa[self.pairs[k][1]], self.OPTIONS, r.paf) for k, r in zip(self.mine, rs))
+            frames = []
+            for sc in (0, 1, 2):                            # one batched call per strand selection of this rank's units
+                us = [u for u in self.mine if self.units[u][1] == sc]
+                if not us:
+                    continue
+                sets = [(self.T[self.pairs[self.units[u][0]][0]], self.Q[self.pairs[self.units[u][0]][1]]) for u in us]
+                rs = self.ctx.align_pairs(sets, self.pm_strand[sc]) if len(sets) > 1 else [self.ctx.align(*sets[0], self.pm_strand[sc], details=False)]
+                call = {}
+                add_stats(call, [r.stats for r in rs])
+                for key, v in call.items():
+                    agg[key] = agg.get(key, 0) + v
+                frames += [_frame(u, r.paf) for u, r in zip(us, rs)]
+                if keep is not None and sc == 0:
+                    keep.extend((self.tfa[self.pairs[self.units[u][0]][0]], self.qfa[self.pairs[self.units[u][0]][1]], self.OPTIONS, r.paf) for u, r in zip(us, rs))
+            blob = b"".join(frames)
         else:
             for k in PER_PAIR + PER_BATCH:
                 agg[k] = 0
@@ -330,12 +345,18 @@ class ChunkWorkload:
 
     def assemble(self, gathered):
         """rank 0: the ranks' framed PAFs -> {pair index: PAF} and one PAF in chunk-pair order"""
-        from cactus_amd.multigpu import _unframe
-        by_index = {}
+        from cactus_amd.multigpu import _unframe, fasta_names, merge_strand_pafs
+        by_unit = {}
         for part in gathered:
             for idx, paf in _unframe(part):
-                by_index[idx] = paf
-        assert sorted(by_index) == list(range(len(self.pairs))), "a chunk pair is missing from the gather"
+                by_unit[idx] = paf
+        assert sorted(by_unit) == list(range(len(self.units))), "a work unit is missing from the gather"
+        by_index = {}
+        for u, (k, sc) in enumerate(self.units):
+            if sc == 0:
+                by_index[k] = by_unit[u]
+            elif sc == 1:                                   # (its '-' half is the next unit)
+                by_index[k] = merge_strand_pafs(by_unit[u], by_unit[u + 1], fasta_names(self.qfa[self.pairs[k][1]]))
         self.by_index = by_index
         return b"".join(by_index[k] for k in range(len(self.pairs)))
 
@@ -598,7 +619,8 @@ def run_rank(a):
             import hashlib
             out["config"]["paf_md5"] = hashlib.md5(gathered["paf"]).hexdigest()
             out["config"]["paf_bytes"] = len(gathered["paf"])
-            out["config"]["chunk_pairs_per_rank"] = [len(x) for x in __import__("cactus_amd.multigpu", fromlist=["assign_pairs"]).assign_pairs(work.weights, world)]
+            out["config"]["work_unit"] = "(chunk pair, query strand)" if work.split else "chunk pair"
+            out["config"]["units_per_rank"] = [len(x) for x in __import__("cactus_amd.multigpu", fromlist=["assign_pairs"]).assign_pairs(work.weights, world)]
             out["parity"] = work.digest_check(work.by_index)
             out["hbm_read"] = work.b_read(tot, per, elapsed / a.steps)
             out["config"]["residency"] = ("chunks resident in HBM before the timed region (parse + upload excluded); seed tables, '-' strands and packed strands "
@@ -725,9 +747,10 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     from cactus_amd.multigpu import assign_pairs
     shares = assign_pairs(w.weights, world)
     load = [sum(w.weights[k] for k in sh) for sh in shares]
+    unit_kind = "(chunk pair, query strand)" if w.split else "chunk pair"
     out = {"workload": w.describe, "chunk_pairs": len(w.pairs), "n_gpus": world, "scaling": "strong", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
            "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
-           "chunk_pairs_per_rank": [len(sh) for sh in shares], "balance_by_weight": (sum(load) / len(load)) / max(load) if max(load) > 0 else 1.0,
+           "work_unit": unit_kind, "units_per_rank": [len(sh) for sh in shares], "balance_by_weight": (sum(load) / len(load)) / max(load) if max(load) > 0 else 1.0,
            "seeds_per_s": tot["seed_hits"] / elapsed, "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
            "dp_cells_per_step": tot["dp_cells"] / steps, "seed_hits_per_step": tot["seed_hits"] / steps, "alignments_per_step": tot["alignments"] / steps,
            "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),

@@ -52,7 +52,7 @@ extern "C" {
 void miblast_params_default(miblast_params *p) {
     p->step = 1; p->transitions = 1; p->xdrop = 910; p->ydrop = 9400; p->hspthresh = 3000; p->gappedthresh = -1;
     p->gap_open = 400; p->gap_extend = 30; p->entropy = 1; p->queryhspbest = 0; p->ambiguous_n = 1; p->gapped = 1;
-    p->format = 0; p->markend = 0; p->queryhsplimit = 0; p->diag_hash16 = 0; p->walls = 0;
+    p->format = 0; p->markend = 0; p->queryhsplimit = 0; p->diag_hash16 = 0; p->walls = 0; p->strands = 0;
 }
 
 int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const char *files[2], int *num_gpu, int *num_threads) {
@@ -116,6 +116,11 @@ int miblast_params_from_argv(int argc, char **argv, miblast_params *p, const cha
             if (!val || (strcmp(val, "exact") && strcmp(val, "hash16"))) return bad(a, "unsupported --miblast-diag form");
             p->diag_hash16 = !strcmp(val, "hash16");
         } else if (key == "--miblast-walls" && !val) p->walls = 1;
+        else if (key == "--strand") {                        // lastz's --strand=both|plus|minus
+            if (!val) return bad(a, "--strand needs both, plus or minus");
+            if (!strcmp(val, "both")) p->strands = 0; else if (!strcmp(val, "plus")) p->strands = 1; else if (!strcmp(val, "minus")) p->strands = 2;
+            else return bad(a, "--strand needs both, plus or minus");
+        }
         else if (key == "--num_gpu") {                       // run_kegalign form: "--num_gpu N" (local_alignment.py:58)
             if (val) { if (!parse_int(val, v) || v < 1) return bad(a, "bad value for option"); }
             else { if (i + 1 >= argc || !parse_int(argv[++i], v) || v < 1) return bad(a, "bad value for option"); }

@@ -1276,6 +1276,7 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
                 if (strand == 0) job.valid_windows = valid;
             }
             out.lookups = valid * (p.transitions ? 1 + kSeedWeight : 1);
+            if ((p.strands == 1 && strand == 1) || (p.strands == 2 && strand == 0)) out.lookups = 0;      // --strand: this one is not searched
         }
         // (the level-synchronous kernels leave the candidates of hits that the suppression rule dropped in the list, marked)
         found.erase(std::remove_if(found.begin(), found.end(), [](const DevHsp &d) { return d.score == INT32_MIN; }), found.end());
@@ -1430,7 +1431,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     bool strand_done[2] = {false, false};
     unsigned long long strand_hits[2] = {0, 0};                  // (for sizing the key buffer of the next call)
     std::future<void> host0;
-    if (one_pass && qtot >= kSeedSpan && env_long("MIBLAST_SEED_FUSED", 1) != 0) {
+    // --strand=plus / minus (miblast_params.strands): the other strand is not searched -- it has no hits, no look-ups, no HSPs
+    const bool skip_strand[2] = {p.strands == 2, p.strands == 1};
+    if (one_pass && qtot >= kSeedSpan && p.strands == 0 && env_long("MIBLAST_SEED_FUSED", 1) != 0) {
         const unsigned long long capH = std::min<unsigned long long>((unsigned long long)keys_a.n, (unsigned long long)hit_cap) / 2;
         // (a pair like the previous one of this workspace must fit, else the attempt costs two searches for nothing)
         if (capH > 0 && w.last_strand_hits + w.last_strand_hits / 8 <= capH) {
@@ -1532,6 +1535,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         }
     }
     for (int strand = 0; strand < 2 && qtot >= kSeedSpan; strand++) {
+        if (skip_strand[strand]) { job.found[strand].clear(); continue; }
         if (strand_done[strand]) {
             if (!job.defer_host && strand == 0 && !host0.valid()) host0 = std::async(std::launch::async, [&p, &job] { seed_host(p, job, 0); });
             continue;
@@ -1656,7 +1660,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     }
     if (host0.valid()) host0.get();
     if (!job.defer_host) {
-        if (qtot >= kSeedSpan) seed_host(p, job, 1);
+        if (qtot >= kSeedSpan) { if (!host0.valid() && p.strands == 2) seed_host(p, job, 0); seed_host(p, job, 1); }
         seed_finish(job);
     }
     return MIBLAST_OK;
@@ -3369,7 +3373,9 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     // a single pair that will fit one key buffer with room to spare (half the launches of the pair-by-pair path; chance hits expected
     // from the sizes: 2 strands x word variants x |T| x |Q| / 4^12 -- an 8 Mb pair would count its 10^8 hits only to be sent back);
     // 2: every single pair goes that way (tests); 0: never -- pair by pair on the lanes below
-    const long batched_mode = p.diag_hash16 ? 2 : env_long("MIBLAST_SEED_BATCHED", 1);      // (diag=hash16 lives in the shared seed stage only)
+    if (p.diag_hash16 && p.strands) { set_error("--strand=plus / minus together with diag=hash16 is not provided"); return MIBLAST_EINVAL; }
+    // (diag=hash16 lives in the shared seed stage only; --strand=plus / minus in the pair-by-pair one: it is the work unit of large chunk pairs)
+    const long batched_mode = p.diag_hash16 ? 2 : p.strands ? 0 : env_long("MIBLAST_SEED_BATCHED", 1);
     bool small_single = false;
     if (n == 1) {
         const double expected = 2.0 * (p.transitions ? 1 + kSeedWeight : 1) * (double)Ts[0]->total * (double)Qs[0]->total / (double)kBuckets;

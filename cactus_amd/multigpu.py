@@ -57,6 +57,26 @@ def gather_bytes(payload: bytes, dist, rank: int, world_size: int, device) -> Op
     return [payload] + [bufs[src].cpu().numpy().tobytes() if src in bufs else b"" for src in range(1, world_size)]
 
 
+def fasta_names(fasta: bytes):
+    """names (first word of the header) of the records of FASTA text, in file order"""
+    return [line[1:].split()[0] if line[1:].split() else b"" for line in fasta.splitlines() if line.startswith(b">")]
+
+
+def merge_strand_pafs(plus: bytes, minus: bytes, query_names) -> bytes:
+    """The PAF of a chunk pair from its two halves `--strand=plus` and `--strand=minus` (miblast_params.strands): lastz writes, query
+    sequence by query sequence in FILE order, the '+' alignments and then the '-' ones, and a half holds its lines in
+    the same order.  query_names: the query file's record names in order (fasta_names)."""
+    def groups(paf):
+        out = {}
+        for line in paf.splitlines(True):
+            out.setdefault(line.split(b"\t", 1)[0], []).append(line)
+        return out
+    gp, gm = groups(plus), groups(minus)
+    known = set(query_names)
+    assert set(gp) <= known and set(gm) <= known, "a PAF query name that is not in the query file"
+    return b"".join(b"".join(gp.get(n, [])) + b"".join(gm.get(n, [])) for n in query_names)
+
+
 def _frame(index: int, paf: bytes) -> bytes:
     return index.to_bytes(8, "little") + len(paf).to_bytes(8, "little") + paf
 

@@ -61,6 +61,11 @@ typedef struct miblast_params {
      * alignments per unit with walls, blocked inputs) is refused with MIBLAST_ELIMIT, never answered in the default reading.     */
     int32_t diag_hash16;   /* --miblast-diag=hash16 */
     int32_t walls;         /* --miblast-walls       */
+    /* --strand=both|plus|minus (lastz's own option; Cactus never passes it): 0 both, 1 only the query's '+' strand, 2 only its '-'
+     * strand.  A query strand's HSPs and alignments do not depend on the other strand's, and a pair's PAF is, query sequence by query
+     * sequence, the '+' lines followed by the '-' lines: (chunk pair, strand) is the exact work unit below the chunk pair
+     * (cactus_amd.multigpu.merge_strand_pafs puts the halves together).                                                 */
+    int32_t strands;
 } miblast_params;
 
 void miblast_params_default(miblast_params *p);

@@ -49,7 +49,7 @@ void olz_params_default(olz_params *p) {
     p->format = 0;
     p->markend = 0;
     p->queryhsplimit = 0;
-    p->diag_hash16 = 0; p->walls = 0;
+    p->diag_hash16 = 0; p->walls = 0; p->strands = 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -491,6 +491,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
     range_t *aln_ranges = (range_t *)calloc((size_t)Q->n_contigs * 2 + 1, sizeof(range_t));
 
     for (int strand = 0; strand < 2; strand++) {
+        if ((p.strands == 1 && strand == 1) || (p.strands == 2 && strand == 0)) continue;      /* --strand=plus / minus */
         double t0s = now_s();
         x.qc = strand ? qrc : Q->codes;
         memset(extent, 0, (size_t)ndiag * 4);

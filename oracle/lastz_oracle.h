@@ -58,6 +58,8 @@ typedef struct olz_params {
                               colliding diagonals are silently dropped; sequential in hit generation order                   */
     int32_t walls;         /* 1: base pairs on the path of an earlier alignment of the same query sequence and strand are hard
                               walls for later DPs (A.7): a cell pairing such bases is dead and no gap passes through it      */
+    int32_t strands;       /* --strand=both|plus|minus: 0 both, 1 only '+', 2 only '-' (the strands are searched and extended
+                              independently of each other: A.8)                                                                */
 } olz_params;
 
 void olz_params_default(olz_params *p);

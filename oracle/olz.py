@@ -14,7 +14,7 @@ CLI_PATH = os.path.join(_HERE, "oracle_lastz")
 
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("step", "transitions", "xdrop", "ydrop", "hspthresh", "gappedthresh", "gap_open",
-                                          "gap_extend", "entropy", "queryhspbest", "ambiguous_n", "gapped", "format", "markend", "queryhsplimit", "diag_hash16", "walls")]
+                                          "gap_extend", "entropy", "queryhspbest", "ambiguous_n", "gapped", "format", "markend", "queryhsplimit", "diag_hash16", "walls", "strands")]
 
 
 class SeqSetS(C.Structure):

@@ -46,6 +46,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--miblast-diag=hash16")) p.diag_hash16 = 1;
         else if (!strcmp(a, "--miblast-diag=exact")) p.diag_hash16 = 0;
         else if (!strcmp(a, "--miblast-walls")) p.walls = 1;
+        else if (!strcmp(a, "--strand=both")) p.strands = 0;
+        else if (!strcmp(a, "--strand=plus")) p.strands = 1;
+        else if (!strcmp(a, "--strand=minus")) p.strands = 2;
         else if (!strncmp(a, "--queryhsplimit=keep,nowarn:", 28)) p.queryhsplimit = atoi(a + 28);
         else if (!strncmp(a, "--querydepth=keep,nowarn:", 25)) { /* no effect with --ungapped (cactus_lastzRepeatMask.py:100) */ }
         else if (!strcmp(a, "--counters")) counters = 1;

@@ -66,7 +66,7 @@ def test_chr20_workload_shards_one_genome_pair_and_the_bytes_do_not_depend_on_th
     args = ["--workload", "chr20", "--chr20-bases", "300000", "--chr20-chunk", "120000", "--steps", "1", "--warmup", "1", "--seed-leg", "0", "--chain-leg", "0",
             "--batch-leg", "0", "--cpu-sample", "0"]
     one = _bench(args)
-    assert one["scaling"] == "strong" and "configs[3]" in one["config"]["workload"] and one["config"]["chunk_pairs_per_rank"] == [9]
+    assert one["scaling"] == "strong" and "configs[3]" in one["config"]["workload"] and one["config"]["units_per_rank"] == [9] and one["config"]["work_unit"] == "chunk pair"
     t, q = gen.make_pair(300000, 3001, sub_rate=0.013, indel_rate=0.002, mask_frac=0.5)
     chunks = lambda name, seq: [gen.fasta_bytes([(f"{name}|{len(seq)}|{s0}", seq[s0:s0 + 130000])]) for s0 in range(0, len(seq), 120000)]      # noqa: E731
     pm = miblast.params_from_args("--step=2 --ambiguous=iupac,100,100 --ydrop=3000 --notransition --queryhspbest=100000".split())
@@ -75,7 +75,10 @@ def test_chr20_workload_shards_one_genome_pair_and_the_bytes_do_not_depend_on_th
     assert one["config"]["paf_md5"] == hashlib.md5(want).hexdigest() and one["config"]["paf_bytes"] == len(want) > 1000
     for n in (2, 3):
         many = _bench(args + ["--gpus", str(n)], MIBLAST_BENCH_SINGLE_DEVICE="1", MIBLAST_BENCH_BACKEND="gloo")
-        assert many["n_gpus"] == n and many["scaling"] == "strong" and sum(many["config"]["chunk_pairs_per_rank"]) == 9 and len(many["config"]["chunk_pairs_per_rank"]) == n
+        # (fewer than four chunk pairs per GPU -- nine over three ranks -- and the units are the 18 (chunk pair, query strand) halves)
+        split = 9 < 4 * n
+        assert many["n_gpus"] == n and many["scaling"] == "strong" and many["config"]["work_unit"] == ("(chunk pair, query strand)" if split else "chunk pair")
+        assert sum(many["config"]["units_per_rank"]) == (18 if split else 9) and len(many["config"]["units_per_rank"]) == n
         assert many["config"]["paf_md5"] == one["config"]["paf_md5"]
         assert many["dp_cells_per_step"] == one["dp_cells_per_step"]                     # the whole job's work, whoever did it
 
@@ -144,7 +147,17 @@ def test_chunk_scale_legs_are_sharded_over_the_ranks_and_every_pair_equals_its_o
     out = _bench(args, MIBLAST_BENCH_SINGLE_DEVICE="1", MIBLAST_BENCH_BACKEND="gloo")
     for which, n_pairs in (("chr20", 9), ("hm", 42)):
         leg = out[which]
-        assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["chunk_pairs"] == n_pairs and sum(leg["chunk_pairs_per_rank"]) == n_pairs
+        assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["chunk_pairs"] == n_pairs
+        assert leg["work_unit"] == "chunk pair" and sum(leg["units_per_rank"]) == n_pairs      # (nine pairs over two ranks: whole pairs; the halves are dealt below four pairs per GPU)
         assert leg["parity"]["same_bytes"] is True and leg["parity"]["pairs_checked"] == n_pairs and leg["parity"]["pairs_differing"] == 0
         assert leg["dp_cells_per_step"] == leg["parity"]["oracle_dp_cells"] and leg["seed_hits_per_step"] == leg["parity"]["oracle_seed_hits"]
         assert 0 < leg["hbm_read"]["frac"] < 1
+
+
+def test_full_size_chr20_dealt_as_strand_halves_equals_the_digests():
+    """BASELINE configs[3] at full size with the (chunk pair, query strand) units forced on one GPU: 18 half-pair jobs in two batched
+    calls, the halves put together on the host -- every chunk pair's PAF still equals the CPU oracle's digest of the WHOLE pair."""
+    out = _bench(["--workload", "chr20", "--split-strands", "1", "--steps", "1", "--warmup", "0", "--seed-leg", "0", "--chain-leg", "0", "--batch-leg", "0", "--cpu-sample", "0"])
+    assert out["config"]["work_unit"] == "(chunk pair, query strand)" and out["config"]["units_per_rank"] == [18]
+    assert out["parity"]["same_bytes"] is True and out["parity"]["pairs_checked"] == 9
+    assert out["dp_cells_per_step"] == out["parity"]["oracle_dp_cells"] and out["seed_hits_per_step"] == out["parity"]["oracle_seed_hits"]

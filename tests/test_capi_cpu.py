@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # 15 x int32 params + the oracle's two comparison switches ; stats = 12 int64 + 4 double + extras
-    assert C.sizeof(miblast.Params) == 68
+    # 15 x int32 params + the oracle's two comparison switches + strands ; stats = 12 int64 + 4 double + extras
+    assert C.sizeof(miblast.Params) == 72
     assert C.sizeof(miblast.Hsp) == 48 and C.sizeof(miblast.Aln) == 64
     assert C.sizeof(miblast.Stats) == 12 * 8 + 4 * 8 + 4 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 6 * 8       # + relay_accepted, relay_rejected, t_traceback_ms, t_merge_ms, dp_reruns, t_dp_busy_ms
 
@@ -40,7 +40,8 @@ def test_default_params_are_lastz_defaults():
     p = miblast.default_params()
     assert (p.step, p.transitions, p.xdrop, p.ydrop, p.hspthresh, p.gappedthresh, p.gap_open, p.gap_extend, p.entropy,
             p.queryhspbest, p.ambiguous_n, p.gapped, p.format, p.markend, p.queryhsplimit) == (1, 1, 910, 9400, 3000, -1, 400, 30, 1, 0, 1, 1, 0, 0, 0)
-    assert (p.diag_hash16, p.walls) == (0, 0)
+    assert (p.diag_hash16, p.walls, p.strands) == (0, 0, 0)
+    assert [miblast.params_from_args([a]).strands for a in ("--strand=both", "--strand=plus", "--strand=minus")] == [0, 1, 2]      # lastz's --strand
     both = miblast.params_from_args(["--miblast-diag=hash16", "--miblast-walls"])       # parsed (one argv serves oracle and product) ...
     assert (both.diag_hash16, both.walls) == (1, 1)                                      # ... and refused at run time (GPU test)
 

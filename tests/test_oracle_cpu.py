@@ -211,3 +211,24 @@ def test_named_switches_for_the_points_a_real_lastz_may_differ_on(olz):
     w = pairs(walled)
     assert all(not (w[i] & w[j]) for i in range(len(w)) for j in range(i + 1, len(w)))          # no base pair on two paths
     assert walled["alns"][0] == free["alns"][0]                                                # the first alignment has nothing to respect
+
+
+def test_strand_halves_interleaved_by_query_sequence_are_the_whole(olz):
+    """--strand=plus / minus (olz_params.strands; lastz's own option): a strand's search, HSPs and alignments do not depend on the
+    other strand's, and the whole PAF is, query sequence by query sequence in file order, the '+' lines then the '-' lines -- so
+    (chunk pair, strand) is an exact work unit (cactus_amd.multigpu.merge_strand_pafs; the GPU suite checks the product's halves)."""
+    from cases import CASES
+    from cactus_amd import miblast
+    from cactus_amd.multigpu import fasta_names, merge_strand_pafs
+    n = 0
+    for name, tf, qf, args in CASES:
+        if any(a.startswith("--format=general") for a in args):
+            continue
+        pm = miblast.params_from_args(args)
+        po = lambda **kw: olz.default_params(**{**{f: getattr(pm, f) for f, _ in pm._fields_}, **kw})      # noqa: E731
+        both, plus, minus = (olz.align(tf, qf, po(strands=s), details=False) for s in (0, 1, 2))
+        assert merge_strand_pafs(plus["paf"], minus["paf"], fasta_names(qf)) == both["paf"], name
+        for k in ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_cells", "dp_rows", "alignments"):
+            assert plus["counters"][k] + minus["counters"][k] == both["counters"][k], (name, k)
+        n += both["paf"].count(b"\n")
+    assert n > 50

@@ -73,6 +73,32 @@ def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
         T.close(); Q.close()
 
 
+def test_strand_halves_of_a_pair_put_together_equal_the_whole(gpu_ctx, olz, monkeypatch):
+    """--strand=plus / minus (miblast_params.strands, lastz's own option): each half equals the oracle's half -- PAF, HSPs, counters --
+    and the two halves interleaved by query sequence in file order (cactus_amd.multigpu.merge_strand_pafs) are the whole pair's PAF:
+    (chunk pair, strand) is an exact work unit below the chunk pair.  Multi-contig, busy-diagonal and plain cases, through
+    the one-pair call and through a batched call."""
+    from cases import DEFAULT, multi_contig, pair
+    from cactus_amd.multigpu import fasta_names, merge_strand_pafs
+    for tf, qf in (multi_contig(9), pair(120000, 3), pair(50000, 12, sub_rate=0.03)):
+        T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+        whole = gpu_ctx.align(T, Q, _params(DEFAULT))
+        halves = []
+        for opt in ("--strand=plus", "--strand=minus"):
+            pm = _params(DEFAULT + [opt])
+            got = gpu_ctx.align(T, Q, pm)
+            want = olz.align(tf, qf, _oracle_params(olz, pm))
+            assert got.paf == want["paf"] and got.hsps == want["hsps"] and got.alns == want["alns"], opt
+            for k in COUNTERS:
+                assert got.stats[k] == want["counters"][k], (opt, k)
+            assert gpu_ctx.align_pairs([(T, Q), (T, Q)], pm)[1].paf == got.paf
+            halves.append(got)
+        assert merge_strand_pafs(halves[0].paf, halves[1].paf, fasta_names(qf)) == whole.paf
+        for k in COUNTERS:
+            assert halves[0].stats[k] + halves[1].stats[k] == whole.stats[k], k
+        T.close(); Q.close()
+
+
 def _ref_argv():
     import json
     return json.load(open(os.path.join(ROOT, "tests", "golden", "ref_argv.json")))["run_lastz"]
