@@ -209,8 +209,8 @@ void launch_index_words_packed(const unsigned long long *p2, const unsigned long
                                uint32_t *counts, hipStream_t s);
 int64_t seed_ord_state_words(int64_t qtot);
 void launch_seed_search_ord(const uint8_t *qcodes, const unsigned long long *p2, const unsigned long long *pm, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
-                            const uint32_t *positions, int transitions, uint32_t hmul, uint32_t hmask, unsigned long long *keys, unsigned long long cap,
-                            unsigned long long *state, hipStream_t s);
+                            const uint32_t *positions, int transitions, uint32_t hmul, uint32_t hmask, unsigned long long *keys, unsigned long long *scratch,
+                            unsigned long long cap, unsigned long long *state, hipStream_t s);      // state[0] = hits of the strand afterwards
 void launch_keys_unhash(unsigned long long *keys, int64_t n, uint32_t hinv, uint32_t hmask, hipStream_t s);
 void launch_scan_index(uint32_t *counts, uint32_t *offsets, unsigned long long *block_sums, uint32_t *occ, hipStream_t s);
 void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *occ, const uint32_t *positions, int transitions,

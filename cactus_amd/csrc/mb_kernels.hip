@@ -410,21 +410,33 @@ void launch_index_words_packed(const unsigned long long *p2, const unsigned long
     hipLaunchKernelGGL(k_index_words_packed, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, p2, pm, n, step, first, words, n_slots, counts);
 }
 
-// (tiles of 4096 positions with one word variant, of 512 with thirteen: the state is sized for the smaller tile)
-int64_t seed_ord_state_words(int64_t qtot) { return 2 + (qtot + kOrdThreadsMin - 1) / kOrdThreadsMin + 8; }      // (+ 8: the lab build's phase clocks)
+// state (u64 words, zeroed by the caller): [0] hits of the strand (also when they did not fit `cap`), [8 ..) one word per tile = its
+// stretch of the scratch, then u32 tile counts, their scan and the scan's block sums -- seed_ord_state_words(qtot) words in all.
+// (tiles of 4096 positions with one word variant, of 512 with thirteen: sized for the smaller tile)
+static int64_t ord_tiles_max(int64_t qtot) { return (((qtot + kOrdThreadsMin - 1) / kOrdThreadsMin + 1) + 3) & ~(int64_t)3; }      // (a multiple of 4: the u32 arrays behind it stay 16-byte aligned)
+int64_t seed_ord_state_words(int64_t qtot) {
+    const int64_t t = ord_tiles_max(qtot);
+    return (8 + t + t / 2 + t / 2 + (t / 2048 + 4) + 8 + 1) & ~(int64_t)1;
+}
 
-// state: seed_ord_state_words(qtot) zeroed words; state[1] = hits of the strand afterwards (also when they did not fit `cap`)
+// scratch: `cap` words (the sort's output buffer serves); keys: `cap` words; the kernels are queued on s, nothing is waited for
 void launch_seed_search_ord(const uint8_t *qcodes, const unsigned long long *p2, const unsigned long long *pm, int64_t qtot, const uint32_t *offsets, const uint32_t *occ,
-                            const uint32_t *positions, int transitions, uint32_t hmul, uint32_t hmask, unsigned long long *keys, unsigned long long cap,
-                            unsigned long long *state, hipStream_t s) {
+                            const uint32_t *positions, int transitions, uint32_t hmul, uint32_t hmask, unsigned long long *keys, unsigned long long *scratch,
+                            unsigned long long cap, unsigned long long *state, hipStream_t s) {
     if (qtot <= 0) return;
     const int threads = transitions ? 512 : 1024, per_tile = threads * (transitions ? 1 : 4);
     const int n_tiles = (int)((qtot + per_tile - 1) / per_tile);
-    const unsigned grid = (unsigned)std::min(n_tiles, transitions ? 768 : 512);      // what a GPU holds at a time: three blocks of 512 / two of 1024 threads per CU
-#define MB_ORD(P, R, NV, T) hipLaunchKernelGGL((k_seed_search_ord<P, R, NV, T>), dim3(grid), dim3(T), 0, s, qcodes, p2, pm, qtot, qtot, offsets, occ, positions, hmul, hmask, keys, cap, state, n_tiles)
+    const int64_t t = ord_tiles_max(qtot);
+    unsigned long long *tile_base = state + 8;
+    uint32_t *tile_cnt = (uint32_t *)(state + 8 + t), *tile_off = (uint32_t *)(state + 8 + t + t / 2);
+    unsigned long long *sums = state + 8 + t + t / 2 + t / 2;
+    const unsigned grid = (unsigned)std::min(n_tiles, transitions ? 3072 : 1024);
+#define MB_ORD(P, R, NV, T) hipLaunchKernelGGL((k_seed_hits<P, R, NV, T>), dim3(grid), dim3(T), 0, s, qcodes, p2, pm, qtot, offsets, occ, scratch, cap, state, tile_base, tile_cnt, n_tiles)
     if (transitions) { if (p2) MB_ORD(true, 1, 1 + kSeedWeight, 512); else MB_ORD(false, 1, 1 + kSeedWeight, 512); }
     else { if (p2) MB_ORD(true, 4, 1, 1024); else MB_ORD(false, 4, 1, 1024); }
 #undef MB_ORD
+    launch_scan_u32(tile_cnt, tile_off, n_tiles, sums, s);
+    hipLaunchKernelGGL(k_seed_keys, dim3((unsigned)std::min(n_tiles, 8192)), dim3(256), 0, s, scratch, tile_base, tile_cnt, tile_off, positions, keys, cap, qtot, per_tile, hmul, hmask, n_tiles);
     MB_HIP(hipGetLastError());
 }
 

@@ -635,7 +635,7 @@ struct Workspace {                      // device buffers that persist across mi
     bool counts_zero = false;                 // `counts` is all zero (build_index leaves it so)
     PackedStrand pack_t;                      // the packed target of the build in progress (scratch)
     std::shared_ptr<SeedTable> own_table;     // MIBLAST_RESIDENT_TABLES=0: the table of the call in progress
-    DevBuf<unsigned long long> ord_state;     // q-ordered seed search: ticket, total and look-back words of both strands
+    DevBuf<unsigned long long> ord_state;     // q-ordered seed search: totals, the tiles' stretches of the scratch, their counts and the scan of those, both strands
     DevBuf<unsigned long long> bsum;
     // seed search / ungapped
     DevBuf<uint8_t> rc;
@@ -1441,29 +1441,20 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             for (auto &row : w.sev) for (hipEvent_t &e : row) if (!e) MB_HIP(hipEventCreate(&e));
             qbsum.ensure(4); w.pin_u64.ensure(16); w.pin_ctr.ensure(2); d_ctr.ensure(2);
             const int64_t ord_words = seed_ord_state_words(qtot);
-            if (ordered) { w.ord_state.ensure(2 * (size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16(2 * (size_t)ord_words * 8), s)); }
+            if (ordered) { w.ord_state.ensure(2 * (size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16(2 * (size_t)ord_words * 8), s)); keys_b.ensure((size_t)capH); }
             else MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
             for (int strand = 0; strand < 2; strand++) {
                 MB_HIP(hipEventRecord(w.sev[strand][0], s));
                 if (ordered)
                     launch_seed_search_ord(qc_d[strand], packed ? qs.packed[strand].p2.p : nullptr, packed ? qs.packed[strand].pm.p : nullptr, qtot, tab.offsets.p, tab.occ.p,
-                                           tab.positions.p, p.transitions, hmul, hmask, keys_a.p + (size_t)strand * capH, capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, s);
+                                           tab.positions.p, p.transitions, hmul, hmask, keys_a.p + (size_t)strand * capH, keys_b.p, capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, s);
                 else
                     launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p + (size_t)strand * capH, capH, qbsum.p + strand, s);
                 MB_HIP(hipEventRecord(w.sev[strand][1], s));
             }
             if (ordered) {
                 for (int strand = 0; strand < 2; strand++)
-                    MB_HIP(hipMemcpyAsync(w.pin_u64.p + strand, w.ord_state.p + (size_t)strand * (size_t)ord_words + 1, 8, hipMemcpyDeviceToHost, s));
-#ifdef MB_ORD_PROF
-                {
-                    const int per_tile = p.transitions ? 512 : 4096;
-                    const int64_t nt = (qtot + per_tile - 1) / per_tile;
-                    unsigned long long pc[5];
-                    MB_HIP(hipMemcpy(pc, w.ord_state.p + 2 + nt, sizeof pc, hipMemcpyDeviceToHost));
-                    if (pc[4]) fprintf(stderr, "[miblast] k_seed_search_ord, block 0 of strand +: %llu tiles; clocks per tile: lookups %llu, scan %llu, look-back %llu, keys %llu\n", pc[4], pc[0] / pc[4], pc[1] / pc[4], pc[2] / pc[4], pc[3] / pc[4]);
-                }
-#endif
+                    MB_HIP(hipMemcpyAsync(w.pin_u64.p + strand, w.ord_state.p + (size_t)strand * (size_t)ord_words, 8, hipMemcpyDeviceToHost, s));
             } else
             MB_HIP(hipMemcpyAsync(w.pin_u64.p, qbsum.p, 16, hipMemcpyDeviceToHost, s));
             tp[2] = now_s();
@@ -1590,16 +1581,16 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         if (one_pass && cap1 > 0 && w.last_strand_hits <= cap1) {
             qbsum.ensure(2);
             const int64_t ord_words = seed_ord_state_words(qtot);
-            if (ordered) { w.ord_state.ensure((size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16((size_t)ord_words * 8), s)); }
+            if (ordered) { w.ord_state.ensure((size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16((size_t)ord_words * 8), s)); keys_b.ensure((size_t)cap1); }
             else MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
             MB_HIP(hipEventRecord(ctx.ev0, s));
             if (ordered)
                 launch_seed_search_ord(qc_d[strand], packed ? qs.packed[strand].p2.p : nullptr, packed ? qs.packed[strand].pm.p : nullptr, qtot, tab.offsets.p, tab.occ.p,
-                                       tab.positions.p, p.transitions, hmul, hmask, keys_a.p, cap1, w.ord_state.p, s);
+                                       tab.positions.p, p.transitions, hmul, hmask, keys_a.p, keys_b.p, cap1, w.ord_state.p, s);
             else
                 launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
             unsigned long long total = 0;
-            w.stage.d2h(&total, ordered ? w.ord_state.p + 1 : qbsum.p, 8, s);
+            w.stage.d2h(&total, ordered ? w.ord_state.p : qbsum.p, 8, s);
             MB_HIP(hipStreamSynchronize(s));
             w.stage.done();
             if (total <= cap1) {
@@ -3368,7 +3359,18 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         j.defer_host = n > 1;
         jobs.push_back(&j);
     }
-    const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, env_long("MIBLAST_SEED_LANES", 12))) : 1;
+    // Several LARGE pairs in one call (chunk pairs of a genome pair: each one's seed stage fills the GPU, a pair with homology fills it
+    // with its DP pieces too): a pair's whole job -- seed stage, gapped stage -- runs on ONE lane, a few lanes side by side, so that one
+    // pair's latency-bound stretches (hand-over checks, tail launches, traceback, the host halves) lie under the other pairs' kernels
+    // instead of under nothing: the gapped stage no longer waits for the seed stage of the LAST pair.  MIBLAST_PAIR_PIPELINE=0: seed
+    // stages of all pairs first (twelve lanes), then the gapped stages of two groups of pairs (round 3's order).
+    // (large: 2 Mb x 2 Mb and more on average -- the sixteen 1 Mb pairs of a batched call fill the GPU only together, in shared DP launches)
+    double cells_avg = 0;
+    for (size_t k = 0; k < n; k++) cells_avg += (double)Ts[k]->total * (double)Qs[k]->total / (double)n;
+    const long pipe_env = env_long("MIBLAST_PAIR_PIPELINE", 1);           // 0 never, 1 large pairs, 2 always (tests)
+    const bool pipeline = n > 1 && !pin.walls && !pin.diag_hash16 && (pipe_env == 2 || (pipe_env == 1 && cells_avg >= 4e12));
+    const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, pipeline ? env_long("MIBLAST_PIPELINE_LANES", 6) : env_long("MIBLAST_SEED_LANES", 12))) : 1;
+    bool pipelined = false;                                              // set when the lanes below have run the gapped stages as well
     // MIBLAST_SEED_BATCHED: 1 (default) the seed stages of a call of several pairs share their launches (seed_phase_batched), and so does
     // a single pair that will fit one key buffer with room to spare (half the launches of the pair-by-pair path; chance hits expected
     // from the sizes: 2 strands x word variants x |T| x |Q| / 4^12 -- an 8 Mb pair would count its 10^8 hits only to be sent back);
@@ -3402,17 +3404,31 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
         std::vector<std::string> lane_err(n_lanes);
         std::vector<std::future<void>> lane_threads;
+        // (pipelined: a lane takes the next pair when it is done with one -- which pairs carry the long gapped stages is not known
+        //  beforehand, and three of them dealt to one lane is the whole step's time; else the pairs are dealt round robin)
+        std::atomic<size_t> next_pair{0};
         for (size_t lane = 0; lane < n_lanes; lane++)
             lane_threads.push_back(std::async(std::launch::async, [&, lane] {
                 try {
                     MB_HIP(hipSetDevice(ctx.device));
                     Ctx &lc = *w.lanes[lane];
-                    for (size_t k = lane; k < n; k += n_lanes) {
+                    for (size_t k = pipeline ? next_pair.fetch_add(1) : lane; k < n; k = pipeline ? next_pair.fetch_add(1) : k + n_lanes) {
                         PairJob &j = *jobs[k];
                         int rc = seed_phase(lc, p, j);
                         if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
                         seed_host(p, j, 0); seed_host(p, j, 1); seed_finish(j);
                         build_units(p, j, (int)k, j.units);
+                        if (!pipeline) continue;
+                        if (j.anchor_mismatch) { lane_rc[lane] = MIBLAST_EHIP; lane_err[lane] = "MIBLAST_CHECK_ANCHORS: k_hsp_anchor disagrees with the host scan"; return; }
+                        // the pair's gapped stage, right away, on this lane's stream and workspace (DpProb.pad0 = the pair's index in the call)
+                        std::vector<PairPtrs> pp(n);
+                        memset(pp.data(), 0, n * sizeof(PairPtrs));
+                        pp[k].tc = j.T->dev(); pp[k].qf = j.qc_d[0]; pp[k].qr = j.qc_d[1];
+                        lc.ws->pair_ptrs.ensure(n);
+                        lc.ws->stage.h2d(lc.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), lc.stream);
+                        const std::vector<size_t> mem{k};
+                        rc = gapped_phase(lc, p, jobs, j.units, &mem);
+                        if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
                     }
                 } catch (const HipFailure &e) {
                     lane_rc[lane] = MIBLAST_EHIP;
@@ -3425,6 +3441,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         for (auto &f : lane_threads) f.get();
         for (size_t lane = 0; lane < n_lanes; lane++)
             if (lane_rc[lane] != MIBLAST_OK) { set_error(lane_err[lane]); return lane_rc[lane]; }
+        pipelined = pipeline;
     } else {
     // Seed stages run back to back on the device; in a batched call the host half of every pair (discovery order, entropy
     // filter, anchors) runs on worker threads meanwhile.
@@ -3470,6 +3487,26 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     size_t total_anchors = 0;
     for (const Unit &u : units) total_anchors += u.anchors.size();
     int rc = MIBLAST_OK;
+    if (pipelined) {
+        // the lanes have run every pair's gapped stage already; launch-level figures of the call = all pairs together (wall time: the call's)
+        miblast_stats sum;
+        memset(&sum, 0, sizeof sum);
+        for (PairJob *j : jobs) {
+            const miblast_stats &a = j->res->stats;
+            sum.gapped_rounds = std::max(sum.gapped_rounds, a.gapped_rounds);
+            sum.dp_sides_run += a.dp_sides_run; sum.dp_cells_run += a.dp_cells_run; sum.dp_rows_run += a.dp_rows_run;
+            sum.t_dp_kernel_ms += a.t_dp_kernel_ms; sum.dp_kernel_launches += a.dp_kernel_launches;
+            sum.relay_accepted += a.relay_accepted; sum.relay_rejected += a.relay_rejected; sum.dp_reruns += a.dp_reruns;
+            sum.t_traceback_ms += a.t_traceback_ms; sum.t_merge_ms += a.t_merge_ms; sum.t_gapped += a.t_gapped;
+        }
+        for (PairJob *j : jobs) {
+            miblast_stats &d = j->res->stats;
+            d.t_gapped = sum.t_gapped; d.gapped_rounds = sum.gapped_rounds; d.dp_sides_run = sum.dp_sides_run; d.dp_cells_run = sum.dp_cells_run;
+            d.dp_rows_run = sum.dp_rows_run; d.t_dp_kernel_ms = sum.t_dp_kernel_ms; d.dp_kernel_launches = sum.dp_kernel_launches;
+            d.relay_accepted = sum.relay_accepted; d.relay_rejected = sum.relay_rejected; d.dp_reruns = sum.dp_reruns;
+            d.t_traceback_ms = sum.t_traceback_ms; d.t_merge_ms = sum.t_merge_ms;
+        }
+    } else
     if (gapped_lanes > 1 && !p.walls && n >= 4 && total_anchors >= (size_t)env_long("MIBLAST_GAPPED_LANES_MIN_ANCHORS", 4096)) {
         // pairs dealt to the groups heaviest first (anchors as the weight)
         const size_t L = std::min(gapped_lanes, n / 2);

@@ -5,9 +5,9 @@
 //   k_pack2bit_mask     a strand as 2 bits per base + 1 mask bit per base (0.375 B/base): what the index build and the seed
 //                       search read instead of 19 code bytes per window
 //   k_index_words_packed  the target's seed words from the packed form (replaces k_index_words on this path)
-//   k_seed_search_ord   seed search of a strand in ONE pass with the keys in q order: tiles of 1024 query positions are taken in order
-//                       (one ticket per tile), a tile's share of the key buffer comes from a decoupled look-back over the tiles before
-//                       it, and its keys are put together in LDS and leave in whole cache lines
+//   k_seed_hits / k_seed_keys   seed search of a strand with ONE look-up pass and the keys in q order: a tile of query positions lists its
+//                       hits into a stretch of scratch reserved with one atomic add; after a scan of the tiles' counts a block per
+//                       tile turns the list into keys at the tile's place in q order, whole cache lines at a time
 //   k_keys_unhash       the keys' diagonals back from their scrambled form after the sort
 //
 // Why the keys are q ordered: the ungapped kernels want the hits of a diagonal together and in q order.  Keys that come out in q order
@@ -83,48 +83,31 @@ __global__ __launch_bounds__(256) void k_index_words_packed(const unsigned long 
     words[s] = w;
 }
 
-// ---- q-ordered one-pass seed search ---------------------------------------------------------------------------------------------
-constexpr int kOrdThreadsMin = 512;           // threads per block: 1024 with one word variant, 512 with thirteen (74 VGPRs: three blocks of 8 waves per CU instead of one of 16);
-                                              // a tile = threads x R query positions (R consecutive ones per thread)
-constexpr int kOrdStage = 6144;               // keys a tile puts together in LDS (48 KiB); a tile with more writes them one by one
-constexpr unsigned long long kOrdFlagA = 1ull << 62, kOrdFlagP = 2ull << 62, kOrdValue = (1ull << 62) - 1ull;
+// ---- q-ordered seed search without a second look-up pass ---------------------------------------------------------------------------
+// k_seed_hits: a tile of query positions (1024 threads x 4 positions with one word variant, 512 x 1 with thirteen) looks its words up and
+//   lists its hits -- (offset of the position in the tile) << 32 | slot in the table's position array -- in thread order into a stretch
+//   of a scratch buffer that it reserves with ONE atomic add: the stretches lie in the order the tiles got there;
+// a scan of the tiles' hit counts gives every tile its place in q order;
+// k_seed_keys: a block per tile fetches the target positions of the tile's hits side by side and writes the keys to that place,
+//   whole cache lines at a time.
+// Nothing waits for anything inside a kernel.  (The first version of this round kept q order with a decoupled look-back over the
+// tiles: half of a tile's time was the wait for the tiles before it, and with a dozen such kernels of other chunk pairs on the GPU a
+// step now and then took seconds -- hundreds of spinning blocks polling the same words.  The scratch costs 8 B written and 8 B read per
+// hit; the sort's output buffer serves.)
+constexpr int kOrdThreadsMin = 512;           // threads per block: 1024 with one word variant, 512 with thirteen (72 VGPRs: three blocks of 8 waves per CU)
 
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// state: [0] ticket, [1] total hits of the strand (written by the last tile), [2 + t] look-back word of tile t -- all zero before the launch.
-// NV word variants per position (1 with --notransition, else 13); R positions per thread (4 with one variant: a quarter of the tiles --
-// tickets, block scans, look-backs -- for the 3 x 10^7 positions of a chunk's strand).
-#ifdef MB_ORD_PROF            // (lab build: shader clocks of a tile's phases, summed over the tiles of block 0 into the words behind the look-back words)
-#define MB_ORD_T(k) const long long ordt##k = (tid == 0) ? (long long)__builtin_readcyclecounter() : 0
-#define MB_ORD_FLUSH() do { if (tid == 0 && blockIdx.x == 0) { unsigned long long *pp = state + 2 + n_tiles; atomicAdd(pp + 0, (unsigned long long)(ordt1 - ordt0)); atomicAdd(pp + 1, (unsigned long long)(ordt2 - ordt1)); \
-    atomicAdd(pp + 2, (unsigned long long)(ordt3 - ordt2)); atomicAdd(pp + 3, (unsigned long long)(ordt4 - ordt3)); atomicAdd(pp + 4, 1ull); } } while (0)
-#else
-#define MB_ORD_T(k) do { } while (0)
-#define MB_ORD_FLUSH() do { } while (0)
-#endif
 template <bool PACKED, int R, int NV, int kOrdThreads>
-__global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_search_ord(const uint8_t *__restrict__ qcodes, const unsigned long long *__restrict__ p2,
-                                                                  const unsigned long long *__restrict__ pm, const int64_t qn, const int64_t qtot,
-                                                                  const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ occ,
-                                                                  const uint32_t *__restrict__ positions, const uint32_t hmul, const uint32_t hmask,
-                                                                  unsigned long long *__restrict__ keys, const unsigned long long cap,
-                                                                  unsigned long long *__restrict__ state, const int n_tiles) {
+__global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_hits(const uint8_t *__restrict__ qcodes, const unsigned long long *__restrict__ p2,
+                                                                             const unsigned long long *__restrict__ pm, const int64_t qn,
+                                                                             const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ occ,
+                                                                             unsigned long long *__restrict__ scratch, const unsigned long long cap,
+                                                                             unsigned long long *__restrict__ total, unsigned long long *__restrict__ tile_base,
+                                                                             uint32_t *__restrict__ tile_cnt, const int n_tiles) {
     constexpr int kTile = kOrdThreads * R;
-    __shared__ unsigned long long stage[kOrdStage];
     __shared__ unsigned wave_sum[kOrdThreads / 64];
-    __shared__ unsigned long long s_excl;
-    __shared__ int s_tile;
+    __shared__ unsigned long long s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    while (true) {
-        if (tid == 0) s_tile = (int)atomicAdd(&state[0], 1ull);          // tiles start in order: the tiles a look-back waits for are running or done
-        __syncthreads();
-        const int tile = s_tile;
-        if (tile >= n_tiles) return;
-        MB_ORD_T(0);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t q0 = (int64_t)tile * kTile + (int64_t)tid * R;
         uint32_t b0[R * NV], b1[R * NV];
         unsigned cnt = 0;
@@ -144,92 +127,50 @@ __global__ __launch_bounds__(kOrdThreads, NV == 1 ? 8 : 6) void k_seed_search_or
                 }
             }
         }
-        MB_ORD_T(1);
         const unsigned incl = (unsigned)dpp_scan_add((int)cnt);
         if (lane == 63) wave_sum[wv] = incl;
         __syncthreads();
-        MB_ORD_T(2);
         unsigned before = 0, all = 0;
 #pragma unroll
         for (int k = 0; k < kOrdThreads / 64; k++) { const unsigned ws = wave_sum[k]; all += ws; before += k < wv ? ws : 0u; }
-        if (wv == 0) {
-            // decoupled look-back by one wave: the tile's own count is published first; then 64 tiles at a time, nearest first, the counts of
-            // the tiles before it are added up until one of them has its inclusive prefix out.  The words carry their values themselves:
-            // relaxed device-scope accesses do.
-            unsigned long long excl = 0;
-            if (lane == 0 && tile > 0) __hip_atomic_store(&state[2 + tile], kOrdFlagA | (unsigned long long)all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int base = tile - 1;
-            while (base >= 0) {
-                const int j = base - lane;
-                unsigned long long v = kOrdFlagP;                       // (before tile 0: an inclusive prefix of 0)
-                if (j >= 0) v = __hip_atomic_load(&state[2 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned f = (unsigned)(v >> 62);
-                const unsigned long long mp = wballot(f == 2u), mz = wballot(f == 0u);
-                const int pl = mp ? (int)__ffsll((long long)mp) - 1 : 63;    // the nearest tile with its prefix out (none: all 64 counts are needed)
-                const unsigned long long need = (2ull << pl) - 1ull;       // lanes 0 .. pl
-                if (mz & need) { __builtin_amdgcn_s_sleep(2); continue; }   // a tile in between has not published yet
-                excl += wave_sum_u64(lane <= pl ? (v & kOrdValue) : 0ull);
-                if (mp) break;
-                base -= 64;
-            }
-            if (lane == 0) {
-                __hip_atomic_store(&state[2 + tile], kOrdFlagP | (excl + (unsigned long long)all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tile == n_tiles - 1) state[1] = excl + (unsigned long long)all;
-                s_excl = excl;
-            }
+        if (tid == 0) {
+            const unsigned long long base = all ? atomicAdd(total, (unsigned long long)all) : 0ull;
+            tile_base[tile] = base; tile_cnt[tile] = all;
+            s_base = base;
         }
         __syncthreads();
-        MB_ORD_T(3);
-        const unsigned long long excl = s_excl;
-        if (excl + all <= cap && all) {                                 // (does not fit: the host makes room and searches again; the totals still come out)
-            unsigned o = before + (incl - cnt);
-            const bool staged = all <= (unsigned)kOrdStage;
-            unsigned long long *const out = keys + excl;
-            if (staged && NV > 1) {
-                // a position's hits are listed in LDS first -- (slot in the table's position array, position's offset in the tile): no memory
-                // access in the lanes' serial loops -- and the tile's threads then fetch the target positions of ALL hits side by side and
-                // write the keys in order, whole cache lines at a time
+        const unsigned long long base = s_base;
+        if (all && base + all <= cap) {                                 // (does not fit: the host makes room and searches again; the counts still come out)
+            unsigned long long *out = scratch + base + before + (incl - cnt);
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const unsigned long long qrel = (unsigned long long)(unsigned)(tid * R + r) << 32;
+            for (int r = 0; r < R; r++) {
+                const unsigned long long qrel = (unsigned long long)(unsigned)(tid * R + r) << 32;
 #pragma unroll
-                    for (int v = 0; v < NV; v++)
-                        for (uint32_t k = b0[r * NV + v]; k < b1[r * NV + v]; k++) stage[o++] = qrel | k;
-                }
-                __syncthreads();
-                const int64_t qbase = (int64_t)tile * kTile;
-                for (unsigned i = tid; i < all; i += kOrdThreads) {
-                    const unsigned long long e = stage[i];
-                    const int64_t q = qbase + (int64_t)(e >> 32);
-                    const uint32_t dq = (uint32_t)((int64_t)positions[(uint32_t)e] - q + qtot);
-                    out[i] = ((unsigned long long)((dq * hmul) & hmask) << 32) | (unsigned long long)(q + kSeedSpan);
-                }
-            } else {
-                // (one word variant: a position has a hit or two, the lanes' loops are short -- the keys are made where the bounds are and only
-                //  pass through LDS to leave in whole cache lines)
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int64_t q = q0 + r;
-                    const unsigned long long q_end = (unsigned long long)(q + kSeedSpan);
-#pragma unroll
-                    for (int v = 0; v < NV; v++)
-                        for (uint32_t k = b0[r * NV + v]; k < b1[r * NV + v]; k++) {
-                            // diagonal d = t_end - q_end = p - q, biased by qtot so that it is not negative, then scrambled (see the head of the file)
-                            const uint32_t dq = (uint32_t)((int64_t)positions[k] - q + qtot);
-                            const unsigned long long key = ((unsigned long long)((dq * hmul) & hmask) << 32) | q_end;
-                            if (staged) stage[o] = key; else out[o] = key;
-                            o++;
-                        }
-                }
-                if (staged) {
-                    __syncthreads();
-                    for (unsigned i = tid; i < all; i += kOrdThreads) out[i] = stage[i];
-                }
+                for (int v = 0; v < NV; v++)
+                    for (uint32_t k = b0[r * NV + v]; k < b1[r * NV + v]; k++) *out++ = qrel | k;
             }
         }
-        __syncthreads();                                                // (stage, s_tile and s_excl are reused by the next tile)
-        MB_ORD_T(4);
-        MB_ORD_FLUSH();
+        __syncthreads();                                                // (wave_sum and s_base are reused by the block's next tile)
+    }
+}
+
+// keys of tile t = its listed hits, in order, at tile_off[t] of the key buffer (tile_off: exclusive scan of tile_cnt)
+__global__ __launch_bounds__(256) void k_seed_keys(const unsigned long long *__restrict__ scratch, const unsigned long long *__restrict__ tile_base,
+                                                   const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off,
+                                                   const uint32_t *__restrict__ positions, unsigned long long *__restrict__ keys, const unsigned long long cap,
+                                                   const int64_t qtot, const int tile_positions, const uint32_t hmul, const uint32_t hmask, const int n_tiles) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned n = tile_cnt[tile];
+        const unsigned long long base = tile_base[tile], off = tile_off[tile];
+        if (!n || base + n > cap || off + n > cap) continue;
+        const int64_t qbase = (int64_t)tile * tile_positions;
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long e = scratch[base + i];
+            const int64_t q = qbase + (int64_t)(e >> 32);
+            // diagonal d = t_end - q_end = p - q, biased by qtot so that it is not negative, then scrambled (see the head of the file)
+            const uint32_t dq = (uint32_t)((int64_t)positions[(uint32_t)e] - q + qtot);
+            keys[off + i] = ((unsigned long long)((dq * hmul) & hmask) << 32) | (unsigned long long)(q + kSeedSpan);
+        }
     }
 }
 
