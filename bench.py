@@ -729,7 +729,11 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     SURVEY 8d's read bytes against the HBM roof of the GPUs in use.  Returns the leg on rank 0, None elsewhere."""
     import hashlib
     from cactus_amd.multigpu import gather_bytes
-    w = ChunkWorkload(a, ctx, rank, world, which)
+    # (a context of its own: its streams and its lanes' are made together, now -- the runtime deals streams to hardware queues in the order
+    #  they are made, and lanes added to a context that has been in use since the start of the process can end up sharing queues)
+    from cactus_amd import miblast as _mb
+    own = _mb.Context(ctx.device)
+    w = ChunkWorkload(a, own, rank, world, which)
     steps, warm = 3, 1
     box = {}
 
@@ -739,7 +743,7 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     if world > 1:
         elapsed, tot = reduce_totals(tot, elapsed, dist, coll_dev)
     if rank != 0:
-        w.close()
+        w.close(); own.close()
         return None
     paf = w.assemble(box["last"])
     by_index = w.by_index
@@ -763,7 +767,7 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
            "roofline_dp": {k: r[k] for k in ("achieved", "frac", "launch_ms", "cells_per_launch")}}
     if a.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = w.cpu_sample(by_index)
-    w.close()
+    w.close(); own.close()
     return out
 
 

@@ -48,9 +48,11 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void alloc(size_t count) {
+        const double t0 = now_s();
         release();
         n = count;
         if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow device allocation: %.1f MB in %.1f ms\n", count * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
     }
     void ensure(size_t count) { if (count > n) alloc(count + count / 4); }
     void ensure_keep(size_t count) {              // grow without losing the contents
@@ -74,9 +76,11 @@ struct PinBuf {
     ~PinBuf() { release(); }
     void ensure(size_t count) {
         if (count <= n) return;
+        const double t0 = now_s();
         release();
         n = count + count / 4;
         MB_HIP(hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault));
+        if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow pinned allocation: %.1f MB in %.1f ms\n", n * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
 };
@@ -621,6 +625,35 @@ void release_seqset(SeqSet &s) {
 
 
 // --------------------------------------------------------------------------------------------------
+// Trace arenas are borrowed for the length of a gapped stage: a process-wide pool per device hands out the smallest free one that
+// holds the stage's estimate (else the largest free one, else a new one) and takes it back when the stage is over.  A chunk pair with
+// homology needs 5-15 GiB, one without a few MB; which lane meets which pair changes from call to call (align_pairs deals large pairs
+// from a queue), and an arena owned by the lane made every lane grow its own in turn -- 0.7 s per 16 GiB hipMalloc and a repeated round,
+// spread over the first steps of a job.  With the pool the large arenas exist once per concurrently running heavy pair.
+namespace {
+struct ArenaPool {
+    struct A { int device; uint8_t *p; size_t n; };
+    std::mutex mu;
+    std::vector<A> free_list;
+    bool take(int device, size_t want, uint8_t *&p, size_t &n) {        // false: none free (the caller allocates)
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = free_list.size();
+        for (size_t i = 0; i < free_list.size(); i++) {
+            if (free_list[i].device != device) continue;
+            if (best == free_list.size()) { best = i; continue; }
+            const size_t a = free_list[i].n, b = free_list[best].n;
+            if ((a >= want && (b < want || a < b)) || (a < want && b < want && a > b)) best = i;
+        }
+        if (best == free_list.size()) return false;
+        p = free_list[best].p; n = free_list[best].n;
+        free_list.erase(free_list.begin() + (long)best);
+        return true;
+    }
+    void give(int device, uint8_t *p, size_t n) { if (!p) return; std::lock_guard<std::mutex> lk(mu); free_list.push_back({device, p, n}); }
+};
+ArenaPool &arena_pool() { static ArenaPool *a = new ArenaPool(); return *a; }
+}  // namespace
+
 // seed position table of a target (CSR over the 2^24 seed words + occupancy bitmap of the buckets) and the packed form of a strand
 // (mb_seed_dense.h); both live with the set they are derived from (SetDerived below) or, as scratch, in a context's workspace
 struct SeedTable {
@@ -675,7 +708,7 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<int> dp_order;                     // a crowded DP launch: piece of block b (longest first)
     DevBuf<DpOut> outs;
     DevBuf<int32_t> grows;
-    DevBuf<uint8_t> arena;
+    struct Arena { uint8_t *p = nullptr; size_t n = 0; } arena;      // borrowed from arena_pool() for the length of a gapped stage
     DevBuf<unsigned long long> arena_next;
     DevBuf<unsigned long long> rowdir;
     DevBuf<uint32_t> ops, ops_packed;
@@ -2129,9 +2162,29 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     memset(&st, 0, sizeof st);
     const double t_g0 = now_s();
     auto PS = [&](const Unit &u) -> miblast_stats & { return jobs[(size_t)u.pair]->res->stats; };
+    struct ArenaLoan {                                                   // back to the pool however the stage ends
+        Workspace &g; int device;
+        ~ArenaLoan() { arena_pool().give(device, g.arena.p, g.arena.n); g.arena.p = nullptr; g.arena.n = 0; }
+    } arena_loan{g, ctx.device};
     if (!units.empty()) {
-        size_t want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
-        if (g.arena.n < want) g.arena.alloc(want);
+        // estimate: 0.65 B per evaluated cell (codes + row records), ~200 columns per row, rows ~ the anchors' HSP columns, twice for
+        // speculation and block granularity; MIBLAST_ARENA_MB fixes the size (tests of the grow-and-retry path)
+        size_t want = 256ull << 20;
+        for (size_t jk = 0; jk < n_members; jk++) {
+            const PairJob *j = jobs[members ? (*members)[jk] : jk];
+            for (const miblast_hsp &h : j->res->hsps) want += (size_t)h.len * 260u;
+        }
+        { size_t cls = (size_t)1 << 30; while (cls < want) cls <<= 1; want = cls; }      // (size classes: 1 GiB, 2 GiB, ... -- the pool's arenas are reused, not multiplied)
+        if (getenv("MIBLAST_ARENA_MB")) want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
+        if (!arena_pool().take(ctx.device, want, g.arena.p, g.arena.n) || (g.arena.n < want && !getenv("MIBLAST_ARENA_MB"))) {
+            arena_pool().give(ctx.device, g.arena.p, g.arena.n);        // (too small a one: it stays in the pool for a lighter stage)
+            g.arena.p = nullptr; g.arena.n = 0;
+            size_t free_b = 0, total_b = 0;
+            MB_HIP(hipMemGetInfo(&free_b, &total_b));
+            want = std::min<size_t>(want, free_b > ((size_t)4 << 30) ? free_b - ((size_t)2 << 30) : free_b / 2);
+            MB_HIP(hipMalloc((void **)&g.arena.p, want));
+            g.arena.n = want;
+        }
         g.arena_next.ensure(1);
     }
     struct Pending { size_t unit, anchor; };
@@ -2884,8 +2937,15 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             const size_t room = free_b + g.arena.n > (2ull << 30) ? free_b + g.arena.n - (2ull << 30) : 0;   // leave 2 GiB for the rest
             size_t bigger = std::min(g.arena.n * 4, room);      // few retries: every retry repeats the round
             if (bigger <= g.arena.n) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
-            g.arena.release();                                  // free first: old + new need not coexist
-            g.arena.alloc(bigger);
+            // (the one that was too small goes back to the pool; a free one of the size wanted is taken if there is one)
+            arena_pool().give(ctx.device, g.arena.p, g.arena.n);
+            g.arena.p = nullptr; g.arena.n = 0;
+            if (!arena_pool().take(ctx.device, bigger, g.arena.p, g.arena.n) || g.arena.n < bigger) {
+                arena_pool().give(ctx.device, g.arena.p, g.arena.n);
+                g.arena.p = nullptr; g.arena.n = 0;
+                MB_HIP(hipMalloc((void **)&g.arena.p, bigger));
+                g.arena.n = bigger;
+            }
         }
         lap(3);
         st.relay_accepted += n_verify_ok; st.relay_rejected += n_verify_bad;
