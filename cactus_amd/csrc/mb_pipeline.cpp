@@ -652,6 +652,7 @@ struct ArenaPool {
     void give(int device, uint8_t *p, size_t n) { if (!p) return; std::lock_guard<std::mutex> lk(mu); free_list.push_back({device, p, n}); }
 };
 ArenaPool &arena_pool() { static ArenaPool *a = new ArenaPool(); return *a; }
+std::atomic<unsigned> &arena_scale_q8() { static std::atomic<unsigned> s{256}; return s; }      // estimate x this / 256 (grows when a stage had to grow its arena)
 }  // namespace
 
 // seed position table of a target (CSR over the 2^24 seed words + occupancy bitmap of the buckets) and the packed form of a strand
@@ -2162,6 +2163,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     memset(&st, 0, sizeof st);
     const double t_g0 = now_s();
     auto PS = [&](const Unit &u) -> miblast_stats & { return jobs[(size_t)u.pair]->res->stats; };
+    size_t arena_raw_estimate = 0;
     struct ArenaLoan {                                                   // back to the pool however the stage ends
         Workspace &g; int device;
         ~ArenaLoan() { arena_pool().give(device, g.arena.p, g.arena.n); g.arena.p = nullptr; g.arena.n = 0; }
@@ -2174,9 +2176,13 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             const PairJob *j = jobs[members ? (*members)[jk] : jk];
             for (const miblast_hsp &h : j->res->hsps) want += (size_t)h.len * 260u;
         }
+        arena_raw_estimate = want;
+        // (a stage that had to grow its arena teaches the estimate: the largest ratio of what was needed to what was estimated so far)
+        want = (size_t)((double)want * (double)arena_scale_q8().load() / 256.0);
         { size_t cls = (size_t)1 << 30; while (cls < want) cls <<= 1; want = cls; }      // (size classes: 1 GiB, 2 GiB, ... -- the pool's arenas are reused, not multiplied)
         if (getenv("MIBLAST_ARENA_MB")) want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
-        if (!arena_pool().take(ctx.device, want, g.arena.p, g.arena.n) || (g.arena.n < want && !getenv("MIBLAST_ARENA_MB"))) {
+        // (MIBLAST_ARENA_MB: an arena of exactly that size, whatever the pool holds -- the tests' way into the grow-and-retry path)
+        if (getenv("MIBLAST_ARENA_MB") || !arena_pool().take(ctx.device, want, g.arena.p, g.arena.n) || g.arena.n < want) {
             arena_pool().give(ctx.device, g.arena.p, g.arena.n);        // (too small a one: it stays in the pool for a lighter stage)
             g.arena.p = nullptr; g.arena.n = 0;
             size_t free_b = 0, total_b = 0;
@@ -2945,6 +2951,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 g.arena.p = nullptr; g.arena.n = 0;
                 MB_HIP(hipMalloc((void **)&g.arena.p, bigger));
                 g.arena.n = bigger;
+            }
+            if (arena_raw_estimate) {
+                const unsigned need = (unsigned)std::min<double>(65536.0 * 256.0, std::ceil((double)g.arena.n * 256.0 / (double)arena_raw_estimate));
+                unsigned cur = arena_scale_q8().load();
+                while (need > cur && !arena_scale_q8().compare_exchange_weak(cur, need)) {}
             }
         }
         lap(3);

@@ -14,7 +14,7 @@ constexpr int kLongRunMax = 32;
 
 constexpr int kRunClasses = 4;                // lane-per-run lists by run length: 1, 2-3, 4-7, 8..kLongRun (a wave then holds runs of similar length)
 
-constexpr int kHeadsPerThread = 4;            // keys per thread of k_run_heads: 4096 keys per block share one atomic per list
+constexpr int kHeadsPerThread = 4;            // keys per thread of k_run_heads: 4096 keys per block share one atomic per list (16: 88 -> 132 us per 1.7 x 10^7 keys)
 
 __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
                                                     unsigned *__restrict__ heads, unsigned *__restrict__ n_heads /* [0..3] short classes, [4] long */) {
