@@ -503,6 +503,10 @@ def dp_roofline(tot, profile_name):
         busy["frac"] = busy["achieved"] / HBM_PEAK_GBS
     return {"bound": "hbm", "kernel": "k_ydrop2 (one-sided Y-drop DP, one wave per piece; k_ydrop1 / k_ydrop for wider windows)", "over_busy_time": busy,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # the same with the cells of COMMITTED anchors only (the oracle's dp_cells; speculative and repeated evaluations left out)
+            "committed_only": {"achieved": (tot["dp_cells"] / launches) * TRACE_BYTES_PER_CELL / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
+                               "frac": ((tot["dp_cells"] / launches) * TRACE_BYTES_PER_CELL / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0) / HBM_PEAK_GBS,
+                               "note": "frac above counts every evaluated cell (what the kernel wrote in that time); this one only the oracle-defined dp_cells"},
             "algorithmic_bytes_per_launch": algo, "bytes_per_cell": TRACE_BYTES_PER_CELL, "bytes_per_cell_written": TRACE_BYTES_WRITTEN, "cells_per_launch": cells, "rows_per_launch": rows,
             "with_row_records": {"achieved": achieved_rows, "frac": achieved_rows / HBM_PEAK_GBS, "bytes_per_launch": algo_rows,
                                  "note": "the same plus 18 B per DP row (16-byte row record + sequence bytes); frac above is SURVEY 8d's 0.5 B per evaluated cell alone"},

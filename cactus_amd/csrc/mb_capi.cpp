@@ -49,6 +49,16 @@ bool parse_int(const char *s, long &v) {
 
 extern "C" {
 
+// The HIP runtime deals a process's streams to 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and two streams on one queue
+// run their kernels one after the other: a context's stream, its lanes' and the streams of the other contexts of a job want queues of
+// their own (16 x 1 Mb pairs in one call: 31 ms side by side, 34 ms one after the other).  Set when the library is loaded -- before the
+// runtime starts, which reads it at its first call -- unless the caller has said otherwise: the front ends (bin/lastz, bin/run_kegalign,
+// bin/paffy) and every process that loads libmiblast.so run with what bench.py measures.  (HSA_ENABLE_INTERRUPT=0, the other setting of
+// bench.py, trades a spinning core per waiting thread for ~25 us per wait: left to the caller.)
+namespace {
+struct RuntimeDefaults { RuntimeDefaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); } } g_runtime_defaults;
+}  // namespace
+
 void miblast_params_default(miblast_params *p) {
     p->step = 1; p->transitions = 1; p->xdrop = 910; p->ydrop = 9400; p->hspthresh = 3000; p->gappedthresh = -1;
     p->gap_open = 400; p->gap_extend = 30; p->entropy = 1; p->queryhspbest = 0; p->ambiguous_n = 1; p->gapped = 1;
