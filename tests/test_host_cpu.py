@@ -259,3 +259,29 @@ def test_initLastz_resolves_gpu_cores_and_memory_like_the_reference(monkeypatch)
     monkeypatch.setattr(configWrapper, "count_amd_gpus", lambda: 0)
     with pytest.raises(RuntimeError, match="Unable to automatically determine"):
         configWrapper.initLastz(copy.deepcopy(base), ns(gpu="all", batchSystem="single_machine"))
+
+
+def test_chunk_scale_workloads_are_the_ones_the_oracle_digests_were_made_from():
+    """cactus_amd/workloads.py (chr20 = BASELINE configs[3], hm = the configs[4] stand-in) must generate, on this numpy, the FASTA
+    bytes whose chunk pairs the committed oracle digests describe (tests/golden/<key>_pairs.json, scripts/oracle_chunk_digests.py):
+    bench.py and the GPU suite compare every chunk pair's PAF with them.  Also: the chunker packs records exactly as
+    cactus_amd.paf.chunking.fasta_chunk does."""
+    import hashlib
+    import json
+    from cactus_amd import workloads
+    from cactus_amd.paf import chunking
+    for key, n_pairs in (("hm", 42), ("chr20", 9)):
+        w = workloads.by_name(key)
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", f"{key}_pairs.json")))
+        assert len(w.pairs) == n_pairs == len(gold["pairs"]) and all(p is not None for p in gold["pairs"])
+        assert gold["fasta_md5"] == hashlib.md5(b"".join(w.tfa + w.qfa)).hexdigest(), key
+        assert gold["options"] == w.options
+    # the in-memory chunker against the file-based one (faffy chunk's packing rule)
+    import tempfile
+    recs = [("a", np.frombuffer(b"ACGT" * 700, dtype=np.uint8)), ("b", np.frombuffer(b"TTGCA" * 90, dtype=np.uint8)), ("c", np.frombuffer(b"G" * 1300, dtype=np.uint8))]
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "g.fa")
+        open(src, "wb").write(gen.fasta_bytes(recs))
+        files = chunking.fasta_chunk(src, os.path.join(d, "chunks"), 1000, 100)
+        names_files = [[l[1:].strip() for l in open(f) if l.startswith(">")] for f in files]
+    assert names_files == [[n for n, _ in f] for f in workloads.chunk_records(recs, 1000, 100)]
