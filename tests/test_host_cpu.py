@@ -272,7 +272,7 @@ def test_chunk_scale_workloads_are_the_ones_the_oracle_digests_were_made_from():
     from cactus_amd.paf import chunking
     for key, n_pairs in (("hm", 42), ("chr20", 9)):
         w = workloads.by_name(key)
-        gold = json.load(open(os.path.join(ROOT, "tests", "golden", f"{key}_pairs.json")))
+        gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{key}_pairs.json")))
         assert len(w.pairs) == n_pairs == len(gold["pairs"]) and all(p is not None for p in gold["pairs"])
         assert gold["fasta_md5"] == hashlib.md5(b"".join(w.tfa + w.qfa)).hexdigest(), key
         assert gold["options"] == w.options
