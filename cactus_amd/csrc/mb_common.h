@@ -142,6 +142,10 @@ struct UxScratch {                            // device scratch of one launch_un
     unsigned *n_entries;                      // [0] list entries written (may exceed entry_cap: the overflowing lanes finish their hit themselves)
     uint32_t *long_bits;                      // one bit per diagonal: the diagonal's run belongs to k_ungapped_long
     uint32_t *dirty_bits;                     // one bit per diagonal: some walk of the run reaches the run's next hit (sequential rule needed)
+    // where a diagonal's bit lies in the two planes: bit (dq * plane_mul) & plane_mask.  The dense seed stage sorts its hits by the
+    // SCRAMBLED diagonal (mb_seed_dense.h): with the same multiplier here neighbours in the sorted order are neighbours in the planes
+    // (a wave of k_ux_accept looks up two cache lines instead of 128).  1 / ~0: the diagonal itself.
+    uint32_t plane_mul, plane_mask;
     unsigned *dirty_runs;                     // first hits of the dirty short runs (the entry list's memory, free after k_ux_tail); n_entries[1] counts them
     unsigned dirty_cap;
     const int32_t *extent;                    // extent[] of the launch, read by the first hit of a run when

@@ -655,8 +655,11 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
                                                        int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     const int lane = threadIdx.x & 63;
     const unsigned n_heads = *n_heads_p;
-    const unsigned h = uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));      // one run per wave
-    if (h >= n_heads) return;
+    // a run per wave and turn; the waves of the grid stride over the list (the list is sized for the worst case, n_hits / (kLongRun + 1)
+    // runs: a block per four POSSIBLE runs were 6 x 10^5 blocks on the 4 x 10^7 chance hits of an 8 Mb x 8 Mb strand, nearly all of them
+    // empty -- 140 us of block dispatch)
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned h = uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))); h < n_heads; h += n_waves) {
     unsigned long long n_ext = 0, n_cols = 0;
     int64_t k0 = heads[h];
     const uint32_t dq = (uint32_t)(keys[k0] >> 32);
@@ -716,6 +719,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
         atomicAdd(&ctr[un.id].extended, n_ext);
         atomicAdd(&ctr[un.id].cols, n_cols);
     }
+    }
 }
 
 // ---- eight-lanes-per-run variant of k_ungapped (the default for the short-run classes) -------------------------------
@@ -736,8 +740,6 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     const uint64_t n = (uint64_t)n_hits;
     unsigned *heads_long = heads + (n + n / 2 + n / 4 + n / 8 + 8);
     if (!n_heads_clean) MB_HIP(hipMemsetAsync(n_heads, 0, up16((kRunClasses + 1) * sizeof(unsigned)), s));      // (n_heads: 8 counters)
-    hipLaunchKernelGGL(k_run_heads, dim3((unsigned)((n_hits + 1024 * kHeadsPerThread - 1) / (1024 * kHeadsPerThread))), dim3(1024), 0, s, keys, n_hits, kLongRun, heads,
-                       n_heads);
     const int64_t max_long = n_hits / (kLongRun + 1) + 1;                        // a long run has more than kLongRun hits
     // Short runs.  Three kernels give the same results:
     //   lane  k_ungapped: a run per lane (the default for sparse hit sets: the phase's 0.6 Mb pairs, where a launch is as long as
@@ -754,6 +756,12 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     //  strand on 6 x 10^7 diagonals, 1.7 ms against 4.8 ms with a run per lane)
     int mode = forced ? forced : (ux && n_hits >= (1 << 19) && (ut.n > 1 || n_hits >= n_diagonals / 4 || n_hits >= (1 << 22))) ? 2 : 1;
     if (mode == 2 && (!ux || xdrop >= (1 << 24))) mode = 1;
+    {   // (the pipeline takes the short runs hit by hit: it wants the list of the long runs only)
+        const dim3 hg((unsigned)((n_hits + 1024 * kHeadsPerThread - 1) / (1024 * kHeadsPerThread)));
+        static const bool all_lists = [] { const char *e = getenv("MIBLAST_UX_ALL_LISTS"); return e && atoi(e) != 0; }();      // (A/B switch: the four short lists as well)
+        if (mode == 2 && !all_lists) hipLaunchKernelGGL(k_run_heads_long, hg, dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
+        else hipLaunchKernelGGL(k_run_heads, hg, dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
+    }
     if (mode == 1) {
         const int64_t blocks = (n_hits + 255) / 256 + kRunClasses;               // upper bound: sum over classes of ceil(runs / 256)
         hipLaunchKernelGGL(k_ungapped, dim3((unsigned)blocks), dim3(256), 0, s, keys, n_hits, heads, n_heads, ut,
@@ -770,7 +778,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
         UxScratch sc = *ux;
         sc.extent = extent; sc.extent_live = extent_clean ? 0 : 1;
         ux = &sc;
-        hipLaunchKernelGGL(k_ux_mark_long, dim3((unsigned)((max_long + 255) / 256)), dim3(256), 0, s, keys, heads_long, n_heads + kRunClasses, ux->long_bits);
+        hipLaunchKernelGGL(k_ux_mark_long, dim3((unsigned)((max_long + 255) / 256)), dim3(256), 0, s, keys, heads_long, n_heads + kRunClasses, *ux);
         hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, ut,
                            xdrop, K, *ux, hsps, hsp_cap, ctr);
         const unsigned tail_blocks = (unsigned)std::min<int64_t>(2048, ((int64_t)ux->entry_cap + 2 * (int64_t)ux->n_blk + 31) / 32);
@@ -779,7 +787,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
         hipLaunchKernelGGL(k_ux_resolve, dim3(256), dim3(256), 0, s, keys, n_hits, ut, extent, *ux, hsps, ctr);
         hipLaunchKernelGGL(k_ux_census, dim3(256), dim3(256), 0, s, ut, hsps, hsp_cap, ctr);
     }
-    hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)((max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
+    hipLaunchKernelGGL(k_ungapped_long, dim3((unsigned)std::min<int64_t>(8192, (max_long + 3) / 4)), dim3(256), 0, s, keys, n_hits, heads_long, n_heads + kRunClasses,
                        ut, extent, xdrop, K, hsps, hsp_cap, ctr);
     hipLaunchKernelGGL(k_hsp_anchor, dim3(512), dim3(256), 0, s, ut, hsps, hsp_cap, ctr);
     MB_HIP(hipGetLastError());                                                   // (a launch that was refused -- grid size, LDS -- must not pass as "no HSPs")

@@ -1257,8 +1257,13 @@ static UnitTab one_unit(const uint8_t *tc, const uint8_t *qc, int64_t ttot, int6
 }
 
 // scratch of the level-synchronous ungapped pipeline for nh hits; rec = nh free 8-byte slots (the strand's unsorted keys)
-static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, int64_t n_diagonals) {
+// plane_mul / plane_mask: the scramble the sorted keys' order follows (UxScratch; 1 / ~0 = none) -- the planes then hold plane_mask + 1 bits
+static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, int64_t n_diagonals, uint32_t plane_mul = 1u, uint32_t plane_mask = 0xFFFFFFFFu) {
     UxScratch sc;
+    static const bool plain_planes = env_long("MIBLAST_UX_PLAIN_PLANES", 0) != 0;      // (A/B switch: bit planes indexed by the diagonal itself)
+    if (plain_planes || plane_mul == 1u || plane_mask > 0x3FFFFFFFu || (int64_t)plane_mask + 1 < n_diagonals) { plane_mul = 1u; plane_mask = 0xFFFFFFFFu; }
+    else n_diagonals = (int64_t)plane_mask + 1;
+    sc.plane_mul = plane_mul; sc.plane_mask = plane_mask;
     // unfinished hits: 16 slots per block of 256 hits + a shared list of nh / 16 + 4096 (40-byte entries: 5 bytes per hit); the same
     // memory later holds the list of dirty runs (4-byte entries: room for 1.25 per hit)
     const size_t n_blk = (nh + 255) / 256, blk_slots = n_blk * 16, cap = nh / 16 + 4096;
@@ -1520,8 +1525,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     MB_HIP(hipEventRecord(w.sev[strand][4], s));
                     // (sized for the larger strand before the first strand's kernels are queued: growing a buffer later would free
                     //  memory that queued kernels still use; the strand's unsorted keys are free after its sort and hold the records)
-                    if (strand == 0 || !fits[0] || !nh[0]) (void)ux_scratch(w, nullptr, (size_t)nh_max, ttot + qtot + 2);
-                    const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2);
+                    const uint32_t pmul = ordered ? hmul : 1u;                   // (the sorted keys follow the scrambled diagonals)
+                    if (strand == 0 || !fits[0] || !nh[0]) (void)ux_scratch(w, nullptr, (size_t)nh_max, ttot + qtot + 2, pmul, hmask);
+                    const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2, pmul, hmask);
                     launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, nullptr, p.xdrop, p.hspthresh,
                                     d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, &uxs, true, s);
                     MB_HIP(hipEventRecord(w.sev[strand][5], s));
@@ -1586,7 +1592,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, up16(sizeof(UngappedCounters)), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
-            const UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2);               // (the unsorted keys are free now)
+            const UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2, hashed ? hmul : 1u, hmask);               // (the unsorted keys are free now)
             launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, ext_p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, &uxs, found.empty() && strand_hits[strand] == nh, s);     // (extent[] is all zero in the first batch only)
             MB_HIP(hipEventRecord(ctx.ev4, s));

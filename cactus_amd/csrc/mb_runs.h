@@ -16,8 +16,11 @@ constexpr int kRunClasses = 4;                // lane-per-run lists by run lengt
 
 constexpr int kHeadsPerThread = 4;            // keys per thread of k_run_heads: 4096 keys per block share one atomic per list (16: 88 -> 132 us per 1.7 x 10^7 keys)
 
-__global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
-                                                    unsigned *__restrict__ heads, unsigned *__restrict__ n_heads /* [0..3] short classes, [4] long */) {
+// kLongOnly: the level-synchronous pipeline (mb_ungapped_ux.h) takes the short runs hit by hit and needs the list of the LONG runs only:
+// one look-ahead per head and one ballot per key instead of four and five (37 x 10^6 keys: 290 -> ... us).
+template <bool kLongOnly>
+__device__ __forceinline__ void run_heads_body(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
+                                                unsigned *__restrict__ heads, unsigned *__restrict__ n_heads /* [0..3] short classes, [4] long */) {
     // list c of the short classes starts at heads + off(c): class 0 at 0 (<= n runs), class 1 at n (<= n/2), class 2 at 3n/2 (<= n/4),
     // class 3 at 7n/4 (<= n/8); the long-run list at 15n/8 + 8 (<= n/(kLongRun+1) <= n/5).
     // (A returning atomic on one address costs ~7 ns whoever issues it: with one key per thread the five atomics of a 1024-key
@@ -35,18 +38,18 @@ __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__
             const uint32_t d = (uint32_t)(keys[i] >> 32);
             const bool head = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != d);
             auto same = [&](int k) -> bool { return (i + k < n_hits) && ((uint32_t)(keys[i + k] >> 32) == d); };
-            if (head) cls[j] = same(kLongRun) ? kRunClasses : same(7) ? 3 : same(3) ? 2 : same(1) ? 1 : 0;
+            if (head) cls[j] = kLongOnly ? (same(kLongRun) ? kRunClasses : -1) : same(kLongRun) ? kRunClasses : same(7) ? 3 : same(3) ? 2 : same(1) ? 1 : 0;
         }
         rank[j] = 0;
 #pragma unroll
-        for (int c = 0; c <= kRunClasses; c++) {
+        for (int c = kLongOnly ? kRunClasses : 0; c <= kRunClasses; c++) {
             const unsigned long long m = wballot(cls[j] == c);
             if (lane == 0) cnt[c][16 * j + w] = (unsigned)__popcll(m);
             if (cls[j] == c) rank[j] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         }
     }
     __syncthreads();
-    if (threadIdx.x <= kRunClasses) {
+    if (threadIdx.x <= kRunClasses && (!kLongOnly || threadIdx.x == kRunClasses)) {
         const int c = threadIdx.x;
         unsigned t = 0;
         for (int k = 0; k < 16 * kHeadsPerThread; k++) { const unsigned v = cnt[c][k]; cnt[c][k] = t; t += v; }
@@ -62,6 +65,14 @@ __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__
         const uint64_t off = c == 0 ? 0 : c == 1 ? n : c == 2 ? n + n / 2 : c == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
         heads[off + base[c] + cnt[c][16 * j + w] + rank[j]] = (unsigned)i;
     }
+}
+__global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
+                                                    unsigned *__restrict__ heads, unsigned *__restrict__ n_heads) {
+    run_heads_body<false>(keys, n_hits, kLongRun, heads, n_heads);
+}
+__global__ __launch_bounds__(1024) void k_run_heads_long(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
+                                                         unsigned *__restrict__ heads, unsigned *__restrict__ n_heads) {
+    run_heads_body<true>(keys, n_hits, kLongRun, heads, n_heads);
 }
 
 // ---- anchors of the HSPs: the gapped stage starts an alignment in the middle of an HSP's best-scoring window of 31

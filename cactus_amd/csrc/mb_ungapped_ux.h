@@ -37,7 +37,8 @@ constexpr int kBlock = 256;
 constexpr unsigned kSlots0 = 12, kSlots1 = 4;  // entry slots owned by wave 0 / wave 1 of a block of k_ux_extend (blk_entries, blk_cnt)
 constexpr uint32_t kCand = 0x80000000u;
 
-__device__ __forceinline__ bool on_long_diagonal(const uint32_t *__restrict__ bits, const uint32_t dq) { return (bits[dq >> 5] >> (dq & 31u)) & 1u; }
+__device__ __forceinline__ uint32_t plane_bit(const UxScratch &sc, const uint32_t dq) { return (dq * sc.plane_mul) & sc.plane_mask; }
+__device__ __forceinline__ bool on_long_diagonal(const UxScratch &sc, const uint32_t dq) { const uint32_t b = plane_bit(sc, dq); return (sc.long_bits[b >> 5] >> (b & 31u)) & 1u; }
 
 // Eight columns of one direction, no early exit and six instructions per column: the running score of every column is a
 // v_dot4c prefix of the signed score bytes; "best so far" is a running maximum of KEYS (score << 3 | 7 - column), so that the
@@ -106,7 +107,6 @@ __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, 
                                            const int bl, const int best_r, const int br, const uint32_t cols, const int K,
                                            const unsigned long long *__restrict__ keys, const int64_t n_hits, const UxScratch &sc,
                                            DevHsp *__restrict__ hsps, const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
-    const uint32_t *__restrict__ long_bits = sc.long_bits;
     unsigned long long *__restrict__ rec = sc.rec;
     // Does this walk reach the next hit of the diagonal -- or, in a later q batch, does an earlier batch's extent reach the run's
     // first hit?  Then the run needs the sequential rule (k_ux_resolve).
@@ -116,10 +116,10 @@ __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, 
         dirty = (uint32_t)(nk >> 32) == dq && q_end + br >= (int32_t)(uint32_t)nk;
     }
     if (sc.extent_live && sc.extent && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != dq)) dirty |= sc.extent[dq] >= q_end;
-    if (dirty) atomicOr(&sc.dirty_bits[dq >> 5], 1u << (dq & 31u));
+    if (dirty) { const uint32_t b = plane_bit(sc, dq); atomicOr(&sc.dirty_bits[b >> 5], 1u << (b & 31u)); }
     uint32_t x = cols;
     const int score = best_l + best_r;
-    if (score >= K && !on_long_diagonal(long_bits, dq)) {
+    if (score >= K && !on_long_diagonal(sc, dq)) {
         const unsigned long long slot = atomicAdd(&ctr->hsps, 1ull);
         if ((int64_t)slot < hsp_cap) {
             DevHsp hs;
@@ -137,11 +137,11 @@ __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, 
 }  // namespace ux
 
 __global__ __launch_bounds__(256) void k_ux_mark_long(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ heads_long,
-                                                      const unsigned *__restrict__ n_long, uint32_t *__restrict__ long_bits) {
+                                                      const unsigned *__restrict__ n_long, const UxScratch sc) {
     const unsigned h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= *n_long) return;
-    const uint32_t dq = (uint32_t)(keys[heads_long[h]] >> 32);
-    atomicOr(&long_bits[dq >> 5], 1u << (dq & 31u));
+    const uint32_t b = ux::plane_bit(sc, (uint32_t)(keys[heads_long[h]] >> 32));
+    atomicOr(&sc.long_bits[b >> 5], 1u << (b & 31u));
 }
 
 __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long long *__restrict__ keys, const int64_t n_hits,
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
         }
         if (xl.live | xr.live) {
             // (a diagonal of k_ungapped_long: nobody reads this hit's record)
-            unfinished = !on_long_diagonal(sc.long_bits, dq);
+            unfinished = !on_long_diagonal(sc, dq);
             e.cl = xl.live ? (clean ? kL1 : 0) : -1; e.cr = xr.live ? (clean ? kR1 : 0) : -1;
             e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos; e.cols = cols;
         } else {
@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
         const unsigned long long nk = i + 1 < n_hits ? keys[i + 1] : ~0ull;
         const unsigned long long pk = i > 0 ? keys[i - 1] : ~0ull;
         const uint32_t dq = (uint32_t)(key >> 32);
-        const bool is_long = (sc.long_bits[dq >> 5] >> (dq & 31u)) & 1u, is_dirty = (sc.dirty_bits[dq >> 5] >> (dq & 31u)) & 1u;
+        const uint32_t pb = ux::plane_bit(sc, dq);
+        const bool is_long = (sc.long_bits[pb >> 5] >> (pb & 31u)) & 1u, is_dirty = (sc.dirty_bits[pb >> 5] >> (pb & 31u)) & 1u;
         if (!is_long && !is_dirty) {
             if (ut.n > 1) {
                 const int u = unit_index(ut, dq);

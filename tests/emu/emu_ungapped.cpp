@@ -212,6 +212,18 @@ int main(int argc, char **argv) {
         }
         const int64_t n_hits = (int64_t)keys.size();
         const int64_t ndiag = (int64_t)dnext;
+        // every other one-unit case of the pipeline: the hits come sorted by the SCRAMBLED diagonal, as the dense seed stage leaves them
+        // (mb_seed_dense.h), and the bit planes follow the same scramble (UxScratch.plane_mul / plane_mask)
+        uint32_t plane_mul = 1u, plane_mask = 0xFFFFFFFFu;
+        if (use_ux && n_units == 1 && (cs & 2)) {
+            int bits = 1; while ((1ll << bits) < ndiag) bits++;
+            plane_mul = 0x9E3779B1u; plane_mask = (uint32_t)((1ull << bits) - 1ull);
+            std::stable_sort(keys.begin(), keys.end(), [&](unsigned long long a, unsigned long long b) {
+                return (((uint32_t)(a >> 32) * plane_mul) & plane_mask) < (((uint32_t)(b >> 32) * plane_mul) & plane_mask);
+            });
+            units[0].keys = keys;                                        // (dbase = 0: the unit's keys are the launch's)
+        }
+        const int64_t nplane = plane_mul == 1u ? ndiag : (int64_t)plane_mask + 1;
         std::vector<int32_t> extent0((size_t)ndiag, 0);
         for (Unit &u : units) {
             std::copy(u.ref.extent.begin(), u.ref.extent.end(), extent0.begin() + (long)u.dbase);
@@ -239,9 +251,10 @@ int main(int argc, char **argv) {
         {   // the lists as k_run_heads itself makes them: the same runs in every list (their order inside a list is free)
             std::vector<unsigned> kheads(heads.size(), 0u);
             unsigned kn[5] = {0, 0, 0, 0, 0};
-            hipLaunchKernelGGL(mb::k_run_heads, dim3((unsigned)((n_hits + 4095) / 4096)), dim3(1024), 0, nullptr, keys.data(), n_hits, long_run, kheads.data(), kn);
+            if (use_ux) hipLaunchKernelGGL(mb::k_run_heads_long, dim3((unsigned)((n_hits + 4095) / 4096)), dim3(1024), 0, nullptr, keys.data(), n_hits, long_run, kheads.data(), kn);
+            else hipLaunchKernelGGL(mb::k_run_heads, dim3((unsigned)((n_hits + 4095) / 4096)), dim3(1024), 0, nullptr, keys.data(), n_hits, long_run, kheads.data(), kn);
             bool same = true;
-            for (int c = 0; c < 5 && same; c++) {
+            for (int c = use_ux ? 4 : 0; c < 5 && same; c++) {
                 const uint64_t off = c == 0 ? 0 : c == 1 ? n : c == 2 ? n + n / 2 : c == 3 ? n + n / 2 + n / 4 : n + n / 2 + n / 4 + n / 8 + 8;
                 same = kn[c] == n_heads[c];
                 if (same) {
@@ -268,13 +281,14 @@ int main(int argc, char **argv) {
             const unsigned n_blk = (unsigned)((n_hits + 255) / 256);
             std::vector<mb::UxEntry> blk_entries((size_t)n_blk * 16 + 1);
             std::vector<unsigned> blk_cnt((size_t)n_blk * 2 + 1, 0u);
-            std::vector<uint32_t> bits((size_t)(ndiag + 31) / 32 + 1, 0u), dirty((size_t)(ndiag + 31) / 32 + 1, 0u);
+            std::vector<uint32_t> bits((size_t)(nplane + 31) / 32 + 1, 0u), dirty((size_t)(nplane + 31) / 32 + 1, 0u);
             unsigned n_entries[2] = {0, 0};
             mb::UxScratch sc; sc.rec = rec.data(); sc.blk_entries = blk_entries.data(); sc.blk_cnt = blk_cnt.data(); sc.n_blk = n_blk; sc.entries = entries.data(); sc.entry_cap = cap; sc.n_entries = n_entries; sc.long_bits = bits.data(); sc.dirty_bits = dirty.data();
+            sc.plane_mul = plane_mul; sc.plane_mask = plane_mask;
             std::vector<unsigned> dirty_runs((size_t)n_hits + 1);
             sc.dirty_runs = dirty_runs.data(); sc.dirty_cap = (unsigned)n_hits; sc.extent = extent.data(); sc.extent_live = extent_clean ? 0 : 1;
             const unsigned *heads_long = heads.data() + (n + n / 2 + n / 4 + n / 8 + 8);
-            hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, bits.data());
+            hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, sc);
             hipLaunchKernelGGL(mb::k_ux_extend, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc,
                                hsps.data(), (int64_t)hsps.size(), ctr);
             hipLaunchKernelGGL(mb::k_ux_tail, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc, hsps.data(), (int64_t)hsps.size(), ctr);
