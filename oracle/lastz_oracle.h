@@ -53,7 +53,10 @@ typedef struct olz_params {
     int32_t queryhsplimit; /* --queryhsplimit=keep,nowarn:N (0 = off): first N HSPs found per query contig and strand */
     /* Named switches for the two points of SURVEY A.9 (#4, #8) where a real lastz may differ from the rules fixed in A.10.
      * Both default to 0 (= A.10, what the MI355X path implements and every parity test uses); they exist so that the day a
-     * lastz binary is at hand (tests/test_p1_lastz_binary.py) the oracle can be flipped to the other reading at once.      */
+     * lastz binary is at hand (tests/test_p1_lastz_binary.py) the oracle can be flipped to the other reading at once.
+     * (A third candidate has no switch yet: lastz bounds one traceback's memory -- --allocate:traceback, default 80 MiB -- and
+     * truncates an alignment whose DP outgrows it; this restatement keeps the whole trace.  It can only matter for sides of
+     * ~5e5 rows and more, i.e. at chunk scale and low divergence: DESIGN.md section 3.)                                     */
     int32_t diag_hash16;   /* 1: diagonal suppression state indexed by (t_end - q_end) & 0xFFFF as lastz's diagEnd[] (A.4): hits on
                               colliding diagonals are silently dropped; sequential in hit generation order                   */
     int32_t walls;         /* 1: base pairs on the path of an earlier alignment of the same query sequence and strand are hard
