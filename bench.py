@@ -394,6 +394,17 @@ class ChunkWorkload:
         calls = [(self.tfa[self.pairs[k][0]], self.qfa[self.pairs[k][1]], self.OPTIONS, by_index[k]) for k in pick]
         out = cpu_baseline(calls, None, f"{len(pick)} of the {len(self.pairs)} chunk pairs (the quickest for the oracle: pairs {pick}) of: " + self.describe, node=False)
         out["sample_pairs"] = pick
+        if os.path.exists(path):
+            # The live sample is made of the pairs the oracle is quickest on -- at chunk scale those are the pairs WITHOUT homology, next to no
+            # DP cells: its seeds/s mean something, its Gcell/s do not.  The whole step on one core is on record from the run that wrote
+            # the digests (scripts/oracle_chunk_digests.py, in the build container: not this box's cores, not timed now).
+            g = json.load(open(path))
+            secs = sum(pr["oracle_seconds"] for pr in g["pairs"] if pr)
+            if secs > 0:
+                cells, hits = sum(pr["dp_cells"] for pr in g["pairs"] if pr), sum(pr["seed_hits"] for pr in g["pairs"] if pr)
+                out["recorded_whole_step"] = {"value": cells / secs / 1e9, "unit": "Gcell/s", "seeds_per_s": hits / secs, "cores": 1, "kind": "port",
+                                              "seconds": secs, "sample": f"all {len(g['pairs'])} chunk pairs, one after the other on one core of the build container "
+                                              "when tests/golden/%s_pairs.json was written (recorded, not measured in this run)" % self.w.key}
         return out
 
     def b_read(self, tot, per, elapsed_step_s):
