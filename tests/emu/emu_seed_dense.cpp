@@ -1,0 +1,171 @@
+// TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_seed_dense.h (packed strands, seed words from the packed form, the q-ordered
+// one-pass seed search k_seed_hits / k_seed_keys, the diagonal scramble and k_keys_unhash) on the HOST -- one pthread per work-item
+// (see hip/hip_runtime.h) -- against a plain restatement of SURVEY A.3 / A.4: the table of the target = for every word the indexed
+// positions, the hits of a strand = for every valid query window, every word variant, every position of its bucket, query position
+// by query position.  Nothing of this is shipped or measured.
+//   emu_seed_dense <seed> <n_cases>      exit status 0 iff every case is identical
+#define MB_EMU 1
+#include <hip/hip_runtime.h>
+#undef __launch_bounds__
+#define __launch_bounds__(...)
+
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <random>
+
+#include "mb_common.h"
+#define __builtin_memcpy memcpy
+
+struct ulonglong2 { unsigned long long x, y; };
+
+namespace mb {
+// inclusive prefix sum over the wave (mb_kernels.hip: six DPP steps), through the per-wave exchange slots
+inline int dpp_scan_add(int v) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu::t_threadIdx.x, w = tid >> 6, lane = tid & 63;
+    g->slot[tid] = (unsigned long long)(unsigned)v;
+    pthread_barrier_wait(&g->wave[w]);
+    int s = 0;
+    for (unsigned l = 0; l <= lane; l++) s += (int)(unsigned)g->slot[(tid & ~63u) | l];
+    pthread_barrier_wait(&g->wave[w]);
+    return s;
+}
+#include "mb_seedword.h"
+#include "mb_seed_dense.h"
+}  // namespace mb
+
+int main(int argc, char **argv) {
+    const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
+    const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
+    int bad = 0;
+    const size_t kBuckets = (size_t)1 << 24;
+    std::vector<uint32_t> offsets(kBuckets + 1), occ(kBuckets / 32), counts(kBuckets + 1);
+    for (int cs = 0; cs < n_cases; cs++) {
+        std::mt19937 rng(seed0 * 15485863u + (unsigned)cs);
+        auto rnd = [&](int n) { return (int)(rng() % (unsigned)n); };
+        const int step = 1 + rnd(3), nvar = cs % 2 ? 1 : 13;
+        const bool packed = cs % 4 < 2;                                       // (the byte-code form of the query is the other instantiation)
+        const int64_t tn = 300 + rnd(4000), qn = cs % 5 == 4 ? rnd(40) : 200 + rnd(nvar == 1 ? 14000 : 5000), first = rnd(step);
+        const int low = 5 + rnd(5);                                            // of 10 bases, how many come from a two-letter alphabet (words repeat: full buckets)
+        auto make_seq = [&](int64_t n, std::vector<uint8_t> &buf) {
+            buf.assign((size_t)n + 2 * mb::kDevPad + 160, mb::kSep);
+            uint8_t *c = buf.data() + mb::kDevPad;
+            for (int64_t i = 0; i < n; i++) c[i] = (uint8_t)(rnd(10) < low ? rnd(2) : rnd(4));
+            for (int s = 0; s < 6 && n > 0; s++) c[rnd((int)n)] = 4;
+            for (int s = 0; s < 3 && n > 0; s++) { const int a = rnd((int)n); for (int k = a; k < std::min<int64_t>(n, a + 30); k++) c[k] |= 8; }
+            for (int s = 0, ns = rnd(3); s < ns && n > 2; s++) c[1 + rnd((int)n - 2)] = mb::kSep;
+        };
+        std::vector<uint8_t> tbuf, qbuf;
+        make_seq(tn, tbuf); make_seq(qn, qbuf);
+        uint8_t *tc = tbuf.data() + mb::kDevPad, *qc = qbuf.data() + mb::kDevPad;
+        for (int c = 0, nc = rnd(8); c < nc && qn > 200; c++) {              // stretches of the target inside the query, transitions here and there
+            const int len = 40 + rnd(120), a = rnd((int)std::max<int64_t>(1, tn - len)), b = rnd((int)(qn - len));
+            for (int x = 0; x < len && a + x < tn; x++) { const uint8_t v = tc[a + x]; qc[b + x] = (v < 4 && rnd(25) == 0) ? (uint8_t)(v ^ 2) : v; }
+        }
+        bool ok = true;
+        const char *why = "";
+        // ---- packed strands: the kernel against a plain loop
+        auto pack = [&](const uint8_t *codes, int64_t n, std::vector<unsigned long long> &p2, std::vector<unsigned long long> &pm) {
+            const int64_t nm = (int64_t)mb::packed_wordsm(n);
+            p2.assign((size_t)std::max<int64_t>((int64_t)mb::packed_words2(n), 2 * nm) + 2, 0x1234567812345678ull); pm.assign((size_t)nm + 2, 0x1234567812345678ull);
+            hipLaunchKernelGGL(mb::k_pack2bit_mask, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, nullptr, codes, n, p2.data(), pm.data(), nm);
+            for (int64_t i = 0; i < nm * 64; i++) {
+                const unsigned c = i < n ? codes[i] : 0xFFu;
+                const unsigned two = (unsigned)(p2[(size_t)(i >> 5)] >> (62 - 2 * (i & 31))) & 3u, m = (unsigned)(pm[(size_t)(i >> 6)] >> (63 - (i & 63))) & 1u;
+                if (two != (c & 3u) || m != (unsigned)((c & 0xFCu) != 0u)) return false;
+            }
+            return true;
+        };
+        std::vector<unsigned long long> tp2, tpm, qp2, qpm;
+        if (!pack(tc, tn, tp2, tpm) || !pack(qc, qn, qp2, qpm)) { ok = false; why = "k_pack2bit_mask"; }
+        // ---- the target's table: words from the packed form against window_word, then a plain counting sort
+        const int64_t n_slots = tn > first ? (tn - first + step - 1) / step : 0;
+        std::fill(counts.begin(), counts.end(), 0u);
+        std::vector<uint32_t> words((size_t)n_slots + 1, 0x77777777u);
+        if (n_slots) hipLaunchKernelGGL(mb::k_index_words_packed, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, nullptr, tp2.data(), tpm.data(), tn, step, first, words.data(), n_slots, counts.data());
+        std::map<uint32_t, std::vector<uint32_t>> table;                      // bucket -> positions, ascending
+        for (int64_t sl = 0; sl < n_slots && ok; sl++) {
+            const int64_t p = first + sl * step;
+            uint32_t w, want = 0xFFFFFFFFu;
+            if (p + mb::kSeedSpan <= tn && mb::window_word(tc, p, w)) { want = mb::dense_bucket(w); table[want].push_back((uint32_t)p); }
+            if (words[(size_t)sl] != want) { ok = false; why = "k_index_words_packed"; }
+        }
+        uint32_t run = 0;
+        std::fill(occ.begin(), occ.end(), 0u);
+        std::vector<uint32_t> positions;
+        {
+            auto it = table.begin();
+            // (offsets of all 2^24 buckets; the occupied ones are few: walk the map)
+            std::fill(offsets.begin(), offsets.end(), 0u);
+            for (; it != table.end(); ++it) {
+                if (counts[it->first] != it->second.size()) { ok = false; why = "bucket counts"; }
+                offsets[it->first] = (uint32_t)it->second.size();
+                occ[it->first >> 5] |= 1u << (it->first & 31u);
+            }
+            for (size_t b = 0; b <= kBuckets; b++) { const uint32_t c = b < kBuckets ? offsets[b] : 0u; offsets[b] = run; run += c; }
+            positions.resize((size_t)run + 1);
+            for (auto &kv : table) std::copy(kv.second.begin(), kv.second.end(), positions.begin() + offsets[kv.first]);
+        }
+        // (the 13 buckets of a word: dense_variant of its bucket = dense_bucket of variant_word)
+        for (int k = 0; k < 200 && ok; k++) {
+            const uint32_t w = (uint32_t)rng() & 0xFFFFFFu;
+            for (int v = 0; v < 13; v++) if (mb::dense_variant(mb::dense_bucket(w), v) != mb::dense_bucket(mb::variant_word(w, v))) { ok = false; why = "dense_variant"; }
+        }
+        // ---- the search: k_seed_hits, the scan of the tiles' counts, k_seed_keys, k_keys_unhash
+        int diag_bits = 1; while ((1ll << diag_bits) < tn + qn + 2) diag_bits++;
+        const uint32_t hmask = (1u << diag_bits) - 1u, hmul = cs % 3 == 2 ? 1u : 0x9E3779B1u;
+        uint32_t hinv = 1u; for (int it = 0; it < 5; it++) hinv *= 2u - hmul * hinv;
+        const int threads = nvar == 13 ? 512 : 1024, per_tile = threads * (nvar == 13 ? 1 : 4);
+        const int n_tiles = (int)((qn + per_tile - 1) / per_tile);
+        // the rule, query position by query position
+        std::vector<std::vector<unsigned long long>> want_q((size_t)std::max<int64_t>(qn, 1));
+        unsigned long long total_want = 0;
+        for (int64_t q = 0; q + mb::kSeedSpan <= qn; q++) {
+            uint32_t w;
+            if (!mb::window_word(qc, q, w)) continue;
+            for (int v = 0; v < nvar; v++) {
+                auto it = table.find(mb::dense_bucket(mb::variant_word(w, v)));
+                if (it == table.end()) continue;
+                for (uint32_t p : it->second) want_q[(size_t)q].push_back(((unsigned long long)(uint32_t)((int64_t)p - q + qn) << 32) | (unsigned long long)(q + mb::kSeedSpan));
+            }
+            total_want += want_q[(size_t)q].size();
+        }
+        for (int pass = 0; pass < 2 && ok && n_tiles > 0; pass++) {
+            // pass 0: room for everything; pass 1: too little room -- the total still comes out, nothing is written past the end
+            const unsigned long long cap = pass == 0 ? total_want + 7 : total_want / 2;
+            std::vector<unsigned long long> scratch((size_t)cap + 8, 0xABABABABABABABABull), keys((size_t)cap + 8, 0xCDCDCDCDCDCDCDCDull), tile_base((size_t)n_tiles + 1, 0ull);
+            std::vector<uint32_t> tile_cnt((size_t)n_tiles + 1, 0u), tile_off((size_t)n_tiles + 1, 0u);
+            unsigned long long total = 0;
+            const unsigned grid = 1u + (unsigned)rnd(std::max(1, n_tiles));   // (fewer blocks than tiles: a block takes several)
+#define EMU_ORD(P, R, NV, T) hipLaunchKernelGGL((mb::k_seed_hits<P, R, NV, T>), dim3(grid), dim3(T), 0, nullptr, qc, qp2.data(), qpm.data(), qn, offsets.data(), occ.data(), scratch.data(), cap, &total, tile_base.data(), tile_cnt.data(), n_tiles)
+            if (nvar == 13) { if (packed) EMU_ORD(true, 1, 13, 512); else EMU_ORD(false, 1, 13, 512); }
+            else { if (packed) EMU_ORD(true, 4, 1, 1024); else EMU_ORD(false, 4, 1, 1024); }
+#undef EMU_ORD
+            if (total != total_want) { ok = false; why = "k_seed_hits total"; break; }
+            { uint32_t r2 = 0; for (int t = 0; t < n_tiles; t++) { tile_off[(size_t)t] = r2; r2 += tile_cnt[(size_t)t]; } }      // (launch_scan_u32 on the device)
+            hipLaunchKernelGGL(mb::k_seed_keys, dim3(1u + (unsigned)rnd(std::max(1, n_tiles))), dim3(256), 0, nullptr, scratch.data(), tile_base.data(), tile_cnt.data(), tile_off.data(),
+                               positions.data(), keys.data(), cap, qn, per_tile, hmul, hmask, n_tiles);
+            for (size_t k = (size_t)cap; k < keys.size(); k++) if (keys[k] != 0xCDCDCDCDCDCDCDCDull || scratch[k] != 0xABABABABABABABABull) { ok = false; why = "write past the end"; }
+            if (pass == 1 || !ok) continue;
+            if (hmul != 1u) {
+                // scrambled keys group the diagonals: unscramble and compare
+                hipLaunchKernelGGL(mb::k_keys_unhash, dim3((unsigned)(((total + 1) / 2 + 255) / 256 + 1)), dim3(256), 0, nullptr, keys.data(), (int64_t)total, hinv, hmask);
+            }
+            size_t at = 0;
+            for (int64_t q = 0; q < qn && ok; q++) {
+                std::vector<unsigned long long> &mine = want_q[(size_t)q];
+                if (mine.empty()) continue;
+                std::vector<unsigned long long> got(keys.begin() + (long)at, keys.begin() + (long)(at + mine.size()));
+                std::sort(got.begin(), got.end()); std::sort(mine.begin(), mine.end());
+                if (got != mine) { ok = false; why = "keys of a query position"; }
+                at += mine.size();
+            }
+            if (ok && at != total) { ok = false; why = "key count"; }
+        }
+        printf("case %d: T %lld (step %d, first %lld) x Q %lld, %d variants, %s query, %s diagonals, %llu hits in %d tiles  %s%s\n", cs, (long long)tn, step, (long long)first,
+               (long long)qn, nvar, packed ? "packed" : "byte-code", hmul == 1u ? "plain" : "scrambled", total_want, n_tiles, ok ? "ok" : "MISMATCH: ", ok ? "" : why);
+        if (!ok) bad++;
+    }
+    return bad ? 1 : 0;
+}

@@ -40,6 +40,20 @@ def test_emulated_batched_seed_stage_matches_the_rule():
     assert out.count(" ok\n") == 3 and "MISMATCH" not in out, out
 
 
+def test_emulated_dense_seed_stage_matches_the_rule():
+    """cactus_amd/csrc/mb_seed_dense.h on the host (tests/emu/emu_seed_dense.cpp): a strand packed to 2 + 1 bits per base holds the
+    bases and the mask a plain loop computes; the target's seed words taken from the packed form are window_word's; the q-ordered
+    one-pass search (k_seed_hits: a tile lists its hits into scratch reserved with one atomic add; k_seed_keys: a block per tile writes
+    the keys at the tile's place in q order) gives, query position by query position, exactly the hits of SURVEY A.4 -- thirteen word
+    variants or one, packed or byte-code query, scrambled diagonals (undone by k_keys_unhash) or plain ones --, and a key buffer that
+    is too small gets the total and no write past its end."""
+    subprocess.run(["make", "-C", EMU_DIR, "emu_seed_dense"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_seed_dense"), "7", "10"], capture_output=True, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert out.count(" ok\n") == 10 and "MISMATCH" not in out, out
+
+
 def test_emulated_set_kernels_match_plain_loops():
     """cactus_amd/csrc/mb_sets.h on the host (tests/emu/emu_sets.cpp): the '-' strands of a call's query sets, and outgroup trimming
     between two calls -- interval marks, edges of the uncovered stretches, the gathered device image of the new set with its contig
