@@ -649,7 +649,44 @@ struct ArenaPool {
         free_list.erase(free_list.begin() + (long)best);
         return true;
     }
-    void give(int device, uint8_t *p, size_t n) { if (!p) return; std::lock_guard<std::mutex> lk(mu); free_list.push_back({device, p, n}); }
+    // What lies free in the pool is bounded (MIBLAST_ARENA_POOL_MB, default a third of the device's memory: 96 GB on an MI355X): a stage that outgrew its arena four times
+    // over leaves arenas of 2, 8, 32, 128 GiB behind, and a job of many different pairs one per size class it ever met.  Beyond the bound
+    // the smallest go first (the large ones are the expensive ones to make again).
+    void give(int device, uint8_t *p, size_t n) {
+        if (!p) return;
+        std::vector<A> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_list.push_back({device, p, n});
+            static const size_t cap = [] {                                  // (a third of the device's memory unless the switch says otherwise)
+                if (getenv("MIBLAST_ARENA_POOL_MB")) return (size_t)env_long("MIBLAST_ARENA_POOL_MB", 64l << 10) << 20;
+                size_t free_b = 0, total_b = 0;
+                return hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b / 3 : (size_t)64 << 30;
+            }();
+            size_t held = 0;
+            for (const A &a : free_list) if (a.device == device) held += a.n;
+            while (held > cap) {
+                size_t smallest = free_list.size();
+                for (size_t i = 0; i < free_list.size(); i++)
+                    if (free_list[i].device == device && (smallest == free_list.size() || free_list[i].n < free_list[smallest].n)) smallest = i;
+                if (smallest == free_list.size()) break;
+                held -= free_list[smallest].n;
+                drop.push_back(free_list[smallest]);
+                free_list.erase(free_list.begin() + (long)smallest);
+            }
+        }
+        for (const A &a : drop) (void)hipFree(a.p);
+    }
+    // everything that lies free on the device back to the runtime (a stage that needs most of the device's memory for its arena)
+    void trim(int device) {
+        std::vector<A> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_list.size();)
+                if (free_list[i].device == device) { drop.push_back(free_list[i]); free_list.erase(free_list.begin() + (long)i); } else i++;
+        }
+        for (const A &a : drop) (void)hipFree(a.p);
+    }
 };
 ArenaPool &arena_pool() { static ArenaPool *a = new ArenaPool(); return *a; }
 std::atomic<unsigned> &arena_scale_q8() { static std::atomic<unsigned> s{256}; return s; }      // estimate x this / 256 (grows when a stage had to grow its arena)
@@ -2182,6 +2219,12 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             const PairJob *j = jobs[members ? (*members)[jk] : jk];
             for (const miblast_hsp &h : j->res->hsps) want += (size_t)h.len * 260u;
         }
+        // (260 B per row is a window of ~200 columns, Cactus's --ydrop=3000 .. 9400; a wider window -- (Y - O) / E columns and a
+        //  quarter again -- takes that much more: --ydrop=20000 four times)
+        {
+            const long win = (p.ydrop > p.gap_open ? (p.ydrop - p.gap_open) / std::max(1, p.gap_extend) : 0) * 5 / 4 + 32;
+            if (win > 512) want = (size_t)((double)want * (double)win / 400.0);
+        }
         arena_raw_estimate = want;
         // (a stage that had to grow its arena teaches the estimate: the largest ratio of what was needed to what was estimated so far)
         want = (size_t)((double)want * (double)arena_scale_q8().load() / 256.0);
@@ -2949,13 +2992,28 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             const size_t room = free_b + g.arena.n > (2ull << 30) ? free_b + g.arena.n - (2ull << 30) : 0;   // leave 2 GiB for the rest
             size_t bigger = std::min(g.arena.n * 4, room);      // few retries: every retry repeats the round
             if (bigger <= g.arena.n) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
-            // (the one that was too small goes back to the pool; a free one of the size wanted is taken if there is one)
-            arena_pool().give(ctx.device, g.arena.p, g.arena.n);
+            // (the one that was too small goes back to the pool -- or, when the larger one needs the room, to the runtime; a free one of the
+            //  size wanted is taken if there is one)
+            const size_t old_n = g.arena.n;
+            if (bigger + (2ull << 30) > free_b) { (void)hipFree(g.arena.p); arena_pool().trim(ctx.device); }
+            else arena_pool().give(ctx.device, g.arena.p, g.arena.n);
             g.arena.p = nullptr; g.arena.n = 0;
             if (!arena_pool().take(ctx.device, bigger, g.arena.p, g.arena.n) || g.arena.n < bigger) {
                 arena_pool().give(ctx.device, g.arena.p, g.arena.n);
                 g.arena.p = nullptr; g.arena.n = 0;
-                MB_HIP(hipMalloc((void **)&g.arena.p, bigger));
+                if (hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
+                    (void)hipGetLastError();
+                    g.arena.p = nullptr;
+                    arena_pool().trim(ctx.device);               // (what other stages left free in the meantime)
+                    MB_HIP(hipMemGetInfo(&free_b, &total_b));
+                    bigger = std::min<size_t>(bigger, free_b > ((size_t)2 << 30) ? free_b - ((size_t)2 << 30) : (size_t)0);
+                    if (bigger <= old_n || hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
+                        (void)hipGetLastError();
+                        g.arena.p = nullptr;
+                        set_error("trace arena does not fit in device memory");
+                        return MIBLAST_ELIMIT;
+                    }
+                }
                 g.arena.n = bigger;
             }
             if (arena_raw_estimate) {

@@ -13,7 +13,7 @@ bad = 0
 t_start = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
-    n = int(rng.integers(2000, 60000))
+    n = int(rng.integers(int(os.environ.get('FUZZ_NMIN', '2000')), int(os.environ.get('FUZZ_NMAX', '60000'))))      # (FUZZ_NMIN / FUZZ_NMAX: chunk-scale cases, e.g. 1700000 3000000)
     sub = float(rng.choice([0.0, 0.01, 0.03, 0.08, 0.15, 0.25]))
     indel = float(rng.choice([0.0, 0.001, 0.005, 0.02]))
     kind = int(rng.integers(0, 5))
