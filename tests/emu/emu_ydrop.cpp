@@ -1,0 +1,272 @@
+// TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_ydrop2.h -- the piece evaluator of k_ydrop2, the gapped stage's DP kernel -- on the
+// HOST: one pthread per lane of the wave, DPP moves / scans, readlane, readfirstlane and ballot exchanged through the wave's slots (see
+// hip/hip_runtime.h), against a plain restatement of SURVEY A.10 ONE_SIDED (rows = query, one cell at a time in row-major order, y-drop
+// against the running best, ties diag > D > I, extension wins gap ties): best cell, cells and rows counted, and the alignment read back
+// from the kernel's 4-bit trace codes through its row records.  Also a side cut in two pieces: the second continues from the first
+// one's exit snapshot and must end where the whole side ends.  Nothing of this is shipped or measured.
+//   emu_ydrop <seed> <n_cases>      exit status 0 iff every case is identical
+#define MB_EMU 1
+#include <hip/hip_runtime.h>
+#undef __launch_bounds__
+#define __launch_bounds__(...)
+
+#include <algorithm>
+#include <cstdio>
+#include <random>
+
+#include "mb_common.h"
+
+// ---- the wave primitives of the evaluator, emulated (every lane of the wave calls them at the same point) ---------------------------
+static inline unsigned long long emu_xchg_begin(unsigned long long mine) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu::t_threadIdx.x;
+    g->slot[tid] = mine;
+    pthread_barrier_wait(&g->wave[tid >> 6]);
+    return 0;
+}
+static inline unsigned long long emu_slot(unsigned lane) { return emu::g_group->slot[(emu::t_threadIdx.x & ~63u) | (lane & 63u)]; }
+static inline void emu_xchg_end() { pthread_barrier_wait(&emu::g_group->wave[emu::t_threadIdx.x >> 6]); }
+
+static inline int yd_readlane(int v, int l) { emu_xchg_begin((unsigned)v); const int o = (int)(unsigned)emu_slot((unsigned)l); emu_xchg_end(); return o; }
+static inline unsigned long long yd_ballot(bool p) {
+    emu_xchg_begin(p ? 1ull : 0ull);
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64; l++) m |= emu_slot(l) << l;
+    emu_xchg_end();
+    return m;
+}
+static inline uint32_t yd_perm(uint32_t hi, uint32_t lo, uint32_t sel) {                          // v_perm_b32, selectors 0..7
+    uint32_t out = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned s = (sel >> (8 * i)) & 0xFFu;
+        if (s > 7) abort();
+        out |= (s < 4 ? (lo >> (8 * s)) & 0xFFu : (hi >> (8 * (s - 4))) & 0xFFu) << (8 * i);
+    }
+    return out;
+}
+static inline uint32_t yd_alignbit(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (n & 31u)); }
+static inline long long yd_clock() { return 0; }
+#define YD_PIN1(a) ((void)0)
+#define YD_PIN2(a, b) ((void)0)
+#define YD_PIN5(a, b, c, d, e) ((void)0)
+#define YD_GLOBAL_UNALIGNED __attribute__((aligned(1)))
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+using std::max;
+using std::min;
+
+namespace mb {
+typedef const uint8_t *gbytes;
+inline gbytes as_global(const uint8_t *p) { return p; }
+constexpr int kNeg2 = -(1 << 30);
+constexpr int kRowChunk = 4096;
+struct RowInfo { unsigned long long off; uint32_t ly; uint32_t pad; };
+inline int dpp_shr1(int v, int fill) {                                 // lane l <- lane l-1, lane 0 <- fill
+    const unsigned lane = emu::t_threadIdx.x & 63;
+    emu_xchg_begin((unsigned)v);
+    const int o = lane ? (int)(unsigned)emu_slot(lane - 1) : fill;
+    emu_xchg_end();
+    return o;
+}
+inline int dpp_shl1(int v, int fill) {                                 // lane l <- lane l+1, lane 63 <- fill
+    const unsigned lane = emu::t_threadIdx.x & 63;
+    emu_xchg_begin((unsigned)v);
+    const int o = lane < 63 ? (int)(unsigned)emu_slot(lane + 1) : fill;
+    emu_xchg_end();
+    return o;
+}
+inline int dpp_scan_max(int v) {                                       // inclusive prefix max over the wave
+    const unsigned lane = emu::t_threadIdx.x & 63;
+    emu_xchg_begin((unsigned)v);
+    int m = v;
+    for (unsigned l = 0; l < lane; l++) m = std::max(m, (int)(unsigned)emu_slot(l));
+    emu_xchg_end();
+    return m;
+}
+inline int uni(int v) { return yd_readlane(v, 0); }                    // readfirstlane: every lane is active wherever the evaluator pins a value
+inline unsigned long long uni64(unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)(unsigned)v); }
+// per-row packed score table (mb_kernels.hip): byte k = HOXD70[k][bq] + 128 for k = A, C, G, T; N scores -100
+inline uint32_t row_score_lut(unsigned bq) {
+    static const int hox[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
+    const unsigned b = bq & 7u;
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) v |= (uint32_t)((b < 4 ? hox[k][b] : -100) + 128) << (8 * k);
+    return v;
+}
+#include "mb_ydrop2.h"
+// (the kernel proper: the __global__ wrapper of mb_kernels.hip)
+void k_ydrop2_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, const int O, const int E, const int Y, uint8_t *arena,
+                  const unsigned long long arena_bytes, unsigned long long *arena_next, const unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps,
+                  const int *order) {
+    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
+}
+}  // namespace mb
+
+// ---- the rule, one cell at a time -----------------------------------------------------------------------------------------------
+static int score_of(unsigned a, unsigned b) {
+    static const int hox[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
+    const unsigned x = a & 7u, y = b & 7u;
+    if ((x | y) & 4u) return -100;
+    return hox[x][y];
+}
+struct Side { int best = 0, bi = 0, bj = 0; long long cells = 0, rows = 0; std::vector<uint8_t> ops; };
+
+static Side one_sided(const uint8_t *tc, const uint8_t *qc, int64_t t0, int64_t q0, int dir, int64_t na, int64_t nb, int O, int E, int Y) {
+    const int NEG = -(1 << 29);
+    Side r;
+    std::vector<int> Cp((size_t)na + 4, NEG), Dp((size_t)na + 4, NEG), Cc((size_t)na + 4, NEG), Dc((size_t)na + 4, NEG);
+    std::vector<int64_t> row_off, row_ly;
+    std::vector<uint8_t> tr;
+    int64_t R0 = 0;
+    if (Y >= O) { R0 = (Y - O) / E; if (R0 > na) R0 = na; }
+    int64_t LY = 0, RY = R0 + 1;
+    row_off.push_back(0); row_ly.push_back(0);
+    for (int64_t j = 0; j <= R0; j++) { Cp[(size_t)j] = j == 0 ? 0 : -(O + (int)j * E); Dp[(size_t)j] = NEG; tr.push_back(j == 0 ? 3 : (uint8_t)(2 | (j >= 2 ? 8 : 0))); }
+    r.cells = R0 + 1;
+    int64_t nrows = 1;
+    int best = 0; int64_t bi = 0, bj = 0;
+    for (int64_t i = 1; i <= nb; i++) {
+        const uint8_t bq = qc[dir > 0 ? q0 + i - 1 : q0 - i];
+        row_off.push_back((int64_t)tr.size()); row_ly.push_back(LY);
+        int Iv = NEG, Cleft = NEG;
+        int64_t first_alive = -1, last_alive = -1;
+        for (int64_t j = LY; j <= na; j++) {
+            int diag = NEG, Dv = NEG, Dext = 0, Iext = 0;
+            if (j - 1 >= LY && j - 1 < RY) diag = Cp[(size_t)(j - 1)] + score_of(tc[dir > 0 ? t0 + j - 1 : t0 - j], bq);
+            if (j < RY) { const int ext = Dp[(size_t)j] - E, opn = Cp[(size_t)j] - O - E; if (ext >= opn) { Dv = ext; Dext = 1; } else Dv = opn; }
+            { const int ext = Iv - E, opn = Cleft - O - E; if (ext >= opn) { Iv = ext; Iext = 1; } else Iv = opn; }
+            int Cv; uint8_t src;
+            if (diag >= Dv && diag >= Iv) { Cv = diag; src = 0; } else if (Dv >= Iv) { Cv = Dv; src = 1; } else { Cv = Iv; src = 2; }
+            r.cells++;
+            if (Cv > best) { best = Cv; bi = i; bj = j; }
+            const bool alive = Cv >= best - Y;
+            if (!alive) Cv = NEG;
+            Cc[(size_t)j] = Cv; Dc[(size_t)j] = Dv; Cleft = Cv;
+            tr.push_back((uint8_t)(src | (Dext ? 4 : 0) | (Iext ? 8 : 0)));
+            if (alive) { if (first_alive < 0) first_alive = j; last_alive = j; }
+            else if (j >= RY) break;
+        }
+        nrows++;
+        if (first_alive < 0) break;
+        for (int64_t j = first_alive; j <= last_alive; j++) { Cp[(size_t)j] = Cc[(size_t)j]; Dp[(size_t)j] = Dc[(size_t)j]; }
+        LY = first_alive; RY = last_alive + 1;
+    }
+    r.rows = nrows; r.best = best; r.bi = (int)bi; r.bj = (int)bj;
+    int64_t i = bi, j = bj; int state = 0;
+    while (i > 0 || j > 0) {
+        const uint8_t tb = tr[(size_t)(row_off[(size_t)i] + (j - row_ly[(size_t)i]))];
+        if (state == 0) { const int src = tb & 3; if (src == 0) { r.ops.push_back(0); i--; j--; } else if (src == 1) state = 1; else if (src == 2) state = 2; else break; }
+        else if (state == 1) { r.ops.push_back(2); if (!(tb & 4)) state = 0; i--; }
+        else { r.ops.push_back(3); if (!(tb & 8)) state = 0; j--; }
+    }
+    return r;
+}
+
+// the alignment of a piece chain read back from the kernel's trace: rows of piece p are records 0 .. of its directory entries
+struct PieceRows { uint64_t row_off; int row_lo; };
+static bool walk_trace(const uint8_t *arena, const unsigned long long *rowdir, const std::vector<PieceRows> &chain, int bi, int bj, std::vector<uint8_t> &ops) {
+    auto code = [&](int i, int j, bool &ok) -> unsigned {
+        // the piece that holds row i: the last one whose row_lo < i (row row_lo itself belongs to the piece before; row 0 to the first)
+        size_t p = 0;
+        for (size_t k = 0; k < chain.size(); k++) if (chain[k].row_lo < i || (i == 0 && k == 0)) p = k;
+        const int rho = i - chain[p].row_lo;
+        const unsigned long long chunk = rowdir[chain[p].row_off + (unsigned)(rho / mb::kRowChunk)];
+        const mb::RowInfo ri = ((const mb::RowInfo *)(arena + chunk))[rho & (mb::kRowChunk - 1)];
+        const int rel = j - (int)ri.ly;
+        if (rel < 0) { ok = false; return 0; }
+        const uint8_t b = arena[ri.off + (unsigned)(rel >> 1)];
+        return (rel & 1) ? b >> 4 : b & 15u;
+    };
+    int i = bi, j = bj, state = 0;
+    bool ok = true;
+    while ((i > 0 || j > 0) && ok) {
+        const unsigned tb = code(i, j, ok);
+        if (state == 0) { const unsigned src = tb & 3u; if (src == 0) { ops.push_back(0); i--; j--; } else if (src == 1) state = 1; else if (src == 2) state = 2; else break; }
+        else if (state == 1) { ops.push_back(2); if (!(tb & 4u)) state = 0; i--; }
+        else { ops.push_back(3); if (!(tb & 8u)) state = 0; j--; }
+        if (i < 0 || j < 0) ok = false;
+    }
+    return ok;
+}
+
+int main(int argc, char **argv) {
+    const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
+    const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
+    int bad = 0;
+    const unsigned long long arena_bytes = 96ull << 20;
+    std::vector<uint8_t> arena((size_t)arena_bytes);
+    for (int cs = 0; cs < n_cases; cs++) {
+        std::mt19937 rng(seed0 * 32452843u + (unsigned)cs);
+        auto rnd = [&](int n) { return (int)(rng() % (unsigned)n); };
+        const int O = 400, E = 30;
+        const int Y = cs % 4 == 0 ? 3000 : cs % 4 == 1 ? 9400 : cs % 4 == 2 ? 600 + rnd(1500) : 4000 + rnd(5000);      // (9400: rows that need the second group of columns)
+        const int dir = cs % 2 ? -1 : 1;
+        const int len = 150 + rnd(250);
+        // two sequences with a common origin: substitutions, a few indels, an N, soft-masked stretches; the side runs into the contig ends
+        const int64_t tn = len + rnd(60), qn = len + rnd(60);
+        std::vector<uint8_t> tb((size_t)tn + 2 * mb::kDevPad + 16, mb::kSep), qb((size_t)qn + 2 * mb::kDevPad + 16, mb::kSep);
+        uint8_t *tc = tb.data() + mb::kDevPad, *qc = qb.data() + mb::kDevPad;
+        for (int64_t i = 0; i < tn; i++) tc[i] = (uint8_t)rnd(4);
+        {
+            const int div = 1 + rnd(cs % 3 == 0 ? 12 : 30);
+            int64_t ti = 0;
+            for (int64_t qi = 0; qi < qn; qi++) {
+                if (rnd(100) < 2) ti += 1 + rnd(6);                      // deletion in the query
+                if (rnd(100) < 2) { qc[qi] = (uint8_t)rnd(4); continue; } // insertion
+                qc[qi] = ti < tn && rnd(100) >= div ? (tc[ti] & 3) : (uint8_t)rnd(4);
+                ti++;
+            }
+        }
+        if (rnd(2)) tc[rnd((int)tn)] = 4;
+        for (int s = 0; s < 20; s++) { tc[rnd((int)tn)] |= 8; qc[rnd((int)qn)] |= 8; }
+        // the side: from an anchor near one end towards the other
+        const int64_t t0 = dir > 0 ? rnd(10) : tn - rnd(10), q0 = dir > 0 ? rnd(10) : qn - rnd(10);
+        const int64_t na = dir > 0 ? tn - t0 : t0, nb = dir > 0 ? qn - q0 : q0;
+        const Side want = one_sided(tc, qc, t0, q0, dir, na, nb, O, E, Y);
+        // ---- the whole side as one piece, then cut in two at a row the DP is still alive at
+        mb::PairPtrs pp; pp.tc = tc; pp.qf = qc; pp.qr = qc;
+        bool ok = true;
+        const char *why = "";
+        for (int mode = 0; mode < 2 && ok; mode++) {
+            const int cut = mode == 0 ? 0 : (int)std::max<long long>(1, std::min<long long>(want.rows - 2, 20 + rnd(80)));
+            if (mode == 1 && want.rows < 8) break;
+            std::fill(arena.begin(), arena.begin() + (64 << 20), (uint8_t)0xEE);
+            std::vector<mb::DpProb> probs(2);
+            std::vector<mb::DpOut> outs(2);
+            std::vector<unsigned long long> rowdir(64, ~0ull);
+            std::vector<uint8_t> snaps((size_t)2 * mb::kSnapSlots * mb::kSnapBytes, 0x5A);
+            unsigned long long arena_next = 0;
+            memset(probs.data(), 0, sizeof(mb::DpProb) * 2); memset(outs.data(), 0xAA, sizeof(mb::DpOut) * 2);
+            mb::DpProb &a = probs[0];
+            a.t0 = (int32_t)t0; a.q0 = (int32_t)q0; a.na = (int32_t)na; a.nb = (int32_t)nb; a.dir = dir; a.strand = 0; a.pad0 = 0; a.row_lo = 0; a.row_off = 0;
+            a.stop_row = mode == 1 ? cut : -1; a.snap_row = mode == 1 ? std::max(1, cut / 2) : -1; a.init_snap = -1; a.snap_idx = 0; a.snap_row2 = -1; a.snap_row3 = -1;
+            hipLaunchKernelGGL(mb::k_ydrop2_emu, dim3(1), dim3(64), 0, nullptr, probs.data(), outs.data(), 1, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next, 64u << 10,
+                               rowdir.data(), snaps.data(), (const int *)nullptr);
+            std::vector<PieceRows> chain{{0, 0}};
+            mb::DpOut fin = outs[0];
+            if (fin.overflow) { ok = false; why = "overflow"; break; }
+            if (mode == 1) {
+                if (!fin.stopped) { ok = false; why = "the first piece did not stop at its stop row"; break; }
+                const mb::SnapHdr *h = (const mb::SnapHdr *)(snaps.data() + (size_t)1 * mb::kSnapBytes);
+                if (!h->valid || h->row != cut) { ok = false; why = "exit snapshot"; break; }
+                mb::DpProb &b = probs[1];
+                b = a; b.row_lo = cut; b.row_off = 8; b.stop_row = -1; b.snap_row = -1; b.init_snap = 1; b.snap_idx = mb::kSnapSlots;
+                hipLaunchKernelGGL(mb::k_ydrop2_emu, dim3(1), dim3(64), 0, nullptr, probs.data() + 1, outs.data() + 1, 1, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next,
+                                   64u << 10, rowdir.data(), snaps.data(), (const int *)nullptr);
+                fin = outs[1];
+                if (fin.overflow) { ok = false; why = "overflow (second piece)"; break; }
+                chain.push_back({8, cut});
+            }
+            if (fin.best != want.best || fin.bi != want.bi || fin.bj != want.bj) { ok = false; why = "best cell"; break; }
+            if (fin.cells != want.cells || fin.rows != want.rows) { ok = false; why = "cells / rows"; break; }
+            std::vector<uint8_t> ops;
+            if (!walk_trace(arena.data(), rowdir.data(), chain, fin.bi, fin.bj, ops) || ops != want.ops) { ok = false; why = "trace"; break; }
+        }
+        printf("case %d: dir %+d, %lld x %lld, ydrop %d: best %d at (%d, %d), %lld cells in %lld rows, %zu ops  %s%s\n", cs, dir, (long long)na, (long long)nb, Y, want.best, want.bi,
+               want.bj, want.cells, want.rows, want.ops.size(), ok ? "ok" : "MISMATCH: ", ok ? "" : why);
+        if (!ok) bad++;
+    }
+    return bad ? 1 : 0;
+}
