@@ -56,6 +56,28 @@ def test_oracle_equals_real_lastz(olz, tmp_path, name, tf, qf, args):
     assert verdicts[required][0], {k: v for k, v in verdicts.items()}
 
 
+@pytest.mark.skipif(LASTZ is None, reason="P1 NOT EXERCISED: no real lastz binary ($MIBLAST_LASTZ / PATH); parity stays unpinned")
+def test_a_side_longer_than_lastz_default_traceback_allocation(olz, tmp_path):
+    """The third A.9 candidate: lastz bounds one traceback's memory (--allocate:traceback, 80 MiB by default) and
+    truncates an alignment whose DP outgrows it; the oracle keeps the whole trace.  A 700 kb pair at 1 % divergence is one alignment whose
+    sides evaluate ~1.2 x 10^8 cells: with a real binary this tells which of the two the Cactus command line gets -- and, run again with
+    --allocate:traceback=1G, whether that alone accounts for the difference."""
+    from cactus_amd import gen, miblast
+    t, q = gen.make_pair(700_000, 4242, sub_rate=0.01, indel_rate=0.0005)
+    tf, qf = gen.fasta_bytes([("id=simT|chr1", t)]), gen.fasta_bytes([("id=simQ|chr1", q)])
+    (tmp_path / "T.fa").write_bytes(tf)
+    (tmp_path / "Q.fa").write_bytes(qf)
+    args = ["--step=2", "--ambiguous=iupac,100,100", "--ydrop=3000", "--notransition"]
+    want = olz.align(tf, qf, olz.default_params(**{f: getattr(miblast.params_from_args(args), f) for f, _ in miblast.params_from_args(args)._fields_}), details=False)["paf"]
+    verdict = {}
+    for label, extra in (("default allocation", []), ("--allocate:traceback=1G", ["--allocate:traceback=1G"])):
+        p = subprocess.run([LASTZ, "T.fa[multiple][nameparse=darkspace]", "Q.fa[nameparse=darkspace]", "--format=paf:wfmash", *args, *extra], cwd=tmp_path, capture_output=True)
+        assert p.returncode == 0, p.stderr.decode()
+        verdict[label] = sorted(p.stdout.splitlines()) == sorted(want.splitlines())
+    assert verdict["--allocate:traceback=1G"], verdict          # with room for the trace the binary must agree with the oracle ...
+    assert verdict["default allocation"], verdict               # ... and if only this one fails, the traceback limit is the switch to add
+
+
 def test_the_skip_is_reported_not_silent():
     if LASTZ is None:
         assert shutil.which("lastz") in (None, os.path.join(ROOT, "bin", "lastz")) or True
