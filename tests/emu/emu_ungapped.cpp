@@ -1,8 +1,9 @@
-// TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_runs.h, mb_ungapped_grp.h and mb_ungapped_ux.h (run heads, the ungapped extension kernels, anchors) on the
+// TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_runs.h, mb_ungapped_lane.h, mb_ungapped_grp.h and mb_ungapped_ux.h (run heads, the ungapped extension kernels
+// of the short runs -- "lane", the default, "ux" --, k_ungapped_long for the long ones, anchors) on the
 // HOST -- one pthread per work-item, DPP / ballot exchanged through per-wave barriers (see hip/hip_runtime.h) -- against a
 // sequential restatement of the rule (oracle/lastz_oracle.c:227-262, :508-521) on random sequence sets with planted homology,
 // separators, N bases and busy diagonals.  Nothing of this is shipped or measured.
-//   emu_ungapped <seed> <n_cases>      exit status 0 iff every case is identical (HSP records, extent[], counters)
+//   emu_ungapped <seed> <n_cases> [lane|ux]     exit status 0 iff every case is identical (HSP records, extent[], counters)
 #define MB_EMU 1
 #include <hip/hip_runtime.h>
 #undef __launch_bounds__
@@ -75,10 +76,53 @@ inline int __ffs(int v) { return __builtin_ffs(v); }
 using std::max;
 using std::min;
 
+// (mb_ungapped_lane.h calls the wave primitives by the names mb_kernels.hip gives them)
+inline unsigned long long __ballot(bool p) { return wballot(p); }
+#define __builtin_amdgcn_readlane(v, l) wreadlane((v), (l))
+template <typename T>
+inline T __shfl_down(T v, int o) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu_tid(), w = tid >> 6, lane = tid & 63;
+    unsigned long long raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    g->slot[tid] = raw;
+    pthread_barrier_wait(&g->wave[w]);
+    raw = g->slot[(tid & ~63u) | (lane + (unsigned)o < 64 ? lane + (unsigned)o : lane)];
+    pthread_barrier_wait(&g->wave[w]);
+    T out;
+    memcpy(&out, &raw, sizeof(T));
+    return out;
+}
+
 namespace mb {
+inline int uni(int v) { return wreadlane(v, 0); }
+inline unsigned long long uni64(unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)(unsigned)v); }
+inline int dpp_shr1(int v, int fill) {                                 // lane l <- lane l-1, lane 0 <- fill
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu_tid(), w = tid >> 6, lane = tid & 63;
+    g->slot[tid] = (unsigned long long)(unsigned)v;
+    pthread_barrier_wait(&g->wave[w]);
+    const int o = lane ? (int)(unsigned)g->slot[tid - 1] : fill;
+    pthread_barrier_wait(&g->wave[w]);
+    return o;
+}
+template <bool kMax>
+inline int emu_scan(int v) {                                           // inclusive prefix sum / prefix max over the wave
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu_tid(), w = tid >> 6, lane = tid & 63;
+    g->slot[tid] = (unsigned long long)(unsigned)v;
+    pthread_barrier_wait(&g->wave[w]);
+    int acc = v;
+    for (unsigned l = 0; l < lane; l++) { const int x = (int)(unsigned)g->slot[(tid & ~63u) | l]; acc = kMax ? std::max(acc, x) : acc + x; }
+    pthread_barrier_wait(&g->wave[w]);
+    return acc;
+}
+inline int dpp_scan_add(int v) { return emu_scan<false>(v); }
+inline int dpp_scan_max(int v) { return emu_scan<true>(v); }
 #include "mb_xdrop.h"
 #include "mb_units.h"
 #include "mb_runs.h"
+#include "mb_ungapped_lane.h"
 #include "mb_ungapped_grp.h"
 #include "mb_ungapped_ux.h"
 }  // namespace mb
@@ -94,12 +138,11 @@ static int score_of(unsigned a, unsigned b) {
 struct Ref { std::vector<mb::DevHsp> hsps; std::vector<int32_t> extent; unsigned long long extended = 0, cols = 0; };
 
 static void reference(const std::vector<unsigned long long> &keys, const uint8_t *tc, const uint8_t *qc, int64_t qtot, int xdrop, int K,
-                      int long_run, Ref &out) {
+                      int /* long_run: the long runs are k_ungapped_long's, the rule is one */, Ref &out) {
     for (size_t i = 0; i < keys.size();) {
         const uint32_t dq = (uint32_t)(keys[i] >> 32);
         int32_t ext = out.extent[dq];
         size_t j = i;
-        { size_t e = i; while (e < keys.size() && (uint32_t)(keys[e] >> 32) == dq) e++; if ((int)(e - i) > long_run) { i = e; continue; } }   // (a run of k_ungapped_long: not the kernels under test)
         for (; j < keys.size() && (uint32_t)(keys[j] >> 32) == dq; j++) {
             const int32_t q_end = (int32_t)(uint32_t)keys[j];
             if (q_end <= ext) continue;
@@ -160,6 +203,7 @@ int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
     const bool use_ux = argc > 3 && !strcmp(argv[3], "ux");             // the level-synchronous pipeline instead of k_ungapped_grp
+    const bool use_lane = argc > 3 && !strcmp(argv[3], "lane");         // the run-per-lane kernel k_ungapped
     int bad = 0;
     for (int cs = 0; cs < n_cases; cs++) {
         std::mt19937 rng(seed0 * 7919u + (unsigned)cs);
@@ -271,7 +315,10 @@ int main(int argc, char **argv) {
         std::vector<mb::UngappedCounters> ctrs((size_t)n_units, mb::UngappedCounters{0, 0, 0});
         mb::UngappedCounters *ctr = ctrs.data();
         const unsigned blocks = 1 + (unsigned)rnd(3);                    // few groups: every group walks many runs
-        if (!use_ux) {
+        if (use_lane) {
+            hipLaunchKernelGGL(mb::k_ungapped, dim3((unsigned)((n_hits + 255) / 256 + mb::kRunClasses)), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, ut,
+                               extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), ctr);
+        } else if (!use_ux) {
             hipLaunchKernelGGL(mb::k_ungapped_grp<5>, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, ut,
                                extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), ctr);
         } else {
@@ -299,6 +346,9 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(mb::k_ux_census, dim3(1), dim3(256), 0, nullptr, ut, hsps.data(), (int64_t)hsps.size(), ctr);
             { unsigned nb = 0; for (unsigned v : blk_cnt) nb += v; printf("  ux: %u + %u of %lld hits left for the tail (block slots + list), %llu candidates, %u dirty runs\n", nb, n_entries[0], (long long)n_hits, ctr[0].hsps, n_entries[1]); }
         }
+        // the long runs, whichever kernel took the short ones: a wave per run and turn, the grid's waves striding over the list
+        hipLaunchKernelGGL(mb::k_ungapped_long, dim3(1u + (unsigned)rnd(2)), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data() + (n + n / 2 + n / 4 + n / 8 + 8), n_heads + 4, ut,
+                           extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), ctr);
         hipLaunchKernelGGL(mb::k_hsp_anchor, dim3(1), dim3(256), 0, nullptr, ut, hsps.data(), (int64_t)hsps.size(), ctr);
         hsps.resize((size_t)ctr[0].hsps);
         bool all_ok = true;
@@ -332,8 +382,8 @@ int main(int argc, char **argv) {
                     if (ext[d] != u.ref.extent[d]) { printf("  first differing extent: diagonal %zu got %d want %d\n", d, ext[d], u.ref.extent[d]); break; }
             }
         }
-        printf("case %d: %d unit(s) hits %lld runs %u xdrop %d K %d  hsps %zu/%zu  %s\n", cs, n_units, (long long)n_hits,
-               n_heads[0] + n_heads[1] + n_heads[2] + n_heads[3], xdrop, K, total_hsps, total_ref, all_ok ? "ok" : "MISMATCH");
+        printf("case %d: %d unit(s) hits %lld runs %u + %u long (> %d hits) xdrop %d K %d  hsps %zu/%zu  %s\n", cs, n_units, (long long)n_hits,
+               n_heads[0] + n_heads[1] + n_heads[2] + n_heads[3], n_heads[4], long_run, xdrop, K, total_hsps, total_ref, all_ok ? "ok" : "MISMATCH");
         if (!all_ok) bad++;
     }
     return bad ? 1 : 0;
