@@ -609,7 +609,7 @@ def run_rank(a):
                       "handovers_accepted_per_step": tot["relay_accepted"] / per, "handovers_rejected_per_step": tot["relay_rejected"] / per,
                       "reruns_per_step": tot["dp_reruns"] / per,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / per, "merge_ms_per_step": tot["t_merge_ms"] / per},
-            "roofline": dp_roofline(tot, "r03_hbm_traffic_pmc.json" if a.workload == "evolver" else "r03_pair_hbm_traffic_pmc.json"),
+            "roofline": dp_roofline(tot, "r04_hbm_traffic_pmc.json" if a.workload == "evolver" else "r03_pair_hbm_traffic_pmc.json"),
             "host": {"cpu_seconds_per_step": tot["host_cpu_seconds"] / per, "busy_threads_avg": tot["host_cpu_seconds"] / world / max(1e-9, elapsed),
                      "cgroup_throttled_periods": tot["host_throttled_periods"], "cgroup_throttled_ms": tot["host_throttled_ms"],
                      "note": "all ranks; a CPU-quota container freezes the process when its threads exceed the quota (outlier steps)"},
