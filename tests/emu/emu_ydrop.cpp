@@ -3,7 +3,8 @@
 // hip/hip_runtime.h), against a plain restatement of SURVEY A.10 ONE_SIDED (rows = query, one cell at a time in row-major order, y-drop
 // against the running best, ties diag > D > I, extension wins gap ties): best cell, cells and rows counted, and the alignment read back
 // from the kernel's 4-bit trace codes through its row records.  Also a side cut in two pieces: the second continues from the first
-// one's exit snapshot and must end where the whole side ends.  Nothing of this is shipped or measured.
+// one's exit snapshot and must end where the whole side ends; and the relay hand-over check (mb_verify.h) on the states the evaluator
+// writes.  Nothing of this is shipped or measured.
 //   emu_ydrop <seed> <n_cases>      exit status 0 iff every case is identical
 #define MB_EMU 1
 #include <hip/hip_runtime.h>
@@ -96,6 +97,20 @@ inline uint32_t row_score_lut(unsigned bq) {
     return v;
 }
 #include "mb_ydrop2.h"
+}  // namespace mb
+// (block-wide OR of a predicate: every work-item publishes its flag, all read all)
+inline int __syncthreads_or(int p) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu::t_threadIdx.x, nt = emu::t_blockDim.x;
+    g->slot[tid] = p ? 1ull : 0ull;
+    pthread_barrier_wait(&g->all);
+    int any = 0;
+    for (unsigned t = 0; t < nt; t++) any |= (int)g->slot[t];
+    pthread_barrier_wait(&g->all);
+    return any;
+}
+namespace mb {
+#include "mb_verify.h"
 // (the kernel proper: the __global__ wrapper of mb_kernels.hip)
 void k_ydrop2_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, const int O, const int E, const int Y, uint8_t *arena,
                   const unsigned long long arena_bytes, unsigned long long *arena_next, const unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps,
@@ -263,6 +278,58 @@ int main(int argc, char **argv) {
             if (fin.cells != want.cells || fin.rows != want.rows) { ok = false; why = "cells / rows"; break; }
             std::vector<uint8_t> ops;
             if (!walk_trace(arena.data(), rowdir.data(), chain, fin.bi, fin.bj, ops) || ops != want.ops) { ok = false; why = "trace"; break; }
+        }
+        // ---- the hand-over check (k_verify) on states the evaluator writes: a piece's entry snapshot after row r against the exit snapshot
+        //      of the same DP stopped at r (equal: accepted, c = 0); the same state with every live value and the best moved by one
+        //      constant (accepted, c = that constant) and shifted by whole columns and rows (accepted under the job's shift / drow); one
+        //      live C or one D that can still matter changed (rejected); a D below what can ever matter again changed (accepted)
+        if (ok && want.rows >= 12) {
+            const int r = (int)std::max<long long>(2, std::min<long long>(want.rows - 3, 10 + rnd(60)));
+            std::fill(arena.begin(), arena.begin() + (64 << 20), (uint8_t)0xEE);
+            std::vector<mb::DpProb> probs(1);
+            std::vector<mb::DpOut> outs(1);
+            std::vector<unsigned long long> rowdir(64, ~0ull);
+            std::vector<uint8_t> snaps((size_t)8 * mb::kSnapBytes, 0);
+            unsigned long long arena_next = 0;
+            memset(probs.data(), 0, sizeof(mb::DpProb));
+            mb::DpProb &a = probs[0];
+            a.t0 = (int32_t)t0; a.q0 = (int32_t)q0; a.na = (int32_t)na; a.nb = (int32_t)nb; a.dir = dir; a.row_lo = 0; a.row_off = 0;
+            a.stop_row = -1; a.snap_row = r; a.init_snap = -1; a.snap_idx = 0; a.snap_row2 = -1; a.snap_row3 = -1;      // the entry snapshot after row r: slot 0
+            hipLaunchKernelGGL(mb::k_ydrop2_emu, dim3(1), dim3(64), 0, nullptr, probs.data(), outs.data(), 1, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next, 64u << 10,
+                               rowdir.data(), snaps.data(), (const int *)nullptr);
+            a.stop_row = r; a.snap_row = -1; a.snap_idx = 4;                                                              // the same DP stopped at r: exit snapshot in slot 5
+            hipLaunchKernelGGL(mb::k_ydrop2_emu, dim3(1), dim3(64), 0, nullptr, probs.data(), outs.data(), 1, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next, 64u << 10,
+                               rowdir.data(), snaps.data(), (const int *)nullptr);
+            auto hdr = [&](int slot) { return (mb::SnapHdr *)(snaps.data() + (size_t)slot * mb::kSnapBytes); };
+            auto Cof = [&](int slot) { return (int *)(snaps.data() + (size_t)slot * mb::kSnapBytes + sizeof(mb::SnapHdr)); };
+            auto Dof = [&](int slot) { return Cof(slot) + mb::kSnapCols; };
+            const int kE = 5;                                                // the upstream piece's exit state
+            if (!hdr(0)->valid || !hdr(kE)->valid) { ok = false; why = "snapshots of the check"; }
+            const int w = hdr(kE)->RY - hdr(kE)->LY, cst = 1000 + rnd(100000), dsh = rnd(500), dr = rnd(300);
+            auto derive = [&](int slot, int dc, int dcol, int drow) {       // slot <- exit state moved by a constant / whole columns / rows
+                memcpy(snaps.data() + (size_t)slot * mb::kSnapBytes, snaps.data() + (size_t)kE * mb::kSnapBytes, mb::kSnapBytes);
+                mb::SnapHdr *h = hdr(slot);
+                h->best -= dc; h->LY -= dcol; h->RY -= dcol; h->row -= drow;
+                for (int x = 0; x < w; x++) { if (Cof(slot)[x] != mb::kNeg) Cof(slot)[x] -= dc; if (Dof(slot)[x] > mb::kNeg2) Dof(slot)[x] -= dc; }
+            };
+            derive(1, cst, 0, 0); derive(2, cst, dsh, dr);
+            derive(3, 0, 0, 0); derive(6, 0, 0, 0); derive(7, 0, 0, 0);
+            int live_c = -1, live_d = -1, dead_d = -1;
+            const int thr = hdr(kE)->best - Y;
+            for (int x = 0; x < w; x++) {
+                if (live_c < 0 && Cof(kE)[x] != mb::kNeg) live_c = x;
+                if (live_d < 0 && Dof(kE)[x] - E >= thr) live_d = x;
+                if (dead_d < 0 && Dof(kE)[x] > mb::kNeg2 && Dof(kE)[x] - E < thr - 50) dead_d = x;
+            }
+            if (live_c >= 0) Cof(3)[live_c] -= 1;
+            if (live_d >= 0) Dof(6)[live_d] -= 1;
+            if (dead_d >= 0) Dof(7)[dead_d] -= 7;
+            std::vector<mb::VerifyJob> vj = {{kE, 0, 0, 0}, {kE, 1, 0, 0}, {kE, 2, dsh, dr}, {kE, 3, 0, 0}, {kE, 6, 0, 0}, {kE, 7, 0, 0}, {kE, 2, dsh + 1, dr}};
+            std::vector<mb::VerifyOut> vo(vj.size());
+            hipLaunchKernelGGL(mb::k_verify, dim3((unsigned)vj.size()), dim3(256), 0, nullptr, vj.data(), vo.data(), (int)vj.size(), snaps.data(), Y, E);
+            const bool v_ok = vo[0].ok && vo[0].c == 0 && vo[1].ok && vo[1].c == cst && vo[2].ok && vo[2].c == cst && (live_c < 0 || !vo[3].ok) && (live_d < 0 || !vo[4].ok) &&
+                              (dead_d < 0 || vo[5].ok) && !vo[6].ok;
+            if (!v_ok) { ok = false; why = "k_verify"; }
         }
         printf("case %d: dir %+d, %lld x %lld, ydrop %d: best %d at (%d, %d), %lld cells in %lld rows, %zu ops  %s%s\n", cs, dir, (long long)na, (long long)nb, Y, want.best, want.bi,
                want.bj, want.cells, want.rows, want.ops.size(), ok ? "ok" : "MISMATCH: ", ok ? "" : why);

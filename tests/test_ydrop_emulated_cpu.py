@@ -4,7 +4,10 @@ and ballot exchanged through the wave's slots -- and compared with a plain resta
 row-major order): best cell, cells and rows counted, and the alignment read back from the kernel's 4-bit trace codes through its row records;
 forward and backward sides that run into the contig ends, Cactus's y-drops (3000: rows inside the first 256 columns; 9400: rows that need
 the second group), an N, soft-masked bases; and every side once more cut in two pieces, the second continuing from the first one's exit
-snapshot (the relay / continuation format of the gapped stage).  The emulation is test infrastructure: libmiblast.so has no CPU path."""
+snapshot (the relay / continuation format of the gapped stage); and the relay hand-over check k_verify (mb_verify.h) on the states the
+evaluator writes: entry and exit state after the same row are equal, a state moved by one constant and by whole columns / rows is accepted
+under the job's offsets, a changed live C or reachable D is rejected, a D that can never matter again may differ.  The emulation is test
+infrastructure: libmiblast.so has no CPU path."""
 import os
 import subprocess
 
