@@ -209,7 +209,8 @@ static bool walk_trace(const uint8_t *arena, const unsigned long long *rowdir, c
 int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
-    int bad = 0;
+    const bool relay_mode = argc > 3 && !strcmp(argv[3], "relay");      // the exactness of an accepted relay hand-over instead of the cut / check tests
+    int bad = 0, relays_accepted = 0, relays_tried = 0;
     const unsigned long long arena_bytes = 96ull << 20;
     std::vector<uint8_t> arena((size_t)arena_bytes);
     for (int cs = 0; cs < n_cases; cs++) {
@@ -244,6 +245,63 @@ int main(int argc, char **argv) {
         mb::PairPtrs pp; pp.tc = tc; pp.qf = qc; pp.qr = qc;
         bool ok = true;
         const char *why = "";
+        // ---- relay mode: an ACCEPTED hand-over is exact.  The upstream piece runs from the side's origin and stops after row r (exit state);
+        //      a relay starts COLD at a cell of the side's own path w rows before r, as the gapped stage starts one at a downstream anchor,
+        //      and takes its entry snapshot after its local row w (the same row of the side); k_verify compares the two under the relay's
+        //      offsets.  If it accepts, the relay continued from that snapshot must end at the side's best cell with the side's score.
+        if (relay_mode) {
+            // the path's cells from the origin outwards (ops come in walk-back order)
+            std::vector<std::pair<int, int>> diag_cells;                 // cells reached by a diagonal step
+            { int i = 0, j = 0; for (size_t k = want.ops.size(); k-- > 0;) { const uint8_t o = want.ops[k]; if (o == 0) { i++; j++; diag_cells.push_back({i, j}); } else if (o == 2) i++; else j++; } }
+            const int r = (int)(want.bi * 6 / 10), w = std::min(r - 4, 60 + rnd(90));
+            std::pair<int, int> at{-1, -1};
+            for (const auto &c : diag_cells) if (c.first <= r - w) at = c;
+            if (want.bi < 40 || w < 20 || at.first < 1) { printf("case %d: side too short for a relay\n", cs); continue; }
+            relays_tried++;
+            const int i0 = at.first, j0 = at.second;                        // the relay's origin: rows / columns of the side before it
+            std::fill(arena.begin(), arena.begin() + (64 << 20), (uint8_t)0xEE);
+            std::vector<mb::DpProb> probs(3);
+            std::vector<mb::DpOut> outs(3);
+            std::vector<unsigned long long> rowdir(64, ~0ull);
+            std::vector<uint8_t> snaps((size_t)3 * mb::kSnapSlots * mb::kSnapBytes, 0);
+            unsigned long long arena_next = 0;
+            memset(probs.data(), 0, sizeof(mb::DpProb) * 3);
+            mb::DpProb &up = probs[0], &rl = probs[1], &ct = probs[2];
+            up.t0 = (int32_t)t0; up.q0 = (int32_t)q0; up.na = (int32_t)na; up.nb = (int32_t)nb; up.dir = dir; up.row_off = 0;
+            up.stop_row = r; up.snap_row = -1; up.init_snap = -1; up.snap_idx = 0; up.snap_row2 = -1; up.snap_row3 = -1;          // exit: slot 1
+            rl = up;
+            rl.t0 = (int32_t)(t0 + dir * j0); rl.q0 = (int32_t)(q0 + dir * i0); rl.na = (int32_t)(na - j0); rl.nb = (int32_t)(nb - i0); rl.row_off = 8;
+            rl.stop_row = r - i0; rl.snap_idx = mb::kSnapSlots;                                                                     // the relay stopped after the same row: slot 5
+            hipLaunchKernelGGL(mb::k_ydrop2_emu, dim3(2), dim3(64), 0, nullptr, probs.data(), outs.data(), 2, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next, 64u << 10,
+                               rowdir.data(), snaps.data(), (const int *)nullptr);
+            if (outs[0].overflow || outs[1].overflow || !outs[0].stopped) { printf("case %d: relay setup failed  MISMATCH\n", cs); bad++; continue; }
+            mb::VerifyJob vj{1, mb::kSnapSlots + 1, j0, i0};
+            mb::VerifyOut vo;
+            hipLaunchKernelGGL(mb::k_verify, dim3(1), dim3(256), 0, nullptr, &vj, &vo, 1, snaps.data(), Y, E);
+            bool exact = true;
+            if (vo.ok && outs[1].stopped) {
+                relays_accepted++;
+                ct = rl; ct.row_lo = r - i0; ct.row_off = 16; ct.stop_row = -1; ct.init_snap = mb::kSnapSlots + 1; ct.snap_idx = 2 * mb::kSnapSlots;
+                hipLaunchKernelGGL(mb::k_ydrop2_emu, dim3(1), dim3(64), 0, nullptr, probs.data() + 2, outs.data() + 2, 1, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next,
+                                   64u << 10, rowdir.data(), snaps.data(), (const int *)nullptr);
+                const mb::DpOut &f = outs[2];
+                // (the side's best lies beyond the hand-over row by the choice of r; the relay counts rows, columns and scores from its origin)
+                exact = !f.overflow && f.best + vo.c == want.best && f.bi + i0 == want.bi && f.bj + j0 == want.bj;
+                // the path from the best cell back to the hand-over row is the side's own
+                if (exact) {
+                    std::vector<uint8_t> ops;
+                    std::vector<PieceRows> chain{{8, 0}, {16, r - i0}};
+                    exact = walk_trace(arena.data(), rowdir.data(), chain, f.bi, f.bj, ops);
+                    size_t n_after = 0;                                  // ops of the side's walk-back until it reaches row r
+                    { int i = want.bi; for (; n_after < want.ops.size() && i > r; n_after++) if (want.ops[n_after] != 3) i--; }
+                    exact = exact && ops.size() >= n_after && std::equal(ops.begin(), ops.begin() + (long)n_after, want.ops.begin());
+                }
+            }
+            printf("case %d: dir %+d, ydrop %d, side of %d rows, hand-over after row %d, relay from (%d, %d) with %d rows of warm-up: %s  %s\n", cs, dir, Y, want.bi, r, i0, j0,
+                   r - i0, vo.ok ? "accepted" : "rejected", exact ? "ok" : "MISMATCH");
+            if (!exact) bad++;
+            continue;
+        }
         for (int mode = 0; mode < 2 && ok; mode++) {
             const int cut = mode == 0 ? 0 : (int)std::max<long long>(1, std::min<long long>(want.rows - 2, 20 + rnd(80)));
             if (mode == 1 && want.rows < 8) break;
@@ -334,6 +392,10 @@ int main(int argc, char **argv) {
         printf("case %d: dir %+d, %lld x %lld, ydrop %d: best %d at (%d, %d), %lld cells in %lld rows, %zu ops  %s%s\n", cs, dir, (long long)na, (long long)nb, Y, want.best, want.bi,
                want.bj, want.cells, want.rows, want.ops.size(), ok ? "ok" : "MISMATCH: ", ok ? "" : why);
         if (!ok) bad++;
+    }
+    if (relay_mode) {
+        printf("relays: %d of %d accepted\n", relays_accepted, relays_tried);
+        if (relays_tried && !relays_accepted) { printf("no hand-over was accepted: the test says nothing  MISMATCH\n"); bad++; }
     }
     return bad ? 1 : 0;
 }

@@ -21,3 +21,17 @@ def test_emulated_ydrop2_piece_evaluator_matches_the_rule_cell_by_cell():
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()
     assert out.count(" ok\n") == 2 and "MISMATCH" not in out, out
+
+
+def test_emulated_relay_hand_over_that_is_accepted_is_exact():
+    """The claim the gapped stage's speed rests on: a relay -- a fresh DP started COLD at a cell of the alignment's own
+    path, as the stage starts one at a downstream anchor -- whose state after a row equals the upstream piece's state after the same row up
+    to one constant (k_verify) evolves like it from there on.  Emulated evaluator and emulated check: whenever the check accepts, the relay
+    continued from its snapshot ends at the side's best cell with the side's score (plus the constant) and its traceback is the side's own
+    down to the hand-over row; a hand-over may also be rejected (too short a warm-up for a wide window) -- then nothing is claimed -- but
+    not all of them."""
+    subprocess.run(["make", "-C", EMU_DIR, "emu_ydrop"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_ydrop"), "5", "3", "relay"], capture_output=True, timeout=1500)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert "MISMATCH" not in out and "accepted  ok" in out, out
