@@ -3,8 +3,8 @@
 // hip/hip_runtime.h), against a plain restatement of SURVEY A.10 ONE_SIDED (rows = query, one cell at a time in row-major order, y-drop
 // against the running best, ties diag > D > I, extension wins gap ties): best cell, cells and rows counted, and the alignment read back
 // from the kernel's 4-bit trace codes through its row records.  Also a side cut in two pieces: the second continues from the first
-// one's exit snapshot and must end where the whole side ends; and the relay hand-over check (mb_verify.h) on the states the evaluator
-// writes.  Nothing of this is shipped or measured.
+// one's exit snapshot and must end where the whole side ends; the relay hand-over check (mb_verify.h) on the states the evaluator
+// writes; and the traceback kernels (mb_trace.h: walkers, predicted joins, stitch) over those chains of pieces.  Nothing of this is shipped or measured.
 //   emu_ydrop <seed> <n_cases>      exit status 0 iff every case is identical
 #define MB_EMU 1
 #include <hip/hip_runtime.h>
@@ -109,7 +109,11 @@ inline int __syncthreads_or(int p) {
     pthread_barrier_wait(&g->all);
     return any;
 }
+inline unsigned long long __ballot(bool p) { return yd_ballot(p); }
+#define __builtin_amdgcn_readlane(v, l) yd_readlane((v), (l))
+#define __builtin_memcpy memcpy
 namespace mb {
+#include "mb_trace.h"
 #include "mb_verify.h"
 // (the kernel proper: the __global__ wrapper of mb_kernels.hip)
 void k_ydrop2_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, const int O, const int E, const int Y, uint8_t *arena,
@@ -206,6 +210,50 @@ static bool walk_trace(const uint8_t *arena, const unsigned long long *rowdir, c
     return ok;
 }
 
+// the side's alignment through the traceback KERNELS (mb_trace.h): one walker per piece from the best cell's piece back to the head, the
+// guessed start of every other piece = the best cell of its last row (exit_j), join walks from predicted entries (k_trace_prejoin), the
+// stitch (k_trace_join); the segments' runs expanded to one op per column.  pieces: head first; (dr, dc) = a piece's origin in the
+// coordinates of the piece before it.
+struct ChainPiece { uint64_t row_off; int row_lo, floor, stop_row, exit_j, dr, dc; };
+static bool trace_kernels(const uint8_t *arena, unsigned long long arena_bytes, const unsigned long long *rowdir, const std::vector<ChainPiece> &pieces, int bi, int bj, int poison,
+                          std::vector<uint8_t> &ops_out) {
+    std::vector<mb::TbWalk> tbw;
+    uint64_t ooff = 0, roff = 0, side_slots = 0;
+    for (size_t x = pieces.size(); x-- > 0;) {
+        const ChainPiece &pc = pieces[x];
+        mb::TbWalk w;
+        memset(&w, 0, sizeof w);
+        w.row_off = pc.row_off; w.row_lo = pc.row_lo; w.floor = x > 0 ? pc.floor : -1;
+        if (x + 1 == pieces.size()) { w.si = bi; w.sj = bj; } else { w.si = pc.stop_row; w.sj = pc.exit_j; }
+        if (x > 0) { w.dr = pc.dr; w.dc = pc.dc; }
+        const uint64_t rows = (uint64_t)(w.si - w.floor), slots = 2 * rows + 2 * 2048 + 8;
+        w.ops_off = ooff; ooff += slots; side_slots += slots;
+        w.rec_off = roff; roff += 3 * rows;
+        tbw.push_back(w);
+    }
+    mb::TbSide ts;
+    memset(&ts, 0, sizeof ts);
+    ts.first_walk = 0; ts.n_walks = (int32_t)tbw.size(); ts.jops_off = ooff; ooff += side_slots; ts.seg_off = 0;
+    for (size_t x = 0; x < tbw.size(); x++) { const unsigned long long jo = x == 0 ? ~0ull : ts.jops_off + (tbw[x].ops_off - tbw[0].ops_off); memcpy(tbw[x].pad, &jo, 8); }
+    std::vector<uint32_t> ops((size_t)ooff + 64, 0xDDDDDDDDu), recs((size_t)roff + 64, 0xBBBBBBBBu);
+    std::vector<mb::TbSeg> segs(2 * tbw.size() + 2);
+    std::vector<mb::TbJoin> joins(tbw.size());
+    hipLaunchKernelGGL(mb::k_trace_walk, dim3((unsigned)tbw.size()), dim3(64), 0, nullptr, tbw.data(), (int)tbw.size(), arena, arena_bytes, rowdir, ops.data(), recs.data());
+    hipLaunchKernelGGL(mb::k_trace_prejoin, dim3((unsigned)tbw.size()), dim3(64), 0, nullptr, tbw.data(), (int)tbw.size(), joins.data(), arena, arena_bytes, rowdir, ops.data(), recs.data(), poison);
+    hipLaunchKernelGGL(mb::k_trace_join, dim3(1), dim3(64), 0, nullptr, &ts, 1, tbw.data(), segs.data(), arena, arena_bytes, rowdir, ops.data(), recs.data(), joins.data());
+    ops_out.clear();
+    for (int q = 0; q < ts.n_segs; q++) {
+        const mb::TbSeg &sg = segs[(size_t)q];
+        for (int k = 0; k < sg.n_runs; k++) {
+            const uint32_t o = ops[(size_t)sg.src + (size_t)k];
+            int len = (int)(o >> 2) - (k == 0 ? sg.first_sub : 0);
+            if (len < 0 || (o & 3u) == 1u) return false;
+            for (int c = 0; c < len; c++) ops_out.push_back((uint8_t)(o & 3u));
+        }
+    }
+    return true;
+}
+
 int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
@@ -296,6 +344,14 @@ int main(int argc, char **argv) {
                     { int i = want.bi; for (; n_after < want.ops.size() && i > r; n_after++) if (want.ops[n_after] != 3) i--; }
                     exact = exact && ops.size() >= n_after && std::equal(ops.begin(), ops.begin() + (long)n_after, want.ops.begin());
                 }
+                // the whole alignment through the traceback kernels: the relay's continuation back to the hand-over row, then the upstream
+                // piece in ITS coordinates (origin offset i0 rows / j0 columns), entered wherever the path crosses row r
+                if (exact) {
+                    std::vector<uint8_t> ops;
+                    std::vector<ChainPiece> cps{{0, 0, -1, r, outs[0].exit_j, 0, 0}, {16, r - i0, r - i0, -1, 0, i0, j0}};
+                    for (int poison = 0; poison < 2 && exact; poison++)
+                        exact = trace_kernels(arena.data(), arena_bytes, rowdir.data(), cps, f.bi, f.bj, poison, ops) && ops == want.ops;
+                }
             }
             printf("case %d: dir %+d, ydrop %d, side of %d rows, hand-over after row %d, relay from (%d, %d) with %d rows of warm-up: %s  %s\n", cs, dir, Y, want.bi, r, i0, j0,
                    r - i0, vo.ok ? "accepted" : "rejected", exact ? "ok" : "MISMATCH");
@@ -336,6 +392,11 @@ int main(int argc, char **argv) {
             if (fin.cells != want.cells || fin.rows != want.rows) { ok = false; why = "cells / rows"; break; }
             std::vector<uint8_t> ops;
             if (!walk_trace(arena.data(), rowdir.data(), chain, fin.bi, fin.bj, ops) || ops != want.ops) { ok = false; why = "trace"; break; }
+            // ... and the same alignment through the traceback kernels, with every other join prediction made wrong on purpose the second time
+            std::vector<ChainPiece> cps{{0, 0, -1, cut, outs[0].exit_j, 0, 0}};
+            if (mode == 1) cps.push_back({8, cut, cut, -1, 0, 0, 0});
+            for (int poison = 0; poison < 2 && ok; poison++)
+                if (!trace_kernels(arena.data(), arena_bytes, rowdir.data(), cps, fin.bi, fin.bj, poison, ops) || ops != want.ops) { ok = false; why = "traceback kernels"; }
         }
         // ---- the hand-over check (k_verify) on states the evaluator writes: a piece's entry snapshot after row r against the exit snapshot
         //      of the same DP stopped at r (equal: accepted, c = 0); the same state with every live value and the best moved by one
