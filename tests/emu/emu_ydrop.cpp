@@ -2,7 +2,8 @@
 // HOST: one pthread per lane of the wave, DPP moves / scans, readlane, readfirstlane and ballot exchanged through the wave's slots (see
 // hip/hip_runtime.h), against a plain restatement of SURVEY A.10 ONE_SIDED (rows = query, one cell at a time in row-major order, y-drop
 // against the running best, ties diag > D > I, extension wins gap ties): best cell, cells and rows counted, and the alignment read back
-// from the kernel's 4-bit trace codes through its row records.  Also a side cut in two pieces: the second continues from the first
+// from the kernel's 4-bit trace codes through its row records; the same through the four-wave kernel body with the LDS ring
+// (mb_ydrop_lds.h).  Also a side cut in two pieces: the second continues from the first
 // one's exit snapshot and must end where the whole side ends; the relay hand-over check (mb_verify.h) on the states the evaluator
 // writes; and the traceback kernels (mb_trace.h: walkers, predicted joins, stitch) over those chains of pieces.  Nothing of this is shipped or measured.
 //   emu_ydrop <seed> <n_cases>      exit status 0 iff every case is identical
@@ -57,6 +58,24 @@ inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 using std::max;
 using std::min;
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+inline int2 make_int2(int x, int y) { int2 v; v.x = x; v.y = y; return v; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline long long clock64() { return 0; }
+template <typename T>
+inline T __shfl_down(T v, int o) {                                    // lane l <- lane l + o (its own value beyond the wave's end)
+    static_assert(sizeof(T) <= 8, "exchange slot is 8 bytes");
+    const unsigned lane = emu::t_threadIdx.x & 63;
+    unsigned long long raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    emu_xchg_begin(raw);
+    raw = emu_slot(lane + (unsigned)o < 64 ? lane + (unsigned)o : lane);
+    emu_xchg_end();
+    T out;
+    memcpy(&out, &raw, sizeof(T));
+    return out;
+}
 
 namespace mb {
 typedef const uint8_t *gbytes;
@@ -96,6 +115,26 @@ inline uint32_t row_score_lut(unsigned bq) {
     for (int k = 0; k < 4; k++) v |= (uint32_t)((b < 4 ? hox[k][b] : -100) + 128) << (8 * k);
     return v;
 }
+inline int lut_score(uint32_t lut, unsigned at) {
+    const unsigned a = at & 7u;
+    const int v = (int)((lut >> ((a & 3u) * 8u)) & 0xFFu) - 128;
+    return (a & 4u) ? -100 : v;
+}
+inline unsigned long long dpp_scan_max64(unsigned long long v) {      // inclusive prefix max over the wave (unsigned keys)
+    const unsigned lane = emu::t_threadIdx.x & 63;
+    emu_xchg_begin(v);
+    unsigned long long m = v;
+    for (unsigned l = 0; l < lane; l++) m = std::max(m, emu_slot(l));
+    emu_xchg_end();
+    return m;
+}
+inline unsigned long long dpp_shr1_64(unsigned long long v, unsigned long long fill) {
+    const unsigned lane = emu::t_threadIdx.x & 63;
+    emu_xchg_begin(v);
+    const unsigned long long o = lane ? emu_slot(lane - 1) : fill;
+    emu_xchg_end();
+    return o;
+}
 #include "mb_ydrop2.h"
 }  // namespace mb
 // (block-wide OR of a predicate: every work-item publishes its flag, all read all)
@@ -115,6 +154,19 @@ inline unsigned long long __ballot(bool p) { return yd_ballot(p); }
 namespace mb {
 #include "mb_trace.h"
 #include "mb_verify.h"
+#include "mb_ydrop_lds.h"
+// (the kernel proper: k_ydrop<false, false, false> of mb_kernels.hip -- the LDS ring, no walls)
+void k_ydrop_lds_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena, unsigned long long arena_bytes,
+                     unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps) {
+    const int pi = (int)blockIdx.x;
+    if (pi >= n) return;
+    const DpProb pr = probs[pi];
+    const PairPtrs pp = pairs[pr.pad0];
+    static YdShared sh;
+    static int2 sCD[kLdsRowCap];
+    static uint8_t sT[kLdsRowCap];
+    ydrop_body<false, false, false>(pr, &outs[pi], pp.tc, pr.strand ? pp.qr : pp.qf, O, E, Y, sCD, sT, kLdsRowCap, &sh, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+}
 // (the kernel proper: the __global__ wrapper of mb_kernels.hip)
 void k_ydrop2_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, const int O, const int E, const int Y, uint8_t *arena,
                   const unsigned long long arena_bytes, unsigned long long *arena_next, const unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps,
@@ -358,9 +410,33 @@ int main(int argc, char **argv) {
             if (!exact) bad++;
             continue;
         }
-        for (int mode = 0; mode < 2 && ok; mode++) {
+        for (int mode = 0; mode < 3 && ok; mode++) {
+            if (mode == 2) {
+                // the four-wave kernel body with the previous row in an LDS ring (mb_ydrop_lds.h: the rerun of rows that outgrow the one-wave
+                // kernels): the whole side, same format of trace and row records
+                std::fill(arena.begin(), arena.begin() + (64 << 20), (uint8_t)0xEE);
+                std::vector<mb::DpProb> probs(1);
+                std::vector<mb::DpOut> outs(1);
+                std::vector<unsigned long long> rowdir(64, ~0ull);
+                std::vector<uint8_t> snaps((size_t)mb::kSnapSlots * mb::kSnapBytes, 0x5A);
+                unsigned long long arena_next = 0;
+                memset(probs.data(), 0, sizeof(mb::DpProb)); memset(outs.data(), 0xAA, sizeof(mb::DpOut));
+                mb::DpProb &a = probs[0];
+                a.t0 = (int32_t)t0; a.q0 = (int32_t)q0; a.na = (int32_t)na; a.nb = (int32_t)nb; a.dir = dir; a.row_lo = 0; a.row_off = 0;
+                a.stop_row = -1; a.snap_row = -1; a.init_snap = -1; a.snap_idx = -1; a.snap_row2 = -1; a.snap_row3 = -1;
+                hipLaunchKernelGGL(mb::k_ydrop_lds_emu, dim3(1), dim3(256), 0, nullptr, probs.data(), outs.data(), 1, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next, 64u << 10,
+                                   rowdir.data(), snaps.data());
+                const mb::DpOut &fin = outs[0];
+                if (fin.overflow) { ok = false; why = "overflow (LDS kernel)"; break; }
+                if (fin.best != want.best || fin.bi != want.bi || fin.bj != want.bj) { ok = false; why = "best cell (LDS kernel)"; break; }
+                if (fin.cells != want.cells || fin.rows != want.rows) { ok = false; why = "cells / rows (LDS kernel)"; break; }
+                std::vector<uint8_t> ops;
+                std::vector<PieceRows> chain{{0, 0}};
+                if (!walk_trace(arena.data(), rowdir.data(), chain, fin.bi, fin.bj, ops) || ops != want.ops) { ok = false; why = "trace (LDS kernel)"; }
+                break;
+            }
             const int cut = mode == 0 ? 0 : (int)std::max<long long>(1, std::min<long long>(want.rows - 2, 20 + rnd(80)));
-            if (mode == 1 && want.rows < 8) break;
+            if (mode == 1 && want.rows < 8) continue;
             std::fill(arena.begin(), arena.begin() + (64 << 20), (uint8_t)0xEE);
             std::vector<mb::DpProb> probs(2);
             std::vector<mb::DpOut> outs(2);

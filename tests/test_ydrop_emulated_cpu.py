@@ -4,7 +4,8 @@ and ballot exchanged through the wave's slots -- and compared with a plain resta
 row-major order): best cell, cells and rows counted, and the alignment read back from the kernel's 4-bit trace codes through its row records;
 forward and backward sides that run into the contig ends, Cactus's y-drops (3000: rows inside the first 256 columns; 9400: rows that need
 the second group), an N, soft-masked bases; and every side once more cut in two pieces, the second continuing from the first one's exit
-snapshot (the relay / continuation format of the gapped stage); and the relay hand-over check k_verify (mb_verify.h) on the states the
+snapshot (the relay / continuation format of the gapped stage); the same sides through the four-wave kernel body with the previous row
+in an LDS ring (mb_ydrop_lds.h: where rows go that outgrow the one-wave kernel); and the relay hand-over check k_verify (mb_verify.h) on the states the
 evaluator writes: entry and exit state after the same row are equal, a state moved by one constant and by whole columns / rows is accepted
 under the job's offsets, a changed live C or reachable D is rejected, a D that can never matter again may differ; and the traceback kernels (mb_trace.h: a walker per piece, join walks from predicted entries --
 every other prediction made wrong on purpose in a second pass --, the stitch) over those chains of pieces give the rule's alignment op for
