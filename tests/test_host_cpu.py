@@ -285,3 +285,14 @@ def test_chunk_scale_workloads_are_the_ones_the_oracle_digests_were_made_from():
         files = chunking.fasta_chunk(src, os.path.join(d, "chunks"), 1000, 100)
         names_files = [[l[1:].strip() for l in open(f) if l.startswith(">")] for f in files]
     assert names_files == [[n for n, _ in f] for f in workloads.chunk_records(recs, 1000, 100)]
+
+
+def test_env_table_is_the_one_the_code_gives():
+    """ENV.md ("one documented table generated from the code") is scripts/env_table.py's output for the sources
+    as they are: a switch added or moved without regenerating the table fails here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "env_table.py")], capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == open(os.path.join(root, "ENV.md")).read(), "run: python scripts/env_table.py > ENV.md"
