@@ -2,7 +2,9 @@
 """Host code under AddressSanitizer + UndefinedBehaviorSanitizer (no GPU involved): the text tools (mp_text.cpp, bin/faffy's main), the PAF
 reader and the chaining stage's host orchestration with its kernels emulated (tests/emu), the FASTA parser (mb_seq.cpp).  Builds the
 instrumented binaries under a temporary directory and drives them with random, mutated and malformed input: every run must end with a
-result or a refusal -- never with a sanitizer report or a signal.   python scripts/host_sanitize.py [n_rounds]"""
+result or a refusal -- never with a sanitizer report or a signal.  --kernels: also the kernels' own sources under the host emulation
+(DP evaluator, LDS body, hand-over check, traceback, ungapped kernels, both seed stages, set kernels), instrumented the same way.
+   python scripts/host_sanitize.py [n_rounds] [--kernels]"""
 import os, random, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +25,7 @@ def reported(p):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200
     random.seed(3)
     bad = 0
     with tempfile.TemporaryDirectory() as d:
@@ -111,6 +113,20 @@ int main() {
                     print("faffy extract", p.stderr.decode()[:800]); bad += 1
                 ex.append(p.stdout)
             bad += ex[0] != ex[1]
+        # ---- the kernels' own sources under the host emulation (tests/emu), instrumented: out-of-bounds accesses of the rings, planes, snapshots
+        #      and trace blocks, shifts and overflows (unaligned 4- and 8-byte loads are meant: -fno-sanitize=alignment)
+        if "--kernels" in sys.argv:
+            for name, runs in (("emu_ydrop", (["3", "2"], ["5", "3", "relay"])), ("emu_ungapped", (["3", "2", "ux"], ["9", "2", "lane"], ["5", "2"])), ("emu_seed_dense", (["7", "6"],)),
+                               ("emu_seed_batch", (["11", "2"],)), ("emu_sets", (["5", "20"],))):
+                exe = os.path.join(d, name)
+                p = sh(["g++", *FLAGS, "-fno-sanitize=alignment", "-Wno-attributes", "-o", exe, os.path.join(EMU, name + ".cpp"), os.path.join(EMU, "emu_launch.cpp")])
+                if p.returncode:
+                    print(p.stderr.decode()[-2000:]); return 1
+                for args in runs:
+                    p = sh([exe, *args])
+                    if p.returncode or reported(p) or b"MISMATCH" in p.stdout:
+                        print(name, args, p.stdout.decode()[-600:], p.stderr.decode()[:1500]); bad += 1
+                print(name, "instrumented: ok" if not bad else "instrumented: see above")
     print("host_sanitize: %d problem(s)" % bad)
     return 1 if bad else 0
 

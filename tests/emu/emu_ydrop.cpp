@@ -58,6 +58,7 @@ inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 using std::max;
 using std::min;
+static int score_of(unsigned a, unsigned b);
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 inline int2 make_int2(int x, int y) { int2 v; v.x = x; v.y = y; return v; }
@@ -109,10 +110,9 @@ inline int uni(int v) { return yd_readlane(v, 0); }                    // readfi
 inline unsigned long long uni64(unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)(unsigned)v); }
 // per-row packed score table (mb_kernels.hip): byte k = HOXD70[k][bq] + 128 for k = A, C, G, T; N scores -100
 inline uint32_t row_score_lut(unsigned bq) {
-    static const int hox[4][4] = {{91, -114, -31, -123}, {-114, 100, -125, -31}, {-31, -125, 100, -114}, {-123, -31, -114, 91}};
     const unsigned b = bq & 7u;
     uint32_t v = 0;
-    for (int k = 0; k < 4; k++) v |= (uint32_t)((b < 4 ? hox[k][b] : -100) + 128) << (8 * k);
+    for (unsigned k = 0; k < 4; k++) v |= (uint32_t)(score_of(k, b) + 128) << (8 * k);      // (score_of: the rule's own table, below)
     return v;
 }
 inline int lut_score(uint32_t lut, unsigned at) {
@@ -464,7 +464,10 @@ int main(int argc, char **argv) {
                 if (fin.overflow) { ok = false; why = "overflow (second piece)"; break; }
                 chain.push_back({8, cut});
             }
-            if (fin.best != want.best || fin.bi != want.bi || fin.bj != want.bj) { ok = false; why = "best cell"; break; }
+            if (fin.best != want.best || fin.bi != want.bi || fin.bj != want.bj) {
+                if (getenv("EMU_YDROP_DEBUG")) fprintf(stderr, "mode %d: got best %d at (%d, %d), %lld cells, %d rows; want %d at (%d, %d)\n", mode, fin.best, fin.bi, fin.bj, (long long)fin.cells, fin.rows, want.best, want.bi, want.bj);
+                ok = false; why = "best cell"; break;
+            }
             if (fin.cells != want.cells || fin.rows != want.rows) { ok = false; why = "cells / rows"; break; }
             std::vector<uint8_t> ops;
             if (!walk_trace(arena.data(), rowdir.data(), chain, fin.bi, fin.bj, ops) || ops != want.ops) { ok = false; why = "trace"; break; }
