@@ -3,7 +3,7 @@
 // HOST -- one pthread per work-item, DPP / ballot exchanged through per-wave barriers (see hip/hip_runtime.h) -- against a
 // sequential restatement of the rule (oracle/lastz_oracle.c:227-262, :508-521) on random sequence sets with planted homology,
 // separators, N bases and busy diagonals.  Nothing of this is shipped or measured.
-//   emu_ungapped <seed> <n_cases> [lane|ux]     exit status 0 iff every case is identical (HSP records, extent[], counters)
+//   emu_ungapped <seed> <n_cases> [lane|ux|h16]     exit status 0 iff every case is identical (HSP records, extent[], counters)
 #define MB_EMU 1
 #include <hip/hip_runtime.h>
 #undef __launch_bounds__
@@ -125,6 +125,8 @@ inline int dpp_scan_max(int v) { return emu_scan<true>(v); }
 #include "mb_ungapped_lane.h"
 #include "mb_ungapped_grp.h"
 #include "mb_ungapped_ux.h"
+#include "mb_seedword.h"
+#include "mb_hash16.h"
 }  // namespace mb
 
 // ---- the rule, sequentially ----------------------------------------------------------------------------------------
@@ -135,7 +137,7 @@ static int score_of(unsigned a, unsigned b) {
     return hox[x][y];
 }
 
-struct Ref { std::vector<mb::DevHsp> hsps; std::vector<int32_t> extent; unsigned long long extended = 0, cols = 0; };
+struct Ref { std::vector<mb::DevHsp> hsps; std::vector<int32_t> extent; unsigned long long extended = 0, cols = 0, crossed = 0; };
 
 static void reference(const std::vector<unsigned long long> &keys, const uint8_t *tc, const uint8_t *qc, int64_t qtot, int xdrop, int K,
                       int /* long_run: the long runs are k_ungapped_long's, the rule is one */, Ref &out) {
@@ -181,6 +183,52 @@ static void reference(const std::vector<unsigned long long> &keys, const uint8_t
     }
 }
 
+// the rule with lastz's 16-bit diagonal hash (oracle/lastz_oracle.c, diag_hash16): one extent per (t_end - q_end) & 0xFFFF, the hits in
+// the order the search generates them -- q_end ascending, then the word variant's rank, then the target position descending
+static void reference_h16(const std::vector<unsigned long long> &keys, const uint8_t *tc, const uint8_t *qc, int64_t qtot, int xdrop, int K, Ref &out) {
+    struct H { int32_t q_end; int rank; int64_t t_end; };
+    std::vector<H> hits;
+    for (unsigned long long k : keys) {
+        const int32_t q_end = (int32_t)(uint32_t)k;
+        const int64_t t_end = (int64_t)(uint32_t)(k >> 32) - qtot + q_end;
+        hits.push_back({q_end, mb::h16_variant_rank(tc, qc, t_end, q_end), t_end});
+    }
+    std::stable_sort(hits.begin(), hits.end(), [](const H &a, const H &b) { return a.q_end != b.q_end ? a.q_end < b.q_end : a.rank != b.rank ? a.rank < b.rank : a.t_end > b.t_end; });
+    std::vector<int32_t> ext16(65536, 0);
+    std::vector<int64_t> by16(65536, 0);                                 // the diagonal whose extension a class's extent comes from
+    for (const H &h : hits) {
+        int32_t &ext = ext16[(size_t)((h.t_end - h.q_end) & 0xFFFF)];
+        if (h.q_end <= ext) { out.crossed += by16[(size_t)((h.t_end - h.q_end) & 0xFFFF)] != h.t_end - h.q_end; continue; }
+        by16[(size_t)((h.t_end - h.q_end) & 0xFFFF)] = h.t_end - h.q_end;
+        const int64_t t_end = h.t_end; const int32_t q_end = h.q_end;
+        int run = 0, bestL = 0, bestR = 0, bl = 0, br = 0;
+        for (int k = 1;; k++) {
+            const unsigned a = tc[t_end - k], b = qc[q_end - k];
+            if (a == mb::kSep || b == mb::kSep) break;
+            run += score_of(a, b); out.cols++;
+            if (run > bestL) { bestL = run; bl = k; } else if (run < bestL - xdrop) break;
+        }
+        run = 0;
+        for (int k = 0;; k++) {
+            const unsigned a = tc[t_end + k], b = qc[q_end + k];
+            if (a == mb::kSep || b == mb::kSep) break;
+            run += score_of(a, b); out.cols++;
+            if (run > bestR) { bestR = run; br = k + 1; } else if (run < bestR - xdrop) break;
+        }
+        out.extended++;
+        ext = q_end + br;
+        if (bestL + bestR >= K) {
+            mb::DevHsp hs;
+            hs.anchor_off = 0; hs.unit = 0;
+            hs.t_start = (int32_t)(t_end - bl); hs.q_start = q_end - bl; hs.len = bl + br; hs.score = bestL + bestR;
+            hs.seed_t_end = (int32_t)t_end; hs.seed_q_end = q_end;
+            for (int c = 0; c < 4; c++) hs.cnt[c] = 0;
+            for (int c = 0; c < hs.len; c++) { const unsigned a = tc[hs.t_start + c] & 7u, b = qc[hs.q_start + c] & 7u; if (a < 4 && a == b) hs.cnt[a]++; }
+            out.hsps.push_back(hs);
+        }
+    }
+}
+
 // the anchor rule of SURVEY A.6, column by column: middle of the best-scoring 31-column window, first on ties
 static int anchor_ref(const mb::DevHsp &h, const uint8_t *tc, const uint8_t *qc) {
     if (h.len <= 31) return h.len / 2;
@@ -204,6 +252,7 @@ int main(int argc, char **argv) {
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
     const bool use_ux = argc > 3 && !strcmp(argv[3], "ux");             // the level-synchronous pipeline instead of k_ungapped_grp
     const bool use_lane = argc > 3 && !strcmp(argv[3], "lane");         // the run-per-lane kernel k_ungapped
+    const bool use_h16 = argc > 3 && !strcmp(argv[3], "h16");           // lastz's 16-bit diagonal hash (mb_hash16.h): every hit extended, the rule per hash class
     int bad = 0;
     for (int cs = 0; cs < n_cases; cs++) {
         std::mt19937 rng(seed0 * 7919u + (unsigned)cs);
@@ -213,13 +262,13 @@ int main(int argc, char **argv) {
         const int xdrop = cs % 3 == 0 ? 910 : cs % 3 == 1 ? 300 + rnd(400) : 1500 + rnd(3000);
         const int K = cs % 2 ? 3000 : 400 + rnd(1500);
         const int long_run = 6 + rnd(27);
-        const bool extent_clean = cs % 2 == 0;                              // (odd cases: extents left by an earlier q batch)
+        const bool extent_clean = use_h16 || cs % 2 == 0;                   // (odd cases: extents left by an earlier q batch)
         struct Unit { int64_t tn, qn; std::vector<uint8_t> tb, qb; uint8_t *tc, *qc; uint32_t dbase; std::vector<unsigned long long> keys; Ref ref; };
         std::vector<Unit> units((size_t)n_units);
         std::vector<unsigned long long> keys;
         uint32_t dnext = 0;
         for (Unit &u : units) {
-            const int64_t tn = u.tn = (n_units > 1 ? 1500 : 3000) + rnd(6000), qn = u.qn = (n_units > 1 ? 1500 : 3000) + rnd(6000);
+            const int64_t tn = u.tn = use_h16 ? 70000 + rnd(30000) : (n_units > 1 ? 1500 : 3000) + rnd(6000), qn = u.qn = (n_units > 1 ? 1500 : 3000) + rnd(6000);      // (h16: target positions 65536 apart exist)
             u.tb.assign((size_t)tn + 2 * mb::kDevPad + 8, mb::kSep); u.qb.assign((size_t)qn + 2 * mb::kDevPad + 8, mb::kSep);
             uint8_t *tc = u.tc = u.tb.data() + mb::kDevPad, *qc = u.qc = u.qb.data() + mb::kDevPad;
             u.dbase = dnext; dnext += (uint32_t)(tn + qn + 2);
@@ -248,6 +297,12 @@ int main(int argc, char **argv) {
             for (int h = 0, nhh = 300 + rnd(1200); h < nhh; h++) add(1 + rnd((int)tn), 1 + rnd((int)qn));
             for (auto &ds : diag_seeds) add(ds.first, ds.second);
             { const int64_t d0 = rnd((int)tn / 2); for (int h = 0, nhh = rnd(40); h < nhh; h++) { const int q = 1 + rnd((int)std::min(qn, tn - d0) - 1); add(d0 + q, q); } }
+            if (use_h16)                                                 // pairs of hits on diagonals 65536 apart: one hash class, the first one's extension may drop the second
+                for (int h = 0; h < 80; h++) {
+                    const int64_t q = 20 + rnd((int)qn - 60), t = 1 + rnd((int)(tn - 65536 - 1));
+                    add(t, q);
+                    add(t + 65536, q + rnd(30));                         // same hash class, a little further along: inside the first one's extension or not
+                }
             std::sort(u.keys.begin(), u.keys.end());
             u.keys.erase(std::unique(u.keys.begin(), u.keys.end()), u.keys.end());
             u.ref.extent.assign((size_t)(tn + qn + 2), 0);
@@ -271,7 +326,8 @@ int main(int argc, char **argv) {
         std::vector<int32_t> extent0((size_t)ndiag, 0);
         for (Unit &u : units) {
             std::copy(u.ref.extent.begin(), u.ref.extent.end(), extent0.begin() + (long)u.dbase);
-            reference(u.keys, u.tc, u.qc, u.qn, xdrop, K, long_run, u.ref);
+            if (use_h16) reference_h16(u.keys, u.tc, u.qc, u.qn, xdrop, K, u.ref);
+            else reference(u.keys, u.tc, u.qc, u.qn, xdrop, K, long_run, u.ref);
         }
         std::vector<mb::SeedUnit> tab((size_t)n_units);
         for (int x = 0; x < n_units; x++) {
@@ -318,7 +374,7 @@ int main(int argc, char **argv) {
         if (use_lane) {
             hipLaunchKernelGGL(mb::k_ungapped, dim3((unsigned)((n_hits + 255) / 256 + mb::kRunClasses)), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, ut,
                                extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), ctr);
-        } else if (!use_ux) {
+        } else if (!use_ux && !use_h16) {
             hipLaunchKernelGGL(mb::k_ungapped_grp<5>, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data(), n_heads, ut,
                                extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), ctr);
         } else {
@@ -335,19 +391,40 @@ int main(int argc, char **argv) {
             std::vector<unsigned> dirty_runs((size_t)n_hits + 1);
             sc.dirty_runs = dirty_runs.data(); sc.dirty_cap = (unsigned)n_hits; sc.extent = extent.data(); sc.extent_live = extent_clean ? 0 : 1;
             const unsigned *heads_long = heads.data() + (n + n / 2 + n / 4 + n / 8 + 8);
-            hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, sc);
+            if (use_h16) sc.extent_live = 0;
+            if (!use_h16) hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, sc);
             hipLaunchKernelGGL(mb::k_ux_extend, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc,
                                hsps.data(), (int64_t)hsps.size(), ctr);
             hipLaunchKernelGGL(mb::k_ux_tail, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc, hsps.data(), (int64_t)hsps.size(), ctr);
+            if (use_h16) {
+                // launch_ungapped_hash16 (mb_kernels.hip): target position descending, then (unit | hash class | q_end | variant rank), both stable;
+                // one lane per class applies the rule to the records
+                std::vector<unsigned long long> k2((size_t)n_hits), k1((size_t)n_hits);
+                std::vector<uint32_t> val((size_t)n_hits);
+                const unsigned nb = (unsigned)((n_hits + 255) / 256);
+                hipLaunchKernelGGL(mb::k_h16_tkeys, dim3(nb), dim3(256), 0, nullptr, keys.data(), n_hits, ut, k2.data(), val.data());
+                { std::vector<uint32_t> o(val); std::stable_sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) { return (k2[a] & 0x7FFFFFFFull) < (k2[b] & 0x7FFFFFFFull); }); val = o; }      // (val[i] = i before the sort)
+                hipLaunchKernelGGL(mb::k_h16_ckeys, dim3(nb), dim3(256), 0, nullptr, keys.data(), n_hits, ut, val.data(), k1.data());
+                {
+                    std::vector<size_t> ord((size_t)n_hits);
+                    for (size_t x = 0; x < ord.size(); x++) ord[x] = x;
+                    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return k1[a] < k1[b]; });
+                    std::vector<unsigned long long> k1s((size_t)n_hits); std::vector<uint32_t> vs((size_t)n_hits);
+                    for (size_t x = 0; x < ord.size(); x++) { k1s[x] = k1[ord[x]]; vs[x] = val[ord[x]]; }
+                    k1 = k1s; val = vs;
+                }
+                hipLaunchKernelGGL(mb::k_h16_resolve, dim3(nb), dim3(256), 0, nullptr, k1.data(), val.data(), n_hits, sc.rec, hsps.data(), ctr);
+            } else {
             // (few blocks: a block's stretch of the sorted hits then spans several units)
             hipLaunchKernelGGL(mb::k_ux_accept, dim3(cs % 2 ? 1u + (unsigned)rnd(2) : (unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, ut, extent.data(), sc, hsps.data(), ctr);
             hipLaunchKernelGGL(mb::k_ux_resolve, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, ut, extent.data(), sc, hsps.data(), ctr);
             { size_t nd = 0; for (uint32_t w : dirty) nd += (size_t)__builtin_popcount(w); printf("  ux: %zu dirty diagonals\n", nd); }
+            }
             hipLaunchKernelGGL(mb::k_ux_census, dim3(1), dim3(256), 0, nullptr, ut, hsps.data(), (int64_t)hsps.size(), ctr);
             { unsigned nb = 0; for (unsigned v : blk_cnt) nb += v; printf("  ux: %u + %u of %lld hits left for the tail (block slots + list), %llu candidates, %u dirty runs\n", nb, n_entries[0], (long long)n_hits, ctr[0].hsps, n_entries[1]); }
         }
         // the long runs, whichever kernel took the short ones: a wave per run and turn, the grid's waves striding over the list
-        hipLaunchKernelGGL(mb::k_ungapped_long, dim3(1u + (unsigned)rnd(2)), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data() + (n + n / 2 + n / 4 + n / 8 + 8), n_heads + 4, ut,
+        if (!use_h16) hipLaunchKernelGGL(mb::k_ungapped_long, dim3(1u + (unsigned)rnd(2)), dim3(256), 0, nullptr, keys.data(), n_hits, heads.data() + (n + n / 2 + n / 4 + n / 8 + 8), n_heads + 4, ut,
                            extent.data(), xdrop, K, hsps.data(), (int64_t)hsps.size(), ctr);
         hipLaunchKernelGGL(mb::k_hsp_anchor, dim3(1), dim3(256), 0, nullptr, ut, hsps.data(), (int64_t)hsps.size(), ctr);
         hsps.resize((size_t)ctr[0].hsps);
@@ -382,6 +459,7 @@ int main(int argc, char **argv) {
                     if (ext[d] != u.ref.extent[d]) { printf("  first differing extent: diagonal %zu got %d want %d\n", d, ext[d], u.ref.extent[d]); break; }
             }
         }
+        if (use_h16) { unsigned long long cr = 0; for (Unit &u : units) cr += u.ref.crossed; printf("  h16: %llu hits dropped by an extension on ANOTHER diagonal of their hash class\n", cr); }
         printf("case %d: %d unit(s) hits %lld runs %u + %u long (> %d hits) xdrop %d K %d  hsps %zu/%zu  %s\n", cs, n_units, (long long)n_hits,
                n_heads[0] + n_heads[1] + n_heads[2] + n_heads[3], n_heads[4], long_run, xdrop, K, total_hsps, total_ref, all_ok ? "ok" : "MISMATCH");
         if (!all_ok) bad++;

@@ -1,7 +1,8 @@
 """Ungapped extension kernels without a GPU: the product's own kernel sources (cactus_amd/csrc/mb_runs.h -- run heads, anchors of the
 HSPs --, mb_ungapped_lane.h -- a diagonal run per lane, and the wave-per-run kernel every choice hands the busy diagonals to --,
 mb_ungapped_grp.h -- eight lanes per diagonal run -- and mb_ungapped_ux.h -- the level-synchronous pipeline for dense hit
-sets) built for the host against the stand-in
+sets --, mb_hash16.h -- lastz's 16-bit diagonal hash as a mode: every hit extended, the rule per hash class in generation order, on targets long
+enough for diagonals 65536 apart to share a class) built for the host against the stand-in
 HIP header of tests/emu (one pthread per work-item; DPP, ballot and readlane exchanged through per-wave barriers) and compared with
 a sequential restatement of the rule of oracle/lastz_oracle.c:227-262, :508-521 (suppression per diagonal, x-drop both ways,
 counters, extent[], HSP records, run-head lists, anchor offsets) on random sequence sets with planted homology, separators, N bases, busy diagonals, extents left
@@ -22,9 +23,9 @@ def built():
     subprocess.run(["make", "-C", EMU_DIR, "emu_ungapped"], check=True, capture_output=True)
 
 
-@pytest.mark.parametrize("mode,seed,cases", [("grp", 5, 2), ("ux", 7, 3), ("ux", 8, 2), ("lane", 9, 3)])
+@pytest.mark.parametrize("mode,seed,cases", [("grp", 5, 2), ("ux", 7, 3), ("ux", 8, 2), ("lane", 9, 3), ("h16", 4, 4)])
 def test_emulated_ungapped_kernels_match_the_sequential_rule(mode, seed, cases):
-    p = subprocess.run([EMU, str(seed), str(cases)] + ([mode] if mode in ("ux", "lane") else []), capture_output=True, timeout=900)
+    p = subprocess.run([EMU, str(seed), str(cases)] + ([mode] if mode in ("ux", "lane", "h16") else []), capture_output=True, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()
     assert out.count(" ok\n") == cases and "MISMATCH" not in out, out
