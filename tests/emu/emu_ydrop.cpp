@@ -319,7 +319,7 @@ int main(int argc, char **argv) {
         const int O = 400, E = 30;
         const int Y = cs % 4 == 0 ? 3000 : cs % 4 == 1 ? 9400 : cs % 4 == 2 ? 600 + rnd(1500) : 4000 + rnd(5000);      // (9400: rows that need the second group of columns)
         const int dir = cs % 2 ? -1 : 1;
-        const int len = 150 + rnd(250);
+        const int len = 120 + rnd(140);
         // two sequences with a common origin: substitutions, a few indels, an N, soft-masked stretches; the side runs into the contig ends
         const int64_t tn = len + rnd(60), qn = len + rnd(60);
         std::vector<uint8_t> tb((size_t)tn + 2 * mb::kDevPad + 16, mb::kSep), qb((size_t)qn + 2 * mb::kDevPad + 16, mb::kSep);
