@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <functional>
 #include <random>
 
 #include "mb_common.h"
@@ -167,6 +168,19 @@ void k_ydrop_lds_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pa
     static uint8_t sT[kLdsRowCap];
     ydrop_body<false, false, false>(pr, &outs[pi], pp.tc, pr.strand ? pp.qr : pp.qf, O, E, Y, sCD, sT, kLdsRowCap, &sh, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
 }
+// (k_ydrop<false, false, true>: the walls variant; wref = the problem's alignments [wa0, wa1))
+void k_ydrop_walls_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena, unsigned long long arena_bytes,
+                       unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps, const WallSeg *wsegs, const int2 *walns, int wa0, int wa1) {
+    const int pi = (int)blockIdx.x;
+    if (pi >= n) return;
+    const DpProb pr = probs[pi];
+    const PairPtrs pp = pairs[pr.pad0];
+    static YdShared sh;
+    static int2 sCD[kLdsRowCap];
+    static uint8_t sT[kLdsRowCap];
+    ydrop_body<false, false, true>(pr, &outs[pi], pp.tc, pr.strand ? pp.qr : pp.qf, O, E, Y, sCD, sT, kLdsRowCap, &sh, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, wsegs,
+                                   walns, wa0, wa1);
+}
 // (the kernel proper: the __global__ wrapper of mb_kernels.hip)
 void k_ydrop2_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, const int O, const int E, const int Y, uint8_t *arena,
                   const unsigned long long arena_bytes, unsigned long long *arena_next, const unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps,
@@ -184,7 +198,10 @@ static int score_of(unsigned a, unsigned b) {
 }
 struct Side { int best = 0, bi = 0, bj = 0; long long cells = 0, rows = 0; std::vector<uint8_t> ops; };
 
-static Side one_sided(const uint8_t *tc, const uint8_t *qc, int64_t t0, int64_t q0, int dir, int64_t na, int64_t nb, int O, int E, int Y) {
+// wall: (target position, query position) -> the pair lies on the path of an earlier alignment (SURVEY A.7 with the walls switch: such a
+// cell is dead and no gap state survives it)
+static Side one_sided(const uint8_t *tc, const uint8_t *qc, int64_t t0, int64_t q0, int dir, int64_t na, int64_t nb, int O, int E, int Y,
+                      const std::function<bool(int64_t, int64_t)> *wall = nullptr) {
     const int NEG = -(1 << 29);
     Side r;
     std::vector<int> Cp((size_t)na + 4, NEG), Dp((size_t)na + 4, NEG), Cc((size_t)na + 4, NEG), Dc((size_t)na + 4, NEG);
@@ -211,8 +228,10 @@ static Side one_sided(const uint8_t *tc, const uint8_t *qc, int64_t t0, int64_t 
             int Cv; uint8_t src;
             if (diag >= Dv && diag >= Iv) { Cv = diag; src = 0; } else if (Dv >= Iv) { Cv = Dv; src = 1; } else { Cv = Iv; src = 2; }
             r.cells++;
+            const bool blocked = wall && j >= 1 && (*wall)(dir > 0 ? t0 + j - 1 : t0 - j, dir > 0 ? q0 + i - 1 : q0 - i);
+            if (blocked) { Cv = NEG; Dv = NEG; Iv = NEG; }
             if (Cv > best) { best = Cv; bi = i; bj = j; }
-            const bool alive = Cv >= best - Y;
+            const bool alive = !blocked && Cv >= best - Y;
             if (!alive) Cv = NEG;
             Cc[(size_t)j] = Cv; Dc[(size_t)j] = Dv; Cleft = Cv;
             tr.push_back((uint8_t)(src | (Dext ? 4 : 0) | (Iext ? 8 : 0)));
@@ -310,7 +329,7 @@ int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
     const bool relay_mode = argc > 3 && !strcmp(argv[3], "relay");      // the exactness of an accepted relay hand-over instead of the cut / check tests
-    int bad = 0, relays_accepted = 0, relays_tried = 0;
+    int bad = 0, relays_accepted = 0, relays_tried = 0, n_wall_cases = 0, n_wall_changed = 0;
     const unsigned long long arena_bytes = 96ull << 20;
     std::vector<uint8_t> arena((size_t)arena_bytes);
     for (int cs = 0; cs < n_cases; cs++) {
@@ -477,6 +496,61 @@ int main(int argc, char **argv) {
             for (int poison = 0; poison < 2 && ok; poison++)
                 if (!trace_kernels(arena.data(), arena_bytes, rowdir.data(), cps, fin.bi, fin.bj, poison, ops) || ops != want.ops) { ok = false; why = "traceback kernels"; }
         }
+        // ---- walls (miblast_params.walls; the WALLS variant of the LDS body): earlier alignments = stretches of this side's own path moved a few
+        //      columns aside, so that the DP has to run along them, across their gaps and around their ends
+        if (ok && !relay_mode && want.ops.size() > 60) {
+            std::vector<std::pair<int64_t, int64_t>> cells;                // (q, t) of the side's aligned pairs, absolute
+            { int i = 0, j = 0; for (size_t k = want.ops.size(); k-- > 0;) { const uint8_t o = want.ops[k]; if (o == 0) { i++; j++; cells.push_back({dir > 0 ? q0 + i - 1 : q0 - i, dir > 0 ? t0 + j - 1 : t0 - j}); } else if (o == 2) i++; else j++; } }
+            std::vector<mb::WallSeg> wsegs;
+            std::vector<int2> walns;
+            std::vector<std::vector<std::pair<int64_t, int64_t>>> wall_cells;
+            const int n_walls = 1 + rnd(3);
+            for (int a = 0; a < n_walls; a++) {
+                const size_t c0 = (size_t)rnd((int)cells.size() / 2), c1 = std::min(cells.size(), c0 + 20 + (size_t)rnd((int)cells.size() / 2));
+                const int shift = (rnd(2) ? 1 : -1) * (1 + rnd(6));
+                std::vector<std::pair<int64_t, int64_t>> w;
+                for (size_t k = c0; k < c1; k++) { const int64_t t = cells[k].second + shift; if (t >= 0 && t < tn) w.push_back({cells[k].first, t}); }
+                std::sort(w.begin(), w.end());
+                const int first = (int)wsegs.size();
+                for (size_t k = 0; k < w.size();) {                      // gap-free runs, q ascending
+                    size_t e = k + 1;
+                    while (e < w.size() && w[e].first == w[e - 1].first + 1 && w[e].second == w[e - 1].second + 1) e++;
+                    mb::WallSeg sg; sg.q0 = (int32_t)w[k].first; sg.t0 = (int32_t)w[k].second; sg.len = (int32_t)(e - k);
+                    wsegs.push_back(sg);
+                    k = e;
+                }
+                int2 al; al.x = first; al.y = (int)wsegs.size();
+                walns.push_back(al);
+                wall_cells.push_back(w);
+            }
+            const std::function<bool(int64_t, int64_t)> wall = [&](int64_t t, int64_t q) {
+                for (const auto &w : wall_cells) if (std::binary_search(w.begin(), w.end(), std::make_pair(q, t))) return true;
+                return false;
+            };
+            const Side ww = one_sided(tc, qc, t0, q0, dir, na, nb, O, E, Y, &wall);
+            std::fill(arena.begin(), arena.begin() + (64 << 20), (uint8_t)0xEE);
+            std::vector<mb::DpProb> probs(1);
+            std::vector<mb::DpOut> outs(1);
+            std::vector<unsigned long long> rowdir(64, ~0ull);
+            std::vector<uint8_t> snaps((size_t)mb::kSnapSlots * mb::kSnapBytes, 0x5A);
+            unsigned long long arena_next = 0;
+            memset(probs.data(), 0, sizeof(mb::DpProb)); memset(outs.data(), 0xAA, sizeof(mb::DpOut));
+            mb::DpProb &a = probs[0];
+            a.t0 = (int32_t)t0; a.q0 = (int32_t)q0; a.na = (int32_t)na; a.nb = (int32_t)nb; a.dir = dir; a.row_lo = 0; a.row_off = 0;
+            a.stop_row = -1; a.snap_row = -1; a.init_snap = -1; a.snap_idx = -1; a.snap_row2 = -1; a.snap_row3 = -1;
+            hipLaunchKernelGGL(mb::k_ydrop_walls_emu, dim3(1), dim3(256), 0, nullptr, probs.data(), outs.data(), 1, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next, 64u << 10,
+                               rowdir.data(), snaps.data(), wsegs.data(), walns.data(), 0, (int)walns.size());
+            const mb::DpOut &fin = outs[0];
+            std::vector<uint8_t> ops;
+            std::vector<PieceRows> chain{{0, 0}};
+            if (fin.overflow || fin.best != ww.best || fin.bi != ww.bi || fin.bj != ww.bj || fin.cells != ww.cells || fin.rows != ww.rows ||
+                !walk_trace(arena.data(), rowdir.data(), chain, fin.bi, fin.bj, ops) || ops != ww.ops) {
+                if (getenv("EMU_YDROP_DEBUG")) fprintf(stderr, "walls: got best %d at (%d, %d), %lld cells, %d rows, overflow %d; want %d at (%d, %d), %lld cells, %lld rows\n", fin.best, fin.bi, fin.bj,
+                                                        (long long)fin.cells, fin.rows, fin.overflow, ww.best, ww.bi, ww.bj, ww.cells, ww.rows);
+                ok = false; why = "walls";
+            }
+            n_wall_cases++; n_wall_changed += ww.best != want.best || ww.ops != want.ops;
+        }
         // ---- the hand-over check (k_verify) on states the evaluator writes: a piece's entry snapshot after row r against the exit snapshot
         //      of the same DP stopped at r (equal: accepted, c = 0); the same state with every live value and the best moved by one
         //      constant (accepted, c = that constant) and shifted by whole columns and rows (accepted under the job's shift / drow); one
@@ -533,6 +607,7 @@ int main(int argc, char **argv) {
                want.bj, want.cells, want.rows, want.ops.size(), ok ? "ok" : "MISMATCH: ", ok ? "" : why);
         if (!ok) bad++;
     }
+    if (!relay_mode) printf("walls: %d of %d sides changed by their walls\n", n_wall_changed, n_wall_cases);
     if (relay_mode) {
         printf("relays: %d of %d accepted\n", relays_accepted, relays_tried);
         if (relays_tried && !relays_accepted) { printf("no hand-over was accepted: the test says nothing  MISMATCH\n"); bad++; }

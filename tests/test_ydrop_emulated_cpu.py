@@ -5,7 +5,8 @@ row-major order): best cell, cells and rows counted, and the alignment read back
 forward and backward sides that run into the contig ends, Cactus's y-drops (3000: rows inside the first 256 columns; 9400: rows that need
 the second group), an N, soft-masked bases; and every side once more cut in two pieces, the second continuing from the first one's exit
 snapshot (the relay / continuation format of the gapped stage); the same sides through the four-wave kernel body with the previous row
-in an LDS ring (mb_ydrop_lds.h: where rows go that outgrow the one-wave kernel); and the relay hand-over check k_verify (mb_verify.h) on the states the
+in an LDS ring (mb_ydrop_lds.h: where rows go that outgrow the one-wave kernel), also in its walls variant (miblast_params.walls: stretches of
+the side's own path moved a few columns aside as earlier alignments whose cells are dead); and the relay hand-over check k_verify (mb_verify.h) on the states the
 evaluator writes: entry and exit state after the same row are equal, a state moved by one constant and by whole columns / rows is accepted
 under the job's offsets, a changed live C or reachable D is rejected, a D that can never matter again may differ; and the traceback kernels (mb_trace.h: a walker per piece, join walks from predicted entries --
 every other prediction made wrong on purpose in a second pass --, the stitch) over those chains of pieces give the rule's alignment op for
