@@ -1,9 +1,11 @@
 // TEST INFRASTRUCTURE ONLY: runs cactus_amd/csrc/mb_seed_dense.h (packed strands, seed words from the packed form, the q-ordered
-// one-pass seed search k_seed_hits / k_seed_keys, the diagonal scramble and k_keys_unhash) on the HOST -- one pthread per work-item
+// one-pass seed search k_seed_hits / k_seed_keys, the diagonal scramble and k_keys_unhash) and mb_seed_index.h (the dense seed table through
+// its kernels -- index words, the scan of the 2^24 bucket counts with the occupancy bitmap, scatter --, the two-pass search in q batches
+// and the unordered one-pass search) on the HOST -- one pthread per work-item
 // (see hip/hip_runtime.h) -- against a plain restatement of SURVEY A.3 / A.4: the table of the target = for every word the indexed
 // positions, the hits of a strand = for every valid query window, every word variant, every position of its bucket, query position
 // by query position.  Nothing of this is shipped or measured.
-//   emu_seed_dense <seed> <n_cases>      exit status 0 iff every case is identical
+//   emu_seed_dense <seed> <n_cases> [table]      exit status 0 iff every case is identical
 #define MB_EMU 1
 #include <hip/hip_runtime.h>
 #undef __launch_bounds__
@@ -18,6 +20,17 @@
 #define __builtin_memcpy memcpy
 
 struct ulonglong2 { unsigned long long x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+static inline int emu_readlane(int v, int l) {
+    emu::Group *g = emu::g_group;
+    const unsigned tid = emu::t_threadIdx.x, w = tid >> 6;
+    g->slot[tid] = (unsigned long long)(unsigned)v;
+    pthread_barrier_wait(&g->wave[w]);
+    const int o = (int)(unsigned)g->slot[(tid & ~63u) | ((unsigned)l & 63u)];
+    pthread_barrier_wait(&g->wave[w]);
+    return o;
+}
+#define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
 
 namespace mb {
 // inclusive prefix sum over the wave (mb_kernels.hip: six DPP steps), through the per-wave exchange slots
@@ -32,12 +45,15 @@ inline int dpp_scan_add(int v) {
     return s;
 }
 #include "mb_seedword.h"
+#include "mb_seed_index.h"
 #include "mb_seed_dense.h"
 }  // namespace mb
 
 int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
+    // "table": also build the table through the kernels (the emulated scan of the 2^24 + 1 bucket counts takes minutes: 8 193 groups, three launches)
+    const bool with_table = argc > 3 && !strcmp(argv[3], "table");
     int bad = 0;
     const size_t kBuckets = (size_t)1 << 24;
     std::vector<uint32_t> offsets(kBuckets + 1), occ(kBuckets / 32), counts(kBuckets + 1);
@@ -112,6 +128,27 @@ int main(int argc, char **argv) {
             const uint32_t w = (uint32_t)rng() & 0xFFFFFFu;
             for (int v = 0; v < 13; v++) if (mb::dense_variant(mb::dense_bucket(w), v) != mb::dense_bucket(mb::variant_word(w, v))) { ok = false; why = "dense_variant"; }
         }
+        // ---- the same table through the kernels of mb_seed_index.h: words from the byte codes (= the packed ones), the three-launch scan of
+        //      the 2^24 + 1 bucket counts (offsets, occupancy bitmap, counts zeroed), the scatter; then the counters cleared
+        if (ok && with_table && cs % 3 == 0) {
+            std::vector<uint32_t> words_b((size_t)n_slots + 1, 0x55555555u), k_counts(kBuckets + 8, 0u), k_offsets(kBuckets + 8, 0xCCCCCCCCu), k_occ(kBuckets / 32, 0xCCCCCCCCu);
+            std::vector<unsigned long long> bsum((kBuckets + 1) / 2048 + 4, 0ull);
+            mb::launch_index_words(tc, tn, step, first, words_b.data(), n_slots, k_counts.data(), nullptr);
+            for (int64_t sl = 0; sl < n_slots && ok; sl++) if (words_b[(size_t)sl] != words[(size_t)sl]) { ok = false; why = "k_index_words"; }
+            mb::launch_scan_index(k_counts.data(), k_offsets.data(), bsum.data(), k_occ.data(), nullptr);
+            for (size_t b = 0; b <= kBuckets && ok; b++) if (k_offsets[b] != offsets[b]) { ok = false; why = "launch_scan_index: offsets"; }
+            for (size_t x = 0; x < kBuckets / 32 && ok; x++) if (k_occ[x] != occ[x]) { ok = false; why = "launch_scan_index: occupancy bitmap"; }
+            for (size_t b = 0; b <= kBuckets && ok; b++) if (k_counts[b] != 0u) { ok = false; why = "launch_scan_index: counts not zeroed"; }
+            std::vector<uint32_t> k_pos((size_t)run + 1, 0xFFFFFFFFu);
+            mb::launch_index_scatter(words.data(), n_slots, step, first, k_offsets.data(), k_counts.data(), k_pos.data(), nullptr);
+            for (auto &kv : table) {
+                std::vector<uint32_t> got(k_pos.begin() + offsets[kv.first], k_pos.begin() + offsets[kv.first + 1]);
+                std::sort(got.begin(), got.end());
+                if (got != kv.second) { ok = false; why = "k_index_scatter"; break; }
+            }
+            mb::launch_index_clear(words.data(), n_slots, k_counts.data(), nullptr);
+            for (auto &kv : table) if (k_counts[kv.first] != 0u) { ok = false; why = "k_index_clear"; }
+        }
         // ---- the search: k_seed_hits, the scan of the tiles' counts, k_seed_keys, k_keys_unhash
         int diag_bits = 1; while ((1ll << diag_bits) < tn + qn + 2) diag_bits++;
         const uint32_t hmask = (1u << diag_bits) - 1u, hmul = cs % 3 == 2 ? 1u : 0x9E3779B1u;
@@ -162,6 +199,44 @@ int main(int argc, char **argv) {
                 at += mine.size();
             }
             if (ok && at != total) { ok = false; why = "key count"; }
+        }
+        // ---- a strand in q batches (k_seed_count, scan, k_seed_fill per batch: the path of a strand whose hits do not fit one key buffer) and
+        //      the one-pass search without q order (k_seed_search: keys in the order the blocks get there)
+        if (ok && qn > 0) {
+            std::vector<uint32_t> qcnt((size_t)qn + 8, 0xCCCCCCCCu), hit_off((size_t)qn + 8, 0u);
+            std::vector<unsigned long long> bsum((size_t)qn / 2048 + 4, 0ull);
+            mb::launch_seed_count(qc, qn, offsets.data(), occ.data(), nvar == 13, qcnt.data(), nullptr);
+            for (int64_t q = 0; q < qn && ok; q++) if (qcnt[(size_t)q] != want_q[(size_t)q].size()) { ok = false; why = "k_seed_count"; }
+            const int64_t cuts[3] = {0, qn / 3, qn};
+            for (int bt = 0; bt < 2 && ok; bt++) {
+                const int64_t q0 = cuts[bt], q1 = cuts[bt + 1];
+                if (q1 <= q0) continue;
+                mb::launch_scan_u32(qcnt.data() + q0, hit_off.data(), q1 - q0, bsum.data(), nullptr);
+                unsigned long long n_b = 0;
+                for (int64_t q = q0; q < q1; q++) n_b += want_q[(size_t)q].size();
+                std::vector<unsigned long long> keys((size_t)n_b + 4, 0xCDCDCDCDCDCDCDCDull);
+                mb::launch_seed_fill(qc, q0, q1, qn, offsets.data(), occ.data(), positions.data(), nvar == 13, hit_off.data(), keys.data(), nullptr, hmul, hmask);
+                size_t at = 0;
+                for (int64_t q = q0; q < q1 && ok; q++) {
+                    std::vector<unsigned long long> mine;
+                    for (unsigned long long k : want_q[(size_t)q]) mine.push_back(((unsigned long long)((((uint32_t)(k >> 32)) * hmul) & hmask) << 32) | (uint32_t)k);
+                    if (hit_off[(size_t)(q - q0)] != at) { ok = false; why = "scan of a q batch"; break; }
+                    std::vector<unsigned long long> got(keys.begin() + (long)at, keys.begin() + (long)(at + mine.size()));
+                    std::sort(got.begin(), got.end()); std::sort(mine.begin(), mine.end());
+                    if (got != mine) { ok = false; why = "k_seed_fill"; }
+                    at += mine.size();
+                }
+                if (ok && keys[(size_t)n_b] != 0xCDCDCDCDCDCDCDCDull) { ok = false; why = "k_seed_fill wrote past its batch"; }
+            }
+            if (ok) {
+                std::vector<unsigned long long> keys((size_t)total_want + 4, 0xCDCDCDCDCDCDCDCDull), all;
+                unsigned long long total = 0;
+                mb::launch_seed_search(qc, qn, offsets.data(), occ.data(), positions.data(), nvar == 13, keys.data(), total_want, &total, nullptr);
+                for (auto &v : want_q) all.insert(all.end(), v.begin(), v.end());
+                keys.resize((size_t)total_want);
+                std::sort(keys.begin(), keys.end()); std::sort(all.begin(), all.end());
+                if (total != total_want || keys != all) { ok = false; why = "k_seed_search"; }
+            }
         }
         printf("case %d: T %lld (step %d, first %lld) x Q %lld, %d variants, %s query, %s diagonals, %llu hits in %d tiles  %s%s\n", cs, (long long)tn, step, (long long)first,
                (long long)qn, nvar, packed ? "packed" : "byte-code", hmul == 1u ? "plain" : "scrambled", total_want, n_tiles, ok ? "ok" : "MISMATCH: ", ok ? "" : why);

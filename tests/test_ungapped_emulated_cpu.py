@@ -48,12 +48,23 @@ def test_emulated_dense_seed_stage_matches_the_rule():
     one-pass search (k_seed_hits: a tile lists its hits into scratch reserved with one atomic add; k_seed_keys: a block per tile writes
     the keys at the tile's place in q order) gives, query position by query position, exactly the hits of SURVEY A.4 -- thirteen word
     variants or one, packed or byte-code query, scrambled diagonals (undone by k_keys_unhash) or plain ones --, and a key buffer that
-    is too small gets the total and no write past its end."""
+    is too small gets the total and no write past its end; and of mb_seed_index.h the strand in q batches (k_seed_count, scan, k_seed_fill) and
+    the one-pass search without q order (k_seed_search)."""
     subprocess.run(["make", "-C", EMU_DIR, "emu_seed_dense"], check=True, capture_output=True)
     p = subprocess.run([os.path.join(EMU_DIR, "emu_seed_dense"), "7", "10"], capture_output=True, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()
     assert out.count(" ok\n") == 10 and "MISMATCH" not in out, out
+
+
+@pytest.mark.skipif(not os.environ.get("MIBLAST_SLOW_TESTS"), reason="three minutes of emulated scan over the 2^24 + 1 bucket counts: MIBLAST_SLOW_TESTS=1")
+def test_emulated_dense_seed_table_through_its_kernels():
+    """mb_seed_index.h on the host: index words from the byte codes (= the packed ones), the three-launch exclusive scan of the bucket
+    counts with the occupancy bitmap and the counts left zeroed, the scatter, the cleared cursors -- against the plain table."""
+    subprocess.run(["make", "-C", EMU_DIR, "emu_seed_dense"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_seed_dense"), "7", "1", "table"], capture_output=True, timeout=1800)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and out.count(" ok\n") == 1 and "MISMATCH" not in out, out + p.stderr.decode()
 
 
 def test_emulated_set_kernels_match_plain_loops():
