@@ -98,3 +98,41 @@ def test_two_rank_chaining_of_contig_parts_equals_single_process():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert got[1] is None and got[0] == single
+
+
+def _reduce_worker(rank, world, port, q):
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.argv = argv
+    # what a rank hands over after its timed steps: counters (here: different on every rank) and its barrier-to-barrier time
+    tot = {"dp_cells": 1000.0 * (rank + 1), "seed_hits": 7.0, "t_dp_kernel_ms": 0.5 + rank}
+    elapsed, summed = bench.reduce_totals(tot, 0.010 * (rank + 1), dist, torch.device("cpu"))
+    q.put((rank, elapsed, summed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_reduction_of_the_bench_line():
+    """bench.py's reduce_totals at world_size 2 (the N > 1 line: value = the units of all ranks / the slowest rank's time): counters are
+    summed over the ranks, the time is the maximum, and every rank gets the same figures."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    for _, elapsed, summed in got:
+        assert abs(elapsed - 0.020) < 1e-12
+        assert summed == {"dp_cells": 3000.0, "seed_hits": 14.0, "t_dp_kernel_ms": 2.0}
