@@ -67,7 +67,7 @@ TRACE_BYTES_WRITTEN = 0.5      # what the DP kernels store per evaluated cell: 4
 PER_PAIR = ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_sides", "dp_cells", "dp_rows", "alignments",
             "t_index", "t_seed", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms")
 PER_BATCH = ("t_gapped", "gapped_rounds", "dp_sides_run", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms", "t_dp_busy_ms", "dp_kernel_launches",
-             "relay_accepted", "relay_rejected", "t_traceback_ms", "t_merge_ms", "dp_reruns")
+             "relay_accepted", "relay_rejected", "t_traceback_ms", "t_merge_ms", "dp_reruns", "relay_inline_checks", "relay_inline_continued")
 
 
 def parse_args():
@@ -607,6 +607,7 @@ def run_rank(a):
             "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
             "relay": {"pieces_per_step": tot["dp_sides_run"] / per, "dp_launches_per_step": tot["dp_kernel_launches"] / per,
                       "handovers_accepted_per_step": tot["relay_accepted"] / per, "handovers_rejected_per_step": tot["relay_rejected"] / per,
+                      "checked_inside_the_launch_per_step": tot["relay_inline_checks"] / per, "pieces_that_went_on_inside_per_step": tot["relay_inline_continued"] / per,
                       "reruns_per_step": tot["dp_reruns"] / per,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / per, "merge_ms_per_step": tot["t_merge_ms"] / per},
             "roofline": dp_roofline(tot, "r04_hbm_traffic_pmc.json" if a.workload == "evolver" else "r03_pair_hbm_traffic_pmc.json"),

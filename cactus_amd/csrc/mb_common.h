@@ -59,6 +59,13 @@ struct DpProb {                               // one one-sided Y-drop DP (SURVEY
     int32_t init_snap;                        // snapshot to continue from (row_lo > 0)
     int32_t snap_idx;                         // entry snapshot slot; the exit snapshot is slot snap_idx + 1 (-1: none)
     int32_t snap_row2, snap_row3;             // > 0: later entry snapshots (slots snap_idx + 2 / + 3): a hand-over rejected at snap_row is retried there
+    // hand-over inside the launch (k_ydrop2, mb_ydrop2.h): a piece that reaches its stop row checks its state against the aimed relay's
+    // entry snapshot itself and, rejected, goes on to the relay's next snapshot / the relay after -- the continuation the host would
+    // otherwise queue as a launch of its own.  All three are 0 when unused (a zeroed record is a piece without an aim).
+    int32_t aim1;                             // 1 + the aimed relay's piece in the round's table (probs of the launch = table + first); 0: none
+    int32_t vjob1;                            // 1 + this piece's check among the launch's VerifyJobs (rewritten to the hand-over it ended at); 0: none
+    int32_t cap_row;                          // the last row the piece may reach on its own (row-chunk directory entries are reserved up to it)
+    int32_t ck0;                              // which entry snapshot of the aimed relay the first check is made against (0: after snap_row, 1 / 2: snap_row2 / 3)
 };
 constexpr int kSnapSlots = 4;                 // snapshot slots per piece: entry, exit, entry 2, entry 3
 
@@ -66,7 +73,8 @@ constexpr int kSnapSlots = 4;                 // snapshot slots per piece: entry
 struct SnapHdr {
     int32_t valid, LY, RY, best, bi, bj, row, rows;
     int64_t cells;
-    int32_t pad[6];
+    int32_t stamp;                            // k_ydrop2: the round's stamp, written LAST (release): a reader inside the same launch trusts a header that carries it
+    int32_t pad[5];
 };
 constexpr int kSnapCols = 2048;               // = kLdsRowCap: only the LDS-ring variant takes snapshots
 constexpr size_t kSnapBytes = sizeof(SnapHdr) + 2 * (size_t)kSnapCols * sizeof(int32_t);
@@ -82,6 +90,7 @@ struct DpOut {
     int32_t overflow;                         // 1: row wider than the LDS ring (rerun with HBM rows); 3: trace arena exhausted
     int32_t n_ops;                            // traceback: number of ops written
     int32_t stopped, exit_j;                  // 1: stopped at stop_row with live cells (exit snapshot written); best column of that row
+    int32_t fin_stop, fin_aim1, fin_ck, fin_checks;   // k_ydrop2: the stop row, aim (1 + piece) and entry snapshot (0..2) the piece ended with; hand-overs it checked itself
     long long prof[6];                        // MIBLAST_DP_PROFILE: shader clocks per phase of the row loop
 };
 
@@ -206,8 +215,8 @@ void launch_seed_fill(const uint8_t *qcodes, int64_t q0, int64_t q1, int64_t qto
                       hipStream_t s, uint32_t hmul = 1u, uint32_t hmask = 0xFFFFFFFFu);      // key diagonal = (d * hmul) & hmask (mb_seed_dense.h)
 void launch_index_clear(const uint32_t *words, int64_t n_slots, uint32_t *cursor, hipStream_t s);
 // ---- seed stage of a large pair (mb_seed_dense.h) ----
-inline size_t packed_words2(int64_t n) { return (size_t)((n + 31) / 32 + 2); }      // u64 words of the 2-bit plane / of the mask plane of n bases
-inline size_t packed_wordsm(int64_t n) { return (size_t)((n + 63) / 64 + 2); }
+inline size_t packed_wordsm(int64_t n) { return (size_t)((n + 63) / 64 + 2); }      // u64 words of the mask plane of n bases (k_pack2bit_mask runs one thread per word)
+inline size_t packed_words2(int64_t n) { return 2 * packed_wordsm(n); }              // ... of the 2-bit plane: every thread stores the two words of its 64 bases, the padding words included
 void launch_pack2bit(const uint8_t *codes, int64_t n, unsigned long long *p2, unsigned long long *pm, hipStream_t s);
 void launch_index_words_packed(const unsigned long long *p2, const unsigned long long *pm, int64_t n, int step, int64_t first, uint32_t *words, int64_t n_slots,
                                uint32_t *counts, hipStream_t s);
@@ -233,7 +242,8 @@ void launch_ydrop(bool global_rows, const DpProb *probs, DpOut *outs, int n, con
                   const void *wsegs = nullptr, const void *walns = nullptr, const void *wref = nullptr, uint8_t *wflags = nullptr);
 void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena,
                    unsigned long long arena_bytes, unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir,
-                   uint8_t *snaps, const int *order, hipStream_t s);      // order: piece of block b (k_ydrop2 only), or nullptr
+                   uint8_t *snaps, const int *order, hipStream_t s,       // order: piece of block b (k_ydrop2 only), or nullptr
+                   int first = 0, struct VerifyJob *vjobs = nullptr, int stamp = 0, int force_mod = 0);   // probs = the round's table, the launch's pieces [first, first + n); k_ydrop2's hand-over inside the launch
 void launch_trace_walk(TbWalk *walks, int n, const uint8_t *arena, unsigned long long arena_bytes,
                        const unsigned long long *rowdir, uint32_t *ops, uint32_t *recs, hipStream_t s);
 void launch_trace_prejoin(const TbWalk *walks, int n, TbJoin *joins, const uint8_t *arena, unsigned long long arena_bytes,

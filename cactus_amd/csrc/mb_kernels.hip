@@ -746,29 +746,29 @@ __global__ __launch_bounds__(64)
 void k_ydrop2(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
               const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
               unsigned long long *__restrict__ arena_next, const unsigned blk_bytes, unsigned long long *__restrict__ rowdir,
-              uint8_t *__restrict__ snaps, const int *__restrict__ order) {
-    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
+              uint8_t *snaps, const int *__restrict__ order, const int first, VerifyJob *__restrict__ vjobs, const int stamp, const int force_mod) {
+    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order, first, vjobs, stamp, force_mod);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
 void k_ydrop2_w5(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n, const PairPtrs *__restrict__ pairs, const int O,
                  const int E, const int Y, uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                  unsigned long long *__restrict__ arena_next, const unsigned blk_bytes, unsigned long long *__restrict__ rowdir,
-                 uint8_t *__restrict__ snaps, const int *__restrict__ order) {
-    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
+                 uint8_t *snaps, const int *__restrict__ order, const int first, VerifyJob *__restrict__ vjobs, const int stamp, const int force_mod) {
+    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order, first, vjobs, stamp, force_mod);
 }
 
 void launch_ydrop1(int K, const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, int O, int E, int Y, uint8_t *arena,
                    unsigned long long arena_bytes, unsigned long long *arena_next, unsigned blk_bytes, unsigned long long *rowdir,
-                   uint8_t *snaps, const int *order, hipStream_t s) {
+                   uint8_t *snaps, const int *order, hipStream_t s, int first, VerifyJob *vjobs, int stamp, int force_mod) {
     if (n <= 0) return;
     dim3 g((unsigned)n), b(64);
     const char *we = getenv("MIBLAST_DP_WAVES");
     const int waves = we ? atoi(we) : 0;
     const bool five = waves == 5;                                       // (round 3: the 4-wave build is the faster one at every size, see above)
-    if (K == 2 && five) hipLaunchKernelGGL(k_ydrop2_w5, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
-    else if (K == 2) hipLaunchKernelGGL(k_ydrop2, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
-    else if (K == 4) hipLaunchKernelGGL((k_ydrop1<4>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
-    else hipLaunchKernelGGL((k_ydrop1<8>), g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    if (K == 2 && five) hipLaunchKernelGGL(k_ydrop2_w5, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order, first, vjobs, stamp, force_mod);
+    else if (K == 2) hipLaunchKernelGGL(k_ydrop2, g, b, 0, s, probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order, first, vjobs, stamp, force_mod);
+    else if (K == 4) hipLaunchKernelGGL((k_ydrop1<4>), g, b, 0, s, probs + first, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
+    else hipLaunchKernelGGL((k_ydrop1<8>), g, b, 0, s, probs + first, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps);
 }
 
 #include "mb_trace.h"

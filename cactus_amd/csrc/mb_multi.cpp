@@ -100,7 +100,7 @@ void add_stats(miblast_stats &a, const miblast_stats &s, bool first_of_batch) {
     if (first_of_batch) {
         a.t_gapped += s.t_gapped; a.gapped_rounds += s.gapped_rounds; a.dp_sides_run += s.dp_sides_run; a.dp_cells_run += s.dp_cells_run;
         a.dp_rows_run += s.dp_rows_run; a.t_dp_kernel_ms += s.t_dp_kernel_ms; a.t_dp_busy_ms += s.t_dp_busy_ms; a.dp_kernel_launches += s.dp_kernel_launches;
-        a.relay_accepted += s.relay_accepted; a.relay_rejected += s.relay_rejected; a.dp_reruns += s.dp_reruns;
+        a.relay_accepted += s.relay_accepted; a.relay_rejected += s.relay_rejected; a.relay_inline_checks += s.relay_inline_checks; a.relay_inline_continued += s.relay_inline_continued; a.dp_reruns += s.dp_reruns;
         a.t_traceback_ms += s.t_traceback_ms; a.t_merge_ms += s.t_merge_ms;
     }
 }

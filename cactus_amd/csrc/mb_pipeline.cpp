@@ -756,6 +756,7 @@ struct Workspace {                      // device buffers that persist across mi
     DevBuf<uint32_t> recs;
     DevBuf<uint8_t> snaps;
     DevBuf<char> dp_up, dp_down;             // a DP launch's pieces + hand-over checks / their results: one copy each way
+    DevBuf<char> round_tab;                   // the round's piece table (DpProb of every piece queued so far), the current launch's hand-over checks behind it
     DevBuf<PairPtrs> pair_ptrs;
     DevBuf<int32_t> wall_segs;                // walls mode: WallSeg runs (3 x int32), run ranges per alignment and alignment ranges per piece (int2 each)
     DevBuf<int32_t> wall_alns, wall_ref;
@@ -1226,7 +1227,8 @@ static void collect_dp_time(Ctx &ctx, miblast_stats &st) {             // after 
 
 static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpProb *probs, DpOut *outs, int n,
                             const PairPtrs *pairs, const miblast_params &p, unsigned blk_bytes, bool defer = false, const DpProb *host_probs = nullptr,
-                            const int32_t *wall_ref = nullptr) {
+                            const int32_t *wall_ref = nullptr, int first = 0, VerifyJob *vjobs = nullptr, int stamp = 0, int force_mod = 0) {
+    // (probs + first = the launch's pieces; k_ydrop2 is given the table itself: its pieces read the records of the relays they are aimed at)
     Workspace &g = *ctx.ws;
     // A launch with more pieces than wave slots: the blocks take the pieces longest first (counting sort by the rows a piece will
     // run at most), so that the launch ends with short pieces instead of a long one started late.  Scheduling only.
@@ -1254,9 +1256,9 @@ static void run_ydrop_timed(Ctx &ctx, miblast_stats &st, int kernel, const DpPro
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     if (kernel == kDpWave2x4 || kernel == kDpWave4 || kernel == kDpWave8)
         launch_ydrop1(kernel, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.arena.p, (unsigned long long)g.arena.n - 64, g.arena_next.p,
-                      blk_bytes, g.rowdir.p, g.snaps.p, order, ctx.stream);
+                      blk_bytes, g.rowdir.p, g.snaps.p, order, ctx.stream, first, vjobs, stamp, force_mod);
     else
-        launch_ydrop(kernel == kDpHbm, probs, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
+        launch_ydrop(kernel == kDpHbm, probs + first, outs, n, pairs, p.gap_open, p.gap_extend, p.ydrop, g.grows.p, g.arena.p,
                      (unsigned long long)g.arena.n - 64, g.arena_next.p, blk_bytes, g.rowdir.p, g.snaps.p, ctx.stream,
                      wall_ref ? g.wall_segs.p : nullptr, wall_ref ? g.wall_alns.p : nullptr, wall_ref, wall_ref && kernel == kDpHbm ? g.wall_flags.p : nullptr);
     MB_HIP(hipEventRecord(ctx.ev1, ctx.stream));
@@ -1771,6 +1773,15 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
     if (targets.size() > (size_t)env_long("MIBLAST_BATCH_TARGETS", 64)) return MIBLAST_OK;
     if (p.diag_hash16 && 2 * n > 256) return MIBLAST_OK;                                      // (the class keys of mb_hash16.h hold 8 bits of unit)
     const int64_t hit_cap = env_long("MIBLAST_HIT_CAP", 32l << 20);
+    // A call whose CHANCE hits alone (strands x word variants x indexed target positions x query positions / 4^12) exceed one key buffer
+    // goes pair by pair: decided here, from the sizes, before a table is built or a query copied (round 4 built the tables of all
+    // targets and counted the hits of all units first -- 13 % of a 42-pair human-mouse step spent on an answer the sizes give).
+    if (n > 1 && !p.diag_hash16) {
+        double expected = 0;
+        for (size_t k = 0; k < n; k++)
+            expected += 2.0 * (p.transitions ? 1 + kSeedWeight : 1) * ((double)jobs[k]->T->total / std::max(1, p.step)) * (double)jobs[k]->Q->total / (double)kBuckets;
+        if (expected > (double)hit_cap) return MIBLAST_OK;
+    }
 
     // ---- tables
     std::vector<BatchTarget> tg(targets.size());
@@ -2189,6 +2200,12 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     const long relay_force_reject = env_long("MIBLAST_RELAY_FORCE_REJECT", 0);   // test knob: reject every n-th hand-over
     const bool chain_heads = env_long("MIBLAST_CHAIN_HEADS", 1) != 0;            // first round: one speculative head per colinear group of anchors
     const bool relay_ckpt = env_long("MIBLAST_RELAY_CKPT", 1) != 0;             // retry a rejected hand-over at the relay's later entry snapshots
+    // the hand-over inside the launch (mb_ydrop2.h): a piece checks its hand-over itself and, rejected, goes on in the same wave.  0: off (every
+    // rejected hand-over is a continuation piece in a launch of its own, as before round 5); MIBLAST_RELAY_INLINE_ROWS: how far past its
+    // planned stop row a piece may go on its own (default: the aimed relay's last entry snapshot and three relays further)
+    const bool relay_inline = env_long("MIBLAST_RELAY_INLINE", 1) != 0;
+    const long relay_inline_rows_env = env_long("MIBLAST_RELAY_INLINE_ROWS", -1);
+    const long relay_inline_force = env_long("MIBLAST_RELAY_INLINE_FORCE_REJECT", 0);   // test knob (mb_ydrop2.h, force_mod)
     // DP kernel of the pieces: the typical window is (Y-O)/E columns to the right of the path and about a quarter of that to
     // the left; windows that outgrow the lanes make the piece overflow and it is rerun with the next wider kernel
     const long win_typ = (p.ydrop > p.gap_open ? (p.ydrop - p.gap_open) / std::max(1, p.gap_extend) : 0) * 5 / 4 + 32;
@@ -2423,6 +2440,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
         // instructions per row; the few pieces that outgrow the lanes are rerun), else 8 columns per lane
         const int dp_kernel = walls ? kDpLds : dp_kernel_env ? (int)dp_kernel_env : win_typ > 448 ? kDpLds : win_typ <= 224 ? kDpWave2x4 : kDpWave8;
+        // rows a piece with a stop row may go on past it inside its launch (k_ydrop2 only); its row-chunk directory is reserved that far
+        const long inline_rows = dp_kernel == kDpWave2x4 && relay_inline && relay_s0 > 0 ? (relay_inline_rows_env >= 0 ? relay_inline_rows_env : 4 * relay_w + 3 * relay_s) : 0;
+        auto reach_of = [&](int32_t stop_row, int32_t nb) -> int32_t { return stop_row > 0 ? (int32_t)std::min<long>((long)nb, (long)stop_row + inline_rows) : nb; };
         // walls of the round: the gap-free runs of every unit's committed alignments, in the strand's coordinates
         std::vector<int32_t> wall_segs, wall_alns;                          // WallSeg = 3 x int32; run range per alignment = 2 x int32
         std::vector<std::pair<int32_t, int32_t>> unit_walls(units.size(), {0, 0});      // alignments [first, last) of a unit
@@ -2610,6 +2630,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             pieces.reserve(4096); probs.reserve(4096); vjobs.reserve(4096); relay_pts.reserve(4096);
             arena_full = false;
             uint64_t dir_entries = 0;
+            static std::atomic<int> stamp_counter{1};
+            const int stamp = stamp_counter.fetch_add(1) + 1;               // of this round's snapshots (a new one for every attempt: the piece numbers start over)
             MB_HIP(hipMemsetAsync(g.arena_next.p, 0, 8, s));
             // entry snapshots of a relay: after relay_w rows, and again after 2 and 4 times that -- a hand-over rejected at the first
             // (the relay's state had not converged yet) is retried at the next with a SHORT continuation of the upstream piece
@@ -2628,7 +2650,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
                 pr.init_snap = init_piece >= 0 ? kSnapSlots * init_piece + 1 : -1; pr.snap_idx = kSnapSlots * id;
                 pr.row_off = dir_entries;
-                const int64_t last = stop_row > 0 ? stop_row : pr.nb;
+                const int64_t last = reach_of(stop_row, pr.nb);
+                pr.cap_row = stop_row > 0 && inline_rows > 0 ? (int32_t)last : 0; pr.ck0 = ckpt;
                 dir_entries += (uint64_t)((last - row_lo) / 4096) + 2;
                 probs.push_back(pr);
                 pieces.push_back(Piece{unit, ot, oq, base.dir, row_lo, min_row, stop_row, target, ckpt, init_piece, -1, -1});
@@ -2697,7 +2720,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         }
                         pr.init_snap = -1; pr.snap_idx = id;                  // (local number: kSnapSlots x the global one when the tables are strung together)
                         pr.row_off = pl.dir_entries;
-                        const int64_t last = stop_row > 0 ? stop_row : pr.nb;
+                        const int64_t last = reach_of(stop_row, pr.nb);
+                        pr.cap_row = stop_row > 0 && inline_rows > 0 ? (int32_t)last : 0; pr.ck0 = 0;
                         pl.dir_entries += (uint64_t)(last / 4096) + 2;
                         pl.probs.push_back(pr);
                         pl.pieces.push_back(Piece{unit, ot, oq, base.dir, 0, snap_row > 0 ? (int32_t)relay_w : -1, stop_row, target, 0, -1, -1, -1});
@@ -2789,22 +2813,31 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 g.rowdir.ensure_keep((size_t)dir_entries + 1);
                 g.snaps.ensure_keep(pieces.size() * kSnapSlots * kSnapBytes);
                 outs.resize(pieces.size()); vres.resize(vjobs.size());
-                for (size_t x = launched; x < pieces.size(); x++)
-                    if (pieces[x].vjob >= 0) vjobs[(size_t)pieces[x].vjob].nslot = kSnapSlots * relay_pts[(size_t)pieces[x].target].piece + (pieces[x].ckpt == 0 ? 0 : pieces[x].ckpt + 1);
-                // the launch's pieces with its hand-over checks behind them travel in one copy, and so do both kinds of results
+                for (size_t x = launched; x < pieces.size(); x++) {
+                    probs[x].aim1 = 0; probs[x].vjob1 = 0;
+                    if (pieces[x].vjob >= 0) {
+                        const int rp = relay_pts[(size_t)pieces[x].target].piece;
+                        vjobs[(size_t)pieces[x].vjob].nslot = kSnapSlots * rp + (pieces[x].ckpt == 0 ? 0 : pieces[x].ckpt + 1);
+                        probs[x].aim1 = rp + 1; probs[x].vjob1 = pieces[x].vjob - (int)vlaunched + 1;       // (the piece may look at the hand-over itself: mb_ydrop2.h)
+                    }
+                }
+                // The launch's pieces go behind the round's table on the device (a piece that checks its own hand-over reads the records of
+                // the relays down its chain, whichever launch they were queued for), the hand-over checks behind them: one copy; both kinds of
+                // results come back in one copy.
                 const size_t up_v = Stager::behind(n_new * sizeof(DpProb)), down_v = Stager::behind(n_new * sizeof(DpOut));
-                g.dp_up.ensure(up_v + v_new * sizeof(VerifyJob) + 256); g.dp_down.ensure(down_v + v_new * sizeof(VerifyOut) + 256);
-                DpProb *const d_probs = (DpProb *)g.dp_up.p;
-                VerifyJob *const d_vjobs = (VerifyJob *)(g.dp_up.p + up_v);
+                g.round_tab.ensure_keep(launched * sizeof(DpProb) + up_v + v_new * sizeof(VerifyJob) + 256); g.dp_down.ensure(down_v + v_new * sizeof(VerifyOut) + 256);
+                DpProb *const d_tab = (DpProb *)g.round_tab.p;
+                DpProb *const d_probs = d_tab + launched;
+                VerifyJob *const d_vjobs = (VerifyJob *)(g.round_tab.p + launched * sizeof(DpProb) + up_v);
                 DpOut *const d_outs = (DpOut *)g.dp_down.p;
                 VerifyOut *const d_vres = (VerifyOut *)(g.dp_down.p + down_v);
-                g.stage.h2d2(g.dp_up.p, probs.data() + launched, n_new * sizeof(DpProb), vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), s);
+                g.stage.h2d2(d_probs, probs.data() + launched, n_new * sizeof(DpProb), vjobs.data() + vlaunched, v_new * sizeof(VerifyJob), s);
                 // valid = 0 in every header of the new pieces' slots (the headers only: the slots are 16 KiB apart); k_ydrop2 does it itself
                 if (dp_kernel != kDpWave2x4) MB_HIP(hipMemset2DAsync(g.snaps.p + launched * kSnapSlots * kSnapBytes, kSnapBytes, 0, sizeof(SnapHdr), n_new * kSnapSlots, s));
                 // DP launch, hand-over checks and the copies of both results: one synchronisation.  (Checks made on pieces that
                 // turn out to need a rerun are simply made again.)
-                run_ydrop_timed(ctx, st, dp_kernel, d_probs, d_outs, (int)n_new, g.pair_ptrs.p, p, kBlk, true, probs.data() + launched,
-                                upload_wall_refs(launched, pieces.size()));
+                run_ydrop_timed(ctx, st, dp_kernel, d_tab, d_outs, (int)n_new, g.pair_ptrs.p, p, kBlk, true, probs.data() + launched,
+                                upload_wall_refs(launched, pieces.size()), (int)launched, d_vjobs, stamp, (int)relay_inline_force);
                 launch_verify(d_vjobs, d_vres, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
                 g.stage.d2h2(outs.data() + launched, n_new * sizeof(DpOut), vres.data() + vlaunched, v_new * sizeof(VerifyOut), g.dp_down.p, s);
                 MB_HIP(hipStreamSynchronize(s));
@@ -2842,6 +2875,30 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         return MIBLAST_ELIMIT;
                     }
                 if (arena_full) break;
+                if (dp_kernel == kDpWave2x4) {
+                    // pieces that looked at their hand-over themselves and went on: the stop row, the aimed relay and the entry snapshot they
+                    // ended with are the piece's from here on (k_verify has judged THAT hand-over: the piece rewrote its check)
+                    std::vector<int> pt_of;
+                    for (size_t x = launched; x < pieces.size(); x++) {
+                        const DpOut &o = outs[x];
+                        if (o.overflow != 0) continue;
+                        st.relay_inline_checks += o.fin_checks;
+                        if (pieces[x].stop_row <= 0 || o.fin_stop == pieces[x].stop_row) continue;
+                        st.relay_inline_continued++;
+                        if (pt_of.empty()) {
+                            pt_of.assign(pieces.size(), -1);
+                            for (size_t r = 0; r < relay_pts.size(); r++) if (relay_pts[r].piece >= 0) pt_of[(size_t)relay_pts[r].piece] = (int)r;
+                        }
+                        pieces[x].stop_row = probs[x].stop_row = o.fin_stop;
+                        pieces[x].ckpt = o.fin_ck;
+                        if (o.fin_aim1 > 0 && pt_of[(size_t)o.fin_aim1 - 1] >= 0) pieces[x].target = pt_of[(size_t)o.fin_aim1 - 1];
+                        if (pieces[x].vjob >= 0) {
+                            const RelayPt &ta = relay_pts[(size_t)pieces[x].target];
+                            vjobs[(size_t)pieces[x].vjob] = VerifyJob{kSnapSlots * (int)x + 1, kSnapSlots * ta.piece + (o.fin_ck == 0 ? 0 : o.fin_ck + 1),
+                                                                     (ta.t - pieces[x].ot) * pieces[x].dir, (ta.q - pieces[x].oq) * pieces[x].dir};
+                        }
+                    }
+                }
                 for (size_t x = launched; x < pieces.size(); x++) {
                     st.dp_sides_run++;
                     const DpOut *o0 = pieces[x].init_piece >= 0 ? &outs[(size_t)pieces[x].init_piece] : nullptr;
@@ -3306,7 +3363,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         miblast_stats &d = j->res->stats;
         d.t_gapped = st.t_gapped; d.gapped_rounds = st.gapped_rounds; d.dp_sides_run = st.dp_sides_run; d.dp_cells_run = st.dp_cells_run;
         d.dp_rows_run = st.dp_rows_run; d.t_dp_kernel_ms = st.t_dp_kernel_ms; d.dp_kernel_launches = st.dp_kernel_launches;
-        d.relay_accepted = st.relay_accepted; d.relay_rejected = st.relay_rejected; d.dp_reruns = st.dp_reruns; d.t_traceback_ms = st.t_traceback_ms; d.t_merge_ms = st.t_merge_ms;
+        d.relay_accepted = st.relay_accepted; d.relay_rejected = st.relay_rejected; d.relay_inline_checks = st.relay_inline_checks; d.relay_inline_continued = st.relay_inline_continued; d.dp_reruns = st.dp_reruns; d.t_traceback_ms = st.t_traceback_ms; d.t_merge_ms = st.t_merge_ms;
     }
     return MIBLAST_OK;
 
@@ -3631,14 +3688,14 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
             sum.gapped_rounds = std::max(sum.gapped_rounds, a.gapped_rounds);
             sum.dp_sides_run += a.dp_sides_run; sum.dp_cells_run += a.dp_cells_run; sum.dp_rows_run += a.dp_rows_run;
             sum.t_dp_kernel_ms += a.t_dp_kernel_ms; sum.dp_kernel_launches += a.dp_kernel_launches;
-            sum.relay_accepted += a.relay_accepted; sum.relay_rejected += a.relay_rejected; sum.dp_reruns += a.dp_reruns;
+            sum.relay_accepted += a.relay_accepted; sum.relay_rejected += a.relay_rejected; sum.relay_inline_checks += a.relay_inline_checks; sum.relay_inline_continued += a.relay_inline_continued; sum.dp_reruns += a.dp_reruns;
             sum.t_traceback_ms += a.t_traceback_ms; sum.t_merge_ms += a.t_merge_ms; sum.t_gapped += a.t_gapped;
         }
         for (PairJob *j : jobs) {
             miblast_stats &d = j->res->stats;
             d.t_gapped = sum.t_gapped; d.gapped_rounds = sum.gapped_rounds; d.dp_sides_run = sum.dp_sides_run; d.dp_cells_run = sum.dp_cells_run;
             d.dp_rows_run = sum.dp_rows_run; d.t_dp_kernel_ms = sum.t_dp_kernel_ms; d.dp_kernel_launches = sum.dp_kernel_launches;
-            d.relay_accepted = sum.relay_accepted; d.relay_rejected = sum.relay_rejected; d.dp_reruns = sum.dp_reruns;
+            d.relay_accepted = sum.relay_accepted; d.relay_rejected = sum.relay_rejected; d.relay_inline_checks = sum.relay_inline_checks; d.relay_inline_continued = sum.relay_inline_continued; d.dp_reruns = sum.dp_reruns;
             d.t_traceback_ms = sum.t_traceback_ms; d.t_merge_ms = sum.t_merge_ms;
         }
     } else
@@ -3706,14 +3763,14 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
                 sum.t_gapped = std::max(sum.t_gapped, a.t_gapped); sum.gapped_rounds = std::max(sum.gapped_rounds, a.gapped_rounds);
                 sum.dp_sides_run += a.dp_sides_run; sum.dp_cells_run += a.dp_cells_run; sum.dp_rows_run += a.dp_rows_run;
                 sum.t_dp_kernel_ms += a.t_dp_kernel_ms; sum.dp_kernel_launches += a.dp_kernel_launches;
-                sum.relay_accepted += a.relay_accepted; sum.relay_rejected += a.relay_rejected; sum.dp_reruns += a.dp_reruns;
+                sum.relay_accepted += a.relay_accepted; sum.relay_rejected += a.relay_rejected; sum.relay_inline_checks += a.relay_inline_checks; sum.relay_inline_continued += a.relay_inline_continued; sum.dp_reruns += a.dp_reruns;
                 sum.t_traceback_ms += a.t_traceback_ms; sum.t_merge_ms += a.t_merge_ms;
             }
             for (PairJob *j : jobs) {
                 miblast_stats &d = j->res->stats;
                 d.t_gapped = sum.t_gapped; d.gapped_rounds = sum.gapped_rounds; d.dp_sides_run = sum.dp_sides_run; d.dp_cells_run = sum.dp_cells_run;
                 d.dp_rows_run = sum.dp_rows_run; d.t_dp_kernel_ms = sum.t_dp_kernel_ms; d.dp_kernel_launches = sum.dp_kernel_launches;
-                d.relay_accepted = sum.relay_accepted; d.relay_rejected = sum.relay_rejected; d.dp_reruns = sum.dp_reruns;
+                d.relay_accepted = sum.relay_accepted; d.relay_rejected = sum.relay_rejected; d.relay_inline_checks = sum.relay_inline_checks; d.relay_inline_continued = sum.relay_inline_continued; d.dp_reruns = sum.dp_reruns;
                 d.t_traceback_ms = sum.t_traceback_ms; d.t_merge_ms = sum.t_merge_ms;
             }
         }

@@ -16,6 +16,12 @@
 #define YD_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define YD_PIN5(a, b, c, d, e) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e))
 #define YD_GLOBAL_UNALIGNED __attribute__((address_space(1), aligned(1)))
+// what one wave of a launch reads of another's snapshot while both run: loads that bypass the caches that are not coherent across
+// CUs / XCDs (agent scope), the stamp as the acquire / release pair around them
+#define yd_ld_agent(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define yd_ld_acquire(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+#define yd_st_release(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#define yd_fence() __threadfence()
 #endif
 
 // k_ydrop2: k_ydrop1 with 4 columns per lane and a SECOND group of 256 columns that is only evaluated when a row needs
@@ -24,18 +30,28 @@
 // that reach further -- the ones that make k_ydrop1<4> overflow and rerun -- just evaluate group B as well, with the scan
 // carries of group A.  B can be skipped whenever the previous row's window ended inside A and this row's break is found in
 // A: no column of B was alive in the previous row then, so all of them already hold dead values (k_ydrop1's invariant).
+//
+// The hand-over inside the launch.  `probs` is the ROUND's piece table, the launch's pieces are [first, first + n).
+// A piece that reaches its stop row alive and is aimed at a relay (DpProb.aim1) looks at the relay's entry snapshot itself -- the relay
+// runs in the same launch or ran in an earlier one of the round; a snapshot counts when its header carries the round's `stamp`, which
+// its writer stores last -- and compares the two states as k_verify does (mb_verify.h).  Equal: it stops; the host reads k_verify's
+// verdict as before.  Not equal: the piece simply goes on -- to the same relay's next entry snapshot, then to the relay after -- which
+// is the continuation the host would otherwise queue as a launch of its own, with the state already in registers.  The check itself
+// decides nothing about results: k_verify, run after the launch on the hand-over the piece ended at (the piece rewrites its
+// VerifyJob), stays the authority, and a snapshot that is not there yet just ends the piece as before.
 static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ probs, DpOut *__restrict__ outs, int n,
                                                     const PairPtrs *__restrict__ pairs, const int O, const int E, const int Y,
                                                     uint8_t *__restrict__ arena, const unsigned long long arena_bytes,
                                                     unsigned long long *__restrict__ arena_next, const unsigned blk_bytes,
-                                                    unsigned long long *__restrict__ rowdir, uint8_t *__restrict__ snaps,
-                                                    const int *__restrict__ order) {
+                                                    unsigned long long *__restrict__ rowdir, uint8_t *snaps,
+                                                    const int *__restrict__ order, const int first, VerifyJob *__restrict__ vjobs,
+                                                    const int stamp, const int force_mod) {
     if ((int)blockIdx.x >= n) return;
     // (order: longest pieces first when a launch holds more pieces than wave slots, so that its tail is made of short ones)
     const int pi = order ? order[blockIdx.x] : (int)blockIdx.x;
     constexpr int K = 4, G = 2, kHalf = 64 * K, kCap = G * kHalf;
     constexpr unsigned kAll = (1u << K) - 1u;
-    const DpProb pr = probs[pi];
+    const DpProb pr = probs[first + pi];
     const PairPtrs pp = pairs[pr.pad0];
     const gbytes tc = as_global(pp.tc);
     const gbytes qc = as_global(pr.strand ? pp.qr : pp.qf);
@@ -143,10 +159,12 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
     int i = row_lo + 1;
     int stopped = 0, exit_j = 0;
     // the next row after which a snapshot is due (entry snapshots of a relay, the exit snapshot at stop_row): one comparison per row
+    int stop_at = pr.stop_row;                                           // moves on when a hand-over is rejected inside the launch
+    int aim = pr.aim1 - 1, ck = pr.ck0, n_checks = 0;                         // the aimed relay (piece of the round's table), which of its entry snapshots, checks made here
     auto next_event = [&](int after) -> int {
         int e = 0x7fffffff;
         if (pr.snap_row > after) e = min(e, pr.snap_row);
-        if (pr.stop_row > after) e = min(e, pr.stop_row);
+        if (stop_at > after) e = min(e, stop_at);
         if (pr.snap_row2 > after) e = min(e, pr.snap_row2);
         if (pr.snap_row3 > after) e = min(e, pr.snap_row3);
         return e;
@@ -333,7 +351,7 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
         if (__builtin_expect(i == evt, 0)) {
             evt = uni(next_event(i));
             // state after row i
-            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == pr.stop_row ? 1 : i == pr.snap_row ? 0 : i == pr.snap_row2 ? 2 : 3)) * kSnapBytes;
+            uint8_t *sp = snaps + (size_t)(pr.snap_idx + (i == stop_at ? 1 : i == pr.snap_row ? 0 : i == pr.snap_row2 ? 2 : 3)) * kSnapBytes;
             int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
             int lmax = kNeg2, lj = 0;
 #pragma unroll
@@ -347,17 +365,85 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
             const int wmax = uni(yd_readlane(dpp_scan_max(lmax), 63));
             const int cand_j = lmax == wmax ? lj : 0x7fffffff;
             exit_j = -uni(yd_readlane(dpp_scan_max(-cand_j), 63));
+            yd_fence();                                                   // (every lane's C / D before the header that announces them)
             if (lane == 0) {
                 SnapHdr *h = (SnapHdr *)sp;
                 h->LY = LY; h->RY = RY; h->best = best; h->bi = bi; h->bj = bj; h->row = i; h->rows = rows; h->cells = cells;
                 h->valid = 1;
+                yd_st_release(&h->stamp, stamp);
             }
-            if (i == pr.stop_row) { stopped = 1; i++; break; }
+            if (i == stop_at) {
+                // ---- the hand-over, checked here (see the head of this file)
+                int nstop = 0;
+                if (aim >= 0 && pr.cap_row > stop_at) {
+                    const DpProb *R = probs + aim;
+                    const int r_t0 = uni(R->t0), r_q0 = uni(R->q0), r_s2 = uni(R->snap_row2), r_s3 = uni(R->snap_row3);
+                    const int drow = (r_q0 - pr.q0) * dir, shift = (r_t0 - pr.t0) * dir;
+                    SnapHdr *nh = (SnapHdr *)(snaps + (size_t)(kSnapSlots * aim + (ck == 0 ? 0 : ck + 1)) * kSnapBytes);
+                    const int seen = uni(yd_ld_acquire(&nh->stamp));
+                    if (seen == stamp && uni(yd_ld_agent(&nh->valid)) != 0) {
+                        const int n_ly = uni(yd_ld_agent(&nh->LY)), n_ry = uni(yd_ld_agent(&nh->RY)), n_best = uni(yd_ld_agent(&nh->best)),
+                                  n_row = uni(yd_ld_agent(&nh->row));
+                        int bad = !(i == n_row + drow && LY == n_ly + shift && RY == n_ry + shift);
+                        if (!bad) {
+                            int *NC = (int *)((uint8_t *)nh + sizeof(SnapHdr)), *ND = NC + kSnapCols;
+                            const int c = best - n_best, thr = best - Y;
+#pragma unroll
+                            for (int g = 0; g < G; g++)
+#pragma unroll
+                                for (int k = 0; k < K; k++) {
+                                    const int j = jb + g * kHalf + K * lane + k;
+                                    if (j >= LY && j < RY) {
+                                        const int ec = C[g][k], ed = D[g][k], nc = yd_ld_agent(NC + (j - LY)), nd = yd_ld_agent(ND + (j - LY));
+                                        const bool ea = ec != kNeg, na_ = nc != kNeg;
+                                        if (ea != na_ || (ea && ec != nc + c)) bad = 1;
+                                        const bool el = ed - E >= thr, nl = nd > kNeg2 && nd + c - E >= thr;
+                                        if (el != nl || (el && ed != nd + c)) bad = 1;
+                                    }
+                                }
+                        }
+                        // (force_mod, a test knob: n > 0 rejects the first check of every n-th piece, -n the first n checks of every piece)
+                        const bool rejected = yd_ballot(bad != 0) != 0ull || (force_mod > 0 && n_checks == 0 && (first + pi) % force_mod == 0) || (force_mod < 0 && n_checks < -force_mod);
+                        n_checks++;
+                        if (rejected) {
+                            // where the host's continuation would go (gapped_phase, make_cont): the same relay's next entry snapshot, else the
+                            // first relay further down the chain whose entry row is still ahead
+                            int a2 = aim, c2 = ck;
+                            if (ck < 2) {
+                                const int sn = ck == 0 ? r_s2 : r_s3;
+                                if (sn > 0 && drow + sn > stop_at) { nstop = drow + sn; c2 = ck + 1; }
+                            }
+                            if (!nstop) {
+                                a2 = uni(R->aim1) - 1;
+                                while (a2 >= 0) {
+                                    const DpProb *R2 = probs + a2;
+                                    const int er = (uni(R2->q0) - pr.q0) * dir + uni(R2->snap_row);
+                                    if (er > stop_at + 64) { nstop = er; c2 = 0; break; }
+                                    a2 = uni(R2->aim1) - 1;
+                                }
+                            }
+                            if (nstop > 0 && nstop <= pr.cap_row) { aim = a2; ck = c2; }
+                            else nstop = 0;
+                        }
+                    }
+                }
+                if (!nstop) { stopped = 1; i++; break; }
+                stop_at = nstop;
+                evt = uni(next_event(i));
+            }
         }
     }
     if (!overflow) flush_rows(i - 1 - row_lo);
     if (lane == 0) {
         out->best = best; out->bi = bi; out->bj = bj; out->rows = rows;
         out->cells = cells; out->clocks = yd_clock() - clk0; out->overflow = overflow; out->n_ops = 0; out->stopped = stopped; out->exit_j = exit_j;
+        out->fin_stop = stop_at; out->fin_aim1 = aim + 1; out->fin_ck = ck; out->fin_checks = n_checks;
+        if (pr.vjob1 > 0 && aim >= 0 && vjobs && !overflow) {                          // the hand-over k_verify is to judge: the one the piece ended at
+            const DpProb *R = probs + aim;
+            VerifyJob vj;
+            vj.eslot = pr.snap_idx + 1; vj.nslot = kSnapSlots * aim + (ck == 0 ? 0 : ck + 1);
+            vj.shift = (R->t0 - pr.t0) * dir; vj.drow = (R->q0 - pr.q0) * dir;
+            vjobs[pr.vjob1 - 1] = vj;
+        }
     }
 }

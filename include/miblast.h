@@ -166,6 +166,8 @@ typedef struct miblast_stats {          /* counters defined by SURVEY.md section
     double  t_dp_busy_ms;                   /* time during which at least one DP launch of the call was running: the union of the launches'
                                              * HIP-event intervals (the groups of a call's pairs launch on streams of their own and overlap;
                                              * t_dp_kernel_ms is the SUM of the launch durations)                            */
+    int64_t relay_inline_checks;            /* hand-overs a piece checked itself inside its DP launch ...              */
+    int64_t relay_inline_continued;         /* ... and pieces that went on past their first stop row there instead of in a launch of their own */
 } miblast_stats;
 
 typedef struct miblast_result miblast_result;

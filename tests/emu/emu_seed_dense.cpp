@@ -84,8 +84,12 @@ int main(int argc, char **argv) {
         // ---- packed strands: the kernel against a plain loop
         auto pack = [&](const uint8_t *codes, int64_t n, std::vector<unsigned long long> &p2, std::vector<unsigned long long> &pm) {
             const int64_t nm = (int64_t)mb::packed_wordsm(n);
-            p2.assign((size_t)std::max<int64_t>((int64_t)mb::packed_words2(n), 2 * nm) + 2, 0x1234567812345678ull); pm.assign((size_t)nm + 2, 0x1234567812345678ull);
+            // exactly what the pipeline allocates (pack_strand: packed_words2 / packed_wordsm words), guard words behind both planes
+            const size_t n2 = mb::packed_words2(n), n1 = mb::packed_wordsm(n);
+            const unsigned long long guard = 0x1234567812345678ull;
+            p2.assign(n2 + 4, guard); pm.assign(n1 + 4, guard);
             hipLaunchKernelGGL(mb::k_pack2bit_mask, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, nullptr, codes, n, p2.data(), pm.data(), nm);
+            for (size_t x = 0; x < 4; x++) if (p2[n2 + x] != guard || pm[n1 + x] != guard) return false;      // a store past a plane
             for (int64_t i = 0; i < nm * 64; i++) {
                 const unsigned c = i < n ? codes[i] : 0xFFu;
                 const unsigned two = (unsigned)(p2[(size_t)(i >> 5)] >> (62 - 2 * (i & 31))) & 3u, m = (unsigned)(pm[(size_t)(i >> 6)] >> (63 - (i & 63))) & 1u;

@@ -53,6 +53,10 @@ static inline long long yd_clock() { return 0; }
 #define YD_PIN2(a, b) ((void)0)
 #define YD_PIN5(a, b, c, d, e) ((void)0)
 #define YD_GLOBAL_UNALIGNED __attribute__((aligned(1)))
+#define yd_ld_agent(p) __atomic_load_n((p), __ATOMIC_RELAXED)
+#define yd_ld_acquire(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define yd_st_release(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define yd_fence() __sync_synchronize()
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
@@ -184,8 +188,8 @@ void k_ydrop_walls_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *
 // (the kernel proper: the __global__ wrapper of mb_kernels.hip)
 void k_ydrop2_emu(const DpProb *probs, DpOut *outs, int n, const PairPtrs *pairs, const int O, const int E, const int Y, uint8_t *arena,
                   const unsigned long long arena_bytes, unsigned long long *arena_next, const unsigned blk_bytes, unsigned long long *rowdir, uint8_t *snaps,
-                  const int *order) {
-    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order);
+                  const int *order, int first = 0, VerifyJob *vjobs = nullptr, int stamp = 0, int force_mod = 0) {
+    ydrop2_piece(probs, outs, n, pairs, O, E, Y, arena, arena_bytes, arena_next, blk_bytes, rowdir, snaps, order, first, vjobs, stamp, force_mod);
 }
 }  // namespace mb
 
@@ -325,10 +329,121 @@ static bool trace_kernels(const uint8_t *arena, unsigned long long arena_bytes, 
     return true;
 }
 
+// ---- inline mode: the hand-over INSIDE the launch (mb_ydrop2.h).  A head piece aimed at relay A, A aimed at relay B, B running to its end --
+//      both relays started cold on the side's own path, as the gapped stage plants them --, all three in ONE launch (the emulation runs the
+//      blocks one after another: relays first, so that their entry snapshots are there when the upstream piece looks).  The pieces check their
+//      hand-overs themselves and go on where one is rejected (every first check is rejected on purpose in the second pass).  Whatever they
+//      decide, following the chain as the host does -- k_verify on the hand-over each piece says it ended at -- must give the side's best cell,
+//      score and cell count.
+static int inline_cases(unsigned seed0, int n_cases) {
+    int bad = 0, concluded = 0, went_on = 0;
+    const unsigned long long arena_bytes = 96ull << 20;
+    std::vector<uint8_t> arena((size_t)arena_bytes);
+    for (int cs = 0; cs < n_cases; cs++) {
+        std::mt19937 rng(seed0 * 2654435761u + (unsigned)cs);
+        auto rnd = [&](int n) { return (int)(rng() % (unsigned)n); };
+        const int O = 400, E = 30;
+        const int Y = cs % 3 == 0 ? 3000 : cs % 3 == 1 ? 4000 : 2000 + rnd(2500);
+        const int dir = cs % 2 ? -1 : 1;
+        const int len = 700 + rnd(300);
+        const int64_t tn = len + rnd(40), qn = len + rnd(40);
+        std::vector<uint8_t> tb((size_t)tn + 2 * mb::kDevPad + 16, mb::kSep), qb((size_t)qn + 2 * mb::kDevPad + 16, mb::kSep);
+        uint8_t *tc = tb.data() + mb::kDevPad, *qc = qb.data() + mb::kDevPad;
+        for (int64_t i = 0; i < tn; i++) tc[i] = (uint8_t)rnd(4);
+        {
+            const int div = 3 + rnd(14);
+            int64_t ti = 0;
+            for (int64_t qi = 0; qi < qn; qi++) {
+                if (rnd(1000) < 8) ti += 1 + rnd(5);
+                if (rnd(1000) < 8) { qc[qi] = (uint8_t)rnd(4); continue; }
+                qc[qi] = ti < tn && rnd(100) >= div ? (tc[ti] & 3) : (uint8_t)rnd(4);
+                ti++;
+            }
+        }
+        for (int s = 0; s < 40; s++) { tc[rnd((int)tn)] |= 8; qc[rnd((int)qn)] |= 8; }
+        const int64_t t0 = dir > 0 ? rnd(10) : tn - rnd(10), q0 = dir > 0 ? rnd(10) : qn - rnd(10);
+        const int64_t na = dir > 0 ? tn - t0 : t0, nb = dir > 0 ? qn - q0 : q0;
+        const Side want = one_sided(tc, qc, t0, q0, dir, na, nb, O, E, Y);
+        mb::PairPtrs pp; pp.tc = tc; pp.qf = qc; pp.qr = qc;
+        std::vector<std::pair<int, int>> diag_cells;
+        { int i = 0, j = 0; for (size_t k = want.ops.size(); k-- > 0;) { const uint8_t o = want.ops[k]; if (o == 0) { i++; j++; diag_cells.push_back({i, j}); } else if (o == 2) i++; else j++; } }
+        if (want.bi < 500) { printf("case %d: side too short (%d rows)\n", cs, want.bi); continue; }
+        const int w = 40 + rnd(50);
+        std::pair<int, int> atA{-1, -1}, atB{-1, -1};
+        for (const auto &c : diag_cells) { if (c.first <= want.bi * 3 / 10) atA = c; if (c.first <= want.bi * 6 / 10) atB = c; }
+        if (atA.first < 1 || atB.first <= atA.first + w) { printf("case %d: no room for two relays\n", cs); continue; }
+        for (int pass = 0; pass < 3; pass++) {              // 1: every first check rejected on purpose; 2: the first three -- past the relay's last snapshot, on to the relay after
+            std::fill(arena.begin(), arena.begin() + (64 << 20), (uint8_t)0xEE);
+            std::vector<mb::DpProb> probs(3);
+            std::vector<mb::DpOut> outs(3);
+            std::vector<mb::VerifyJob> vjobs(2, mb::VerifyJob{-1, -1, 0, 0});
+            std::vector<unsigned long long> rowdir(64, ~0ull);
+            std::vector<uint8_t> snaps((size_t)3 * mb::kSnapSlots * mb::kSnapBytes, 0x11);      // (stale bytes: no header carries the stamp)
+            unsigned long long arena_next = 0;
+            memset(probs.data(), 0, sizeof(mb::DpProb) * 3);
+            mb::DpProb &hd = probs[0], &ra = probs[1], &rb = probs[2];
+            hd.t0 = (int32_t)t0; hd.q0 = (int32_t)q0; hd.na = (int32_t)na; hd.nb = (int32_t)nb; hd.dir = dir; hd.row_off = 0;
+            hd.snap_row = 0; hd.init_snap = -1; hd.snap_idx = 0; hd.snap_row2 = hd.snap_row3 = 0;
+            ra = hd; rb = hd;
+            ra.t0 = (int32_t)(t0 + dir * atA.second); ra.q0 = (int32_t)(q0 + dir * atA.first); ra.na = (int32_t)(na - atA.second); ra.nb = (int32_t)(nb - atA.first);
+            rb.t0 = (int32_t)(t0 + dir * atB.second); rb.q0 = (int32_t)(q0 + dir * atB.first); rb.na = (int32_t)(na - atB.second); rb.nb = (int32_t)(nb - atB.first);
+            ra.row_off = 8; rb.row_off = 16; ra.snap_idx = mb::kSnapSlots; rb.snap_idx = 2 * mb::kSnapSlots;
+            hd.stop_row = atA.first + w; hd.aim1 = 2; hd.vjob1 = 1; hd.cap_row = (int32_t)nb;
+            ra.snap_row = w; ra.stop_row = (atB.first - atA.first) + w; ra.aim1 = 3; ra.vjob1 = 2; ra.cap_row = ra.nb;
+            if (2 * w < ra.stop_row) ra.snap_row2 = 2 * w;
+            if (4 * w < ra.stop_row) ra.snap_row3 = 4 * w;
+            rb.snap_row = w; rb.snap_row2 = 2 * w; rb.snap_row3 = 4 * w; rb.stop_row = 0;
+            const int order[3] = {2, 1, 0};
+            const int stamp = 1000 + cs;
+            hipLaunchKernelGGL(mb::k_ydrop2_emu, dim3(3), dim3(64), 0, nullptr, probs.data(), outs.data(), 3, &pp, O, E, Y, arena.data(), arena_bytes, &arena_next, 64u << 10,
+                               rowdir.data(), snaps.data(), order, 0, vjobs.data(), stamp, pass == 0 ? 0 : pass == 1 ? 1 : -3);
+            bool ok = true, concl = true;
+            const char *why = "";
+            int cur = 0, gbest = -1, gbi = 0, gbj = 0;
+            long long c_off = 0, cells = 0, entry_cells = 0;
+            int hops = 0, checks = outs[0].fin_checks + outs[1].fin_checks;
+            for (;; hops++) {
+                const mb::DpOut &o = outs[(size_t)cur];
+                if (o.overflow) { ok = false; why = "overflow"; break; }
+                const int dr = (probs[(size_t)cur].q0 - hd.q0) * dir, dc = (probs[(size_t)cur].t0 - hd.t0) * dir;
+                if ((long long)o.best + c_off > gbest) { gbest = (int)(o.best + c_off); gbi = o.bi + dr; gbj = o.bj + dc; }
+                cells += o.cells - entry_cells;
+                if (!o.stopped) break;
+                const int aim = o.fin_aim1 - 1, ck = o.fin_ck;
+                if (aim <= cur || aim > 2 || probs[(size_t)cur].vjob1 == 0) { ok = false; why = "a piece stopped without a relay ahead"; break; }
+                const mb::VerifyJob vj{mb::kSnapSlots * cur + 1, mb::kSnapSlots * aim + (ck == 0 ? 0 : ck + 1), (probs[(size_t)aim].t0 - probs[(size_t)cur].t0) * dir,
+                                       (probs[(size_t)aim].q0 - probs[(size_t)cur].q0) * dir};
+                if (memcmp(&vj, &vjobs[(size_t)probs[(size_t)cur].vjob1 - 1], sizeof vj)) { ok = false; why = "the piece's own VerifyJob is not the hand-over it ended at"; break; }
+                mb::VerifyOut vo;
+                hipLaunchKernelGGL(mb::k_verify, dim3(1), dim3(256), 0, nullptr, &vj, &vo, 1, snaps.data(), Y, E);
+                // the piece's own verdict: it stopped after a check of its own (fin_checks > 0: the last one accepted) or because it had no room / no snapshot
+                if (!vo.ok) { concl = false; break; }
+                c_off += vo.c; entry_cells = vo.n_cells; cur = aim;
+            }
+            if (ok && concl) {
+                concluded++;
+                if (gbest != want.best || gbi != want.bi || gbj != want.bj) { ok = false; why = "best cell / score"; }
+                else if (cells != want.cells) { ok = false; why = "cells"; }
+            }
+            if (pass >= 1 && outs[0].fin_checks > 0 && outs[0].fin_stop == hd.stop_row && outs[0].stopped) { ok = false; why = "a first check that was to be rejected ended the piece"; }
+            if (outs[0].fin_stop > hd.stop_row || outs[1].fin_stop > ra.stop_row) went_on++;
+            printf("case %d pass %d: dir %+d ydrop %d, side of %d rows, relays at rows %d and %d, warm-up %d: head ended at row %d (aim %d, snapshot %d), relay A at its row %d (aim %d, snapshot %d), %d checks inside the launch, chain of %d: %s  %s %s\n",
+                   cs, pass, dir, Y, want.bi, atA.first, atB.first, w, outs[0].fin_stop, outs[0].fin_aim1 - 1, outs[0].fin_ck, outs[1].fin_stop, outs[1].fin_aim1 - 1, outs[1].fin_ck, checks, hops + 1,
+                   concl ? "concluded" : "last hand-over rejected", ok ? "ok" : "MISMATCH", why);
+            if (!ok) bad++;
+        }
+    }
+    printf("inline: %d chains concluded, %d pieces went on past their first stop\n", concluded, went_on);
+    if (!concluded || !went_on) { printf("nothing concluded or nothing went on: the test says nothing  MISMATCH\n"); bad++; }
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
     const bool relay_mode = argc > 3 && !strcmp(argv[3], "relay");      // the exactness of an accepted relay hand-over instead of the cut / check tests
+    const bool inline_mode = argc > 3 && !strcmp(argv[3], "inline");    // the hand-over checked (and, rejected, continued) inside the launch
+    if (inline_mode) return inline_cases(seed0, n_cases);
     int bad = 0, relays_accepted = 0, relays_tried = 0, n_wall_cases = 0, n_wall_changed = 0;
     const unsigned long long arena_bytes = 96ull << 20;
     std::vector<uint8_t> arena((size_t)arena_bytes);
