@@ -2175,7 +2175,8 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
 // share one k_ydrop launch, so several chunk pairs fill the GPU together
 // `members`: the pairs whose units are in `units` (nullptr: all pairs of `jobs`) -- a large call runs the gapped stages of two
 // groups of its pairs side by side, each on a stream and workspace of its own (align_pairs)
-static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, std::vector<Unit> &units, const std::vector<size_t> *members = nullptr) {
+// `in_flight`: how many gapped stages of this size share the GPU at a time (0: all groups of the call, jobs / members) -- the relay regime follows it
+static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, std::vector<Unit> &units, const std::vector<size_t> *members = nullptr, size_t in_flight = 0) {
     const size_t batch_max = (size_t)env_long("MIBLAST_GAPPED_BATCH_MAX", 4096);
     const long shadow_q0 = env_long("MIBLAST_SHADOW_Q", 1 << 16);        // spatial thinning of speculative anchors
     // anchors per round the thinning aims at: a lone pair is probed generously (an idle GPU, rounds cost latency); in a batch every
@@ -2425,16 +2426,16 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // long pieces waste less on warm-up and relays are only spent on sides that survive relay_s0 rows (16 x 1 Mb pairs, ~600
         // sides: 66 ms per call against 75 ms with the short pieces).
         // (a group of a split call shares the GPU with the other group: the regime follows the sides of the whole call)
-        const long nsides_call = (long)nsides * (long)jobs.size() / (long)std::max<size_t>(1, n_members);
-        const bool crowd = nsides_call > 400;
+        const long nsides_call = in_flight ? (long)nsides * (long)in_flight : (long)nsides * (long)jobs.size() / (long)std::max<size_t>(1, n_members);
+        const bool crowd = nsides_call > env_long("MIBLAST_CROWD_SIDES", 400);
         // (a handful of sides -- a trimmed outgroup call of the phase: every launch runs at lone-wave speed and most hand-overs are
         //  retried; 448-row pieces: 19 -> 17 DP launches and 10.2 -> 9.4 ms of DP kernel time per phase; 320 and 256 need more launches)
         const long relay_s_tiny = env_long("MIBLAST_RELAY_S_TINY", 448);
-        if (relay_s_env <= 0) relay_s = crowd ? 2048 : nsides_call > 96 ? env_long("MIBLAST_RELAY_S_MID", 768) : nsides_call > 16 ? 640 : relay_s_tiny;
+        if (relay_s_env <= 0) relay_s = crowd ? env_long("MIBLAST_RELAY_S_CROWD", 2048) : nsides_call > 96 ? env_long("MIBLAST_RELAY_S_MID", 768) : nsides_call > 16 ? env_long("MIBLAST_RELAY_S_FEW", 640) : relay_s_tiny;
         if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
         // (a handful of sides: 384 warm-up rows -- most hand-overs of such a call are rejected after 128, and a retry is a launch of
         //  its own: 17 -> 11 DP launches per phase)
-        if (relay_w_env <= 0) relay_w = crowd ? 192 : nsides_call > 16 ? 128 : env_long("MIBLAST_RELAY_W_TINY", 384);
+        if (relay_w_env <= 0) relay_w = crowd ? env_long("MIBLAST_RELAY_W_CROWD", 192) : nsides_call > 16 ? env_long("MIBLAST_RELAY_W_MID", 128) : env_long("MIBLAST_RELAY_W_TINY", 384);
         const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: unless thousands of sides are in flight, 2: always
         const bool plant_at_once = plant_env == 2 || (!crowd && plant_env != 0);
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
@@ -2916,6 +2917,17 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                     }
                     fprintf(stderr, "[miblast] round %d.%ld: %zu pieces, %zu checks, max rows %d (%lld shader clocks = %.0f per row), dp kernel total %.2f ms so far, shadow_q %ld\n",
                             round, n_subrounds, n_new, v_new, maxrows, clk, (double)clk / std::max(1, maxrows), st.t_dp_kernel_ms, shadow_q);
+                    {   // the pieces that set the launch's time: the three that ran the most rows, and how many rows the others ran
+                        std::vector<std::pair<int, size_t>> rr;
+                        for (size_t x = launched; x < pieces.size(); x++) rr.emplace_back(outs[x].rows - (pieces[x].init_piece >= 0 ? outs[(size_t)pieces[x].init_piece].rows : 0), x);
+                        std::sort(rr.begin(), rr.end(), [](const std::pair<int, size_t> &a, const std::pair<int, size_t> &b) { return a.first > b.first; });
+                        for (size_t y = 0; y < std::min<size_t>(3, rr.size()); y++) {
+                            const size_t x = rr[y].second;
+                            fprintf(stderr, "[miblast]     longest %zu: piece %zu rows %d (row_lo %d planned stop %d, ended at stop %d aim %d ck %d, %d checks inside, stopped %d, snap_row %d) nb %d\n", y, x, rr[y].first,
+                                    probs[x].row_lo, probs[x].stop_row, outs[x].fin_stop, outs[x].fin_aim1 - 1, outs[x].fin_ck, outs[x].fin_checks, outs[x].stopped, probs[x].snap_row, probs[x].nb);
+                        }
+                        if (rr.size() > 8) fprintf(stderr, "[miblast]     rows: median %d, 90th percentile %d, 99th %d\n", rr[rr.size() / 2].first, rr[rr.size() / 10].first, rr[rr.size() / 100].first);
+                    }
                 }
                 const size_t first_new = launched;
                 launched = pieces.size(); vlaunched = vjobs.size();
@@ -3081,8 +3093,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         }
         lap(3);
         st.relay_accepted += n_verify_ok; st.relay_rejected += n_verify_bad;
-        if (debug) fprintf(stderr, "[miblast] round %d: %d sides in %zu pieces, %ld launches, hand-overs %ld accepted / %ld rejected\n",
-                           round, nsides, pieces.size(), n_subrounds, n_verify_ok, n_verify_bad);
+        if (debug) fprintf(stderr, "[miblast] round %d: %d sides in %zu pieces, %ld launches, hand-overs %ld accepted / %ld rejected (regime: %ld sides in flight%s, S0 %ld S %ld W %ld, %s)\n",
+                           round, nsides, pieces.size(), n_subrounds, n_verify_ok, n_verify_bad, nsides_call, crowd ? " = crowd" : "", relay_s0, relay_s, relay_w, plant_at_once ? "chains planted with the heads" : "relays after the first stop");
 
         // ---- results of the round; traceback of the anchors reaching --gappedthresh -----------------------------
         // Speculation produces duplicates: anchors whose DP found an alignment that an earlier anchor of the unit will have
@@ -3563,6 +3575,8 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     const bool pipeline = n > 1 && !pin.walls && !pin.diag_hash16 && (pipe_env == 2 || (pipe_env == 1 && cells_avg >= 4e12));
     const size_t n_lanes = n > 1 ? (size_t)std::min<long>((long)n, std::max(1l, pipeline ? env_long("MIBLAST_PIPELINE_LANES", 6) : env_long("MIBLAST_SEED_LANES", 12))) : 1;
     bool pipelined = false;                                              // set when the lanes below have run the gapped stages as well
+    std::vector<char> group_leader;                                      // pipelined: first pair of every group (launch-level figures are counted once per group)
+    std::vector<double> lane_gapped;                                     // ... and the gapped stages' wall time per lane
     // MIBLAST_SEED_BATCHED: 1 (default) the seed stages of a call of several pairs share their launches (seed_phase_batched), and so does
     // a single pair that will fit one key buffer with room to spare (half the launches of the pair-by-pair path; chance hits expected
     // from the sizes: 2 strands x word variants x |T| x |Q| / 4^12 -- an 8 Mb pair would count its 10^8 hits only to be sent back);
@@ -3599,27 +3613,44 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         // (pipelined: a lane takes the next pair when it is done with one -- which pairs carry the long gapped stages is not known
         //  beforehand, and three of them dealt to one lane is the whole step's time; else the pairs are dealt round robin)
         std::atomic<size_t> next_pair{0};
+        // (pipelined, many pairs: a lane takes a GROUP of consecutive pairs -- their seed stages one after the other, then ONE gapped stage
+        //  for the group: its DP launches are as long as their longest piece whatever they hold, so the pairs of a group share them instead
+        //  of each paying for its own; 42 pairs on 6 lanes: groups of 3.  MIBLAST_PIPELINE_GROUP fixes the size)
+        const size_t group = !pipeline ? 1 : (size_t)std::max(1l, env_long("MIBLAST_PIPELINE_GROUP", (long)std::min<size_t>(4, std::max<size_t>(1, n / (2 * n_lanes)))));
+        const size_t n_groups = (n + group - 1) / group;
+        group_leader.assign(n, 0); lane_gapped.assign(n_lanes, 0.0);
         for (size_t lane = 0; lane < n_lanes; lane++)
             lane_threads.push_back(std::async(std::launch::async, [&, lane] {
                 try {
                     MB_HIP(hipSetDevice(ctx.device));
                     Ctx &lc = *w.lanes[lane];
-                    for (size_t k = pipeline ? next_pair.fetch_add(1) : lane; k < n; k = pipeline ? next_pair.fetch_add(1) : k + n_lanes) {
-                        PairJob &j = *jobs[k];
-                        int rc = seed_phase(lc, p, j);
-                        if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
-                        seed_host(p, j, 0); seed_host(p, j, 1); seed_finish(j);
-                        build_units(p, j, (int)k, j.units);
+                    for (size_t k0 = pipeline ? next_pair.fetch_add(group) : lane; k0 < n; k0 = pipeline ? next_pair.fetch_add(group) : k0 + n_lanes) {
+                        std::vector<size_t> mem;
+                        for (size_t k = k0; k < std::min(n, k0 + group); k++) {
+                            PairJob &j = *jobs[k];
+                            int rc = seed_phase(lc, p, j);
+                            if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
+                            seed_host(p, j, 0); seed_host(p, j, 1); seed_finish(j);
+                            build_units(p, j, (int)k, j.units);
+                            if (j.anchor_mismatch) { lane_rc[lane] = MIBLAST_EHIP; lane_err[lane] = "MIBLAST_CHECK_ANCHORS: k_hsp_anchor disagrees with the host scan"; return; }
+                            mem.push_back(k);
+                        }
                         if (!pipeline) continue;
-                        if (j.anchor_mismatch) { lane_rc[lane] = MIBLAST_EHIP; lane_err[lane] = "MIBLAST_CHECK_ANCHORS: k_hsp_anchor disagrees with the host scan"; return; }
-                        // the pair's gapped stage, right away, on this lane's stream and workspace (DpProb.pad0 = the pair's index in the call)
+                        // the group's gapped stage, right away, on this lane's stream and workspace (DpProb.pad0 = a pair's index in the call)
                         std::vector<PairPtrs> pp(n);
                         memset(pp.data(), 0, n * sizeof(PairPtrs));
-                        pp[k].tc = j.T->dev(); pp[k].qf = j.qc_d[0]; pp[k].qr = j.qc_d[1];
+                        std::vector<Unit> gu;
+                        for (size_t k : mem) {
+                            PairJob &j = *jobs[k];
+                            pp[k].tc = j.T->dev(); pp[k].qf = j.qc_d[0]; pp[k].qr = j.qc_d[1];
+                            for (Unit &u : j.units) gu.push_back(std::move(u));
+                            j.units.clear();
+                        }
                         lc.ws->pair_ptrs.ensure(n);
                         lc.ws->stage.h2d(lc.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), lc.stream);
-                        const std::vector<size_t> mem{k};
-                        rc = gapped_phase(lc, p, jobs, j.units, &mem);
+                        const int rc = gapped_phase(lc, p, jobs, gu, &mem, std::min(n_lanes, n_groups));
+                        for (Unit &u : gu) jobs[(size_t)u.pair]->units.push_back(std::move(u));          // (back to their pairs, in order)
+                        group_leader[mem[0]] = 1; lane_gapped[lane] += jobs[mem[0]]->res->stats.t_gapped;
                         if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
                     }
                 } catch (const HipFailure &e) {
@@ -3683,14 +3714,17 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         // the lanes have run every pair's gapped stage already; launch-level figures of the call = all pairs together (wall time: the call's)
         miblast_stats sum;
         memset(&sum, 0, sizeof sum);
-        for (PairJob *j : jobs) {
-            const miblast_stats &a = j->res->stats;
+        for (size_t k = 0; k < n; k++) {
+            if (!group_leader[k]) continue;
+            const miblast_stats &a = jobs[k]->res->stats;
             sum.gapped_rounds = std::max(sum.gapped_rounds, a.gapped_rounds);
             sum.dp_sides_run += a.dp_sides_run; sum.dp_cells_run += a.dp_cells_run; sum.dp_rows_run += a.dp_rows_run;
             sum.t_dp_kernel_ms += a.t_dp_kernel_ms; sum.dp_kernel_launches += a.dp_kernel_launches;
             sum.relay_accepted += a.relay_accepted; sum.relay_rejected += a.relay_rejected; sum.relay_inline_checks += a.relay_inline_checks; sum.relay_inline_continued += a.relay_inline_continued; sum.dp_reruns += a.dp_reruns;
-            sum.t_traceback_ms += a.t_traceback_ms; sum.t_merge_ms += a.t_merge_ms; sum.t_gapped += a.t_gapped;
+            sum.t_traceback_ms += a.t_traceback_ms; sum.t_merge_ms += a.t_merge_ms;
         }
+        // (the call's gapped wall time: the lanes run side by side -- the longest lane's, as the grouped branch below takes the longest group's)
+        for (double t : lane_gapped) sum.t_gapped = std::max(sum.t_gapped, t);
         for (PairJob *j : jobs) {
             miblast_stats &d = j->res->stats;
             d.t_gapped = sum.t_gapped; d.gapped_rounds = sum.gapped_rounds; d.dp_sides_run = sum.dp_sides_run; d.dp_cells_run = sum.dp_cells_run;

@@ -1,20 +1,23 @@
-"""Host side of the blast phase: the Toil job functions of
-/root/reference/src/cactus/paf/local_alignment.py that sit directly on the hot path, kept with the
-same names, arguments, return values and error behaviour so the parity tests read like the
-reference's callers:
+"""Host side of the blast phase where it differs from the reference's: the job functions of
+/root/reference/src/cactus/paf/local_alignment.py that sit on the hot path, with the reference's names, arguments, return values and
+error behaviour, written around the MI355X front ends.
 
-    run_lastz                 :29-97    one chunk-pair job  -> PAF file id
-    make_chunked_alignments   :370-408  chunk both genomes, all-vs-all run_lastz, then combine
-    combine_chunks            :336-356  dechunk + concatenate
-    chain_alignments          :607-657  merge, add the inverted copies, split by query contig when large
-    chain_tile_trim_filter_one_contig :660-727  paffy chain | tile | trim | filter | chain | filter
-    trim_unaligned_sequences  :861-904  paffy to_bed | faffy extract | paffy upconvert (second half)
+The reference's OWN function bodies are what the CPU suite runs against <repo>/bin (tests/refjobs.py imports the file unmodified:
+run_lastz, make_chunked_alignments, combine_chunks, the outgroup chain, trim_unaligned_sequences); this module exists for what that
+cannot cover -- the GPU box has no /root/reference, a deployment has no Toil stand-ins -- and holds only what the AMD path needs:
 
-What differs, on purpose: the `lastz` / `run_kegalign` found on PATH are the MI355X front ends in
-<repo>/bin (or, with MIBLAST_INPROCESS=1, the same code through the C ABI via ctypes), AMD GPUs are
-requested as 'rocm:N', faffy and paffy's chunk/dechunk are replaced by cactus_amd.paf.chunking, and the `paffy`
-of the chaining stage is <repo>/bin/paffy (chain, tile and trim run on the GPU; with MIBLAST_INPROCESS=1 the whole
-per-contig job is one call through include/mipaf.h).  cactus_consolidated and everything after it are untouched.
+    select_lastz_params       :41-53    distance -> option string
+    lastz_command             :54-68    argv of one chunk-pair job (bin/lastz / bin/run_kegalign take the reference's grammar)
+    run_lastz                 :29-97    one chunk-pair job -> PAF file id; MIBLAST_INPROCESS=1: the same job through the C ABI
+    make_chunked_alignments   :370-408  chunk both genomes, one run_lastz job per chunk pair ('rocm:N' accelerators), combine
+    combine_chunks            :336-367  dechunk + concatenate (batched)
+    make_ingroup_to_outgroup_alignments_0..3  :421-526  the outgroup chain with trimming between the calls
+    chain_alignments, chain_tile_trim_filter_one_contig  :607-727  paffy chain | tile | trim | filter
+
+faffy / paffy's text steps are cactus_amd.paf.chunking (or the native text code behind bin/faffy, bin/paffy); the chaining stage's
+`paffy` is <repo>/bin/paffy.  trim_unaligned_sequences (:861-904) has no mirror: its three tools are bin/paffy to_bed, bin/faffy
+extract, bin/paffy upconvert, driven by the reference's own body in the CPU suite and by cactus_amd.paf.chunking.trim_to_aligned in
+process.  cactus_consolidated and everything after it are untouched.
 """
 from __future__ import annotations
 
@@ -28,65 +31,64 @@ from cactus_amd.shared.common import cactus_call, cactus_clamp_memory, getLogLev
 from cactus_amd.shared.configWrapper import accelerator_string
 
 STDERR_KEYWORDS = ['terminate', 'error', 'fail', 'assert', 'signal', 'abort', 'segmentation', 'sigsegv', 'kill']
+DIVERGENCE_CLASSES = ("one", "two", "three", "four", "five")
+
+
+def _blast(params):
+    return params.find("blast")
+
+
+def _blast_int(params, name, default):
+    return getOptionalAttrib(_blast(params), name, typeFn=int, default=default)
 
 
 def select_lastz_params(distance, params, gpu):
-    """distance -> lastz option string, exactly the rule of local_alignment.py:44-51: the first of
-    one..five whose divergence bound is >= distance, else "default" (or always default if useDefault)."""
-    lastz_params_node = params.find("blast")
-    lastz_divergence_node = lastz_params_node.find("kegalignArguments" if gpu else "lastzArguments")
-    divergences = params.find("constants").find("divergences")
-    lastz_params = lastz_divergence_node.attrib["default"]
-    if not getOptionalAttrib(divergences, 'useDefault', typeFn=bool, default=False):
-        for i in "one", "two", "three", "four", "five":
-            if distance <= float(divergences.attrib[i]):
-                lastz_params = lastz_divergence_node.attrib[i]
-                break
-    return lastz_params
+    """The option set of a pair at `distance` (:44-51): the first divergence class whose bound is not below it, else "default";
+    always "default" with <divergences useDefault>."""
+    option_sets = _blast(params).find("kegalignArguments" if gpu else "lastzArguments").attrib
+    bounds = params.find("constants").find("divergences")
+    if getOptionalAttrib(bounds, 'useDefault', typeFn=bool, default=False):
+        return option_sets["default"]
+    return next((option_sets[c] for c in DIVERGENCE_CLASSES if distance <= float(bounds.attrib[c])), option_sets["default"])
+
+
+def lastz_command(target_fa, query_fa, options, gpu, cores):
+    """argv of the chunk-pair job (:54-68).  CPU form: file names carry lastz's modifiers; GPU form: bare names, and the devices /
+    host threads of the job go last as separate tokens."""
+    if gpu:
+        assert gpu > 0
+        return ['run_kegalign', target_fa, query_fa, '--format=paf:wfmash'] + options.split(' ') + ['--num_gpu', str(gpu), '--num_threads', str(cores)]
+    return ['lastz', target_fa + '[multiple][nameparse=darkspace]', query_fa + '[nameparse=darkspace]', '--format=paf:wfmash'] + options.split(' ')
+
+
+def stderr_offence(messages):
+    """(keyword, line) of the first stderr line the GPU branch treats as a failure although the exit code was 0 (:75-83), or None."""
+    for line in (messages or "").lower().split("\n"):
+        if line.startswith("signals delivered"):
+            continue
+        hit = next((k for k in STDERR_KEYWORDS if k in line and 'signals' not in line), None)
+        if hit:
+            return hit, line
+    return None
 
 
 def run_lastz(job, name_A, genome_A, name_B, genome_B, distance, params):
-    work_dir = job.fileStore.getLocalTempDir()
-    alignment_file = os.path.join(work_dir, '{}_{}.paf'.format(name_A, name_B))
-    genome_a_file = os.path.join(work_dir, '{}.fa'.format(name_A))
-    genome_b_file = os.path.join(work_dir, '{}.fa'.format(name_B))
-    job.fileStore.readGlobalFile(genome_A, genome_a_file)
-    job.fileStore.readGlobalFile(genome_B, genome_b_file)
-
-    lastz_params_node = params.find("blast")
-    gpu = getOptionalAttrib(lastz_params_node, 'gpu', typeFn=int, default=0)
-    cpu = getOptionalAttrib(lastz_params_node, 'cpu', typeFn=int, default=None)
-    lastz_params = select_lastz_params(distance, params, gpu)
-    if gpu:
-        lastz_bin = 'run_kegalign'
-        suffix_a, suffix_b = '', ''
-        assert gpu > 0
-        lastz_params += ' --num_gpu {} --num_threads {}'.format(gpu, job.cores)
-    else:
-        lastz_bin = 'lastz'
-        suffix_a = '[multiple][nameparse=darkspace]'
-        suffix_b = '[nameparse=darkspace]'
-
-    lastz_cmd = [lastz_bin,
-                 '{}{}'.format(os.path.basename(genome_a_file), suffix_a),
-                 '{}{}'.format(os.path.basename(genome_b_file), suffix_b),
-                 '--format=paf:wfmash'] + lastz_params.split(' ')
-
+    scratch = job.fileStore.getLocalTempDir()
+    local = {name: os.path.join(scratch, name + '.fa') for name in (name_A, name_B)}
+    job.fileStore.readGlobalFile(genome_A, local[name_A])
+    job.fileStore.readGlobalFile(genome_B, local[name_B])
+    paf_path = os.path.join(scratch, name_A + '_' + name_B + '.paf')
+    gpu, cpu = _blast_int(params, 'gpu', 0), _blast_int(params, 'cpu', None)
+    command = lastz_command(name_A + '.fa', name_B + '.fa', select_lastz_params(distance, params, gpu), gpu, job.cores)
     if os.environ.get("MIBLAST_INPROCESS") == "1":
-        messages = _run_inprocess(lastz_cmd, work_dir, alignment_file)
+        messages = _run_inprocess(command, scratch, paf_path)
     else:
-        messages = cactus_call(parameters=lastz_cmd, outfile=alignment_file, work_dir=work_dir, returnStdErr=True,
-                               gpus=gpu, cpus=cpu, job_memory=job.memory)
-
-    if gpu:
-        # same guard as local_alignment.py:75-83 -- our front end keeps stderr empty on success
-        for line in (messages or "").lower().split("\n"):
-            if not line.startswith("signals delivered"):
-                for keyword in STDERR_KEYWORDS:
-                    if keyword in line and 'signals' not in line:
-                        job.fileStore.logToMaster("KegAlign offending line: " + line)
-                        raise RuntimeError('{} exited 0 but keyword "{}" found in stderr'.format(lastz_cmd, keyword))
-    return job.fileStore.writeGlobalFile(alignment_file)
+        messages = cactus_call(parameters=command, outfile=paf_path, work_dir=scratch, returnStdErr=True, gpus=gpu, cpus=cpu, job_memory=job.memory)
+    offence = stderr_offence(messages) if gpu else None            # (our front ends keep stderr empty on success)
+    if offence:
+        job.fileStore.logToMaster("KegAlign offending line: " + offence[1])
+        raise RuntimeError('{} exited 0 but keyword "{}" found in stderr'.format(command, offence[0]))
+    return job.fileStore.writeGlobalFile(paf_path)
 
 
 def _run_inprocess(lastz_cmd, work_dir, alignment_file):
@@ -123,148 +125,98 @@ def _run_inprocess(lastz_cmd, work_dir, alignment_file):
 
 
 def combine_chunks(job, chunked_alignment_files, batch_size):
-    if len(chunked_alignment_files) >= 2 * batch_size:
-        batch_results = []
-        for chunk_idx in range(math.ceil(len(chunked_alignment_files) / batch_size)):
-            batch = chunked_alignment_files[chunk_idx * batch_size: chunk_idx * batch_size + batch_size]
-            batch_results.append(job.addChildJobFn(combine_chunks, batch, batch_size).rv())
-        return job.addFollowOnJobFn(merge_combined_chunks, batch_results).rv()
-    alignment_file = job.fileStore.getLocalTempFile()
-    for chunk in chunked_alignment_files:
-        chunking.paf_dechunk(job.fileStore.readGlobalFile(chunk), alignment_file, append=True)
-        job.fileStore.deleteGlobalFile(chunk)
-    return job.fileStore.writeGlobalFile(alignment_file)
+    """:336-356 -- every chunk pair's PAF back in genome coordinates (paffy dechunk), end to end; from two batches' worth of files on,
+    one child job per batch and a merge behind them."""
+    n = len(chunked_alignment_files)
+    if n >= 2 * batch_size:
+        parts = [job.addChildJobFn(combine_chunks, chunked_alignment_files[at:at + batch_size], batch_size).rv() for at in range(0, n, batch_size)]
+        assert len(parts) == math.ceil(n / batch_size)
+        return job.addFollowOnJobFn(merge_combined_chunks, parts).rv()
+    combined = job.fileStore.getLocalTempFile()
+    for file_id in chunked_alignment_files:
+        chunking.paf_dechunk(job.fileStore.readGlobalFile(file_id), combined, append=True)
+        job.fileStore.deleteGlobalFile(file_id)
+    return job.fileStore.writeGlobalFile(combined)
 
 
 def merge_combined_chunks(job, combined_chunks):
-    output_path = job.fileStore.getLocalTempFile()
-    with open(output_path, 'a') as output_file:
-        for chunk in combined_chunks:
-            with open(job.fileStore.readGlobalFile(chunk, mutable=True), 'r') as chunk_file:
-                output_file.write(chunk_file.read())
-            job.fileStore.deleteGlobalFile(chunk)
-    return job.fileStore.writeGlobalFile(output_path)
+    merged = job.fileStore.getLocalTempFile()
+    concat_global_files(job, combined_chunks, merged)
+    return job.fileStore.writeGlobalFile(merged)
 
 
 def make_chunked_alignments(job, event_a, genome_a, event_b, genome_b, distance, params):
-    lastz_params_node = params.find("blast")
-    gpu = getOptionalAttrib(lastz_params_node, 'gpu', typeFn=int, default=0)
-    lastz_cores = getOptionalAttrib(lastz_params_node, 'cpu', typeFn=int, default=None)
-    lastz_memory = getOptionalAttrib(lastz_params_node, 'lastz_memory', typeFn=int, default=None)
-    chunk_attr = 'bigChunkSize' if gpu else 'chunkSize'
+    blast = _blast(params).attrib
+    gpu, cores, fixed_memory = _blast_int(params, 'gpu', 0), _blast_int(params, 'cpu', None), _blast_int(params, 'lastz_memory', None)
+    chunk_size, overlap = int(blast['bigChunkSize' if gpu else 'chunkSize']), int(blast["overlapSize"])
 
-    def make_chunks(genome):
-        output_chunks_dir = job.fileStore.getLocalTempDir()
-        chunk_files = chunking.fasta_chunk(job.fileStore.readGlobalFile(genome), output_chunks_dir,
-                                           int(params.find("blast").attrib[chunk_attr]),
-                                           int(params.find("blast").attrib["overlapSize"]))
-        return [job.fileStore.writeGlobalFile(chunk, cleanup=True) for chunk in chunk_files]
+    def chunks_of(genome):
+        files = chunking.fasta_chunk(job.fileStore.readGlobalFile(genome), job.fileStore.getLocalTempDir(), chunk_size, overlap)
+        return [job.fileStore.writeGlobalFile(f, cleanup=True) for f in files]
 
-    chunks_a = make_chunks(genome_a)
-    chunks_b = make_chunks(genome_b)
-    accelerators = accelerator_string(gpu)
-    chunked_alignment_files = []
-    for i, chunk_a in enumerate(chunks_a):
-        for j, chunk_b in enumerate(chunks_b):
-            memory = lastz_memory if lastz_memory else max(200000000, 15 * (chunk_a.size + chunk_b.size))
-            chunked_alignment_files.append(job.addChildJobFn(run_lastz, '{}_{}'.format(event_a, i), chunk_a,
-                                                             '{}_{}'.format(event_b, j), chunk_b, distance, params,
-                                                             cores=lastz_cores,
-                                                             disk=max(4 * (chunk_a.size + chunk_b.size), memory),
-                                                             memory=memory, accelerators=accelerators).rv())
-    dechunk_batch_size = getOptionalAttrib(lastz_params_node, 'dechunkBatchSize', typeFn=int, default=int(1e9))
-    return job.addFollowOnJobFn(combine_chunks, chunked_alignment_files, dechunk_batch_size).rv()
+    pair_pafs = []
+    pieces_a, pieces_b = chunks_of(genome_a), chunks_of(genome_b)
+    for i, a in enumerate(pieces_a):
+        for j, b in enumerate(pieces_b):
+            both = a.size + b.size
+            memory = fixed_memory or max(200000000, 15 * both)
+            pair_pafs.append(job.addChildJobFn(run_lastz, '{}_{}'.format(event_a, i), a, '{}_{}'.format(event_b, j), b, distance, params,
+                                               cores=cores, disk=max(4 * both, memory), memory=memory,
+                                               accelerators=accelerator_string(gpu)).rv())        # AMD GPUs: 'rocm:N' (the reference asks for 'cuda:N')
+    return job.addFollowOnJobFn(combine_chunks, pair_pafs, _blast_int(params, 'dechunkBatchSize', int(1e9))).rv()
 
 
-# ---- ingroup -> outgroup alignments with progressive trimming (local_alignment.py:411-526) -----------------------------
+# ---- ingroup -> outgroup alignments with progressive trimming (:411-526) ----------------------------------------------------
 def invert_alignments(job, alignment_file):
-    """ Invert the pafs in the alignment_file (paffy invert, :411-418) """
-    src = job.fileStore.readGlobalFile(alignment_file)
-    dst = job.fileStore.getLocalTempFile()
-    with open(src) as fin, open(dst, "w") as fout:
-        for line in fin:
-            if line.strip():
-                fout.write(chunking.paf_invert_line(line))
+    """paffy invert (:411-418): query and target of every record swapped"""
+    inverted = job.fileStore.getLocalTempFile()
+    with open(job.fileStore.readGlobalFile(alignment_file)) as records, open(inverted, "w") as out:
+        out.writelines(chunking.paf_invert_line(r) for r in records if r.strip())
     job.fileStore.deleteGlobalFile(alignment_file)
-    return job.fileStore.writeGlobalFile(dst)
+    return job.fileStore.writeGlobalFile(inverted)
 
 
 def make_ingroup_to_outgroup_alignments_0(job, ingroup_event, outgroup_events, event_names_to_sequences, distances, params):
-    alignment_file = job.addChildJobFn(make_ingroup_to_outgroup_alignments_1, ingroup_event, outgroup_events,
-                                       event_names_to_sequences, distances, params).rv()
-    # Invert the final alignment so that the query is the outgroup and the target is the ingroup
-    return job.addFollowOnJobFn(invert_alignments, alignment_file).rv()
+    chain = job.addChildJobFn(make_ingroup_to_outgroup_alignments_1, ingroup_event, outgroup_events, event_names_to_sequences, distances, params).rv()
+    return job.addFollowOnJobFn(invert_alignments, chain).rv()         # (the outgroup becomes the query)
 
 
 def make_ingroup_to_outgroup_alignments_1(job, ingroup_event, outgroup_events, event_names_to_sequences, distances, params):
     """events are plain names here (the reference passes tree nodes and uses .iD); distances is keyed by (ingroup, outgroup)"""
-    outgroup = outgroup_events[0]
-    alignment = job.addChildJobFn(make_chunked_alignments, outgroup, event_names_to_sequences[outgroup],
-                                  ingroup_event, event_names_to_sequences[ingroup_event], distances[ingroup_event, outgroup], params).rv()
-    if len(outgroup_events) > 1:
-        return job.addFollowOnJobFn(make_ingroup_to_outgroup_alignments_2, alignment, ingroup_event, outgroup_events[1:],
-                                    dict(event_names_to_sequences), distances, params).rv()
-    return alignment
+    nearest, later = outgroup_events[0], outgroup_events[1:]
+    found = job.addChildJobFn(make_chunked_alignments, nearest, event_names_to_sequences[nearest], ingroup_event,
+                              event_names_to_sequences[ingroup_event], distances[ingroup_event, nearest], params).rv()
+    if not later:
+        return found
+    return job.addFollowOnJobFn(make_ingroup_to_outgroup_alignments_2, found, ingroup_event, later, dict(event_names_to_sequences), distances, params).rv()
 
 
 def make_ingroup_to_outgroup_alignments_2(job, alignments, ingroup_event, outgroup_events, event_names_to_sequences, distances, params):
-    # identify all ingroup sub-sequences that remain unaligned longer than a threshold (:451-475)
-    work_dir = job.fileStore.getLocalTempDir()
-    alignments_file = os.path.join(work_dir, '{}.paf'.format(ingroup_event))
-    job.fileStore.readGlobalFile(alignments, alignments_file)
-    ingroup_seq_file = os.path.join(work_dir, '{}.fa'.format(ingroup_event))
-    job.fileStore.readGlobalFile(event_names_to_sequences[ingroup_event], ingroup_seq_file)
-    bed = chunking.paf_to_bed_unaligned(alignments_file, ingroup_seq_file, int(params.find("blast").attrib['trimMinSize']))
-    seq_file = os.path.join(work_dir, '{}_subseq.fa'.format(ingroup_event))
-    chunking.fasta_extract(bed, ingroup_seq_file, seq_file, int(params.find("blast").attrib['trimFlanking']))
-    # replace the ingroup sequences with remaining sequences and recurse over the remaining outgroups
-    event_names_to_sequences[ingroup_event] = job.fileStore.writeGlobalFile(seq_file)
-    if os.path.getsize(seq_file) == 0:
+    """what of the ingroup stayed unaligned (stretches of trimMinSize and more, trimFlanking bases around them: :451-489) goes to the
+    next outgroup"""
+    scratch = job.fileStore.getLocalTempDir()
+    paf, fasta, rest = (os.path.join(scratch, ingroup_event + ext) for ext in ('.paf', '.fa', '_subseq.fa'))
+    job.fileStore.readGlobalFile(alignments, paf)
+    job.fileStore.readGlobalFile(event_names_to_sequences[ingroup_event], fasta)
+    blast = _blast(params).attrib
+    chunking.fasta_extract(chunking.paf_to_bed_unaligned(paf, fasta, int(blast['trimMinSize'])), fasta, rest, int(blast['trimFlanking']))
+    event_names_to_sequences[ingroup_event] = job.fileStore.writeGlobalFile(rest)
+    if os.path.getsize(rest) == 0:
         return alignments
-    alignments2 = job.addChildJobFn(make_ingroup_to_outgroup_alignments_1, ingroup_event, outgroup_events,
-                                    event_names_to_sequences, distances, params).rv()
-    return job.addFollowOnJobFn(make_ingroup_to_outgroup_alignments_3, ingroup_event, event_names_to_sequences[ingroup_event],
-                                alignments, alignments2).rv()
+    more = job.addChildJobFn(make_ingroup_to_outgroup_alignments_1, ingroup_event, outgroup_events, event_names_to_sequences, distances, params).rv()
+    return job.addFollowOnJobFn(make_ingroup_to_outgroup_alignments_3, ingroup_event, event_names_to_sequences[ingroup_event], alignments, more).rv()
 
 
 def make_ingroup_to_outgroup_alignments_3(job, ingroup_event, ingroup_seq_file, alignments, alignments2, has_resources=False):
-    # use paffy dechunk --query to correct the subsequence coordinates of alignments2, then cat (:515-520)
-    a1 = job.fileStore.readGlobalFile(alignments)
-    a2 = job.fileStore.readGlobalFile(alignments2)
-    merged = job.fileStore.getLocalTempFile()
-    with open(merged, "w") as out, open(a1) as f1:
-        out.write(f1.read())
-    chunking.paf_dechunk(a2, merged, query_only=True, append=True)
+    """the later outgroups' records back in the ingroup's own coordinates (paffy dechunk --query, :515), behind the first outgroup's"""
+    together = job.fileStore.getLocalTempFile()
+    shutil.copyfile(job.fileStore.readGlobalFile(alignments), together)
+    chunking.paf_dechunk(job.fileStore.readGlobalFile(alignments2), together, query_only=True, append=True)
     job.fileStore.deleteGlobalFile(ingroup_seq_file)
-    return job.fileStore.writeGlobalFile(merged)
+    return job.fileStore.writeGlobalFile(together)
 
 
-def trim_unaligned_sequences(job, sequences, alignments, params, has_resources=False):
-    """:861-904 -- the genomes cut down to what the blast alignments cover (+ trimOutgroupFlanking), and the alignments rewritten to
-    those sub-sequences.  The three tools run as the reference runs them -- bin/paffy to_bed / upconvert and bin/faffy extract are the
-    native text code of libmiblast (mp_text.cpp); the same steps in process: cactus_amd.paf.chunking.trim_to_aligned."""
-    work_dir = job.fileStore.getLocalTempDir()
-    alignments_file = os.path.join(work_dir, 'alignments.paf')
-    job.fileStore.readGlobalFile(alignments, alignments_file)
-    bed_file = alignments_file + '.bed'
-    cactus_call(parameters=['paffy', 'to_bed', "--binary", "--excludeUnaligned", "--includeInverted",
-                            '-i', alignments_file, "--logLevel", getLogLevelString()], outfile=bed_file, returnStdErr=True, job_memory=job.memory)
-    trimmed_sequence_files = []
-    for i, sequence in enumerate(sequences):
-        seq_file = os.path.join(work_dir, '{}.fa'.format(i))
-        job.fileStore.readGlobalFile(sequence, seq_file)
-        trimmed_seq_file = seq_file + '.trim'
-        cactus_call(parameters=['faffy', 'extract', "-i", bed_file, seq_file, "--skipMissing", "--minSize", "1",
-                                "--flank", params.find("blast").attrib["trimOutgroupFlanking"], "--logLevel", getLogLevelString()],
-                    outfile=trimmed_seq_file, returnStdErr=True, job_memory=job.memory)
-        trimmed_sequence_files.append(trimmed_seq_file)
-    trimmed_alignments = alignments_file + '.trim'
-    cactus_call(parameters=['paffy', 'upconvert', "-i", alignments_file, "--logLevel", getLogLevelString()] + trimmed_sequence_files,
-                outfile=trimmed_alignments, returnStdErr=True)
-    return [job.fileStore.writeGlobalFile(i) for i in trimmed_sequence_files], job.fileStore.writeGlobalFile(trimmed_alignments)
-
-
-# ---- chaining stage (local_alignment.py:594-734): chain -> tile -> trim -> filter -> chain -> filter ---------------------------
+# ---- chaining stage (:594-734): chain -> tile -> trim -> filter -> chain -> filter ------------------------------------------
 # Same job functions, arguments, file flow and thresholds as the reference; written around two small helpers (the paffy command
 # lines of one per-contig job, and "run these piped commands into this file").
 def concat_global_files(job, file_ids, output_path):
@@ -304,11 +256,11 @@ def chain_alignments(job, alignment_files, alignment_names, reference_event_name
     """:607-657 -- merge the PAF files, append their inverted copy, and chain the lot: in one job when the merged file is at most
     chainSplitMinSize bytes, else split by query contig (paffy split_file, parts of >= chainContigGroupSize bases) with one job
     per part and a merge at the end."""
-    work_dir = job.fileStore.getLocalTempDir()
-    merged = os.path.join(work_dir, 'merged.paf')
+    scratch = job.fileStore.getLocalTempDir()
+    merged = os.path.join(scratch, 'merged.paf')
     concat_global_files(job, alignment_files, merged)
     if include_inverted_alignments:
-        snapshot = os.path.join(work_dir, 'merged_copy.paf')           # invert reads a copy while its output is appended to the original
+        snapshot = os.path.join(scratch, 'merged_copy.paf')            # invert reads a copy while its output is appended to the original
         shutil.copyfile(merged, snapshot)
         _pipe_to(job, ['paffy', 'invert', '--inputFile', snapshot], merged, append=True)
         os.remove(snapshot)
@@ -320,7 +272,7 @@ def chain_alignments(job, alignment_files, alignment_names, reference_event_name
 
     if os.path.getsize(merged) <= int(_blast_attrib(params, "chainSplitMinSize", "1000000000")):
         return one_job(merged)
-    prefix = os.path.join(work_dir, 'split_')
+    prefix = os.path.join(scratch, 'split_')
     cactus_call(parameters=['paffy', 'split_file', '--inputFile', merged, '--query', '--prefix', prefix,
                             '--minLength', str(int(_blast_attrib(params, "chainContigGroupSize", "10000000"))),
                             '--logLevel', getLogLevelString()], job_memory=job.memory)
@@ -334,9 +286,9 @@ def chain_tile_trim_filter_one_contig(job, split_file_id, reference_event_name, 
     then the primaries that keep their chain score, then the demoted ones relabelled tp:A:S / tl:i:2.  With MIBLAST_INPROCESS=1 the
     job is one mipaf_chain_tile_trim_filter call (one device context instead of one per piped process); the bytes are the same
     either way (tests/test_zz_chain_gpu.py)."""
-    work_dir = job.fileStore.getLocalTempDir()
-    source = os.path.join(work_dir, 'input.paf')
-    result = os.path.join(work_dir, 'output.paf')
+    scratch = job.fileStore.getLocalTempDir()
+    source = os.path.join(scratch, 'input.paf')
+    result = os.path.join(scratch, 'output.paf')
     job.fileStore.readGlobalFile(split_file_id, source)
     secondary = int(_blast_attrib(params, "outputSecondaryAlignments")) != 0
 
@@ -359,8 +311,8 @@ def chain_tile_trim_filter_one_contig(job, split_file_id, reference_event_name, 
         if not secondary:
             _pipe_to(job, first_pass + [cmd['chain'], cmd['score']], result)
         else:
-            filtered = os.path.join(work_dir, 'filter.paf')
-            rechained = os.path.join(work_dir, 'primary_chain.paf')
+            filtered = os.path.join(scratch, 'filter.paf')
+            rechained = os.path.join(scratch, 'primary_chain.paf')
             _pipe_to(job, first_pass, filtered)
             _pipe_to(job, [cmd['primary'] + ['--inputFile', filtered, '--invert']], result)
             _pipe_to(job, [cmd['chain'] + ['--inputFile', filtered]], rechained)

@@ -1,9 +1,12 @@
 """Process boundary of the blast path: the local-binaries slice of cactus_call
 (/root/reference/src/cactus/shared/common.py:732-994) and getOptionalAttrib (:226), with the same
 argument names, stdout->outfile behaviour and RuntimeError-on-non-zero-exit convention
-(:962-988).  Docker / singularity modes, memory accounting and realtime logging are out of
-scope (orchestration, unchanged).  The MI355X front ends live in <repo>/bin and
-are put first on PATH, which is how CACTUS_BINARIES_MODE=local finds `lastz` and `paffy` (:793-795)."""
+(:962-988).  The MI355X front ends live in <repo>/bin and are put first on PATH, which is how
+CACTUS_BINARIES_MODE=local finds `lastz` and `paffy` (:793-795).  The container modes are here as far as the GPU job needs them:
+dockerCommand / singularityCommand build the argv of common.py:536-560 / :646-705 with the AMD way of handing a container its GPUs
+(the reference's `--gpus N` / `--nv` are NVIDIA's; SURVEY 8b, last row) and cactus_call wraps a command in them under
+CACTUS_BINARIES_MODE=docker|singularity.  Image pulls, memory accounting and realtime logging stay with the reference
+(orchestration, unchanged)."""
 from __future__ import annotations
 
 import os
@@ -32,6 +35,52 @@ def getOptionalAttrib(node, attribName, typeFn=None, default=None, errorIfNotPre
     return default
 
 
+# ---- containers on an AMD node (common.py:536-560 singularityCommand, :646-705 dockerCommand) -----------------------------------------
+# A ROCm container sees a GPU through the kernel driver's device nodes, not through a runtime hook: /dev/kfd (compute) and the render
+# nodes under /dev/dri, with the groups that own them; WHICH GPUs of the node is ROCR_VISIBLE_DEVICES inside the container (the role
+# `--gpus "device=..."` plays for NVIDIA under Slurm, common.py:668-671).  Singularity / Apptainer bind the same with --rocm.
+AMD_DOCKER_DEVICE_ARGS = ['--device=/dev/kfd', '--device=/dev/dri', '--group-add', 'video', '--group-add', 'render',
+                          '--security-opt', 'seccomp=unconfined']
+
+
+def amd_visible_devices(gpus, environ=None):
+    """The value of ROCR_VISIBLE_DEVICES for a job of `gpus` GPUs: what the scheduler assigned if it says (Slurm's SLURM_JOB_GPUS, or a
+    ROCR_ / HIP_VISIBLE_DEVICES already set for the worker), else the first `gpus` ordinals."""
+    environ = os.environ if environ is None else environ
+    for name in ('SLURM_JOB_GPUS', 'ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES'):
+        if environ.get(name):
+            return environ[name]
+    return ','.join(str(i) for i in range(int(gpus)))
+
+
+def dockerCommand(tool=None, work_dir=None, parameters=None, rm=True, port=None, dockstore=None, entrypoint=None, gpus=None, cpus=None,
+                  environ=None):
+    """argv of `docker run` for one tool invocation: the reference's call (:660-705) with the GPUs of the job handed over the AMD way.
+    `tool` is the image (the reference resolves it with getDockerImage(gpu=...): the `-gpu` tag suffix of :383-397 is its concern)."""
+    work_dir = os.getcwd() if work_dir is None else work_dir
+    call = ['docker', 'run', '--interactive', '--net=host', '--log-driver=none', '-u', '%s:%s' % (os.getuid(), os.getgid()),
+            '-v', '{}:/data'.format(os.path.abspath(work_dir))]
+    if gpus:
+        call += AMD_DOCKER_DEVICE_ARGS + ['-e', 'ROCR_VISIBLE_DEVICES=' + amd_visible_devices(gpus, environ), '-e', 'HSA_ENABLE_IPC_MODE_LEGACY=0']
+    if cpus:
+        call += ['--cpus', str(cpus)]
+    call += ['--entrypoint', entrypoint if entrypoint is not None else '/opt/cactus/wrapper.sh']
+    if port is not None:
+        call += ['-p', '{0}:{0}'.format(port)]
+    if rm:
+        call += ['--rm']
+    return call + [tool] + list(parameters or [])
+
+
+def singularityCommand(tool=None, work_dir=None, parameters=None, port=None, file_store=None, gpus=None, cpus=None):
+    """argv of `singularity exec` (:536-585): --rocm where the reference passes --nv; `tool` is the sandbox / image path."""
+    work_dir = os.getcwd() if work_dir is None else work_dir
+    call = ['singularity', '--silent', 'exec', '-u', '-B', '{}:{}'.format(os.path.abspath(work_dir), '/mnt'), '--pwd', '/mnt']
+    if gpus:
+        call += ['--rocm']
+    return call + [tool] + list(parameters or [])
+
+
 def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpus=None, cpus=None, job_memory=None,
                 outappend=False, check_output=False, env=None):
     """Runs one command locally, or -- when `parameters` is a list of commands -- the commands piped into each other as the
@@ -41,6 +90,15 @@ def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpu
     assert parameters
     commands = [parameters] if isinstance(parameters[0], str) else list(parameters)
     call_env = dict(os.environ if env is None else env)
+    mode = call_env.get("CACTUS_BINARIES_MODE", "local")
+    if mode in ("docker", "singularity"):
+        # the tool runs inside the image named by CACTUS_DOCKER_IMAGE / CACTUS_SINGULARITY_IMG (the reference resolves these itself:
+        # getDockerImage, importSingularityImage); the job's GPUs go in the AMD way
+        image = call_env.get("CACTUS_DOCKER_IMAGE" if mode == "docker" else "CACTUS_SINGULARITY_IMG")
+        if not image:
+            raise RuntimeError("CACTUS_BINARIES_MODE={} needs {}".format(mode, "CACTUS_DOCKER_IMAGE" if mode == "docker" else "CACTUS_SINGULARITY_IMG"))
+        wrap = dockerCommand if mode == "docker" else singularityCommand
+        commands = [wrap(tool=image, work_dir=work_dir, parameters=c, gpus=gpus, cpus=cpus) for c in commands]
     call_env["PATH"] = BIN_DIR + os.pathsep + call_env.get("PATH", "")
     stdout = subprocess.PIPE if check_output else None
     fh = None

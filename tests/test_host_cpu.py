@@ -296,3 +296,42 @@ def test_env_table_is_the_one_the_code_gives():
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "env_table.py")], capture_output=True, text=True, cwd=root)
     assert out.returncode == 0, out.stderr
     assert out.stdout == open(os.path.join(root, "ENV.md")).read(), "run: python scripts/env_table.py > ENV.md"
+
+
+def test_container_modes_hand_the_gpus_over_the_amd_way(tmp_path, monkeypatch):
+    """common.py:536-560 (singularity exec ... --nv) and :646-705 (docker run ... --gpus N | --gpus "device=$SLURM_JOB_GPUS"): the same
+    call shapes with the AMD way of giving a container its GPUs -- the driver's device nodes + groups and ROCR_VISIBLE_DEVICES for docker,
+    --rocm for singularity (last row) -- and nothing GPU-related on a CPU job."""
+    from cactus_amd.shared import common
+    argv = ['run_kegalign', 'A.fa', 'B.fa', '--format=paf:wfmash', '--num_gpu', '2', '--num_threads', '8']
+    d = common.dockerCommand(tool='quay.io/cactus:amd', work_dir=str(tmp_path), parameters=argv, gpus=2, cpus=8, environ={})
+    assert d[:2] == ['docker', 'run'] and d[-len(argv):] == argv and d[-len(argv) - 1] == 'quay.io/cactus:amd'
+    assert '--device=/dev/kfd' in d and '--device=/dev/dri' in d and '--gpus' not in d
+    assert d[d.index('--group-add') + 1] == 'video' and 'render' in d
+    assert 'ROCR_VISIBLE_DEVICES=0,1' in d and d[d.index('--cpus') + 1] == '8'
+    assert d[d.index('-v') + 1] == '{}:/data'.format(tmp_path) and d[d.index('--entrypoint') + 1] == '/opt/cactus/wrapper.sh' and '--rm' in d
+    # Slurm names the GPUs of the job (the reference: --gpus "device=$SLURM_JOB_GPUS")
+    assert 'ROCR_VISIBLE_DEVICES=4,5' in common.dockerCommand(tool='img', work_dir=str(tmp_path), parameters=argv, gpus=2, environ={'SLURM_JOB_GPUS': '4,5'})
+    cpu_job = common.dockerCommand(tool='img', work_dir=str(tmp_path), parameters=['lastz', 'a', 'b'], gpus=0, environ={})
+    assert not any('kfd' in a or 'ROCR' in a for a in cpu_job)
+    s = common.singularityCommand(tool='/img/cactus.sif', work_dir=str(tmp_path), parameters=argv, gpus=2)
+    assert s[:3] == ['singularity', '--silent', 'exec'] and '--rocm' in s and '--nv' not in s and s[-len(argv):] == argv
+    assert s[s.index('-B') + 1] == '{}:/mnt'.format(tmp_path) and s[s.index('--pwd') + 1] == '/mnt'
+    assert '--rocm' not in common.singularityCommand(tool='/img/cactus.sif', work_dir=str(tmp_path), parameters=['lastz'], gpus=0)
+    # cactus_call wraps the command under CACTUS_BINARIES_MODE=docker|singularity: a stand-in `docker` on PATH records what it is given
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    for name in ("docker", "singularity"):
+        (fake / name).write_text("#!/bin/sh\necho \"$0 $@\" > {}/{}.argv\n".format(tmp_path, name))
+        (fake / name).chmod(0o755)
+    env = dict(os.environ, CACTUS_BINARIES_MODE="docker", CACTUS_DOCKER_IMAGE="quay.io/cactus:amd", PATH=str(fake) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setattr(common, "BIN_DIR", str(fake))
+    common.cactus_call(parameters=argv, work_dir=str(tmp_path), gpus=2, env=env)
+    seen = (tmp_path / "docker.argv").read_text()
+    assert '--device=/dev/kfd' in seen and 'quay.io/cactus:amd run_kegalign A.fa B.fa' in seen
+    env.update(CACTUS_BINARIES_MODE="singularity", CACTUS_SINGULARITY_IMG="/img/cactus.sif")
+    common.cactus_call(parameters=argv, work_dir=str(tmp_path), gpus=2, env=env)
+    assert '--rocm /img/cactus.sif run_kegalign' in (tmp_path / "singularity.argv").read_text()
+    env.pop("CACTUS_SINGULARITY_IMG")
+    with pytest.raises(RuntimeError):
+        common.cactus_call(parameters=argv, work_dir=str(tmp_path), gpus=2, env=env)

@@ -135,7 +135,6 @@ def test_trim_to_aligned_four_implementations_write_the_oracles_bytes(tmp_path, 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from localjob import LocalJob
     from cactus_amd import mipaf
-    from cactus_amd.paf.local_alignment import trim_unaligned_sequences
     files, paf = two_genome_case(seed)
     flank = (0, 7, 60, 2000)[seed % 4]
     paths = []
@@ -158,11 +157,17 @@ def test_trim_to_aligned_four_implementations_write_the_oracles_bytes(tmp_path, 
     native = [mipaf.fasta_extract_text(bed, p.read_bytes(), flank, 1, True) for p in paths]
     assert [x.decode() for x in native] == want_files
     assert mipaf.upconvert_text(paf.encode(), native).decode() == want_paf
-    # the job function over the CLI faces (argv of the reference)
-    job = LocalJob()
-    params = ET.fromstring(f'<cactusWorkflowConfig><blast trimOutgroupFlanking="{flank}"/></cactusWorkflowConfig>')
-    seq_ids, paf_id = trim_unaligned_sequences(job, [job.fileStore.writeGlobalFile(str(p)) for p in paths], job.fileStore.writeGlobalFile(str(tmp_path / "a.paf")), params)
-    assert [open(str(i)).read() for i in seq_ids] == want_files and open(str(paf_id)).read() == want_paf
+    # the CLI faces with the argv of the reference's job (local_alignment.py:877-899; the job function itself is the REFERENCE's own
+    # body in tests/test_reference_jobs_cpu.py -- there is no mirror of it)
+    def tool(argv, out):
+        with open(out, "wb") as sink:
+            r = subprocess.run([os.path.join(ROOT, "bin", argv[0])] + argv[1:], stdout=sink, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        return out
+    bed_file = tool(['paffy', 'to_bed', "--binary", "--excludeUnaligned", "--includeInverted", '-i', str(tmp_path / "a.paf"), "--logLevel", "INFO"], str(tmp_path / "a.bed"))
+    cli_files = [tool(['faffy', 'extract', "-i", bed_file, str(p), "--skipMissing", "--minSize", "1", "--flank", str(flank), "--logLevel", "INFO"], str(p) + ".trim") for p in paths]
+    cli_paf = tool(['paffy', 'upconvert', "-i", str(tmp_path / "a.paf"), "--logLevel", "INFO"] + cli_files, str(tmp_path / "a.paf.trim"))
+    assert [open(f).read() for f in cli_files] == want_files and open(cli_paf).read() == want_paf
     # dechunk undoes upconvert
     assert mipaf.dechunk_text(want_paf.encode()) == paf.encode()
 
