@@ -50,6 +50,7 @@ void olz_params_default(olz_params *p) {
     p->markend = 0;
     p->queryhsplimit = 0;
     p->diag_hash16 = 0; p->walls = 0; p->strands = 0;
+    p->query_softmask = 0; p->step_origin = 0; p->xdrop_le = 0; p->hspbest_ties = 0; p->traceback_cells = 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -179,11 +180,12 @@ static uint8_t *revcomp_codes(const olz_seqset *s) {
 static inline int seedable(uint8_t c) { return c < 4; }
 
 /* valid_from[p] helper: fills ok[p]=1 iff window [p,p+19) seedable */
-static uint8_t *window_valid_map(const uint8_t *codes, int64_t n) {
+/* (ignore_mask: the query_softmask switch -- lowercase ACGT seeds too; separators and N never do) */
+static uint8_t *window_valid_map_m(const uint8_t *codes, int64_t n, int ignore_mask) {
     uint8_t *ok = (uint8_t *)calloc((size_t)n + 1, 1);
     int64_t run = 0;                       /* seedable run length ending at i */
     for (int64_t i = 0; i < n; i++) {
-        run = seedable(codes[i]) ? run + 1 : 0;
+        run = (ignore_mask ? (codes[i] != OLZ_SEP && (codes[i] & 7u) < 4) : seedable(codes[i])) ? run + 1 : 0;
         if (run >= SEED_SPAN) ok[i - SEED_SPAN + 1] = 1;
     }
     return ok;
@@ -195,10 +197,24 @@ static inline uint32_t seed_word(const uint8_t *codes, int64_t p) {
     return w;
 }
 
+static uint8_t *window_valid_map(const uint8_t *codes, int64_t n) { return window_valid_map_m(codes, n, 0); }
+
 /* INDEX(T, step) of SURVEY A.10: CSR, ascending p inside a bucket */
+static int build_index_origin(const olz_seqset *T, int32_t step, int per_sequence, uint32_t **offsets_out, uint32_t **positions_out);
 int olz_build_index(const olz_seqset *T, int32_t step, uint32_t **offsets_out, uint32_t **positions_out) {
+    return build_index_origin(T, step, 0, offsets_out, positions_out);
+}
+/* (per_sequence: the step_origin switch -- positions are taken every `step` from the start of each sequence, not of the concatenation) */
+static int build_index_origin(const olz_seqset *T, int32_t step, int per_sequence, uint32_t **offsets_out, uint32_t **positions_out) {
     int64_t n = T->total;
     uint8_t *ok = window_valid_map(T->codes, n);
+    if (per_sequence && step > 1) {
+        for (int c = 0; c < T->n_contigs; c++)
+            for (int64_t p = T->starts[c]; p < T->starts[c] + T->lens[c]; p++)
+                if ((p - T->starts[c]) % step) ok[p] = 0;
+        step = 1;                                           /* (what survived above IS the per-sequence lattice) */
+        for (int c = 0; c + 1 < T->n_contigs; c++) ok[T->starts[c] + T->lens[c]] = 0;
+    }
     uint32_t *off = (uint32_t *)calloc((size_t)N_BUCKETS + 1, sizeof(uint32_t));
     for (int64_t p = 0; p + SEED_SPAN <= n; p += step)
         if (ok[p]) off[seed_word(T->codes, p) + 1]++;
@@ -230,6 +246,7 @@ static olz_hsp ungapped(ctx_t *x, int64_t t_end, int64_t q_end) {
     int64_t tlo = T->starts[tcg], thi = tlo + T->lens[tcg];
     int64_t qlo = Q->starts[qcg], qhi = qlo + Q->lens[qcg];
     int32_t xdrop = x->p->xdrop;
+    const int32_t le = x->p->xdrop_le ? 1 : 0;          /* (run <= best - xdrop  <=>  run < best - xdrop + 1) */
     int32_t run = 0, bestL = 0, bestR = 0;
     int64_t bl = 0, br = 0;
     for (int64_t k = 1;; k++) {
@@ -238,7 +255,7 @@ static olz_hsp ungapped(ctx_t *x, int64_t t_end, int64_t q_end) {
         run += olz_score(x->tc[i], x->qc[j], 1);
         x->c->ungapped_cols++;
         if (run > bestL) { bestL = run; bl = k; }
-        else if (run < bestL - xdrop) break;
+        else if (run < bestL - xdrop + le) break;
     }
     run = 0;
     for (int64_t k = 0;; k++) {
@@ -247,7 +264,7 @@ static olz_hsp ungapped(ctx_t *x, int64_t t_end, int64_t q_end) {
         run += olz_score(x->tc[i], x->qc[j], 1);
         x->c->ungapped_cols++;
         if (run > bestR) { bestR = run; br = k + 1; }
-        else if (run < bestR - xdrop) break;
+        else if (run < bestR - xdrop + le) break;
     }
     olz_hsp h;
     memset(&h, 0, sizeof h);
@@ -356,6 +373,7 @@ static side_t one_sided(ctx_t *x, int64_t t0, int64_t q0, int dir, int64_t na, i
     r.cells += R0 + 1;
     int64_t nrows = 1;
     for (int64_t i = 1; i <= nb; i++) {
+        if (x->p->traceback_cells > 0 && tlen >= x->p->traceback_cells) break;      /* the traceback_cells switch: the memory of one traceback is spent */
         uint8_t bq = qc[dir > 0 ? q0 + i - 1 : q0 - i];
         if (nrows + 1 > rcap) { rcap *= 2; row_off = realloc(row_off, (size_t)rcap * 8); row_ly = realloc(row_ly, (size_t)rcap * 8); }
         row_off[nrows] = tlen; row_ly[nrows] = LY;
@@ -446,6 +464,11 @@ static int cmp_rank(const void *a, const void *b) {
     if (x->score != y->score) return x->score > y->score ? -1 : 1;
     return x->ord < y->ord ? -1 : (x->ord > y->ord ? 1 : 0);
 }
+static int cmp_rank_later(const void *a, const void *b) {      /* the hspbest_ties switch: of equal scores the later found first */
+    const rank_t *x = (const rank_t *)a, *y = (const rank_t *)b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    return x->ord > y->ord ? -1 : (x->ord < y->ord ? 1 : 0);
+}
 static int cmp_i64(const void *a, const void *b) {
     int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
     return x < y ? -1 : (x > y ? 1 : 0);
@@ -471,7 +494,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
     double t_begin = now_s();
 
     uint32_t *off = NULL, *posv = NULL;
-    olz_build_index(T, p.step, &off, &posv);
+    build_index_origin(T, p.step, p.step_origin, &off, &posv);
     res->c.t_index = now_s() - t_begin;
 
     uint8_t *qrc = revcomp_codes(Q);
@@ -495,7 +518,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
         double t0s = now_s();
         x.qc = strand ? qrc : Q->codes;
         memset(extent, 0, (size_t)ndiag * 4);
-        uint8_t *qok = window_valid_map(x.qc, Q->total);
+        uint8_t *qok = window_valid_map_m(x.qc, Q->total, p.query_softmask);
         olz_hsp *sh = NULL; int64_t nsh = 0, capsh = 0;       /* this strand, found order */
         /* SEARCH(Qs) of SURVEY A.10 */
         for (int64_t q = 0; q + SEED_SPAN <= Q->total; q++) {
@@ -543,7 +566,7 @@ int olz_align(const olz_seqset *T, const olz_seqset *Q, const olz_params *pp, ol
                 rank_t *rk = NULL; int64_t nr = 0, capr = 0;
                 for (int64_t k = 0; k < nsh; k++) if (sh[k].q_contig == qc_i) { rank_t e = {sh[k].score, k}; PUSH(rk, nr, capr, e); }
                 if (nr > p.queryhspbest) {
-                    qsort(rk, (size_t)nr, sizeof *rk, cmp_rank);
+                    qsort(rk, (size_t)nr, sizeof *rk, p.hspbest_ties ? cmp_rank_later : cmp_rank);
                     int64_t *keep = (int64_t *)malloc((size_t)p.queryhspbest * 8);
                     for (int64_t k = 0; k < p.queryhspbest; k++) keep[k] = rk[k].ord;
                     qsort(keep, (size_t)p.queryhspbest, 8, cmp_i64);

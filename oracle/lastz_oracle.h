@@ -54,15 +54,27 @@ typedef struct olz_params {
     /* Named switches for the two points of SURVEY A.9 (#4, #8) where a real lastz may differ from the rules fixed in A.10.
      * Both default to 0 (= A.10, what the MI355X path implements and every parity test uses); they exist so that the day a
      * lastz binary is at hand (tests/test_p1_lastz_binary.py) the oracle can be flipped to the other reading at once.
-     * (A third candidate has no switch yet: lastz bounds one traceback's memory -- --allocate:traceback, default 80 MiB -- and
-     * truncates an alignment whose DP outgrows it; this restatement keeps the whole trace.  It can only matter for sides of
-     * ~5e5 rows and more, i.e. at chunk scale and low divergence: DESIGN.md section 3.)                                     */
+     * (The bounded traceback -- --allocate:traceback, default 80 MiB, an alignment whose DP outgrows it is truncated -- is the
+     * traceback_cells switch further down; it can only matter for sides of ~5e5 rows and more, i.e. at chunk scale and low
+     * divergence: DESIGN.md section 3.)                                                                                       */
     int32_t diag_hash16;   /* 1: diagonal suppression state indexed by (t_end - q_end) & 0xFFFF as lastz's diagEnd[] (A.4): hits on
                               colliding diagonals are silently dropped; sequential in hit generation order                   */
     int32_t walls;         /* 1: base pairs on the path of an earlier alignment of the same query sequence and strand are hard
                               walls for later DPs (A.7): a cell pairing such bases is dead and no gap passes through it      */
     int32_t strands;       /* --strand=both|plus|minus: 0 both, 1 only '+', 2 only '-' (the strands are searched and extended
                               independently of each other: A.8)                                                                */
+    /* Further named switches for SURVEY A.9 (round 5; oracle side only -- the product implements the A.10 reading, and the two above).
+     * Each is a reading of upstream lastz that A.10 decided AGAINST on a "medium / low confidence" item; 0 = A.10.  With a lastz
+     * binary at hand tests/test_p1_lastz_binary.py runs every combination that explains a difference (bisection by switch).    */
+    int32_t query_softmask;  /* A.9 #2.  0: lowercase query bases do not seed (A.1 rule "apply to both"); 1: only the TARGET's soft-masking
+                                keeps a position out of the seed search -- a lowercase query window of ACGT seeds like an uppercase one   */
+    int32_t step_origin;     /* A.9 #5.  0: --step counts from position 0 of the concatenated target; 1: from the start of every sequence of
+                                a [multiple] target (indexed positions p with (p - start of p's sequence) % step == 0)                   */
+    int32_t xdrop_le;        /* A.9 #9.  0: an ungapped walk stops when run < best - xdrop; 1: when run <= best - xdrop                     */
+    int32_t hspbest_ties;    /* A.9 #11. 0: --queryhspbest keeps the EARLIER found of equal-scoring HSPs at the cut; 1: the later found    */
+    int64_t traceback_cells; /* lastz's bounded traceback (--allocate:traceback=<bytes>, default 80 MiB).  > 0: a
+                                one-sided DP that has stored this many cells evaluates no further row -- the alignment ends at the best
+                                cell found until then and the rest of the homology is left to a later anchor.  0: unbounded (A.10).       */
 } olz_params;
 
 void olz_params_default(olz_params *p);

@@ -14,7 +14,8 @@ CLI_PATH = os.path.join(_HERE, "oracle_lastz")
 
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("step", "transitions", "xdrop", "ydrop", "hspthresh", "gappedthresh", "gap_open",
-                                          "gap_extend", "entropy", "queryhspbest", "ambiguous_n", "gapped", "format", "markend", "queryhsplimit", "diag_hash16", "walls", "strands")]
+                                          "gap_extend", "entropy", "queryhspbest", "ambiguous_n", "gapped", "format", "markend", "queryhsplimit", "diag_hash16", "walls", "strands",
+                                          "query_softmask", "step_origin", "xdrop_le", "hspbest_ties")] + [("traceback_cells", C.c_int64)]
 
 
 class SeqSetS(C.Structure):

@@ -51,6 +51,18 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--strand=minus")) p.strands = 2;
         else if (!strncmp(a, "--queryhsplimit=keep,nowarn:", 28)) p.queryhsplimit = atoi(a + 28);
         else if (!strncmp(a, "--querydepth=keep,nowarn:", 25)) { /* no effect with --ungapped (cactus_lastzRepeatMask.py:100) */ }
+        /* the named switches of SURVEY A.9 (lastz_oracle.h); --allocate:traceback is lastz's own spelling of the last one */
+        else if (!strcmp(a, "--oracle-query-softmask=ignore")) p.query_softmask = 1;
+        else if (!strcmp(a, "--oracle-step-origin=sequence")) p.step_origin = 1;
+        else if (!strcmp(a, "--oracle-xdrop=le")) p.xdrop_le = 1;
+        else if (!strcmp(a, "--oracle-hspbest-ties=later")) p.hspbest_ties = 1;
+        else if (!strncmp(a, "--oracle-traceback-cells=", 25)) p.traceback_cells = atoll(a + 25);
+        else if (!strncmp(a, "--allocate:traceback=", 21)) {
+            char *end = NULL;
+            double v = strtod(a + 21, &end);
+            if (end && (*end == 'K' || *end == 'k')) v *= 1024.0; else if (end && (*end == 'M' || *end == 'm')) v *= 1048576.0; else if (end && (*end == 'G' || *end == 'g')) v *= 1073741824.0;
+            p.traceback_cells = (int64_t)v;                  /* (one byte of traceback per DP cell) */
+        }
         else if (!strcmp(a, "--counters")) counters = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }

@@ -232,3 +232,69 @@ def test_strand_halves_interleaved_by_query_sequence_are_the_whole(olz):
             assert plus["counters"][k] + minus["counters"][k] == both["counters"][k], (name, k)
         n += both["paf"].count(b"\n")
     assert n > 50
+
+
+def test_the_other_named_switches_of_survey_a9_change_what_they_name(olz):
+    """SURVEY A.9 #2, #5, #9, #11 and the bounded traceback (lastz_oracle.h, round 5): each switch is off by default (= A.10 = every
+    committed expectation) and, on, changes the output of a case built for it -- so that a difference from a real lastz binary can be
+    bisected by switch (tests/test_p1_lastz_binary.py)."""
+    rng = np.random.default_rng(11)
+    base = dict(hspthresh=2200, gappedthresh=2400, ydrop=4000)
+    p0 = olz.default_params(**base)
+    assert (p0.query_softmask, p0.step_origin, p0.xdrop_le, p0.hspbest_ties, p0.traceback_cells) == (0, 0, 0, 0, 0)
+    # (#2) a query that is soft-masked throughout: no query window seeds under A.10 (rule "apply to both"); with the switch only the
+    # target's masking counts and the copy is found
+    s = _rand(1200, 21)
+    tf, qf = _fa("T|m", s), _fa("Q|m", s.lower())
+    a10 = olz.align(tf, qf, p0)
+    seeded = olz.align(tf, qf, olz.default_params(query_softmask=1, **base))
+    assert a10["counters"]["seed_hits"] == 0 and a10["paf"] == b""
+    assert seeded["counters"]["seed_hits"] > 0 and seeded["counters"]["alignments"] == 1
+    # ... and a masked TARGET window keeps out of the table either way
+    assert olz.align(_fa("T|m", s.lower()), _fa("Q|m", s), olz.default_params(query_softmask=1, **base))["counters"]["seed_hits"] == 0
+    # (#5) --step=2 over a [multiple] target whose second sequence starts at an odd position of the concatenation (300 bases + one
+    # separator before it): counted from position 0 the indexed positions of that sequence are the even ones, counted from the
+    # sequence's own start the odd ones.  The seed hit that makes the copy's HSP tells which lattice the table holds.
+    first, second = _rand(300, 22), _rand(900, 23)
+    tf = (_fa("T|a", first) + _fa("T|b", second))
+    qf = _fa("Q|s", second)
+    whole = olz.align(tf, qf, olz.default_params(step=2, gapped=0, **base))
+    per_seq = olz.align(tf, qf, olz.default_params(step=2, step_origin=1, gapped=0, **base))
+    seed_pos = lambda res: {(h[6] - 19) % 2 for h in res["hsps"] if h[0] == 0}
+    assert seed_pos(whole) == {0} and seed_pos(per_seq) == {1}
+    assert whole["hsps"][0][7] == per_seq["hsps"][0][7] + 1                  # the query position whose word is the first to hit
+    # (#9) a walk whose running score falls EXACTLY x-drop below its best and recovers: strict "<" goes on and joins the two
+    # stretches into one HSP, "<=" stops there.  6 columns of N against a base (-100 each) + 10 transitions (-31 each) = -910.
+    left, right = _rand(260, 24), _rand(400, 25)
+    tv = {"A": "G", "G": "A", "C": "T", "T": "C"}
+    mid_q = "".join(rng.choice(list("ACGT"), 16))
+    mid_t = "N" * 6 + "".join(tv[c] for c in mid_q[6:])
+    tf, qf = _fa("T|x", left + mid_t + right), _fa("Q|x", left + mid_q + right)
+    strict = olz.align(tf, qf, olz.default_params(gapped=0, **base))
+    le = olz.align(tf, qf, olz.default_params(gapped=0, xdrop_le=1, **base))
+    span = lambda res: sorted((h[2], h[2] + h[4]) for h in res["hsps"] if h[0] == 0)
+    assert any(a <= 200 and b >= 300 for a, b in span(strict)), span(strict)          # one HSP across the dip
+    assert not any(a <= 200 and b >= 300 for a, b in span(le)), span(le)             # ... none with "<="
+    assert len(span(le)) > len(span(strict))
+    # (#11) --queryhspbest=1 and two HSPs of one score (two identical copies in the target): A.10 keeps the one found first, the
+    # switch the one found later
+    unit = _rand(120, 26)
+    tf, qf = _fa("T|k", _rand(300, 27) + unit + _rand(300, 28) + unit + _rand(300, 29)), _fa("Q|k", _rand(50, 30) + "N" * 20 + unit + "N" * 20 + _rand(50, 31))      # (N against anything: -100 -- neither HSP grows past the unit)
+    first_kept = olz.align(tf, qf, olz.default_params(gapped=0, queryhspbest=1, **base))
+    later_kept = olz.align(tf, qf, olz.default_params(gapped=0, queryhspbest=1, hspbest_ties=1, **base))
+    both = olz.align(tf, qf, olz.default_params(gapped=0, **base))
+    assert len(both["hsps"]) == 2 and both["hsps"][0][5] == both["hsps"][1][5]
+    assert first_kept["hsps"] == [both["hsps"][0]] and later_kept["hsps"] == [both["hsps"][1]]
+    # (bounded traceback) a 6 000-column alignment with room for 150 000 cells per side: the alignment is cut where the memory ends
+    # and the rest is found again from a later anchor -- more, shorter alignments, every one of them a valid PAF record
+    a = gen.random_sequence(6000, rng)
+    t, q = a, gen.mutate(a, rng, 0.04, 0.002)
+    tf, qf = gen.fasta_bytes([("T|b", t)]), gen.fasta_bytes([("Q|b", q)])
+    whole = olz.align(tf, qf, p0)
+    cut = olz.align(tf, qf, olz.default_params(traceback_cells=150000, **base))
+    assert whole["counters"]["alignments"] == 1 and cut["counters"]["alignments"] > 1
+    assert max(al[4] - al[3] for al in cut["alns"]) < whole["alns"][0][4] - whole["alns"][0][3]
+    full = {"T|b": t.tobytes().decode(), "Q|b": q.tobytes().decode()}
+    assert pafcheck.check_paf(cut["paf"].decode(), full, full) == cut["counters"]["alignments"]
+    # a budget no side reaches changes nothing
+    assert olz.align(tf, qf, olz.default_params(traceback_cells=1 << 40, **base))["paf"] == whole["paf"]
