@@ -218,6 +218,9 @@ class EvolverPhase:
                 pool.put(cx)
             with lock:
                 add_stats(agg, [r.stats for r in rs])
+                # (bases of the call's targets and queries: SURVEY 8d's read terms -- every call builds its table and packs its strands)
+                agg["t_bases"] = agg.get("t_bases", 0) + sum(t.total for t, _ in sets)
+                agg["q_bases"] = agg.get("q_bases", 0) + sum(q.total for _, q in sets)
             if TIMELINE:
                 print(f"[bench] align_pairs of {len(pairs)} pairs: {(time.perf_counter() - t0) * 1e3:.2f} ms (since step start {(time.perf_counter() - t_step) * 1e3:.2f}); "
                       f"t_gapped {rs[0].stats['t_gapped'] * 1e3:.2f}, dp {rs[0].stats['t_dp_kernel_ms']:.2f}, max t_seed+index {max(r.stats['t_seed'] + r.stats['t_index'] for r in rs) * 1e3:.2f}", file=sys.stderr)
@@ -283,16 +286,18 @@ class ChunkWorkload:
     """The chunk-scale configurations (cactus_amd/workloads.py): `chr20` = BASELINE configs[3], `hm` = the scaled
     stand-in for configs[4] (config 5).  ONE genome pair, chunked exactly as the CPU path chunks it (faffy chunk -c chunkSize -o 10000:
     cactus_progressive_config.xml:90-92, /root/reference/src/cactus/paf/local_alignment.py:378-387), every (target chunk, query chunk)
-    pair an independent job (:395-405) with the option set of its divergence.  The work units -- chunk pairs, or with --split-pairs
-    (chunk pair, query half) -- are dealt to the ranks longest first (cactus_amd.multigpu); a rank aligns its share in ONE batched call,
-    target-major: a target chunk's seed table is built once per step and stays resident while the query chunks stream through it (SURVEY
-    8e; the library keeps it with the set, miblast_drop_derived at the start of every step makes the step pay for it).  The only exchange
+    pair an independent job (:395-405) with the option set of its divergence.  The work units -- chunk pairs, or with --split-strands
+    (chunk pair, query strand) -- are owned TARGET-MAJOR (cactus_amd.multigpu.assign_target_major): rank g owns the target
+    chunks i mod N with all their units (fewer target chunks than ranks: a chunk's column is shared by a group of ranks, longest unit
+    first); a rank aligns its share in ONE batched call: a target chunk's seed table is built once per step -- on one rank when there
+    are at least as many target chunks as ranks, never more than ceil(Na / N) per rank -- and stays resident while the query chunks
+    stream through it (the library keeps it with the set; miblast_drop_derived at the start of every step makes the step pay for it).  The only exchange
     is the gather of the framed PAFs to rank 0, which strings them together in chunk-pair order -- the bytes do not depend on the number
     of GPUs.  Total work is fixed: STRONG scaling."""
 
     def __init__(self, a, ctx, rank, world, which):
         from cactus_amd import miblast, workloads
-        from cactus_amd.multigpu import assign_pairs
+        from cactus_amd.multigpu import assign_target_major
         self.ctx, self.rank, self.world, self.miblast = ctx, rank, world, miblast
         kw = {}
         if which == "chr20" and (a.chr20_bases, a.chr20_chunk) != (64_444_167, 30_000_000):
@@ -306,7 +311,11 @@ class ChunkWorkload:
         self.split = mode == "1" or (mode == "auto" and world > 1 and len(w.pairs) < 4 * world)
         self.units = [(k, sc) for k in range(len(w.pairs)) for sc in ((1, 2) if self.split else (0,))]
         self.weights = [w.weights()[k] * (0.5 if sc else 1.0) for k, sc in self.units]
-        self.mine = assign_pairs(self.weights, world)[rank]
+        # target-major ownership: rank g owns the target chunks i mod N with all their units; fewer target chunks than ranks:
+        # a chunk's column is shared by a group of ranks (cactus_amd.multigpu.assign_target_major)
+        self.shares = assign_target_major([w.pairs[k][0] for k, _ in self.units], self.weights, world)
+        self.mine = self.shares[rank]
+        self.tables_per_rank = [len({w.pairs[self.units[u][0]][0] for u in sh}) for sh in self.shares]
         self.pm_strand = {sc: miblast.params_from_args(w.options.split() + ([] if sc == 0 else ["--strand=" + ("plus" if sc == 1 else "minus")])) for sc in (0, 1, 2)}
         need_t, need_q = sorted({self.pairs[self.units[u][0]][0] for u in self.mine}), sorted({self.pairs[self.units[u][0]][1] for u in self.mine})
         self.T = {i: ctx.seqset_from_fasta_bytes(self.tfa[i]) for i in need_t}                 # only this rank's chunks go to its HBM
@@ -375,36 +384,35 @@ class ChunkWorkload:
                 "oracle_cpu_seconds_all_pairs": sum(p["oracle_seconds"] for p in gold["pairs"] if p),
                 "oracle_dp_cells": sum(p["dp_cells"] for p in gold["pairs"] if p), "oracle_seed_hits": sum(p["seed_hits"] for p in gold["pairs"] if p)}
 
-    def cpu_sample(self, by_index, budget_s=25.0):
-        """the bounded CPU sample of a chunk-scale workload: the chunk pairs the oracle is quickest on (by its committed run times),
-        as many as fit ~25 s, run live on this box and diffed byte for byte"""
+    def cpu_sample(self, by_index, budget_s=75.0):
+        """SURVEY 8d's CPU baseline of a chunk-scale workload, live on this box in this run: the chunk pairs as min(pairs, cores)
+        single-threaded oracle processes side by side, each pinned to a core (the reference's CPU path: one lastz process per chunk
+        pair, one core each -- cactus_progressive_config.xml:4, local_alignment.py:402), every PAF diffed byte for byte against the
+        GPU's, cells and hits from the processes' own counters.  With fewer cores than pairs the longest pairs go first; if the
+        whole list would take more than ~budget_s of wall time the sample is the heaviest pairs that fit (never fewer than the cores
+        hold, at least eight, the pairs WITH homology first -- they carry the DP cells)."""
         path = os.path.join(ROOT, "tests", "golden", f"{self.w.key}_pairs.json")
-        order = list(range(len(self.pairs)))
+        n = len(self.pairs)
+        est = [float(self.weights[k]) for k in range(n)] if not self.split else [float(self.w.weights()[k]) for k in range(n)]
         if os.path.exists(path):
             gold = json.load(open(path))["pairs"]
-            order.sort(key=lambda k: gold[k]["oracle_seconds"] if gold[k] else 1e9)
+            est = [gold[k]["oracle_seconds"] if gold[k] else 60.0 for k in range(n)]
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        order = sorted(range(n), key=lambda k: (-est[k], k))
+        pick = list(order)
+        if os.path.exists(path) and sum(est) / max(1, min(cores, n)) > budget_s and max(est) < budget_s:
             pick, t = [], 0.0
             for k in order:
-                sec = gold[k]["oracle_seconds"] if gold[k] else 60.0
-                if pick and t + sec > budget_s:
+                if len(pick) >= max(8, min(cores, n)) and (t + est[k]) / max(1, min(cores, n)) > budget_s:
                     break
-                pick.append(k); t += sec
-        else:
-            pick = [min(order, key=lambda k: self.weights[k])]
+                pick.append(k); t += est[k]
+        pick.sort()
         calls = [(self.tfa[self.pairs[k][0]], self.qfa[self.pairs[k][1]], self.OPTIONS, by_index[k]) for k in pick]
-        out = cpu_baseline(calls, None, f"{len(pick)} of the {len(self.pairs)} chunk pairs (the quickest for the oracle: pairs {pick}) of: " + self.describe, node=False)
-        out["sample_pairs"] = pick
-        if os.path.exists(path):
-            # The live sample is made of the pairs the oracle is quickest on -- at chunk scale those are the pairs WITHOUT homology, next to no
-            # DP cells: its seeds/s mean something, its Gcell/s do not.  The whole step on one core is on record from the run that wrote
-            # the digests (scripts/oracle_chunk_digests.py, in the build container: not this box's cores, not timed now).
-            g = json.load(open(path))
-            secs = sum(pr["oracle_seconds"] for pr in g["pairs"] if pr)
-            if secs > 0:
-                cells, hits = sum(pr["dp_cells"] for pr in g["pairs"] if pr), sum(pr["seed_hits"] for pr in g["pairs"] if pr)
-                out["recorded_whole_step"] = {"value": cells / secs / 1e9, "unit": "Gcell/s", "seeds_per_s": hits / secs, "cores": 1, "kind": "port",
-                                              "seconds": secs, "sample": f"all {len(g['pairs'])} chunk pairs, one after the other on one core of the build container "
-                                              "when tests/golden/%s_pairs.json was written (recorded, not measured in this run)" % self.w.key}
+        node = cpu_baseline_concurrent(calls, None, None, order=[est[k] for k in pick])
+        out = {"value": node["value"], "unit": "Gcell/s", "seeds_per_s": node["seeds_per_s"], "cores": node["cores"], "kind": "port",
+               "sample": ("all %d chunk pairs" % n if len(pick) == n else "%d of the %d chunk pairs (the heaviest for the oracle: pairs %s)" % (len(pick), n, pick))
+                         + " of: " + self.describe + " -- one single-threaded oracle process per pair, min(pairs, cores) at a time, pinned (SURVEY 8d)",
+               "seconds": node["seconds_wall"], "cpu_seconds": node["cpu_seconds"], "same_bytes": node["same_bytes"], "sample_pairs": pick, "node": node}
         return out
 
     def b_read(self, tot, per, elapsed_step_s):
@@ -425,6 +433,21 @@ class ChunkWorkload:
                 "achieved_GBps": total / elapsed_step_s / 1e9, "peak_GBps": HBM_PEAK_GBS * self.world, "frac": total / elapsed_step_s / 1e9 / (HBM_PEAK_GBS * self.world),
                 "note": "SURVEY 8d read terms only, nothing padded; the gapped DP is VALU / issue bound (its bytes are negligible), so a step in which it is "
                         "a third of the time cannot come near the roof: see per-stage kernel times"}
+
+
+def phase_b_read(tot, per, elapsed_step_s, world, work):
+    """SURVEY 8d's algorithmic READ bytes of one step of the blast phase, per stage and whole-phase, against the HBM roof (the same
+    terms as the chunk legs' b_read; a call of the phase builds its own table and packs its own strands, so T and Q count per call)."""
+    nvar_note = "13 or 1 look-ups per query position and strand are in seed_lookups"
+    t_bases, q_bases = tot["t_bases"] / per, tot["q_bases"] / per
+    look, hits, cols, rows = tot["seed_lookups"] / per, tot["seed_hits"] / per, tot["ungapped_cols"] / per, tot["dp_rows"] / per
+    stages = {"index": 1.375 * t_bases, "seed_search": 0.375 * q_bases * 2 + 8.0 * look + 4.0 * hits, "ungapped": 8.0 * hits + 0.5 * cols, "gapped": 0.75 * rows}
+    total = sum(stages.values())
+    return {"bytes_per_step": {k: float(v) for k, v in stages.items()}, "bytes_total": float(total), "achieved_GBps": total / elapsed_step_s / 1e9,
+            "peak_GBps": HBM_PEAK_GBS * world, "frac": total / elapsed_step_s / 1e9 / (HBM_PEAK_GBS * world),
+            "note": "SURVEY 8d read terms only, nothing padded (" + nvar_note + "); a phase of twenty 0.6 Mb calls is latency bound (SURVEY 8d's worked example: "
+                    "a 1 Mb pair's reads are 30 us at the roof), and its DP is VALU / issue bound: the whole-phase fraction says how far a small "
+                    "configuration is from the roof, not how good the kernels are -- see roofline (DP kernel) and the chunk legs"}
 
 
 def reduce_totals(tot, elapsed, dist, coll_dev):
@@ -611,6 +634,7 @@ def run_rank(a):
                       "reruns_per_step": tot["dp_reruns"] / per,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / per, "merge_ms_per_step": tot["t_merge_ms"] / per},
             "roofline": dp_roofline(tot, "r04_hbm_traffic_pmc.json" if a.workload == "evolver" else "r03_pair_hbm_traffic_pmc.json"),
+            "hbm_read": phase_b_read(tot, per, elapsed / a.steps, world, work) if "t_bases" in tot else None,
             "host": {"cpu_seconds_per_step": tot["host_cpu_seconds"] / per, "busy_threads_avg": tot["host_cpu_seconds"] / world / max(1e-9, elapsed),
                      "cgroup_throttled_periods": tot["host_throttled_periods"], "cgroup_throttled_ms": tot["host_throttled_ms"],
                      "note": "all ranks; a CPU-quota container freezes the process when its threads exceed the quota (outlier steps)"},
@@ -636,7 +660,9 @@ def run_rank(a):
             out["config"]["paf_md5"] = hashlib.md5(gathered["paf"]).hexdigest()
             out["config"]["paf_bytes"] = len(gathered["paf"])
             out["config"]["work_unit"] = "(chunk pair, query strand)" if work.split else "chunk pair"
-            out["config"]["units_per_rank"] = [len(x) for x in __import__("cactus_amd.multigpu", fromlist=["assign_pairs"]).assign_pairs(work.weights, world)]
+            out["config"]["units_per_rank"] = [len(x) for x in work.shares]
+            out["config"]["tables_built_per_step"] = {"per_rank": work.tables_per_rank, "total": sum(work.tables_per_rank), "target_chunks": len(work.tfa),
+                                                      "bound_per_rank": -(-len(work.tfa) // world)}
             out["parity"] = work.digest_check(work.by_index)
             out["hbm_read"] = work.b_read(tot, per, elapsed / a.steps)
             out["config"]["residency"] = ("chunks resident in HBM before the timed region (parse + upload excluded); seed tables, '-' strands and packed strands "
@@ -764,13 +790,14 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     paf = w.assemble(box["last"])
     by_index = w.by_index
     r = dp_roofline(tot, "none")
-    from cactus_amd.multigpu import assign_pairs
-    shares = assign_pairs(w.weights, world)
+    shares = w.shares
     load = [sum(w.weights[k] for k in sh) for sh in shares]
     unit_kind = "(chunk pair, query strand)" if w.split else "chunk pair"
     out = {"workload": w.describe, "chunk_pairs": len(w.pairs), "n_gpus": world, "scaling": "strong", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
            "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
            "work_unit": unit_kind, "units_per_rank": [len(sh) for sh in shares], "balance_by_weight": (sum(load) / len(load)) / max(load) if max(load) > 0 else 1.0,
+           "ownership": "target-major (SURVEY 8e): rank g owns target chunks i mod N; fewer target chunks than ranks: a chunk's column shared by a group of ranks",
+           "tables_built_per_step": {"per_rank": w.tables_per_rank, "total": sum(w.tables_per_rank), "target_chunks": len(w.tfa), "bound_per_rank": -(-len(w.tfa) // world)},
            "seeds_per_s": tot["seed_hits"] / elapsed, "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
            "dp_cells_per_step": tot["dp_cells"] / steps, "seed_hits_per_step": tot["seed_hits"] / steps, "alignments_per_step": tot["alignments"] / steps,
            "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
@@ -896,9 +923,10 @@ def cpu_baseline(kept_calls, dp_cells_gpu, describe, node=True):
     return out
 
 
-def cpu_baseline_concurrent(kept_calls, cells, hits):
+def cpu_baseline_concurrent(kept_calls, cells, hits, order=None):
     """min(calls, cores) oracle processes at a time (oracle/oracle_lastz, the lastz-argv front end of the same restatement), one core
-    each: wall time of the whole list, longest calls first."""
+    each: wall time of the whole list, longest calls first (`order`: estimated seconds per call, else by size).  cells / hits None:
+    taken from the processes' own counters (--counters), with the CPU seconds of every call."""
     import shutil
     import tempfile
     exe = os.path.join(ROOT, "oracle", "oracle_lastz")
@@ -912,30 +940,39 @@ def cpu_baseline_concurrent(kept_calls, cells, hits):
         for k, (tf, qf, opts, paf) in enumerate(kept_calls):
             tp, qp = os.path.join(work, f"{k}.t.fa"), os.path.join(work, f"{k}.q.fa")
             open(tp, "wb").write(tf); open(qp, "wb").write(qf)
-            jobs.append((len(tf) * len(qf), k, [exe, tp + "[multiple][nameparse=darkspace]", qp + "[nameparse=darkspace]", "--format=paf:wfmash"] + opts.split(), paf))
+            jobs.append((order[k] if order else len(tf) * len(qf), k, [exe, tp + "[multiple][nameparse=darkspace]", qp + "[nameparse=darkspace]", "--format=paf:wfmash", "--counters"] + opts.split(), paf))
         jobs.sort(key=lambda x: (-x[0], x[1]))
         taskset = shutil.which("taskset")
         free, running, same = list(cores[:width]), {}, True
+        per_call = {}
         t0 = time.perf_counter()
         pending = list(jobs)
         while pending or running:
             while pending and free:
                 _, k, cmd, paf = pending.pop(0)
                 core = free.pop(0)
-                outp = os.path.join(work, f"{k}.paf")            # (to a file: a finished job never waits on a full pipe)
-                p = subprocess.Popen(([taskset, "-c", str(core)] if taskset else []) + cmd, stdout=open(outp, "wb"), stderr=subprocess.DEVNULL)
-                running[p.pid] = (p, core, paf, outp)
+                outp, errp = os.path.join(work, f"{k}.paf"), os.path.join(work, f"{k}.err")            # (to files: a finished job never waits on a full pipe)
+                p = subprocess.Popen(([taskset, "-c", str(core)] if taskset else []) + cmd, stdout=open(outp, "wb"), stderr=open(errp, "wb"))
+                running[p.pid] = (p, core, paf, outp, errp, k)
             pid, status = os.wait()                              # whichever job ends first gives its core to the next one
             if pid not in running:
                 continue
-            p, core, paf, outp = running.pop(pid)
+            p, core, paf, outp, errp, k = running.pop(pid)
             p.returncode = os.waitstatus_to_exitcode(status)
             same = same and p.returncode == 0 and open(outp, "rb").read() == paf
+            try:
+                per_call[k] = json.loads(open(errp).read().strip().splitlines()[-1])
+            except Exception:                                    # noqa: BLE001
+                per_call[k] = {}
             free.append(core)
         wall = time.perf_counter() - t0
     finally:
         shutil.rmtree(work, ignore_errors=True)
+    if cells is None:
+        cells, hits = sum(c.get("dp_cells", 0) for c in per_call.values()), sum(c.get("seed_hits", 0) for c in per_call.values())
+    cpu_s = [round(per_call.get(k, {}).get("t_total", 0.0), 3) for k in range(len(kept_calls))]
     return {"value": cells / wall / 1e9, "unit": "Gcell/s", "seeds_per_s": hits / wall, "cores": width, "cores_available": len(cores), "seconds_wall": wall,
+            "cpu_seconds_per_call": cpu_s, "cpu_seconds": sum(cpu_s), "dp_cells": int(cells), "seed_hits": int(hits),
             "pinned_with_taskset": bool(taskset), "same_bytes": same,
             "model": "SURVEY 8d: min(calls, cores) single-threaded processes at a time, one lastz job per core"}
 

@@ -3615,8 +3615,10 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         std::atomic<size_t> next_pair{0};
         // (pipelined, many pairs: a lane takes a GROUP of consecutive pairs -- their seed stages one after the other, then ONE gapped stage
         //  for the group: its DP launches are as long as their longest piece whatever they hold, so the pairs of a group share them instead
-        //  of each paying for its own; 42 pairs on 6 lanes: groups of 3.  MIBLAST_PIPELINE_GROUP fixes the size)
-        const size_t group = !pipeline ? 1 : (size_t)std::max(1l, env_long("MIBLAST_PIPELINE_GROUP", (long)std::min<size_t>(4, std::max<size_t>(1, n / (2 * n_lanes)))));
+        //  of each paying for its own.  Many small pairs only (four and more per lane): 42 pairs on 6 lanes go in groups of 7 -- 185 -> 39 DP
+        //  launches per step of the human-mouse stand-in, the DP's busy time 125 -> 39 ms; nine 30 Mb pairs stay single: a group of two would
+        //  put two of the three heavy diagonal pairs on one lane.  MIBLAST_PIPELINE_GROUP fixes the size)
+        const size_t group = !pipeline ? 1 : (size_t)std::max(1l, env_long("MIBLAST_PIPELINE_GROUP", n >= 4 * n_lanes ? (long)std::min<size_t>(8, (n + n_lanes - 1) / n_lanes) : 1l));
         const size_t n_groups = (n + group - 1) / group;
         group_leader.assign(n, 0); lane_gapped.assign(n_lanes, 0.0);
         for (size_t lane = 0; lane < n_lanes; lane++)

@@ -23,6 +23,44 @@ def assign_pairs(weights: Sequence[float], world_size: int) -> List[List[int]]:
     return out
 
 
+def assign_target_major(unit_targets: Sequence[int], weights: Sequence[float], world_size: int) -> List[List[int]]:
+    """Target-major ownership of the work units of ONE genome pair (the jobs are the independent run_lastz jobs of
+    /root/reference/src/cactus/paf/local_alignment.py:395-405): unit_targets[u] = the target chunk of unit u (a chunk pair, or a
+    (chunk pair, query strand) half).  With at least as many target chunks as ranks, rank g owns the target chunks {i : i mod N == g}
+    and every unit of an owned chunk -- a chunk's seed table is built once, on one GPU, and all its query chunks stream through it.
+    With FEWER target chunks than ranks a chunk's column of units is shared: the ranks are split between the chunks in proportion to
+    the columns' weights (every chunk at least one), the units of a column are dealt longest first to the column's ranks, and each of
+    those ranks builds that one table.  Either way no rank builds more than ceil(Na / N) tables.  Deterministic (every rank
+    computes the same deal); returns the unit indices per rank, ascending."""
+    targets = sorted(set(unit_targets))
+    na = len(targets)
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    if na == 0:
+        return out
+    col = {t: [u for u in range(len(unit_targets)) if unit_targets[u] == t] for t in targets}
+    if na >= world_size:
+        for k, t in enumerate(targets):
+            out[k % world_size] += col[t]
+    else:
+        colw = {t: sum(weights[u] for u in col[t]) for t in targets}
+        share = {t: 1 for t in targets}
+        for _ in range(world_size - na):                      # one more rank at a time to the column with the most weight per rank
+            t = max(targets, key=lambda x: (colw[x] / share[x], -x))
+            share[t] += 1
+        first = 0
+        for t in targets:
+            ranks = list(range(first, first + share[t]))
+            first += share[t]
+            load = {r: 0.0 for r in ranks}
+            for u in sorted(col[t], key=lambda i: (-weights[i], i)):
+                r = min(ranks, key=lambda k: (load[k], k))
+                out[r].append(u)
+                load[r] += weights[u]
+    for lst in out:
+        lst.sort()
+    return out
+
+
 def share_host_cores(local_world_size: int) -> int:
     """One rank per GPU on a node: every rank takes an equal share of the host cores for its worker threads (the reference
     passes job.cores as --num_threads for the same reason, /root/reference/src/cactus/paf/local_alignment.py:58).

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cactus_amd.multigpu import assign_pairs, blast_pairs_sharded, chain_parts_sharded
+from cactus_amd.multigpu import assign_pairs, assign_target_major, blast_pairs_sharded, chain_parts_sharded
 
 
 def _fake_align(pair):
@@ -40,6 +40,31 @@ def test_assign_pairs_lpt_is_deterministic_and_balanced():
     loads = [sum(w[i] for i in part) for part in a]
     assert max(loads) - min(loads) <= 3
     assert assign_pairs([1.0] * 3, 8)[:3] == [[0], [1], [2]]
+
+
+def test_target_major_ownership_builds_a_table_once_and_never_more_than_the_bound_per_rank():
+    """rank g owns the target chunks i mod N with all their units; with fewer target chunks than ranks a chunk's column of
+    units is shared by a group of ranks.  Every unit exactly once, no rank with more than ceil(Na / N) target chunks, a chunk on ONE
+    rank whenever Na >= N, nobody idle while a column has units to spare -- for the shapes of both chunk-scale legs (chr20: 3 x 3
+    chunk pairs, also as strand halves; the human-mouse stand-in: 7 x 6) at 1, 2, 3 and 8 ranks."""
+    for na, nb, halves in ((3, 3, False), (3, 3, True), (7, 6, False), (104, 91, False)):
+        units = [(i, j, h) for i in range(na) for j in range(nb) for h in ((1, 2) if halves else (0,))]
+        targets = [u[0] for u in units]
+        weights = [(30.0 + i) * (30.0 + (j * 7) % 5) * (0.5 if h else 1.0) for i, j, h in units]
+        for world in (1, 2, 3, 8):
+            shares = assign_target_major(targets, weights, world)
+            assert shares == assign_target_major(targets, weights, world)
+            assert sorted(sum(shares, [])) == list(range(len(units)))
+            per_rank = [{targets[u] for u in sh} for sh in shares]
+            assert max(len(t) for t in per_rank) <= -(-na // world)
+            if na >= world:
+                owners = {t: [r for r in range(world) if t in per_rank[r]] for t in range(na)}
+                assert all(len(o) == 1 and o[0] == t % world for t, o in owners.items())
+                assert sum(len(t) for t in per_rank) == na                      # every table built exactly once
+            else:
+                assert all(sh for sh in shares[:min(world, len(units))])          # every rank has work
+                loads = [sum(weights[u] for u in sh) for sh in shares if sh]
+                assert max(loads) <= 2.5 * (sum(loads) / len(loads))
 
 
 def test_two_rank_gloo_gather_equals_single_process():
