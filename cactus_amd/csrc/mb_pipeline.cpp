@@ -1814,6 +1814,7 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
     handled = true;
     for (size_t k = 0; k < n; k++) { memset(&jobs[k]->res->stats, 0, sizeof(miblast_stats)); jobs[k]->t_begin = t_begin; }
 
+    const double t_prep0 = now_s();
     // ---- '-' strands (device + pinned host copy: discovery order, anchors, '='/'X' classification read it): one buffer, one launch and
     //      one copy back for the distinct query sets of the call
     {
@@ -1849,6 +1850,7 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         }
     }
 
+    const double t_prep1 = now_s();
     // ---- seed tables of the distinct targets
     // (bitmaps, bucket counts and the scatter's cursors lie one behind the other: one fill zeroes them)
     const size_t bx_cnt_words = up16((size_t)n_cnt * 4) / 4;
@@ -1876,6 +1878,7 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
                             w.bx_scan.p, s);
     MB_HIP(hipEventRecord(w.sev[0][2], s));
     unsigned long long total = 0;
+    const double t_prep2 = now_s();
     if (q_slots > 0) {
         MB_HIP(hipMemcpyAsync(w.pin_scan.p, w.bx_scan.p, ((size_t)n_tiles + 1) * 8, hipMemcpyDeviceToHost, s));
         MB_HIP(hipStreamSynchronize(s));                                           // (1) hits of every unit
@@ -1974,6 +1977,9 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         st.t_seedfill_ms = ms_fill + ms_count; st.t_sort_ms = ms_sort; st.t_ungapped_kernel_ms = ms_ung; st.ungapped_kernel_launches = total ? 1 : 0;
         (void)ms_index;
     }
+    if (env_long("MIBLAST_DEBUG", 0))
+        fprintf(stderr, "[miblast]   host timeline of the index part: set-up %.2f ms, '-' strands queued %.2f, tables + count queued %.2f, wait %.2f\n", (t_prep0 - t_begin) * 1e3, (t_prep1 - t_prep0) * 1e3,
+                (t_prep2 - t_prep1) * 1e3, (t_begin + t_index - t_prep2) * 1e3);
     if (env_long("MIBLAST_DEBUG", 0))
         fprintf(stderr, "[miblast] batched seed stage: %zu pairs, %zu targets, %llu hits, %zu HSP candidates; index %.2f ms (kernels %.2f), count %.2f, fill %.2f, sort %.2f, ungapped %.2f; device part %.2f ms\n",
                 n, targets.size(), total, n_found, t_index * 1e3, ms_index, ms_count, ms_fill, ms_sort, ms_ung, t_dev * 1e3);
@@ -2252,10 +2258,21 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (getenv("MIBLAST_ARENA_MB") || !arena_pool().take(ctx.device, want, g.arena.p, g.arena.n) || g.arena.n < want) {
             arena_pool().give(ctx.device, g.arena.p, g.arena.n);        // (too small a one: it stays in the pool for a lighter stage)
             g.arena.p = nullptr; g.arena.n = 0;
+            // (several lanes size their arenas at the same time: the look at the free memory and the allocation are one step, and an
+            //  allocation that does not fit after all -- another context of the process took the room -- gives the pool's idle arenas back
+            //  to the runtime and tries again with half, down to 256 MiB; the stage grows its arena later if the trace needs more)
+            static std::mutex arena_alloc_mutex;
+            std::lock_guard<std::mutex> lk(arena_alloc_mutex);
             size_t free_b = 0, total_b = 0;
             MB_HIP(hipMemGetInfo(&free_b, &total_b));
             want = std::min<size_t>(want, free_b > ((size_t)4 << 30) ? free_b - ((size_t)2 << 30) : free_b / 2);
-            MB_HIP(hipMalloc((void **)&g.arena.p, want));
+            while (hipMalloc((void **)&g.arena.p, want) != hipSuccess) {
+                (void)hipGetLastError();
+                g.arena.p = nullptr;
+                arena_pool().trim(ctx.device);
+                if (want <= ((size_t)256 << 20)) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
+                want = std::max<size_t>((size_t)256 << 20, want / 2);
+            }
             g.arena.n = want;
         }
         g.arena_next.ensure(1);
@@ -3086,7 +3103,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 g.arena.n = bigger;
             }
             if (arena_raw_estimate) {
-                const unsigned need = (unsigned)std::min<double>(65536.0 * 256.0, std::ceil((double)g.arena.n * 256.0 / (double)arena_raw_estimate));
+                // (what one outlier stage needed teaches the estimate of every later stage of the process: at most 16 x, not without bound)
+                const unsigned need = (unsigned)std::min<double>(16.0 * 256.0, std::ceil((double)g.arena.n * 256.0 / (double)arena_raw_estimate));
                 unsigned cur = arena_scale_q8().load();
                 while (need > cur && !arena_scale_q8().compare_exchange_weak(cur, need)) {}
             }

@@ -18,6 +18,16 @@
 #include <unordered_map>
 #include <vector>
 
+// a decimal column of a (ptr, len) text buffer: digits from b up to e at most -- never past the caller's buffer, whatever follows it
+// (the C ABI takes buffers that need not be NUL-terminated); an empty or non-numeric column reads as 0 as strtoll's would
+static inline long long field_i64(const char *b, const char *e) {
+    bool neg = false;
+    if (b < e && (*b == '-' || *b == '+')) { neg = *b == '-'; b++; }
+    long long v = 0;
+    for (; b < e && *b >= '0' && *b <= '9'; b++) v = v * 10 + (*b - '0');
+    return neg ? -v : v;
+}
+
 namespace {
 
 struct FaRec { std::string name; size_t body = 0, body_end = 0; int64_t len = 0; };
@@ -195,9 +205,9 @@ int mipaf_to_bed_text(const char *paf, size_t paf_len, const char *fasta, size_t
             return MIBLAST_OK;
         };
         int rc = for_paf_lines(paf, paf_len, "to_bed", [&](size_t p, size_t, const char *t[9]) -> int {
-            int r = add(paf + p, (size_t)(t[0] - (paf + p)), strtoll(t[0] + 1, nullptr, 10), strtoll(t[1] + 1, nullptr, 10), strtoll(t[2] + 1, nullptr, 10), true);
+            int r = add(paf + p, (size_t)(t[0] - (paf + p)), field_i64(t[0] + 1, t[1]), field_i64(t[1] + 1, t[2]), field_i64(t[2] + 1, t[3]), true);
             if (r != MIBLAST_OK || !include_inverted) return r;
-            return add(t[4] + 1, (size_t)(t[5] - (t[4] + 1)), strtoll(t[5] + 1, nullptr, 10), strtoll(t[6] + 1, nullptr, 10), strtoll(t[7] + 1, nullptr, 10), false);
+            return add(t[4] + 1, (size_t)(t[5] - (t[4] + 1)), field_i64(t[5] + 1, t[6]), field_i64(t[6] + 1, t[7]), field_i64(t[7] + 1, t[8]), false);
         });
         if (rc != MIBLAST_OK) return rc;
         std::string out;
@@ -240,7 +250,7 @@ int mipaf_fasta_extract_text(const char *bed, size_t bed_len, const char *fasta,
             const char *t1 = t0 ? (const char *)memchr(t0 + 1, '\t', (size_t)(bed + end - (t0 + 1))) : nullptr;
             if (!t1) { mb::set_error("extract: BED line " + std::to_string(line_no) + " has fewer than 3 columns"); return MIBLAST_EINVAL; }
             const std::string name(bed + p, (size_t)(t0 - (bed + p)));
-            const int64_t s = strtoll(t0 + 1, nullptr, 10), e = strtoll(t1 + 1, nullptr, 10);
+            const int64_t s = field_i64(t0 + 1, t1), e = field_i64(t1 + 1, bed + end);
             auto it = by_name.find(name);
             if (it == by_name.end()) {
                 if (skip_missing) continue;
@@ -302,7 +312,7 @@ int mipaf_upconvert_text(const char *paf, size_t paf_len, const char *const *fas
         char buf[96];
         int rc = for_paf_lines(paf, paf_len, "upconvert", [&](size_t p, size_t end, const char *t[9]) -> int {
             const std::string qn(paf + p, (size_t)(t[0] - (paf + p))), tn(t[4] + 1, (size_t)(t[5] - (t[4] + 1)));
-            const int64_t qs = strtoll(t[1] + 1, nullptr, 10), qe = strtoll(t[2] + 1, nullptr, 10), ts = strtoll(t[6] + 1, nullptr, 10), te = strtoll(t[7] + 1, nullptr, 10);
+            const int64_t qs = field_i64(t[1] + 1, t[2]), qe = field_i64(t[2] + 1, t[3]), ts = field_i64(t[6] + 1, t[7]), te = field_i64(t[7] + 1, t[8]);
             const Sub *q = nullptr, *tg = nullptr;
             int r = find(qn, qs, qe, q);
             if (r == MIBLAST_OK) r = find(tn, ts, te, tg);

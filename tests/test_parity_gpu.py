@@ -52,7 +52,7 @@ def test_case_matches_oracle(gpu_ctx, olz, monkeypatch, name, tf, qf, args):
     {"MIBLAST_SEED_PACKED": "2", "MIBLAST_HIT_CAP": "3000"},            # q batches (two-pass path, extent[] carried from batch to batch)
 ], ids=lambda e: ",".join(f"{k[8:].lower()}={v}" for k, v in e.items()))
 def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
-    """The seed stage of a large pair (mb_seed_dense.h: packed strands, q-ordered one-pass search with LDS-staged keys, scrambled
+    """The seed stage of a large pair (mb_seed_dense.h: packed strands, q-ordered one-pass search -- k_seed_hits + k_seed_keys --, scrambled
     diagonals, tables and '-' strands resident with their sets) on every case, with each of its switches: same bytes, HSP list in
     discovery order and counters as the oracle's.  Every case runs twice on the same resident sets, so the second call takes the
     both-strands-in-one-go path with the tables of the first."""
