@@ -2177,6 +2177,593 @@ static void build_units(const miblast_params &p, PairJob &job, int pair, std::ve
     }
 }
 
+// ---- the gapped stage, in units (round 5; until then gapped_phase was one function of 1 200 lines) -------------------------------------
+// gapped_phase (below) runs the rounds; a round is
+//   gapped_commit_and_nominate   commit what can be committed in anchor order, pick the next speculative batch of anchors
+//   (gapped_phase itself)        the one-sided DPs of the batch as chains of pieces: relay planting, the DP launches with their hand-over
+//                                checks, continuations, the wide sides -- what is left behind is a RoundDp
+//   gapped_finish_round          scores and boxes of the batch, the traceback in two phases, the merge into '=' / 'X' / 'I' / 'D' runs
+// and the trace arena is taken and grown by acquire_trace_arena / grow_trace_arena.
+namespace {
+struct Pending { size_t unit, anchor; };          // an anchor nominated for a speculative pair of one-sided DPs
+struct Piece {
+    int unit; int32_t ot, oq, dir;      // origin (concatenated coordinates) and direction
+    int32_t row_lo, min_row, stop_row;
+    int target;                         // relay point the stop row is aimed at (index into relay_pts, -1: none)
+    int ckpt;                           // which entry snapshot of that relay the hand-over is checked against (0: after relay_w rows, 1: 2x, 2: 4x)
+    int init_piece;                     // continuation: the piece whose exit snapshot it starts from
+    int vjob;                           // index into vres of the hand-over check made after it ran (-1: none)
+    int cont;                           // the piece that continues this one after a rejected hand-over (-1: none)
+};
+struct SideRun {
+    DpProb base;
+    int unit = 0;
+    std::vector<int> cur;               // pieces of the current run (one origin), in row order
+    size_t accounted = 0;               // how many of them are folded into the result
+    std::vector<int> chain;             // validated pieces, head first
+    std::vector<int32_t> chain_floor;   // per chain entry: the rows of that piece up to this one belong to the piece before it (head: -1)
+    long long c_off = 0;                // score of the current run's origin in the head's scores
+    long long acc_cells = 0, acc_rows = 0, entry_cells = 0, entry_rows = 0;
+    int gbest = -1, gbi = 0, gbj = 0, best_piece = -1;
+    bool done = false, wide = false;
+};
+// what the DPs of a round leave behind for its traceback: the sides' validated chains and the pieces they are made of
+struct RoundDp {
+    std::vector<SideRun> sides;
+    std::vector<Piece> pieces;
+    std::vector<DpProb> probs;
+    std::vector<DpOut> outs;
+};
+struct NominateCfg { size_t batch_max; long shadow_q0, shadow_d, spec_target, relay_s0_env; bool chain_heads, walls; };
+}  // namespace
+
+namespace {
+struct NextPt { int32_t ok, t, q, set_tail; };                 // set_tail >= 0: a virtual tail relay, that many lattice lines past the last anchor
+struct RelayLattice { long relay_s, relay_w, relay_tol, relay_gap, relay_tail_rows; };     // spacing, warm-up rows, diagonal tolerance, bridging distance (lattice steps), tail
+}  // namespace
+// the relay after the point (t, q) of a unit, walking in direction dir: in the first q-bucket of width relay_s at least
+// min_dq rows away, the best-scoring anchor (= smallest index, preferably near the start of the bucket) whose
+// diagonal lies within relay_tol of (t - q).  A bucket without such an anchor gets a VIRTUAL relay on the line to
+// the next anchor further down (any cell near the path works as an origin -- a fresh DP locks onto the path and
+// its state converges all the same; k_verify decides) so that stretches without seeds (soft-masked repeats)
+// do not turn into one long piece.  No anchor within relay_gap buckets: the chain ends.
+// Depends on the unit's anchors and the point only, so chains started from different heads merge.
+static NextPt relay_next_point(const Unit &u, const RelayLattice &lat, const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) {
+    const long relay_s = lat.relay_s, relay_w = lat.relay_w, relay_tol = lat.relay_tol, relay_gap = lat.relay_gap, relay_tail_rows = lat.relay_tail_rows;
+    const int32_t dirn = b.dir;
+    const long s_from = (long)dirn * q + min_dq;                 // first admissible position in walking order, s = dir * q
+    const long line = (s_from >= 0 ? (s_from + relay_s - 1) / relay_s : -((-s_from) / relay_s)) * relay_s;   // next lattice line (ceil)
+    auto in_bounds = [&](int32_t ct, int32_t cq) -> bool {
+        const int32_t dr = (cq - b.q0) * dirn, dc = (ct - b.t0) * dirn;
+        return dr > 0 && dc > 0 && dc < b.na - 64 && dr < b.nb - (int32_t)relay_w - 64;
+    };
+    // anchors with s in [s_lo, s_hi), nearest to the lattice line first
+    auto scan = [&](long s_lo, long s_hi, long want) -> long {
+        const long q_lo = dirn > 0 ? s_lo : -(s_hi - 1), q_hi = dirn > 0 ? s_hi : -s_lo + 1;      // [q_lo, q_hi)
+        auto it = std::lower_bound(u.by_q.begin(), u.by_q.end(), q_lo, [&](uint32_t x, long qq) { return (long)u.anchors[x].q < qq; });
+        long best = -1, best_d = 0;
+        for (; it != u.by_q.end() && (long)u.anchors[*it].q < q_hi; ++it) {
+            const Anchor &c = u.anchors[*it];
+            if (!in_bounds(c.t, c.q)) continue;
+            if (std::labs((long)(c.t - c.q) - (long)(t - q)) > relay_tol) continue;
+            const long d = std::labs((long)dirn * c.q - want);
+            if (best < 0 || d < best_d || (d == best_d && (long)*it < best)) { best = (long)*it; best_d = d; }
+        }
+        return best;
+    };
+    const long near = scan(std::max(s_from, line - relay_s / 4), line + relay_s / 4, line);
+    if (near >= 0) return NextPt{1, u.anchors[(size_t)near].t, u.anchors[(size_t)near].q, -1};
+    // no anchor at this lattice line: bridge towards the next anchor further down, if there is one
+    const long far = scan(line + relay_s / 4, line + relay_gap * relay_s, line);
+    if (far < 0) {
+        // past the last anchor an alignment may still run on for a while (soft-masked sequence has no seeds): a few
+        // more virtual relays straight down the diagonal keep that tail from becoming one long piece
+        if ((long)(from_tail + 1) * relay_s > relay_tail_rows) return NextPt{0, 0, 0, -1};
+        const int32_t vq = (int32_t)(dirn * line), vt = (int32_t)((long)t + (long)(vq - q));
+        if ((long)(vq - q) * dirn <= 0 || !in_bounds(vt, vq)) return NextPt{0, 0, 0, -1};
+        return NextPt{1, vt, vq, from_tail + 1};
+    }
+    const Anchor &c = u.anchors[(size_t)far];
+    const int32_t vq = (int32_t)(dirn * line);
+    const long span = (long)(c.q - q) * dirn, step = (long)(vq - q) * dirn;
+    const long ddiag = (long)(c.t - c.q) - (long)(t - q);
+    const int32_t vt = (int32_t)((long)t + (long)(vq - q) + (span > 0 ? ddiag * step / span : 0));
+    if (step <= 0 || !in_bounds(vt, vq)) return NextPt{1, c.t, c.q, -1};
+    return NextPt{1, vt, vq, -1};
+}
+
+// commit + nomination of a round: `pend` = the anchors whose DPs the round runs (empty: the stage is done), shadow_q = the thinning
+// neighbourhood that was used (diagnostics)
+static void gapped_commit_and_nominate(std::vector<PairJob *> &jobs, std::vector<Unit> &units, const NominateCfg &cfg, int round, std::vector<Pending> &pend,
+                                       long &shadow_q) {
+    const size_t batch_max = cfg.batch_max;
+    const long shadow_q0 = cfg.shadow_q0, shadow_d = cfg.shadow_d, spec_target = cfg.spec_target, relay_s0_env = cfg.relay_s0_env;
+    const bool chain_heads = cfg.chain_heads, walls = cfg.walls;
+    auto PS = [&](const Unit &u) -> miblast_stats & { return jobs[(size_t)u.pair]->res->stats; };
+    // commit what can be committed, then nominate the next speculative batch of every unit
+    // commit what can be committed
+    for (size_t ui = 0; ui < units.size(); ui++) {
+        Unit &u = units[ui];
+        while (u.next < u.anchors.size()) {
+            const Anchor &a = u.anchors[u.next];
+            if (u.cov[u.next]) { PS(u).anchors_skipped++; u.cache.erase(u.next); u.next++; continue; }
+            auto it = u.cache.find(u.next);
+            if (it == u.cache.end()) break;
+            Cached &c = it->second;
+            if (walls && c.epoch != u.kept.size()) { u.cache.erase(it); break; }     // ran against fewer walls than the unit has now: evaluate it again
+            if (c.accepted && !c.traced) { u.cache.erase(it); break; }    // predicted covered, but is not: evaluate it again
+            PS(u).dp_sides += 2; PS(u).dp_cells += c.cells; PS(u).dp_rows += c.rows;
+            if (c.accepted) {
+                miblast_aln A;
+                memset(&A, 0, sizeof A);
+                A.strand = u.strand; A.q_contig = u.q_contig; A.t_contig = jobs[(size_t)u.pair]->T->contig_of(a.t);
+                A.t_lo = c.t_lo; A.t_hi = c.t_hi; A.q_lo = c.q_lo; A.q_hi = c.q_hi;
+                A.score = c.score; A.dmin = c.dmin; A.dmax = c.dmax; A.anchor_t = a.t; A.anchor_q = a.q;
+                u.kept_anchor_score.push_back(a.score);
+                A.ops_off = (int64_t)u.unit_ops.size(); A.n_ops = (int64_t)c.ops.size();
+                u.unit_ops.insert(u.unit_ops.end(), c.ops.begin(), c.ops.end());
+                u.kept.push_back(A);
+                u.mark(u.cov, A.t_lo, A.t_hi, A.q_lo, A.q_hi, A.dmin, A.dmax);
+            }
+            u.cache.erase(it);
+            u.next++;
+        }
+        if (walls)                                                       // what ran against fewer walls is stale: drop it now, so that it is nominated again
+            for (auto it = u.cache.begin(); it != u.cache.end();) it = it->second.epoch != u.kept.size() ? u.cache.erase(it) : std::next(it);
+    }
+    // Nomination of the next speculative batch is a pure scheduling heuristic: results never depend on it because
+    // anchors are committed strictly in order above.  The first unresolved anchor of every unit is always nominated
+    // (progress); the others are thinned: skip what an uncommitted accepted result would cover, and keep at most one
+    // new anchor per (diagonal band, query neighbourhood).  The neighbourhood is the smallest of a 4x ladder that
+    // keeps the batch within `spec_target` anchors, so an idle GPU is filled with probes in the first round (a
+    // single one-sided DP is a row-sequential chain: rounds cost latency, parallel probes cost almost nothing).
+    parallel_for(units.size(), [&](size_t ui) {
+        Unit &u = units[ui];
+        std::fill(u.tent.begin(), u.tent.end(), 0);
+        for (const auto &kv : u.cache) {
+            const Cached &c = kv.second;
+            if (c.accepted) u.mark(u.tent, c.t_lo, c.t_hi, c.q_lo, c.q_hi, c.dmin, c.dmax);
+        }
+    });
+    pend.clear();
+    shadow_q = shadow_q0;
+    // (the units are independent: every unit's candidates are picked on the worker threads and strung together in unit order)
+    auto gather = [&](std::vector<std::vector<Pending>> &per, std::vector<Pending> &out) {
+        size_t total = 0;
+        for (const auto &v : per) total += v.size();
+        out.clear(); out.reserve(total);
+        for (const auto &v : per) out.insert(out.end(), v.begin(), v.end());
+    };
+    // First round: one head per colinear group of anchors (Unit::index_anchors) -- the best anchor of the group that is still
+    // open; its relay chain covers the rest of the group.  Whatever is left uncovered after that round (groups that bridge a
+    // stretch the extension does not survive) goes through the spatial thinning below, many at a time.
+    if (round == 0 && chain_heads && relay_s0_env != 0) {
+        std::vector<std::vector<Pending>> per(units.size());
+        parallel_for(units.size(), [&](size_t ui) {
+            Unit &u = units[ui];
+            std::vector<uint8_t> taken(u.n_comp, 0);
+            size_t n_taken = 0;
+            for (size_t k = u.next; k < u.anchors.size() && n_taken < batch_max; k++) {
+                if (u.cov[k] || u.cache.count(k)) continue;
+                if (k != u.next && (u.tent[k] || taken[u.comp[k]])) continue;
+                taken[u.comp[k]] = 1;
+                n_taken++;
+                per[ui].push_back(Pending{ui, k});
+            }
+        });
+        gather(per, pend);
+    }
+    for (int level = 0; level < 6 && !(round == 0 && chain_heads && relay_s0_env != 0); level++) {
+        std::vector<Pending> cand;
+        const long sq = std::max(64l, shadow_q0 >> (2 * level));
+        std::vector<std::vector<Pending>> per(units.size());
+        parallel_for(units.size(), [&](size_t ui) {
+            Unit &u = units[ui];
+            // taken anchors are bucketed on a (diagonal band, query neighbourhood) grid: the shadow test looks at 3x3 cells
+            std::unordered_map<long long, std::vector<Anchor>> grid;
+            size_t n_taken = 0;
+            auto cell = [&](const Anchor &a, long dd, long dq) -> long long {
+                const long gd = ((long)(a.t - a.q) + (1l << 31)) / (shadow_d + 1) + dd, gq = (long)a.q / (sq + 1) + dq;
+                return (long long)gd * (1ll << 32) + gq;
+            };
+            for (size_t k = u.next; k < u.anchors.size() && n_taken < batch_max; k++) {
+                if (u.cov[k] || u.cache.count(k)) continue;
+                const Anchor &a = u.anchors[k];
+                if (k != u.next) {
+                    if (u.tent[k]) continue;
+                    bool shadowed = false;
+                    for (long dd = -1; dd <= 1 && !shadowed; dd++)
+                        for (long dq = -1; dq <= 1 && !shadowed; dq++) {
+                            auto it = grid.find(cell(a, dd, dq));
+                            if (it == grid.end()) continue;
+                            for (const Anchor &b : it->second)
+                                if (std::labs((long)(a.t - a.q) - (long)(b.t - b.q)) <= shadow_d && std::labs((long)a.q - (long)b.q) <= sq) { shadowed = true; break; }
+                        }
+                    if (shadowed) continue;
+                }
+                grid[cell(a, 0, 0)].push_back(a);
+                n_taken++;
+                per[ui].push_back(Pending{ui, k});
+            }
+        });
+        gather(per, cand);
+        if (level > 0 && (long)cand.size() > spec_target) break;      // keep the previous (coarser) level
+        pend.swap(cand);
+        shadow_q = sq;
+        if ((long)pend.size() >= spec_target / 2) break;              // full enough
+    }
+}
+
+// the trace arena of a stage: borrowed from the pool (or made) at a size estimated from the anchors' HSPs
+static int acquire_trace_arena(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, const std::vector<size_t> *members, size_t n_members,
+                               size_t &arena_raw_estimate) {
+    Workspace &g = *ctx.ws;
+    // estimate: 0.65 B per evaluated cell (codes + row records), ~200 columns per row, rows ~ the anchors' HSP columns, twice for
+    // speculation and block granularity; MIBLAST_ARENA_MB fixes the size (tests of the grow-and-retry path)
+    size_t want = 256ull << 20;
+    for (size_t jk = 0; jk < n_members; jk++) {
+        const PairJob *j = jobs[members ? (*members)[jk] : jk];
+        for (const miblast_hsp &h : j->res->hsps) want += (size_t)h.len * 260u;
+    }
+    // (260 B per row is a window of ~200 columns, Cactus's --ydrop=3000 .. 9400; a wider window -- (Y - O) / E columns and a
+    //  quarter again -- takes that much more: --ydrop=20000 four times)
+    {
+        const long win = (p.ydrop > p.gap_open ? (p.ydrop - p.gap_open) / std::max(1, p.gap_extend) : 0) * 5 / 4 + 32;
+        if (win > 512) want = (size_t)((double)want * (double)win / 400.0);
+    }
+    arena_raw_estimate = want;
+    // (a stage that had to grow its arena teaches the estimate: the largest ratio of what was needed to what was estimated so far)
+    want = (size_t)((double)want * (double)arena_scale_q8().load() / 256.0);
+    { size_t cls = (size_t)1 << 30; while (cls < want) cls <<= 1; want = cls; }      // (size classes: 1 GiB, 2 GiB, ... -- the pool's arenas are reused, not multiplied)
+    if (getenv("MIBLAST_ARENA_MB")) want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
+    // (MIBLAST_ARENA_MB: an arena of exactly that size, whatever the pool holds -- the tests' way into the grow-and-retry path)
+    if (getenv("MIBLAST_ARENA_MB") || !arena_pool().take(ctx.device, want, g.arena.p, g.arena.n) || g.arena.n < want) {
+        arena_pool().give(ctx.device, g.arena.p, g.arena.n);        // (too small a one: it stays in the pool for a lighter stage)
+        g.arena.p = nullptr; g.arena.n = 0;
+        // (several lanes size their arenas at the same time: the look at the free memory and the allocation are one step, and an
+        //  allocation that does not fit after all -- another context of the process took the room -- gives the pool's idle arenas back
+        //  to the runtime and tries again with half, down to 256 MiB; the stage grows its arena later if the trace needs more)
+        static std::mutex arena_alloc_mutex;
+        std::lock_guard<std::mutex> lk(arena_alloc_mutex);
+        size_t free_b = 0, total_b = 0;
+        MB_HIP(hipMemGetInfo(&free_b, &total_b));
+        want = std::min<size_t>(want, free_b > ((size_t)4 << 30) ? free_b - ((size_t)2 << 30) : free_b / 2);
+        while (hipMalloc((void **)&g.arena.p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            g.arena.p = nullptr;
+            arena_pool().trim(ctx.device);
+            if (want <= ((size_t)256 << 20)) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
+            want = std::max<size_t>((size_t)256 << 20, want / 2);
+        }
+        g.arena.n = want;
+    }
+    g.arena_next.ensure(1);
+    return MIBLAST_OK;
+}
+
+// the round's trace did not fit: a larger arena (the round is repeated)
+static int grow_trace_arena(Ctx &ctx, size_t arena_raw_estimate) {
+    Workspace &g = *ctx.ws;
+    size_t free_b = 0, total_b = 0;
+    MB_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t room = free_b + g.arena.n > (2ull << 30) ? free_b + g.arena.n - (2ull << 30) : 0;   // leave 2 GiB for the rest
+    size_t bigger = std::min(g.arena.n * 4, room);      // few retries: every retry repeats the round
+    if (bigger <= g.arena.n) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
+    // (the one that was too small goes back to the pool -- or, when the larger one needs the room, to the runtime; a free one of the
+    //  size wanted is taken if there is one)
+    const size_t old_n = g.arena.n;
+    if (bigger + (2ull << 30) > free_b) { (void)hipFree(g.arena.p); arena_pool().trim(ctx.device); }
+    else arena_pool().give(ctx.device, g.arena.p, g.arena.n);
+    g.arena.p = nullptr; g.arena.n = 0;
+    if (!arena_pool().take(ctx.device, bigger, g.arena.p, g.arena.n) || g.arena.n < bigger) {
+        arena_pool().give(ctx.device, g.arena.p, g.arena.n);
+        g.arena.p = nullptr; g.arena.n = 0;
+        if (hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
+            (void)hipGetLastError();
+            g.arena.p = nullptr;
+            arena_pool().trim(ctx.device);               // (what other stages left free in the meantime)
+            MB_HIP(hipMemGetInfo(&free_b, &total_b));
+            bigger = std::min<size_t>(bigger, free_b > ((size_t)2 << 30) ? free_b - ((size_t)2 << 30) : (size_t)0);
+            if (bigger <= old_n || hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
+                (void)hipGetLastError();
+                g.arena.p = nullptr;
+                set_error("trace arena does not fit in device memory");
+                return MIBLAST_ELIMIT;
+            }
+        }
+        g.arena.n = bigger;
+    }
+    if (arena_raw_estimate) {
+        // (what one outlier stage needed teaches the estimate of every later stage of the process: at most 16 x, not without bound)
+        const unsigned need = (unsigned)std::min<double>(16.0 * 256.0, std::ceil((double)g.arena.n * 256.0 / (double)arena_raw_estimate));
+        unsigned cur = arena_scale_q8().load();
+        while (need > cur && !arena_scale_q8().compare_exchange_weak(cur, need)) {}
+    }
+    return MIBLAST_OK;
+}
+
+// results of a round's DPs: score and box of every nominated anchor into its unit's cache, then the traceback of what reaches
+// --gappedthresh, in two phases (see below), and the merge of the walkers' runs into the alignment's ops
+static int gapped_finish_round(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, std::vector<Unit> &units, const std::vector<Pending> &pend,
+                               const RoundDp &rd, miblast_stats &st, bool debug) {
+    Workspace &g = *ctx.ws;
+    hipStream_t s = ctx.stream;
+    const std::vector<SideRun> &sides = rd.sides;
+    const std::vector<Piece> &pieces = rd.pieces;
+    const std::vector<DpProb> &probs = rd.probs;
+    const std::vector<DpOut> &outs = rd.outs;
+    // ---- results of the round; traceback of the anchors reaching --gappedthresh -----------------------------
+    // Speculation produces duplicates: anchors whose DP found an alignment that an earlier anchor of the unit will have
+    // committed by the time their turn comes (they are then skipped as covered).  Tracing and merging those is wasted, so
+    // the traceback runs in two phases: first the results that lie in no earlier accepted box of their unit (nothing can
+    // cover them: they will be committed), then -- their diagonal bands now known -- the rest minus what they cover.
+    std::vector<Cached *> cres(pend.size(), nullptr);
+    for (size_t k = 0; k < pend.size(); k++) {
+        Unit &u = units[pend[k].unit];
+        Cached c;
+        const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
+        const Anchor &a = u.anchors[pend[k].anchor];
+        c.score = R.gbest + L.gbest;
+        c.cells = R.acc_cells + L.acc_cells; c.rows = R.acc_rows + L.acc_rows;
+        c.t_lo = a.t - L.gbj; c.t_hi = a.t + R.gbj; c.q_lo = a.q - L.gbi; c.q_hi = a.q + R.gbi;
+        c.accepted = c.score >= p.gappedthresh;
+        c.traced = false;
+        c.epoch = u.kept.size();
+        c.dmin = 0x7fffffff; c.dmax = -0x7fffffff - 1;          // set by the merge; until then covers nothing
+        cres[k] = &u.cache.emplace(pend[k].anchor, std::move(c)).first->second;      // (references into an unordered_map stay valid)
+    }
+    auto trace = [&](const std::vector<size_t> &acc) -> int {
+    std::vector<TbSide> tbs;
+    std::vector<TbWalk> tbw;
+    uint64_t ooff = 0, roff = 0, soff = 0;          // run slots, row records (3 x u32 each), segments
+    for (size_t k : acc) {
+            for (int side = 0; side < 2; side++) {
+                const SideRun &sd = sides[2 * k + (size_t)side];
+                TbSide ts;
+                memset(&ts, 0, sizeof ts);
+                ts.first_walk = (int32_t)tbw.size();
+                // one walker per piece of the chain, from the piece that holds the best cell back to the head
+                size_t at = 0;
+                while (at < sd.chain.size() && sd.chain[at] != sd.best_piece) at++;
+                uint64_t side_slots = 0;
+                for (size_t x = at + 1; x-- > 0;) {
+                    const int pc = sd.chain[x];
+                    const Piece &pp = pieces[(size_t)pc];
+                    TbWalk w;
+                    memset(&w, 0, sizeof w);
+                    w.row_off = probs[(size_t)pc].row_off; w.row_lo = pp.row_lo; w.floor = x > 0 ? sd.chain_floor[x] : -1;
+                    if (x == at) { w.si = sd.gbi - (pp.oq - sd.base.q0) * pp.dir; w.sj = sd.gbj - (pp.ot - sd.base.t0) * pp.dir; }
+                    else { w.si = pp.stop_row; w.sj = outs[(size_t)pc].exit_j; }      // guess: the best cell of the piece's last row
+                    if (x > 0) {
+                        const Piece &pv = pieces[(size_t)sd.chain[x - 1]];
+                        w.dr = (pp.oq - pv.oq) * pp.dir; w.dc = (pp.ot - pv.ot) * pp.dir;
+                    }
+                    const uint64_t rows = (uint64_t)(w.si - w.floor);
+                    const uint64_t slots = 2 * rows + 2 * (uint64_t)kLdsRowCap + 8;      // a run per step at worst
+                    w.ops_off = ooff; ooff += slots; side_slots += slots;
+                    w.rec_off = roff; roff += 3 * rows;
+                    tbw.push_back(w);
+                }
+                ts.n_walks = (int32_t)tbw.size() - ts.first_walk;
+                ts.jops_off = ooff; ooff += side_slots;                  // the join walk can at worst repeat every walk
+                for (size_t x = (size_t)ts.first_walk; x < tbw.size(); x++) {          // ... each piece's in its own share
+                    const unsigned long long jo = x == (size_t)ts.first_walk ? ~0ull : ts.jops_off + (tbw[x].ops_off - tbw[(size_t)ts.first_walk].ops_off);
+                    memcpy(tbw[x].pad, &jo, 8);
+                }
+                ts.seg_off = soff; soff += 2 * (uint64_t)ts.n_walks + 1;
+                tbs.push_back(ts);
+            }
+                }
+    const double t_tb0 = now_s();
+    std::vector<unsigned long long> coff;           // first packed run of every side (+ total)
+    if (!acc.empty()) {
+        // walks, sides and segments lie one behind the other: walks + sides go up in one copy, sides + segments come back in one
+        const size_t at_sides = Stager::behind(tbw.size() * sizeof(TbWalk)), at_segs = at_sides + Stager::behind(tbs.size() * sizeof(TbSide));
+        const size_t at_joins = at_segs + Stager::behind(((size_t)soff + 1) * sizeof(TbSeg));
+        g.tb_blk.ensure(at_joins + tbw.size() * sizeof(TbJoin) + 256);
+        TbWalk *const d_walks = (TbWalk *)g.tb_blk.p;
+        TbSide *const d_sides = (TbSide *)(g.tb_blk.p + at_sides);
+        TbSeg *const d_segs = (TbSeg *)(g.tb_blk.p + at_segs);
+        TbJoin *const d_joins = (TbJoin *)(g.tb_blk.p + at_joins);
+        g.ops.ensure((size_t)ooff + 64); g.recs.ensure((size_t)roff + 64);
+        g.stage.h2d2(g.tb_blk.p, tbw.data(), tbw.size() * sizeof(TbWalk), tbs.data(), tbs.size() * sizeof(TbSide), s);
+        launch_trace_walk(d_walks, (int)tbw.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, s);
+        // the join walks of all pieces at once, from predicted entries (MIBLAST_TRACE_PREJOIN=0: none, the sides walk themselves;
+        // 2: every other prediction is made wrong on purpose -- both for the tests)
+        const long prejoin = env_long("MIBLAST_TRACE_PREJOIN", 1);
+        if (prejoin) launch_trace_prejoin(d_walks, (int)tbw.size(), d_joins, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, prejoin == 2, s);
+        launch_trace_join(d_sides, (int)tbs.size(), d_walks, d_segs, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p,
+                          g.ops.p, g.recs.p, prejoin ? d_joins : nullptr, s);
+        std::vector<TbSeg> segs((size_t)soff + 1);
+        g.stage.d2h2(tbs.data(), tbs.size() * sizeof(TbSide), segs.data(), (size_t)soff * sizeof(TbSeg), d_sides, s);
+        MB_HIP(hipStreamSynchronize(s));
+        g.stage.done();
+        // only the run slots actually used travel: the segments are packed on the device in walk order, then one copy
+        std::vector<TbSeg> flat;
+        std::vector<unsigned long long> dst;
+        coff.assign(tbs.size() + 1, 0);
+        unsigned long long ctot = 0;
+        for (size_t x = 0; x < tbs.size(); x++) {
+            coff[x] = ctot;
+            for (int q = 0; q < tbs[x].n_segs; q++) {
+                const TbSeg &sg = segs[(size_t)tbs[x].seg_off + (size_t)q];
+                flat.push_back(sg); dst.push_back(ctot); ctot += (unsigned long long)sg.n_runs;
+            }
+        }
+        coff[tbs.size()] = ctot;
+        const size_t at_dst = Stager::behind(flat.size() * sizeof(TbSeg));
+        g.tb_blk.ensure(at_dst + (dst.size() + 1) * sizeof(unsigned long long) + 256);
+        g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
+        g.stage.h2d2(g.tb_blk.p, flat.data(), flat.size() * sizeof(TbSeg), dst.data(), dst.size() * sizeof(unsigned long long), s);
+        launch_pack_segs((const TbSeg *)g.tb_blk.p, (const unsigned long long *)(g.tb_blk.p + at_dst), (int)flat.size(), g.ops.p, g.ops_packed.p, s);
+        if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));
+        g.stage.done();
+        const uint32_t *hops = g.hops.p;
+        st.t_traceback_ms += (now_s() - t_tb0) * 1e3;
+        if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, tbs.size(), (unsigned long long)ooff);
+        if (debug) fprintf(stderr, "[miblast]   %zu walkers, %zu segments, %llu runs\n", tbw.size(), flat.size(), ctot);
+        const double t_mg0 = now_s();
+        // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
+        // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
+        std::vector<Cached *> cptr(acc.size());
+        for (size_t x = 0; x < acc.size(); x++) cptr[x] = &units[pend[acc[x]].unit].cache[pend[acc[x]].anchor];   // no map mutation inside the workers
+        // A long alignment is merged in chunks of runs on several threads: the (t, q) position of every chunk start is
+        // a cheap prefix over the run lengths; the chunks' run-length strings are stitched afterwards.
+        struct MergeTask { size_t x, r0, r1; int64_t tt, qq; std::vector<uint32_t> ops; int32_t dmin, dmax; };
+        std::vector<MergeTask> tasks;
+        std::vector<std::pair<size_t, size_t>> task_range(acc.size());
+        std::vector<std::pair<int64_t, int64_t>> reached(acc.size());
+        const size_t kRunsPerTask = 2048;
+        auto run_at = [&](size_t x, size_t run) -> uint32_t {
+            const uint32_t *Rops = hops + coff[2 * x], *Lops = hops + coff[2 * x + 1];
+            const size_t nR = (size_t)(coff[2 * x + 1] - coff[2 * x]), nL = (size_t)(coff[2 * x + 2] - coff[2 * x + 1]);
+            return run < nL ? Lops[run] : Rops[nR - 1 - (run - nL)];
+        };
+        // (the prefix walk of every alignment on the worker threads, the task lists strung together afterwards)
+        std::vector<std::vector<MergeTask>> per(acc.size());
+        parallel_for(acc.size(), [&](size_t x) {
+            const Cached &c = *cptr[x];
+            const size_t nruns = (size_t)(coff[2 * x + 2] - coff[2 * x]);
+            int64_t tt = c.t_lo, qq = c.q_lo;
+            for (size_t r0 = 0; r0 < nruns || r0 == 0; r0 += kRunsPerTask) {
+                const size_t r1 = std::min(nruns, r0 + kRunsPerTask);
+                per[x].push_back(MergeTask{x, r0, r1, tt, qq, {}, 0x7fffffff, -0x7fffffff - 1});
+                for (size_t r = r0; r < r1; r++) {
+                    const uint32_t e = run_at(x, r), o = e & 3u, len = e >> 2;
+                    if (o == 0) { tt += len; qq += len; } else if (o == 2) qq += len; else tt += len;
+                }
+                if (r1 >= nruns) break;
+            }
+            reached[x] = {tt, qq};
+        });
+        for (size_t x = 0; x < acc.size(); x++) {
+            task_range[x].first = tasks.size();
+            for (MergeTask &t : per[x]) tasks.push_back(std::move(t));
+            task_range[x].second = tasks.size();
+        }
+        const double t_mg1 = now_s();
+        parallel_for(tasks.size(), [&](size_t ti) {
+            MergeTask &t = tasks[ti];
+            const Unit &u = units[pend[acc[t.x]].unit];
+            const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
+            const uint8_t *qc = jobs[(size_t)u.pair]->qc_h[u.strand];
+            int64_t tt = t.tt, qq = t.qq;
+            uint32_t cur_op = 0, cur_len = 0;
+            std::vector<uint32_t> out;                          // thread-local until the end: no false sharing on the task array
+            out.reserve(4 * (t.r1 - t.r0) + 16);
+            int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
+            auto push = [&](uint32_t op, uint32_t len) {
+                if (cur_len && op == cur_op) cur_len += len;
+                else { if (cur_len) out.push_back((cur_len << 2) | cur_op); cur_op = op; cur_len = len; }
+            };
+            for (size_t run = t.r0; run < t.r1; run++) {
+                const uint32_t e = run_at(t.x, run);
+                const uint32_t o = e & 3u, len = e >> 2;
+                if (len == 0) continue;                         // a splice that fell on a run boundary
+                if (o == 0) {
+                    const int32_t d = (int32_t)(tt - qq);
+                    dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+                    const uint8_t *tp = tc_h + tt, *qp = qc + qq;
+                    // '=' iff both bases are the same of A, C, G, T.  Eight columns per step: the matching columns of the
+                    // eight as a bit mask, then whole runs of equal bits at a time (a run of '=' is dozens of columns long)
+                    uint32_t m = 0;
+                    for (; m + 8 <= len; m += 8) {
+                        unsigned bits = match_bits8(tp + m, qp + m), left = 8;
+                        while (left) {
+                            const unsigned one = bits & 1u;
+                            const unsigned n = std::min(left, (unsigned)__builtin_ctz((one ? ~bits : bits) | 0x100u));
+                            push(one ? 0u : 1u, n);
+                            bits >>= n; left -= n;
+                        }
+                    }
+                    for (; m < len; m++) {
+                        const unsigned a = tp[m] & 7u, b = qp[m] & 7u;
+                        push((a < 4u && a == b) ? 0u : 1u, 1);
+                    }
+                    tt += len; qq += len;
+                } else if (o == 2) { push(2, len); qq += len; }
+                else { push(3, len); tt += len; }
+            }
+            if (cur_len) out.push_back((cur_len << 2) | cur_op);
+            t.ops.swap(out); t.dmin = dmin; t.dmax = dmax;
+        });
+        const double t_mg2 = now_s();
+        if (debug) fprintf(stderr, "[miblast]   merge: prefix %.2f ms, %zu tasks %.2f ms (hw threads %u)\n", (t_mg1 - t_mg0) * 1e3, tasks.size(), (t_mg2 - t_mg1) * 1e3, std::thread::hardware_concurrency());
+        std::atomic<int> bad{0};
+        parallel_for(acc.size(), [&](size_t x) {
+            Cached &c = *cptr[x];
+            size_t total = 0;
+            for (size_t ti = task_range[x].first; ti < task_range[x].second; ti++) total += tasks[ti].ops.size();
+            c.ops.reserve(total);
+            int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
+            for (size_t ti = task_range[x].first; ti < task_range[x].second; ti++) {
+                const MergeTask &t = tasks[ti];
+                dmin = std::min(dmin, t.dmin); dmax = std::max(dmax, t.dmax);
+                size_t from = 0;
+                if (!c.ops.empty() && !t.ops.empty() && ((c.ops.back() ^ t.ops[0]) & 3u) == 0) { c.ops.back() += t.ops[0] & ~3u; from = 1; }   // same op across the seam
+                c.ops.insert(c.ops.end(), t.ops.begin() + (long)from, t.ops.end());
+            }
+            c.dmin = dmin; c.dmax = dmax;
+            if (reached[x].first != c.t_hi || reached[x].second != c.q_hi) {
+                const size_t k = acc[x];
+                if (!bad++ && debug) {
+                    const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
+                    fprintf(stderr, "[miblast] span error: anchor %zu box t %d..%d q %d..%d reached t %lld q %lld; R: best %d at (%d,%d) chain %zu; L: best %d at (%d,%d) chain %zu\n",
+                            k, c.t_lo, c.t_hi, c.q_lo, c.q_hi, (long long)reached[x].first, (long long)reached[x].second, R.gbest, R.gbi, R.gbj, R.chain.size(),
+                            L.gbest, L.gbi, L.gbj, L.chain.size());
+                }
+            }
+        });
+        if (bad) { set_error("internal: traceback does not span the alignment box"); return (int)MIBLAST_EHIP; }
+        for (Cached *c : cptr) c->traced = true;
+        st.t_merge_ms += (now_s() - t_mg0) * 1e3;
+        if (debug) fprintf(stderr, "[miblast]   host merge: %.2f ms\n", (now_s() - t_mg0) * 1e3);
+    }
+    return (int)MIBLAST_OK;
+    };
+    {
+        // commit order inside a unit = anchor index; group this round's accepted results by unit
+        std::unordered_map<size_t, std::vector<size_t>> by_unit;
+        for (size_t k = 0; k < pend.size(); k++) if (cres[k]->accepted) by_unit[pend[k].unit].push_back(k);
+        std::vector<size_t> first, later;
+        struct Box { size_t anchor; const Cached *c; };
+        std::unordered_map<size_t, std::vector<Box>> boxes;     // per unit: accepted results, old (traced in earlier rounds) and new
+        for (auto &kv : by_unit) {
+            Unit &u = units[kv.first];
+            std::vector<size_t> &ks = kv.second;
+            std::sort(ks.begin(), ks.end(), [&](size_t x, size_t y) { return pend[x].anchor < pend[y].anchor; });
+            std::vector<Box> &bx = boxes[kv.first];
+            for (const auto &e : u.cache) if (e.second.accepted) bx.push_back(Box{e.first, &e.second});
+            for (size_t k : ks) {
+                const Anchor &a = u.anchors[pend[k].anchor];
+                bool inside = false;
+                for (const Box &b : bx)
+                    if (b.anchor < pend[k].anchor && a.t >= b.c->t_lo && a.t < b.c->t_hi && a.q >= b.c->q_lo && a.q < b.c->q_hi) { inside = true; break; }
+                (inside ? later : first).push_back(k);
+            }
+        }
+        std::sort(first.begin(), first.end());
+        int rc = trace(first);
+        if (rc != MIBLAST_OK) return rc;
+        std::vector<size_t> second;
+        for (size_t k : later) {
+            const Unit &u = units[pend[k].unit];
+            const Anchor &a = u.anchors[pend[k].anchor];
+            const int32_t d = a.t - a.q;
+            bool covered = false;
+            for (const Box &b : boxes[pend[k].unit])
+                if (b.c->traced && b.anchor < pend[k].anchor && a.t >= b.c->t_lo && a.t < b.c->t_hi && a.q >= b.c->q_lo && a.q < b.c->q_hi &&
+                    d >= b.c->dmin && d <= b.c->dmax) { covered = true; break; }
+            if (!covered) second.push_back(k);
+        }
+        std::sort(second.begin(), second.end());
+        rc = trace(second);
+        if (rc != MIBLAST_OK) return rc;
+    }
+    return MIBLAST_OK;
+}
+
 // score-ordered gapped extension of every unit of every pair of the batch: all speculative one-sided DPs of a round
 // share one k_ydrop launch, so several chunk pairs fill the GPU together
 // `members`: the pairs whose units are in `units` (nullptr: all pairs of `jobs`) -- a large call runs the gapped stages of two
@@ -2229,171 +2816,23 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     miblast_stats st;                        // launch-level counters shared by all pairs of the batch
     memset(&st, 0, sizeof st);
     const double t_g0 = now_s();
-    auto PS = [&](const Unit &u) -> miblast_stats & { return jobs[(size_t)u.pair]->res->stats; };
     size_t arena_raw_estimate = 0;
     struct ArenaLoan {                                                   // back to the pool however the stage ends
         Workspace &g; int device;
         ~ArenaLoan() { arena_pool().give(device, g.arena.p, g.arena.n); g.arena.p = nullptr; g.arena.n = 0; }
     } arena_loan{g, ctx.device};
     if (!units.empty()) {
-        // estimate: 0.65 B per evaluated cell (codes + row records), ~200 columns per row, rows ~ the anchors' HSP columns, twice for
-        // speculation and block granularity; MIBLAST_ARENA_MB fixes the size (tests of the grow-and-retry path)
-        size_t want = 256ull << 20;
-        for (size_t jk = 0; jk < n_members; jk++) {
-            const PairJob *j = jobs[members ? (*members)[jk] : jk];
-            for (const miblast_hsp &h : j->res->hsps) want += (size_t)h.len * 260u;
-        }
-        // (260 B per row is a window of ~200 columns, Cactus's --ydrop=3000 .. 9400; a wider window -- (Y - O) / E columns and a
-        //  quarter again -- takes that much more: --ydrop=20000 four times)
-        {
-            const long win = (p.ydrop > p.gap_open ? (p.ydrop - p.gap_open) / std::max(1, p.gap_extend) : 0) * 5 / 4 + 32;
-            if (win > 512) want = (size_t)((double)want * (double)win / 400.0);
-        }
-        arena_raw_estimate = want;
-        // (a stage that had to grow its arena teaches the estimate: the largest ratio of what was needed to what was estimated so far)
-        want = (size_t)((double)want * (double)arena_scale_q8().load() / 256.0);
-        { size_t cls = (size_t)1 << 30; while (cls < want) cls <<= 1; want = cls; }      // (size classes: 1 GiB, 2 GiB, ... -- the pool's arenas are reused, not multiplied)
-        if (getenv("MIBLAST_ARENA_MB")) want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
-        // (MIBLAST_ARENA_MB: an arena of exactly that size, whatever the pool holds -- the tests' way into the grow-and-retry path)
-        if (getenv("MIBLAST_ARENA_MB") || !arena_pool().take(ctx.device, want, g.arena.p, g.arena.n) || g.arena.n < want) {
-            arena_pool().give(ctx.device, g.arena.p, g.arena.n);        // (too small a one: it stays in the pool for a lighter stage)
-            g.arena.p = nullptr; g.arena.n = 0;
-            // (several lanes size their arenas at the same time: the look at the free memory and the allocation are one step, and an
-            //  allocation that does not fit after all -- another context of the process took the room -- gives the pool's idle arenas back
-            //  to the runtime and tries again with half, down to 256 MiB; the stage grows its arena later if the trace needs more)
-            static std::mutex arena_alloc_mutex;
-            std::lock_guard<std::mutex> lk(arena_alloc_mutex);
-            size_t free_b = 0, total_b = 0;
-            MB_HIP(hipMemGetInfo(&free_b, &total_b));
-            want = std::min<size_t>(want, free_b > ((size_t)4 << 30) ? free_b - ((size_t)2 << 30) : free_b / 2);
-            while (hipMalloc((void **)&g.arena.p, want) != hipSuccess) {
-                (void)hipGetLastError();
-                g.arena.p = nullptr;
-                arena_pool().trim(ctx.device);
-                if (want <= ((size_t)256 << 20)) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
-                want = std::max<size_t>((size_t)256 << 20, want / 2);
-            }
-            g.arena.n = want;
-        }
-        g.arena_next.ensure(1);
+        const int rc_arena = acquire_trace_arena(ctx, p, jobs, members, n_members, arena_raw_estimate);
+        if (rc_arena != MIBLAST_OK) return rc_arena;
     }
-    struct Pending { size_t unit, anchor; };
+    const NominateCfg nominate_cfg{batch_max, shadow_q0, shadow_d, spec_target, relay_s0_env, chain_heads, walls};
     for (int round = 0;; round++) {
         double tm[6] = {0, 0, 0, 0, 0, 0};                 // debug: where a round's host time goes
         double tm_t = now_s();
         auto lap = [&](int k) { const double n = now_s(); tm[k] += n - tm_t; tm_t = n; };
-        // commit what can be committed, then nominate the next speculative batch of every unit
-        // commit what can be committed
-        for (size_t ui = 0; ui < units.size(); ui++) {
-            Unit &u = units[ui];
-            while (u.next < u.anchors.size()) {
-                const Anchor &a = u.anchors[u.next];
-                if (u.cov[u.next]) { PS(u).anchors_skipped++; u.cache.erase(u.next); u.next++; continue; }
-                auto it = u.cache.find(u.next);
-                if (it == u.cache.end()) break;
-                Cached &c = it->second;
-                if (walls && c.epoch != u.kept.size()) { u.cache.erase(it); break; }     // ran against fewer walls than the unit has now: evaluate it again
-                if (c.accepted && !c.traced) { u.cache.erase(it); break; }    // predicted covered, but is not: evaluate it again
-                PS(u).dp_sides += 2; PS(u).dp_cells += c.cells; PS(u).dp_rows += c.rows;
-                if (c.accepted) {
-                    miblast_aln A;
-                    memset(&A, 0, sizeof A);
-                    A.strand = u.strand; A.q_contig = u.q_contig; A.t_contig = jobs[(size_t)u.pair]->T->contig_of(a.t);
-                    A.t_lo = c.t_lo; A.t_hi = c.t_hi; A.q_lo = c.q_lo; A.q_hi = c.q_hi;
-                    A.score = c.score; A.dmin = c.dmin; A.dmax = c.dmax; A.anchor_t = a.t; A.anchor_q = a.q;
-                    u.kept_anchor_score.push_back(a.score);
-                    A.ops_off = (int64_t)u.unit_ops.size(); A.n_ops = (int64_t)c.ops.size();
-                    u.unit_ops.insert(u.unit_ops.end(), c.ops.begin(), c.ops.end());
-                    u.kept.push_back(A);
-                    u.mark(u.cov, A.t_lo, A.t_hi, A.q_lo, A.q_hi, A.dmin, A.dmax);
-                }
-                u.cache.erase(it);
-                u.next++;
-            }
-            if (walls)                                                       // what ran against fewer walls is stale: drop it now, so that it is nominated again
-                for (auto it = u.cache.begin(); it != u.cache.end();) it = it->second.epoch != u.kept.size() ? u.cache.erase(it) : std::next(it);
-        }
-        // Nomination of the next speculative batch is a pure scheduling heuristic: results never depend on it because
-        // anchors are committed strictly in order above.  The first unresolved anchor of every unit is always nominated
-        // (progress); the others are thinned: skip what an uncommitted accepted result would cover, and keep at most one
-        // new anchor per (diagonal band, query neighbourhood).  The neighbourhood is the smallest of a 4x ladder that
-        // keeps the batch within `spec_target` anchors, so an idle GPU is filled with probes in the first round (a
-        // single one-sided DP is a row-sequential chain: rounds cost latency, parallel probes cost almost nothing).
-        parallel_for(units.size(), [&](size_t ui) {
-            Unit &u = units[ui];
-            std::fill(u.tent.begin(), u.tent.end(), 0);
-            for (const auto &kv : u.cache) {
-                const Cached &c = kv.second;
-                if (c.accepted) u.mark(u.tent, c.t_lo, c.t_hi, c.q_lo, c.q_hi, c.dmin, c.dmax);
-            }
-        });
         std::vector<Pending> pend;
         long shadow_q = shadow_q0;
-        // (the units are independent: every unit's candidates are picked on the worker threads and strung together in unit order)
-        auto gather = [&](std::vector<std::vector<Pending>> &per, std::vector<Pending> &out) {
-            size_t total = 0;
-            for (const auto &v : per) total += v.size();
-            out.clear(); out.reserve(total);
-            for (const auto &v : per) out.insert(out.end(), v.begin(), v.end());
-        };
-        // First round: one head per colinear group of anchors (Unit::index_anchors) -- the best anchor of the group that is still
-        // open; its relay chain covers the rest of the group.  Whatever is left uncovered after that round (groups that bridge a
-        // stretch the extension does not survive) goes through the spatial thinning below, many at a time.
-        if (round == 0 && chain_heads && relay_s0_env != 0) {
-            std::vector<std::vector<Pending>> per(units.size());
-            parallel_for(units.size(), [&](size_t ui) {
-                Unit &u = units[ui];
-                std::vector<uint8_t> taken(u.n_comp, 0);
-                size_t n_taken = 0;
-                for (size_t k = u.next; k < u.anchors.size() && n_taken < batch_max; k++) {
-                    if (u.cov[k] || u.cache.count(k)) continue;
-                    if (k != u.next && (u.tent[k] || taken[u.comp[k]])) continue;
-                    taken[u.comp[k]] = 1;
-                    n_taken++;
-                    per[ui].push_back(Pending{ui, k});
-                }
-            });
-            gather(per, pend);
-        }
-        for (int level = 0; level < 6 && !(round == 0 && chain_heads && relay_s0_env != 0); level++) {
-            std::vector<Pending> cand;
-            const long sq = std::max(64l, shadow_q0 >> (2 * level));
-            std::vector<std::vector<Pending>> per(units.size());
-            parallel_for(units.size(), [&](size_t ui) {
-                Unit &u = units[ui];
-                // taken anchors are bucketed on a (diagonal band, query neighbourhood) grid: the shadow test looks at 3x3 cells
-                std::unordered_map<long long, std::vector<Anchor>> grid;
-                size_t n_taken = 0;
-                auto cell = [&](const Anchor &a, long dd, long dq) -> long long {
-                    const long gd = ((long)(a.t - a.q) + (1l << 31)) / (shadow_d + 1) + dd, gq = (long)a.q / (sq + 1) + dq;
-                    return (long long)gd * (1ll << 32) + gq;
-                };
-                for (size_t k = u.next; k < u.anchors.size() && n_taken < batch_max; k++) {
-                    if (u.cov[k] || u.cache.count(k)) continue;
-                    const Anchor &a = u.anchors[k];
-                    if (k != u.next) {
-                        if (u.tent[k]) continue;
-                        bool shadowed = false;
-                        for (long dd = -1; dd <= 1 && !shadowed; dd++)
-                            for (long dq = -1; dq <= 1 && !shadowed; dq++) {
-                                auto it = grid.find(cell(a, dd, dq));
-                                if (it == grid.end()) continue;
-                                for (const Anchor &b : it->second)
-                                    if (std::labs((long)(a.t - a.q) - (long)(b.t - b.q)) <= shadow_d && std::labs((long)a.q - (long)b.q) <= sq) { shadowed = true; break; }
-                            }
-                        if (shadowed) continue;
-                    }
-                    grid[cell(a, 0, 0)].push_back(a);
-                    n_taken++;
-                    per[ui].push_back(Pending{ui, k});
-                }
-            });
-            gather(per, cand);
-            if (level > 0 && (long)cand.size() > spec_target) break;      // keep the previous (coarser) level
-            pend.swap(cand);
-            shadow_q = sq;
-            if ((long)pend.size() >= spec_target / 2) break;              // full enough
-        }
+        gapped_commit_and_nominate(jobs, units, nominate_cfg, round, pend, shadow_q);
         if (pend.empty()) break;
         st.gapped_rounds++;
         lap(0);
@@ -2412,27 +2851,6 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         // from its snapshot to the relay after that.  Relays sit on a lattice of the unit's anchors that does not
         // depend on the side (next_relay), so every side running through the same alignment shares them.  Results
         // (score, end cell, trace, cell and row counts) never depend on where relays start or whether they are accepted.
-        struct Piece {
-            int unit; int32_t ot, oq, dir;      // origin (concatenated coordinates) and direction
-            int32_t row_lo, min_row, stop_row;
-            int target;                         // relay point the stop row is aimed at (index into relay_pts, -1: none)
-            int ckpt;                           // which entry snapshot of that relay the hand-over is checked against (0: after relay_w rows, 1: 2x, 2: 4x)
-            int init_piece;                     // continuation: the piece whose exit snapshot it starts from
-            int vjob;                           // index into vres of the hand-over check made after it ran (-1: none)
-            int cont;                           // the piece that continues this one after a rejected hand-over (-1: none)
-        };
-        struct SideRun {
-            DpProb base;
-            int unit = 0;
-            std::vector<int> cur;               // pieces of the current run (one origin), in row order
-            size_t accounted = 0;               // how many of them are folded into the result
-            std::vector<int> chain;             // validated pieces, head first
-            std::vector<int32_t> chain_floor;   // per chain entry: the rows of that piece up to this one belong to the piece before it (head: -1)
-            long long c_off = 0;                // score of the current run's origin in the head's scores
-            long long acc_cells = 0, acc_rows = 0, entry_cells = 0, entry_rows = 0;
-            int gbest = -1, gbi = 0, gbj = 0, best_piece = -1;
-            bool done = false, wide = false;
-        };
         const int nsides = (int)pend.size() * 2;
         // few sides (one chunk pair): short pieces, the longest one sets the time.  Many sides (batched pairs): the GPU is full
         // anyway, longer pieces waste less on warm-up overlap.
@@ -2490,8 +2908,9 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             g.stage.h2d(g.wall_segs.p, wall_segs.data(), wall_segs.size() * 4, s);
             g.stage.h2d(g.wall_alns.p, wall_alns.data(), wall_alns.size() * 4, s);
         }
-        std::vector<SideRun> sides;
-        std::vector<Piece> pieces;
+        RoundDp rd;
+        std::vector<SideRun> &sides = rd.sides;
+        std::vector<Piece> &pieces = rd.pieces;
         // per piece the alignments of its unit (uploaded with the pieces of a launch)
         auto upload_wall_refs = [&](size_t first, size_t last) -> const int32_t * {
             if (!walls) return nullptr;
@@ -2501,8 +2920,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             g.stage.h2d(g.wall_ref.p + 2 * first, ref.data(), ref.size() * 4, s);
             return g.wall_ref.p + 2 * first;
         };
-        std::vector<DpProb> probs;
-        std::vector<DpOut> outs;
+        std::vector<DpProb> &probs = rd.probs;
+        std::vector<DpOut> &outs = rd.outs;
         std::vector<VerifyJob> vjobs;
         std::vector<VerifyOut> vres;
         struct RelayPt { int unit; int32_t t, q, dir; int piece; int tail; };   // origin of a relay; piece = its fresh DP (-1: not queued yet); tail = virtual relays since the last anchor
@@ -2521,57 +2940,8 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
             relay_pts.push_back(RelayPt{unit, t, q, dir, -1, 0});
             return (int)relay_pts.size() - 1;
         };
-        // the relay after the point (t, q) of a unit, walking in direction dir: in the first q-bucket of width relay_s at least
-        // min_dq rows away, the best-scoring anchor (= smallest index, preferably near the start of the bucket) whose
-        // diagonal lies within relay_tol of (t - q).  A bucket without such an anchor gets a VIRTUAL relay on the line to
-        // the next anchor further down (any cell near the path works as an origin -- a fresh DP locks onto the path and
-        // its state converges all the same; k_verify decides) so that stretches without seeds (soft-masked repeats)
-        // do not turn into one long piece.  No anchor within relay_gap buckets: the chain ends.
-        // Depends on the unit's anchors and the point only, so chains started from different heads merge.
-        struct NextPt { int32_t ok, t, q, set_tail; };                 // set_tail >= 0: a virtual tail relay, that many lattice lines past the last anchor
-        auto next_point = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) -> NextPt {
-            const Unit &u = units[(size_t)unit];
-            const int32_t dirn = b.dir;
-            const long s_from = (long)dirn * q + min_dq;                 // first admissible position in walking order, s = dir * q
-            const long line = (s_from >= 0 ? (s_from + relay_s - 1) / relay_s : -((-s_from) / relay_s)) * relay_s;   // next lattice line (ceil)
-            auto in_bounds = [&](int32_t ct, int32_t cq) -> bool {
-                const int32_t dr = (cq - b.q0) * dirn, dc = (ct - b.t0) * dirn;
-                return dr > 0 && dc > 0 && dc < b.na - 64 && dr < b.nb - (int32_t)relay_w - 64;
-            };
-            // anchors with s in [s_lo, s_hi), nearest to the lattice line first
-            auto scan = [&](long s_lo, long s_hi, long want) -> long {
-                const long q_lo = dirn > 0 ? s_lo : -(s_hi - 1), q_hi = dirn > 0 ? s_hi : -s_lo + 1;      // [q_lo, q_hi)
-                auto it = std::lower_bound(u.by_q.begin(), u.by_q.end(), q_lo, [&](uint32_t x, long qq) { return (long)u.anchors[x].q < qq; });
-                long best = -1, best_d = 0;
-                for (; it != u.by_q.end() && (long)u.anchors[*it].q < q_hi; ++it) {
-                    const Anchor &c = u.anchors[*it];
-                    if (!in_bounds(c.t, c.q)) continue;
-                    if (std::labs((long)(c.t - c.q) - (long)(t - q)) > relay_tol) continue;
-                    const long d = std::labs((long)dirn * c.q - want);
-                    if (best < 0 || d < best_d || (d == best_d && (long)*it < best)) { best = (long)*it; best_d = d; }
-                }
-                return best;
-            };
-            const long near = scan(std::max(s_from, line - relay_s / 4), line + relay_s / 4, line);
-            if (near >= 0) return NextPt{1, u.anchors[(size_t)near].t, u.anchors[(size_t)near].q, -1};
-            // no anchor at this lattice line: bridge towards the next anchor further down, if there is one
-            const long far = scan(line + relay_s / 4, line + relay_gap * relay_s, line);
-            if (far < 0) {
-                // past the last anchor an alignment may still run on for a while (soft-masked sequence has no seeds): a few
-                // more virtual relays straight down the diagonal keep that tail from becoming one long piece
-                if ((long)(from_tail + 1) * relay_s > relay_tail_rows) return NextPt{0, 0, 0, -1};
-                const int32_t vq = (int32_t)(dirn * line), vt = (int32_t)((long)t + (long)(vq - q));
-                if ((long)(vq - q) * dirn <= 0 || !in_bounds(vt, vq)) return NextPt{0, 0, 0, -1};
-                return NextPt{1, vt, vq, from_tail + 1};
-            }
-            const Anchor &c = u.anchors[(size_t)far];
-            const int32_t vq = (int32_t)(dirn * line);
-            const long span = (long)(c.q - q) * dirn, step = (long)(vq - q) * dirn;
-            const long ddiag = (long)(c.t - c.q) - (long)(t - q);
-            const int32_t vt = (int32_t)((long)t + (long)(vq - q) + (span > 0 ? ddiag * step / span : 0));
-            if (step <= 0 || !in_bounds(vt, vq)) return NextPt{1, c.t, c.q, -1};
-            return NextPt{1, vt, vq, -1};
-        };
+        const RelayLattice lattice{relay_s, relay_w, relay_tol, relay_gap, relay_tail_rows};
+        auto next_point = [&](int unit, const DpProb &b, int32_t t, int32_t q, int32_t min_dq, int from_tail) -> NextPt { return relay_next_point(units[(size_t)unit], lattice, b, t, q, min_dq, from_tail); };
         // The lattice step is a pure function of the unit's anchors and the point, and it is where planting spends its time (two
         // scans of the anchor index per step): the chains of all heads are therefore walked ahead of the planting, one task per
         // (unit, direction) on the worker threads, into chain_memo; the serial planting below then finds its steps there.
@@ -3073,316 +3443,16 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                 }
             }
             if (!arena_full) break;
-            size_t free_b = 0, total_b = 0;
-            MB_HIP(hipMemGetInfo(&free_b, &total_b));
-            const size_t room = free_b + g.arena.n > (2ull << 30) ? free_b + g.arena.n - (2ull << 30) : 0;   // leave 2 GiB for the rest
-            size_t bigger = std::min(g.arena.n * 4, room);      // few retries: every retry repeats the round
-            if (bigger <= g.arena.n) { set_error("trace arena does not fit in device memory"); return MIBLAST_ELIMIT; }
-            // (the one that was too small goes back to the pool -- or, when the larger one needs the room, to the runtime; a free one of the
-            //  size wanted is taken if there is one)
-            const size_t old_n = g.arena.n;
-            if (bigger + (2ull << 30) > free_b) { (void)hipFree(g.arena.p); arena_pool().trim(ctx.device); }
-            else arena_pool().give(ctx.device, g.arena.p, g.arena.n);
-            g.arena.p = nullptr; g.arena.n = 0;
-            if (!arena_pool().take(ctx.device, bigger, g.arena.p, g.arena.n) || g.arena.n < bigger) {
-                arena_pool().give(ctx.device, g.arena.p, g.arena.n);
-                g.arena.p = nullptr; g.arena.n = 0;
-                if (hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
-                    (void)hipGetLastError();
-                    g.arena.p = nullptr;
-                    arena_pool().trim(ctx.device);               // (what other stages left free in the meantime)
-                    MB_HIP(hipMemGetInfo(&free_b, &total_b));
-                    bigger = std::min<size_t>(bigger, free_b > ((size_t)2 << 30) ? free_b - ((size_t)2 << 30) : (size_t)0);
-                    if (bigger <= old_n || hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
-                        (void)hipGetLastError();
-                        g.arena.p = nullptr;
-                        set_error("trace arena does not fit in device memory");
-                        return MIBLAST_ELIMIT;
-                    }
-                }
-                g.arena.n = bigger;
-            }
-            if (arena_raw_estimate) {
-                // (what one outlier stage needed teaches the estimate of every later stage of the process: at most 16 x, not without bound)
-                const unsigned need = (unsigned)std::min<double>(16.0 * 256.0, std::ceil((double)g.arena.n * 256.0 / (double)arena_raw_estimate));
-                unsigned cur = arena_scale_q8().load();
-                while (need > cur && !arena_scale_q8().compare_exchange_weak(cur, need)) {}
-            }
+            const int rc_grow = grow_trace_arena(ctx, arena_raw_estimate);
+            if (rc_grow != MIBLAST_OK) return rc_grow;
         }
         lap(3);
         st.relay_accepted += n_verify_ok; st.relay_rejected += n_verify_bad;
         if (debug) fprintf(stderr, "[miblast] round %d: %d sides in %zu pieces, %ld launches, hand-overs %ld accepted / %ld rejected (regime: %ld sides in flight%s, S0 %ld S %ld W %ld, %s)\n",
                            round, nsides, pieces.size(), n_subrounds, n_verify_ok, n_verify_bad, nsides_call, crowd ? " = crowd" : "", relay_s0, relay_s, relay_w, plant_at_once ? "chains planted with the heads" : "relays after the first stop");
 
-        // ---- results of the round; traceback of the anchors reaching --gappedthresh -----------------------------
-        // Speculation produces duplicates: anchors whose DP found an alignment that an earlier anchor of the unit will have
-        // committed by the time their turn comes (they are then skipped as covered).  Tracing and merging those is wasted, so
-        // the traceback runs in two phases: first the results that lie in no earlier accepted box of their unit (nothing can
-        // cover them: they will be committed), then -- their diagonal bands now known -- the rest minus what they cover.
-        std::vector<Cached *> cres(pend.size(), nullptr);
-        for (size_t k = 0; k < pend.size(); k++) {
-            Unit &u = units[pend[k].unit];
-            Cached c;
-            const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
-            const Anchor &a = u.anchors[pend[k].anchor];
-            c.score = R.gbest + L.gbest;
-            c.cells = R.acc_cells + L.acc_cells; c.rows = R.acc_rows + L.acc_rows;
-            c.t_lo = a.t - L.gbj; c.t_hi = a.t + R.gbj; c.q_lo = a.q - L.gbi; c.q_hi = a.q + R.gbi;
-            c.accepted = c.score >= p.gappedthresh;
-            c.traced = false;
-            c.epoch = u.kept.size();
-            c.dmin = 0x7fffffff; c.dmax = -0x7fffffff - 1;          // set by the merge; until then covers nothing
-            cres[k] = &u.cache.emplace(pend[k].anchor, std::move(c)).first->second;      // (references into an unordered_map stay valid)
-        }
-        auto trace = [&](const std::vector<size_t> &acc) -> int {
-        std::vector<TbSide> tbs;
-        std::vector<TbWalk> tbw;
-        uint64_t ooff = 0, roff = 0, soff = 0;          // run slots, row records (3 x u32 each), segments
-        for (size_t k : acc) {
-                for (int side = 0; side < 2; side++) {
-                    const SideRun &sd = sides[2 * k + (size_t)side];
-                    TbSide ts;
-                    memset(&ts, 0, sizeof ts);
-                    ts.first_walk = (int32_t)tbw.size();
-                    // one walker per piece of the chain, from the piece that holds the best cell back to the head
-                    size_t at = 0;
-                    while (at < sd.chain.size() && sd.chain[at] != sd.best_piece) at++;
-                    uint64_t side_slots = 0;
-                    for (size_t x = at + 1; x-- > 0;) {
-                        const int pc = sd.chain[x];
-                        const Piece &pp = pieces[(size_t)pc];
-                        TbWalk w;
-                        memset(&w, 0, sizeof w);
-                        w.row_off = probs[(size_t)pc].row_off; w.row_lo = pp.row_lo; w.floor = x > 0 ? sd.chain_floor[x] : -1;
-                        if (x == at) { w.si = sd.gbi - (pp.oq - sd.base.q0) * pp.dir; w.sj = sd.gbj - (pp.ot - sd.base.t0) * pp.dir; }
-                        else { w.si = pp.stop_row; w.sj = outs[(size_t)pc].exit_j; }      // guess: the best cell of the piece's last row
-                        if (x > 0) {
-                            const Piece &pv = pieces[(size_t)sd.chain[x - 1]];
-                            w.dr = (pp.oq - pv.oq) * pp.dir; w.dc = (pp.ot - pv.ot) * pp.dir;
-                        }
-                        const uint64_t rows = (uint64_t)(w.si - w.floor);
-                        const uint64_t slots = 2 * rows + 2 * (uint64_t)kLdsRowCap + 8;      // a run per step at worst
-                        w.ops_off = ooff; ooff += slots; side_slots += slots;
-                        w.rec_off = roff; roff += 3 * rows;
-                        tbw.push_back(w);
-                    }
-                    ts.n_walks = (int32_t)tbw.size() - ts.first_walk;
-                    ts.jops_off = ooff; ooff += side_slots;                  // the join walk can at worst repeat every walk
-                    for (size_t x = (size_t)ts.first_walk; x < tbw.size(); x++) {          // ... each piece's in its own share
-                        const unsigned long long jo = x == (size_t)ts.first_walk ? ~0ull : ts.jops_off + (tbw[x].ops_off - tbw[(size_t)ts.first_walk].ops_off);
-                        memcpy(tbw[x].pad, &jo, 8);
-                    }
-                    ts.seg_off = soff; soff += 2 * (uint64_t)ts.n_walks + 1;
-                    tbs.push_back(ts);
-                }
-                    }
-        const double t_tb0 = now_s();
-        std::vector<unsigned long long> coff;           // first packed run of every side (+ total)
-        if (!acc.empty()) {
-            // walks, sides and segments lie one behind the other: walks + sides go up in one copy, sides + segments come back in one
-            const size_t at_sides = Stager::behind(tbw.size() * sizeof(TbWalk)), at_segs = at_sides + Stager::behind(tbs.size() * sizeof(TbSide));
-            const size_t at_joins = at_segs + Stager::behind(((size_t)soff + 1) * sizeof(TbSeg));
-            g.tb_blk.ensure(at_joins + tbw.size() * sizeof(TbJoin) + 256);
-            TbWalk *const d_walks = (TbWalk *)g.tb_blk.p;
-            TbSide *const d_sides = (TbSide *)(g.tb_blk.p + at_sides);
-            TbSeg *const d_segs = (TbSeg *)(g.tb_blk.p + at_segs);
-            TbJoin *const d_joins = (TbJoin *)(g.tb_blk.p + at_joins);
-            g.ops.ensure((size_t)ooff + 64); g.recs.ensure((size_t)roff + 64);
-            g.stage.h2d2(g.tb_blk.p, tbw.data(), tbw.size() * sizeof(TbWalk), tbs.data(), tbs.size() * sizeof(TbSide), s);
-            launch_trace_walk(d_walks, (int)tbw.size(), g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, s);
-            // the join walks of all pieces at once, from predicted entries (MIBLAST_TRACE_PREJOIN=0: none, the sides walk themselves;
-            // 2: every other prediction is made wrong on purpose -- both for the tests)
-            const long prejoin = env_long("MIBLAST_TRACE_PREJOIN", 1);
-            if (prejoin) launch_trace_prejoin(d_walks, (int)tbw.size(), d_joins, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p, g.ops.p, g.recs.p, prejoin == 2, s);
-            launch_trace_join(d_sides, (int)tbs.size(), d_walks, d_segs, g.arena.p, (unsigned long long)g.arena.n, g.rowdir.p,
-                              g.ops.p, g.recs.p, prejoin ? d_joins : nullptr, s);
-            std::vector<TbSeg> segs((size_t)soff + 1);
-            g.stage.d2h2(tbs.data(), tbs.size() * sizeof(TbSide), segs.data(), (size_t)soff * sizeof(TbSeg), d_sides, s);
-            MB_HIP(hipStreamSynchronize(s));
-            g.stage.done();
-            // only the run slots actually used travel: the segments are packed on the device in walk order, then one copy
-            std::vector<TbSeg> flat;
-            std::vector<unsigned long long> dst;
-            coff.assign(tbs.size() + 1, 0);
-            unsigned long long ctot = 0;
-            for (size_t x = 0; x < tbs.size(); x++) {
-                coff[x] = ctot;
-                for (int q = 0; q < tbs[x].n_segs; q++) {
-                    const TbSeg &sg = segs[(size_t)tbs[x].seg_off + (size_t)q];
-                    flat.push_back(sg); dst.push_back(ctot); ctot += (unsigned long long)sg.n_runs;
-                }
-            }
-            coff[tbs.size()] = ctot;
-            const size_t at_dst = Stager::behind(flat.size() * sizeof(TbSeg));
-            g.tb_blk.ensure(at_dst + (dst.size() + 1) * sizeof(unsigned long long) + 256);
-            g.ops_packed.ensure((size_t)ctot + 64); g.hops.ensure((size_t)ctot + 64);
-            g.stage.h2d2(g.tb_blk.p, flat.data(), flat.size() * sizeof(TbSeg), dst.data(), dst.size() * sizeof(unsigned long long), s);
-            launch_pack_segs((const TbSeg *)g.tb_blk.p, (const unsigned long long *)(g.tb_blk.p + at_dst), (int)flat.size(), g.ops.p, g.ops_packed.p, s);
-            if (ctot) MB_HIP(hipMemcpyAsync(g.hops.p, g.ops_packed.p, (size_t)ctot * 4, hipMemcpyDeviceToHost, s));
-            MB_HIP(hipStreamSynchronize(s));
-            g.stage.done();
-            const uint32_t *hops = g.hops.p;
-            st.t_traceback_ms += (now_s() - t_tb0) * 1e3;
-            if (debug) fprintf(stderr, "[miblast]   traceback kernel + copies: %.2f ms (%zu sides, %llu run slots)\n", (now_s() - t_tb0) * 1e3, tbs.size(), (unsigned long long)ooff);
-            if (debug) fprintf(stderr, "[miblast]   %zu walkers, %zu segments, %llu runs\n", tbw.size(), flat.size(), ctot);
-            const double t_mg0 = now_s();
-            // merge the two sides into a forward run-length '=XID' string (left walk-back order is already
-            // forward, the right one is reversed), split aligned pairs into '=' / 'X', track the diagonal band
-            std::vector<Cached *> cptr(acc.size());
-            for (size_t x = 0; x < acc.size(); x++) cptr[x] = &units[pend[acc[x]].unit].cache[pend[acc[x]].anchor];   // no map mutation inside the workers
-            // A long alignment is merged in chunks of runs on several threads: the (t, q) position of every chunk start is
-            // a cheap prefix over the run lengths; the chunks' run-length strings are stitched afterwards.
-            struct MergeTask { size_t x, r0, r1; int64_t tt, qq; std::vector<uint32_t> ops; int32_t dmin, dmax; };
-            std::vector<MergeTask> tasks;
-            std::vector<std::pair<size_t, size_t>> task_range(acc.size());
-            std::vector<std::pair<int64_t, int64_t>> reached(acc.size());
-            const size_t kRunsPerTask = 2048;
-            auto run_at = [&](size_t x, size_t run) -> uint32_t {
-                const uint32_t *Rops = hops + coff[2 * x], *Lops = hops + coff[2 * x + 1];
-                const size_t nR = (size_t)(coff[2 * x + 1] - coff[2 * x]), nL = (size_t)(coff[2 * x + 2] - coff[2 * x + 1]);
-                return run < nL ? Lops[run] : Rops[nR - 1 - (run - nL)];
-            };
-            // (the prefix walk of every alignment on the worker threads, the task lists strung together afterwards)
-            std::vector<std::vector<MergeTask>> per(acc.size());
-            parallel_for(acc.size(), [&](size_t x) {
-                const Cached &c = *cptr[x];
-                const size_t nruns = (size_t)(coff[2 * x + 2] - coff[2 * x]);
-                int64_t tt = c.t_lo, qq = c.q_lo;
-                for (size_t r0 = 0; r0 < nruns || r0 == 0; r0 += kRunsPerTask) {
-                    const size_t r1 = std::min(nruns, r0 + kRunsPerTask);
-                    per[x].push_back(MergeTask{x, r0, r1, tt, qq, {}, 0x7fffffff, -0x7fffffff - 1});
-                    for (size_t r = r0; r < r1; r++) {
-                        const uint32_t e = run_at(x, r), o = e & 3u, len = e >> 2;
-                        if (o == 0) { tt += len; qq += len; } else if (o == 2) qq += len; else tt += len;
-                    }
-                    if (r1 >= nruns) break;
-                }
-                reached[x] = {tt, qq};
-            });
-            for (size_t x = 0; x < acc.size(); x++) {
-                task_range[x].first = tasks.size();
-                for (MergeTask &t : per[x]) tasks.push_back(std::move(t));
-                task_range[x].second = tasks.size();
-            }
-            const double t_mg1 = now_s();
-            parallel_for(tasks.size(), [&](size_t ti) {
-                MergeTask &t = tasks[ti];
-                const Unit &u = units[pend[acc[t.x]].unit];
-                const uint8_t *tc_h = jobs[(size_t)u.pair]->tc_h;
-                const uint8_t *qc = jobs[(size_t)u.pair]->qc_h[u.strand];
-                int64_t tt = t.tt, qq = t.qq;
-                uint32_t cur_op = 0, cur_len = 0;
-                std::vector<uint32_t> out;                          // thread-local until the end: no false sharing on the task array
-                out.reserve(4 * (t.r1 - t.r0) + 16);
-                int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
-                auto push = [&](uint32_t op, uint32_t len) {
-                    if (cur_len && op == cur_op) cur_len += len;
-                    else { if (cur_len) out.push_back((cur_len << 2) | cur_op); cur_op = op; cur_len = len; }
-                };
-                for (size_t run = t.r0; run < t.r1; run++) {
-                    const uint32_t e = run_at(t.x, run);
-                    const uint32_t o = e & 3u, len = e >> 2;
-                    if (len == 0) continue;                         // a splice that fell on a run boundary
-                    if (o == 0) {
-                        const int32_t d = (int32_t)(tt - qq);
-                        dmin = std::min(dmin, d); dmax = std::max(dmax, d);
-                        const uint8_t *tp = tc_h + tt, *qp = qc + qq;
-                        // '=' iff both bases are the same of A, C, G, T.  Eight columns per step: the matching columns of the
-                        // eight as a bit mask, then whole runs of equal bits at a time (a run of '=' is dozens of columns long)
-                        uint32_t m = 0;
-                        for (; m + 8 <= len; m += 8) {
-                            unsigned bits = match_bits8(tp + m, qp + m), left = 8;
-                            while (left) {
-                                const unsigned one = bits & 1u;
-                                const unsigned n = std::min(left, (unsigned)__builtin_ctz((one ? ~bits : bits) | 0x100u));
-                                push(one ? 0u : 1u, n);
-                                bits >>= n; left -= n;
-                            }
-                        }
-                        for (; m < len; m++) {
-                            const unsigned a = tp[m] & 7u, b = qp[m] & 7u;
-                            push((a < 4u && a == b) ? 0u : 1u, 1);
-                        }
-                        tt += len; qq += len;
-                    } else if (o == 2) { push(2, len); qq += len; }
-                    else { push(3, len); tt += len; }
-                }
-                if (cur_len) out.push_back((cur_len << 2) | cur_op);
-                t.ops.swap(out); t.dmin = dmin; t.dmax = dmax;
-            });
-            const double t_mg2 = now_s();
-            if (debug) fprintf(stderr, "[miblast]   merge: prefix %.2f ms, %zu tasks %.2f ms (hw threads %u)\n", (t_mg1 - t_mg0) * 1e3, tasks.size(), (t_mg2 - t_mg1) * 1e3, std::thread::hardware_concurrency());
-            std::atomic<int> bad{0};
-            parallel_for(acc.size(), [&](size_t x) {
-                Cached &c = *cptr[x];
-                size_t total = 0;
-                for (size_t ti = task_range[x].first; ti < task_range[x].second; ti++) total += tasks[ti].ops.size();
-                c.ops.reserve(total);
-                int32_t dmin = 0x7fffffff, dmax = -0x7fffffff - 1;
-                for (size_t ti = task_range[x].first; ti < task_range[x].second; ti++) {
-                    const MergeTask &t = tasks[ti];
-                    dmin = std::min(dmin, t.dmin); dmax = std::max(dmax, t.dmax);
-                    size_t from = 0;
-                    if (!c.ops.empty() && !t.ops.empty() && ((c.ops.back() ^ t.ops[0]) & 3u) == 0) { c.ops.back() += t.ops[0] & ~3u; from = 1; }   // same op across the seam
-                    c.ops.insert(c.ops.end(), t.ops.begin() + (long)from, t.ops.end());
-                }
-                c.dmin = dmin; c.dmax = dmax;
-                if (reached[x].first != c.t_hi || reached[x].second != c.q_hi) {
-                    const size_t k = acc[x];
-                    if (!bad++ && debug) {
-                        const SideRun &R = sides[2 * k], &L = sides[2 * k + 1];
-                        fprintf(stderr, "[miblast] span error: anchor %zu box t %d..%d q %d..%d reached t %lld q %lld; R: best %d at (%d,%d) chain %zu; L: best %d at (%d,%d) chain %zu\n",
-                                k, c.t_lo, c.t_hi, c.q_lo, c.q_hi, (long long)reached[x].first, (long long)reached[x].second, R.gbest, R.gbi, R.gbj, R.chain.size(),
-                                L.gbest, L.gbi, L.gbj, L.chain.size());
-                    }
-                }
-            });
-            if (bad) { set_error("internal: traceback does not span the alignment box"); return (int)MIBLAST_EHIP; }
-            for (Cached *c : cptr) c->traced = true;
-            st.t_merge_ms += (now_s() - t_mg0) * 1e3;
-            if (debug) fprintf(stderr, "[miblast]   host merge: %.2f ms\n", (now_s() - t_mg0) * 1e3);
-        }
-        return (int)MIBLAST_OK;
-        };
-        {
-            // commit order inside a unit = anchor index; group this round's accepted results by unit
-            std::unordered_map<size_t, std::vector<size_t>> by_unit;
-            for (size_t k = 0; k < pend.size(); k++) if (cres[k]->accepted) by_unit[pend[k].unit].push_back(k);
-            std::vector<size_t> first, later;
-            struct Box { size_t anchor; const Cached *c; };
-            std::unordered_map<size_t, std::vector<Box>> boxes;     // per unit: accepted results, old (traced in earlier rounds) and new
-            for (auto &kv : by_unit) {
-                Unit &u = units[kv.first];
-                std::vector<size_t> &ks = kv.second;
-                std::sort(ks.begin(), ks.end(), [&](size_t x, size_t y) { return pend[x].anchor < pend[y].anchor; });
-                std::vector<Box> &bx = boxes[kv.first];
-                for (const auto &e : u.cache) if (e.second.accepted) bx.push_back(Box{e.first, &e.second});
-                for (size_t k : ks) {
-                    const Anchor &a = u.anchors[pend[k].anchor];
-                    bool inside = false;
-                    for (const Box &b : bx)
-                        if (b.anchor < pend[k].anchor && a.t >= b.c->t_lo && a.t < b.c->t_hi && a.q >= b.c->q_lo && a.q < b.c->q_hi) { inside = true; break; }
-                    (inside ? later : first).push_back(k);
-                }
-            }
-            std::sort(first.begin(), first.end());
-            int rc = trace(first);
-            if (rc != MIBLAST_OK) return rc;
-            std::vector<size_t> second;
-            for (size_t k : later) {
-                const Unit &u = units[pend[k].unit];
-                const Anchor &a = u.anchors[pend[k].anchor];
-                const int32_t d = a.t - a.q;
-                bool covered = false;
-                for (const Box &b : boxes[pend[k].unit])
-                    if (b.c->traced && b.anchor < pend[k].anchor && a.t >= b.c->t_lo && a.t < b.c->t_hi && a.q >= b.c->q_lo && a.q < b.c->q_hi &&
-                        d >= b.c->dmin && d <= b.c->dmax) { covered = true; break; }
-                if (!covered) second.push_back(k);
-            }
-            std::sort(second.begin(), second.end());
-            rc = trace(second);
-            if (rc != MIBLAST_OK) return rc;
-        }
+        const int rc_fin = gapped_finish_round(ctx, p, jobs, units, pend, rd, st, debug);
+        if (rc_fin != MIBLAST_OK) return rc_fin;
         lap(4);
         if (debug) fprintf(stderr, "[miblast]   round %d host timeline: commit+nominate %.2f ms, plant %.2f, launches+sync %.2f, advance+continuations %.2f, results+traceback %.2f\n",
                            round, tm[0] * 1e3, tm[1] * 1e3, tm[2] * 1e3, tm[3] * 1e3, tm[4] * 1e3);

@@ -273,6 +273,15 @@ RELAY_CONFIGS = [
     {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_TRACE_PREJOIN": "0"},
     {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_TRACE_PREJOIN": "2"},
     {"MIBLAST_RELAY_S0": "32", "MIBLAST_RELAY_S": "300", "MIBLAST_RELAY_W": "70", "MIBLAST_RELAY_FORCE_REJECT": "3", "MIBLAST_TRACE_PREJOIN": "2"},
+    # round 5, the hand-over inside the DP launch (mb_ydrop2.h): off (every rejected hand-over a launch of its own, as before); every second
+    # piece's first check rejected on purpose (the piece goes on to the relay's next snapshot in the same wave); the first three checks of
+    # EVERY piece rejected (past the relay's last snapshot, on to the relay after); next to no room to go on (the host's continuation
+    # takes over); both kinds of forced rejection at once
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_INLINE": "0", "MIBLAST_RELAY_FORCE_REJECT": "2"},
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_INLINE_FORCE_REJECT": "2"},
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "512", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_INLINE_FORCE_REJECT": "-3"},
+    {"MIBLAST_RELAY_S0": "64", "MIBLAST_RELAY_S": "256", "MIBLAST_RELAY_W": "64", "MIBLAST_RELAY_INLINE_FORCE_REJECT": "-1", "MIBLAST_RELAY_INLINE_ROWS": "100"},
+    {"MIBLAST_RELAY_S0": "48", "MIBLAST_RELAY_S": "300", "MIBLAST_RELAY_W": "70", "MIBLAST_RELAY_INLINE_FORCE_REJECT": "3", "MIBLAST_RELAY_FORCE_REJECT": "4", "MIBLAST_RELAY_CKPT": "0"},
 ]
 
 
@@ -305,6 +314,12 @@ def test_relay_handover_matches_oracle(gpu_ctx, olz, monkeypatch, env):
             assert got.stats["relay_accepted"] > 0, "the case must exercise hand-overs"
             if "MIBLAST_RELAY_FORCE_REJECT" in env:
                 assert got.stats["relay_rejected"] > 0
+            if env.get("MIBLAST_RELAY_INLINE") == "0":
+                assert got.stats["relay_inline_checks"] == 0 and got.stats["relay_inline_continued"] == 0
+            if "MIBLAST_RELAY_INLINE_FORCE_REJECT" in env and args is DEFAULT:                # (--ydrop=4000: the one-wave kernel that has the check)
+                assert got.stats["relay_inline_checks"] > 0
+                if "MIBLAST_RELAY_INLINE_ROWS" not in env:
+                    assert got.stats["relay_inline_continued"] > 0, "no piece went on inside its launch"
 
 
 def test_full_size_properties_1mb(gpu_ctx, olz, monkeypatch):

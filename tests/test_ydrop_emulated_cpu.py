@@ -39,3 +39,17 @@ def test_emulated_relay_hand_over_that_is_accepted_is_exact():
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()
     assert "MISMATCH" not in out and "accepted  ok" in out, out
+
+
+def test_emulated_hand_over_inside_the_launch_leaves_the_results_alone():
+    """Round 5: a piece that reaches its stop row checks its hand-over itself and, rejected, goes on in the same wave
+    -- to the relay's next entry snapshot, then to the relay after -- instead of leaving that to a continuation piece in a launch of its
+    own.  Emulated launch of a head aimed at relay A aimed at relay B (the relays' blocks first, so that their snapshots are there): as the
+    pieces decide for themselves, with the first check of every piece rejected on purpose, and with the first three -- whatever they do,
+    following the chain as the host does (k_verify on the hand-over each piece says it ended at) gives the side's best cell, score and
+    cell count, and the VerifyJob a piece rewrites is the hand-over it ended at."""
+    subprocess.run(["make", "-C", EMU_DIR, "emu_ydrop"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_ydrop"), "9", "1", "inline"], capture_output=True, timeout=1500)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert "MISMATCH" not in out and out.count("concluded  ok") >= 2 and "pass 2" in out, out
