@@ -19,9 +19,29 @@
 // what one wave of a launch reads of another's snapshot while both run: loads that bypass the caches that are not coherent across
 // CUs / XCDs (agent scope), the stamp as the acquire / release pair around them
 #define yd_ld_agent(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define yd_ld_acquire(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
-#define yd_st_release(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
-#define yd_fence() __threadfence()
+// (the reader: the stamp and everything it reads of the snapshot afterwards are agent-scope loads -- they go to the coherent level, past this
+//  XCD's L2 --, issued in order behind a branch on the stamp's value; an agent-scope ACQUIRE would invalidate the L2 for every check)
+static __device__ __forceinline__ int yd_ld_acquire_i32(const int *p) {
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return v;
+}
+#define yd_ld_acquire(p) yd_ld_acquire_i32(p)
+// A snapshot is WRITTEN with agent-scope stores (write-through: nothing of it stays dirty in this XCD's L2), its lanes' stores are waited
+// for (a workgroup-scope release fence: s_waitcnt, no cache maintenance), then the stamp goes out the same way.  An agent-scope release
+// FENCE instead writes the whole L2 back -- every wave's half-filled trace lines, ten thousand times per launch: the first version of
+// this did, and the DP launches' WRITE_SIZE went from 1.28 to 1.54 times their algorithmic bytes (profiles/r05_hbm_traffic_pmc.json).
+#define yd_st_agent(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define yd_st_release(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define yd_fence() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); } while (0)
+// a lane's four columns of a snapshot in ONE 16-byte write-through store: the wave's stores of an instruction are then one contiguous
+// kilobyte.  (Four dword stores per lane are four instructions that each touch every fourth dword of the same lines: written through,
+// every 32-byte sector went to memory four times -- 170 MB of the 1 100 MB a step's DP launches wrote, profiles/README.md.)
+typedef int yd_int4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void yd_st_agent4(int *p, int a, int b, int c, int d) {
+    const yd_int4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 #endif
 
 // k_ydrop2: k_ydrop1 with 4 columns per lane and a SECOND group of 256 columns that is only evaluated when a row needs
@@ -355,12 +375,21 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
             int *sC = (int *)(sp + sizeof(SnapHdr)), *sD = sC + kSnapCols;
             int lmax = kNeg2, lj = 0;
 #pragma unroll
-            for (int g = 0; g < G; g++)
+            for (int g = 0; g < G; g++) {
+                const int j0 = jb + g * kHalf + K * lane;
+                if (j0 >= LY && j0 + K <= RY) {                              // (all four columns inside the window: nearly every lane that writes at all)
+                    yd_st_agent4(&sC[j0 - LY], C[g][0], C[g][1], C[g][2], C[g][3]);
+                    yd_st_agent4(&sD[j0 - LY], D[g][0], D[g][1], D[g][2], D[g][3]);
+                }
 #pragma unroll
                 for (int k = 0; k < K; k++) {
-                    const int j = jb + g * kHalf + K * lane + k;
-                    if (j >= LY && j < RY) { sC[j - LY] = C[g][k]; sD[j - LY] = D[g][k]; if (C[g][k] > lmax) { lmax = C[g][k]; lj = j; } }
+                    const int j = j0 + k;
+                    if (j >= LY && j < RY) {
+                        if (!(j0 >= LY && j0 + K <= RY)) { yd_st_agent(&sC[j - LY], C[g][k]); yd_st_agent(&sD[j - LY], D[g][k]); }
+                        if (C[g][k] > lmax) { lmax = C[g][k]; lj = j; }
+                    }
                 }
+            }
             // best cell of the row, leftmost on ties: (score, -column) maximum over the wave
             const int wmax = uni(yd_readlane(dpp_scan_max(lmax), 63));
             const int cand_j = lmax == wmax ? lj : 0x7fffffff;
@@ -368,8 +397,10 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
             yd_fence();                                                   // (every lane's C / D before the header that announces them)
             if (lane == 0) {
                 SnapHdr *h = (SnapHdr *)sp;
-                h->LY = LY; h->RY = RY; h->best = best; h->bi = bi; h->bj = bj; h->row = i; h->rows = rows; h->cells = cells;
-                h->valid = 1;
+                yd_st_agent(&h->LY, LY); yd_st_agent(&h->RY, RY); yd_st_agent(&h->best, best); yd_st_agent(&h->bi, bi); yd_st_agent(&h->bj, bj);
+                yd_st_agent(&h->row, i); yd_st_agent(&h->rows, rows); yd_st_agent(&h->cells, (int64_t)cells);
+                yd_st_agent(&h->valid, 1);
+                yd_fence();                                               // (the header's fields before the stamp that vouches for them)
                 yd_st_release(&h->stamp, stamp);
             }
             if (i == stop_at) {

@@ -56,6 +56,8 @@ static inline long long yd_clock() { return 0; }
 #define yd_ld_agent(p) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define yd_ld_acquire(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
 #define yd_st_release(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define yd_st_agent(p, v) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
+static inline void yd_st_agent4(int *p, int a, int b, int c, int d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 #define yd_fence() __sync_synchronize()
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
