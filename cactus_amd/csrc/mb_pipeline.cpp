@@ -2337,23 +2337,54 @@ static void gapped_commit_and_nominate(std::vector<PairJob *> &jobs, std::vector
     // First round: one head per colinear group of anchors (Unit::index_anchors) -- the best anchor of the group that is still
     // open; its relay chain covers the rest of the group.  Whatever is left uncovered after that round (groups that bridge a
     // stretch the extension does not survive) goes through the spatial thinning below, many at a time.
-    if (round == 0 && chain_heads && relay_s0_env != 0) {
+    const long heads_rounds = env_long("MIBLAST_HEAD_ROUNDS", 1);      // 0: groups give heads in the first round only (rounds 1.. thin spatially, as before round 5)
+    const bool by_groups = chain_heads && relay_s0_env != 0 && (round == 0 || heads_rounds != 0);
+    if (by_groups) {
         std::vector<std::vector<Pending>> per(units.size());
+        // (round 5: a head per STRETCH of a group -- head_span rows of q, at most head_max stretches per group.  A group is what ONE alignment is
+        //  likely to run through, but the head's extension often ends inside it -- a diverged stretch the y-drop does not survive -- and what
+        //  lies behind used to wait for a round of its own: on the phase's 6-pair call 20 anchors, 429 pieces and 2 ms of the critical
+        //  path.  Heads on the same alignment share their relay pieces (the lattice does not depend on the head), so a further head costs its
+        //  own first piece and nothing else; what it finds that an earlier head has covered is dropped before the traceback.  0: one per group.)
+        // In the FIRST round a group gives one head (MIBLAST_HEAD_SPAN0 = 0: stretch heads everywhere cost the 6-pair call of the mammals phase
+        // 50 % more cells for nothing, and a 30 Mb chunk pair 20 % of its step); a group that still has open anchors after that IS broken into
+        // several alignments, and from the second round on every stretch of it gives a head -- its fragments are found side by side instead
+        // of eight duplicates on the nearest one (the spatial thinning of the rounds before round 5: MIBLAST_HEAD_ROUNDS=0); the phase's
+        // step 18.0-18.1 -> 17.1-17.5 ms.  (MIBLAST_HEAD_SPAN0 with MIBLAST_HEAD_FEW = 16 groups took the evolverPrimates stand-in from 16.8 to
+        // 12.6 ms -- but for the reason the wider bridging distance of the relay lattice now removes at no cost in cells: MIBLAST_RELAY_GAP.)
+        long head_span = round == 0 ? env_long("MIBLAST_HEAD_SPAN0", 0) : env_long("MIBLAST_HEAD_SPAN", 16384);
+        const long head_max = std::max(1l, env_long("MIBLAST_HEAD_MAX", 8));
+        if (round == 0 && head_span > 0) {
+            // (stretch heads in the first round only for a call of FEW groups: its launches are as long as their longest piece whatever they hold)
+            size_t groups = 0;
+            for (const Unit &u : units) groups += u.n_comp;
+            if ((long)groups > env_long("MIBLAST_HEAD_FEW", 16)) head_span = 0;
+        }
         parallel_for(units.size(), [&](size_t ui) {
             Unit &u = units[ui];
-            std::vector<uint8_t> taken(u.n_comp, 0);
+            // a group's q range -> the width of its stretches
+            std::vector<int32_t> q_lo(u.n_comp, 0x7fffffff), q_hi(u.n_comp, -0x7fffffff - 1);
+            if (head_span > 0)
+                for (size_t k = 0; k < u.anchors.size(); k++) { q_lo[u.comp[k]] = std::min(q_lo[u.comp[k]], u.anchors[k].q); q_hi[u.comp[k]] = std::max(q_hi[u.comp[k]], u.anchors[k].q); }
+            std::vector<uint8_t> taken((size_t)u.n_comp * (size_t)head_max, 0);
             size_t n_taken = 0;
             for (size_t k = u.next; k < u.anchors.size() && n_taken < batch_max; k++) {
                 if (u.cov[k] || u.cache.count(k)) continue;
-                if (k != u.next && (u.tent[k] || taken[u.comp[k]])) continue;
-                taken[u.comp[k]] = 1;
+                const uint32_t c = u.comp[k];
+                size_t slot = (size_t)c * (size_t)head_max;
+                if (head_span > 0) {
+                    const long width = std::max(head_span, ((long)q_hi[c] - (long)q_lo[c]) / head_max + 1);
+                    slot += (size_t)std::min<long>(head_max - 1, ((long)u.anchors[k].q - (long)q_lo[c]) / width);
+                }
+                if (k != u.next && (u.tent[k] || taken[slot])) continue;
+                taken[slot] = 1;
                 n_taken++;
                 per[ui].push_back(Pending{ui, k});
             }
         });
         gather(per, pend);
     }
-    for (int level = 0; level < 6 && !(round == 0 && chain_heads && relay_s0_env != 0); level++) {
+    for (int level = 0; level < 6 && !by_groups; level++) {
         std::vector<Pending> cand;
         const long sq = std::max(64l, shadow_q0 >> (2 * level));
         std::vector<std::vector<Pending>> per(units.size());
@@ -2391,6 +2422,21 @@ static void gapped_commit_and_nominate(std::vector<PairJob *> &jobs, std::vector
         pend.swap(cand);
         shadow_q = sq;
         if ((long)pend.size() >= spec_target / 2) break;              // full enough
+    }
+    if (round > 0 && env_long("MIBLAST_DEBUG", 0) > 2) {
+        // why a later round: every nominee with the alignments its unit has committed so far (an anchor of a group whose head's alignment
+        // did not reach it, or reached it on another diagonal)
+        for (const Pending &pd : pend) {
+            const Unit &u = units[pd.unit];
+            const Anchor &a = u.anchors[pd.anchor];
+            fprintf(stderr, "[miblast]   round %d nominee: unit %zu anchor %zu of %zu (group %u) t %d q %d diagonal %d score %d;", round, pd.unit, pd.anchor, u.anchors.size(), u.comp[pd.anchor], a.t, a.q,
+                    a.t - a.q, a.score);
+            for (const miblast_aln &A : u.kept)
+                if (a.q >= A.q_lo - 20000 && a.q < A.q_hi + 20000)
+                    fprintf(stderr, " [kept t %d..%d q %d..%d band %d..%d anchor (%d,%d)%s]", A.t_lo, A.t_hi, A.q_lo, A.q_hi, A.dmin, A.dmax, A.anchor_t, A.anchor_q,
+                            a.t >= A.t_lo && a.t < A.t_hi && a.q >= A.q_lo && a.q < A.q_hi ? " IN BOX" : "");
+            fprintf(stderr, "\n");
+        }
     }
 }
 
@@ -2784,7 +2830,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     long relay_s = std::max(256l, relay_s_env > 0 ? relay_s_env : 1280l);
     const long relay_w_env = env_long("MIBLAST_RELAY_W", 0), relay_tol = env_long("MIBLAST_RELAY_TOL", 512);
     long relay_w = std::max(64l, relay_w_env > 0 ? relay_w_env : 192l);
-    const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 8)),
+    // (relay_gap: lattice steps a chain bridges without an anchor -- virtual relays on the line to the next anchor.  8 until round 5; 16: the
+    //  evolverPrimates stand-in -- option set "one": every second position, no transitions, half the sequence soft-masked -- has stretches of
+    //  5 000 - 10 000 rows without an anchor inside its alignments; a chain that ended there left the rest of the side to a planting of
+    //  its own after the launch, three times per round: 16.8 -> 10.6 ms per phase, the cells evaluated unchanged)
+    const long relay_max = env_long("MIBLAST_RELAY_MAX", 4096), relay_gap = std::max(1l, env_long("MIBLAST_RELAY_GAP", 16)),
                relay_tail_rows = env_long("MIBLAST_RELAY_TAIL_ROWS", 4096);     // how far past the last anchor virtual relays are planted
     // No piece of a relayed side runs unbounded: where a chain ends (no anchor ahead within the bridging distance -- a long
     // soft-masked stretch has no seeds) the piece stops after a few lattice steps and, if the extension is still alive, the side
