@@ -2918,9 +2918,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         const long relay_s_tiny = env_long("MIBLAST_RELAY_S_TINY", 448);
         if (relay_s_env <= 0) relay_s = crowd ? env_long("MIBLAST_RELAY_S_CROWD", 2048) : nsides_call > 96 ? env_long("MIBLAST_RELAY_S_MID", 768) : nsides_call > 16 ? env_long("MIBLAST_RELAY_S_FEW", 640) : relay_s_tiny;
         if (relay_s0_env < 0) relay_s0 = crowd ? 256 : 64;
-        // (a handful of sides: 384 warm-up rows -- most hand-overs of such a call are rejected after 128, and a retry is a launch of
-        //  its own: 17 -> 11 DP launches per phase)
-        if (relay_w_env <= 0) relay_w = crowd ? env_long("MIBLAST_RELAY_W_CROWD", 192) : nsides_call > 16 ? env_long("MIBLAST_RELAY_W_MID", 128) : env_long("MIBLAST_RELAY_W_TINY", 384);
+        // (a handful of sides: until round 5 384 warm-up rows -- most hand-overs of such a call are rejected after 128, and a retry was a
+        //  launch of its own.  With the hand-over inside the launch a rejected piece goes on to the relay's snapshots after 256 and 512 rows
+        //  by itself, and the launch is as long as its longest piece: 128 again -- the trimmed levels' launches 1.05 -> ~0.6 ms, the
+        //  phase 17.3-17.8 -> 17.0 ms, the evolverPrimates stand-in 10.4 -> 9.8)
+        if (relay_w_env <= 0) relay_w = crowd ? env_long("MIBLAST_RELAY_W_CROWD", 192) : nsides_call > 16 ? env_long("MIBLAST_RELAY_W_MID", 128) : env_long("MIBLAST_RELAY_W_TINY", 128);
         const long plant_env = env_long("MIBLAST_RELAY_PLANT_AT_ONCE", 1);            // 0: never, 1: unless thousands of sides are in flight, 2: always
         const bool plant_at_once = plant_env == 2 || (!crowd && plant_env != 0);
         // one wave per piece; 4 columns per lane when the GPU is saturated and the typical window fits 256 columns (fewest
