@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cactus_amd.multigpu import assign_pairs, assign_target_major, blast_pairs_sharded, chain_parts_sharded
+from cactus_amd.multigpu import assign_pairs, assign_target_major, blast_pairs_sharded, chain_parts_sharded, gather_bytes
 
 
 def _fake_align(pair):
@@ -83,6 +83,45 @@ def test_two_rank_gloo_gather_equals_single_process():
         assert p.exitcode == 0
     assert got[1] is None
     assert got[0] == single == b"".join(_fake_align(p) for p in pairs)
+
+
+def _big_gather_worker(rank, world, port, sizes, q):
+    import hashlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = sizes[rank]
+    # (a payload that is cheap to make and to check: the rank's byte, a counter every 4 KiB)
+    buf = bytearray([65 + rank]) * n
+    for k in range(0, n, 4096):
+        buf[k:k + 8] = k.to_bytes(8, "little")
+    mine = hashlib.md5(buf).hexdigest()
+    got = gather_bytes(bytes(buf), dist, rank, world, torch.device("cpu"))
+    del buf
+    if rank == 0:
+        q.put(("gathered", [(len(x), hashlib.md5(x).hexdigest()) for x in got]))
+    q.put((rank, (n, mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_of_payloads_of_very_different_and_large_sizes():
+    """The one exchange of the multi-GPU path at the scale SURVEY 8e names for a whole-genome run ("~2-5 GB total"): three ranks whose PAF
+    payloads are 600 MB, nothing at all and 150 MB.  gather_bytes sends every payload point-to-point into a buffer of exactly its size --
+    nothing padded to the largest, nothing of size world x max allocated -- and rank 0 gets every byte (md5 per payload)."""
+    sizes = [150 << 20, 0, 600 << 20] if os.environ.get("MIBLAST_TEST_BIG_GATHER", "1") != "0" else [3 << 20, 0, 12 << 20]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_big_gather_worker, args=(r, 3, port, sizes, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    msgs = dict(q.get(timeout=600) for _ in range(4))
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert msgs["gathered"] == [msgs[r] for r in range(3)]
+    assert [n for n, _ in msgs["gathered"]] == sizes
 
 
 # ---- chaining stage: per-contig parts sharded over ranks (the job itself is the oracle here: CPU test) ------------------------------
