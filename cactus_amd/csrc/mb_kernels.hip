@@ -266,7 +266,7 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
     {   // (the pipeline takes the short runs hit by hit: it wants the list of the long runs only)
         const dim3 hg((unsigned)((n_hits + 1024 * kHeadsPerThread - 1) / (1024 * kHeadsPerThread)));
         static const bool all_lists = [] { const char *e = getenv("MIBLAST_UX_ALL_LISTS"); return e && atoi(e) != 0; }();      // (A/B switch: the four short lists as well)
-        if (mode == 2 && !all_lists) hipLaunchKernelGGL(k_run_heads_long, hg, dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
+        if (mode == 2 && !all_lists) hipLaunchKernelGGL(k_run_heads_long, dim3((unsigned)std::min<int64_t>((n_hits + 1023) / 1024, 4096)), dim3(256), 0, s, keys, n_hits, kLongRun, heads, n_heads);
         else hipLaunchKernelGGL(k_run_heads, hg, dim3(1024), 0, s, keys, n_hits, kLongRun, heads, n_heads);
     }
     if (mode == 1) {

@@ -70,9 +70,20 @@ __global__ __launch_bounds__(1024) void k_run_heads(const unsigned long long *__
                                                     unsigned *__restrict__ heads, unsigned *__restrict__ n_heads) {
     run_heads_body<false>(keys, n_hits, kLongRun, heads, n_heads);
 }
-__global__ __launch_bounds__(1024) void k_run_heads_long(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
-                                                         unsigned *__restrict__ heads, unsigned *__restrict__ n_heads) {
-    run_heads_body<true>(keys, n_hits, kLongRun, heads, n_heads);
+// The long runs only (what the level-synchronous pipeline asks for).  Round 5: a plain streaming pass -- a key looks kLongRun keys
+// ahead first (the same diagonal there: it lies in a run of more than kLongRun hits; next to never true for chance hits), only then
+// back for the run's head, and a head takes its slot of the list with an atomic of its own: long runs are the busy diagonals of real
+// homology, a few hundred per strand, so the atomics are no traffic at all, while the block-wide counting of run_heads_body (LDS
+// counters, two barriers, a ballot per key and class) made this kernel 7 % of the kernel time of a step of 42 small chunk pairs.
+__global__ __launch_bounds__(256) void k_run_heads_long(const unsigned long long *__restrict__ keys, int64_t n_hits, const int kLongRun,
+                                                        unsigned *__restrict__ heads, unsigned *__restrict__ n_heads) {
+    const uint64_t n = (uint64_t)n_hits;
+    const uint64_t off = n + n / 2 + n / 4 + n / 8 + 8;                // (where run_heads_body puts the long-run list)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + kLongRun < n_hits; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = (uint32_t)(keys[i] >> 32);
+        if ((uint32_t)(keys[i + kLongRun] >> 32) != d) continue;
+        if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != d) heads[off + atomicAdd(&n_heads[kRunClasses], 1u)] = (unsigned)i;
+    }
 }
 
 // ---- anchors of the HSPs: the gapped stage starts an alignment in the middle of an HSP's best-scoring window of 31

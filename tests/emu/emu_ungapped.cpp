@@ -351,7 +351,7 @@ int main(int argc, char **argv) {
         {   // the lists as k_run_heads itself makes them: the same runs in every list (their order inside a list is free)
             std::vector<unsigned> kheads(heads.size(), 0u);
             unsigned kn[5] = {0, 0, 0, 0, 0};
-            if (use_ux) hipLaunchKernelGGL(mb::k_run_heads_long, dim3((unsigned)((n_hits + 4095) / 4096)), dim3(1024), 0, nullptr, keys.data(), n_hits, long_run, kheads.data(), kn);
+            if (use_ux) hipLaunchKernelGGL(mb::k_run_heads_long, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_hits + 1023) / 1024, 3))), dim3(256), 0, nullptr, keys.data(), n_hits, long_run, kheads.data(), kn);      // (few blocks: the stride loop is walked)
             else hipLaunchKernelGGL(mb::k_run_heads, dim3((unsigned)((n_hits + 4095) / 4096)), dim3(1024), 0, nullptr, keys.data(), n_hits, long_run, kheads.data(), kn);
             bool same = true;
             for (int c = use_ux ? 4 : 0; c < 5 && same; c++) {
