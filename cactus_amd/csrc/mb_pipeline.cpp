@@ -1415,6 +1415,9 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
             std::vector<int32_t> kept_anc;
             for (std::vector<size_t> &idx : by_contig) {
                 if ((int64_t)idx.size() > p.queryhspbest) {
+                    // (ties at the cut: the earlier found -- SURVEY A.10 --, or with miblast_params.hspbest_ties the later found: A.9 #11)
+                    if (p.hspbest_ties) std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return hs[a].score != hs[b].score ? hs[a].score > hs[b].score : a > b; });
+                    else
                     std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return hs[a].score > hs[b].score; });
                     idx.resize((size_t)p.queryhspbest);
                     std::sort(idx.begin(), idx.end());
@@ -3693,6 +3696,12 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     miblast_params p = pin;
     if (p.gappedthresh < 0) p.gappedthresh = p.hspthresh;
     if (p.step < 1) p.step = 1;
+    if (p.query_softmask || p.step_origin) {
+        set_error("query_softmask / step_origin (SURVEY A.9 #2, #5) are switches of the CPU oracle only: the MI355X path implements the A.10 reading of both");
+        return MIBLAST_EINVAL;
+    }
+    // (A.9 #9: every ungapped kernel stops a walk at run < best - xdrop; with integers run <= best - xdrop is the same test one lower)
+    if (p.xdrop_le) p.xdrop -= 1;
     std::vector<std::unique_ptr<PairJob>> store;
     std::vector<PairJob *> jobs;
     std::vector<Unit> units;

@@ -19,7 +19,8 @@ class MiblastError(RuntimeError):
 class Params(C.Structure):
     """miblast_params; defaults = lastz defaults."""
     _fields_ = [(n, C.c_int32) for n in ("step", "transitions", "xdrop", "ydrop", "hspthresh", "gappedthresh", "gap_open",
-                                          "gap_extend", "entropy", "queryhspbest", "ambiguous_n", "gapped", "format", "markend", "queryhsplimit", "diag_hash16", "walls", "strands")]
+                                          "gap_extend", "entropy", "queryhspbest", "ambiguous_n", "gapped", "format", "markend", "queryhsplimit", "diag_hash16", "walls", "strands",
+                                          "query_softmask", "step_origin", "xdrop_le", "hspbest_ties")]
 
     def __repr__(self):
         return "Params(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_) + ")"

@@ -66,6 +66,15 @@ typedef struct miblast_params {
      * sequence, the '+' lines followed by the '-' lines: (chunk pair, strand) is the exact work unit below the chunk pair
      * (cactus_amd.multigpu.merge_strand_pafs puts the halves together).                                                 */
     int32_t strands;
+    /* Round 5: the oracle's further comparison switches for SURVEY A.9 (oracle/lastz_oracle.h), same names, same order -- the structs stay
+     * copy-compatible up to here.  The MI355X path implements the two that cost nothing: xdrop_le (A.9 #9: an ungapped walk stops at
+     * run <= best - xdrop; --miblast-xdrop=le) and hspbest_ties (A.9 #11: --queryhspbest keeps the LATER found of equal scores at the cut;
+     * --miblast-hspbest-ties=later).  query_softmask (#2) and step_origin (#5) are oracle-side only: a call that sets them is refused
+     * with MIBLAST_EINVAL, never answered in the default reading.                                                                      */
+    int32_t query_softmask;
+    int32_t step_origin;
+    int32_t xdrop_le;
+    int32_t hspbest_ties;
 } miblast_params;
 
 void miblast_params_default(miblast_params *p);

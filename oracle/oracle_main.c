@@ -54,8 +54,10 @@ int main(int argc, char **argv) {
         /* the named switches of SURVEY A.9 (lastz_oracle.h); --allocate:traceback is lastz's own spelling of the last one */
         else if (!strcmp(a, "--oracle-query-softmask=ignore")) p.query_softmask = 1;
         else if (!strcmp(a, "--oracle-step-origin=sequence")) p.step_origin = 1;
-        else if (!strcmp(a, "--oracle-xdrop=le")) p.xdrop_le = 1;
-        else if (!strcmp(a, "--oracle-hspbest-ties=later")) p.hspbest_ties = 1;
+        else if (!strcmp(a, "--oracle-xdrop=le") || !strcmp(a, "--miblast-xdrop=le")) p.xdrop_le = 1;          /* (--miblast-...: the spelling the MI355X front ends take: one argv serves both) */
+        else if (!strcmp(a, "--miblast-xdrop=lt")) p.xdrop_le = 0;
+        else if (!strcmp(a, "--oracle-hspbest-ties=later") || !strcmp(a, "--miblast-hspbest-ties=later")) p.hspbest_ties = 1;
+        else if (!strcmp(a, "--miblast-hspbest-ties=earlier")) p.hspbest_ties = 0;
         else if (!strncmp(a, "--oracle-traceback-cells=", 25)) p.traceback_cells = atoll(a + 25);
         else if (!strncmp(a, "--allocate:traceback=", 21)) {
             char *end = NULL;

@@ -947,3 +947,64 @@ def test_contexts_of_any_priority_give_the_same_bytes(olz):
     run("again", low)
     assert got["again"] == want + [want[0]]
     low.close(); high.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--miblast-xdrop=le"], ["--miblast-hspbest-ties=later"], ["--miblast-xdrop=le", "--miblast-hspbest-ties=later"]],
+                         ids=["xdrop_le", "hspbest_ties", "both"])
+def test_the_cheap_a9_switches_on_the_device_equal_the_oracles(gpu_ctx, olz, monkeypatch, extra):
+    """Round 5: SURVEY A.9 #9 (a walk stops at run <= best - xdrop) and #11 (--queryhspbest keeps the later found of equal scores) are
+    switches of the MI355X path too (miblast_params.xdrop_le / hspbest_ties, --miblast-xdrop=le / --miblast-hspbest-ties=later): on every
+    case, with every ungapped kernel, the oracle's bytes, HSP list and counters under the same switches; on the two cases built so that
+    the switch changes the result (tests/test_oracle_cpu.py), the change itself; and the two oracle-only switches are refused, not ignored."""
+    import numpy as np
+    from cactus_amd import gen, miblast
+    for kernel in ("lane", "ux"):
+        monkeypatch.setenv("MIBLAST_UNGAPPED", kernel)
+        for name, tf, qf, args in CASES:
+            pm = _params(list(args) + extra)
+            T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+            got = gpu_ctx.align(T, Q, pm)
+            want = olz.align(tf, qf, _oracle_params(olz, pm))
+            assert got.paf == want["paf"], (name, kernel)
+            assert got.hsps == want["hsps"], (name, kernel)
+            for k in COUNTERS:
+                assert got.stats[k] == want["counters"][k], (name, kernel, k)
+            T.close(); Q.close()
+    monkeypatch.delenv("MIBLAST_UNGAPPED")
+    rng = np.random.default_rng(11)
+    rnd = lambda n, seed: gen.random_sequence(n, np.random.default_rng(seed)).tobytes().decode()
+    fa = lambda name, s: (">%s\n%s\n" % (name, s)).encode()
+    base = ["--hspthresh=2200", "--gappedthresh=2400", "--ydrop=4000", "--ungapped", "--format=general:name1,zstart1,end1,name2,zstart2+,end2+"]
+    # the dip of exactly x-drop (six N columns + ten transitions = -910) between two stretches: one HSP across it with "<", none with "<="
+    left, right = rnd(260, 24), rnd(400, 25)
+    tv = {"A": "G", "G": "A", "C": "T", "T": "C"}
+    mid_q = "".join(rng.choice(list("ACGT"), 16))
+    mid_t = "N" * 6 + "".join(tv[c] for c in mid_q[6:])
+    tf, qf = fa("T|x", left + mid_t + right), fa("Q|x", left + mid_q + right)
+    outs = {}
+    for label, more in (("lt", []), ("le", ["--miblast-xdrop=le"])):
+        pm = _params(base + more)
+        T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+        outs[label] = gpu_ctx.align(T, Q, pm)
+        assert outs[label].paf == olz.align(tf, qf, _oracle_params(olz, pm))["paf"]
+    assert outs["lt"].paf != outs["le"].paf and len(outs["le"].hsps) > len(outs["lt"].hsps)
+    # two equal-scoring HSPs under --queryhspbest=1: the first found, or the later found
+    unit = rnd(120, 26)
+    tf = fa("T|k", rnd(300, 27) + unit + rnd(300, 28) + unit + rnd(300, 29))
+    qf = fa("Q|k", rnd(50, 30) + "N" * 20 + unit + "N" * 20 + rnd(50, 31))
+    kept = {}
+    for label, more in (("earlier", []), ("later", ["--miblast-hspbest-ties=later"])):
+        pm = _params(base + ["--queryhspbest=1"] + more)
+        T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+        kept[label] = gpu_ctx.align(T, Q, pm)
+        want = olz.align(tf, qf, _oracle_params(olz, pm))
+        assert kept[label].paf == want["paf"] and kept[label].hsps == want["hsps"] and len(want["hsps"]) == 1
+    assert kept["earlier"].hsps != kept["later"].hsps
+    # oracle-only switches: refused
+    for field in ("query_softmask", "step_origin"):
+        pm = _params(base)
+        setattr(pm, field, 1)
+        T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+        with pytest.raises(miblast.MiblastError):
+            gpu_ctx.align(T, Q, pm)
