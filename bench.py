@@ -65,7 +65,7 @@ TRACE_BYTES_PER_CELL = 0.5     # SURVEY 8d "Gapped: write 0.5*C (4-bit traceback
 TIMELINE = bool(os.environ.get("MIBLAST_BENCH_TIMELINE"))       # per-call wall times of a step on stderr
 TRACE_BYTES_WRITTEN = 0.5      # what the DP kernels store per evaluated cell: 4-bit trace codes, two columns per byte
 PER_PAIR = ("seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps", "anchors", "dp_sides", "dp_cells", "dp_rows", "alignments",
-            "t_index", "t_seed", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms")
+            "t_index", "t_seed", "t_ungapped_kernel_ms", "t_sort_ms", "t_seedfill_ms", "seed_binned")
 PER_BATCH = ("t_gapped", "gapped_rounds", "dp_sides_run", "dp_cells_run", "dp_rows_run", "t_dp_kernel_ms", "t_dp_busy_ms", "dp_kernel_launches",
              "relay_accepted", "relay_rejected", "t_traceback_ms", "t_merge_ms", "dp_reruns", "relay_inline_checks", "relay_inline_continued")
 
@@ -800,6 +800,7 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
            "tables_built_per_step": {"per_rank": w.tables_per_rank, "total": sum(w.tables_per_rank), "target_chunks": len(w.tfa), "bound_per_rank": -(-len(w.tfa) // world)},
            "seeds_per_s": tot["seed_hits"] / elapsed, "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
            "dp_cells_per_step": tot["dp_cells"] / steps, "seed_hits_per_step": tot["seed_hits"] / steps, "alignments_per_step": tot["alignments"] / steps,
+           "strands_grouped_in_lds_per_step": tot["seed_binned"] / steps,      # (mb_seed_bin.h: bins + LDS instead of the device-wide radix sort; the rest went through rocprim)
            "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
            "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3 / world) / 1e9,
            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / steps, "ydrop_busy": tot["t_dp_busy_ms"] / steps, "ungapped": tot["t_ungapped_kernel_ms"] / steps,

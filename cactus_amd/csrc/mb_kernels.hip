@@ -150,6 +150,38 @@ void launch_keys_unhash(unsigned long long *keys, int64_t n, uint32_t hinv, uint
     hipLaunchKernelGGL(k_keys_unhash, dim3((unsigned)(((n + 1) / 2 + 255) / 256)), dim3(256), 0, s, keys, n, hinv, hmask);
 }
 
+// ---- the keys of a strand grouped by diagonal: bins by the top bits of the scrambled diagonal, a work-group per bin in LDS (mb_seed_bin.h)
+#include "mb_seed_bin.h"
+
+int64_t bin_state_words() { return (kBinStateWords + 3) & ~3; }
+int bin_plan_words() { return kBinPlanWords; }
+int bin_cap_big() { return kBinCapBig; }
+int bin_bits_for(unsigned long long n, int diag_bits, int mean) { return bin_bits(n, diag_bits, mean); }
+
+// queued behind the kernels that write the keys and their number (*n_ptr); state: bin_state_words() zeroed u32 words.  The plan --
+// state[0 .. 8) -- is what the host reads back together with the number of keys.
+void launch_bin_plan(const unsigned long long *keys, const unsigned long long *n_ptr, unsigned long long cap, int diag_bits, int mean, uint32_t *state, hipStream_t s) {
+    hipLaunchKernelGGL(k_bin_count, dim3(256), dim3(1024), 0, s, keys, n_ptr, cap, diag_bits, mean, state);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, n_ptr, cap, diag_bits, mean, state);
+    MB_HIP(hipGetLastError());
+}
+
+// in: n keys (scrambled diagonal << 32 | q end) in any order; out: the same keys grouped by diagonal (unscrambled), q ascending inside a
+// diagonal -- the array sort_keys(.., 32, 32 + diag_bits) + launch_keys_unhash give.  `in` is left as it was (with more than one bin `out` holds the keys
+// bin by bin in between).  nbits / n_big: the plan of launch_bin_plan for these keys (largest bin <= bin_cap_big()).
+void launch_bin_group(unsigned long long *in, unsigned long long *out, int64_t n, int diag_bits, int nbits, int n_big, uint32_t *state, uint32_t hinv, uint32_t hmask,
+                      hipStream_t s) {
+    if (n <= 0) return;
+    const unsigned long long *binned = in;
+    if (nbits > 0) {
+        hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, in, out, n, diag_bits, nbits, state);
+        binned = out;
+    }
+    hipLaunchKernelGGL((k_bin_sort<kBinCapSmall, 11, 512>), dim3(1u << nbits), dim3(512), 0, s, binned, out, state, diag_bits, nbits, hinv, hmask);
+    if (n_big > 0) hipLaunchKernelGGL((k_bin_sort<kBinCapBig, 12, 1024>), dim3(1u << nbits), dim3(1024), 0, s, binned, out, state, diag_bits, nbits, hinv, hmask);
+    MB_HIP(hipGetLastError());
+}
+
 // ---- the seed stage of all pairs of a call in shared launches (mb_seed_batch.h) ------------------------------------------------
 #include "mb_seed_batch.h"
 

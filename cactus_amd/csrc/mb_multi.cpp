@@ -94,7 +94,7 @@ void add_stats(miblast_stats &a, const miblast_stats &s, bool first_of_batch) {
     a.hsps_pre_entropy += s.hsps_pre_entropy; a.hsps += s.hsps; a.anchors += s.anchors; a.anchors_skipped += s.anchors_skipped;
     a.dp_sides += s.dp_sides; a.dp_cells += s.dp_cells; a.dp_rows += s.dp_rows; a.alignments += s.alignments;
     a.t_index += s.t_index; a.t_seed += s.t_seed;
-    a.seed_batches += s.seed_batches;
+    a.seed_batches += s.seed_batches; a.seed_binned += s.seed_binned;
     a.t_ungapped_kernel_ms += s.t_ungapped_kernel_ms; a.ungapped_kernel_launches += s.ungapped_kernel_launches;
     a.t_sort_ms += s.t_sort_ms; a.t_seedfill_ms += s.t_seedfill_ms;
     if (first_of_batch) {

@@ -707,6 +707,7 @@ struct Workspace {                      // device buffers that persist across mi
     PackedStrand pack_t;                      // the packed target of the build in progress (scratch)
     std::shared_ptr<SeedTable> own_table;     // MIBLAST_RESIDENT_TABLES=0: the table of the call in progress
     DevBuf<unsigned long long> ord_state;     // q-ordered seed search: totals, the tiles' stretches of the scratch, their counts and the scan of those, both strands
+    DevBuf<uint32_t> bin_state;               // grouping by diagonal without the sort (mb_seed_bin.h): plan, counts, places and cursors of the bins, both strands
     DevBuf<unsigned long long> bsum;
     // seed search / ungapped
     DevBuf<uint8_t> rc;
@@ -1441,6 +1442,11 @@ static void seed_finish(PairJob &job) {
     }
 }
 
+// the plan k_bin_scan left for a strand's nh keys (mb_seed_bin.h): were they counted, and does the largest bin fit the large LDS sorter?
+static bool bin_plan_fits(const uint32_t *plan, unsigned long long nh) {
+    return nh > 0 && nh < (1ull << 31) && plan[4] == 0u && plan[3] == (uint32_t)nh && plan[1] > 0u && plan[1] <= (uint32_t)bin_cap_big();
+}
+
 // index build + seed search + ungapped extension + HSP filters of one pair (uses the shared seed workspace)
 static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     hipStream_t s = ctx.stream;
@@ -1482,6 +1488,10 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     const uint32_t hmul = scramble ? 0x9E3779B1u : 1u;
     uint32_t hinv = 1u;
     for (int it = 0; it < 5; it++) hinv *= 2u - hmul * hinv;           // Newton: hmul * hinv = 1 mod 2^32 (hmul odd)
+    // grouping by diagonal through bins + LDS instead of the device-wide sort (mb_seed_bin.h); rocprim stays for the strands it does not fit
+    const bool binned = ordered && env_long("MIBLAST_SORT_BIN", 1) != 0;
+    const int bin_mean = (int)std::max<long>(1, env_long("MIBLAST_BIN_MEAN", 2800));
+    const int64_t bsw = bin_state_words();
 
     // ---- seed search + ungapped extension, per strand ----------------------------------------------
     // hits per q batch of a strand.  A large pair's strand is ONE batch whenever it can be (no extent[] then, one sort, one launch of the
@@ -1524,6 +1534,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             const int64_t ord_words = seed_ord_state_words(qtot);
             if (ordered) { w.ord_state.ensure(2 * (size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16(2 * (size_t)ord_words * 8), s)); keys_b.ensure((size_t)capH); }
             else MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
+            if (binned) { w.bin_state.ensure(2 * (size_t)bsw); MB_HIP(hipMemsetAsync(w.bin_state.p, 0, 2 * (size_t)bsw * 4, s)); }
             for (int strand = 0; strand < 2; strand++) {
                 MB_HIP(hipEventRecord(w.sev[strand][0], s));
                 if (ordered)
@@ -1532,10 +1543,14 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                 else
                     launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p + (size_t)strand * capH, capH, qbsum.p + strand, s);
                 MB_HIP(hipEventRecord(w.sev[strand][1], s));
+                // the plan of the bins (how many, the largest) comes back with the strand's hit count: the device knows that count first
+                if (binned) launch_bin_plan(keys_a.p + (size_t)strand * capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, capH, diag_bits, bin_mean, w.bin_state.p + (size_t)strand * (size_t)bsw, s);
             }
             if (ordered) {
-                for (int strand = 0; strand < 2; strand++)
+                for (int strand = 0; strand < 2; strand++) {
                     MB_HIP(hipMemcpyAsync(w.pin_u64.p + strand, w.ord_state.p + (size_t)strand * (size_t)ord_words, 8, hipMemcpyDeviceToHost, s));
+                    if (binned) MB_HIP(hipMemcpyAsync(w.pin_u64.p + 4 + 4 * strand, w.bin_state.p + (size_t)strand * (size_t)bsw, 32, hipMemcpyDeviceToHost, s));
+                }
             } else
             MB_HIP(hipMemcpyAsync(w.pin_u64.p, qbsum.p, 16, hipMemcpyDeviceToHost, s));
             tp[2] = now_s();
@@ -1560,9 +1575,16 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                 for (int strand = 0; strand < 2; strand++) {
                     if (!fits[strand] || !nh[strand]) continue;
                     MB_HIP(hipEventRecord(w.sev[strand][2], s));
+                    const uint32_t *plan = (const uint32_t *)(w.pin_u64.p + 4 + 4 * strand);
+                    if (binned && bin_plan_fits(plan, nh[strand])) {
+                        // the keys dealt into bins by the top bits of the scrambled diagonal, every bin ordered in LDS (mb_seed_bin.h): the same array
+                        launch_bin_group(keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p + (size_t)strand * (size_t)bsw, hinv, hmask, s);
+                        st.seed_binned++;
+                    } else {
                     // (q-ordered keys: a stable sort by the diagonal bits alone)
                     sort_keys(sort_temp.p, sort_keys_temp_bytes((int64_t)nh[strand], sort_bits), keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], ordered ? 32 : 0, sort_bits, s);
                     if (ordered && hmul != 1u) launch_keys_unhash(keys_b.p, (int64_t)nh[strand], hinv, hmask, s);
+                    }
                     MB_HIP(hipEventRecord(w.sev[strand][3], s));
                     MB_HIP(hipEventRecord(w.sev[strand][4], s));
                     // (sized for the larger strand before the first strand's kernels are queued: growing a buffer later would free
@@ -1618,7 +1640,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         std::vector<DevHsp> found;
         int rc_batch = MIBLAST_OK;
         // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
-        auto extend_batch = [&](unsigned long long nh, bool timed_fill, bool q_ordered, bool hashed) -> int {
+        auto extend_batch = [&](unsigned long long nh, bool timed_fill, bool q_ordered, bool hashed, const uint32_t *plan = nullptr) -> int {
             if (nh >= (1ull << 31)) { set_error("more than 2^31 seed hits in one batch (unmasked repeat?)"); return MIBLAST_ELIMIT; }
             strand_hits[strand] += nh;
             st.seed_hits += (int64_t)nh;
@@ -1629,8 +1651,13 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             size_t tb = sort_keys_temp_bytes((int64_t)nh, sort_bits);
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev1, s));
+            if (plan && hashed && bin_plan_fits(plan, nh)) {
+                launch_bin_group(keys_a.p, keys_b.p, (int64_t)nh, diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p, hinv, hmask, s);
+                st.seed_binned++;
+            } else {
             sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, q_ordered ? 32 : 0, sort_bits, s);       // (k_seed_fill writes the keys in q order)
             if (hashed && hmul != 1u) launch_keys_unhash(keys_b.p, (int64_t)nh, hinv, hmask, s);
+            }
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, up16(sizeof(UngappedCounters)), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
@@ -1672,12 +1699,20 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             else
                 launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p, cap1, qbsum.p, s);
             unsigned long long total = 0;
+            uint32_t plan[8] = {0, 0, 0, 0, 1, 0, 0, 0};
+            if (binned) {
+                w.bin_state.ensure((size_t)bsw); MB_HIP(hipMemsetAsync(w.bin_state.p, 0, (size_t)bsw * 4, s));
+                launch_bin_plan(keys_a.p, w.ord_state.p, cap1, diag_bits, bin_mean, w.bin_state.p, s);
+                w.pin_u64.ensure(16);
+                MB_HIP(hipMemcpyAsync(w.pin_u64.p + 4, w.bin_state.p, 32, hipMemcpyDeviceToHost, s));
+            }
             w.stage.d2h(&total, ordered ? w.ord_state.p : qbsum.p, 8, s);
             MB_HIP(hipStreamSynchronize(s));
             w.stage.done();
+            if (binned) memcpy(plan, w.pin_u64.p + 4, 32);
             if (total <= cap1) {
                 one_pass_done = true;
-                if (total) { rc_batch = extend_batch(total, true, ordered, ordered); if (rc_batch != MIBLAST_OK) return rc_batch; }
+                if (total) { rc_batch = extend_batch(total, true, ordered, ordered, binned ? plan : nullptr); if (rc_batch != MIBLAST_OK) return rc_batch; }
             }
         }
         if (!one_pass_done) {

@@ -1,7 +1,7 @@
 // mb_seed_dense.h -- seed stage of a large chunk pair (gfx950, wave64): packed sequences, the q-ordered one-pass seed search (hit lists
 // per tile of query positions, keys written in q order by a second kernel), and the diagonal scrambling that keeps the key sort balanced.
-// (The keys are ordered by diagonal with rocprim's radix sort afterwards: binning by diagonal in LDS is NOT built -- DESIGN.md section 9.)  Included by mb_kernels.hip inside namespace mb
-// after mb_seedword.h.
+// (Behind it the keys are grouped by diagonal through bins + LDS -- mb_seed_bin.h -- or, for a strand that does not fit, by rocprim's radix
+// sort.)  Included by mb_kernels.hip inside namespace mb after mb_seedword.h.
 //
 //   k_pack2bit_mask     a strand as 2 bits per base + 1 mask bit per base (0.375 B/base): what the index build and the seed
 //                       search read instead of 19 code bytes per window

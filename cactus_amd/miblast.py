@@ -48,7 +48,7 @@ class Stats(C.Structure):
                    ("t_ungapped_kernel_ms", C.c_double), ("ungapped_kernel_launches", C.c_int64), ("t_sort_ms", C.c_double),
                    ("t_seedfill_ms", C.c_double), ("dp_rows_run", C.c_int64),
                    ("relay_accepted", C.c_int64), ("relay_rejected", C.c_int64), ("t_traceback_ms", C.c_double), ("t_merge_ms", C.c_double), ("dp_reruns", C.c_int64),
-                   ("t_dp_busy_ms", C.c_double), ("relay_inline_checks", C.c_int64), ("relay_inline_continued", C.c_int64)])
+                   ("t_dp_busy_ms", C.c_double), ("relay_inline_checks", C.c_int64), ("relay_inline_continued", C.c_int64), ("seed_binned", C.c_int64)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

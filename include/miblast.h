@@ -177,6 +177,7 @@ typedef struct miblast_stats {          /* counters defined by SURVEY.md section
                                              * t_dp_kernel_ms is the SUM of the launch durations)                            */
     int64_t relay_inline_checks;            /* hand-overs a piece checked itself inside its DP launch ...              */
     int64_t relay_inline_continued;         /* ... and pieces that went on past their first stop row there instead of in a launch of their own */
+    int64_t seed_binned;                    /* strands whose seed hits were grouped by diagonal through bins + LDS (mb_seed_bin.h) instead of the device-wide radix sort */
 } miblast_stats;
 
 typedef struct miblast_result miblast_result;

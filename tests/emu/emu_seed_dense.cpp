@@ -5,7 +5,7 @@
 // (see hip/hip_runtime.h) -- against a plain restatement of SURVEY A.3 / A.4: the table of the target = for every word the indexed
 // positions, the hits of a strand = for every valid query window, every word variant, every position of its bucket, query position
 // by query position.  Nothing of this is shipped or measured.
-//   emu_seed_dense <seed> <n_cases> [table]      exit status 0 iff every case is identical
+//   emu_seed_dense <seed> <n_cases> [table|bin]      exit status 0 iff every case is identical (bin: mb_seed_bin.h only)
 #define MB_EMU 1
 #include <hip/hip_runtime.h>
 #undef __launch_bounds__
@@ -47,13 +47,97 @@ inline int dpp_scan_add(int v) {
 #include "mb_seedword.h"
 #include "mb_seed_index.h"
 #include "mb_seed_dense.h"
+#include "mb_seed_bin.h"
 }  // namespace mb
+
+// ---- mb_seed_bin.h: keys grouped by diagonal through bins and LDS buckets, against std::sort by (scrambled diagonal, q) + the unscrambling.
+//      Cases: few keys (one bin), many small bins (a small `mean`), diagonals with hundreds / thousands of hits (long rank loops, the large
+//      sorter), plain and scrambled diagonals, keys that did not fit (nothing planned).
+static int bin_cases(unsigned seed0, int n_cases) {
+    int bad = 0;
+    for (int cs = 0; cs < n_cases; cs++) {
+        std::mt19937_64 rng(seed0 * 2654435761u + (unsigned)cs);
+        auto rnd = [&](unsigned long long n) { return (unsigned long long)(rng() % n); };
+        const int diag_bits = 8 + (int)rnd(20);
+        const uint32_t hmask = (1u << diag_bits) - 1u, hmul = cs % 4 == 3 ? 1u : 0x9E3779B1u;
+        uint32_t hinv = 1u; for (int it = 0; it < 5; it++) hinv *= 2u - hmul * hinv;
+        const int mean = cs % 3 == 0 ? 2800 : 40 + (int)rnd(400);
+        const size_t n_chance = cs % 5 == 4 ? rnd(60) : 200 + rnd(cs % 3 == 0 ? 30000 : 6000);
+        std::vector<unsigned long long> keys;
+        std::map<uint32_t, std::vector<uint32_t>> per_diag;            // diagonal -> q ends (distinct)
+        auto add = [&](uint32_t d, uint32_t q) { per_diag[d & hmask].push_back(q); };
+        for (size_t i = 0; i < n_chance; i++) add((uint32_t)rnd(1ull << diag_bits), (uint32_t)rnd(1u << 24));
+        const int n_heavy = (int)rnd(4);
+        for (int h = 0; h < n_heavy; h++) {                             // a diagonal of real homology: many hits, neighbours too
+            const uint32_t d = (uint32_t)rnd(1ull << diag_bits), len = cs % 7 == 6 && h == 0 ? 5000 + (uint32_t)rnd(6000) : 30 + (uint32_t)rnd(900);
+            for (uint32_t k = 0; k < len; k++) add(d + (rnd(20) == 0 ? 1u : 0u), 19 + 3 * k + (uint32_t)rnd(3));
+        }
+        for (auto &kv : per_diag) {
+            std::sort(kv.second.begin(), kv.second.end());
+            kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+            for (uint32_t q : kv.second) keys.push_back(((unsigned long long)((kv.first * hmul) & hmask) << 32) | q);
+        }
+        std::shuffle(keys.begin(), keys.end(), rng);
+        const unsigned long long n = keys.size();
+        std::vector<unsigned long long> want(keys);
+        std::sort(want.begin(), want.end());
+        for (auto &k : want) k = ((unsigned long long)((((uint32_t)(k >> 32)) * hinv) & hmask) << 32) | (uint32_t)k;
+        bool ok = true;
+        const char *why = "";
+        const size_t sw = (size_t)mb::kBinStateWords + 8;
+        std::vector<uint32_t> state(sw, 0u);
+        unsigned long long n_dev = n;
+        // (1) keys that did not fit their buffer: no plan, nothing counted
+        {
+            std::vector<uint32_t> st2(sw, 0u);
+            unsigned long long big = n + 5;
+            hipLaunchKernelGGL(mb::k_bin_count, dim3(2), dim3(1024), 0, nullptr, keys.data(), &big, n, diag_bits, mean, st2.data());
+            hipLaunchKernelGGL(mb::k_bin_scan, dim3(1), dim3(1024), 0, nullptr, &big, n, diag_bits, mean, st2.data());
+            if (st2[4] != 1u) { ok = false; why = "overflow not flagged"; }
+            for (size_t x = 5; x < sw && ok; x++) if (st2[x]) { ok = false; why = "overflow: something counted"; }
+        }
+        // (2) the plan
+        hipLaunchKernelGGL(mb::k_bin_count, dim3(1 + (unsigned)rnd(3)), dim3(1024), 0, nullptr, keys.data(), &n_dev, n + rnd(3), diag_bits, mean, state.data());
+        hipLaunchKernelGGL(mb::k_bin_scan, dim3(1), dim3(1024), 0, nullptr, &n_dev, n + 3, diag_bits, mean, state.data());
+        const int nbits = mb::bin_bits(n, diag_bits, mean), nb = 1 << nbits;
+        uint32_t mx = 0, big = 0, run = 0;
+        {
+            std::vector<uint32_t> cnt((size_t)nb, 0u);
+            for (auto k : keys) cnt[nbits ? (uint32_t)(k >> 32) >> (diag_bits - nbits) : 0u]++;
+            for (int b = 0; b < nb && ok; b++) {
+                if (mb::bin_starts(state.data())[b] != run || mb::bin_cursors(state.data())[b] != run || mb::bin_counts(state.data())[b] != cnt[(size_t)b]) { ok = false; why = "plan: a bin's place"; }
+                run += cnt[(size_t)b]; mx = std::max(mx, cnt[(size_t)b]); big += cnt[(size_t)b] > (uint32_t)mb::kBinCapSmall;
+            }
+            if (ok && (mb::bin_starts(state.data())[nb] != n || state[0] != (uint32_t)nbits || state[1] != mx || state[2] != big || state[3] != (uint32_t)n || state[4] != 0u)) { ok = false; why = "plan: head"; }
+        }
+        // (3) scatter + the sorter(s), as launch_bin_group queues them; the output buffer has guard words on both sides
+        std::vector<unsigned long long> in(keys), outbuf((size_t)n + 16, 0xEEEEEEEEEEEEEEEEull);
+        unsigned long long *out = outbuf.data() + 8;
+        if (ok && n && mx <= (uint32_t)mb::kBinCapBig) {
+            const unsigned long long *binned = in.data();
+            if (nbits > 0) {
+                hipLaunchKernelGGL(mb::k_bin_scatter, dim3((unsigned)((n + mb::kBinChunk - 1) / mb::kBinChunk)), dim3(1024), 0, nullptr, in.data(), out, (int64_t)n, diag_bits, nbits, state.data());
+                binned = out;
+                for (int b = 0; b < nb && ok; b++) if (mb::bin_cursors(state.data())[b] != mb::bin_starts(state.data())[b + 1]) { ok = false; why = "scatter: a bin not filled exactly"; }
+            }
+            hipLaunchKernelGGL((mb::k_bin_sort<mb::kBinCapSmall, 11, 512>), dim3((unsigned)nb), dim3(512), 0, nullptr, binned, out, state.data(), diag_bits, nbits, hinv, hmask);
+            if (big) hipLaunchKernelGGL((mb::k_bin_sort<mb::kBinCapBig, 12, 1024>), dim3((unsigned)nb), dim3(1024), 0, nullptr, binned, out, state.data(), diag_bits, nbits, hinv, hmask);
+            for (int g = 0; g < 8; g++) if (outbuf[(size_t)g] != 0xEEEEEEEEEEEEEEEEull || outbuf[(size_t)n + 8 + (size_t)g] != 0xEEEEEEEEEEEEEEEEull) { ok = false; why = "a store outside the keys"; }
+            if (ok && !std::equal(want.begin(), want.end(), out)) { ok = false; why = "grouped keys differ from sort + unscramble"; }
+        }
+        printf("bin case %d: %llu keys, %d diagonal bits (%s), mean %d -> %d bins, largest %u, %u beyond the small sorter%s  %s%s\n", cs, n, diag_bits, hmul == 1u ? "plain" : "scrambled",
+               mean, nb, mx, big, mx > (uint32_t)mb::kBinCapBig ? " (beyond the large one too: rocprim's case)" : "", ok ? "ok" : "MISMATCH: ", ok ? "" : why);
+        if (!ok) bad++;
+    }
+    return bad ? 1 : 0;
+}
 
 int main(int argc, char **argv) {
     const unsigned seed0 = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n_cases = argc > 2 ? atoi(argv[2]) : 4;
     // "table": also build the table through the kernels (the emulated scan of the 2^24 + 1 bucket counts takes minutes: 8 193 groups, three launches)
     const bool with_table = argc > 3 && !strcmp(argv[3], "table");
+    if (argc > 3 && !strcmp(argv[3], "bin")) return bin_cases(seed0, n_cases);
     int bad = 0;
     const size_t kBuckets = (size_t)1 << 24;
     std::vector<uint32_t> offsets(kBuckets + 1), occ(kBuckets / 32), counts(kBuckets + 1);

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     # 15 x int32 params + the oracle's two comparison switches + strands ; stats = 12 int64 + 4 double + extras
     assert C.sizeof(miblast.Params) == 88
     assert C.sizeof(miblast.Hsp) == 48 and C.sizeof(miblast.Aln) == 64
-    assert C.sizeof(miblast.Stats) == 12 * 8 + 4 * 8 + 4 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 6 * 8 + 2 * 8       # + relay_accepted, relay_rejected, t_traceback_ms, t_merge_ms, dp_reruns, t_dp_busy_ms + relay_inline_checks, relay_inline_continued
+    assert C.sizeof(miblast.Stats) == 12 * 8 + 4 * 8 + 4 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 6 * 8 + 2 * 8 + 8       # + relay_accepted, relay_rejected, t_traceback_ms, t_merge_ms, dp_reruns, t_dp_busy_ms + relay_inline_checks, relay_inline_continued + seed_binned
 
 
 def test_default_params_are_lastz_defaults():

@@ -50,6 +50,9 @@ def test_case_matches_oracle(gpu_ctx, olz, monkeypatch, name, tf, qf, args):
     {"MIBLAST_DIAG_SCRAMBLE": "0"},                                     # keys sorted by the plain diagonal
     {"MIBLAST_RESIDENT_TABLES": "0"},                                   # a table per call in the context's own memory
     {"MIBLAST_SEED_PACKED": "2", "MIBLAST_HIT_CAP": "3000"},            # q batches (two-pass path, extent[] carried from batch to batch)
+    {"MIBLAST_BIN_MEAN": "40"},                                         # keys grouped by diagonal through MANY bins + LDS (mb_seed_bin.h; the default mean gives these cases one bin or two)
+    {"MIBLAST_BIN_MEAN": "40", "MIBLAST_SEED_FUSED": "0"},              # ... strands one after the other
+    {"MIBLAST_SORT_BIN": "0"},                                          # ... and not at all: rocprim's radix sort + k_keys_unhash, as before round 5
 ], ids=lambda e: ",".join(f"{k[8:].lower()}={v}" for k, v in e.items()))
 def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
     """The seed stage of a large pair (mb_seed_dense.h: packed strands, q-ordered one-pass search -- k_seed_hits + k_seed_keys --, scrambled
@@ -59,6 +62,7 @@ def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
     monkeypatch.setenv("MIBLAST_SEED_BATCHED", "0")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    binned = 0
     for name, tf, qf, args in CASES:
         pm = _params(args)
         T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
@@ -70,7 +74,51 @@ def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
             assert got.alns == want["alns"] and got.ops == want["ops"], (name, rep)
             for k in COUNTERS:
                 assert got.stats[k] == want["counters"][k], (name, rep, k)
+            binned += got.stats["seed_binned"]
         T.close(); Q.close()
+    if env.get("MIBLAST_SORT_BIN") == "0" or env.get("MIBLAST_SEED_ORDERED") == "0":
+        assert binned == 0
+    elif "MIBLAST_HIT_CAP" not in env and "MIBLAST_DIAG_SCRAMBLE" not in env:
+        assert binned > 0, "no strand took the bins + LDS path"
+
+
+def test_grouping_by_diagonal_in_lds_equals_the_radix_sort_on_a_large_pair(gpu_ctx, olz, monkeypatch):
+    """mb_seed_bin.h at the size it is for: a 1.5 Mb pair at 3 % divergence (1.5 x 10^6 hits per strand: hundreds of bins, diagonals of real
+    homology with hundreds of hits each -- long rank loops -- next to chance hits) gives the bytes, HSPs and counters of the rocprim path
+    and of the oracle, with the default mean and with one that sends bins to the large sorter; a pair aligned to ITSELF (one diagonal
+    holds every hit of the + strand: no LDS holds that) falls back to rocprim for that strand and still agrees."""
+    from cactus_amd import gen
+    from cases import DEFAULT
+    monkeypatch.setenv("MIBLAST_SEED_BATCHED", "0")
+    pm = _params(DEFAULT)
+    t, q = gen.make_pair(1_500_000, 77, sub_rate=0.03, indel_rate=0.001)
+    tf, qf = gen.fasta_bytes([("id=T|c", t)]), gen.fasta_bytes([("id=Q|c", q)])
+    want = olz.align(tf, qf, _oracle_params(olz, pm))
+    T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+    runs = {}
+    for label, env in (("radix", {"MIBLAST_SORT_BIN": "0"}), ("bins", {}), ("large bins", {"MIBLAST_BIN_MEAN": "9000"})):
+        for k in ("MIBLAST_SORT_BIN", "MIBLAST_BIN_MEAN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for rep in range(2):                                            # (the second call takes the both-strands-in-one-go path)
+            runs[label] = gpu_ctx.align(T, Q, pm)
+        got = runs[label]
+        assert got.paf == want["paf"] and got.hsps == want["hsps"] and got.alns == want["alns"], label
+        for k in COUNTERS:
+            assert got.stats[k] == want["counters"][k], (label, k)
+        assert got.stats["seed_binned"] == (0 if label == "radix" else 2), (label, got.stats["seed_binned"])
+    T.close(); Q.close()
+    monkeypatch.delenv("MIBLAST_BIN_MEAN", raising=False)
+    t = gen.random_sequence(60_000, __import__("numpy").random.default_rng(5))
+    tf, qf = gen.fasta_bytes([("id=S|c", t)]), gen.fasta_bytes([("id=S2|c", t)])
+    want = olz.align(tf, qf, _oracle_params(olz, pm))
+    T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
+    for rep in range(2):
+        got = gpu_ctx.align(T, Q, pm)
+        assert got.paf == want["paf"] and got.hsps == want["hsps"], rep
+        assert got.stats["seed_binned"] <= 1, "the + strand of a self alignment cannot have gone through LDS"
+    T.close(); Q.close()
 
 
 def test_strand_halves_of_a_pair_put_together_equal_the_whole(gpu_ctx, olz, monkeypatch):

@@ -57,6 +57,20 @@ def test_emulated_dense_seed_stage_matches_the_rule():
     assert out.count(" ok\n") == 10 and "MISMATCH" not in out, out
 
 
+def test_emulated_grouping_by_diagonal_in_lds_equals_sort_and_unscramble():
+    """cactus_amd/csrc/mb_seed_bin.h on the host: the plan (bins from the key count the device reads, their places, the largest bin, the bins
+    beyond the small sorter; nothing planned for keys that did not fit their buffer), the scatter (every bin filled exactly) and the two
+    LDS sorters -- buckets, ranks, unscrambling, guard words around the output -- give the array std::sort by (scrambled diagonal, q) and the
+    unscrambling give: one bin and hundreds, a dozen keys and tens of thousands, diagonals with thousands of hits (the large sorter), plain
+    and scrambled diagonals."""
+    subprocess.run(["make", "-C", EMU_DIR, "emu_seed_dense"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_seed_dense"), "2", "21", "bin"], capture_output=True, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert out.count(" ok\n") == 21 and "MISMATCH" not in out, out
+    assert "1 beyond the small sorter" in out, "no case reached the large sorter"
+
+
 @pytest.mark.skipif(not os.environ.get("MIBLAST_SLOW_TESTS"), reason="three minutes of emulated scan over the 2^24 + 1 bucket counts: MIBLAST_SLOW_TESTS=1")
 def test_emulated_dense_seed_table_through_its_kernels():
     """mb_seed_index.h on the host: index words from the byte codes (= the packed ones), the three-launch exclusive scan of the bucket
