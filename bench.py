@@ -620,6 +620,7 @@ def run_rank(a):
             "seeds_per_s": tot["seed_hits"] / elapsed,
             "seed_lookups_per_s": tot["seed_lookups"] / elapsed,
             "dp_cells_per_step": tot["dp_cells"] / per, "seed_hits_per_step": tot["seed_hits"] / per, "alignments_per_step": tot["alignments"] / per,
+            "strands_grouped_in_lds_per_step": tot["seed_binned"] / per,      # (mb_seed_bin.h: bins + LDS instead of the device-wide radix sort; the other strands went through rocprim)
             "stage_seconds_per_step": {k: tot[k] / per for k in ("t_index", "t_seed", "t_gapped")},
             "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / per, "ydrop_busy": tot["t_dp_busy_ms"] / per, "ungapped": tot["t_ungapped_kernel_ms"] / per,
                                          "sort": tot["t_sort_ms"] / per, "seed_fill": tot["t_seedfill_ms"] / per},

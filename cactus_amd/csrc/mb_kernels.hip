@@ -154,27 +154,28 @@ void launch_keys_unhash(unsigned long long *keys, int64_t n, uint32_t hinv, uint
 #include "mb_seed_bin.h"
 
 int64_t bin_state_words() { return (kBinStateWords + 3) & ~3; }
-int bin_plan_words() { return kBinPlanWords; }
 int bin_cap_big() { return kBinCapBig; }
-int bin_bits_for(unsigned long long n, int diag_bits, int mean) { return bin_bits(n, diag_bits, mean); }
+int64_t bin_matrix_words_for(unsigned long long cap, int diag_bits, int mean) { return (int64_t)((bin_matrix_words(cap, diag_bits, mean) + 3ull) & ~3ull); }
 
-// queued behind the kernels that write the keys and their number (*n_ptr); state: bin_state_words() zeroed u32 words.  The plan --
-// state[0 .. 8) -- is what the host reads back together with the number of keys.
-void launch_bin_plan(const unsigned long long *keys, const unsigned long long *n_ptr, unsigned long long cap, int diag_bits, int mean, uint32_t *state, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin_count, dim3(256), dim3(1024), 0, s, keys, n_ptr, cap, diag_bits, mean, state);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, n_ptr, cap, diag_bits, mean, state);
+// queued behind the kernels that write the keys and their number (*n_ptr); state: bin_state_words() zeroed u32 words; matrix:
+// bin_matrix_words_for(cap, ..) words (not initialised).  The plan -- state[0 .. 8) -- is what the host reads back together with the number of keys.
+void launch_bin_plan(const unsigned long long *keys, const unsigned long long *n_ptr, unsigned long long cap, int diag_bits, int mean, uint32_t *state, uint32_t *matrix,
+                     hipStream_t s) {
+    const unsigned long long room = std::min<unsigned long long>(cap, kBinKeysMax);
+    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)std::max<unsigned long long>(1, (room + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, keys, n_ptr, cap, diag_bits, mean, state, matrix);
+    hipLaunchKernelGGL(k_bin_scan, dim3((1u << kBinBitsMax) / 256u), dim3(256), 0, s, n_ptr, cap, diag_bits, mean, state, matrix);
     MB_HIP(hipGetLastError());
 }
 
 // in: n keys (scrambled diagonal << 32 | q end) in any order; out: the same keys grouped by diagonal (unscrambled), q ascending inside a
 // diagonal -- the array sort_keys(.., 32, 32 + diag_bits) + launch_keys_unhash give.  `in` is left as it was (with more than one bin `out` holds the keys
 // bin by bin in between).  nbits / n_big: the plan of launch_bin_plan for these keys (largest bin <= bin_cap_big()).
-void launch_bin_group(unsigned long long *in, unsigned long long *out, int64_t n, int diag_bits, int nbits, int n_big, uint32_t *state, uint32_t hinv, uint32_t hmask,
-                      hipStream_t s) {
+void launch_bin_group(const unsigned long long *in, unsigned long long *out, int64_t n, int diag_bits, int nbits, int n_big, const uint32_t *state, const uint32_t *matrix,
+                      uint32_t hinv, uint32_t hmask, hipStream_t s) {
     if (n <= 0) return;
     const unsigned long long *binned = in;
     if (nbits > 0) {
-        hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, in, out, n, diag_bits, nbits, state);
+        hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, in, out, n, diag_bits, nbits, state, matrix);
         binned = out;
     }
     hipLaunchKernelGGL((k_bin_sort<kBinCapSmall, 11, 512>), dim3(1u << nbits), dim3(512), 0, s, binned, out, state, diag_bits, nbits, hinv, hmask);

