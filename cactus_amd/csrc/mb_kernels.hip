@@ -175,7 +175,8 @@ void launch_bin_group(const unsigned long long *in, unsigned long long *out, int
     if (n <= 0) return;
     const unsigned long long *binned = in;
     if (nbits > 0) {
-        hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, in, out, n, diag_bits, nbits, state, matrix);
+        if (nbits <= kBinStagedBits) hipLaunchKernelGGL(k_bin_scatter_staged, dim3((unsigned)((n + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, in, out, n, diag_bits, nbits, state, matrix);
+        else hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, in, out, n, diag_bits, nbits, state, matrix);
         binned = out;
     }
     hipLaunchKernelGGL((k_bin_sort<kBinCapSmall, 11, 512>), dim3(1u << nbits), dim3(512), 0, s, binned, out, state, diag_bits, nbits, hinv, hmask);

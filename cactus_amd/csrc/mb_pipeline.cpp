@@ -1490,7 +1490,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     for (int it = 0; it < 5; it++) hinv *= 2u - hmul * hinv;           // Newton: hmul * hinv = 1 mod 2^32 (hmul odd)
     // grouping by diagonal through bins + LDS instead of the device-wide sort (mb_seed_bin.h); rocprim stays for the strands it does not fit
     const bool binned = ordered && env_long("MIBLAST_SORT_BIN", 1) != 0;
-    const int bin_mean = (int)std::max<long>(1, env_long("MIBLAST_BIN_MEAN", 2800));
+    const int bin_mean = (int)std::max<long>(1, env_long("MIBLAST_BIN_MEAN", 11000));
     const int64_t bsw = bin_state_words();
 
     // ---- seed search + ungapped extension, per strand ----------------------------------------------

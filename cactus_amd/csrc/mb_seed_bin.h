@@ -6,15 +6,15 @@
 // gave that with four passes over the keys (16 B per key and pass, plus the histogram, plus k_keys_unhash: ~ 96 B per key) and was a
 // fifth of the kernel time of a human x mouse chunk pair.  The keys need no ORDER between diagonals, only grouping -- and the scrambled
 // diagonal (d * C mod 2^B, mb_seed_dense.h) spreads real homology evenly over its top bits:
-//   k_bin_count    a work-group per chunk of 32 768 keys: LDS histogram of the top `nbits` bits of the scrambled diagonal, written as the
+//   k_bin_count    a work-group per chunk of 16 384 keys: LDS histogram of the top `nbits` bits of the scrambled diagonal, written as the
 //                  chunk's row of a (chunks x bins) matrix.  nbits follows from the number of keys, which the device knows before the
 //                  host does: the kernel reads it where k_seed_hits left it
 //   k_bin_scan     a work-item per bin runs down its column (the row entries become "keys of this bin in earlier chunks"); the last
 //                  work-group to finish scans the bins' totals: their places, the largest bin and the number of bins beyond the small
 //                  sorter's room -- the plan the host reads back with the strand's hit count (no extra synchronisation)
-//   k_bin_scatter  a work-group per chunk: its row + the bins' places into LDS, then every key to its bin with one LDS atomic.  No
-//                  atomic on device memory anywhere (the first version reserved the stretches with them: 1.4 million returning atomics
-//                  per strand, performed at the memory side of the fabric, were most of its time)
+//   k_bin_scatter_staged   a work-group per chunk: the chunk dealt into its bins IN LDS (histogram, scan, place), then written out bin by bin
+//                  to the places its matrix row gives -- runs of 64-128 B per bin instead of one 8-B store per key and cache line.  (No atomic
+//                  on device memory anywhere.  k_bin_scatter: the same without the staging, for more than 2 048 bins.)
 //   k_bin_sort     a work-group per bin: the bin's keys into LDS by BUCKET = the next 11 / 12 bits of the scrambled diagonal (count, scan,
 //                  place).  A bucket holds a key or two: every key finds its rank among the keys of its bucket ((diagonal, q) ascending)
 //                  and is written to that place with its diagonal unscrambled.  A bucket with more than 32 keys is a diagonal of real
@@ -30,9 +30,9 @@
 #pragma once
 
 constexpr int kBinBitsMax = 13;                // at most 8 192 bins (the LDS histograms of k_bin_count / k_bin_scatter: 32 KB)
-constexpr int kBinMeanDefault = 2800;          // bins are as few as keep the mean bin at or below this many keys (Poisson spread stays within 4 096)
+constexpr int kBinMeanDefault = 11000;         // bins are as few as keep the mean bin at or below this many keys: the large sorter's, with room for the diagonals of real homology
 constexpr int kBinCapSmall = 4096, kBinCapBig = 16384;
-constexpr int kBinChunk = 32768;               // keys per work-group of k_bin_count / k_bin_scatter
+constexpr int kBinChunk = 16384;               // keys per work-group of k_bin_count / k_bin_scatter: what the scatter stages in LDS
 constexpr unsigned long long kBinKeysMax = 1ull << 26;     // more keys than this: no plan (the matrix would outgrow its use; the mean bin the large sorter)
 constexpr int kBinRunShort = 32;               // a bucket of up to this many keys is ranked by counting
 constexpr int kBinRunWave = 2048;              // a longer one is sorted by one wave, beyond this size by the work-group
@@ -145,7 +145,63 @@ __global__ __launch_bounds__(256) void k_bin_scan(const unsigned long long *__re
     if (tid == 0) { state[0] = (uint32_t)nbits; state[1] = s_max; state[2] = s_big; state[3] = (uint32_t)n; starts[nb] = (uint32_t)n; }
 }
 
-// grid: a work-group per chunk of the n keys
+// grid: a work-group per chunk of the n keys; at most 2 048 bins.  The chunk is dealt into its bins in LDS first and leaves it bin by bin:
+// a wave's store touches the few cache lines its keys' runs lie in (16 K keys into 1 024 bins: runs of 128 B) instead of 64 lines, one per
+// key -- stores of single keys to 4 096 bins made the direct scatter below 273 us per 11.5 million keys where a radix pass takes 70.
+constexpr int kBinStagedBits = 11;
+__global__ __launch_bounds__(1024) void k_bin_scatter_staged(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out, const int64_t n,
+                                                              const int diag_bits, const int nbits, const uint32_t *__restrict__ state, const uint32_t *__restrict__ matrix) {
+    constexpr int kPer = kBinChunk / 1024, kNb = 1 << kBinStagedBits, kCPer = kNb / 1024;
+    __shared__ unsigned long long tile[kBinChunk];
+    __shared__ uint32_t cursor[kNb];
+    __shared__ uint32_t delta[kNb];
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * kBinChunk;
+    const uint32_t m = (uint32_t)(i0 + kBinChunk < n ? kBinChunk : n - i0);
+    const uint32_t *row = matrix + ((size_t)blockIdx.x << nbits), *starts = state + kBinPlanWords + (1 << kBinBitsMax);
+#pragma unroll
+    for (int k = 0; k < kCPer; k++) cursor[tid * kCPer + k] = 0u;
+    unsigned long long key[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const uint32_t i = (uint32_t)(tid + k * 1024);
+        key[k] = i < m ? in[i0 + i] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; k++) if ((uint32_t)(tid + k * 1024) < m) atomicAdd(&cursor[bin_of(key[k], diag_bits, nbits)], 1u);
+    __syncthreads();
+    {
+        uint32_t c[kCPer], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kCPer; k++) { c[k] = cursor[tid * kCPer + k]; sum += c[k]; }
+        const uint32_t incl = (uint32_t)dpp_scan_add((int)sum);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t at = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 16; k++) at += k < wv ? wsum[k] : 0u;
+#pragma unroll
+        for (int k = 0; k < kCPer; k++) {
+            const int b = tid * kCPer + k;
+            cursor[b] = at;
+            delta[b] = b < (1 << nbits) ? starts[b] + row[b] - at : 0u;      // (place in the bin of the chunk's first key of bin b, minus its place in the tile)
+            at += c[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; k++) if ((uint32_t)(tid + k * 1024) < m) tile[atomicAdd(&cursor[bin_of(key[k], diag_bits, nbits)], 1u)] = key[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const uint32_t i = (uint32_t)(tid + k * 1024);
+        if (i < m) { const unsigned long long kk = tile[i]; out[delta[bin_of(kk, diag_bits, nbits)] + i] = kk; }
+    }
+}
+
+// the same without the staging (more than 2 048 bins: a chunk holds a key or two of each)
 __global__ __launch_bounds__(1024) void k_bin_scatter(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out, const int64_t n,
                                                        const int diag_bits, const int nbits, const uint32_t *__restrict__ state, const uint32_t *__restrict__ matrix) {
     __shared__ uint32_t base[1 << kBinBitsMax];

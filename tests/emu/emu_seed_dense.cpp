@@ -63,8 +63,8 @@ static int bin_cases(unsigned seed0, int n_cases) {
         const int diag_bits = 8 + (int)rnd(20);
         const uint32_t hmask = (1u << diag_bits) - 1u, hmul = cs % 4 == 3 ? 1u : 0x9E3779B1u;
         uint32_t hinv = 1u; for (int it = 0; it < 5; it++) hinv *= 2u - hmul * hinv;
-        const int mean = cs % 3 == 0 ? 2800 : 40 + (int)rnd(400);
-        const size_t n_chance = cs % 5 == 4 ? rnd(60) : cs % 11 == 10 ? 70000 + rnd(9000) : 200 + rnd(cs % 3 == 0 ? 30000 : 6000);      // (more than two chunks of 32 768 now and then)
+        const int mean = cs % 3 == 0 ? (cs % 2 ? 2800 : 11000) : 40 + (int)rnd(400);
+        const size_t n_chance = cs % 5 == 4 ? rnd(60) : cs % 11 == 10 ? 70000 + rnd(9000) : 200 + rnd(cs % 3 == 0 ? 30000 : 6000);      // (several chunks now and then)
         std::vector<unsigned long long> keys;
         std::map<uint32_t, std::vector<uint32_t>> per_diag;            // diagonal -> q ends (distinct)
         auto add = [&](uint32_t d, uint32_t q) { per_diag[d & hmask].push_back(q); };
@@ -123,7 +123,8 @@ static int bin_cases(unsigned seed0, int n_cases) {
         if (ok && n && mx <= (uint32_t)mb::kBinCapBig) {
             const unsigned long long *binned = in.data();
             if (nbits > 0) {
-                hipLaunchKernelGGL(mb::k_bin_scatter, dim3((unsigned)((n + mb::kBinChunk - 1) / mb::kBinChunk)), dim3(1024), 0, nullptr, in.data(), out, (int64_t)n, diag_bits, nbits, state.data(), matrix.data());
+                if (nbits <= mb::kBinStagedBits && cs % 2 == 0) hipLaunchKernelGGL(mb::k_bin_scatter_staged, dim3((unsigned)((n + mb::kBinChunk - 1) / mb::kBinChunk)), dim3(1024), 0, nullptr, in.data(), out, (int64_t)n, diag_bits, nbits, state.data(), matrix.data());
+                else hipLaunchKernelGGL(mb::k_bin_scatter, dim3((unsigned)((n + mb::kBinChunk - 1) / mb::kBinChunk)), dim3(1024), 0, nullptr, in.data(), out, (int64_t)n, diag_bits, nbits, state.data(), matrix.data());
                 binned = out;
                 for (int b = 0; b < nb && ok; b++)                          // every bin holds its own keys (in some order)
                     for (uint32_t x = mb::bin_starts(state.data())[b]; x < mb::bin_starts(state.data())[b + 1]; x++)

@@ -85,7 +85,7 @@ def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
 def test_grouping_by_diagonal_in_lds_equals_the_radix_sort_on_a_large_pair(gpu_ctx, olz, monkeypatch):
     """mb_seed_bin.h at the size it is for: a 1.5 Mb pair at 3 % divergence (1.5 x 10^6 hits per strand: hundreds of bins, diagonals of real
     homology with hundreds of hits each -- long rank loops -- next to chance hits) gives the bytes, HSPs and counters of the rocprim path
-    and of the oracle, with the default mean and with one that sends bins to the large sorter; a pair aligned to ITSELF (one diagonal
+    and of the oracle, with the default mean (bins of ~ 8 000 keys: the staged scatter, the large sorter), with bins for the small sorter and with 8 192 bins (the direct scatter); a pair aligned to ITSELF (one diagonal
     holds every hit of the + strand: no LDS holds that) falls back to rocprim for that strand and still agrees."""
     from cactus_amd import gen
     from cases import DEFAULT
@@ -96,7 +96,7 @@ def test_grouping_by_diagonal_in_lds_equals_the_radix_sort_on_a_large_pair(gpu_c
     want = olz.align(tf, qf, _oracle_params(olz, pm))
     T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
     runs = {}
-    for label, env in (("radix", {"MIBLAST_SORT_BIN": "0"}), ("bins", {}), ("large bins", {"MIBLAST_BIN_MEAN": "6000"})):
+    for label, env in (("radix", {"MIBLAST_SORT_BIN": "0"}), ("bins", {}), ("small bins", {"MIBLAST_BIN_MEAN": "2800"}), ("many bins", {"MIBLAST_BIN_MEAN": "300"})):
         for k in ("MIBLAST_SORT_BIN", "MIBLAST_BIN_MEAN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
