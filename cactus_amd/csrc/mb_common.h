@@ -231,7 +231,7 @@ int bin_cap_big();
 int64_t bin_matrix_words_for(unsigned long long cap, int diag_bits, int mean);
 void launch_bin_plan(const unsigned long long *keys, const unsigned long long *n_ptr, unsigned long long cap, int diag_bits, int mean, uint32_t *state, uint32_t *matrix,
                      hipStream_t s);
-void launch_bin_group(const unsigned long long *in, unsigned long long *out, int64_t n, int diag_bits, int nbits, int n_big, const uint32_t *state, const uint32_t *matrix,
+void launch_bin_group(const unsigned long long *in, unsigned long long *out, int64_t n, int diag_bits, int nbits, int n_small, int n_big, const uint32_t *state, const uint32_t *matrix,
                       uint32_t hinv, uint32_t hmask, hipStream_t s);
 void launch_scan_index(uint32_t *counts, uint32_t *offsets, unsigned long long *block_sums, uint32_t *occ, hipStream_t s);
 void launch_seed_search(const uint8_t *qcodes, int64_t qtot, const uint32_t *offsets, const uint32_t *occ, const uint32_t *positions, int transitions,

@@ -162,15 +162,15 @@ int64_t bin_matrix_words_for(unsigned long long cap, int diag_bits, int mean) { 
 void launch_bin_plan(const unsigned long long *keys, const unsigned long long *n_ptr, unsigned long long cap, int diag_bits, int mean, uint32_t *state, uint32_t *matrix,
                      hipStream_t s) {
     const unsigned long long room = std::min<unsigned long long>(cap, kBinKeysMax);
-    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)std::max<unsigned long long>(1, (room + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, keys, n_ptr, cap, diag_bits, mean, state, matrix);
+    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)std::max<unsigned long long>(1, (room + kBinChunk - 1) / kBinChunk)), dim3(256), 0, s, keys, n_ptr, cap, diag_bits, mean, state, matrix);
     hipLaunchKernelGGL(k_bin_scan, dim3((1u << kBinBitsMax) / 256u), dim3(256), 0, s, n_ptr, cap, diag_bits, mean, state, matrix);
     MB_HIP(hipGetLastError());
 }
 
 // in: n keys (scrambled diagonal << 32 | q end) in any order; out: the same keys grouped by diagonal (unscrambled), q ascending inside a
 // diagonal -- the array sort_keys(.., 32, 32 + diag_bits) + launch_keys_unhash give.  `in` is left as it was (with more than one bin `out` holds the keys
-// bin by bin in between).  nbits / n_big: the plan of launch_bin_plan for these keys (largest bin <= bin_cap_big()).
-void launch_bin_group(const unsigned long long *in, unsigned long long *out, int64_t n, int diag_bits, int nbits, int n_big, const uint32_t *state, const uint32_t *matrix,
+// bin by bin in between).  nbits / n_small / n_big (plan words 0, 6, 2): the plan of launch_bin_plan for these keys (largest bin <= bin_cap_big()).
+void launch_bin_group(const unsigned long long *in, unsigned long long *out, int64_t n, int diag_bits, int nbits, int n_small, int n_big, const uint32_t *state, const uint32_t *matrix,
                       uint32_t hinv, uint32_t hmask, hipStream_t s) {
     if (n <= 0) return;
     const unsigned long long *binned = in;
@@ -179,7 +179,7 @@ void launch_bin_group(const unsigned long long *in, unsigned long long *out, int
         else hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBinChunk - 1) / kBinChunk)), dim3(1024), 0, s, in, out, n, diag_bits, nbits, state, matrix);
         binned = out;
     }
-    hipLaunchKernelGGL((k_bin_sort<kBinCapSmall, 11, 512>), dim3(1u << nbits), dim3(512), 0, s, binned, out, state, diag_bits, nbits, hinv, hmask);
+    if (n_small > 0) hipLaunchKernelGGL((k_bin_sort<kBinCapSmall, 11, 512>), dim3(1u << nbits), dim3(512), 0, s, binned, out, state, diag_bits, nbits, hinv, hmask);
     if (n_big > 0) hipLaunchKernelGGL((k_bin_sort<kBinCapBig, 12, 1024>), dim3(1u << nbits), dim3(1024), 0, s, binned, out, state, diag_bits, nbits, hinv, hmask);
     MB_HIP(hipGetLastError());
 }

@@ -1580,7 +1580,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     const uint32_t *plan = (const uint32_t *)(w.pin_u64.p + 4 + 4 * strand);
                     if (binned && bin_plan_fits(plan, nh[strand])) {
                         // the keys dealt into bins by the top bits of the scrambled diagonal, every bin ordered in LDS (mb_seed_bin.h): the same array
-                        launch_bin_group(keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p + (size_t)strand * (size_t)bsw,
+                        launch_bin_group(keys_a.p + (size_t)strand * capH, keys_b.p, (int64_t)nh[strand], diag_bits, (int)plan[0], (int)plan[6], (int)plan[2], w.bin_state.p + (size_t)strand * (size_t)bsw,
                                          w.bin_matrix.p + (size_t)strand * (size_t)bmw, hinv, hmask, s);
                         st.seed_binned++;
                     } else {
@@ -1655,7 +1655,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             sort_temp.ensure(tb + 16);
             MB_HIP(hipEventRecord(ctx.ev1, s));
             if (plan && hashed && bin_plan_fits(plan, nh)) {
-                launch_bin_group(keys_a.p, keys_b.p, (int64_t)nh, diag_bits, (int)plan[0], (int)plan[2], w.bin_state.p, w.bin_matrix.p, hinv, hmask, s);
+                launch_bin_group(keys_a.p, keys_b.p, (int64_t)nh, diag_bits, (int)plan[0], (int)plan[6], (int)plan[2], w.bin_state.p, w.bin_matrix.p, hinv, hmask, s);
                 st.seed_binned++;
             } else {
             sort_keys(sort_temp.p, tb, keys_a.p, keys_b.p, (int64_t)nh, q_ordered ? 32 : 0, sort_bits, s);       // (k_seed_fill writes the keys in q order)

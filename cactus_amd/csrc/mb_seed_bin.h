@@ -38,7 +38,7 @@ constexpr int kBinRunShort = 32;               // a bucket of up to this many ke
 constexpr int kBinRunWave = 2048;              // a longer one is sorted by one wave, beyond this size by the work-group
 constexpr int kBinPlanWords = 8;               // u32 words at the head of a strand's bin state
 // bin state of a strand (u32 words): [0] nbits [1] largest bin [2] bins beyond kBinCapSmall [3] keys [4] 1 if there is no plan (the keys did
-// not fit their buffer, or are too many) [5] work-groups of k_bin_scan that are done; [8, 8 + 8192) keys per bin; then 8193 places
+// not fit their buffer, or are too many) [5] work-groups of k_bin_scan that are done [6] non-empty bins within kBinCapSmall; [8, 8 + 8192) keys per bin; then 8193 places
 constexpr int kBinStateWords = kBinPlanWords + (1 << kBinBitsMax) + (1 << kBinBitsMax) + 8;
 __host__ __device__ __forceinline__ uint32_t *bin_counts(uint32_t *state) { return state + kBinPlanWords; }
 __host__ __device__ __forceinline__ uint32_t *bin_starts(uint32_t *state) { return state + kBinPlanWords + (1 << kBinBitsMax); }
@@ -65,8 +65,9 @@ __device__ __forceinline__ bool bin_no_plan(const unsigned long long n, const un
 #define MB_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
-// grid: one work-group per chunk the key buffer could hold (those behind the last key leave at once)
-__global__ __launch_bounds__(1024) void k_bin_count(const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ n_ptr,
+// grid: one work-group (of 256: four waves find room on a CU that others share; sixteen wait for a free one) per chunk the key buffer could hold
+// (those behind the last key leave at once)
+__global__ __launch_bounds__(256) void k_bin_count(const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ n_ptr,
                                                      const unsigned long long cap, const int diag_bits, const int mean, uint32_t *__restrict__ state,
                                                      uint32_t *__restrict__ matrix) {
     __shared__ uint32_t hist[1 << kBinBitsMax];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bin_scan(const unsigned long long *__re
                                                    uint32_t *state, uint32_t *__restrict__ matrix) {
     constexpr int kPer = (1 << kBinBitsMax) / 256;
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t s_max, s_big, s_ticket;
+    __shared__ uint32_t s_max, s_big, s_small, s_ticket;
     const unsigned long long n = *n_ptr;
     if (bin_no_plan(n, cap)) return;
     const int nbits = bin_bits(n, diag_bits, mean), nb = 1 << nbits;
@@ -119,13 +120,13 @@ __global__ __launch_bounds__(256) void k_bin_scan(const unsigned long long *__re
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;
     __threadfence();
-    if (tid == 0) { s_max = 0u; s_big = 0u; }
-    uint32_t c[kPer], sum = 0, mx = 0, big = 0;
+    if (tid == 0) { s_max = 0u; s_big = 0u; s_small = 0u; }
+    uint32_t c[kPer], sum = 0, mx = 0, big = 0, small = 0;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
         const int b = tid * kPer + k;
         c[k] = b < nb ? __atomic_load_n(&counts[b], __ATOMIC_RELAXED) : 0u;
-        sum += c[k]; mx = c[k] > mx ? c[k] : mx; big += c[k] > (uint32_t)kBinCapSmall ? 1u : 0u;
+        sum += c[k]; mx = c[k] > mx ? c[k] : mx; big += c[k] > (uint32_t)kBinCapSmall ? 1u : 0u; small += c[k] > 0u && c[k] <= (uint32_t)kBinCapSmall ? 1u : 0u;
     }
     const uint32_t incl = (uint32_t)dpp_scan_add((int)sum);
     if (lane == 63) wsum[wv] = incl;
@@ -141,8 +142,9 @@ __global__ __launch_bounds__(256) void k_bin_scan(const unsigned long long *__re
     }
     if (mx) atomicMax(&s_max, mx);
     if (big) atomicAdd(&s_big, big);
+    if (small) atomicAdd(&s_small, small);
     __syncthreads();
-    if (tid == 0) { state[0] = (uint32_t)nbits; state[1] = s_max; state[2] = s_big; state[3] = (uint32_t)n; starts[nb] = (uint32_t)n; }
+    if (tid == 0) { state[0] = (uint32_t)nbits; state[1] = s_max; state[2] = s_big; state[3] = (uint32_t)n; state[6] = s_small; starts[nb] = (uint32_t)n; }
 }
 
 // grid: a work-group per chunk of the n keys; at most 2 048 bins.  The chunk is dealt into its bins in LDS first and leaves it bin by bin:

@@ -94,7 +94,7 @@ static int bin_cases(unsigned seed0, int n_cases) {
         {
             std::vector<uint32_t> st2(sw, 0u), mx2(mw, 0x5A5A5A5Au);
             unsigned long long big = n + 5;
-            hipLaunchKernelGGL(mb::k_bin_count, dim3(2), dim3(1024), 0, nullptr, keys.data(), &big, n, diag_bits, mean, st2.data(), mx2.data());
+            hipLaunchKernelGGL(mb::k_bin_count, dim3(2), dim3(256), 0, nullptr, keys.data(), &big, n, diag_bits, mean, st2.data(), mx2.data());
             hipLaunchKernelGGL(mb::k_bin_scan, dim3((1u << mb::kBinBitsMax) / 256u), dim3(256), 0, nullptr, &big, n, diag_bits, mean, st2.data(), mx2.data());
             if (st2[4] != 1u) { ok = false; why = "overflow not flagged"; }
             for (size_t x = 5; x < sw && ok; x++) if (st2[x]) { ok = false; why = "overflow: something counted"; }
@@ -103,18 +103,18 @@ static int bin_cases(unsigned seed0, int n_cases) {
         std::vector<uint32_t> matrix(mw, 0x5A5A5A5Au);
         const unsigned long long cap = n + rnd(8);
         const unsigned n_chunks_cap = (unsigned)std::max<unsigned long long>(1, (cap + mb::kBinChunk - 1) / mb::kBinChunk);
-        hipLaunchKernelGGL(mb::k_bin_count, dim3(n_chunks_cap), dim3(1024), 0, nullptr, keys.data(), &n_dev, cap, diag_bits, mean, state.data(), matrix.data());
+        hipLaunchKernelGGL(mb::k_bin_count, dim3(n_chunks_cap), dim3(256), 0, nullptr, keys.data(), &n_dev, cap, diag_bits, mean, state.data(), matrix.data());
         hipLaunchKernelGGL(mb::k_bin_scan, dim3((1u << mb::kBinBitsMax) / 256u), dim3(256), 0, nullptr, &n_dev, cap, diag_bits, mean, state.data(), matrix.data());
         const int nbits = mb::bin_bits(n, diag_bits, mean), nb = 1 << nbits;
-        uint32_t mx = 0, big = 0, run = 0;
+        uint32_t mx = 0, big = 0, small = 0, run = 0;
         {
             std::vector<uint32_t> cnt((size_t)nb, 0u);
             for (auto k : keys) cnt[nbits ? (uint32_t)(k >> 32) >> (diag_bits - nbits) : 0u]++;
             for (int b = 0; b < nb && ok; b++) {
                 if (mb::bin_starts(state.data())[b] != run || mb::bin_counts(state.data())[b] != cnt[(size_t)b]) { ok = false; why = "plan: a bin's place"; }
-                run += cnt[(size_t)b]; mx = std::max(mx, cnt[(size_t)b]); big += cnt[(size_t)b] > (uint32_t)mb::kBinCapSmall;
+                run += cnt[(size_t)b]; mx = std::max(mx, cnt[(size_t)b]); big += cnt[(size_t)b] > (uint32_t)mb::kBinCapSmall; small += cnt[(size_t)b] > 0 && cnt[(size_t)b] <= (uint32_t)mb::kBinCapSmall;
             }
-            if (ok && n && (mb::bin_starts(state.data())[nb] != n || state[0] != (uint32_t)nbits || state[1] != mx || state[2] != big || state[3] != (uint32_t)n || state[4] != 0u)) { ok = false; why = "plan: head"; }
+            if (ok && n && (mb::bin_starts(state.data())[nb] != n || state[0] != (uint32_t)nbits || state[1] != mx || state[2] != big || state[3] != (uint32_t)n || state[4] != 0u || state[6] != small)) { ok = false; why = "plan: head"; }
             for (size_t x = mw - 8; x < mw; x++) if (matrix[x] != 0x5A5A5A5Au) { ok = false; why = "a store behind the matrix"; }
         }
         // (3) scatter + the sorter(s), as launch_bin_group queues them; the output buffer has guard words on both sides
@@ -130,7 +130,7 @@ static int bin_cases(unsigned seed0, int n_cases) {
                     for (uint32_t x = mb::bin_starts(state.data())[b]; x < mb::bin_starts(state.data())[b + 1]; x++)
                         if ((uint32_t)(out[x] >> 32) >> (diag_bits - nbits) != (uint32_t)b) { ok = false; why = "scatter: a key in the wrong bin"; break; }
             }
-            hipLaunchKernelGGL((mb::k_bin_sort<mb::kBinCapSmall, 11, 512>), dim3((unsigned)nb), dim3(512), 0, nullptr, binned, out, state.data(), diag_bits, nbits, hinv, hmask);
+            if (small) hipLaunchKernelGGL((mb::k_bin_sort<mb::kBinCapSmall, 11, 512>), dim3((unsigned)nb), dim3(512), 0, nullptr, binned, out, state.data(), diag_bits, nbits, hinv, hmask);
             if (big) hipLaunchKernelGGL((mb::k_bin_sort<mb::kBinCapBig, 12, 1024>), dim3((unsigned)nb), dim3(1024), 0, nullptr, binned, out, state.data(), diag_bits, nbits, hinv, hmask);
             for (int g = 0; g < 8; g++) if (outbuf[(size_t)g] != 0xEEEEEEEEEEEEEEEEull || outbuf[(size_t)n + 8 + (size_t)g] != 0xEEEEEEEEEEEEEEEEull) { ok = false; why = "a store outside the keys"; }
             if (ok && !std::equal(want.begin(), want.end(), out)) { ok = false; why = "grouped keys differ from sort + unscramble"; }
