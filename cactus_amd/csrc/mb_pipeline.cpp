@@ -727,6 +727,7 @@ struct Workspace {                      // device buffers that persist across mi
     hipEvent_t ev_base = nullptr;             // start of the current call (DpSpans::base)
     hipEvent_t sev[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
     unsigned long long last_strand_hits = 0;  // hits of the larger strand of the last pair seeded with this workspace
+    std::atomic<unsigned long long> hits_hint{0};   // (of a context's own workspace) the largest strand its lanes have met: Ctx::hits_hint of the lanes points here
     PinBuf<unsigned long long> pin_u64;
     PinBuf<UngappedCounters> pin_ctr;
     PinBuf<DevHsp> pin_hsps;
@@ -1521,6 +1522,20 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     // no bubble between the strands' kernels.  A strand whose hits do not fit goes through the per-strand path below.
     bool strand_done[2] = {false, false};
     unsigned long long strand_hits[2] = {0, 0};                  // (for sizing the key buffer of the next call)
+    // A lane of a call of several large pairs takes whichever pair comes next: the first time it meets a larger one than before, every buffer
+    // below grows -- five device allocations of up to 2 GB, each freeing the old block first (hipFree waits for the device: all lanes stand
+    // still) -- and a step now and then took 650 ms instead of 170.  The lanes share the largest strand any of them has met and size for it
+    // once, before anything is queued.
+    if (ctx.hits_hint) {
+        const unsigned long long hint = ctx.hits_hint->load(std::memory_order_relaxed);
+        if (hint > 0 && 2 * (hint + hint / 8) <= (unsigned long long)hit_cap) {
+            const size_t want = (size_t)(hint + hint / 8);
+            keys_a.ensure(2 * want); keys_b.ensure(want); d_hsps.ensure(2 * want);
+            w.heads.ensure(2 * want + want / 4 + 64);
+            (void)ux_scratch(w, nullptr, want, ttot + qtot + 2, hmul, hmask);
+            if (binned) { w.bin_state.ensure(2 * (size_t)bsw); w.bin_matrix.ensure(2 * (size_t)bin_matrix_words_for(std::min<unsigned long long>((unsigned long long)keys_a.n, (unsigned long long)hit_cap) / 2, diag_bits, bin_mean)); }
+        }
+    }
     std::future<void> host0;
     // --strand=plus / minus (miblast_params.strands): the other strand is not searched -- it has no hits, no look-ups, no HSPs
     const bool skip_strand[2] = {p.strands == 2, p.strands == 1};
@@ -1761,6 +1776,10 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         const unsigned long long want = 2 * (std::max(strand_hits[0], strand_hits[1]) + std::max(strand_hits[0], strand_hits[1]) / 4) + 1024;
         if (want <= (unsigned long long)hit_cap && (unsigned long long)keys_a.n < want) keys_a.ensure((size_t)want);
         w.last_strand_hits = std::max(strand_hits[0], strand_hits[1]);
+        if (ctx.hits_hint) {
+            unsigned long long seen = ctx.hits_hint->load(std::memory_order_relaxed);
+            while (w.last_strand_hits > seen && !ctx.hits_hint->compare_exchange_weak(seen, w.last_strand_hits, std::memory_order_relaxed)) {}
+        }
     }
     {
         static const long spike_ms = env_long("MIBLAST_DEBUG_SPIKE", 0);
@@ -3794,7 +3813,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         // while the other lanes keep the device busy.  A pair's result does not depend on its lane.
         Workspace &w = *ctx.ws;
         while (w.lanes.size() < n_lanes) w.lanes.push_back(lane_create(ctx.device, ctx.priority));
-        for (Ctx *l : w.lanes) l->spans = ctx.spans;
+        for (Ctx *l : w.lanes) { l->spans = ctx.spans; l->hits_hint = &w.hits_hint; }
         std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
         std::vector<std::string> lane_err(n_lanes);
         std::vector<std::future<void>> lane_threads;
