@@ -264,7 +264,6 @@ void miblast_ctx_destroy(miblast_ctx *c) {
     mb::workspace_destroy(c->c.ws);
     mb::chain_cache_destroy(c->c.chain_cache);
     delete c;
-    try { mb::flush_deferred_frees(true); } catch (...) {}
 }
 
 int miblast_seqset_from_fasta_mem(miblast_ctx *ctx, const char *buf, size_t len, miblast_seqset **out) {
@@ -330,7 +329,7 @@ int miblast_seqset_from_fasta_file(miblast_ctx *ctx, const char *path, miblast_s
 }
 
 void miblast_drop_derived(void) {
-    try { mb::drop_derived(); mb::flush_deferred_frees(true); } catch (...) {}
+    try { mb::drop_derived(); } catch (...) {}
 }
 
 int miblast_seqsets_unaligned(miblast_ctx *ctx, size_t n, const miblast_seqset *const *queries, const char *const *pafs, const size_t *paf_lens,
@@ -408,7 +407,6 @@ int miblast_align(miblast_ctx *ctx, const miblast_seqset *target, const miblast_
         miblast_result *r = new miblast_result();
         int rc;
         try { rc = mb::align(ctx->c, target->s, query->s, *p, r->r); } catch (...) { delete r; throw; }
-        mb::flush_deferred_frees(false);
         if (rc != MIBLAST_OK) { delete r; return rc; }
         *out = r;
         return MIBLAST_OK;
@@ -429,7 +427,6 @@ int miblast_align_pairs(miblast_ctx *ctx, const miblast_seqset *const *targets, 
             for (size_t k = 0; k < n_pairs; k++) { owned[k] = new miblast_result(); ts[k] = &targets[k]->s; qs[k] = &queries[k]->s; rs[k] = &owned[k]->r; }
             rc = mb::align_pairs(ctx->c, ts.data(), qs.data(), n_pairs, *p, rs.data());
         } catch (...) { cleanup(); throw; }
-        mb::flush_deferred_frees(false);
         if (rc != MIBLAST_OK) { cleanup(); return rc; }
         for (size_t k = 0; k < n_pairs; k++) results[k] = owned[k];
         return MIBLAST_OK;

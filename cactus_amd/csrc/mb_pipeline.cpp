@@ -38,32 +38,6 @@ double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// A buffer that GROWS while other host threads keep the device busy (the lanes of a call, the contexts of a phase) must not free its old
-// block then and there: hipFree / hipHostFree wait until the device is idle, and with the runtime polling instead of taking interrupts that
-// wait came back after 0.5 - 1 s, every other thread's allocation queued behind it (one step in three of the 42-pair workload took 650 ms
-// instead of 166).  The old block goes on a list instead and is freed when a call ends with enough of them collected, when the derived
-// data are dropped or when a context closes -- moments at which the caller's work on the device is over.
-long env_long(const char *name, long dflt);
-std::mutex g_defer_mu;
-std::vector<void *> g_defer_dev, g_defer_pin;
-size_t g_defer_bytes = 0;
-void defer_free(void *p, size_t bytes, bool pinned) {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    (pinned ? g_defer_pin : g_defer_dev).push_back(p);
-    g_defer_bytes += bytes;
-}
-void flush_deferred_frees_impl(bool all) {
-    std::vector<void *> dev, pin;
-    {
-        std::lock_guard<std::mutex> lk(g_defer_mu);
-        static const size_t limit = (size_t)env_long("MIBLAST_DEFER_FREE_MB", 16384) << 20;
-        if (!all && g_defer_bytes < limit) return;
-        dev.swap(g_defer_dev); pin.swap(g_defer_pin); g_defer_bytes = 0;
-    }
-    for (void *q : dev) (void)hipFree(q);
-    for (void *q : pin) (void)hipHostFree(q);
-}
-
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -75,15 +49,9 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void alloc(size_t count) {
         const double t0 = now_s();
-        if (p) defer_free(p, n * sizeof(T), false);                  // (not freed here: see flush_deferred_frees)
-        p = nullptr;
+        release();
         n = count;
-        if (count && hipMalloc((void **)&p, count * sizeof(T)) != hipSuccess) {      // no room: what is waiting to be freed first, then once more
-            (void)hipGetLastError();
-            p = nullptr;
-            flush_deferred_frees_impl(true);
-            MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
-        }
+        if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow device allocation: %.1f MB in %.1f ms\n", count * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
     }
     void ensure(size_t count) { if (count > n) alloc(count + count / 4); }
@@ -92,7 +60,7 @@ struct DevBuf {
         T *old = p; const size_t old_n = n;
         p = nullptr; n = count + count / 2;
         MB_HIP(hipMalloc((void **)&p, n * sizeof(T)));
-        if (old) { MB_HIP(hipMemcpy(p, old, old_n * sizeof(T), hipMemcpyDeviceToDevice)); defer_free(old, old_n * sizeof(T), false); }
+        if (old) { MB_HIP(hipMemcpy(p, old, old_n * sizeof(T), hipMemcpyDeviceToDevice)); (void)hipFree(old); }
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
@@ -109,8 +77,7 @@ struct PinBuf {
     void ensure(size_t count) {
         if (count <= n) return;
         const double t0 = now_s();
-        if (p) defer_free(p, n * sizeof(T), true);                   // (not freed here: see flush_deferred_frees)
-        p = nullptr;
+        release();
         n = count + count / 4;
         MB_HIP(hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow pinned allocation: %.1f MB in %.1f ms\n", n * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
@@ -1088,8 +1055,6 @@ static void forget_derived(const SeqSet &S) {
     auto it = c.sets.find(S.d_buf);
     if (it != c.sets.end()) { gone = it->second; c.sets.erase(it); }
 }
-void flush_deferred_frees(bool all) { flush_deferred_frees_impl(all); }
-
 void drop_derived() {
     std::vector<std::shared_ptr<SetDerived>> gone;
     DerivedCache &c = derived_cache();

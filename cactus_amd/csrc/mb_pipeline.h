@@ -42,7 +42,6 @@ int ctx_set_priority(Ctx &ctx, int level);
 void ctx_pair_streams(Ctx &ctx);     // the context's stream and its lanes' on hardware queues of their own
 void upload_seqset(SeqSet &s, int device);
 void release_seqset(SeqSet &s);
-void flush_deferred_frees(bool all);   // blocks that growing buffers left behind (freed when a call ends with enough of them collected; all: now)
 void drop_derived();                 // frees what the library keeps with resident sets: seed tables, '-' strands, packed strands (made again on demand)
 // outgroup trimming on the device (mb_pipeline.cpp): what no alignment of `paf` covers of the resident query set, as a new resident set
 // (n items in one call; outs[k] is left empty and nothing_left[k] set when every base of Qs[k] is covered)
