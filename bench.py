@@ -777,7 +777,8 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     from cactus_amd import miblast as _mb
     own = _mb.Context(ctx.device)
     w = ChunkWorkload(a, own, rank, world, which)
-    steps, warm = 3, 2                                    # (two untimed steps: the lanes' buffers and the pool's trace arenas have met the heaviest pairs)
+    steps, warm = 3, 3                                    # (three untimed steps: the lanes' buffers and the pool's trace arenas have met the heaviest pairs -- the lanes size their
+                                                          #  buffers at the start of the second for what the first one met, the gapped stages' tables follow the groups the lanes happen to take)
     box = {}
 
     def gather(paf):

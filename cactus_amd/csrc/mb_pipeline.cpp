@@ -1493,6 +1493,13 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     const bool binned = ordered && env_long("MIBLAST_SORT_BIN", 1) != 0;
     const int bin_mean = (int)std::max<long>(1, env_long("MIBLAST_BIN_MEAN", 11000));
     const int64_t bsw = bin_state_words();
+    // the most keys a plan of bins is made for: it follows the largest strand seen so far (by any lane of the call), NOT the key buffer -- that one
+    // grows in steps of its own, and a matrix sized by it was allocated anew (hipFree: every lane waits, 0.5 - 1 s with the runtime polling) in the
+    // middle of later steps.  A strand beyond it gets no plan and goes through rocprim once.
+    auto bin_room = [&](unsigned long long cap) -> unsigned long long {
+        const unsigned long long seen = std::max<unsigned long long>(ctx.hits_hint ? ctx.hits_hint->load(std::memory_order_relaxed) : 0ull, w.last_strand_hits);
+        return std::min<unsigned long long>(cap, std::max<unsigned long long>(1ull << 20, seen + seen / 4));
+    };
 
     // ---- seed search + ungapped extension, per strand ----------------------------------------------
     // hits per q batch of a strand.  A large pair's strand is ONE batch whenever it can be (no extent[] then, one sort, one launch of the
@@ -1533,7 +1540,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             keys_a.ensure(2 * want); keys_b.ensure(want); d_hsps.ensure(2 * want);
             w.heads.ensure(2 * want + want / 4 + 64);
             (void)ux_scratch(w, nullptr, want, ttot + qtot + 2, hmul, hmask);
-            if (binned) { w.bin_state.ensure(2 * (size_t)bsw); w.bin_matrix.ensure(2 * (size_t)bin_matrix_words_for(std::min<unsigned long long>((unsigned long long)keys_a.n, (unsigned long long)hit_cap) / 2, diag_bits, bin_mean)); }
+            if (binned) { w.bin_state.ensure(2 * (size_t)bsw); w.bin_matrix.ensure(2 * (size_t)bin_matrix_words_for(bin_room(std::min<unsigned long long>((unsigned long long)keys_a.n, (unsigned long long)hit_cap) / 2), diag_bits, bin_mean)); }
         }
     }
     std::future<void> host0;
@@ -1549,7 +1556,8 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             const int64_t ord_words = seed_ord_state_words(qtot);
             if (ordered) { w.ord_state.ensure(2 * (size_t)ord_words); MB_HIP(hipMemsetAsync(w.ord_state.p, 0, up16(2 * (size_t)ord_words * 8), s)); keys_b.ensure((size_t)capH); }
             else MB_HIP(hipMemsetAsync(qbsum.p, 0, 16, s));
-            const int64_t bmw = binned ? bin_matrix_words_for(capH, diag_bits, bin_mean) : 0;
+            const unsigned long long bcap = binned ? bin_room(capH) : 0;
+            const int64_t bmw = binned ? bin_matrix_words_for(bcap, diag_bits, bin_mean) : 0;
             if (binned) { w.bin_state.ensure(2 * (size_t)bsw); w.bin_matrix.ensure(2 * (size_t)bmw); MB_HIP(hipMemsetAsync(w.bin_state.p, 0, 2 * (size_t)bsw * 4, s)); }
             for (int strand = 0; strand < 2; strand++) {
                 MB_HIP(hipEventRecord(w.sev[strand][0], s));
@@ -1560,7 +1568,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     launch_seed_search(qc_d[strand], qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, keys_a.p + (size_t)strand * capH, capH, qbsum.p + strand, s);
                 MB_HIP(hipEventRecord(w.sev[strand][1], s));
                 // the plan of the bins (how many, the largest) comes back with the strand's hit count: the device knows that count first
-                if (binned) launch_bin_plan(keys_a.p + (size_t)strand * capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, capH, diag_bits, bin_mean, w.bin_state.p + (size_t)strand * (size_t)bsw,
+                if (binned) launch_bin_plan(keys_a.p + (size_t)strand * capH, w.ord_state.p + (size_t)strand * (size_t)ord_words, bcap, diag_bits, bin_mean, w.bin_state.p + (size_t)strand * (size_t)bsw,
                                             w.bin_matrix.p + (size_t)strand * (size_t)bmw, s);
             }
             if (ordered) {
@@ -1719,9 +1727,10 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             unsigned long long total = 0;
             uint32_t plan[8] = {0, 0, 0, 0, 1, 0, 0, 0};
             if (binned) {
-                w.bin_state.ensure((size_t)bsw); w.bin_matrix.ensure((size_t)bin_matrix_words_for(cap1, diag_bits, bin_mean));
+                const unsigned long long bcap1 = bin_room(cap1);
+                w.bin_state.ensure((size_t)bsw); w.bin_matrix.ensure((size_t)bin_matrix_words_for(bcap1, diag_bits, bin_mean));
                 MB_HIP(hipMemsetAsync(w.bin_state.p, 0, (size_t)bsw * 4, s));
-                launch_bin_plan(keys_a.p, w.ord_state.p, cap1, diag_bits, bin_mean, w.bin_state.p, w.bin_matrix.p, s);
+                launch_bin_plan(keys_a.p, w.ord_state.p, bcap1, diag_bits, bin_mean, w.bin_state.p, w.bin_matrix.p, s);
                 w.pin_u64.ensure(16);
                 MB_HIP(hipMemcpyAsync(w.pin_u64.p + 4, w.bin_state.p, 32, hipMemcpyDeviceToHost, s));
             }
@@ -3736,6 +3745,29 @@ static void output_layout(const miblast_params &p, PairJob &job, OutputJob &oj) 
     st.t_total = now_s() - job.t_begin;
 }
 
+// A lane's seed-stage buffers sized for the largest strand the call's context has met, at the lane's START -- before it takes a pair: a lane
+// that the others leave no pair in one step (they are taken from a queue) would otherwise make these allocations in the middle of a later
+// step, and a device allocation while other lanes keep the device busy stalls every lane (seed_phase).
+static void presize_lane(Ctx &lc, int64_t max_diags) {
+    if (!lc.hits_hint) return;
+    Workspace &w = *lc.ws;
+    const unsigned long long hint = lc.hits_hint->load(std::memory_order_relaxed);
+    const int64_t hit_cap = getenv("MIBLAST_HIT_CAP") ? env_long("MIBLAST_HIT_CAP", 32l << 20) : env_long("MIBLAST_DENSE_HIT_CAP", 128l << 20);
+    if (hint == 0 || 2 * (hint + hint / 8) > (unsigned long long)hit_cap) return;
+    const size_t want = (size_t)(hint + hint / 8);
+    w.keys_a.ensure(2 * want); w.keys_b.ensure(want); w.hsps.ensure(2 * want);
+    w.heads.ensure(2 * want + want / 4 + 64); w.n_heads.ensure(8);
+    const int diag_bits = std::min(30, std::max(1, (int)std::ceil(std::log2((double)(max_diags + 2)))));
+    (void)ux_scratch(w, nullptr, want, (int64_t)1 << diag_bits);
+    if (env_long("MIBLAST_SEED_ORDERED", 1) != 0 && env_long("MIBLAST_SORT_BIN", 1) != 0) {
+        const int bin_mean = (int)std::max<long>(1, env_long("MIBLAST_BIN_MEAN", 11000));
+        const unsigned long long seen = std::max<unsigned long long>(hint, w.last_strand_hits);
+        const unsigned long long room = std::min<unsigned long long>(std::min<unsigned long long>((unsigned long long)w.keys_a.n, (unsigned long long)hit_cap) / 2,
+                                                                     std::max<unsigned long long>(1ull << 20, seen + seen / 4));
+        w.bin_state.ensure(2 * (size_t)bin_state_words()); w.bin_matrix.ensure(2 * (size_t)bin_matrix_words_for(room, diag_bits, bin_mean));
+    }
+}
+
 int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
     const double t_call0 = now_s();
     MB_HIP(hipSetDevice(ctx.device));
@@ -3814,6 +3846,8 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         Workspace &w = *ctx.ws;
         while (w.lanes.size() < n_lanes) w.lanes.push_back(lane_create(ctx.device, ctx.priority));
         for (Ctx *l : w.lanes) { l->spans = ctx.spans; l->hits_hint = &w.hits_hint; }
+        int64_t max_diags = 0;
+        for (size_t k = 0; k < n; k++) max_diags = std::max<int64_t>(max_diags, Ts[k]->total + Qs[k]->total);
         std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
         std::vector<std::string> lane_err(n_lanes);
         std::vector<std::future<void>> lane_threads;
@@ -3833,6 +3867,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
                 try {
                     MB_HIP(hipSetDevice(ctx.device));
                     Ctx &lc = *w.lanes[lane];
+                    presize_lane(lc, max_diags);
                     for (size_t k0 = pipeline ? next_pair.fetch_add(group) : lane; k0 < n; k0 = pipeline ? next_pair.fetch_add(group) : k0 + n_lanes) {
                         std::vector<size_t> mem;
                         for (size_t k = k0; k < std::min(n, k0 + group); k++) {
