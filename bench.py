@@ -777,7 +777,7 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     from cactus_amd import miblast as _mb
     own = _mb.Context(ctx.device)
     w = ChunkWorkload(a, own, rank, world, which)
-    steps, warm = 3, 3                                    # (three untimed steps: the lanes' buffers and the pool's trace arenas have met the heaviest pairs -- the lanes size their
+    steps, warm = 5, 3                                    # (three untimed steps: the lanes' buffers and the pool's trace arenas have met the heaviest pairs -- the lanes size their
                                                           #  buffers at the start of the second for what the first one met, the gapped stages' tables follow the groups the lanes happen to take)
     box = {}
 
@@ -796,6 +796,9 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     load = [sum(w.weights[k] for k in sh) for sh in shares]
     unit_kind = "(chunk pair, query strand)" if w.split else "chunk pair"
     out = {"workload": w.describe, "chunk_pairs": len(w.pairs), "n_gpus": world, "scaling": "strong", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+           # (rank 0's single steps: a step in which a lane's tables or trace arena grow -- a device allocation while the other lanes keep the device
+           #  busy -- takes 0.3 - 0.6 s longer than the others; the mean above includes it, the median does not)
+           "step_ms_spread": dict(timed_steps.last_spread),
            "value": tot["dp_cells"] / elapsed / 1e9, "unit": "Gcell/s",
            "work_unit": unit_kind, "units_per_rank": [len(sh) for sh in shares], "balance_by_weight": (sum(load) / len(load)) / max(load) if max(load) > 0 else 1.0,
            "ownership": "target-major (SURVEY 8e): rank g owns target chunks i mod N; fewer target chunks than ranks: a chunk's column shared by a group of ranks",
