@@ -24,9 +24,10 @@
 //                  Two instantiations: bins of up to 4 096 keys (41 KB of LDS, three work-groups per CU) and of up to 16 384 (146 KB).
 // The result is the SAME array rocprim's stable sort by the scrambled diagonal followed by k_keys_unhash gives (bins, buckets and ranks
 // are all ascending in (scrambled diagonal, q), and a (diagonal, q) pair occurs once), so everything behind it is untouched and the two
-// paths are compared key by key in the tests.  ~ 17 B of reads + 17 B of writes per key instead of ~ 96.
-// A strand whose largest bin does not fit the large sorter (one diagonal with > ~ 13 000 hits: a self alignment; or diagonals left
-// unscrambled) goes through rocprim as before: the host sees the plan before it queues either.
+// paths are compared key by key in the tests.  24 B read + 16 B written per key (PMC: 43 B with the matrix and the scatter's partial lines) instead of ~ 96;
+// standing alone 192 us per strand of 11.5 million keys against rocprim's 289 (MI355X, profiles/README.md).
+// A strand whose largest bin does not fit the large sorter (one diagonal with more than ~ 8 000 hits on top of a full bin: a self alignment; or
+// diagonals left unscrambled), or of more than 2^26 keys, goes through rocprim as before: the host sees the plan before it queues either.
 #pragma once
 
 constexpr int kBinBitsMax = 13;                // at most 8 192 bins (the LDS histograms of k_bin_count / k_bin_scatter: 32 KB)

@@ -64,10 +64,10 @@ def test_emulated_grouping_by_diagonal_in_lds_equals_sort_and_unscramble():
     unscrambling give: one bin and hundreds, a dozen keys and tens of thousands, diagonals with thousands of hits (the large sorter), plain
     and scrambled diagonals."""
     subprocess.run(["make", "-C", EMU_DIR, "emu_seed_dense"], check=True, capture_output=True)
-    p = subprocess.run([os.path.join(EMU_DIR, "emu_seed_dense"), "2", "21", "bin"], capture_output=True, timeout=900)
+    p = subprocess.run([os.path.join(EMU_DIR, "emu_seed_dense"), "2", "11", "bin"], capture_output=True, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()
-    assert out.count(" ok\n") == 21 and "MISMATCH" not in out, out
+    assert out.count(" ok\n") == 11 and "MISMATCH" not in out, out
     assert "1 beyond the small sorter" in out, "no case reached the large sorter"
 
 
