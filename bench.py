@@ -103,7 +103,106 @@ def parse_args():
                     help="1 Mb x 1 Mb chunk pairs aligned in ONE miblast_align_pairs call (0 = skip); reported under batched_pairs, never in value")
     ap.add_argument("--seed-leg", type=int, default=8_000_000,
                     help="chunk size of the extra seed-stage leg on a pure-random pair (0 = skip); reported under seed_stage, never in value")
+    ap.add_argument("--full-out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_full.json"),
+                    help="file the FULL result object goes to (every leg with its counters, notes and per-pair figures); stdout's one line is the compact form of it")
     return ap.parse_args()
+
+
+LINE_LIMIT = 6000              # bytes of the printed line (the driver reads an 8 KB tail of stdout: round 5's 20 KB line did not parse)
+
+
+def _num(x, digits=5):
+    """floats at `digits` significant figures (the full file keeps every digit)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _short(text, n=200):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_line(out, full_path):
+    """The ONE line of stdout: the contract's keys, the roofline of the dominant kernel, the CPU baseline, and one small object per leg.  Everything
+    else (per-stage counters, notes, per-pair CPU seconds, the legs' own baselines) is in the file `full` names."""
+    def pick(d, keys):
+        return {k: _num(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+    line = {k: _num(out[k], 7) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 420), "collective_backend": cfg.get("collective_backend"),
+                      "timed_region": "sequence sets resident in HBM: FASTA parse + host-to-device copy are OUTSIDE the step (every run_lastz job pays them; DESIGN.md section 6 has the inclusive rate)"}
+    for k in ("paf_md5", "units_per_rank"):
+        if k in cfg:
+            line["config"][k] = cfg[k]
+    sp = out.get("step_ms_spread") or {}
+    line["step_ms"] = pick(sp, ("min", "median", "max"))
+    r = out.get("roofline") or {}
+    line["roofline"] = dict(pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes_per_launch", "cells_per_launch", "bytes_per_cell")),
+                            kernel="k_ydrop2")
+    if isinstance(r.get("valu"), dict):
+        line["roofline"]["valu"] = pick(r["valu"], ("frac", "frac_of_measured_peak", "cells_evaluated_per_s_per_gpu"))
+    if isinstance(r.get("saturated"), dict):
+        line["roofline"]["saturated"] = pick(r["saturated"], ("frac", "launch_ms", "gapped_gcells_per_s_kernel"))
+    if isinstance(out.get("hbm_read"), dict):
+        line["hbm_read"] = pick(out["hbm_read"], ("frac", "achieved_GBps", "peak_GBps", "bytes_total"))
+    for k in ("speculation_factor", "gapped_gcells_per_s_kernel", "seeds_per_s", "device_allocs_in_timed_steps"):
+        if k in out:
+            line[k] = _num(out[k])
+    if isinstance(out.get("parity"), dict):
+        line["parity"] = pick(out["parity"], ("same_bytes", "pairs_checked", "pairs_differing"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "seconds", "calls", "same_bytes", "same_dp_cells", "calls_differing"))
+        line["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 160)
+        if isinstance(cb.get("node"), dict):
+            line["cpu_baseline"]["node"] = pick(cb["node"], ("value", "cores", "cores_available", "seconds_wall", "same_bytes"))
+    legs = {}
+    for name in ("primates", "pair_1mb", "batched_pairs", "seed_stage", "chr20", "hm", "chain_stage"):
+        leg = out.get(name)
+        if not isinstance(leg, dict):
+            continue
+        o = pick(leg, ("ms_per_step", "ms_per_call", "steps", "value", "unit", "seeds_per_s", "records_per_s", "seconds", "frac", "chunk_pairs", "gapped_gcells_per_s_kernel",
+                       "device_allocs_in_timed_steps"))
+        if isinstance(leg.get("step_ms_spread"), dict):
+            o["step_ms"] = pick(leg["step_ms_spread"], ("min", "median", "max"))
+        if isinstance(leg.get("hbm_read"), dict):
+            o["hbm_read_frac"] = _num(leg["hbm_read"].get("frac"))
+        if isinstance(leg.get("roofline_dp") or leg.get("roofline"), dict):
+            o["dp_frac"] = _num((leg.get("roofline_dp") or leg.get("roofline")).get("frac"))
+        if isinstance(leg.get("parity"), dict):
+            o["parity"] = pick(leg["parity"], ("same_bytes", "pairs_checked", "pairs_differing"))
+        if isinstance(leg.get("cpu_baseline"), dict):
+            o["cpu_baseline"] = pick(leg["cpu_baseline"], ("value", "unit", "records_per_s", "cores", "seconds", "same_bytes"))
+        legs[name] = o
+    if legs:
+        line["legs"] = legs
+    if "legs_note" in out:
+        line["legs_note"] = _short(out["legs_note"], 200)
+    line["full"] = full_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                               # never again a line the driver cannot read: the legs go first, then the notes
+        for k in ("legs_note", "legs", "step_ms", "hbm_read"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
+
+
+def emit(out, full_path):
+    """full object -> file, compact line -> stdout (exactly one line)"""
+    try:
+        tmp = full_path + ".tmp%d" % os.getpid()
+        with open(tmp, "w") as f:
+            json.dump(out, f)
+            f.write("\n")
+        os.replace(tmp, full_path)
+    except OSError as e:                                     # (a read-only tree: the line still goes out)
+        print(f"bench.py: could not write {full_path}: {e}", file=sys.stderr)
+        full_path = None
+    print(compact_line(out, full_path), flush=True)
 
 
 def spawn_ranks(a) -> int:
@@ -700,7 +799,7 @@ def run_rank(a):
                 out["cpu_baseline"] = work.cpu_sample(work.by_index)
             else:
                 out["cpu_baseline"] = cpu_baseline(keep, tot["dp_cells"] / per, work.describe)
-        print(json.dumps(out), flush=True)
+        emit(out, a.full_out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

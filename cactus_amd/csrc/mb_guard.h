@@ -1,0 +1,120 @@
+// mb_guard.h -- MIBLAST_DEBUG_GUARD: every device allocation of the library at its EXACT size with a canary behind it.
+//
+// The normal allocators round sizes up (DevBuf::ensure adds a quarter, the block cache rounds to 4 096 bytes and hands out blocks up to
+// twice the size asked for, the chaining stage's cache up to four times): a kernel that writes a few elements past what the host sized is
+// absorbed by that slack on most runs and faults -- or corrupts a neighbour -- on the run whose layout leaves none.  Under
+//   MIBLAST_DEBUG_GUARD=1   an allocation is hipMalloc(bytes + 4 KiB), the 4 KiB behind the last byte asked for are a pattern (0xA5) that is
+//                           checked whenever the block is freed and by guard::check_all() (the pipeline calls it at the end of every stage:
+//                           the device is synchronised first); no head-room, no recycling of blocks between owners;
+//   MIBLAST_DEBUG_GUARD=2   as 1, and the block itself starts as 0xCD bytes: state that a kernel reads before anything wrote it shows as
+//                           wild indices / scores at once instead of as whatever a recycled page held.
+// A damaged canary is reported with the allocation's tag, size and the first damaged offset, and the process aborts.
+// Debug facility: outputs are unchanged by it (the GPU suite runs under it once per round: profiles/r06_guard_suite.log).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace mb {
+namespace guard {
+
+constexpr size_t kCanary = 4096;
+
+inline int level() {
+    static const int lv = [] { const char *v = getenv("MIBLAST_DEBUG_GUARD"); return v && *v ? atoi(v) : 0; }();
+    return lv;
+}
+inline bool on() { return level() > 0; }
+
+struct Rec { size_t bytes; const char *tag; int device; };
+struct Registry {
+    std::mutex mu;
+    std::unordered_map<void *, Rec> live;
+    unsigned long long n_alloc = 0, n_check = 0;
+};
+inline void report();
+inline Registry &registry() { static Registry *r = [] { atexit(report); return new Registry(); }(); return *r; }          // (never destroyed: frees may come after main)
+
+[[noreturn]] inline void die(const char *what, void *p, const Rec &r, long off, const char *where) {
+    if (const char *path = getenv("MIBLAST_DEBUG_GUARD_LOG")) if (FILE *f = fopen(path, "a")) { fprintf(f, "[miblast guard] pid %d: %s: allocation '%s' (%zu bytes), canary byte +%ld, seen at: %s\n", (int)getpid(), what, r.tag ? r.tag : "?", r.bytes, off, where ? where : "?"); fclose(f); }
+    fprintf(stderr, "[miblast guard] %s: allocation '%s' (%zu bytes at %p, device %d): first damaged canary byte at +%ld behind its end (seen at: %s)\n",
+            what, r.tag ? r.tag : "?", r.bytes, p, r.device, off, where ? where : "?");
+    fflush(stderr);
+    abort();
+}
+
+inline long first_damage(void *p, const Rec &r) {
+    static thread_local std::vector<unsigned char> host(kCanary);
+    if (hipMemcpy(host.data(), (char *)p + r.bytes, kCanary, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    for (size_t i = 0; i < kCanary; i++) if (host[i] != 0xA5) return (long)i;
+    return -1;
+}
+
+// hipMalloc's stand-in.  Returns hipSuccess / the error of hipMalloc (the trace arena retries smaller on failure).
+inline hipError_t alloc(void **out, size_t bytes, const char *tag) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes + kCanary);
+    if (e != hipSuccess) { *out = nullptr; return e; }
+    if (level() > 1 && bytes) (void)hipMemset(p, 0xCD, bytes);
+    (void)hipMemset((char *)p + bytes, 0xA5, kCanary);
+    (void)hipDeviceSynchronize();
+    int dev = 0; (void)hipGetDevice(&dev);
+    Registry &g = registry();
+    { std::lock_guard<std::mutex> lk(g.mu); g.live[p] = Rec{bytes, tag, dev}; g.n_alloc++; }
+    *out = p;
+    return hipSuccess;
+}
+
+inline void free(void *p, const char *where = "free") {
+    if (!p) return;
+    Registry &g = registry();
+    Rec r{0, nullptr, 0}; bool known = false;
+    { std::lock_guard<std::mutex> lk(g.mu); auto it = g.live.find(p); if (it != g.live.end()) { r = it->second; known = true; g.live.erase(it); } }
+    if (known) {
+        int cur = 0; (void)hipGetDevice(&cur);
+        if (cur != r.device) (void)hipSetDevice(r.device);
+        (void)hipDeviceSynchronize();
+        const long off = first_damage(p, r);
+        if (off >= 0) die("overrun found on free", p, r, off, where);
+        if (cur != r.device) (void)hipSetDevice(cur);
+    }
+    (void)hipFree(p);
+}
+
+// every live allocation's canary (of the current device), after the device has finished what is queued
+inline void check_all(const char *where) {
+    if (!on()) return;
+    int cur = 0; (void)hipGetDevice(&cur);
+    (void)hipDeviceSynchronize();
+    Registry &g = registry();
+    std::lock_guard<std::mutex> lk(g.mu);                  // (held over the sweep: a block on the list cannot be freed under it -- free() takes the block off the list first)
+    g.n_check++;
+    for (auto &kv : g.live) {
+        if (kv.second.device != cur) continue;
+        const long off = first_damage(kv.first, kv.second);
+        if (off >= 0) die("overrun", kv.first, kv.second, off, where);
+    }
+}
+
+// at process exit, one line per process appended to the file MIBLAST_DEBUG_GUARD_LOG names (the front ends' stderr stays empty)
+inline void report() {
+    const char *path = getenv("MIBLAST_DEBUG_GUARD_LOG");
+    if (!on() || !path || !*path) return;
+    Registry &g = registry();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (FILE *f = fopen(path, "a")) {
+        fprintf(f, "[miblast guard] pid %d level %d: %llu guarded allocations, %llu sweeps over the live ones, %zu live at exit, no canary damaged\n", (int)getpid(), level(), g.n_alloc,
+                g.n_check, g.live.size());
+        fclose(f);
+    }
+}
+
+}  // namespace guard
+}  // namespace mb

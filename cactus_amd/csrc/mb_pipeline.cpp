@@ -12,6 +12,7 @@
 //   * a one-sided DP is a chain of rows: it is cut at relays (fresh DPs started downstream) whose state
 //     after a warm-up must equal the upstream state exactly, else the upstream piece is continued.
 #include "mb_pipeline.h"
+#include "mb_guard.h"
 
 #include <algorithm>
 #include <chrono>
@@ -51,18 +52,20 @@ struct DevBuf {
         const double t0 = now_s();
         release();
         n = count;
-        if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        if (count && guard::on()) MB_HIP(guard::alloc((void **)&p, count * sizeof(T), __PRETTY_FUNCTION__));
+        else if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow device allocation: %.1f MB in %.1f ms\n", count * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
     }
-    void ensure(size_t count) { if (count > n) alloc(count + count / 4); }
+    void ensure(size_t count) { if (count > n) alloc(guard::on() ? count : count + count / 4); }       // (guard mode: exactly what was asked for, a canary behind it)
     void ensure_keep(size_t count) {              // grow without losing the contents
         if (count <= n) return;
         T *old = p; const size_t old_n = n;
-        p = nullptr; n = count + count / 2;
-        MB_HIP(hipMalloc((void **)&p, n * sizeof(T)));
-        if (old) { MB_HIP(hipMemcpy(p, old, old_n * sizeof(T), hipMemcpyDeviceToDevice)); (void)hipFree(old); }
+        p = nullptr; n = guard::on() ? count : count + count / 2;
+        if (guard::on()) MB_HIP(guard::alloc((void **)&p, n * sizeof(T), __PRETTY_FUNCTION__));
+        else MB_HIP(hipMalloc((void **)&p, n * sizeof(T)));
+        if (old) { MB_HIP(hipMemcpy(p, old, old_n * sizeof(T), hipMemcpyDeviceToDevice)); if (guard::on()) guard::free(old, "DevBuf::ensure_keep"); else (void)hipFree(old); }
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) { if (guard::on()) guard::free(p, "DevBuf::release"); else (void)hipFree(p); } p = nullptr; n = 0; }
 };
 
 // pinned host staging buffer: one large device-to-host copy at link speed, no page faults
@@ -470,6 +473,12 @@ struct DeviceBlocks {
     size_t cached = 0;
     static constexpr size_t kKeep = (size_t)8 << 30;        // (of 288 GB: the derived data of a genome pair's chunks comes and goes with every step of a bench)
     void *take(int device, size_t bytes, size_t &cap) {
+        if (guard::on()) {                                   // exact size, canary behind it, no recycling
+            void *p = nullptr;
+            cap = bytes;
+            MB_HIP(guard::alloc(&p, bytes, "DeviceBlocks::take"));
+            return p;
+        }
         {
             std::lock_guard<std::mutex> lk(mu);
             size_t best = free_list.size();
@@ -488,6 +497,7 @@ struct DeviceBlocks {
         return p;
     }
     void give(int device, void *p, size_t cap) {
+        if (guard::on()) { guard::free(p, "DeviceBlocks::give"); return; }
         {
             std::lock_guard<std::mutex> lk(mu);
             if (cached + cap <= kKeep) { free_list.push_back({device, p, cap}); cached += cap; return; }
@@ -3369,7 +3379,12 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                         g.stage.d2h(so.data(), g.outs.p, so.size() * sizeof(DpOut), s);
                         MB_HIP(hipStreamSynchronize(s));
                         g.stage.done();
-                        for (size_t y = 0; y < again.size(); y++) outs[again[y]] = so[y];
+                        // only k_ydrop2 writes the fin_* fields: a rerun piece made no check of its own and ended with what it was queued with
+                        for (size_t y = 0; y < again.size(); y++) {
+                            const size_t x = again[y];
+                            so[y].fin_stop = probs[x].stop_row; so[y].fin_aim1 = probs[x].aim1; so[y].fin_ck = probs[x].ck0; so[y].fin_checks = 0;
+                            outs[x] = so[y];
+                        }
                         st.dp_reruns += (int64_t)again.size();
                         if (debug) fprintf(stderr, "[miblast]   %zu of %zu pieces outgrew the one-wave kernel and were rerun (dp kernel total %.2f ms)\n", again.size(), n_new, st.t_dp_kernel_ms);
                         launch_verify(d_vjobs, d_vres, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
@@ -3768,7 +3783,7 @@ static void presize_lane(Ctx &lc, int64_t max_diags) {
     }
 }
 
-int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
+static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
     const double t_call0 = now_s();
     MB_HIP(hipSetDevice(ctx.device));
     Pool::Hot keep_workers_awake;
@@ -3831,6 +3846,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
     bool batched_done = false;
     if (n >= 1 && (batched_mode >= 2 || (batched_mode == 1 && (n > 1 || small_single)))) {
         int rc = seed_phase_batched(ctx, p, jobs, batched_done);
+        guard::check_all("seed stage (batched)");
         if (rc != MIBLAST_OK) return rc;
         if (!batched_done) for (PairJob *j : jobs) { j->found[0].clear(); j->found[1].clear(); j->units.clear(); }
     }
@@ -3873,6 +3889,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
                         for (size_t k = k0; k < std::min(n, k0 + group); k++) {
                             PairJob &j = *jobs[k];
                             int rc = seed_phase(lc, p, j);
+                            guard::check_all("seed stage (lane)");
                             if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
                             seed_host(p, j, 0); seed_host(p, j, 1); seed_finish(j);
                             build_units(p, j, (int)k, j.units);
@@ -3893,6 +3910,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
                         lc.ws->pair_ptrs.ensure(n);
                         lc.ws->stage.h2d(lc.ws->pair_ptrs.p, pp.data(), n * sizeof(PairPtrs), lc.stream);
                         const int rc = gapped_phase(lc, p, jobs, gu, &mem, std::min(n_lanes, n_groups));
+                        guard::check_all("gapped stage (lane)");
                         for (Unit &u : gu) jobs[(size_t)u.pair]->units.push_back(std::move(u));          // (back to their pairs, in order)
                         group_leader[mem[0]] = 1; lane_gapped[lane] += jobs[mem[0]]->res->stats.t_gapped;
                         if (rc != MIBLAST_OK) { lane_rc[lane] = rc; lane_err[lane] = last_error_text(); return; }
@@ -3918,6 +3936,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         PairJob &j = *jobs[k];
         const double t_a = now_s();
         int rc = seed_phase(ctx, p, j);
+        guard::check_all("seed stage");
         if (rc != MIBLAST_OK) { for (auto &f : host_tasks) if (f.valid()) f.wait(); return rc; }
         const double t_b = now_s();
         if (j.defer_host) {
@@ -4013,6 +4032,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
                 try {
                     MB_HIP(hipSetDevice(ctx.device));
                     lane_rc[x] = gapped_phase(*w0.lanes[x - 1], p, jobs, gunits[x], &members[x]);
+                    guard::check_all("gapped stage (part)");
                     if (lane_rc[x] != MIBLAST_OK) lane_err[x] = last_error_text();
                 } catch (const HipFailure &e) {
                     lane_rc[x] = MIBLAST_EHIP;
@@ -4025,6 +4045,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         }
         try {
             rc = gapped_phase(ctx, p, jobs, gunits[0], &members[0]);
+            guard::check_all("gapped stage (first part)");
         } catch (...) {
             for (auto &f : others) f.get();
             throw;
@@ -4054,6 +4075,7 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         }
     } else {
         rc = gapped_phase(ctx, p, jobs, units);
+        guard::check_all("gapped stage");
     }
     if (rc != MIBLAST_OK) return rc;
     {
@@ -4079,6 +4101,12 @@ int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size
         fprintf(stderr, "[miblast] call of %zu pairs: seed stages %.2f ms, gapped stage %.2f ms, output %.2f ms, all %.2f ms\n", n, (t_call1 - t_call0) * 1e3, (t_o - t_call1) * 1e3,
                 (now_s() - t_o) * 1e3, (now_s() - t_call0) * 1e3);
     return MIBLAST_OK;
+}
+
+int align_pairs(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
+    const int rc = align_pairs_impl(ctx, Ts, Qs, n, pin, results);
+    guard::check_all("end of a call");                     // (MIBLAST_DEBUG_GUARD; nothing otherwise)
+    return rc;
 }
 
 int align(Ctx &ctx, const SeqSet &T, const SeqSet &Q, const miblast_params &pin, Result &res) {

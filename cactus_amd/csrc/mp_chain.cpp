@@ -5,6 +5,7 @@
 // three compute steps: without a device context they cannot be called at all.
 #include "mp_common.h"
 #include "mb_pipeline.h"
+#include "mb_guard.h"
 
 #include "../../include/mipaf.h"
 
@@ -67,6 +68,13 @@ struct DevCache {
     std::vector<Slot> slots;
     size_t total = 0;
     void *get(size_t bytes, size_t &cap) {
+        if (mb::guard::on()) {                               // MIBLAST_DEBUG_GUARD: exact size, canary behind it, nothing reused
+            void *p = nullptr;
+            MB_HIP(mb::guard::alloc(&p, bytes, "DevCache::get"));
+            slots.push_back(Slot{p, bytes, true});
+            total += bytes; cap = bytes;
+            return p;
+        }
         bytes = std::max<size_t>(bytes, 256);
         int best = -1;
         for (size_t i = 0; i < slots.size(); i++)
@@ -81,13 +89,18 @@ struct DevCache {
         return p;
     }
     void put(void *p) {
+        if (mb::guard::on()) {
+            for (size_t i = 0; i < slots.size(); i++) if (slots[i].p == p) { total -= slots[i].cap; slots.erase(slots.begin() + (long)i); break; }
+            mb::guard::free(p, "DevCache::put");
+            return;
+        }
         for (Slot &s : slots) if (s.p == p) { s.used = false; return; }
     }
     void trim(size_t keep_bytes) {                            // after a job: give back what is idle beyond the budget
         for (size_t i = slots.size(); i-- > 0 && total > keep_bytes;)
             if (!slots[i].used) { (void)hipFree(slots[i].p); total -= slots[i].cap; slots.erase(slots.begin() + (long)i); }
     }
-    ~DevCache() { for (Slot &s : slots) (void)hipFree(s.p); }
+    ~DevCache() { for (Slot &s : slots) { if (mb::guard::on()) mb::guard::free(s.p, "~DevCache"); else (void)hipFree(s.p); } }
 };
 thread_local DevCache *g_cache = nullptr;
 struct UseCache {                          // the calling thread's Dev<> objects draw from this context's cache
@@ -97,6 +110,7 @@ struct UseCache {                          // the calling thread's Dev<> objects
         g_cache = (DevCache *)ctx.chain_cache;
     }
     ~UseCache() {
+        mb::guard::check_all("end of a chaining-stage call");
         if (g_cache) g_cache->trim((size_t)std::max(0l, env_long_mp("MIPAF_CACHE_MB", 8192)) << 20);
         g_cache = prev;
     }
@@ -113,12 +127,13 @@ struct Dev {                               // device array with the lifetime of 
     Dev &operator=(const Dev &) = delete;
     ~Dev() {
         if (!p) return;
-        if (from) from->put(p); else (void)hipFree(p);
+        if (from) from->put(p); else if (mb::guard::on()) mb::guard::free(p, "~Dev"); else (void)hipFree(p);
     }
     void alloc(size_t count) {
         n = count;
         const size_t bytes = std::max<size_t>(1, count) * sizeof(T);
         if (g_cache) { size_t cap; p = (T *)g_cache->get(bytes, cap); from = g_cache; }
+        else if (mb::guard::on()) MB_HIP(mb::guard::alloc((void **)&p, bytes, "Dev::alloc"));
         else MB_HIP(hipMalloc((void **)&p, bytes));
     }
     void upload(const std::vector<T> &v, hipStream_t s) {

@@ -16,12 +16,33 @@ SMALL = ["--ancestor", "60000", "--steps", "1", "--warmup", "1", "--seed-leg", "
 
 
 def _bench(args, **env):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, **env), cwd=ROOT)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout
-    return json.loads(lines[0])
+    """Runs bench.py; checks the printed line (ONE line, < 8 000 bytes, the contract's keys, the figures of the full object) and returns the
+    FULL object of the file the line names."""
+    import tempfile
+    fd, full = tempfile.mkstemp(suffix=".json", prefix="bench_full_")
+    os.close(fd)
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--full-out", full], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **env), cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        assert len(lines[0].encode()) < 8000, len(lines[0])
+        line = json.loads(lines[0])
+        out = json.load(open(full))
+    finally:
+        os.unlink(full)
+    assert line["full"] == full
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == out[k], k
+    for k in ("value", "ms_per_step"):
+        assert abs(line[k] - out[k]) <= 1e-5 * abs(out[k]), k
+    assert line["config"]["workload"][:100] == out["config"]["workload"][:100] and "OUTSIDE the step" in line["config"]["timed_region"]
+    r = line["roofline"]
+    assert r["kernel"] == "k_ydrop2" and r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 * r["frac"] + 1e-12
+    if "cpu_baseline" in out:
+        assert line["cpu_baseline"]["same_bytes"] == out["cpu_baseline"]["same_bytes"] and line["cpu_baseline"]["cores"] == out["cpu_baseline"]["cores"]
+    return out
 
 
 def test_bench_line_carries_the_oracle_diff_of_the_benched_workload():

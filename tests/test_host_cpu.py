@@ -335,3 +335,49 @@ def test_container_modes_hand_the_gpus_over_the_amd_way(tmp_path, monkeypatch):
     env.pop("CACTUS_SINGULARITY_IMG")
     with pytest.raises(RuntimeError):
         common.cactus_call(parameters=argv, work_dir=str(tmp_path), gpus=2, env=env)
+
+
+def test_bench_line_is_compact_and_carries_the_contract():
+    """SURVEY 8d / round-5 review: the driver reads an 8 KB tail of stdout, and round 5's 20 KB line did not parse.  bench.compact_line() of a
+    full result object (round 5's own, every leg present) must be ONE line below 8 000 bytes with the contract's keys, `roofline` and
+    `cpu_baseline`; the full object goes to the file the line names."""
+    import importlib.util
+    import json
+    import io
+    import contextlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in ("r05_bench.json", "r04_bench.json", "r05_hm_bench_under_rocprof.json"):
+        full = json.loads(open(os.path.join(root, "profiles", name)).read().strip().splitlines()[-1])
+        assert len(json.dumps(full)) > 8000 or "hm" in name
+        text = bench.compact_line(full, "bench_full.json")
+        assert "\n" not in text and len(text.encode()) < 8000
+        line = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in line, k
+        assert line["unit"] == "Gcell/s" and line["dtype"] == "int32" and line["vs_baseline"] is None and "workload" in line["config"]
+        assert "OUTSIDE the step" in line["config"]["timed_region"]
+        r = line["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "algorithmic_bytes_per_launch"):
+            assert k in r, k
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 * r["frac"] and "frac_of_measured_peak" in r["valu"]
+        assert abs(line["value"] - full["value"]) < 1e-5 * full["value"] and line["full"] == "bench_full.json"
+        if "cpu_baseline" in full:
+            cb = line["cpu_baseline"]
+            assert cb["kind"] == "port" and cb["cores"] == full["cpu_baseline"]["cores"] and cb["same_bytes"] is True and "sample" in cb and cb["value"] > 0
+        if "hm" in full:
+            for leg in ("chr20", "hm"):
+                assert line["legs"][leg]["parity"]["same_bytes"] is True and line["legs"][leg]["ms_per_step"] > 0 and "hbm_read_frac" in line["legs"][leg]
+    # a grotesquely long workload description cannot push the line over the limit either
+    full["config"]["workload"] = "x" * 50000
+    assert len(bench.compact_line(full, "f").encode()) < 8000
+    # emit(): the file holds the full object, stdout exactly the one line
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.emit(full, os.path.join(d, "full.json"))
+        assert buf.getvalue().count("\n") == 1 and json.loads(buf.getvalue())["full"] == os.path.join(d, "full.json")
+        assert json.load(open(os.path.join(d, "full.json"))) == full
