@@ -53,25 +53,40 @@ extern "C" {
 // The HIP runtime deals a process's streams to 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and two streams on one queue
 // run their kernels one after the other: a context's stream, its lanes' and the streams of the other contexts of a job want queues of
 // their own (16 x 1 Mb pairs in one call: 31 ms side by side, 34 ms one after the other).  Set when the library is loaded -- before the
-// runtime starts, which reads it at its first call -- unless the caller has said otherwise: the front ends (bin/lastz, bin/run_kegalign,
-// bin/paffy) and every process that loads libmiblast.so run with what bench.py measures.  HSA_ENABLE_INTERRUPT=0, the other setting of
-// bench.py, trades a spinning core per waiting thread for ~25 us per wait (a phase of 20 calls: 19.1 -> 18.3 ms): round 5 applies
-// bench.py's own rule here too -- polling when the process may use 24 cores or more, unless the caller has said otherwise
-// (MIBLAST_POLL=0 leaves the runtime's default) -- so the shipped front ends run with it on the nodes the bench measures it on.
+// runtime starts, which reads it at its first call -- unless the caller has said otherwise.
+// HSA_DISABLE_COREDUMP_ON_EXCEPTION: a device fault makes the ROCm runtime write a GPU core dump before it reports anything; under a
+// piped kernel.core_pattern inside a container its helper cannot be started and the dumping process dies of SIGPIPE with nothing but
+// "GPU coredump: execvp failed" on stderr (GPUTEST_r05) -- and a Toil job has no use for a dump of a 288 GB device.  Without the dump the
+// runtime's own report (faulting address, reason) reaches stderr and the exit is the abort cactus_call expects.  Caller's setting wins.
+// HSA_ENABLE_INTERRUPT=0 (polling) is NOT set by the library on its own any more: miblast_frontend_runtime_defaults() below, called by the
+// front ends, or MIBLAST_POLL=1 in the environment of a process that loads the library.
 namespace {
+bool poll_rule(int threads) {
+    const char *poll = getenv("MIBLAST_POLL");
+    if (poll && *poll == '0') return false;
+    if (threads <= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        threads = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 0;
+    }
+    if (threads < 24 && !(poll && *poll == '1')) return false;
+    setenv("HSA_ENABLE_INTERRUPT", "0", 0);
+    const char *v = getenv("HSA_ENABLE_INTERRUPT");
+    return v && *v == '0';
+}
 struct RuntimeDefaults {
     RuntimeDefaults() {
         setenv("GPU_MAX_HW_QUEUES", "16", 0);
+        setenv("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1", 0);
         const char *poll = getenv("MIBLAST_POLL");
-        if (!(poll && *poll == '0')) {
-            cpu_set_t set;
-            CPU_ZERO(&set);
-            const int cores = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 0;
-            if (cores >= 24) setenv("HSA_ENABLE_INTERRUPT", "0", 0);
-        }
+        if (poll && *poll == '1') (void)poll_rule(1 << 20);
     }
 } g_runtime_defaults;
 }  // namespace
+
+int miblast_frontend_runtime_defaults(int threads) { return poll_rule(threads) ? 1 : 0; }
+
+size_t miblast_params_size(void) { return sizeof(miblast_params); }
 
 void miblast_params_default(miblast_params *p) {
     p->step = 1; p->transitions = 1; p->xdrop = 910; p->ydrop = 9400; p->hspthresh = 3000; p->gappedthresh = -1;

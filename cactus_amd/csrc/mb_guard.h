@@ -8,10 +8,17 @@
 //                           the device is synchronised first); no head-room, no recycling of blocks between owners;
 //   MIBLAST_DEBUG_GUARD=2   as 1, and the block itself starts as 0xCD bytes: state that a kernel reads before anything wrote it shows as
 //                           wild indices / scores at once instead of as whatever a recycled page held.
+//   MIBLAST_DEBUG_GUARD=3   an electric fence: the block is mapped with the virtual-memory calls (hipMemAddressReserve / hipMemCreate / hipMemMap) so
+//                           that its last byte (rounded up to 16) is the LAST MAPPED byte -- the address range behind it is reserved and never mapped.
+//                           A kernel that READS or writes one element past what the host sized faults at once, on every run, instead of on the
+//                           run whose layout puts an unmapped page there (round 5's GPUTEST fault was of that kind: not reproduced in 400 runs
+//                           of the same command).  The runtime then names the address; the SIGABRT handler of this mode prints the table of live
+//                           blocks (tag, range) so that the address can be read as "N bytes behind block X".  Blocks start as 0xCD as in 2.
 // A damaged canary is reported with the allocation's tag, size and the first damaged offset, and the process aborts.
 // Debug facility: outputs are unchanged by it (the GPU suite runs under it once per round: profiles/r06_guard_suite.log).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include <cstdint>
@@ -33,7 +40,7 @@ inline int level() {
 }
 inline bool on() { return level() > 0; }
 
-struct Rec { size_t bytes; const char *tag; int device; };
+struct Rec { size_t bytes; const char *tag; int device; void *base = nullptr; size_t mapped = 0, reserved = 0; hipMemGenericAllocationHandle_t handle = {}; };
 struct Registry {
     std::mutex mu;
     std::unordered_map<void *, Rec> live;
@@ -51,6 +58,7 @@ inline Registry &registry() { static Registry *r = [] { atexit(report); return n
 }
 
 inline long first_damage(void *p, const Rec &r) {
+    if (r.base) return -1;                                 // (fenced block: nothing mapped behind it to look at)
     static thread_local std::vector<unsigned char> host(kCanary);
     if (hipMemcpy(host.data(), (char *)p + r.bytes, kCanary, hipMemcpyDeviceToHost) != hipSuccess) return -2;
     for (size_t i = 0; i < kCanary; i++) if (host[i] != 0xA5) return (long)i;
@@ -58,18 +66,68 @@ inline long first_damage(void *p, const Rec &r) {
 }
 
 // hipMalloc's stand-in.  Returns hipSuccess / the error of hipMalloc (the trace arena retries smaller on failure).
+inline void dump_live(int);
+inline hipError_t fenced(void **out, size_t bytes, Rec &r) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = r.device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran < 4096) gran = 4096;
+    const size_t user = (bytes + 15) & ~(size_t)15;          // (16-byte loads and stores stay aligned: an overrun of less than that many bytes goes unseen)
+    r.mapped = (user + gran - 1) / gran * gran;
+    if (r.mapped == 0) r.mapped = gran;
+    r.reserved = r.mapped + gran;
+    if ((e = hipMemAddressReserve(&r.base, r.reserved, gran, nullptr, 0)) != hipSuccess) return e;
+    if ((e = hipMemCreate(&r.handle, r.mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(r.base, r.reserved); return e; }
+    if ((e = hipMemMap(r.base, r.mapped, 0, r.handle, 0)) != hipSuccess) { (void)hipMemRelease(r.handle); (void)hipMemAddressFree(r.base, r.reserved); return e; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(r.base, r.mapped, &acc, 1)) != hipSuccess) { (void)hipMemUnmap(r.base, r.mapped); (void)hipMemRelease(r.handle); (void)hipMemAddressFree(r.base, r.reserved); return e; }
+    (void)hipMemset(r.base, 0xCD, r.mapped);
+    *out = (char *)r.base + (r.mapped - user);
+    return hipSuccess;
+}
+
 inline hipError_t alloc(void **out, size_t bytes, const char *tag) {
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes + kCanary);
-    if (e != hipSuccess) { *out = nullptr; return e; }
-    if (level() > 1 && bytes) (void)hipMemset(p, 0xCD, bytes);
-    (void)hipMemset((char *)p + bytes, 0xA5, kCanary);
-    (void)hipDeviceSynchronize();
     int dev = 0; (void)hipGetDevice(&dev);
+    Rec r{bytes, tag, dev};
+    if (level() >= 3) {
+        static const bool handler = [] { signal(SIGABRT, dump_live); return true; }();
+        (void)handler;
+        hipError_t e = fenced(&p, bytes, r);
+        if (e != hipSuccess) { *out = nullptr; return e; }
+    } else {
+        hipError_t e = hipMalloc(&p, bytes + kCanary);
+        if (e != hipSuccess) { *out = nullptr; return e; }
+        if (level() > 1 && bytes) (void)hipMemset(p, 0xCD, bytes);
+        (void)hipMemset((char *)p + bytes, 0xA5, kCanary);
+    }
+    (void)hipDeviceSynchronize();
     Registry &g = registry();
-    { std::lock_guard<std::mutex> lk(g.mu); g.live[p] = Rec{bytes, tag, dev}; g.n_alloc++; }
+    { std::lock_guard<std::mutex> lk(g.mu); g.live[p] = r; g.n_alloc++; }
     *out = p;
     return hipSuccess;
+}
+
+// SIGABRT in fence mode (the runtime aborts after naming the faulting address): the live blocks, so that the address can be placed
+inline void dump_live(int) {
+    Registry &g = registry();
+    fprintf(stderr, "[miblast guard] live blocks at the abort (an address just behind an `end` is an overrun of that block):\n");
+    for (auto &kv : g.live)
+        fprintf(stderr, "[miblast guard]   %p .. end %p  %zu bytes  %s\n", kv.first, (void *)((char *)kv.first + kv.second.bytes), kv.second.bytes, kv.second.tag ? kv.second.tag : "?");
+    fflush(stderr);
+    if (const char *path = getenv("MIBLAST_DEBUG_GUARD_LOG")) if (FILE *f = fopen(path, "a")) {
+        fprintf(f, "[miblast guard] pid %d: ABORT (device fault?) with %zu live blocks:\n", (int)getpid(), g.live.size());
+        for (auto &kv : g.live) fprintf(f, "    %p .. end %p  %zu bytes  %s\n", kv.first, (void *)((char *)kv.first + kv.second.bytes), kv.second.bytes, kv.second.tag ? kv.second.tag : "?");
+        fclose(f);
+    }
+    signal(SIGABRT, SIG_DFL);
+    abort();
 }
 
 inline void free(void *p, const char *where = "free") {
@@ -83,7 +141,9 @@ inline void free(void *p, const char *where = "free") {
         (void)hipDeviceSynchronize();
         const long off = first_damage(p, r);
         if (off >= 0) die("overrun found on free", p, r, off, where);
+        if (r.base) { (void)hipMemUnmap(r.base, r.mapped); (void)hipMemRelease(r.handle); (void)hipMemAddressFree(r.base, r.reserved); }
         if (cur != r.device) (void)hipSetDevice(cur);
+        if (r.base) return;
     }
     (void)hipFree(p);
 }
@@ -110,7 +170,7 @@ inline void report() {
     Registry &g = registry();
     std::lock_guard<std::mutex> lk(g.mu);
     if (FILE *f = fopen(path, "a")) {
-        fprintf(f, "[miblast guard] pid %d level %d: %llu guarded allocations, %llu sweeps over the live ones, %zu live at exit, no canary damaged\n", (int)getpid(), level(), g.n_alloc,
+        fprintf(f, "[miblast guard] pid %d level %d: %llu guarded allocations, %llu sweeps over the live ones, %zu live at exit, no canary damaged, no fault\n", (int)getpid(), level(), g.n_alloc,
                 g.n_check, g.live.size());
         fclose(f);
     }

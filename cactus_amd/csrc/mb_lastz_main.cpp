@@ -47,6 +47,7 @@ int main(int argc, char **argv) {
     bool threads_given = false;
     for (int i = 1; i < argc; i++) threads_given |= !strcmp(argv[i], "--num_threads");
     if (threads_given) miblast_set_host_threads(num_threads);      // run_kegalign form: the cores the job owns
+    (void)miblast_frontend_runtime_defaults(threads_given ? num_threads : 0);      // (before the first device call: polling waits when the job owns the cores for them)
     int ndev = miblast_device_count();
     if (ndev <= 0) { fprintf(stderr, "lastz (miblast): no MI355X visible; this build has no CPU path\n"); return 3; }
     if (num_gpu > ndev) { fprintf(stderr, "lastz (miblast): --num_gpu %d but only %d visible\n", num_gpu, ndev); return 3; }

@@ -137,6 +137,7 @@ int main(int argc, char **argv) {
         if (!(native && *native && strcmp(native, "0") != 0)) delegate(argv, false);      // returns only if no other paffy exists
     }
     if (cmd == "to_bed" || cmd == "upconvert") return text_command(cmd, argc, argv);
+    (void)miblast_frontend_runtime_defaults(0);                    // (before the first device call: include/miblast.h)
     const char *input = nullptr, *output = nullptr, *prefix = "split_", *trim_identity = nullptr;
     mipaf_chain_params cp;
     mipaf_chain_params_default(&cp);

@@ -75,6 +75,8 @@ def load() -> C.CDLL:
     P = C.POINTER
     sig = {
         "miblast_params_default": (None, [P(Params)]),
+        "miblast_params_size": (C.c_size_t, []),
+        "miblast_frontend_runtime_defaults": (C.c_int, [C.c_int]),
         "miblast_params_from_argv": (C.c_int, [C.c_int, P(cp), P(Params), P(cp), P(C.c_int), P(C.c_int)]),
         "miblast_device_count": (C.c_int, []),
         "miblast_set_host_threads": (C.c_int, [C.c_int]),
@@ -114,11 +116,13 @@ def load() -> C.CDLL:
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)           # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
+    if lib.miblast_params_size() != C.sizeof(Params):       # (the struct carries no version field: this is the check instead)
+        raise MiblastError(f"miblast_params: this binding has {C.sizeof(Params)} bytes, {LIB_PATH} has {lib.miblast_params_size()}: rebuild the library or update the binding")
     _lib = lib
     return lib
 
 
-EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_from_argv", "miblast_device_count", "miblast_set_host_threads",
+EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_size", "miblast_frontend_runtime_defaults", "miblast_params_from_argv", "miblast_device_count", "miblast_set_host_threads",
                     "miblast_ctx_create", "miblast_ctx_set_priority",
                     "miblast_ctx_destroy", "miblast_seqset_from_fasta_file", "miblast_seqset_from_fasta_mem",
                     "miblast_seqset_free", "miblast_drop_derived", "miblast_seqsets_unaligned", "miblast_seqset_fasta", "miblast_seqset_n_contigs", "miblast_seqset_total", "miblast_seqset_name",

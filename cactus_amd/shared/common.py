@@ -81,6 +81,26 @@ def singularityCommand(tool=None, work_dir=None, parameters=None, port=None, fil
     return call + [tool] + list(parameters or [])
 
 
+def container_work_dir(work_dir, parameters):
+    """What the reference's prepareWorkDir does (common.py:695-730): a container only sees the ONE directory that is mounted into it
+    (/data for docker, /mnt for singularity -- the container's working directory), so (1) without a work_dir the directory is derived from
+    the arguments that name existing files or directories (their common prefix when they lie in several), falling back to the current
+    directory, and (2) every argument loses that directory prefix -- also inside an argument that carries several paths -- so that the
+    tool opens the files relative to the mount.  Returns (work_dir, rewritten parameters)."""
+    if not work_dir:
+        dirs = {os.path.dirname(par) for par in parameters if os.path.isfile(par) or os.path.isdir(par)}
+        if len(dirs) > 1:
+            work_dir = os.path.commonprefix(sorted(dirs))
+        elif dirs:
+            work_dir = dirs.pop()
+    if not work_dir:
+        work_dir = os.getcwd()
+    if work_dir == '.' or os.environ.get('CACTUS_DOCKER_MODE', 1) == "0":
+        return work_dir, list(parameters)
+    prefix = work_dir if work_dir.endswith('/') else work_dir + '/'
+    return work_dir, [par.replace(prefix, '') for par in parameters]
+
+
 def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpus=None, cpus=None, job_memory=None,
                 outappend=False, check_output=False, env=None):
     """Runs one command locally, or -- when `parameters` is a list of commands -- the commands piped into each other as the
@@ -97,8 +117,23 @@ def cactus_call(parameters, outfile=None, work_dir=None, returnStdErr=False, gpu
         image = call_env.get("CACTUS_DOCKER_IMAGE" if mode == "docker" else "CACTUS_SINGULARITY_IMG")
         if not image:
             raise RuntimeError("CACTUS_BINARIES_MODE={} needs {}".format(mode, "CACTUS_DOCKER_IMAGE" if mode == "docker" else "CACTUS_SINGULARITY_IMG"))
-        wrap = dockerCommand if mode == "docker" else singularityCommand
-        commands = [wrap(tool=image, work_dir=work_dir, parameters=c, gpus=gpus, cpus=cpus) for c in commands]
+        # ONE container per call, as in the reference (common.py:764-778): piped commands become `bash -c 'set -eo pipefail && a | b'` inside it
+        # (docker: bash as the entry point), and the arguments are rewritten relative to the mounted work directory
+        entrypoint = None
+        if len(commands) > 1:
+            import shlex
+            flat = [x for c in commands for x in c]
+            work_dir, _ = container_work_dir(work_dir, flat)
+            inner = ['bash', '-c', 'set -eo pipefail && ' + ' | '.join(' '.join(shlex.quote(x) for x in c) for c in commands)]
+            if mode == "docker":
+                entrypoint, inner = '/bin/bash', inner[1:]
+        else:
+            inner = commands[0]
+        work_dir, inner = container_work_dir(work_dir, inner)
+        if mode == "docker":
+            commands = [dockerCommand(tool=image, work_dir=work_dir, parameters=inner, gpus=gpus, cpus=cpus, entrypoint=entrypoint)]
+        else:
+            commands = [singularityCommand(tool=image, work_dir=work_dir, parameters=inner, gpus=gpus, cpus=cpus)]
     call_env["PATH"] = BIN_DIR + os.pathsep + call_env.get("PATH", "")
     stdout = subprocess.PIPE if check_output else None
     fh = None

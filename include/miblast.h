@@ -78,6 +78,17 @@ typedef struct miblast_params {
 } miblast_params;
 
 void miblast_params_default(miblast_params *p);
+/* sizeof(miblast_params) as THIS build of the library has it.  The struct has grown between rounds (18 -> 22 fields) and carries no version
+ * field: a binding checks its own struct against this once at load (cactus_amd/miblast.py does) instead of letting
+ * miblast_params_from_argv write past a shorter one.                                                                                       */
+size_t miblast_params_size(void);
+/* What the shipped front ends (bin/lastz, bin/run_kegalign, bin/paffy) call first thing in main(), BEFORE the first device call: with
+ * `threads` host threads (<= 0: the cores of the affinity mask) of 24 or more the ROCm runtime is told to poll its completion signals
+ * (HSA_ENABLE_INTERRUPT=0: ~25 us less per wait, a spinning core per waiting thread) -- bench.py's own rule -- unless the caller's
+ * environment has set the variable or MIBLAST_POLL=0.  The LIBRARY does not do this on its own any more (round 5 did, in its static
+ * constructor: a host application that merely loaded libmiblast.so got busy-spinning waits); MIBLAST_POLL=1 asks a library user's
+ * process for it explicitly.  Returns 1 when polling was switched on, else 0.                                                          */
+int miblast_frontend_runtime_defaults(int threads);
 
 /* Replaces lastz's own option parser for the argv run_lastz builds (local_alignment.py:60-68).
  * argv[0] is ignored.  On return files[0]/files[1] point INTO argv (target, query) with any

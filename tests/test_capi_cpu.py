@@ -36,6 +36,50 @@ def test_struct_layouts_match_header():
     assert C.sizeof(miblast.Stats) == 12 * 8 + 4 * 8 + 4 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 6 * 8 + 2 * 8 + 8       # + relay_accepted, relay_rejected, t_traceback_ms, t_merge_ms, dp_reruns, t_dp_busy_ms + relay_inline_checks, relay_inline_continued + seed_binned
 
 
+def test_params_struct_of_header_binding_library_and_integration_stub_agree():
+    """Round-5 review: INTEGRATION.md's stub declared 18 fields while the header had 22 -- miblast_params_from_argv would have written 16 bytes past
+    a pasted struct.  The field list of the header, of cactus_amd/miblast.py, of INTEGRATION.md's stub and sizeof(miblast_params) as the LIBRARY
+    reports it (miblast_params_size) must all agree."""
+    hdr = open(os.path.join(ROOT, "include", "miblast.h")).read()
+    body = hdr[hdr.index("typedef struct miblast_params {"):hdr.index("} miblast_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    header_fields = re.findall(r"\bint32_t\s+([a-z_0-9]+)\s*;", body)
+    binding_fields = [n for n, _ in miblast.Params._fields_]
+    assert header_fields == binding_fields and len(header_fields) == 22
+    lib = miblast.load()
+    assert lib.miblast_params_size() == C.sizeof(miblast.Params) == 4 * len(header_fields)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class MiblastParams(C.Structure):"):]
+    stub = stub[:stub.index("_lib.miblast_params_from_argv.argtypes")]
+    stub_fields = re.findall(r'"([a-z_0-9]+)"', stub[stub.index("_fields_"):stub.index(")]")])
+    assert stub_fields == header_fields, (stub_fields, header_fields)
+    assert "%d x int32" % len(header_fields) in stub and "miblast_params_size" in stub
+    # the oracle's struct is copy-compatible (tests memcpy between the two)
+    ohdr = open(os.path.join(ROOT, "oracle", "lastz_oracle.h")).read()
+    obody = re.sub(r"/\*.*?\*/", "", ohdr[ohdr.index("typedef struct"):], flags=re.S)
+    ofields = re.findall(r"\bint32_t\s+([a-z_0-9]+)\s*;", obody[:obody.index("}")])
+    assert ofields[:len(header_fields)] == header_fields
+
+
+def test_polling_is_the_front_ends_choice_not_the_librarys():
+    """loading libmiblast.so must not switch the whole process to busy-spinning waits.  The rule lives in
+    miblast_frontend_runtime_defaults (called by bin/lastz ...); the library's constructor only sets it under MIBLAST_POLL=1."""
+    code = ("import os, ctypes; os.environ.pop('HSA_ENABLE_INTERRUPT', None); os.environ.pop('MIBLAST_POLL', None); "
+            "lib = ctypes.CDLL(%r); a = os.environ.get('HSA_ENABLE_INTERRUPT'); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "before = libc.getenv(b'HSA_ENABLE_INTERRUPT'); r = lib.miblast_frontend_runtime_defaults(64); after = libc.getenv(b'HSA_ENABLE_INTERRUPT'); "
+            "r2 = lib.miblast_frontend_runtime_defaults(4); core = libc.getenv(b'HSA_DISABLE_COREDUMP_ON_EXCEPTION'); print(before, r, after, r2, core)" % miblast.LIB_PATH)
+    env = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_INTERRUPT", "MIBLAST_POLL", "HSA_DISABLE_COREDUMP_ON_EXCEPTION")}
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["None", "1", "b'0'", "0", "b'1'"], out.stdout      # (r2: a small job asks for nothing)
+    out = subprocess.run([os.sys.executable, "-c", code.replace("r = lib.miblast_frontend_runtime_defaults(64)", "r = lib.miblast_frontend_runtime_defaults(8)")],
+                         capture_output=True, text=True, env=env)
+    assert out.stdout.split() == ["None", "0", "None", "0", "b'1'"], out.stdout
+    out = subprocess.run([os.sys.executable, "-c", code.replace("os.environ.pop('MIBLAST_POLL', None); ", "")], capture_output=True, text=True, env=dict(env, MIBLAST_POLL="0"))
+    assert out.stdout.split()[:3] == ["None", "0", "None"], out.stdout
+
+
 def test_default_params_are_lastz_defaults():
     p = miblast.default_params()
     assert (p.step, p.transitions, p.xdrop, p.ydrop, p.hspthresh, p.gappedthresh, p.gap_open, p.gap_extend, p.entropy,

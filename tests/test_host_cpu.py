@@ -332,6 +332,24 @@ def test_container_modes_hand_the_gpus_over_the_amd_way(tmp_path, monkeypatch):
     env.update(CACTUS_BINARIES_MODE="singularity", CACTUS_SINGULARITY_IMG="/img/cactus.sif")
     common.cactus_call(parameters=argv, work_dir=str(tmp_path), gpus=2, env=env)
     assert '--rocm /img/cactus.sif run_kegalign' in (tmp_path / "singularity.argv").read_text()
+    # prepareWorkDir (common.py:695-730): absolute paths under the work directory are rewritten relative to the mount, also inside one argument
+    # that holds several; without a work_dir it is derived from the arguments that exist
+    (tmp_path / "A.fa").write_text(">a\nACGT\n"); (tmp_path / "sub").mkdir(); (tmp_path / "sub" / "B.fa").write_text(">b\nACGT\n")
+    wd, pars = common.container_work_dir(str(tmp_path), ['lastz', str(tmp_path / "A.fa") + '[multiple]', '%s %s' % (tmp_path / "A.fa", tmp_path / "sub" / "B.fa"), '--x'])
+    assert wd == str(tmp_path) and pars == ['lastz', 'A.fa[multiple]', 'A.fa sub/B.fa', '--x']
+    wd, pars = common.container_work_dir(None, ['paffy', 'chain', '-i', str(tmp_path / "A.fa")])
+    assert wd == str(tmp_path) and pars == ['paffy', 'chain', '-i', 'A.fa']
+    wd, pars = common.container_work_dir(None, ['faffy', str(tmp_path / "A.fa"), str(tmp_path / "sub" / "B.fa")])
+    assert wd.rstrip('/') == str(tmp_path) and pars[1:] == ['A.fa', 'sub/B.fa']
+    assert common.container_work_dir(None, ['lastz', '--help'])[0] == os.getcwd()
+    # a piped command list is ONE container running bash -c 'set -eo pipefail && a | b' (common.py:764-778), paths relative to the mount
+    env.update(CACTUS_BINARIES_MODE="docker")
+    common.cactus_call(parameters=[['paffy', 'invert', '-i', str(tmp_path / "A.fa")], ['paffy', 'chain', '--maxGapLength', '10']], work_dir=str(tmp_path), env=env)
+    seen = (tmp_path / "docker.argv").read_text()
+    assert seen.count('docker run') == 1 and '--entrypoint /bin/bash' in seen and seen.rstrip().endswith("quay.io/cactus:amd -c set -eo pipefail && paffy invert -i A.fa | paffy chain --maxGapLength 10")
+    env.update(CACTUS_BINARIES_MODE="singularity")
+    common.cactus_call(parameters=[['paffy', 'invert', '-i', str(tmp_path / "A.fa")], ['paffy', 'chain']], work_dir=str(tmp_path), env=env)
+    assert (tmp_path / "singularity.argv").read_text().rstrip().endswith("/img/cactus.sif bash -c set -eo pipefail && paffy invert -i A.fa | paffy chain")
     env.pop("CACTUS_SINGULARITY_IMG")
     with pytest.raises(RuntimeError):
         common.cactus_call(parameters=argv, work_dir=str(tmp_path), gpus=2, env=env)
