@@ -581,6 +581,8 @@ def timed_steps(work, steps, warmup, sync, gather):
     if nogc:
         gc.collect(); gc.disable()
     thr0, cpu0 = cpu_throttle_state(), time.process_time()
+    from cactus_amd import miblast as _mbl
+    allocs0 = _mbl.device_allocs()                     # hipMalloc + hipFree calls of the library so far: none are wanted inside the timed steps
     t0 = time.perf_counter()
     tot, keep = {}, None
     marks = [t0]
@@ -601,6 +603,7 @@ def timed_steps(work, steps, warmup, sync, gather):
     timed_steps.last_spread = {"min": each[0], "median": each[len(each) // 2], "max": each[-1]} if each else {}      # (of this rank)
     thr1 = cpu_throttle_state()
     tot["host_cpu_seconds"] = time.process_time() - cpu0
+    tot["device_allocs_in_timed_steps"] = _mbl.device_allocs() - allocs0
     tot["host_throttled_periods"] = thr1[0] - thr0[0]
     tot["host_throttled_ms"] = (thr1[1] - thr0[1]) / 1e3
     return elapsed, tot, keep
@@ -728,6 +731,9 @@ def run_rank(a):
             "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3 / world) / 1e9,
             "gapped_gcells_per_s_sum_of_launches": tot["dp_cells_run"] / max(1e-9, tot["t_dp_kernel_ms"] * 1e-3 / world) / 1e9,
             "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
+            # hipMalloc + hipFree calls of the library inside the timed steps, all ranks (miblast_debug_device_allocs): a device allocation in the middle
+            # of a step stalls every lane; 0 once the workspaces have met the workload in the warm-up steps
+            "device_allocs_in_timed_steps": int(tot["device_allocs_in_timed_steps"]),
             "relay": {"pieces_per_step": tot["dp_sides_run"] / per, "dp_launches_per_step": tot["dp_kernel_launches"] / per,
                       "handovers_accepted_per_step": tot["relay_accepted"] / per, "handovers_rejected_per_step": tot["relay_rejected"] / per,
                       "checked_inside_the_launch_per_step": tot["relay_inline_checks"] / per, "pieces_that_went_on_inside_per_step": tot["relay_inline_continued"] / per,
@@ -876,7 +882,7 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
     from cactus_amd import miblast as _mb
     own = _mb.Context(ctx.device)
     w = ChunkWorkload(a, own, rank, world, which)
-    steps, warm = 5, 3                                    # (three untimed steps: the lanes' buffers and the pool's trace arenas have met the heaviest pairs -- the lanes size their
+    steps, warm = 10, 3                                   # (three untimed steps: the lanes' buffers and the pool's trace arenas have met the heaviest pairs -- the lanes size their
                                                           #  buffers at the start of the second for what the first one met, the gapped stages' tables follow the groups the lanes happen to take)
     box = {}
 
@@ -906,6 +912,7 @@ def chunk_leg(a, ctx, which, rank=0, world=1, dist=None, coll_dev=None, sync=Non
            "dp_cells_per_step": tot["dp_cells"] / steps, "seed_hits_per_step": tot["seed_hits"] / steps, "alignments_per_step": tot["alignments"] / steps,
            "strands_grouped_in_lds_per_step": tot["seed_binned"] / steps,      # (mb_seed_bin.h: bins + LDS instead of the device-wide radix sort; the rest went through rocprim)
            "speculation_factor": tot["dp_cells_run"] / max(1.0, tot["dp_cells"]),
+           "device_allocs_in_timed_steps": int(tot["device_allocs_in_timed_steps"]),
            "gapped_gcells_per_s_kernel": tot["dp_cells_run"] / max(1e-9, tot["t_dp_busy_ms"] * 1e-3 / world) / 1e9,
            "stage_kernel_ms_per_step": {"ydrop": tot["t_dp_kernel_ms"] / steps, "ydrop_busy": tot["t_dp_busy_ms"] / steps, "ungapped": tot["t_ungapped_kernel_ms"] / steps,
                                         "sort": tot["t_sort_ms"] / steps, "seed_search": tot["t_seedfill_ms"] / steps,

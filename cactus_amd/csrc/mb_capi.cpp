@@ -2,6 +2,7 @@
 // escape).  There is deliberately no CPU path: without a gfx950 device every compute entry point
 // returns MIBLAST_ENODEV.
 #include "mb_pipeline.h"
+#include "mb_guard.h"
 
 #include <sched.h>
 #include <cstdio>
@@ -567,6 +568,8 @@ int miblast_build_index(miblast_ctx *ctx, const miblast_seqset *target, int32_t 
 void miblast_free(void *p) { free(p); }
 
 const char *miblast_last_error(void) { return mb::g_last_error.c_str(); }
+long long miblast_debug_device_allocs(void) { return mb::device_alloc_calls().load(); }
+
 const char *miblast_version(void) { return "miblast 0.1 (gfx950)"; }
 
 }  // extern "C"

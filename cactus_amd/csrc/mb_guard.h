@@ -21,6 +21,7 @@
 #include <signal.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,12 @@
 #include <vector>
 
 namespace mb {
+// hipMalloc / hipFree calls made by the library since the process started (every site counts itself).  Either call in the middle of a step
+// stalls every lane of a call -- hipFree waits for an idle device, and with the runtime polling the wait is 0.3 - 1 s --
+// so bench.py reads this around its timed steps: device_allocs_in_timed_steps on the line must be 0 (miblast_debug_device_allocs()).
+inline std::atomic<long long> &device_alloc_calls() { static std::atomic<long long> n{0}; return n; }
+inline void count_device_alloc() { device_alloc_calls().fetch_add(1, std::memory_order_relaxed); }
+
 namespace guard {
 
 constexpr size_t kCanary = 4096;

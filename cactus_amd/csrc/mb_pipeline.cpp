@@ -52,6 +52,7 @@ struct DevBuf {
         const double t0 = now_s();
         release();
         n = count;
+        if (count) count_device_alloc();
         if (count && guard::on()) MB_HIP(guard::alloc((void **)&p, count * sizeof(T), __PRETTY_FUNCTION__));
         else if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow device allocation: %.1f MB in %.1f ms\n", count * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
@@ -61,11 +62,12 @@ struct DevBuf {
         if (count <= n) return;
         T *old = p; const size_t old_n = n;
         p = nullptr; n = guard::on() ? count : count + count / 2;
+        count_device_alloc(); if (old) count_device_alloc();
         if (guard::on()) MB_HIP(guard::alloc((void **)&p, n * sizeof(T), __PRETTY_FUNCTION__));
         else MB_HIP(hipMalloc((void **)&p, n * sizeof(T)));
         if (old) { MB_HIP(hipMemcpy(p, old, old_n * sizeof(T), hipMemcpyDeviceToDevice)); if (guard::on()) guard::free(old, "DevBuf::ensure_keep"); else (void)hipFree(old); }
     }
-    void release() { if (p) { if (guard::on()) guard::free(p, "DevBuf::release"); else (void)hipFree(p); } p = nullptr; n = 0; }
+    void release() { if (p) count_device_alloc(); if (p) { if (guard::on()) guard::free(p, "DevBuf::release"); else (void)hipFree(p); } p = nullptr; n = 0; }
 };
 
 // pinned host staging buffer: one large device-to-host copy at link speed, no page faults
@@ -493,6 +495,7 @@ struct DeviceBlocks {
         }
         void *p = nullptr;
         cap = (bytes + 4095) & ~(size_t)4095;
+        count_device_alloc();
         MB_HIP(hipMalloc(&p, cap));
         return p;
     }
@@ -502,6 +505,7 @@ struct DeviceBlocks {
             std::lock_guard<std::mutex> lk(mu);
             if (cached + cap <= kKeep) { free_list.push_back({device, p, cap}); cached += cap; return; }
         }
+        count_device_alloc();
         (void)hipFree(p);
     }
     ~DeviceBlocks() { for (Block &b : free_list) (void)hipFree(b.p); }
@@ -685,7 +689,7 @@ struct ArenaPool {
                 free_list.erase(free_list.begin() + (long)smallest);
             }
         }
-        for (const A &a : drop) (void)hipFree(a.p);
+        for (const A &a : drop) { count_device_alloc(); (void)hipFree(a.p); }
     }
     // everything that lies free on the device back to the runtime (a stage that needs most of the device's memory for its arena)
     void trim(int device) {
@@ -695,7 +699,7 @@ struct ArenaPool {
             for (size_t i = 0; i < free_list.size();)
                 if (free_list[i].device == device) { drop.push_back(free_list[i]); free_list.erase(free_list.begin() + (long)i); } else i++;
         }
-        for (const A &a : drop) (void)hipFree(a.p);
+        for (const A &a : drop) { count_device_alloc(); (void)hipFree(a.p); }
     }
 };
 ArenaPool &arena_pool() { static ArenaPool *a = new ArenaPool(); return *a; }
@@ -2554,6 +2558,7 @@ static int acquire_trace_arena(Ctx &ctx, const miblast_params &p, std::vector<Pa
         size_t free_b = 0, total_b = 0;
         MB_HIP(hipMemGetInfo(&free_b, &total_b));
         want = std::min<size_t>(want, free_b > ((size_t)4 << 30) ? free_b - ((size_t)2 << 30) : free_b / 2);
+        count_device_alloc();
         while (hipMalloc((void **)&g.arena.p, want) != hipSuccess) {
             (void)hipGetLastError();
             g.arena.p = nullptr;
@@ -2578,12 +2583,13 @@ static int grow_trace_arena(Ctx &ctx, size_t arena_raw_estimate) {
     // (the one that was too small goes back to the pool -- or, when the larger one needs the room, to the runtime; a free one of the
     //  size wanted is taken if there is one)
     const size_t old_n = g.arena.n;
-    if (bigger + (2ull << 30) > free_b) { (void)hipFree(g.arena.p); arena_pool().trim(ctx.device); }
+    if (bigger + (2ull << 30) > free_b) { count_device_alloc(); (void)hipFree(g.arena.p); arena_pool().trim(ctx.device); }
     else arena_pool().give(ctx.device, g.arena.p, g.arena.n);
     g.arena.p = nullptr; g.arena.n = 0;
     if (!arena_pool().take(ctx.device, bigger, g.arena.p, g.arena.n) || g.arena.n < bigger) {
         arena_pool().give(ctx.device, g.arena.p, g.arena.n);
         g.arena.p = nullptr; g.arena.n = 0;
+        count_device_alloc();
         if (hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
             (void)hipGetLastError();
             g.arena.p = nullptr;

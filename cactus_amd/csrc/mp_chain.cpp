@@ -82,6 +82,7 @@ struct DevCache {
         if (best >= 0) { slots[(size_t)best].used = true; cap = slots[(size_t)best].cap; return slots[(size_t)best].p; }
         const size_t want = ((bytes + bytes / 4 + 0xffff) >> 16) << 16;
         void *p = nullptr;
+        mb::count_device_alloc();
         MB_HIP(hipMalloc(&p, want));
         slots.push_back(Slot{p, want, true});
         total += want;
@@ -98,7 +99,7 @@ struct DevCache {
     }
     void trim(size_t keep_bytes) {                            // after a job: give back what is idle beyond the budget
         for (size_t i = slots.size(); i-- > 0 && total > keep_bytes;)
-            if (!slots[i].used) { (void)hipFree(slots[i].p); total -= slots[i].cap; slots.erase(slots.begin() + (long)i); }
+            if (!slots[i].used) { mb::count_device_alloc(); (void)hipFree(slots[i].p); total -= slots[i].cap; slots.erase(slots.begin() + (long)i); }
     }
     ~DevCache() { for (Slot &s : slots) { if (mb::guard::on()) mb::guard::free(s.p, "~DevCache"); else (void)hipFree(s.p); } }
 };

@@ -112,6 +112,7 @@ def load() -> C.CDLL:
         "miblast_free": (None, [vp]),
         "miblast_last_error": (cp, []),
         "miblast_version": (cp, []),
+        "miblast_debug_device_allocs": (C.c_longlong, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)           # AttributeError here = header/library mismatch
@@ -130,7 +131,7 @@ EXPORTED_SYMBOLS = ("miblast_params_default", "miblast_params_size", "miblast_fr
                     "miblast_result_paf", "miblast_result_stats", "miblast_result_hsps", "miblast_result_alns",
                     "miblast_result_ops", "miblast_align_files", "miblast_multi_create", "miblast_multi_destroy", "miblast_multi_num_gpu",
                     "miblast_multi_align_files", "miblast_multi_align_fasta_pairs", "miblast_build_index", "miblast_free",
-                    "miblast_last_error", "miblast_version")
+                    "miblast_last_error", "miblast_version", "miblast_debug_device_allocs")
 
 
 def _check(rc: int):
@@ -162,6 +163,11 @@ def device_count() -> int:
     if n < 0:                                  # an invalid $MIBLAST_DEVICE_MAP is an error, not a shorter device list
         _check(n)
     return n
+
+
+def device_allocs() -> int:
+    """hipMalloc + hipFree calls the library has made in this process so far (miblast_debug_device_allocs)"""
+    return int(load().miblast_debug_device_allocs())
 
 
 def drop_derived() -> None:

@@ -117,10 +117,15 @@ def human_mouse(a_bases: int = 36_000_000, chunk: int = 4_500_000, seed: int = 5
          f"shuffled / partly inverted syntenic segments, conserved blocks ~37 % of the sequence at 70-92 % identity, about half soft-masked, seed {seed}; "
          f"chunkSize {chunk} + overlap {OVERLAP} (NOT the reference's chunk size: its CPU path chunks at 30 Mb, cactus_progressive_config.xml:90 -- at this scale "
          f"one chunk pair; {chunk} keeps the many-pairs shape of the real run's 104 x 91 grid, so this leg times MANY SMALL chunk pairs, not 30 Mb ones)")
-    w = ChunkedGenomePair("hm" if (a_bases, chunk, seed) == (36_000_000, 4_500_000, 5001) else f"hm_{a_bases}_{chunk}_{seed}", d, OPTIONS_DEFAULT, a, b, chunk)
+    if chunk >= 30_000_000:
+        d = d[:d.index("chunkSize")] + f"chunkSize {chunk} + overlap {OVERLAP} -- the reference's own chunk size (cactus_progressive_config.xml:90): FEW LARGE chunk pairs"
+    key = "hm" if (a_bases, chunk, seed) == (36_000_000, 4_500_000, 5001) else "hm30" if (a_bases, chunk, seed) == (36_000_000, 30_000_000, 5001) else f"hm_{a_bases}_{chunk}_{seed}"
+    w = ChunkedGenomePair(key, d, OPTIONS_DEFAULT, a, b, chunk)
     w.describe += f" -> {len(w.tfa)} x {len(w.qfa)} = {len(w.pairs)} chunk pairs, option set \"default\""
     return w
 
 
 def by_name(name: str, **kw) -> ChunkedGenomePair:
+    if name == "hm30":                                     # the same genome pair cut at the reference's chunk size: 2 x 2 chunk pairs, one of them 30 Mb x 30 Mb
+        return human_mouse(chunk=30_000_000, **kw)
     return {"chr20": chr20, "hm": human_mouse}[name](**kw)

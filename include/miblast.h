@@ -248,6 +248,10 @@ int miblast_build_index(miblast_ctx *ctx, const miblast_seqset *target, int32_t 
 void miblast_free(void *p);
 
 const char *miblast_last_error(void);
+/* Diagnostics: hipMalloc + hipFree calls the library has made in this process so far.  A device allocation in the middle of a job stalls every
+ * concurrent job on the device (hipFree waits for an idle device); bench.py reads this around its timed steps and reports the difference as
+ * device_allocs_in_timed_steps, which is 0 once the workspaces have met the workload.                                                  */
+long long miblast_debug_device_allocs(void);
 const char *miblast_version(void);
 
 #ifdef __cplusplus
