@@ -182,3 +182,14 @@ def test_full_size_chr20_dealt_as_strand_halves_equals_the_digests():
     assert out["config"]["work_unit"] == "(chunk pair, query strand)" and out["config"]["units_per_rank"] == [18]
     assert out["parity"]["same_bytes"] is True and out["parity"]["pairs_checked"] == 9
     assert out["dp_cells_per_step"] == out["parity"]["oracle_dp_cells"] and out["seed_hits_per_step"] == out["parity"]["oracle_seed_hits"]
+
+
+def test_human_mouse_stand_in_at_the_reference_chunk_size_equals_the_digests():
+    """BASELINE configs[4] at the reference's own chunk size (cactus_progressive_config.xml:90 chunkSize 30 Mb): the stand-in genome pair cut
+    into 2 chunk pairs, one of them 32.6 Mb x 32.0 Mb under the DEFAULT option set (step 1, 13 word variants: 854 million seed hits, several
+    q batches per strand) -- both pairs' PAFs equal the CPU oracle's digests (tests/golden/hm30_pairs.json: one oracle run of 610 s), hits and
+    cells counted as the oracle counts them."""
+    out = _bench(["--workload", "hm30", "--steps", "1", "--warmup", "0", "--seed-leg", "0", "--chain-leg", "0", "--batch-leg", "0", "--cpu-sample", "0"])
+    assert "chunkSize 30000000" in out["config"]["workload"] and out["config"]["units_per_rank"] == [2]
+    assert out["parity"]["same_bytes"] is True and out["parity"]["pairs_checked"] == 2 and out["parity"]["pairs_differing"] == 0
+    assert out["dp_cells_per_step"] == out["parity"]["oracle_dp_cells"] and out["seed_hits_per_step"] == out["parity"]["oracle_seed_hits"] > 9e8
