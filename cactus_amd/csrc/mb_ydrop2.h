@@ -81,9 +81,12 @@ static __device__ __forceinline__ void ydrop2_piece(const DpProb *__restrict__ p
     const int64_t t0 = pr.t0, q0 = pr.q0;
     const int row_lo = pr.row_lo;
     const long long clk0 = yd_clock();
-    // the piece's own snapshot slots start out invalid (nothing reads them before this launch is over: the hand-over checks and the
-    // continuations that start from them come after it in stream order)
-    if (pr.snap_idx >= 0 && lane < kSnapSlots) ((SnapHdr *)(snaps + (size_t)(pr.snap_idx + lane) * kSnapBytes))->valid = 0;
+    // the piece's own snapshot slots start out invalid.  Since the hand-over moved into the launch, pieces of the SAME launch read these headers
+    // (the upstream piece that is aimed at this one looks at its entry snapshots): what such a reader trusts is the `stamp`, unique per round
+    // and written last by the snapshot's writer -- a slot that still carries an older round's stamp (or none) is "not there yet" whatever its
+    // `valid` says -- so this store decides nothing inside the launch; it is an agent-scope store like every other write to a header, for the
+    // readers that come after the launch in stream order (k_verify, continuations) and so that no header field is ever written two ways.
+    if (pr.snap_idx >= 0 && lane < kSnapSlots) yd_st_agent(&((SnapHdr *)(snaps + (size_t)(pr.snap_idx + lane) * kSnapBytes))->valid, 0);
     const int OE = O + E;
     int overflow = 0;
     int R0 = 0;

@@ -15,9 +15,9 @@ cannot cover -- the GPU box has no /root/reference, a deployment has no Toil sta
     chain_alignments, chain_tile_trim_filter_one_contig  :607-727  paffy chain | tile | trim | filter
 
 faffy / paffy's text steps are cactus_amd.paf.chunking (or the native text code behind bin/faffy, bin/paffy); the chaining stage's
-`paffy` is <repo>/bin/paffy.  trim_unaligned_sequences (:861-904) has no mirror: its three tools are bin/paffy to_bed, bin/faffy
-extract, bin/paffy upconvert, driven by the reference's own body in the CPU suite and by cactus_amd.paf.chunking.trim_to_aligned in
-process.  cactus_consolidated and everything after it are untouched.
+`paffy` is <repo>/bin/paffy.  trim_unaligned_sequences (:861-904) is at the end of this file: the three tools of its body are bin/paffy
+to_bed, bin/faffy extract, bin/paffy upconvert (the reference's own body drives them in the CPU suite; cactus_amd.paf.chunking.trim_to_aligned
+is the same on text in process).  cactus_consolidated and everything after it are untouched.
 """
 from __future__ import annotations
 
@@ -330,3 +330,30 @@ def merge_processed_alignments(job, processed_file_ids):
     final = os.path.join(job.fileStore.getLocalTempDir(), 'final.paf')
     concat_global_files(job, processed_file_ids, final)
     return job.fileStore.writeGlobalFile(final)
+
+
+# ---- the genomes cut down to what is aligned (:861-904; cactus_progressive.py:182 calls it when outgroups are trimmed for the next node) -------
+def trim_unaligned_sequences(job, sequences, alignments, params, has_resources=False):
+    """-> ([trimmed sequence file ids], trimmed alignment file id).  Without resources of its own the job re-issues itself as a child with
+    disk / memory for `paffy to_bed --includeInverted`'s two bytes per base of every sequence plus the alignments (:865-869)."""
+    if not has_resources:
+        need = 4 * sum(seq.size for seq in sequences) + 2 * alignments.size
+        return job.addChildJobFn(trim_unaligned_sequences, sequences, alignments, params, has_resources=True,
+                                 disk=need, memory=cactus_clamp_memory(need)).rv()
+    scratch = job.fileStore.getLocalTempDir()
+    paf = os.path.join(scratch, 'alignments.paf')
+    job.fileStore.readGlobalFile(alignments, paf)
+    log = ["--logLevel", getLogLevelString()]
+    bed = paf + '.bed'                                     # what the alignments cover, either side (binary: covered or not)
+    cactus_call(parameters=['paffy', 'to_bed', "--binary", "--excludeUnaligned", "--includeInverted", '-i', paf] + log,
+                outfile=bed, returnStdErr=True, job_memory=job.memory)
+    flank = _blast(params).attrib["trimOutgroupFlanking"]
+    kept = []
+    for k, sequence in enumerate(sequences):               # every genome reduced to the covered stretches (+ flank), sub-sequence names NAME|LEN|START
+        fasta = os.path.join(scratch, '{}.fa'.format(k))
+        job.fileStore.readGlobalFile(sequence, fasta)
+        cactus_call(parameters=['faffy', 'extract', "-i", bed, fasta, "--skipMissing", "--minSize", "1", "--flank", flank] + log,
+                    outfile=fasta + '.trim', returnStdErr=True, job_memory=job.memory)
+        kept.append(fasta + '.trim')
+    cactus_call(parameters=['paffy', 'upconvert', "-i", paf] + log + kept, outfile=paf + '.trim', returnStdErr=True)     # the alignments in the reduced sequences' coordinates
+    return [job.fileStore.writeGlobalFile(f) for f in kept], job.fileStore.writeGlobalFile(paf + '.trim')

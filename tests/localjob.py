@@ -69,8 +69,10 @@ class LocalJob:
         self.fileStore = fileStore or LocalFileStore()
         self.cores = cores
         self.memory = memory
+        self.children = []                     # what was asked for every child / follow-on job: {"fn", "cores", "memory", "disk", "accelerators"}
 
     def addChildJobFn(self, fn, *args, cores=None, memory=None, disk=None, accelerators=None, **kw):
+        self.__dict__.setdefault("children", []).append({"fn": fn, "cores": cores, "memory": memory, "disk": disk, "accelerators": accelerators})
         child = LocalJob(self.fileStore, cores or self.cores, memory or self.memory)
         return _Promise(fn(child, *args, **kw))
 

@@ -160,3 +160,30 @@ def test_reference_trim_unaligned_sequences(ref, tmp_path):
     sections = want.split("== ")
     assert [open(str(s)).read() for s in seqs] == [s.split("\n", 1)[1] for s in sections if s.startswith("file ")]
     assert open(str(out)).read() == [s.split("\n", 1)[1] for s in sections if s.startswith("paf")][0]
+
+
+def test_mirror_trim_unaligned_sequences_equals_the_reference_job(ref, tmp_path):
+    """cactus_amd.paf.local_alignment.trim_unaligned_sequences (the job a deployment without /root/reference runs) gives the files the
+    reference's own body gives over the same front ends, and without resources of its own it re-issues itself as a child job with the
+    reference's disk / memory request (local_alignment.py:865-869)."""
+    from cactus_amd.paf import local_alignment as mirror
+    from test_text_oracle_cpu import two_genome_case
+    files, paf = two_genome_case(5)
+    cfg = params(trimOutgroupFlanking=30)
+    results = []
+    for fn in (ref.trim_unaligned_sequences, mirror.trim_unaligned_sequences):
+        job = LocalJob()
+        ids = []
+        for k, recs in enumerate(files):
+            p = tmp_path / f"h{k}.fa"
+            p.write_bytes(gen.fasta_bytes(recs))
+            ids.append(job.fileStore.writeGlobalFile(str(p)))
+        (tmp_path / "b.paf").write_text(paf)
+        seqs, out = fn(job, ids, job.fileStore.writeGlobalFile(str(tmp_path / "b.paf")), cfg, has_resources=fn is ref.trim_unaligned_sequences)
+        results.append(([open(str(s)).read() for s in seqs], open(str(out)).read()))
+        if fn is mirror.trim_unaligned_sequences:                      # (went through the child job: LocalJob records what was asked for)
+            asked = job.children[-1]
+            size = sum(i.size for i in ids)
+            assert asked["fn"] is mirror.trim_unaligned_sequences and asked["disk"] == 4 * size + 2 * os.path.getsize(str(tmp_path / "b.paf"))
+            assert asked["memory"] == max(2 ** 28, asked["disk"])
+    assert results[0] == results[1] and len(results[0][0]) == len(files) and results[0][1].count("\n") > 3
