@@ -9,7 +9,7 @@
 //   MIBLAST_DEBUG_GUARD=2   as 1, and the block itself starts as 0xCD bytes: state that a kernel reads before anything wrote it shows as
 //                           wild indices / scores at once instead of as whatever a recycled page held.
 //   MIBLAST_DEBUG_GUARD=3   an electric fence: the block is mapped with the virtual-memory calls (hipMemAddressReserve / hipMemCreate / hipMemMap) so
-//                           that its last byte (rounded up to 16) is the LAST MAPPED byte -- the address range behind it is reserved and never mapped.
+//                           that its last byte (rounded up to 256, hipMalloc's alignment; MIBLAST_DEBUG_GUARD_ALIGN) is the LAST MAPPED byte -- the address range behind it is reserved and never mapped.
 //                           A kernel that READS or writes one element past what the host sized faults at once, on every run, instead of on the
 //                           run whose layout puts an unmapped page there (round 5's GPUTEST fault was of that kind: not reproduced in 400 runs
 //                           of the same command).  The runtime then names the address; the SIGABRT handler of this mode prints the table of live
@@ -83,7 +83,10 @@ inline hipError_t fenced(void **out, size_t bytes, Rec &r) {
     hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
     if (e != hipSuccess) return e;
     if (gran < 4096) gran = 4096;
-    const size_t user = (bytes + 15) & ~(size_t)15;          // (16-byte loads and stores stay aligned: an overrun of less than that many bytes goes unseen)
+    // the block's start keeps the alignment hipMalloc gives every block (256 bytes: rocprim lays its temporary storage out from it, kernels
+    // load 16 bytes at a time): an overrun of fewer bytes than the padding this costs goes unseen -- MIBLAST_DEBUG_GUARD_ALIGN=16 narrows it
+    static const size_t align = [] { const char *v = getenv("MIBLAST_DEBUG_GUARD_ALIGN"); const long a = v && *v ? atol(v) : 256; return (size_t)(a >= 4 && (a & (a - 1)) == 0 ? a : 256); }();
+    const size_t user = (bytes + align - 1) & ~(align - 1);
     r.mapped = (user + gran - 1) / gran * gran;
     if (r.mapped == 0) r.mapped = gran;
     r.reserved = r.mapped + gran;
@@ -103,7 +106,10 @@ inline hipError_t alloc(void **out, size_t bytes, const char *tag) {
     void *p = nullptr;
     int dev = 0; (void)hipGetDevice(&dev);
     Rec r{bytes, tag, dev};
-    if (level() >= 3) {
+    // MIBLAST_DEBUG_GUARD_ONLY=<text>: only the blocks whose tag contains <text> get the fence, the others a canary (to find WHICH block a
+    // kernel overruns when the runtime's fault report names no usable address)
+    static const char *only = getenv("MIBLAST_DEBUG_GUARD_ONLY");
+    if (level() >= 3 && (!only || !*only || (tag && strstr(tag, only)))) {
         static const bool handler = [] { signal(SIGABRT, dump_live); return true; }();
         (void)handler;
         hipError_t e = fenced(&p, bytes, r);

@@ -57,9 +57,26 @@ struct DevBuf {
         else if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow device allocation: %.1f MB in %.1f ms\n", count * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
     }
-    void ensure(size_t count) { if (count > n) alloc(guard::on() ? count : count + count / 4); }       // (guard mode: exactly what was asked for, a canary behind it)
+    // hw: a high-water mark shared by the same buffer of every lane of a context (Workspace::gapped_hw).  Which lane meets the heaviest group of
+    // pairs changes from call to call, and a lane that grew its tables in the middle of a later step stalled every lane (a device allocation beside
+    // busy lanes: DESIGN.md section 6); with the mark a buffer that has to grow goes straight to the largest size any lane has needed, and
+    // presize() -- at a lane's start, before it takes a pair -- brings it there without waiting for the need.
+    std::atomic<size_t> *hw = nullptr;
+    size_t marked(size_t count) {
+        if (!hw) return count;
+        size_t seen = hw->load(std::memory_order_relaxed);
+        while (seen < count && !hw->compare_exchange_weak(seen, count, std::memory_order_relaxed)) {}
+        return std::max(count, seen);
+    }
+    void ensure(size_t count) {
+        if (count <= n) { (void)marked(count); return; }
+        count = marked(count);
+        alloc(guard::on() ? count : count + count / 4);
+    }
+    void presize() { if (hw && hw->load(std::memory_order_relaxed) > n) { const size_t c = hw->load(std::memory_order_relaxed); alloc(guard::on() ? c : c + c / 4); } }
     void ensure_keep(size_t count) {              // grow without losing the contents
-        if (count <= n) return;
+        if (count <= n) { (void)marked(count); return; }
+        count = marked(count);
         T *old = p; const size_t old_n = n;
         p = nullptr; n = guard::on() ? count : count + count / 2;
         count_device_alloc(); if (old) count_device_alloc();
@@ -79,7 +96,13 @@ struct PinBuf {
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
     ~PinBuf() { release(); }
+    std::atomic<size_t> *hw = nullptr;           // (as DevBuf::hw: pinned allocations beside busy lanes stall as well)
     void ensure(size_t count) {
+        if (hw) {
+            size_t seen = hw->load(std::memory_order_relaxed);
+            while (seen < count && !hw->compare_exchange_weak(seen, count, std::memory_order_relaxed)) {}
+            if (count > n) count = std::max(count, seen);
+        }
         if (count <= n) return;
         const double t0 = now_s();
         release();
@@ -87,6 +110,7 @@ struct PinBuf {
         MB_HIP(hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow pinned allocation: %.1f MB in %.1f ms\n", n * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
     }
+    void presize() { if (hw && hw->load(std::memory_order_relaxed) > n) ensure(hw->load(std::memory_order_relaxed)); }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
 };
 
@@ -780,6 +804,17 @@ struct Workspace {                      // device buffers that persist across mi
     // batched calls: extra lanes (own stream, events and seed-stage buffers) so that the seed stages of several pairs are on
     // the device at the same time
     std::vector<Ctx *> lanes;
+    // (of a context's own workspace) high-water marks of the gapped stage's tables over all lanes: DevBuf::hw of the lanes' buffers point here
+    std::atomic<size_t> gapped_hw[16] = {};
+    void share_marks(Workspace &owner) {
+        std::atomic<size_t> *m = owner.gapped_hw;
+        probs.hw = m + 0; outs.hw = m + 1; dp_order.hw = m + 2; rowdir.hw = m + 3; ops.hw = m + 4; ops_packed.hw = m + 5; coff.hw = m + 6; tb_blk.hw = m + 7;
+        recs.hw = m + 8; snaps.hw = m + 9; dp_up.hw = m + 10; dp_down.hw = m + 11; round_tab.hw = m + 12; hops.hw = m + 13; grows.hw = m + 14;
+    }
+    void presize_gapped() {
+        probs.presize(); outs.presize(); dp_order.presize(); rowdir.presize(); ops.presize(); ops_packed.presize(); coff.presize(); tb_blk.presize();
+        recs.presize(); snaps.presize(); dp_up.presize(); dp_down.presize(); round_tab.presize(); hops.presize(); grows.presize();
+    }
 };
 
 Workspace *workspace_create() { return new Workspace(); }
@@ -823,7 +858,7 @@ void ctx_pair_streams(Ctx &ctx) {
     MB_HIP(hipSetDevice(ctx.device));
     Workspace &w = *ctx.ws;
     const size_t gapped_lanes = (size_t)std::min<long>(8, std::max(1l, env_long("MIBLAST_GAPPED_LANES", 2)));
-    while (w.lanes.size() + 1 < gapped_lanes) w.lanes.push_back(lane_create(ctx.device, ctx.priority));
+    while (w.lanes.size() + 1 < gapped_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); }
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     for (Ctx *l : w.lanes) MB_HIP(hipEventRecord(l->ev0, l->stream));
     MB_HIP(hipStreamSynchronize(ctx.stream));
@@ -3772,6 +3807,7 @@ static void output_layout(const miblast_params &p, PairJob &job, OutputJob &oj) 
 static void presize_lane(Ctx &lc, int64_t max_diags) {
     if (!lc.hits_hint) return;
     Workspace &w = *lc.ws;
+    w.presize_gapped();                                    // the gapped stage's tables at the largest size any lane of the context has needed
     const unsigned long long hint = lc.hits_hint->load(std::memory_order_relaxed);
     const int64_t hit_cap = getenv("MIBLAST_HIT_CAP") ? env_long("MIBLAST_HIT_CAP", 32l << 20) : env_long("MIBLAST_DENSE_HIT_CAP", 128l << 20);
     if (hint == 0 || 2 * (hint + hint / 8) > (unsigned long long)hit_cap) return;
@@ -3792,6 +3828,7 @@ static void presize_lane(Ctx &lc, int64_t max_diags) {
 static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *const *Qs, size_t n, const miblast_params &pin, Result **results) {
     const double t_call0 = now_s();
     MB_HIP(hipSetDevice(ctx.device));
+    ctx.ws->share_marks(*ctx.ws);                          // (the context's own tables take part in its lanes' high-water marks)
     Pool::Hot keep_workers_awake;
     ctx.ws->stage.abort();
     for (Ctx *lane : ctx.ws->lanes) lane->ws->stage.abort();
@@ -3866,8 +3903,8 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         // lane runs the device half of a pair's seed stage, then the host half (discovery order, entropy filter, anchors)
         // while the other lanes keep the device busy.  A pair's result does not depend on its lane.
         Workspace &w = *ctx.ws;
-        while (w.lanes.size() < n_lanes) w.lanes.push_back(lane_create(ctx.device, ctx.priority));
-        for (Ctx *l : w.lanes) { l->spans = ctx.spans; l->hits_hint = &w.hits_hint; }
+        while (w.lanes.size() < n_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); }
+        for (Ctx *l : w.lanes) { l->spans = ctx.spans; l->hits_hint = &w.hits_hint; l->ws->share_marks(w); }
         int64_t max_diags = 0;
         for (size_t k = 0; k < n; k++) max_diags = std::max<int64_t>(max_diags, Ts[k]->total + Qs[k]->total);
         std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
@@ -4022,7 +4059,7 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         for (Unit &u : units) gunits[group_of[(size_t)u.pair]].push_back(std::move(u));
         units.clear();
         Workspace &w0 = *ctx.ws;
-        while (w0.lanes.size() + 1 < L) w0.lanes.push_back(lane_create(ctx.device, ctx.priority));
+        while (w0.lanes.size() + 1 < L) { w0.lanes.push_back(lane_create(ctx.device, ctx.priority)); w0.lanes.back()->ws->share_marks(w0); }
         for (Ctx *l : w0.lanes) l->spans = ctx.spans;
         std::vector<PairPtrs> pp(n);
         for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }
