@@ -162,6 +162,11 @@ struct UxScratch {                            // device scratch of one launch_un
     // what a launch zeroes first: the two bit planes lie one behind the other from long_bits on, the counters (n_entries, blk_cnt) from
     // n_entries on; byte counts in multiples of 16 (a fill of any other size is two launches)
     unsigned long long zero_bits_bytes, zero_cnt_bytes;
+    // level 1 of k_ux_extend from the packed strands of the launch's ONE unit (mb_ungapped_ux.h, round 6): the extension's 12-byte records
+    // (32 bases: 2-bit codes + a flag per base that is N or a separator) of the target and of the searched query strand; t_n / q_n = bases.
+    // Null / 0: windows from the code bytes.
+    const uint32_t *t_px, *q_px;
+    long long t_n, q_n;
 };
 inline size_t up16(size_t bytes) { return (bytes + 15) & ~(size_t)15; }
 
@@ -217,7 +222,9 @@ void launch_index_clear(const uint32_t *words, int64_t n_slots, uint32_t *cursor
 // ---- seed stage of a large pair (mb_seed_dense.h) ----
 inline size_t packed_wordsm(int64_t n) { return (size_t)((n + 63) / 64 + 2); }      // u64 words of the mask plane of n bases (k_pack2bit_mask runs one thread per word)
 inline size_t packed_words2(int64_t n) { return 2 * packed_wordsm(n); }              // ... of the 2-bit plane: every thread stores the two words of its 64 bases, the padding words included
-void launch_pack2bit(const uint8_t *codes, int64_t n, unsigned long long *p2, unsigned long long *pm, hipStream_t s);
+inline size_t packed_dwordsx(int64_t n) { return 6 * packed_wordsm(n); }             // ... of the ungapped extension's records (12 bytes per 32 bases: mb_ungapped_ux.h)
+void launch_pack2bit(const uint8_t *codes, int64_t n, unsigned long long *p2, unsigned long long *pm, hipStream_t s,
+                     uint32_t *px = nullptr);                           // px (packed_dwordsx(n) dwords): the ungapped extension's records as well
 void launch_index_words_packed(const unsigned long long *p2, const unsigned long long *pm, int64_t n, int step, int64_t first, uint32_t *words, int64_t n_slots,
                                uint32_t *counts, hipStream_t s);
 int64_t seed_ord_state_words(int64_t qtot);

@@ -104,9 +104,9 @@ void launch_revcomp_sets(const RcItem *items, int n_items, int64_t grid_bytes, u
 // ---- the seed stage of a large pair: packed strands, q-ordered one-pass search, scrambled diagonals (mb_seed_dense.h) ------------
 #include "mb_seed_dense.h"
 
-void launch_pack2bit(const uint8_t *codes, int64_t n, unsigned long long *p2, unsigned long long *pm, hipStream_t s) {
+void launch_pack2bit(const uint8_t *codes, int64_t n, unsigned long long *p2, unsigned long long *pm, hipStream_t s, uint32_t *px) {
     const int64_t nm = (int64_t)packed_wordsm(n);
-    hipLaunchKernelGGL(k_pack2bit_mask, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, codes, n, p2, pm, nm);
+    hipLaunchKernelGGL(k_pack2bit_mask, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, codes, n, p2, pm, nm, px);
 }
 
 void launch_index_words_packed(const unsigned long long *p2, const unsigned long long *pm, int64_t n, int step, int64_t first, uint32_t *words, int64_t n_slots,
@@ -320,6 +320,11 @@ void launch_ungapped(const unsigned long long *keys, int64_t n_hits, unsigned *h
         sc.extent = extent; sc.extent_live = extent_clean ? 0 : 1;
         ux = &sc;
         hipLaunchKernelGGL(k_ux_mark_long, dim3((unsigned)((max_long + 255) / 256)), dim3(256), 0, s, keys, heads_long, n_heads + kRunClasses, *ux);
+        // level 1 from the packed strands when the caller has them (one unit: the dense path of a large pair): mb_ungapped_ux.h
+        if (ux->t_px && ux->q_px && ut.n <= 1)
+            hipLaunchKernelGGL(k_ux_extend_pk, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, ut,
+                               xdrop, K, *ux, hsps, hsp_cap, ctr);
+        else
         hipLaunchKernelGGL(k_ux_extend, dim3((unsigned)((n_hits + ux::kBlock - 1) / ux::kBlock)), dim3(ux::kBlock), 0, s, keys, n_hits, ut,
                            xdrop, K, *ux, hsps, hsp_cap, ctr);
         const unsigned tail_blocks = (unsigned)std::min<int64_t>(2048, ((int64_t)ux->entry_cap + 2 * (int64_t)ux->n_blk + 31) / 32);

@@ -736,7 +736,7 @@ struct SeedTable {
     int step = 0; int64_t first = 0, n_slots = 0; uint32_t n_positions = 0;
     PoolBuf<uint32_t> offsets, occ, positions;
 };
-struct PackedStrand { PoolBuf<unsigned long long> p2, pm; bool ready = false; };
+struct PackedStrand { PoolBuf<unsigned long long> p2, pm; PoolBuf<uint32_t> px; bool ready = false; };      // px: the ungapped extension's records (mb_ungapped_ux.h)
 
 struct Workspace {                      // device buffers that persist across miblast_align() calls of one context
     // seed position table
@@ -1082,6 +1082,7 @@ struct SetDerived {
     PoolBuf<uint8_t> d_rc;                          // '-' strand, kDevPad separator bytes either side
     PoolPin<uint8_t> h_rc;                          // ... and its host copy ([SEP] codes [SEP])
     PackedStrand packed[2];
+    PackedStrand packed_t;                          // the set as a TARGET: its '+' strand packed for the ungapped extension's windows
 };
 namespace {
 struct DerivedCache {
@@ -1114,8 +1115,8 @@ void drop_derived() {
 
 // the packed form (2 bits + 1 mask bit per base, mb_seed_dense.h) of n code bytes
 static void pack_strand(const uint8_t *codes, int64_t n, PackedStrand &ps, hipStream_t s) {
-    ps.p2.ensure(packed_words2(n)); ps.pm.ensure(packed_wordsm(n));
-    launch_pack2bit(codes, n, ps.p2.p, ps.pm.p, s);
+    ps.p2.ensure(packed_words2(n)); ps.pm.ensure(packed_wordsm(n)); ps.px.ensure(packed_dwordsx(n));
+    launch_pack2bit(codes, n, ps.p2.p, ps.pm.p, s, ps.px.p);
     ps.ready = true;
 }
 
@@ -1209,6 +1210,18 @@ static std::shared_ptr<SetDerived> acquire_strands(Ctx &ctx, const SeqSet &Q, bo
         if (!d->packed[1].ready) { pack_strand(d->d_rc.p + kDevPad, qtot, d->packed[1], s); queued = true; }
     }
     if (queued) MB_HIP(hipStreamSynchronize(s));                        // (complete before another lane's stream reads them)
+    return d;
+}
+
+// the packed form of a target (the seed stage's planes + the ungapped extension's records): resident with the set like its seed table, for the windows of the
+// ungapped extension (k_ux_extend_pk).  0.375 B per base.
+static std::shared_ptr<SetDerived> acquire_packed_target(Ctx &ctx, const SeqSet &T) {
+    std::shared_ptr<SetDerived> d = derived_of(T);
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (!d->packed_t.ready && T.total > 0) {
+        pack_strand(T.dev(), T.total, d->packed_t, ctx.stream);
+        MB_HIP(hipStreamSynchronize(ctx.stream));                       // (complete before another lane's stream reads it)
+    }
     return d;
 }
 
@@ -1335,6 +1348,7 @@ struct PairJob {                          // one chunk pair of a (possibly batch
     double t_begin = 0;
     std::shared_ptr<SeedTable> table;     // the target's seed table and the query's derived strands, held for the call (seed_phase)
     std::shared_ptr<SetDerived> strands;
+    std::shared_ptr<SetDerived> target_packed;        // the target's packed form (k_ux_extend_pk), kept alive for the length of the job
 };
 
 // a launch of the ungapped kernels over ONE seed unit: a strand of a pair (the table lives in the kernel arguments)
@@ -1366,6 +1380,7 @@ static UxScratch ux_scratch(Workspace &w, unsigned long long *rec, size_t nh, in
     sc.long_bits = w.ux_bits.p; sc.dirty_bits = w.ux_bits.p + plane;
     sc.dirty_runs = (unsigned *)w.ux_entries.p; sc.dirty_cap = (unsigned)std::min<size_t>((blk_slots + cap) * (sizeof(UxEntry) / sizeof(unsigned)), 0x7fffffffu);
     sc.extent = nullptr; sc.extent_live = 1;
+    sc.t_px = sc.q_px = nullptr; sc.t_n = sc.q_n = 0;
     return sc;
 }
 
@@ -1528,6 +1543,16 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     const bool packed = ordered && (packed_mode == 2 || (packed_mode == 1 && qtot >= (1 << 16)));
     job.strands = acquire_strands(ctx, Q, packed);
     const SetDerived &qs = *job.strands;
+    // level 1 of the ungapped extension from the packed strands (mb_ungapped_ux.h, round 6): the target's packed form stays resident with it as
+    // its table does; MIBLAST_UX_PACKED=0: windows from the code bytes as before (A/B switch; 2: also below the size that packs the query)
+    const long ux_packed_mode = env_long("MIBLAST_UX_PACKED", 1);
+    const bool ux_packed = packed && ux_packed_mode != 0 && (ux_packed_mode == 2 || ttot >= (1 << 16));
+    if (ux_packed) job.target_packed = acquire_packed_target(ctx, T);
+    auto ux_windows = [&](UxScratch &sc, int strand) {
+        if (!ux_packed || !job.target_packed || !job.target_packed->packed_t.ready || !qs.packed[strand].ready) return;
+        sc.t_px = job.target_packed->packed_t.px.p; sc.t_n = ttot;
+        sc.q_px = qs.packed[strand].px.p; sc.q_n = qtot;
+    };
     job.tc_h = T.host(); job.qc_h[0] = Q.host(); job.qc_h[1] = qs.h_rc.p + 1;
     job.qc_d[0] = Q.dev(); job.qc_d[1] = qs.d_rc.p + kDevPad;
     const uint8_t *const *qc_d = job.qc_d;
@@ -1666,7 +1691,8 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     //  memory that queued kernels still use; the strand's unsorted keys are free after its sort and hold the records)
                     const uint32_t pmul = ordered ? hmul : 1u;                   // (the sorted keys follow the scrambled diagonals)
                     if (strand == 0 || !fits[0] || !nh[0]) (void)ux_scratch(w, nullptr, (size_t)nh_max, ttot + qtot + 2, pmul, hmask);
-                    const UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2, pmul, hmask);
+                    UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2, pmul, hmask);
+                    ux_windows(uxs, strand);
                     launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, nullptr, p.xdrop, p.hspthresh,
                                     d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, &uxs, true, s);
                     MB_HIP(hipEventRecord(w.sev[strand][5], s));
@@ -1736,7 +1762,8 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev2, s));
             MB_HIP(hipMemsetAsync(d_ctr.p, 0, up16(sizeof(UngappedCounters)), s));
             MB_HIP(hipEventRecord(ctx.ev3, s));
-            const UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2, hashed ? hmul : 1u, hmask);               // (the unsorted keys are free now)
+            UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2, hashed ? hmul : 1u, hmask);               // (the unsorted keys are free now)
+            ux_windows(uxs, strand);
             launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, ext_p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, &uxs, found.empty() && strand_hits[strand] == nh, s);     // (extent[] is all zero in the first batch only)
             MB_HIP(hipEventRecord(ctx.ev4, s));

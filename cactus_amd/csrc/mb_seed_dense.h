@@ -26,12 +26,15 @@
 // separator, beyond the end).  Both arrays hold two words more than the bases need (a window reads word w and w + 1).
 // (packed_words2 / packed_wordsm: mb_common.h)
 
+// px (optional): the ungapped extension's form of the strand (mb_ungapped_ux.h) -- per 32 bases a 12-byte record {low, high dword of the 2-bit
+// word, one flag per base (bit 31 - k) that is set when the base is an N / IUPAC code or a separator (or lies beyond the end)}: what the
+// extension cannot score from two bits; a soft-masked base is NOT flagged (it extends like any other base).
 __global__ __launch_bounds__(256) void k_pack2bit_mask(const uint8_t *__restrict__ codes, const int64_t n, unsigned long long *__restrict__ p2,
-                                                        unsigned long long *__restrict__ pm, const int64_t n_words_m) {
+                                                        unsigned long long *__restrict__ pm, const int64_t n_words_m, uint32_t *__restrict__ px) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // mask word = 64 bases = two 2-bit words
     if (w >= n_words_m) return;
     const int64_t i0 = w * 64;
-    unsigned long long a = 0, b = 0, m = 0;
+    unsigned long long a = 0, b = 0, m = 0, sp = 0;
     if (i0 + 64 <= n) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -44,6 +47,7 @@ __global__ __launch_bounds__(256) void k_pack2bit_mask(const uint8_t *__restrict
                 const unsigned long long two = (unsigned long long)(c & 3u);
                 if (i < 32) a |= two << (62 - 2 * i); else b |= two << (62 - 2 * (i - 32));
                 m |= (unsigned long long)((c & 0xFCu) != 0u) << (63 - i);
+                sp |= (unsigned long long)((c & 0x84u) != 0u) << (63 - i);
             }
         }
     } else {
@@ -52,9 +56,15 @@ __global__ __launch_bounds__(256) void k_pack2bit_mask(const uint8_t *__restrict
             const unsigned long long two = (unsigned long long)(c & 3u);
             if (i < 32) a |= two << (62 - 2 * i); else b |= two << (62 - 2 * (i - 32));
             m |= (unsigned long long)((c & 0xFCu) != 0u) << (63 - i);
+            sp |= (unsigned long long)((c & 0x84u) != 0u) << (63 - i);
         }
     }
     p2[2 * w] = a; p2[2 * w + 1] = b; pm[w] = m;
+    if (px) {
+        uint32_t *r = px + 6 * w;
+        r[0] = (uint32_t)a; r[1] = (uint32_t)(a >> 32); r[2] = (uint32_t)(sp >> 32);
+        r[3] = (uint32_t)b; r[4] = (uint32_t)(b >> 32); r[5] = (uint32_t)sp;
+    }
 }
 
 // the seed word of the window at p (12 of 19, first care base most significant) and whether all 19 bases may be seeded

@@ -102,6 +102,57 @@ __device__ __forceinline__ void load_right2(const uint8_t *p_end, const int j, u
     c_even = v.lo; c_odd = v.hi;
 }
 
+// ---- level 1 from the PACKED strands (round 6) ------------------------------------------------------------------------------------
+// The windows of a hit -- 48 columns to the left of the seed end, 32 to the right, in both sequences -- are 160 random bytes: 4.5 cache
+// lines of 128 B per hit, which is what bounds this kernel on a chunk pair (~ 400 B fetched per hit at 4.6 TB/s).
+// The extension's own packed form of a strand (k_pack2bit_mask writes it beside the seed stage's planes) holds 32 bases in a 12-byte record:
+// the 2-bit codes as in the seed stage's plane (first base most significant) and ONE BIT per base that is set for N / IUPAC codes and
+// separators -- not for soft-masked bases, which extend like any other.  The 128 bases around a seed end are five records, 60 contiguous
+// bytes per sequence (1.5 cache lines instead of 2.25), and a strand is 0.375 B per base instead of 1: a 4.5 Mb chunk pair's strands stay
+// in an XCD's L2.  A window that holds an N or a separator, or crosses an end of the set, takes the byte path as before.  The 2-bit fields
+// become the code bytes ux_chunk works on through a 256-entry table in LDS (four bases per look-up): everything behind the loads is the
+// byte path's own code, so the results are the byte path's.
+struct PkWin { unsigned long long a[4], n0, n1; };     // bases [e - 64, e + 64): base e - 64 + i = bits 63 - 2 (i & 31), 62 - 2 (i & 31) of a[i >> 5]; n0 / n1: its bit 63 - (i & 63)
+struct PkRec { uint32_t a_lo, a_hi, n; };               // 32 bases: base k = bits 63 - 2 k, 62 - 2 k of (a_hi : a_lo), its N / separator flag bit 31 - k of n
+__device__ __forceinline__ unsigned long long pk_funnel(const unsigned long long hi, const unsigned long long lo, const unsigned sh) {
+    return sh ? (hi << sh) | (lo >> (64u - sh)) : hi;             // 64 bits from bit `sh` (counted from the top, 0 .. 63) of hi:lo
+}
+__device__ __forceinline__ PkWin pk_load(const uint32_t *__restrict__ px, const int64_t e) {
+    const int64_t b = e - 64;
+    PkRec r[5];                                                       // 60 contiguous bytes, dword aligned: three 16-byte loads and one of 12
+#ifdef MB_EMU
+    __builtin_memcpy(r, px + 3 * (b >> 5), sizeof r);
+#else
+    typedef uint32_t pk_u4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef uint32_t pk_u3 __attribute__((ext_vector_type(3), aligned(4)));
+    const uint32_t *src = px + 3 * (b >> 5);
+    const pk_u4 v0 = *(const pk_u4 *)src, v1 = *(const pk_u4 *)(src + 4), v2 = *(const pk_u4 *)(src + 8);
+    const pk_u3 v3 = *(const pk_u3 *)(src + 12);
+    r[0] = PkRec{v0.x, v0.y, v0.z}; r[1] = PkRec{v0.w, v1.x, v1.y}; r[2] = PkRec{v1.z, v1.w, v2.x}; r[3] = PkRec{v2.y, v2.z, v2.w}; r[4] = PkRec{v3.x, v3.y, v3.z};
+#endif
+    const unsigned s1 = (unsigned)(b & 31), s2 = 2u * s1;
+    unsigned long long w[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) w[k] = ((unsigned long long)r[k].a_hi << 32) | r[k].a_lo;
+    PkWin o;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o.a[k] = pk_funnel(w[k], w[k + 1], s2);
+    // (s1 <= 31: the third word's share is its top s1 bits)
+    o.n0 = ((((unsigned long long)r[0].n << 32) | r[1].n) << s1) | ((unsigned long long)r[2].n >> (32u - s1));
+    o.n1 = ((((unsigned long long)r[2].n << 32) | r[3].n) << s1) | ((unsigned long long)r[4].n >> (32u - s1));
+    return o;
+}
+// the eight code bytes (memory order: byte k = the base at position start + k) of a 16-bit field whose first base is most significant
+__device__ __forceinline__ unsigned long long pk_bytes(const uint32_t *lut, const unsigned f16) {
+    return (unsigned long long)lut[(f16 >> 8) & 0xFFu] | ((unsigned long long)lut[f16 & 0xFFu] << 32);
+}
+// chunk c of the left walk = bases [e - 8 (c + 1), e - 8 c), of the right walk = bases [e + 8 c, e + 8 c + 8)   (c: compile-time)
+template <int C> __device__ __forceinline__ unsigned pk_left(const PkWin &w) { return (unsigned)(w.a[1 - (C >> 2)] >> (16 * (C & 3))) & 0xFFFFu; }
+template <int C> __device__ __forceinline__ unsigned pk_right(const PkWin &w) { return (unsigned)(w.a[2 + (C >> 2)] >> (48 - 16 * (C & 3))) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t pk_lut_entry(const unsigned h) {      // h = four bases, the first in bits 7..6
+    return ((h >> 6) & 3u) | (((h >> 4) & 3u) << 8) | (((h >> 2) & 3u) << 16) | ((h & 3u) << 24);
+}
+
 // a finished hit: its record and, if it scores, its candidate HSP (census later, only if the rule keeps the hit)
 __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, const int unit, const int32_t q_end, const int64_t t_end, const int best_l,
                                            const int bl, const int best_r, const int br, const uint32_t cols, const int K,
@@ -144,16 +195,22 @@ __global__ __launch_bounds__(256) void k_ux_mark_long(const unsigned long long *
     atomicOr(&sc.long_bits[b >> 5], 1u << (b & 31u));
 }
 
-__global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long long *__restrict__ keys, const int64_t n_hits,
-                                                           const UnitTab ut,
-                                                           const int xdrop, const int K, const UxScratch sc, DevHsp *__restrict__ hsps,
-                                                           const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
+template <bool PACKED>
+__device__ __forceinline__ void ux_extend_body(const unsigned long long *__restrict__ keys, const int64_t n_hits,
+                                               const UnitTab ut,
+                                               const int xdrop, const int K, const UxScratch sc, DevHsp *__restrict__ hsps,
+                                               const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
     using namespace ux;
     __shared__ UxEntry slots[kBlock];
     __shared__ unsigned wave_cnt[kBlock / 64];
+    __shared__ uint32_t pk_lut[PACKED ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
     const bool valid = i < n_hits;
+    if (PACKED) {                                                        // (kBlock = 256: an entry per work-item)
+        pk_lut[tid & 255] = pk_lut_entry((unsigned)tid & 255u);
+        __syncthreads();
+    }
     // ---- level 1: every lane the same 5 + 3 chunks
     UxEntry e;
     e.i = (uint32_t)i; e.cl = -1; e.cr = -1; e.run_l = 0; e.best_l = 0; e.bpos_l = 0; e.run_r = 0; e.best_r = 0; e.bpos_r = 0; e.cols = 0;
@@ -166,10 +223,31 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
         const uint8_t *tc = un.tc, *qc = un.qc;
         const int64_t t_end = (int64_t)dq - un.qoff + q_end;
         unsigned long long aL[kL1], bL[kL1], aR[kR1], bR[kR1];
+        bool from_packed = false;
+        if (PACKED) {
+            static_assert(kL1 == 6 && kR1 == 4, "the packed window holds 64 bases either side of the seed end");
+            // (both windows inside their sets: the packed planes hold nothing before position 0)
+            if (t_end >= 64 && t_end + 64 <= sc.t_n && q_end >= 64 && (int64_t)q_end + 64 <= sc.q_n) {
+                const PkWin wt = pk_load(sc.t_px, t_end), wq = pk_load(sc.q_px, (int64_t)q_end);
+                // an N or a separator among the level's columns [e - 48, e + 32) = bits 16 .. 95 of the window
+                const unsigned long long special = ((wt.n0 | wq.n0) & 0x0000FFFFFFFFFFFFull) | ((wt.n1 | wq.n1) & 0xFFFFFFFF00000000ull);
+                if (special == 0ull) {
+                    aL[0] = pk_bytes(pk_lut, pk_left<0>(wt)); aL[1] = pk_bytes(pk_lut, pk_left<1>(wt)); aL[2] = pk_bytes(pk_lut, pk_left<2>(wt));
+                    aL[3] = pk_bytes(pk_lut, pk_left<3>(wt)); aL[4] = pk_bytes(pk_lut, pk_left<4>(wt)); aL[5] = pk_bytes(pk_lut, pk_left<5>(wt));
+                    bL[0] = pk_bytes(pk_lut, pk_left<0>(wq)); bL[1] = pk_bytes(pk_lut, pk_left<1>(wq)); bL[2] = pk_bytes(pk_lut, pk_left<2>(wq));
+                    bL[3] = pk_bytes(pk_lut, pk_left<3>(wq)); bL[4] = pk_bytes(pk_lut, pk_left<4>(wq)); bL[5] = pk_bytes(pk_lut, pk_left<5>(wq));
+                    aR[0] = pk_bytes(pk_lut, pk_right<0>(wt)); aR[1] = pk_bytes(pk_lut, pk_right<1>(wt)); aR[2] = pk_bytes(pk_lut, pk_right<2>(wt)); aR[3] = pk_bytes(pk_lut, pk_right<3>(wt));
+                    bR[0] = pk_bytes(pk_lut, pk_right<0>(wq)); bR[1] = pk_bytes(pk_lut, pk_right<1>(wq)); bR[2] = pk_bytes(pk_lut, pk_right<2>(wq)); bR[3] = pk_bytes(pk_lut, pk_right<3>(wq));
+                    from_packed = true;
+                }
+            }
+        }
+        if (!from_packed) {
 #pragma unroll
-        for (int j = 0; j < kL1 / 2; j++) { load_left2(tc + t_end, j, aL[2 * j], aL[2 * j + 1]); load_left2(qc + q_end, j, bL[2 * j], bL[2 * j + 1]); }
+            for (int j = 0; j < kL1 / 2; j++) { load_left2(tc + t_end, j, aL[2 * j], aL[2 * j + 1]); load_left2(qc + q_end, j, bL[2 * j], bL[2 * j + 1]); }
 #pragma unroll
-        for (int j = 0; j < kR1 / 2; j++) { load_right2(tc + t_end, j, aR[2 * j], aR[2 * j + 1]); load_right2(qc + q_end, j, bR[2 * j], bR[2 * j + 1]); }
+            for (int j = 0; j < kR1 / 2; j++) { load_right2(tc + t_end, j, aR[2 * j], aR[2 * j + 1]); load_right2(qc + q_end, j, bR[2 * j], bR[2 * j + 1]); }
+        }
         XState xl{0, 0, 0, true}, xr{0, 0, 0, true};
         uint32_t cols = 0;
         unsigned long long seps = 0;
@@ -265,6 +343,18 @@ __global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long lo
             }
         }
     }
+}
+
+__global__ __launch_bounds__(ux::kBlock) void k_ux_extend(const unsigned long long *__restrict__ keys, const int64_t n_hits, const UnitTab ut,
+                                                           const int xdrop, const int K, const UxScratch sc, DevHsp *__restrict__ hsps,
+                                                           const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
+    ux_extend_body<false>(keys, n_hits, ut, xdrop, K, sc, hsps, hsp_cap, ctr);
+}
+// level 1 from the packed strands of the launch's ONE unit (UxScratch::t_px / q_px); everything else as k_ux_extend
+__global__ __launch_bounds__(ux::kBlock) void k_ux_extend_pk(const unsigned long long *__restrict__ keys, const int64_t n_hits, const UnitTab ut,
+                                                              const int xdrop, const int K, const UxScratch sc, DevHsp *__restrict__ hsps,
+                                                              const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
+    ux_extend_body<true>(keys, n_hits, ut, xdrop, K, sc, hsps, hsp_cap, ctr);
 }
 
 // The listed hits to the end: a group of 8 lanes per hit, 64 columns per step (the state machine of k_ungapped_grp with the

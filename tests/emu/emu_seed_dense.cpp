@@ -184,8 +184,16 @@ int main(int argc, char **argv) {
             const size_t n2 = mb::packed_words2(n), n1 = mb::packed_wordsm(n);
             const unsigned long long guard = 0x1234567812345678ull;
             p2.assign(n2 + 4, guard); pm.assign(n1 + 4, guard);
-            hipLaunchKernelGGL(mb::k_pack2bit_mask, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, nullptr, codes, n, p2.data(), pm.data(), nm);
-            for (size_t x = 0; x < 4; x++) if (p2[n2 + x] != guard || pm[n1 + x] != guard) return false;      // a store past a plane
+            const size_t nx = mb::packed_dwordsx(n);                    // the ungapped extension's records (mb_ungapped_ux.h): 12 bytes per 32 bases
+            std::vector<uint32_t> px(nx + 4, 0x12345678u);
+            hipLaunchKernelGGL(mb::k_pack2bit_mask, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, nullptr, codes, n, p2.data(), pm.data(), nm, px.data());
+            for (size_t x = 0; x < 4; x++) if (p2[n2 + x] != guard || pm[n1 + x] != guard || px[nx + x] != 0x12345678u) return false;      // a store past a plane
+            for (int64_t i = 0; i < nm * 64; i++) {                      // base i of record i >> 5: codes as in p2, a flag for N / IUPAC / separator / beyond the end only
+                const unsigned c = i < n ? codes[i] : 0xFFu;
+                const uint32_t *r = px.data() + 3 * (i >> 5);
+                const unsigned long long a = ((unsigned long long)r[1] << 32) | r[0];
+                if (((unsigned)(a >> (62 - 2 * (i & 31))) & 3u) != (c & 3u) || ((r[2] >> (31 - (i & 31))) & 1u) != (unsigned)((c & 0x84u) != 0u)) return false;
+            }
             for (int64_t i = 0; i < nm * 64; i++) {
                 const unsigned c = i < n ? codes[i] : 0xFFu;
                 const unsigned two = (unsigned)(p2[(size_t)(i >> 5)] >> (62 - 2 * (i & 31))) & 3u, m = (unsigned)(pm[(size_t)(i >> 6)] >> (63 - (i & 63))) & 1u;

@@ -393,6 +393,29 @@ int main(int argc, char **argv) {
             const unsigned *heads_long = heads.data() + (n + n / 2 + n / 4 + n / 8 + 8);
             if (use_h16) sc.extent_live = 0;
             if (!use_h16) hipLaunchKernelGGL(mb::k_ux_mark_long, dim3((n_heads[4] + 255) / 256 + 1), dim3(256), 0, nullptr, keys.data(), heads_long, n_heads + 4, sc);
+            // every other one-unit case: level 1 from the PACKED strands (k_ux_extend_pk: the extension's 12-byte records, made here
+            // by a plain loop) -- hits whose windows hold an N or a separator, or cross an end of a set, take the byte path inside it
+            sc.t_px = sc.q_px = nullptr; sc.t_n = sc.q_n = 0;
+            std::vector<uint32_t> tpx, qpx;
+            const bool use_pk = n_units == 1 && !use_h16 && (cs % 2 == 1 || cs % 5 == 2);
+            if (use_pk) {
+                auto pack = [](const uint8_t *codes, int64_t nb, std::vector<uint32_t> &px) {      // (the layout k_pack2bit_mask writes: mb_seed_dense.h)
+                    const size_t recs = 2 * (size_t)((nb + 63) / 64 + 2);
+                    px.assign(3 * recs, 0u);
+                    for (int64_t i = 0; i < (int64_t)recs * 32; i++) {
+                        const unsigned c = i < nb ? codes[i] : 0xFFu;
+                        const unsigned long long two = (unsigned long long)(c & 3u) << (62 - 2 * (i & 31));
+                        uint32_t *r = px.data() + 3 * (i >> 5);
+                        r[0] |= (uint32_t)two; r[1] |= (uint32_t)(two >> 32);
+                        if (c & 0x84u) r[2] |= 1u << (31 - (i & 31));
+                    }
+                };
+                pack(units[0].tc, units[0].tn, tpx); pack(units[0].qc, units[0].qn, qpx);
+                sc.t_px = tpx.data(); sc.q_px = qpx.data(); sc.t_n = units[0].tn; sc.q_n = units[0].qn;
+                hipLaunchKernelGGL(mb::k_ux_extend_pk, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc,
+                                   hsps.data(), (int64_t)hsps.size(), ctr);
+                printf("  ux: level 1 from the packed strands\n");
+            } else
             hipLaunchKernelGGL(mb::k_ux_extend, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc,
                                hsps.data(), (int64_t)hsps.size(), ctr);
             hipLaunchKernelGGL(mb::k_ux_tail, dim3(blocks), dim3(256), 0, nullptr, keys.data(), n_hits, ut, xdrop, K, sc, hsps.data(), (int64_t)hsps.size(), ctr);
