@@ -1513,6 +1513,27 @@ static bool bin_plan_fits(const uint32_t *plan, unsigned long long nh) {
 }
 
 // index build + seed search + ungapped extension + HSP filters of one pair (uses the shared seed workspace)
+// MIBLAST_DEBUG_KEYS=1 (diagnostics, with the guard runs of round 6): the sorted hit keys of a strand as the ungapped kernels are about to
+// read them -- every q_end in (0, qtot], every t_end = diagonal - qtot + q_end in (0, ttot]; anything else is reported and the call refused.
+static bool debug_check_keys(const char *where, const unsigned long long *d_keys, int64_t n, int64_t ttot, int64_t qtot, hipStream_t s) {
+    static const bool on = env_long("MIBLAST_DEBUG_KEYS", 0) != 0;
+    if (!on || n <= 0) return true;
+    std::vector<unsigned long long> h((size_t)n);
+    MB_HIP(hipStreamSynchronize(s));
+    MB_HIP(hipMemcpy(h.data(), d_keys, (size_t)n * 8, hipMemcpyDeviceToHost));
+    int64_t bad = 0, first = -1;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t q_end = (int64_t)(uint32_t)h[(size_t)i], d = (int64_t)(h[(size_t)i] >> 32), t_end = d - qtot + q_end;
+        if (q_end < 1 || q_end > qtot || t_end < 1 || t_end > ttot) { if (first < 0) first = i; bad++; }
+    }
+    if (bad) {
+        const int64_t q_end = (int64_t)(uint32_t)h[(size_t)first], d = (int64_t)(h[(size_t)first] >> 32);
+        fprintf(stderr, "[miblast debug] %s: %lld of %lld keys lie outside the pair (ttot %lld, qtot %lld); the first: index %lld key %016llx diagonal %lld q_end %lld t_end %lld\n", where,
+                (long long)bad, (long long)n, (long long)ttot, (long long)qtot, (long long)first, h[(size_t)first], (long long)d, (long long)q_end, (long long)(d - qtot + q_end));
+    }
+    return bad == 0;
+}
+
 static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
     hipStream_t s = ctx.stream;
     const SeqSet &T = *job.T, &Q = *job.Q;
@@ -1693,6 +1714,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
                     if (strand == 0 || !fits[0] || !nh[0]) (void)ux_scratch(w, nullptr, (size_t)nh_max, ttot + qtot + 2, pmul, hmask);
                     UxScratch uxs = ux_scratch(w, keys_a.p + (size_t)strand * capH, (size_t)nh[strand], ttot + qtot + 2, pmul, hmask);
                     ux_windows(uxs, strand);
+                    if (!debug_check_keys("both strands in one go", keys_b.p, (int64_t)nh[strand], ttot, qtot, s)) { set_error("MIBLAST_DEBUG_KEYS: hit keys outside the pair"); return MIBLAST_EHIP; }
                     launch_ungapped(keys_b.p, (int64_t)nh[strand], w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, nullptr, p.xdrop, p.hspthresh,
                                     d_hsps.p + hoff[strand], (int64_t)nh[strand], d_ctr.p + strand, &uxs, true, s);
                     MB_HIP(hipEventRecord(w.sev[strand][5], s));
@@ -1764,6 +1786,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev3, s));
             UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2, hashed ? hmul : 1u, hmask);               // (the unsorted keys are free now)
             ux_windows(uxs, strand);
+            if (!debug_check_keys("a strand at a time", keys_b.p, (int64_t)nh, ttot, qtot, s)) { set_error("MIBLAST_DEBUG_KEYS: hit keys outside the pair"); return MIBLAST_EHIP; }
             launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, ext_p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, &uxs, found.empty() && strand_hits[strand] == nh, s);     // (extent[] is all zero in the first batch only)
             MB_HIP(hipEventRecord(ctx.ev4, s));

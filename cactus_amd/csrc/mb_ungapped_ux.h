@@ -297,11 +297,28 @@ __device__ __forceinline__ void ux_extend_body(const unsigned long long *__restr
         t_end = (int64_t)dq - un.qoff + q_end;
         const int cl0 = max(e.cl, 0), cr0 = max(e.cr, 0);
         unsigned long long aL[kL2], bL[kL2], aR[kR2], bR[kR2];
+        bool from_packed = false;
+        if (PACKED) {
+            static_assert(kL2 == 2 && kR2 == 2, "level 2 = the outer 16 columns either side of the packed window");
+            // a hit that comes from a complete level 1 (a direction that has ended does not matter): its level-2 columns [e - 64, e - 48) and
+            // [e + 32, e + 48) are the ends of the same packed window -- the records level 1 read a moment ago
+            if ((e.cl == kL1 || e.cl < 0) && (e.cr == kR1 || e.cr < 0) && t_end >= 64 && t_end + 64 <= sc.t_n && q_end >= 64 && (int64_t)q_end + 64 <= sc.q_n) {
+                const PkWin wt = pk_load(sc.t_px, t_end), wq = pk_load(sc.q_px, (int64_t)q_end);
+                const unsigned long long special = ((wt.n0 | wq.n0) >> 48) | (((wt.n1 | wq.n1) >> 16) & 0xFFFFull);
+                if (special == 0ull) {
+                    aL[0] = pk_bytes(pk_lut, pk_left<6>(wt)); aL[1] = pk_bytes(pk_lut, pk_left<7>(wt)); bL[0] = pk_bytes(pk_lut, pk_left<6>(wq)); bL[1] = pk_bytes(pk_lut, pk_left<7>(wq));
+                    aR[0] = pk_bytes(pk_lut, pk_right<4>(wt)); aR[1] = pk_bytes(pk_lut, pk_right<5>(wt)); bR[0] = pk_bytes(pk_lut, pk_right<4>(wq)); bR[1] = pk_bytes(pk_lut, pk_right<5>(wq));
+                    from_packed = true;
+                }
+            }
+        }
+        if (!from_packed) {
         // (cl0 and cr0 are even: level 1 took an even number of chunks)
 #pragma unroll
         for (int j = 0; j < kL2 / 2; j++) { load_left2(tc + t_end, cl0 / 2 + j, aL[2 * j], aL[2 * j + 1]); load_left2(qc + q_end, cl0 / 2 + j, bL[2 * j], bL[2 * j + 1]); }
 #pragma unroll
         for (int j = 0; j < kR2 / 2; j++) { load_right2(tc + t_end, cr0 / 2 + j, aR[2 * j], aR[2 * j + 1]); load_right2(qc + q_end, cr0 / 2 + j, bR[2 * j], bR[2 * j + 1]); }
+        }
         xl = XState{e.run_l, e.best_l, e.bpos_l, e.cl >= 0};
         xr = XState{e.run_r, e.best_r, e.bpos_r, e.cr >= 0};
         unsigned long long seps = 0;
