@@ -235,6 +235,7 @@ void launch_keys_unhash(unsigned long long *keys, int64_t n, uint32_t hinv, uint
 // grouping the keys by diagonal without the device-wide sort (mb_seed_bin.h)
 int64_t bin_state_words();
 int bin_cap_big();
+unsigned long long bin_keys_max();          // more keys than this get no plan (mb_seed_bin.h)
 int64_t bin_matrix_words_for(unsigned long long cap, int diag_bits, int mean);
 void launch_bin_plan(const unsigned long long *keys, const unsigned long long *n_ptr, unsigned long long cap, int diag_bits, int mean, uint32_t *state, uint32_t *matrix,
                      hipStream_t s);

@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,14 @@ namespace mb {
 // so bench.py reads this around its timed steps: device_allocs_in_timed_steps on the line must be 0 (miblast_debug_device_allocs()).
 inline std::atomic<long long> &device_alloc_calls() { static std::atomic<long long> n{0}; return n; }
 inline void count_device_alloc() { device_alloc_calls().fetch_add(1, std::memory_order_relaxed); }
+// MIBLAST_DEBUG_ALLOC=2: every device allocation / release of the library on stderr (which buffer still grows in the middle of a job?)
+inline void note_device_alloc(const char *what, size_t bytes) {
+    static const int lv = [] { const char *v = getenv("MIBLAST_DEBUG_ALLOC"); return v && *v ? atoi(v) : 0; }();
+    if (lv >= 2) {
+        static const auto t0 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[miblast] %9.3f s  device allocation: %.3f MB  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), bytes / 1e6, what);
+    }
+}
 
 namespace guard {
 

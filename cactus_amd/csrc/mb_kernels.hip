@@ -155,6 +155,7 @@ void launch_keys_unhash(unsigned long long *keys, int64_t n, uint32_t hinv, uint
 
 int64_t bin_state_words() { return (kBinStateWords + 3) & ~3; }
 int bin_cap_big() { return kBinCapBig; }
+unsigned long long bin_keys_max() { return kBinKeysMax; }
 int64_t bin_matrix_words_for(unsigned long long cap, int diag_bits, int mean) { return (int64_t)((bin_matrix_words(cap, diag_bits, mean) + 3ull) & ~3ull); }
 
 // queued behind the kernels that write the keys and their number (*n_ptr); state: bin_state_words() zeroed u32 words; matrix:

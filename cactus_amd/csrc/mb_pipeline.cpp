@@ -52,7 +52,7 @@ struct DevBuf {
         const double t0 = now_s();
         release();
         n = count;
-        if (count) count_device_alloc();
+        if (count) { count_device_alloc(); note_device_alloc(__PRETTY_FUNCTION__, count * sizeof(T)); }
         if (count && guard::on()) MB_HIP(guard::alloc((void **)&p, count * sizeof(T), __PRETTY_FUNCTION__));
         else if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow device allocation: %.1f MB in %.1f ms\n", count * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
@@ -80,11 +80,12 @@ struct DevBuf {
         T *old = p; const size_t old_n = n;
         p = nullptr; n = guard::on() ? count : count + count / 2;
         count_device_alloc(); if (old) count_device_alloc();
+        note_device_alloc(__PRETTY_FUNCTION__, n * sizeof(T));
         if (guard::on()) MB_HIP(guard::alloc((void **)&p, n * sizeof(T), __PRETTY_FUNCTION__));
         else MB_HIP(hipMalloc((void **)&p, n * sizeof(T)));
         if (old) { MB_HIP(hipMemcpy(p, old, old_n * sizeof(T), hipMemcpyDeviceToDevice)); if (guard::on()) guard::free(old, "DevBuf::ensure_keep"); else (void)hipFree(old); }
     }
-    void release() { if (p) count_device_alloc(); if (p) { if (guard::on()) guard::free(p, "DevBuf::release"); else (void)hipFree(p); } p = nullptr; n = 0; }
+    void release() { if (p) { count_device_alloc(); note_device_alloc("(release) DevBuf", n * sizeof(T)); } if (p) { if (guard::on()) guard::free(p, "DevBuf::release"); else (void)hipFree(p); } p = nullptr; n = 0; }
 };
 
 // pinned host staging buffer: one large device-to-host copy at link speed, no page faults
@@ -519,7 +520,7 @@ struct DeviceBlocks {
         }
         void *p = nullptr;
         cap = (bytes + 4095) & ~(size_t)4095;
-        count_device_alloc();
+        count_device_alloc(); note_device_alloc("block cache (sequence sets, seed tables, strands)", cap);
         MB_HIP(hipMalloc(&p, cap));
         return p;
     }
@@ -529,7 +530,7 @@ struct DeviceBlocks {
             std::lock_guard<std::mutex> lk(mu);
             if (cached + cap <= kKeep) { free_list.push_back({device, p, cap}); cached += cap; return; }
         }
-        count_device_alloc();
+        count_device_alloc(); note_device_alloc("(release) block cache over its budget", cap);
         (void)hipFree(p);
     }
     ~DeviceBlocks() { for (Block &b : free_list) (void)hipFree(b.p); }
@@ -713,7 +714,7 @@ struct ArenaPool {
                 free_list.erase(free_list.begin() + (long)smallest);
             }
         }
-        for (const A &a : drop) { count_device_alloc(); (void)hipFree(a.p); }
+        for (const A &a : drop) { count_device_alloc(); note_device_alloc("(release) trace arena", a.n); (void)hipFree(a.p); }
     }
     // everything that lies free on the device back to the runtime (a stage that needs most of the device's memory for its arena)
     void trim(int device) {
@@ -723,7 +724,7 @@ struct ArenaPool {
             for (size_t i = 0; i < free_list.size();)
                 if (free_list[i].device == device) { drop.push_back(free_list[i]); free_list.erase(free_list.begin() + (long)i); } else i++;
         }
-        for (const A &a : drop) { count_device_alloc(); (void)hipFree(a.p); }
+        for (const A &a : drop) { count_device_alloc(); note_device_alloc("(release) trace arena", a.n); (void)hipFree(a.p); }
     }
 };
 ArenaPool &arena_pool() { static ArenaPool *a = new ArenaPool(); return *a; }
@@ -1760,6 +1761,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         }
         const double t0 = now_s();
         int32_t *ext_p = nullptr;                                       // set when the strand turns out to need several batches
+        unsigned long long batch_cap = (unsigned long long)hit_cap;     // hits per q batch (two-pass path)
         std::vector<DevHsp> found;
         int rc_batch = MIBLAST_OK;
         // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
@@ -1850,18 +1852,29 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         {
             unsigned long long all = 0;
             for (int64_t b = 0; b < n_qblk; b++) all += h_qbsum[(size_t)b];
-            if (all > (unsigned long long)hit_cap) {                    // several q batches: the diagonals' extents go from one to the next
+            // A strand in several q batches (round 6): a batch that fits a plan of bins goes through the bins + LDS as a single-batch strand does
+            // (mb_seed_bin.h) instead of four radix passes; MIBLAST_BATCH_BINS=2 also cuts the batches to the size the STAGED scatter takes
+            // (2 048 bins of the mean size: ~ 2 x 10^7 keys instead of 2^27) -- see batch_bins below for what that measured.  MIBLAST_HIT_CAP, when
+            // set, wins.
+            batch_cap = (unsigned long long)hit_cap;
+            if (binned && !getenv("MIBLAST_HIT_CAP") && env_long("MIBLAST_BATCH_BINS", 0) == 2)
+                batch_cap = std::min<unsigned long long>(batch_cap, (unsigned long long)bin_mean << 11);
+            if (all > batch_cap) {                                      // several q batches: the diagonals' extents go from one to the next
                 extent.ensure((size_t)(ttot + qtot + 8));
                 MB_HIP(hipMemsetAsync(extent.p, 0, up16((size_t)(ttot + qtot + 2) * 4), s));
                 ext_p = extent.p;
             }
         }
+        // MIBLAST_BATCH_BINS: 1 (default) a batch that fits a plan of bins takes the bins; 2 also cuts the batches to the staged scatter's size
+        // (measured on the 32 Mb x 32 Mb pair of hm30: sorts 36 -> 15 ms of kernel time per step, the step 235 -> 243 ms -- fourteen times the
+        // batches, each with its read-backs; not the default); 0: radix sort as before
+        const bool batch_bins = binned && env_long("MIBLAST_BATCH_BINS", 1) != 0;
         int64_t b0 = 0;
         while (b0 < n_qblk) {
-            // greedy batch of whole 2048-position blocks with at most hit_cap hits
+            // greedy batch of whole 2048-position blocks with at most batch_cap hits
             int64_t b1 = b0;
             unsigned long long nh = 0;
-            while (b1 < n_qblk && (b1 == b0 || nh + h_qbsum[(size_t)b1] <= (unsigned long long)hit_cap)) nh += h_qbsum[(size_t)b1++];
+            while (b1 < n_qblk && (b1 == b0 || nh + h_qbsum[(size_t)b1] <= batch_cap)) nh += h_qbsum[(size_t)b1++];
             const int64_t q0 = b0 * 2048, q1 = std::min(qtot, b1 * 2048);
             b0 = b1;
             if (nh == 0) continue;
@@ -1870,7 +1883,19 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             MB_HIP(hipEventRecord(ctx.ev0, s));
             launch_scan_u32(qcnt.p + q0, hit_off.p, q1 - q0, scan_scratch.p, s);
             launch_seed_fill(qc_d[strand], q0, q1, qtot, tab.offsets.p, tab.occ.p, tab.positions.p, p.transitions, hit_off.p, keys_a.p, s, hmul, hmask);
-            rc_batch = extend_batch(nh, true, env_long("MIBLAST_SORT_DIAG_ONLY", 1) != 0, true);
+            uint32_t plan[8] = {0, 0, 0, 0, 1, 0, 0, 0};
+            if (batch_bins && nh <= bin_keys_max()) {
+                // the plan of the batch's bins: its key count goes to the device (the kernels read it there), the plan comes back
+                w.ord_state.ensure(2); w.bin_state.ensure((size_t)bsw); w.bin_matrix.ensure((size_t)bin_matrix_words_for(nh, diag_bits, bin_mean)); w.pin_u64.ensure(16);
+                w.stage.h2d(w.ord_state.p, &nh, 8, s);
+                MB_HIP(hipMemsetAsync(w.bin_state.p, 0, (size_t)bsw * 4, s));
+                launch_bin_plan(keys_a.p, w.ord_state.p, nh, diag_bits, bin_mean, w.bin_state.p, w.bin_matrix.p, s);
+                MB_HIP(hipMemcpyAsync(w.pin_u64.p + 4, w.bin_state.p, 32, hipMemcpyDeviceToHost, s));
+                MB_HIP(hipStreamSynchronize(s));
+                w.stage.done();
+                memcpy(plan, w.pin_u64.p + 4, 32);
+            }
+            rc_batch = extend_batch(nh, true, env_long("MIBLAST_SORT_DIAG_ONLY", 1) != 0, true, batch_bins ? plan : nullptr);
             if (rc_batch != MIBLAST_OK) return rc_batch;
         }
         }
@@ -2643,7 +2668,7 @@ static int acquire_trace_arena(Ctx &ctx, const miblast_params &p, std::vector<Pa
         size_t free_b = 0, total_b = 0;
         MB_HIP(hipMemGetInfo(&free_b, &total_b));
         want = std::min<size_t>(want, free_b > ((size_t)4 << 30) ? free_b - ((size_t)2 << 30) : free_b / 2);
-        count_device_alloc();
+        count_device_alloc(); note_device_alloc("trace arena", want);
         while (hipMalloc((void **)&g.arena.p, want) != hipSuccess) {
             (void)hipGetLastError();
             g.arena.p = nullptr;
@@ -2668,13 +2693,13 @@ static int grow_trace_arena(Ctx &ctx, size_t arena_raw_estimate) {
     // (the one that was too small goes back to the pool -- or, when the larger one needs the room, to the runtime; a free one of the
     //  size wanted is taken if there is one)
     const size_t old_n = g.arena.n;
-    if (bigger + (2ull << 30) > free_b) { count_device_alloc(); (void)hipFree(g.arena.p); arena_pool().trim(ctx.device); }
+    if (bigger + (2ull << 30) > free_b) { count_device_alloc(); note_device_alloc("(release) trace arena before growing", g.arena.n); (void)hipFree(g.arena.p); arena_pool().trim(ctx.device); }
     else arena_pool().give(ctx.device, g.arena.p, g.arena.n);
     g.arena.p = nullptr; g.arena.n = 0;
     if (!arena_pool().take(ctx.device, bigger, g.arena.p, g.arena.n) || g.arena.n < bigger) {
         arena_pool().give(ctx.device, g.arena.p, g.arena.n);
         g.arena.p = nullptr; g.arena.n = 0;
-        count_device_alloc();
+        count_device_alloc(); note_device_alloc("trace arena (grown)", bigger);
         if (hipMalloc((void **)&g.arena.p, bigger) != hipSuccess) {
             (void)hipGetLastError();
             g.arena.p = nullptr;
