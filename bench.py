@@ -82,8 +82,9 @@ def parse_args():
     ap.add_argument("--split-strands", default="auto", choices=("auto", "0", "1"),
                     help="chunk-scale workloads: deal (chunk pair, query strand) units instead of whole chunk pairs (exact: miblast_params.strands; the halves of a "
                          "pair are put together on rank 0) -- auto: when there are fewer than four chunk pairs per GPU")
-    ap.add_argument("--chunk-legs", type=int, default=1, help="evolver workload: also time the chunk-scale configurations chr20 (configs[3]) and hm (configs[4] stand-in) "
-                                                              "on this GPU, every chunk pair checked against its oracle digest (0 = skip); reported under chr20 / hm")
+    ap.add_argument("--chunk-legs", type=int, default=2, help="evolver workload: also time the chunk-scale configurations chr20 (configs[3]) and hm (configs[4] stand-in) "
+                                                              "on this GPU, every chunk pair checked against its oracle digest (0 = skip; 1 = chr20 + hm; 2, the default, = + hm30: "
+                                                              "the stand-in genome pair at the reference's own 30 Mb chunk size); reported under chr20 / hm / hm30")
     ap.add_argument("--chr20-bases", type=int, default=64_444_167, help="chr20 workload: bases of the synthetic chromosome (SURVEY 8d config 4)")
     ap.add_argument("--chr20-chunk", type=int, default=30_000_000,
                     help="chr20 workload: chunkSize (cactus_progressive_config.xml:90; overlap 10 000, :92).  A finer chunking gives more pairs to deal "

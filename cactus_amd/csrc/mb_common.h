@@ -43,6 +43,10 @@ struct UnitTab {                              // by value in the kernel argument
     SeedUnit one;
     const SeedUnit *tab;
     int32_t n;
+    // where a diagonal's entry of extent[] lies: slot (dq * ext_mul) & ext_mask, or dq itself when ext_mul is 0 (the default: a zeroed table).
+    // A strand in several q batches whose keys are sorted by the SCRAMBLED diagonal (mb_seed_dense.h) keeps its extents in the same order:
+    // the kernels that read and leave them walk the array as they walk the keys, instead of touching a random line per run (round 6).
+    uint32_t ext_mul, ext_mask;
 };
 
 struct DpProb {                               // one one-sided Y-drop DP (SURVEY A.7 ONE_SIDED)

@@ -56,7 +56,11 @@ inline int level() {
 }
 inline bool on() { return level() > 0; }
 
+#ifdef MB_EMU_HIP_STANDIN
+struct Rec { size_t bytes; const char *tag; int device; void *base = nullptr; size_t mapped = 0, reserved = 0; };      // (host emulation: levels 1 and 2 only)
+#else
 struct Rec { size_t bytes; const char *tag; int device; void *base = nullptr; size_t mapped = 0, reserved = 0; hipMemGenericAllocationHandle_t handle = {}; };
+#endif
 struct Registry {
     std::mutex mu;
     std::unordered_map<void *, Rec> live;
@@ -83,6 +87,9 @@ inline long first_damage(void *p, const Rec &r) {
 
 // hipMalloc's stand-in.  Returns hipSuccess / the error of hipMalloc (the trace arena retries smaller on failure).
 inline void dump_live(int);
+#ifdef MB_EMU_HIP_STANDIN
+inline hipError_t fenced(void **, size_t, Rec &) { return hipErrorInvalidValue; }
+#else
 inline hipError_t fenced(void **out, size_t bytes, Rec &r) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
@@ -110,6 +117,8 @@ inline hipError_t fenced(void **out, size_t bytes, Rec &r) {
     *out = (char *)r.base + (r.mapped - user);
     return hipSuccess;
 }
+
+#endif
 
 inline hipError_t alloc(void **out, size_t bytes, const char *tag) {
     void *p = nullptr;
@@ -163,7 +172,9 @@ inline void free(void *p, const char *where = "free") {
         (void)hipDeviceSynchronize();
         const long off = first_damage(p, r);
         if (off >= 0) die("overrun found on free", p, r, off, where);
+#ifndef MB_EMU_HIP_STANDIN
         if (r.base) { (void)hipMemUnmap(r.base, r.mapped); (void)hipMemRelease(r.handle); (void)hipMemAddressFree(r.base, r.reserved); }
+#endif
         if (cur != r.device) (void)hipSetDevice(cur);
         if (r.base) return;
     }

@@ -811,6 +811,8 @@ struct Workspace {                      // device buffers that persist across mi
         std::atomic<size_t> *m = owner.gapped_hw;
         probs.hw = m + 0; outs.hw = m + 1; dp_order.hw = m + 2; rowdir.hw = m + 3; ops.hw = m + 4; ops_packed.hw = m + 5; coff.hw = m + 6; tb_blk.hw = m + 7;
         recs.hw = m + 8; snaps.hw = m + 9; dp_up.hw = m + 10; dp_down.hw = m + 11; round_tab.hw = m + 12; hops.hw = m + 13; grows.hw = m + 14;
+        // (the seed stage's buffers follow Ctx::hits_hint, presize_lane; giving them marks of this kind as well -- tried at the end of round 6 --
+        //  left as many allocations in the timed steps and cost 3 - 5 % of the chunk legs' step: every lane then holds every buffer at its largest)
     }
     void presize_gapped() {
         probs.presize(); outs.presize(); dp_order.presize(); rowdir.presize(); ops.presize(); ops_packed.presize(); coff.presize(); tb_blk.presize();
@@ -1762,6 +1764,7 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
         const double t0 = now_s();
         int32_t *ext_p = nullptr;                                       // set when the strand turns out to need several batches
         unsigned long long batch_cap = (unsigned long long)hit_cap;     // hits per q batch (two-pass path)
+        bool ext_scrambled = false;                                     // extent[] slots follow the keys' scramble (q batches)
         std::vector<DevHsp> found;
         int rc_batch = MIBLAST_OK;
         // sort + ungapped extension of the nh keys in keys_a (one q-ordered batch); collects the HSPs
@@ -1789,7 +1792,9 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             UxScratch uxs = ux_scratch(w, keys_a.p, (size_t)nh, ttot + qtot + 2, hashed ? hmul : 1u, hmask);               // (the unsorted keys are free now)
             ux_windows(uxs, strand);
             if (!debug_check_keys("a strand at a time", keys_b.p, (int64_t)nh, ttot, qtot, s)) { set_error("MIBLAST_DEBUG_KEYS: hit keys outside the pair"); return MIBLAST_EHIP; }
-            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, one_unit(T.dev(), qc_d[strand], ttot, qtot), ttot + qtot, ext_p, p.xdrop, p.hspthresh, d_hsps.p,
+            UnitTab ut1 = one_unit(T.dev(), qc_d[strand], ttot, qtot);
+            if (ext_p && ext_scrambled && hashed) { ut1.ext_mul = hmul; ut1.ext_mask = hmask; }
+            launch_ungapped(keys_b.p, (int64_t)nh, w.heads.p, w.n_heads.p, ut1, ttot + qtot, ext_p, p.xdrop, p.hspthresh, d_hsps.p,
                             (int64_t)d_hsps.n, d_ctr.p, &uxs, found.empty() && strand_hits[strand] == nh, s);     // (extent[] is all zero in the first batch only)
             MB_HIP(hipEventRecord(ctx.ev4, s));
             UngappedCounters hc;
@@ -1860,8 +1865,12 @@ static int seed_phase(Ctx &ctx, const miblast_params &p, PairJob &job) {
             if (binned && !getenv("MIBLAST_HIT_CAP") && env_long("MIBLAST_BATCH_BINS", 0) == 2)
                 batch_cap = std::min<unsigned long long>(batch_cap, (unsigned long long)bin_mean << 11);
             if (all > batch_cap) {                                      // several q batches: the diagonals' extents go from one to the next
-                extent.ensure((size_t)(ttot + qtot + 8));
-                MB_HIP(hipMemsetAsync(extent.p, 0, up16((size_t)(ttot + qtot + 2) * 4), s));
+                // (the batches' keys are sorted by the scrambled diagonal: the extents lie in the same order -- UnitTab::ext_mul -- so that the
+                //  kernels walk the array as they walk the keys; MIBLAST_EXTENT_SCRAMBLE=0: a slot per plain diagonal)
+                ext_scrambled = hmul != 1u && diag_bits < 32 && env_long("MIBLAST_EXTENT_SCRAMBLE", 1) != 0;
+                const size_t slots = ext_scrambled ? (size_t)hmask + 1 : (size_t)(ttot + qtot + 2);
+                extent.ensure(slots + 8);
+                MB_HIP(hipMemsetAsync(extent.p, 0, up16(slots * 4), s));
                 ext_p = extent.p;
             }
         }
@@ -2119,7 +2128,7 @@ static int seed_phase_batched(Ctx &ctx, const miblast_params &p, std::vector<Pai
         MB_HIP(hipEventRecord(w.sev[0][5], s));
         const UxScratch uxs = ux_scratch(w, w.keys_a.p, nh, n_diag + 2);            // (the unsorted keys are free now)
         UnitTab ut;
-        ut.one = units[0]; ut.tab = w.bx_units.p; ut.n = (int32_t)units.size();
+        ut.one = units[0]; ut.tab = w.bx_units.p; ut.n = (int32_t)units.size(); ut.ext_mul = 0; ut.ext_mask = 0;
         if (p.diag_hash16) {
             // lastz's 16-bit diagonal hash: every hit extended, the rule per hash class afterwards (mb_hash16.h)
             launch_ungapped_hash16(w.keys_b.p, (int64_t)nh, ut, n_diag, p.xdrop, p.hspthresh, w.hsps.p, (int64_t)nh, d_ctr, &uxs, w.h16_ka.p, w.h16_kb.p, w.h16_va.p,

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
             k++; cur = nxt;
             nxt = k + 1 < n_hits ? keys[k + 1] : ~0ull;
         } else {
-            if (l8 == 0) extent_put(extent, dq, ext);
+            if (l8 == 0) extent_put(extent, ut, dq, ext);
             need_run = true;
         }
         phase = 0;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, kMinWaves) void k_ungapped_grp(const unsigned 
                     cur = keys[k];
                     nxt = k + 1 < n_hits ? keys[k + 1] : ~0ull;
                     dq = (uint32_t)(cur >> 32);
-                    ext = extent_get(extent, dq);
+                    ext = extent_get(extent, ut, dq);
                     need_run = false;
                     if (ut.n > 1) {
                         const UnitRef nu = unit_of(ut, dq);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
         const UnitRef un = unit_of(ut, dq);
         const uint8_t *tc = un.tc, *qc = un.qc;
         my_unit = un.id;
-        int32_t ext = extent_get(extent, dq);
+        int32_t ext = extent_get(extent, ut, dq);
         while (true) {
             const int32_t q_end = (int32_t)(uint32_t)key;
             if (q_end > ext) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_ungapped(const unsigned long long *__re
             key = keys[k];
             if ((uint32_t)(key >> 32) != dq) break;
         }
-        extent_put(extent, dq, ext);
+        extent_put(extent, ut, dq, ext);
     }
     unit_count(ctr, my_unit, n_ext, n_cols);
 }
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
     const uint32_t dq = (uint32_t)(keys[k0] >> 32);
     const UnitRef un = unit_of(ut, dq);                              // (one run per wave: uniform)
     const uint8_t *tc = un.tc, *qc = un.qc;
-    int32_t ext = extent_get(extent, dq);
+    int32_t ext = extent_get(extent, ut, dq);
     bool run_done = false;
     while (!run_done) {
         // 64 hits of the run at a time; all suppressed hits of the block are skipped with one ballot
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_ungapped_long(const unsigned long long 
         k0 += 64;
     }
     if (lane == 0) {
-        extent_put(extent, dq, ext);
+        extent_put(extent, ut, dq, ext);
         atomicAdd(&ctr[un.id].extended, n_ext);
         atomicAdd(&ctr[un.id].cols, n_cols);
     }

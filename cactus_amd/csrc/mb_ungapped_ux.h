@@ -157,7 +157,7 @@ __device__ __forceinline__ uint32_t pk_lut_entry(const unsigned h) {      // h =
 __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, const int unit, const int32_t q_end, const int64_t t_end, const int best_l,
                                            const int bl, const int best_r, const int br, const uint32_t cols, const int K,
                                            const unsigned long long *__restrict__ keys, const int64_t n_hits, const UxScratch &sc,
-                                           DevHsp *__restrict__ hsps, const int64_t hsp_cap, UngappedCounters *__restrict__ ctr) {
+                                           DevHsp *__restrict__ hsps, const int64_t hsp_cap, UngappedCounters *__restrict__ ctr, const UnitTab &ut) {
     unsigned long long *__restrict__ rec = sc.rec;
     // Does this walk reach the next hit of the diagonal -- or, in a later q batch, does an earlier batch's extent reach the run's
     // first hit?  Then the run needs the sequential rule (k_ux_resolve).
@@ -166,7 +166,7 @@ __device__ __forceinline__ void finish_hit(const uint32_t i, const uint32_t dq, 
         const unsigned long long nk = keys[i + 1];
         dirty = (uint32_t)(nk >> 32) == dq && q_end + br >= (int32_t)(uint32_t)nk;
     }
-    if (sc.extent_live && sc.extent && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != dq)) dirty |= sc.extent[dq] >= q_end;
+    if (sc.extent_live && sc.extent && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != dq)) dirty |= sc.extent[extent_slot(ut, dq)] >= q_end;
     if (dirty) { const uint32_t b = plane_bit(sc, dq); atomicOr(&sc.dirty_bits[b >> 5], 1u << (b & 31u)); }
     uint32_t x = cols;
     const int score = best_l + best_r;
@@ -268,7 +268,7 @@ __device__ __forceinline__ void ux_extend_body(const unsigned long long *__restr
             e.cl = xl.live ? (clean ? kL1 : 0) : -1; e.cr = xr.live ? (clean ? kR1 : 0) : -1;
             e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos; e.cols = cols;
         } else {
-            finish_hit((uint32_t)i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+            finish_hit((uint32_t)i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr, ut);
         }
     }
     // ---- the unfinished hits of the block, packed at the front
@@ -335,7 +335,7 @@ __device__ __forceinline__ void ux_extend_body(const unsigned long long *__restr
             e.run_l = xl.run; e.best_l = xl.best; e.bpos_l = xl.bpos; e.run_r = xr.run; e.best_r = xr.best; e.bpos_r = xr.bpos;
         }                                                             // (else: a separator ahead -- the entry goes on as it came)
         spill = xl.live | xr.live;
-        if (!spill) finish_hit(e.i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+        if (!spill) finish_hit(e.i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr, ut);
     }
     // ---- still running: to k_ux_tail.  A returning atomic on one address costs ~7 ns whoever issues it, and nearly every block has
     //      a straggler or two: the first two waves of a block own 12 + 4 slots of the entry array (count stored, no atomic); only
@@ -356,7 +356,7 @@ __device__ __forceinline__ void ux_extend_body(const unsigned long long *__restr
                 // the list is full: this lane walks its hit to the end itself (slow and rare; same result)
                 while (xl.live) { xdrop_chunk<-1>(load8(tc + t_end - 8 * (e.cl + 1)), load8(qc + q_end - 8 * (e.cl + 1)), e.cl, xdrop, xl, e.cols); e.cl++; }
                 while (xr.live) { xdrop_chunk<+1>(load8(tc + t_end + 8 * e.cr), load8(qc + q_end + 8 * e.cr), e.cr, xdrop, xr, e.cols); e.cr++; }
-                finish_hit(e.i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+                finish_hit(e.i, dq, un.id, q_end, t_end, xl.best, xl.bpos, xr.best, xr.bpos, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr, ut);
             }
         }
     }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_ux_tail(const unsigned long long *__res
                 phase = 4;
             }
             if (phase == 4) {
-                if (l8 == 0) ux::finish_hit(e.i, dq, un.id, q_end, t_end, e.best_l, e.bpos_l, e.best_r, e.bpos_r, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr);
+                if (l8 == 0) ux::finish_hit(e.i, dq, un.id, q_end, t_end, e.best_l, e.bpos_l, e.best_r, e.bpos_r, e.cols, K, keys, n_hits, sc, hsps, hsp_cap, ctr, ut);
                 phase = 0;
             }
         }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void k_ux_accept(const unsigned long long *__r
             }
             n_kept++; n_cols += cols;
             // the last hit of the run leaves the diagonal's extent
-            if ((uint32_t)(nk >> 32) != dq) extent_put(extent, dq, (int32_t)(uint32_t)key + (int32_t)(uint32_t)rc);
+            if ((uint32_t)(nk >> 32) != dq) extent_put(extent, ut, dq, (int32_t)(uint32_t)key + (int32_t)(uint32_t)rc);
         } else if (is_dirty && !is_long && (uint32_t)(pk >> 32) != dq) {
             const unsigned slot = atomicAdd(&n_dbuf, 1u);                // (LDS)
             if (slot < kDirtyBuf) dbuf[slot] = (unsigned)i;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void k_ux_resolve(const unsigned long long *__
                 n_ext = 0; n_cols = 0; cur = u;
             }
         }
-        int32_t ext = extent_get(extent, dq);
+        int32_t ext = extent_get(extent, ut, dq);
         while (true) {
             const int32_t q_end = (int32_t)(uint32_t)key;
             if (q_end > ext) {
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_ux_resolve(const unsigned long long *__
             key = keys[k];
             if ((uint32_t)(key >> 32) != dq) break;
         }
-        extent_put(extent, dq, ext);
+        extent_put(extent, ut, dq, ext);
     }
     unit_count(ctr, cur, n_ext, n_cols);                             // (one pair of atomics per wave)
 }

@@ -22,8 +22,9 @@ inline const SeedUnit *unit_table(const UnitTab &ut) { return ut.tab; }
 // extent[] of a launch -- the right end of the last extension on a diagonal, carried from one q-ordered batch of a strand's hits to the
 // next.  A strand whose hits are ONE batch needs none: the pipeline passes nullptr (every diagonal starts at 0, nothing is kept), which
 // saves the fill of 4 B per diagonal (240 MB per strand of a 30 Mb x 30 Mb chunk pair) and a random read + write per diagonal run.
-__device__ __forceinline__ int32_t extent_get(const int32_t *__restrict__ extent, const uint32_t dq) { return extent ? extent[dq] : 0; }
-__device__ __forceinline__ void extent_put(int32_t *__restrict__ extent, const uint32_t dq, const int32_t v) { if (extent) extent[dq] = v; }
+__device__ __forceinline__ uint32_t extent_slot(const UnitTab &ut, const uint32_t dq) { return ut.ext_mul ? (dq * ut.ext_mul) & ut.ext_mask : dq; }
+__device__ __forceinline__ int32_t extent_get(const int32_t *__restrict__ extent, const UnitTab &ut, const uint32_t dq) { return extent ? extent[extent_slot(ut, dq)] : 0; }
+__device__ __forceinline__ void extent_put(int32_t *__restrict__ extent, const UnitTab &ut, const uint32_t dq, const int32_t v) { if (extent) extent[extent_slot(ut, dq)] = v; }
 
 struct UnitRef {
     const uint8_t *tc, *qc;

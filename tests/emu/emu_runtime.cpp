@@ -18,6 +18,7 @@ const std::string &last_error_text() { return g_err; }
 
 extern "C" {
 int miblast_device_count(void) { return 1; }
+int miblast_frontend_runtime_defaults(int) { return 0; }      // (the front end asks for polling waits: nothing to poll here)
 int miblast_ctx_create(int, miblast_ctx **ctx) { *ctx = new miblast_ctx(); return MIBLAST_OK; }
 void miblast_ctx_destroy(miblast_ctx *ctx) { if (ctx) mb::chain_cache_destroy(ctx->c.chain_cache); delete ctx; }
 const char *miblast_last_error(void) { return mb::g_err.c_str(); }

@@ -335,7 +335,7 @@ int main(int argc, char **argv) {
             tab[(size_t)x].tc = units[(size_t)x].tc; tab[(size_t)x].qc = units[(size_t)x].qc; tab[(size_t)x].qtot = (int32_t)units[(size_t)x].qn; tab[(size_t)x].ttot = (int32_t)units[(size_t)x].tn;
             tab[(size_t)x].dbase = units[(size_t)x].dbase;
         }
-        mb::UnitTab ut; ut.one = tab[0]; ut.tab = tab.data(); ut.n = n_units;
+        mb::UnitTab ut; ut.one = tab[0]; ut.tab = tab.data(); ut.n = n_units; ut.ext_mul = 0; ut.ext_mask = 0;
         // class lists as k_run_heads lays them out (every run is "short" here)
         const uint64_t n = (uint64_t)n_hits;
         std::vector<unsigned> heads((size_t)(2 * n + n / 4 + 64), 0u);
@@ -367,6 +367,14 @@ int main(int argc, char **argv) {
             heads = kheads;
         }
         std::vector<int32_t> extent = extent0;
+        // the scrambled one-unit cases keep extent[] in the order of their keys too (UnitTab::ext_mul: a strand in several q batches, round 6):
+        // the kernels see the slots permuted, the comparison below reads them back by diagonal
+        const bool ext_scrambled = plane_mul != 1u && n_units == 1;
+        if (ext_scrambled) {
+            extent.assign((size_t)plane_mask + 1, 0);
+            for (size_t d = 0; d < extent0.size(); d++) extent[(size_t)(((uint32_t)d * plane_mul) & plane_mask)] = extent0[d];
+            ut.ext_mul = plane_mul; ut.ext_mask = plane_mask;
+        }
         std::vector<mb::DevHsp> hsps((size_t)n_hits + 8);
         std::vector<mb::UngappedCounters> ctrs((size_t)n_units, mb::UngappedCounters{0, 0, 0});
         mb::UngappedCounters *ctr = ctrs.data();
@@ -463,7 +471,8 @@ int main(int argc, char **argv) {
             for (mb::DevHsp &d : u.ref.hsps) d.unit = 0;
             std::sort(mine.begin(), mine.end(), hsp_less);
             std::sort(u.ref.hsps.begin(), u.ref.hsps.end(), hsp_less);
-            const std::vector<int32_t> ext(extent.begin() + (long)u.dbase, extent.begin() + (long)u.dbase + (long)(u.tn + u.qn + 2));
+            std::vector<int32_t> ext(extent.begin() + (long)(ext_scrambled ? 0 : u.dbase), extent.begin() + (long)(ext_scrambled ? 0 : u.dbase) + (long)(u.tn + u.qn + 2));
+            if (ext_scrambled) for (size_t d = 0; d < ext.size(); d++) ext[d] = extent[(size_t)(((uint32_t)d * plane_mul) & plane_mask)];
             bool ok = anchors_ok && ctr[x].extended == u.ref.extended && ctr[x].cols == u.ref.cols && mine.size() == u.ref.hsps.size() && ext == u.ref.extent;
             for (size_t i = 0; ok && i < mine.size(); i++) ok = memcmp(&mine[i], &u.ref.hsps[i], sizeof(mb::DevHsp)) == 0;
             total_hsps += mine.size(); total_ref += u.ref.hsps.size();

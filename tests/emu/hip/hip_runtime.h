@@ -5,6 +5,7 @@
 // work-items) buffer between two wave barriers.  Workgroups run one after another.  Nothing of this is shipped, linked
 // into libmiblast.so, or measured; the product has no CPU path.
 #pragma once
+#define MB_EMU_HIP_STANDIN 1                  // (mb_guard.h: no virtual-memory calls here -- the electric fence is a device-only tool)
 
 #include <pthread.h>
 
@@ -33,6 +34,8 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
