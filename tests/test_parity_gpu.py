@@ -53,6 +53,11 @@ def test_case_matches_oracle(gpu_ctx, olz, monkeypatch, name, tf, qf, args):
     {"MIBLAST_BIN_MEAN": "40"},                                         # keys grouped by diagonal through MANY bins + LDS (mb_seed_bin.h; the default mean gives these cases one bin or two)
     {"MIBLAST_BIN_MEAN": "40", "MIBLAST_SEED_FUSED": "0"},              # ... strands one after the other
     {"MIBLAST_SORT_BIN": "0"},                                          # ... and not at all: rocprim's radix sort + k_keys_unhash, as before round 5
+    {"MIBLAST_SEED_PACKED": "2", "MIBLAST_UX_PACKED": "2"},             # round 6: the windows of the ungapped extension from the packed strands (k_ux_extend_pk) whatever the size ...
+    {"MIBLAST_SEED_PACKED": "2", "MIBLAST_UX_PACKED": "2", "MIBLAST_UNGAPPED": "ux"},      # ... with the level-synchronous pipeline forced (small cases take the run-per-lane kernel otherwise)
+    {"MIBLAST_SEED_PACKED": "2", "MIBLAST_UX_PACKED": "0", "MIBLAST_UNGAPPED": "ux"},      # ... and from the code bytes
+    {"MIBLAST_SEED_PACKED": "2", "MIBLAST_HIT_CAP": "3000", "MIBLAST_UX_PACKED": "2", "MIBLAST_UNGAPPED": "ux"},      # q batches: extent[] in the keys' scrambled order, batches through the bins, packed windows
+    {"MIBLAST_SEED_PACKED": "2", "MIBLAST_HIT_CAP": "3000", "MIBLAST_EXTENT_SCRAMBLE": "0", "MIBLAST_BATCH_BINS": "0"},      # ... a slot per plain diagonal, batches through the radix sort
 ], ids=lambda e: ",".join(f"{k[8:].lower()}={v}" for k, v in e.items()))
 def test_dense_seed_path_switches_match_oracle(gpu_ctx, olz, monkeypatch, env):
     """The seed stage of a large pair (mb_seed_dense.h: packed strands, q-ordered one-pass search -- k_seed_hits + k_seed_keys --, scrambled
