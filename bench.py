@@ -745,7 +745,7 @@ def run_rank(a):
                       "checked_inside_the_launch_per_step": tot["relay_inline_checks"] / per, "pieces_that_went_on_inside_per_step": tot["relay_inline_continued"] / per,
                       "reruns_per_step": tot["dp_reruns"] / per,
                       "traceback_ms_per_step": tot["t_traceback_ms"] / per, "merge_ms_per_step": tot["t_merge_ms"] / per},
-            "roofline": dp_roofline(tot, "r05_hbm_traffic_pmc.json" if a.workload == "evolver" else "r03_pair_hbm_traffic_pmc.json"),
+            "roofline": dp_roofline(tot, "r06_hbm_traffic_pmc.json" if a.workload == "evolver" else "r03_pair_hbm_traffic_pmc.json"),
             "hbm_read": phase_b_read(tot, per, elapsed / a.steps, world, work) if "t_bases" in tot else None,
             "host": {"cpu_seconds_per_step": tot["host_cpu_seconds"] / per, "busy_threads_avg": tot["host_cpu_seconds"] / world / max(1e-9, elapsed),
                      "cgroup_throttled_periods": tot["host_throttled_periods"], "cgroup_throttled_ms": tot["host_throttled_ms"],
