@@ -374,6 +374,7 @@ int main(int argc, char **argv) {
             extent.assign((size_t)plane_mask + 1, 0);
             for (size_t d = 0; d < extent0.size(); d++) extent[(size_t)(((uint32_t)d * plane_mul) & plane_mask)] = extent0[d];
             ut.ext_mul = plane_mul; ut.ext_mask = plane_mask;
+            printf("  extent slots in the order of the scrambled keys\n");
         }
         std::vector<mb::DevHsp> hsps((size_t)n_hits + 8);
         std::vector<mb::UngappedCounters> ctrs((size_t)n_units, mb::UngappedCounters{0, 0, 0});

@@ -31,6 +31,17 @@ def test_emulated_ungapped_kernels_match_the_sequential_rule(mode, seed, cases):
     assert out.count(" ok\n") == cases and "MISMATCH" not in out, out
 
 
+def test_emulated_packed_windows_and_scrambled_extent_slots_match_the_sequential_rule():
+    """Round 6: level 1 and 2 of the level-synchronous pipeline from the PACKED strands (k_ux_extend_pk: 12-byte records of 32 bases, code bytes
+    through a table in LDS; windows with an N, a separator or an end of the set take the byte loads) and extent[] kept in the order of the
+    scrambled keys (UnitTab::ext_mul: a strand in several q batches) -- same HSPs, counters and extents as the sequential rule."""
+    p = subprocess.run([EMU, "3", "16", "ux"], capture_output=True, timeout=1800)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert out.count(" ok\n") == 16 and "MISMATCH" not in out, out
+    assert out.count("level 1 from the packed strands") >= 3 and out.count("extent slots in the order of the scrambled keys") >= 1, out
+
+
 def test_emulated_batched_seed_stage_matches_the_rule():
     """cactus_amd/csrc/mb_seed_batch.h on the host: the sparse seed tables of several targets (bitmap + rank directory + CSR) hold
     exactly the positions SURVEY A.3 indexes, and the seed search over all (pair, strand) units of a call writes, unit by unit in
