@@ -115,7 +115,10 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
     const int64_t cap = std::min<int64_t>(kBlockCap, std::max<int64_t>(64, env_ll("MIBLAST_BLOCK_BASES", kBlockCap)));
     // one header / end marker per job, suppression state shared by diagonals 65536 apart (diag=hash16), earlier alignments as walls
     // for later ones: such jobs are not assembled from blocks
-    const bool one_block_only = p.format != 0 || p.markend || p.diag_hash16 || p.walls;
+    // (round 6: --format=general and --markend ARE assembled from blocks now -- the HSP lists of a query block's target blocks merged in the
+    //  order one search over the whole target finds them, below)
+    const bool one_block_only = p.diag_hash16 || p.walls;
+    const bool general = p.format != 0;
     const int step = std::max(1, p.step);
 
     // ---- blocks and the job grid ---------------------------------------------------------------------------------
@@ -137,11 +140,11 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
         if (rc == MIBLAST_OK) rc = partition(Q, cap, one_block_only ? cap : q_limit, qblk[k]);
         if (rc != MIBLAST_OK) return rc;
         if (one_block_only && (tblk[k].size() > 1 || qblk[k].size() > 1)) {
-            set_error("--format=general / --markend / --miblast-diag=hash16 / --miblast-walls jobs are not assembled from blocks: input longer than 2^30 bases");
+            set_error("--miblast-diag=hash16 / --miblast-walls jobs are not assembled from blocks: input longer than 2^30 bases");
             return MIBLAST_ELIMIT;
         }
-        if (tblk[k].size() > 1 && (p.queryhspbest > 0 || p.queryhsplimit > 0)) {
-            set_error("--queryhspbest / --queryhsplimit rank HSPs over the whole target: not available when the target needs more than one block "
+        if (tblk[k].size() > 1 && (p.queryhspbest > 0 || (p.queryhsplimit > 0 && !general))) {
+            set_error("--queryhspbest (and --queryhsplimit before a gapped stage) rank HSPs over the whole target: not available when the target needs more than one block "
                       "(KegAlign's option sets do not pass them, cactus_progressive_config.xml:138-146)");
             return MIBLAST_ELIMIT;
         }
@@ -234,6 +237,71 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
     // ---- assembly in the order of one job over the whole files ------------------------------------------------------
     paf.clear();
     size_t x0 = 0;
+    if (general) {
+        // --format=general:name1,zstart1,end1,name2,zstart2+,end2+ [--markend] (the repeat masker's call, cactus_lastzRepeatMask.py:97-105): ONE
+        // header line, then per query sequence (file order) the '+' HSPs and the '-' HSPs in the order one search over the WHOLE target finds
+        // them -- query position ascending, word variant, target position descending (seed_host, mb_pipeline.cpp) --, at most --queryhsplimit
+        // per query sequence and strand (every block kept its own first N: the first N of the whole target are among them), one end marker.
+        auto put_num = [&](int64_t v) { char buf[24]; int n = snprintf(buf, sizeof buf, "%lld", (long long)v); paf.append(buf, (size_t)n); };
+        for (size_t k = 0; k < n_pairs; k++) {
+            const SeqSet &T = *Ts[k], &Q = *Qs[k];
+            const size_t n_tb = tblk[k].size(), n_qb = qblk[k].size();
+            if (n_tb == 1 && n_qb == 1) { paf += jobs[x0]->res.paf; x0 += 1; continue; }      // (one block pair: the job's own text)
+            paf += "#name1\tzstart1\tend1\tname2\tzstart2+\tend2+\n";
+            const uint8_t *th = T.host(), *qh = Q.host();
+            for (size_t qb = 0; qb < n_qb; qb++) {
+                const Block &QB = qblk[k][qb];
+                struct Ent { int32_t qc, strand, q_end, rank; int64_t neg_t; const miblast_hsp *h; int64_t t_origin; };
+                std::vector<Ent> ents;
+                for (size_t tb = 0; tb < n_tb; tb++) {
+                    const Result &r = jobs[x0 + qb * n_tb + tb]->res;
+                    const Block &TB = tblk[k][tb];
+                    for (const miblast_hsp &h : r.hsps) {
+                        // the word variant that made the hit (0 exact, 1 + k a transition at care position k): the 19 bases before the seed end
+                        // in the target and in the searched strand of the query -- the '-' strand read off the '+' strand's codes, contig-wise mirrored
+                        uint8_t tw[kSeedSpan], qw[kSeedSpan];
+                        const int64_t t_end = TB.origin + h.seed_t_end;
+                        for (int c = 0; c < kSeedSpan; c++) tw[c] = th[t_end - kSeedSpan + c];
+                        const int qc_g = QB.c0 + h.q_contig;
+                        const int64_t cst = Q.starts[(size_t)qc_g], cln = Q.lens[(size_t)qc_g];
+                        const int64_t q_in = (int64_t)h.seed_q_end - (cst - QB.origin);          // seed end inside the contig, on the searched strand
+                        for (int c = 0; c < kSeedSpan; c++) {
+                            const int64_t ps = q_in - kSeedSpan + c;
+                            if (!h.strand) qw[c] = qh[cst + ps];
+                            else { const uint8_t b = qh[cst + (cln - 1 - ps)]; qw[c] = (uint8_t)((b & 4u) ? b : (b & ~3u) | (3u - (b & 3u))); }
+                        }
+                        ents.push_back(Ent{qc_g, h.strand, h.seed_q_end, seed_variant_rank(tw, qw), -t_end, &h, TB.origin});
+                    }
+                }
+                std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) {
+                    if (a.qc != b.qc) return a.qc < b.qc;
+                    if (a.strand != b.strand) return a.strand < b.strand;
+                    if (a.q_end != b.q_end) return a.q_end < b.q_end;
+                    if (a.rank != b.rank) return a.rank < b.rank;
+                    return a.neg_t < b.neg_t;
+                });
+                int cur_qc = -1, cur_strand = -1; int64_t taken = 0;
+                for (const Ent &e : ents) {
+                    if (e.qc != cur_qc || e.strand != cur_strand) { cur_qc = e.qc; cur_strand = e.strand; taken = 0; }
+                    if (p.queryhsplimit > 0 && taken >= p.queryhsplimit) continue;
+                    taken++;
+                    const miblast_hsp &h = *e.h;
+                    const int64_t t_start = e.t_origin + h.t_start;
+                    const int tcg = T.contig_of(t_start);
+                    const int64_t cst = Q.starts[(size_t)e.qc], cln = Q.lens[(size_t)e.qc];
+                    int64_t qs = (int64_t)h.q_start - (cst - QB.origin), qe = qs + h.len;
+                    if (h.strand) { const int64_t s2 = cln - qe, e2 = cln - qs; qs = s2; qe = e2; }
+                    paf += T.names[(size_t)tcg]; paf.push_back('\t');
+                    put_num(t_start - T.starts[(size_t)tcg]); paf.push_back('\t');
+                    put_num(t_start - T.starts[(size_t)tcg] + h.len); paf.push_back('\t');
+                    paf += Q.names[(size_t)e.qc]; paf.push_back('\t');
+                    put_num(qs); paf.push_back('\t'); put_num(qe); paf.push_back('\n');
+                }
+            }
+            if (p.markend) paf += "# lastz end-of-file\n";
+            x0 += n_tb * n_qb;
+        }
+    } else
     for (size_t k = 0; k < n_pairs; k++) {
         const size_t n_tb = tblk[k].size(), n_qb = qblk[k].size();
         for (size_t qb = 0; qb < n_qb; qb++) {

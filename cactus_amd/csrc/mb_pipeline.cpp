@@ -1228,6 +1228,8 @@ static std::shared_ptr<SetDerived> acquire_packed_target(Ctx &ctx, const SeqSet 
     return d;
 }
 
+int seed_variant_rank(const uint8_t *t19, const uint8_t *q19) { return variant_rank(t19, q19, kSeedSpan, kSeedSpan); }
+
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions) {
     MB_HIP(hipSetDevice(ctx.device));
     ctx.ws->stage.abort();

@@ -66,6 +66,9 @@ private:
 int set_host_threads(int n);      // 0 = automatic; returns the threads in use or -1 (a job is running)
 int host_threads();
 int export_index(Ctx &ctx, const SeqSet &T, int step, uint32_t **offsets, uint32_t **positions);
+// rank of the word variant behind a seed hit (0: the words are equal; 1 + k: a transition at care position k; 99: neither) from the 19 code
+// bytes before the seed end in the target and in the searched strand of the query: the middle key of the order a sequential search finds hits in
+int seed_variant_rank(const uint8_t *t19, const uint8_t *q19);
 
 }  // namespace mb
 

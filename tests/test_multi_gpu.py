@@ -125,6 +125,49 @@ def test_run_kegalign_front_end_uses_every_gpu_of_the_job(olz, tmp_path, monkeyp
     assert p.returncode != 0 and b"num_gpu" in p.stderr
 
 
+@pytest.mark.parametrize("limit", [0, 7, 2])
+def test_repeat_mask_call_assembled_from_blocks_equals_one_oracle_run(olz, monkeypatch, limit):
+    """The repeat masker's call (cactus_lastzRepeatMask.py:97-105: fragments against the assembly, --ungapped --format=general:... --markend,
+    --queryhsplimit=keep,nowarn:N) on a target that needs SEVERAL blocks (round 6; refused until then): one header line, the HSPs of every
+    query sequence in the order one search over the whole target finds them (query position, word variant, target position descending --
+    copies of a repeat in different blocks hit the same query position), at most N per sequence and strand, one end marker: the bytes of ONE
+    oracle run over the whole files.  Several query blocks too (two logical devices)."""
+    from cactus_amd import gen, miblast
+    from cactus_amd.preprocessor.lastz_repeat_mask import fasta_fragments
+    rng = np.random.default_rng(31 + limit)
+    unit = gen.random_sequence(500, rng)
+    trecs = []
+    for c in range(6):
+        parts = []
+        for k in range(5):
+            parts.append(gen.random_sequence(int(rng.integers(400, 1500)), rng))
+            parts.append(gen.mutate(unit, rng, 0.04, 0.0) if (k + c) % 2 == 0 else gen.revcomp(gen.mutate(unit, rng, 0.05, 0.0)))
+        trecs.append(("id=E|c%d" % c, np.concatenate(parts)))
+    tf = gen.fasta_bytes(trecs)
+    qf = fasta_fragments(tf.decode(), 200, 100, "zero").encode()
+    args = "--step=3 --ambiguous=iupac,100,100 --ungapped --format=general:name1,zstart1,end1,name2,zstart2+,end2+ --markend".split()
+    if limit:
+        args.insert(4, "--queryhsplimit=keep,nowarn:%d" % limit)
+    pm, want = _oracle(olz, tf, qf, args)
+    assert want["paf"].count(b"\n") > 300 and want["paf"].endswith(b"# lastz end-of-file\n")
+    m = miblast.Multi(1)
+    try:
+        whole, _ = m.align_fasta_pairs([(tf, qf)], pm)
+        assert whole == want["paf"]
+        monkeypatch.setenv("MIBLAST_BLOCK_BASES", "9000")          # the target in three or four blocks, the fragments in several
+        blocked, _ = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert blocked == want["paf"]
+    monkeypatch.setenv("MIBLAST_DEVICE_MAP", "0,0")
+    m = miblast.Multi(2)
+    try:
+        two, _ = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert two == want["paf"]
+
+
 def test_limits_of_the_blocked_path_are_refused_loudly(monkeypatch):
     from cactus_amd import miblast
     tf, qf = genome_like(404)
