@@ -728,7 +728,13 @@ struct ArenaPool {
     }
 };
 ArenaPool &arena_pool() { static ArenaPool *a = new ArenaPool(); return *a; }
-std::atomic<unsigned> &arena_scale_q8() { static std::atomic<unsigned> s{256}; return s; }      // estimate x this / 256 (grows when a stage had to grow its arena)
+// estimate x this / 256 (grows when a stage had to grow its arena).  Per CONTEXT since round 6 (Workspace::arena_scale of the context that owns the
+// call, its lanes point there): the factor was one per process, and in a process that runs several kinds of jobs -- the bench line: the phase's
+// small pairs, then chr20, then 42 human-mouse chunk pairs, each leg in a context of its own -- what an outlier stage of one kind had taught (16 x)
+// made every stage of the next kind ask for arenas of 16 GiB where 1 GiB holds its trace: new ones were allocated in the middle of timed steps
+// (0.7 s each, a step of 620 ms among steps of 146).  The process-wide one stays as the fallback of a context without an owner.
+std::atomic<unsigned> &arena_scale_q8() { static std::atomic<unsigned> s{256}; return s; }
+std::atomic<unsigned> &arena_scale_of(Ctx &ctx) { return ctx.arena_scale ? *ctx.arena_scale : arena_scale_q8(); }
 }  // namespace
 
 // seed position table of a target (CSR over the 2^24 seed words + occupancy bitmap of the buckets) and the packed form of a strand
@@ -806,6 +812,7 @@ struct Workspace {                      // device buffers that persist across mi
     // the device at the same time
     std::vector<Ctx *> lanes;
     // (of a context's own workspace) high-water marks of the gapped stage's tables over all lanes: DevBuf::hw of the lanes' buffers point here
+    std::atomic<unsigned> arena_scale{256};          // (of a context's own workspace) see arena_scale_q8
     std::atomic<size_t> gapped_hw[16] = {};
     void share_marks(Workspace &owner) {
         std::atomic<size_t> *m = owner.gapped_hw;
@@ -861,7 +868,7 @@ void ctx_pair_streams(Ctx &ctx) {
     MB_HIP(hipSetDevice(ctx.device));
     Workspace &w = *ctx.ws;
     const size_t gapped_lanes = (size_t)std::min<long>(8, std::max(1l, env_long("MIBLAST_GAPPED_LANES", 2)));
-    while (w.lanes.size() + 1 < gapped_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); }
+    while (w.lanes.size() + 1 < gapped_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); w.lanes.back()->arena_scale = ctx.arena_scale; }
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     for (Ctx *l : w.lanes) MB_HIP(hipEventRecord(l->ev0, l->stream));
     MB_HIP(hipStreamSynchronize(ctx.stream));
@@ -2664,7 +2671,7 @@ static int acquire_trace_arena(Ctx &ctx, const miblast_params &p, std::vector<Pa
     }
     arena_raw_estimate = want;
     // (a stage that had to grow its arena teaches the estimate: the largest ratio of what was needed to what was estimated so far)
-    want = (size_t)((double)want * (double)arena_scale_q8().load() / 256.0);
+    want = (size_t)((double)want * (double)arena_scale_of(ctx).load() / 256.0);
     { size_t cls = (size_t)1 << 30; while (cls < want) cls <<= 1; want = cls; }      // (size classes: 1 GiB, 2 GiB, ... -- the pool's arenas are reused, not multiplied)
     if (getenv("MIBLAST_ARENA_MB")) want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
     // (MIBLAST_ARENA_MB: an arena of exactly that size, whatever the pool holds -- the tests' way into the grow-and-retry path)
@@ -2729,8 +2736,8 @@ static int grow_trace_arena(Ctx &ctx, size_t arena_raw_estimate) {
     if (arena_raw_estimate) {
         // (what one outlier stage needed teaches the estimate of every later stage of the process: at most 16 x, not without bound)
         const unsigned need = (unsigned)std::min<double>(16.0 * 256.0, std::ceil((double)g.arena.n * 256.0 / (double)arena_raw_estimate));
-        unsigned cur = arena_scale_q8().load();
-        while (need > cur && !arena_scale_q8().compare_exchange_weak(cur, need)) {}
+        unsigned cur = arena_scale_of(ctx).load();
+        while (need > cur && !arena_scale_of(ctx).compare_exchange_weak(cur, need)) {}
     }
     return MIBLAST_OK;
 }
@@ -3915,6 +3922,8 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
     const double t_call0 = now_s();
     MB_HIP(hipSetDevice(ctx.device));
     ctx.ws->share_marks(*ctx.ws);                          // (the context's own tables take part in its lanes' high-water marks)
+    if (!ctx.arena_scale) ctx.arena_scale = &ctx.ws->arena_scale;
+    for (Ctx *l : ctx.ws->lanes) l->arena_scale = ctx.arena_scale;
     Pool::Hot keep_workers_awake;
     ctx.ws->stage.abort();
     for (Ctx *lane : ctx.ws->lanes) lane->ws->stage.abort();
@@ -3989,7 +3998,7 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         // lane runs the device half of a pair's seed stage, then the host half (discovery order, entropy filter, anchors)
         // while the other lanes keep the device busy.  A pair's result does not depend on its lane.
         Workspace &w = *ctx.ws;
-        while (w.lanes.size() < n_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); }
+        while (w.lanes.size() < n_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); w.lanes.back()->arena_scale = ctx.arena_scale; }
         for (Ctx *l : w.lanes) { l->spans = ctx.spans; l->hits_hint = &w.hits_hint; l->ws->share_marks(w); }
         int64_t max_diags = 0;
         for (size_t k = 0; k < n; k++) max_diags = std::max<int64_t>(max_diags, Ts[k]->total + Qs[k]->total);
@@ -4145,7 +4154,7 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         for (Unit &u : units) gunits[group_of[(size_t)u.pair]].push_back(std::move(u));
         units.clear();
         Workspace &w0 = *ctx.ws;
-        while (w0.lanes.size() + 1 < L) { w0.lanes.push_back(lane_create(ctx.device, ctx.priority)); w0.lanes.back()->ws->share_marks(w0); }
+        while (w0.lanes.size() + 1 < L) { w0.lanes.push_back(lane_create(ctx.device, ctx.priority)); w0.lanes.back()->ws->share_marks(w0); w0.lanes.back()->arena_scale = ctx.arena_scale; }
         for (Ctx *l : w0.lanes) l->spans = ctx.spans;
         std::vector<PairPtrs> pp(n);
         for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }
