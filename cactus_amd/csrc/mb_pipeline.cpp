@@ -716,6 +716,12 @@ struct ArenaPool {
         }
         for (const A &a : drop) { count_device_alloc(); note_device_alloc("(release) trace arena", a.n); (void)hipFree(a.p); }
     }
+    size_t count_free(int device, size_t at_least) {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t n = 0;
+        for (const A &a : free_list) n += a.device == device && a.n >= at_least;
+        return n;
+    }
     // everything that lies free on the device back to the runtime (a stage that needs most of the device's memory for its arena)
     void trim(int device) {
         std::vector<A> drop;
@@ -813,6 +819,7 @@ struct Workspace {                      // device buffers that persist across mi
     std::vector<Ctx *> lanes;
     // (of a context's own workspace) high-water marks of the gapped stage's tables over all lanes: DevBuf::hw of the lanes' buffers point here
     std::atomic<unsigned> arena_scale{256};          // (of a context's own workspace) see arena_scale_q8
+    std::atomic<size_t> arena_class{0};              // ... the largest trace arena a stage of the context has asked for (reserve_arenas)
     std::atomic<size_t> gapped_hw[16] = {};
     void share_marks(Workspace &owner) {
         std::atomic<size_t> *m = owner.gapped_hw;
@@ -828,6 +835,10 @@ struct Workspace {                      // device buffers that persist across mi
 };
 
 Workspace *workspace_create() { return new Workspace(); }
+static std::atomic<size_t> &arena_class_of(Ctx &ctx) {
+    static std::atomic<size_t> process_wide{0};
+    return ctx.arena_class ? *ctx.arena_class : process_wide;
+}
 
 static Ctx *lane_create(int device, int priority) {
     Ctx *c = new Ctx();
@@ -868,7 +879,7 @@ void ctx_pair_streams(Ctx &ctx) {
     MB_HIP(hipSetDevice(ctx.device));
     Workspace &w = *ctx.ws;
     const size_t gapped_lanes = (size_t)std::min<long>(8, std::max(1l, env_long("MIBLAST_GAPPED_LANES", 2)));
-    while (w.lanes.size() + 1 < gapped_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); w.lanes.back()->arena_scale = ctx.arena_scale; }
+    while (w.lanes.size() + 1 < gapped_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); w.lanes.back()->arena_scale = ctx.arena_scale; w.lanes.back()->arena_class = ctx.arena_class; }
     MB_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     for (Ctx *l : w.lanes) MB_HIP(hipEventRecord(l->ev0, l->stream));
     MB_HIP(hipStreamSynchronize(ctx.stream));
@@ -2652,6 +2663,36 @@ static void gapped_commit_and_nominate(std::vector<PairJob *> &jobs, std::vector
     }
 }
 
+// What a stage USED of its arena teaches the factor of its context (round 6; before, a stage that had outgrown its arena taught the size that
+// finally held it -- four times the one before -- up to 16 x: 16 GiB arenas for stages whose trace is 1 GiB, 0.7 s of hipMalloc each whenever
+// more of them ran side by side than the pool held).  The factor follows 1.5 x the largest used / estimated ratio met, the class of the largest
+// arena asked for is remembered (reserve_arenas).
+static void arena_learn(Ctx &ctx, size_t raw_estimate, unsigned long long used) {
+    if (!raw_estimate || !used) return;
+    const unsigned need = (unsigned)std::min<double>(64.0 * 256.0, std::ceil(1.5 * (double)used * 256.0 / (double)raw_estimate));
+    std::atomic<unsigned> &sc = arena_scale_of(ctx);
+    unsigned cur = sc.load();
+    while (need > cur && !sc.compare_exchange_weak(cur, need)) {}
+}
+static std::atomic<size_t> &arena_class_of(Ctx &ctx);     // (the largest arena a stage of the context has asked for: Workspace::arena_class)
+
+// Before the lanes of a pipelined call start: enough arenas of the context's largest class in the pool for the stages that may run side by side
+// (at most `stages`, at most MIBLAST_ARENA_RESERVE_MB -- 32 GiB -- of them in all), so that no lane has to make one in the middle of the call.
+static void reserve_arenas(Ctx &ctx, size_t stages) {
+    if (getenv("MIBLAST_ARENA_MB")) return;
+    const size_t cls = arena_class_of(ctx).load(std::memory_order_relaxed);
+    if (!cls || !stages) return;
+    const size_t budget = (size_t)std::max(0l, env_long("MIBLAST_ARENA_RESERVE_MB", 32l << 10)) << 20;
+    const size_t n_want = std::min(stages, std::max<size_t>(1, budget / cls));
+    size_t have = arena_pool().count_free(ctx.device, cls);
+    for (; have < n_want; have++) {
+        uint8_t *p = nullptr;
+        count_device_alloc(); note_device_alloc("trace arena (reserved at the start of a call)", cls);
+        if (hipMalloc((void **)&p, cls) != hipSuccess) { (void)hipGetLastError(); break; }
+        arena_pool().give(ctx.device, p, cls);
+    }
+}
+
 // the trace arena of a stage: borrowed from the pool (or made) at a size estimated from the anchors' HSPs
 static int acquire_trace_arena(Ctx &ctx, const miblast_params &p, std::vector<PairJob *> &jobs, const std::vector<size_t> *members, size_t n_members,
                                size_t &arena_raw_estimate) {
@@ -2674,6 +2715,7 @@ static int acquire_trace_arena(Ctx &ctx, const miblast_params &p, std::vector<Pa
     want = (size_t)((double)want * (double)arena_scale_of(ctx).load() / 256.0);
     { size_t cls = (size_t)1 << 30; while (cls < want) cls <<= 1; want = cls; }      // (size classes: 1 GiB, 2 GiB, ... -- the pool's arenas are reused, not multiplied)
     if (getenv("MIBLAST_ARENA_MB")) want = (size_t)env_long("MIBLAST_ARENA_MB", 4096) << 20;
+    else { std::atomic<size_t> &cm = arena_class_of(ctx); size_t cur = cm.load(); while (want > cur && !cm.compare_exchange_weak(cur, want)) {} }
     // (MIBLAST_ARENA_MB: an arena of exactly that size, whatever the pool holds -- the tests' way into the grow-and-retry path)
     if (getenv("MIBLAST_ARENA_MB") || !arena_pool().take(ctx.device, want, g.arena.p, g.arena.n) || g.arena.n < want) {
         arena_pool().give(ctx.device, g.arena.p, g.arena.n);        // (too small a one: it stays in the pool for a lighter stage)
@@ -2733,12 +2775,7 @@ static int grow_trace_arena(Ctx &ctx, size_t arena_raw_estimate) {
         }
         g.arena.n = bigger;
     }
-    if (arena_raw_estimate) {
-        // (what one outlier stage needed teaches the estimate of every later stage of the process: at most 16 x, not without bound)
-        const unsigned need = (unsigned)std::min<double>(16.0 * 256.0, std::ceil((double)g.arena.n * 256.0 / (double)arena_raw_estimate));
-        unsigned cur = arena_scale_of(ctx).load();
-        while (need > cur && !arena_scale_of(ctx).compare_exchange_weak(cur, need)) {}
-    }
+    (void)arena_raw_estimate;                                  // (the factor learns from what the stage USED, at its end: arena_learn)
     return MIBLAST_OK;
 }
 
@@ -3081,6 +3118,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
     memset(&st, 0, sizeof st);
     const double t_g0 = now_s();
     size_t arena_raw_estimate = 0;
+    unsigned long long arena_used = 0;                                    // the most a round of this stage wrote into its arena
     struct ArenaLoan {                                                   // back to the pool however the stage ends
         Workspace &g; int device;
         ~ArenaLoan() { arena_pool().give(device, g.arena.p, g.arena.n); g.arena.p = nullptr; g.arena.n = 0; }
@@ -3494,8 +3532,11 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
                                 upload_wall_refs(launched, pieces.size()), (int)launched, d_vjobs, stamp, (int)relay_inline_force);
                 launch_verify(d_vjobs, d_vres, (int)v_new, g.snaps.p, p.ydrop, p.gap_extend, s);
                 g.stage.d2h2(outs.data() + launched, n_new * sizeof(DpOut), vres.data() + vlaunched, v_new * sizeof(VerifyOut), g.dp_down.p, s);
+                unsigned long long arena_now = 0;                       // what the round's trace has taken of the arena so far (the same copy-back)
+                g.stage.d2h(&arena_now, g.arena_next.p, 8, s);
                 MB_HIP(hipStreamSynchronize(s));
                 g.stage.done();
+                arena_used = std::max(arena_used, arena_now);
                 collect_dp_time(ctx, st);
                 lap(2);
                 if (debug) fprintf(stderr, "[miblast]   first pass (kernel %d): dp kernel total %.2f ms\n", dp_kernel, st.t_dp_kernel_ms);
@@ -3728,6 +3769,7 @@ static int gapped_phase(Ctx &ctx, const miblast_params &p, std::vector<PairJob *
         if (debug) fprintf(stderr, "[miblast]   round %d host timeline: commit+nominate %.2f ms, plant %.2f, launches+sync %.2f, advance+continuations %.2f, results+traceback %.2f\n",
                            round, tm[0] * 1e3, tm[1] * 1e3, tm[2] * 1e3, tm[3] * 1e3, tm[4] * 1e3);
     }
+    arena_learn(ctx, arena_raw_estimate, arena_used);
     st.t_gapped = now_s() - t_g0;
     for (size_t jk = 0; jk < n_members; jk++) {      // launch-level figures are shared by the pairs that were in flight together
         PairJob *j = jobs[members ? (*members)[jk] : jk];
@@ -3922,8 +3964,8 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
     const double t_call0 = now_s();
     MB_HIP(hipSetDevice(ctx.device));
     ctx.ws->share_marks(*ctx.ws);                          // (the context's own tables take part in its lanes' high-water marks)
-    if (!ctx.arena_scale) ctx.arena_scale = &ctx.ws->arena_scale;
-    for (Ctx *l : ctx.ws->lanes) l->arena_scale = ctx.arena_scale;
+    if (!ctx.arena_scale) { ctx.arena_scale = &ctx.ws->arena_scale; ctx.arena_class = &ctx.ws->arena_class; }
+    for (Ctx *l : ctx.ws->lanes) { l->arena_scale = ctx.arena_scale; l->arena_class = ctx.arena_class; }
     Pool::Hot keep_workers_awake;
     ctx.ws->stage.abort();
     for (Ctx *lane : ctx.ws->lanes) lane->ws->stage.abort();
@@ -3998,7 +4040,7 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         // lane runs the device half of a pair's seed stage, then the host half (discovery order, entropy filter, anchors)
         // while the other lanes keep the device busy.  A pair's result does not depend on its lane.
         Workspace &w = *ctx.ws;
-        while (w.lanes.size() < n_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); w.lanes.back()->arena_scale = ctx.arena_scale; }
+        while (w.lanes.size() < n_lanes) { w.lanes.push_back(lane_create(ctx.device, ctx.priority)); w.lanes.back()->ws->share_marks(w); w.lanes.back()->arena_scale = ctx.arena_scale; w.lanes.back()->arena_class = ctx.arena_class; }
         for (Ctx *l : w.lanes) { l->spans = ctx.spans; l->hits_hint = &w.hits_hint; l->ws->share_marks(w); }
         int64_t max_diags = 0;
         for (size_t k = 0; k < n; k++) max_diags = std::max<int64_t>(max_diags, Ts[k]->total + Qs[k]->total);
@@ -4015,6 +4057,7 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         //  put two of the three heavy diagonal pairs on one lane.  MIBLAST_PIPELINE_GROUP fixes the size)
         const size_t group = !pipeline ? 1 : (size_t)std::max(1l, env_long("MIBLAST_PIPELINE_GROUP", n >= 4 * n_lanes ? (long)std::min<size_t>(8, (n + n_lanes - 1) / n_lanes) : 1l));
         const size_t n_groups = (n + group - 1) / group;
+        reserve_arenas(ctx, std::min(n_lanes, n_groups));          // (nothing of the call is queued yet: the allocations stall nobody)
         group_leader.assign(n, 0); lane_gapped.assign(n_lanes, 0.0);
         for (size_t lane = 0; lane < n_lanes; lane++)
             lane_threads.push_back(std::async(std::launch::async, [&, lane] {
@@ -4154,7 +4197,7 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         for (Unit &u : units) gunits[group_of[(size_t)u.pair]].push_back(std::move(u));
         units.clear();
         Workspace &w0 = *ctx.ws;
-        while (w0.lanes.size() + 1 < L) { w0.lanes.push_back(lane_create(ctx.device, ctx.priority)); w0.lanes.back()->ws->share_marks(w0); w0.lanes.back()->arena_scale = ctx.arena_scale; }
+        while (w0.lanes.size() + 1 < L) { w0.lanes.push_back(lane_create(ctx.device, ctx.priority)); w0.lanes.back()->ws->share_marks(w0); w0.lanes.back()->arena_scale = ctx.arena_scale; w0.lanes.back()->arena_class = ctx.arena_class; }
         for (Ctx *l : w0.lanes) l->spans = ctx.spans;
         std::vector<PairPtrs> pp(n);
         for (size_t k = 0; k < n; k++) { pp[k].tc = jobs[k]->T->dev(); pp[k].qf = jobs[k]->qc_d[0]; pp[k].qr = jobs[k]->qc_d[1]; }

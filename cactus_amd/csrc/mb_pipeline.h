@@ -25,6 +25,7 @@ struct Ctx {
     void *chain_cache = nullptr;        // device buffers the chaining stage keeps between calls (mp_chain.cpp)
     DpSpans *spans = nullptr;           // where this context's DP launches report their intervals during a call (mb_pipeline.cpp)
     std::atomic<unsigned> *arena_scale = nullptr;   // what the trace arenas' estimate is multiplied by (x / 256): the context's own, shared with its lanes (mb_pipeline.cpp)
+    std::atomic<size_t> *arena_class = nullptr;     // ... and the largest arena a stage of the context has asked for
     std::atomic<unsigned long long> *hits_hint = nullptr;   // a lane: the largest strand (seed hits) any lane of its context has met -- its buffers are sized for that before a call's kernels are queued
 };
 void chain_cache_destroy(void *cache);  // mp_chain.cpp
