@@ -3945,7 +3945,20 @@ static void presize_lane(Ctx &lc, int64_t max_diags) {
     w.presize_gapped();                                    // the gapped stage's tables at the largest size any lane of the context has needed
     const unsigned long long hint = lc.hits_hint->load(std::memory_order_relaxed);
     const int64_t hit_cap = getenv("MIBLAST_HIT_CAP") ? env_long("MIBLAST_HIT_CAP", 32l << 20) : env_long("MIBLAST_DENSE_HIT_CAP", 128l << 20);
-    if (hint == 0 || 2 * (hint + hint / 8) > (unsigned long long)hit_cap) return;
+    if (hint == 0) return;
+    if (2 * (hint + hint / 8) > (unsigned long long)hit_cap) {
+        // strands in q batches (a 30 Mb x 30 Mb pair under the default option set: 4 x 10^8 hits per strand): every batch's buffers at the size of
+        // the largest batch there can be, ONCE -- the batches of a strand differ in size, and a lane that met a slightly larger one in a later step
+        // made its key, HSP and head buffers anew in the middle of that step (hm30: a step of 928 ms among steps of 228)
+        const size_t want = (size_t)hit_cap;
+        w.keys_a.ensure(want); w.keys_b.ensure(want); w.hsps.ensure(want);
+        w.heads.ensure(2 * want + want / 4 + 64); w.n_heads.ensure(8);
+        const int diag_bits = std::min(30, std::max(1, (int)std::ceil(std::log2((double)(max_diags + 2)))));
+        (void)ux_scratch(w, nullptr, want, (int64_t)1 << diag_bits);
+        w.sort_temp.ensure(sort_keys_temp_bytes((int64_t)want, 32 + diag_bits) + 16);
+        w.extent.ensure(((size_t)1 << diag_bits) + 8);
+        return;
+    }
     const size_t want = (size_t)(hint + hint / 8);
     w.keys_a.ensure(2 * want); w.keys_b.ensure(want); w.hsps.ensure(2 * want);
     w.heads.ensure(2 * want + want / 4 + 64); w.n_heads.ensure(8);
