@@ -39,6 +39,18 @@ double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+void release_idle_arenas();          // (the pool's free trace arenas of the current device back to the runtime: defined beside ArenaPool)
+
+// A buffer that does not fit while the pool of trace arenas holds idle ones (up to a third of the device, plus what a call reserved): those go
+// back to the runtime and the allocation is tried once more before the call gives up.
+inline hipError_t device_malloc_or_trim(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    release_idle_arenas();
+    return hipMalloc(p, bytes);
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -54,7 +66,7 @@ struct DevBuf {
         n = count;
         if (count) { count_device_alloc(); note_device_alloc(__PRETTY_FUNCTION__, count * sizeof(T)); }
         if (count && guard::on()) MB_HIP(guard::alloc((void **)&p, count * sizeof(T), __PRETTY_FUNCTION__));
-        else if (count) MB_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        else if (count) MB_HIP(device_malloc_or_trim((void **)&p, count * sizeof(T)));
         if (getenv("MIBLAST_DEBUG_ALLOC") && now_s() - t0 > 0.02) fprintf(stderr, "[miblast] slow device allocation: %.1f MB in %.1f ms\n", count * sizeof(T) / 1e6, (now_s() - t0) * 1e3);
     }
     // hw: a high-water mark shared by the same buffer of every lane of a context (Workspace::gapped_hw).  Which lane meets the heaviest group of
@@ -734,6 +746,10 @@ struct ArenaPool {
     }
 };
 ArenaPool &arena_pool() { static ArenaPool *a = new ArenaPool(); return *a; }
+void release_idle_arenas() {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) arena_pool().trim(dev);
+}
 // estimate x this / 256 (grows when a stage had to grow its arena).  Per CONTEXT since round 6 (Workspace::arena_scale of the context that owns the
 // call, its lanes point there): the factor was one per process, and in a process that runs several kinds of jobs -- the bench line: the phase's
 // small pairs, then chr20, then 42 human-mouse chunk pairs, each leg in a context of its own -- what an outlier stage of one kind had taught (16 x)
