@@ -19,8 +19,11 @@
 //         positions with (block origin + p) % step == 0; what does depend on the whole target is the ORDER in which
 //         a query sequence's alignments are written (anchor order: HSP score descending, then t, then q -- A.6/A.8),
 //         so the blocks' lists are merged on that key with t in whole-file coordinates;
-//       - the per-query HSP limits (--queryhspbest / --queryhsplimit) rank HSPs over the whole target: they are
-//         refused when the target needs more than one block (KegAlign's option sets never pass them, xml:138-146).
+//       - --queryhspbest=N ranks a query sequence's HSPs over the whole target: when the target needs more than one block the seed
+//         stages of all its blocks run once WITHOUT the limit, the HSPs of a query sequence and strand are ranked over the blocks as one
+//         search over the whole target ranks them (score; of equal scores the earlier found), and the jobs proper are given the last
+//         HSP kept (HspBestCut) instead of ranking their own block's (round 6; refused until then).  --queryhsplimit before a gapped
+//         stage, or together with --queryhspbest, over a target in several blocks is still refused.
 //
 // No data-path collective: block pairs are independent; the only exchange is this in-process gather of
 // the PAF lines.  The one-process-per-GPU form of the same sharding (torch.distributed, RCCL gather) is bench.py /
@@ -124,6 +127,7 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
     // ---- blocks and the job grid ---------------------------------------------------------------------------------
     std::vector<std::vector<Block>> tblk(n_pairs), qblk(n_pairs);
     std::vector<std::unique_ptr<Job>> jobs;
+    bool any_cut = false;                                  // --queryhspbest over a target in several blocks: two passes (below)
     for (size_t k = 0; k < n_pairs; k++) {
         const SeqSet &T = *Ts[k], &Q = *Qs[k];
         // Enough block pairs to occupy every device when the contigs allow it: the query side is split first (exact by
@@ -143,11 +147,12 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
             set_error("--miblast-diag=hash16 / --miblast-walls jobs are not assembled from blocks: input longer than 2^30 bases");
             return MIBLAST_ELIMIT;
         }
-        if (tblk[k].size() > 1 && (p.queryhspbest > 0 || (p.queryhsplimit > 0 && !general))) {
-            set_error("--queryhspbest (and --queryhsplimit before a gapped stage) rank HSPs over the whole target: not available when the target needs more than one block "
-                      "(KegAlign's option sets do not pass them, cactus_progressive_config.xml:138-146)");
+        if (tblk[k].size() > 1 && p.queryhsplimit > 0 && (p.queryhspbest > 0 || !general)) {
+            set_error("--queryhsplimit before a gapped stage (or together with --queryhspbest) cuts the HSP list of the whole target in found order: not available when the "
+                      "target needs more than one block (the repeat masker's --ungapped call is; KegAlign's option sets do not pass it, cactus_progressive_config.xml:138-146)");
             return MIBLAST_ELIMIT;
         }
+        if (tblk[k].size() > 1 && p.queryhspbest > 0) any_cut = true;
         for (size_t qb = 0; qb < qblk[k].size(); qb++)
             for (size_t tb = 0; tb < tblk[k].size(); tb++) {
                 std::unique_ptr<Job> j(new Job());
@@ -175,12 +180,14 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
     std::vector<int> dev_rc((size_t)n_dev, MIBLAST_OK);
     std::vector<std::string> dev_err((size_t)n_dev);
     std::vector<std::vector<std::pair<size_t, bool>>> dev_done((size_t)n_dev);      // (job, first of its batch)
+    std::vector<char> active(jobs.size(), 1);              // the jobs of the current pass
+    miblast_params p_run = p;                              // ... and its options
     auto device_main = [&](int d) {
         try {
             Ctx &ctx = *ctxs[(size_t)d];
             MB_HIP(hipSetDevice(ctx.device));
             std::vector<size_t> mine;
-            for (size_t x = 0; x < jobs.size(); x++) if (jobs[x]->device == d) mine.push_back(x);     // (pair, query block, target block) order
+            for (size_t x = 0; x < jobs.size(); x++) if (jobs[x]->device == d && active[x]) mine.push_back(x);     // (pair, query block, target block) order
             size_t at = 0;
             while (at < mine.size()) {
                 // a batch: block pairs that share one align_pairs() call (merged gapped launches), every block uploaded once
@@ -212,7 +219,7 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
                     bt.push_back(tsets[{j.pair, j.tb}].get()); bq.push_back(qsets[{j.pair, j.qb}].get()); br.push_back(&j.res);
                     at++;
                 }
-                const int rc = align_pairs(ctx, bt.data(), bq.data(), br.size(), p, br.data());
+                const int rc = align_pairs(ctx, bt.data(), bq.data(), br.size(), p_run, br.data());
                 if (rc != MIBLAST_OK) { dev_rc[(size_t)d] = rc; dev_err[(size_t)d] = last_error_text(); return; }
                 for (size_t x = first; x < at; x++) dev_done[(size_t)d].push_back({mine[x], x == first});
             }
@@ -225,14 +232,106 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
             dev_rc[(size_t)d] = MIBLAST_EHIP; dev_err[(size_t)d] = std::string("internal: ") + e.what();
         }
     };
-    if (n_dev == 1) device_main(0);
-    else {
-        std::vector<std::thread> th;
-        for (int d = 0; d < n_dev; d++) th.emplace_back(device_main, d);
-        for (std::thread &t : th) t.join();
+    auto run_pass = [&]() -> int {
+        for (auto &v : dev_done) v.clear();
+        if (n_dev == 1) device_main(0);
+        else {
+            std::vector<std::thread> th;
+            for (int d = 0; d < n_dev; d++) th.emplace_back(device_main, d);
+            for (std::thread &t : th) t.join();
+        }
+        for (int d = 0; d < n_dev; d++)
+            if (dev_rc[(size_t)d] != MIBLAST_OK) { set_error(dev_err[(size_t)d]); return dev_rc[(size_t)d]; }
+        return MIBLAST_OK;
+    };
+    // the word variant that made an HSP's seed hit (0 exact, 1 + k a transition at care position k): the 19 bases before the seed end in the
+    // target and in the searched strand of the query -- the '-' strand read off the '+' strand's codes, contig-wise mirrored
+    auto variant_of = [&](size_t k, const Block &TB, const Block &QB, const miblast_hsp &h) -> int {
+        const SeqSet &T = *Ts[k], &Q = *Qs[k];
+        const uint8_t *th = T.host(), *qh = Q.host();
+        uint8_t tw[kSeedSpan], qw[kSeedSpan];
+        const int64_t t_end = TB.origin + h.seed_t_end;
+        for (int c = 0; c < kSeedSpan; c++) tw[c] = th[t_end - kSeedSpan + c];
+        const int qc_g = QB.c0 + h.q_contig;
+        const int64_t cst = Q.starts[(size_t)qc_g], cln = Q.lens[(size_t)qc_g];
+        const int64_t q_in = (int64_t)h.seed_q_end - (cst - QB.origin);          // seed end inside the contig, on the searched strand
+        for (int c = 0; c < kSeedSpan; c++) {
+            const int64_t ps = q_in - kSeedSpan + c;
+            if (!h.strand) qw[c] = qh[cst + ps];
+            else { const uint8_t b = qh[cst + (cln - 1 - ps)]; qw[c] = (uint8_t)((b & 4u) ? b : (b & ~3u) | (3u - (b & 3u))); }
+        }
+        return seed_variant_rank(tw, qw);
+    };
+    // ---- --queryhspbest over a target in several blocks: what the whole target keeps ------------------------------------
+    // The seed stages of those jobs once without the limit (and without a gapped stage); per query sequence and strand the HSPs of all target
+    // blocks ranked as seed_host ranks one block's (mb_pipeline.cpp: score descending, of equal scores the earlier found -- query position,
+    // word variant, target position descending --, with hspbest_ties the later found); the N-th is the cut the jobs proper are given.
+    std::vector<std::vector<HspBestCut>> cuts;             // per (pair, query block) in job order: 2 x contigs of the block
+    std::vector<size_t> cut_of(jobs.size(), (size_t)-1);
+    if (any_cut) {
+        p_run.queryhspbest = 0; p_run.gapped = 0;
+        {
+            size_t x = 0;
+            for (size_t k = 0; k < n_pairs; k++) {
+                const size_t cnt = tblk[k].size() * qblk[k].size();
+                for (size_t e = 0; e < cnt; e++) active[x + e] = tblk[k].size() > 1;
+                x += cnt;
+            }
+        }
+        int rc = run_pass();
+        if (rc != MIBLAST_OK) return rc;
+        size_t x = 0;
+        for (size_t k = 0; k < n_pairs; k++) {
+            const size_t n_tb = tblk[k].size(), n_qb = qblk[k].size();
+            if (n_tb > 1)
+                for (size_t qb = 0; qb < n_qb; qb++) {
+                    const Block &QB = qblk[k][qb];
+                    struct Ent { int32_t qc, strand, score, q_end, rank; int64_t neg_t; };
+                    std::vector<Ent> ents;
+                    for (size_t tb = 0; tb < n_tb; tb++) {
+                        const Block &TB = tblk[k][tb];
+                        for (const miblast_hsp &h : jobs[x + qb * n_tb + tb]->res.hsps)
+                            ents.push_back(Ent{h.q_contig, h.strand, h.score, h.seed_q_end, variant_of(k, TB, QB, h), -(TB.origin + (int64_t)h.seed_t_end)});
+                    }
+                    const bool later = p.hspbest_ties != 0;
+                    std::sort(ents.begin(), ents.end(), [later](const Ent &a, const Ent &b) {
+                        if (a.qc != b.qc) return a.qc < b.qc;
+                        if (a.strand != b.strand) return a.strand < b.strand;
+                        if (a.score != b.score) return a.score > b.score;
+                        if (a.q_end != b.q_end) return later ? a.q_end > b.q_end : a.q_end < b.q_end;
+                        if (a.rank != b.rank) return later ? a.rank > b.rank : a.rank < b.rank;
+                        return later ? a.neg_t > b.neg_t : a.neg_t < b.neg_t;
+                    });
+                    std::vector<HspBestCut> cut(2 * (size_t)(QB.c1 - QB.c0));
+                    for (size_t i = 0; i < ents.size();) {
+                        size_t j = i;
+                        while (j < ents.size() && ents[j].qc == ents[i].qc && ents[j].strand == ents[i].strand) j++;
+                        if ((int64_t)(j - i) > (int64_t)p.queryhspbest) {
+                            const Ent &e = ents[i + (size_t)p.queryhspbest - 1];
+                            HspBestCut &c = cut[2 * (size_t)e.qc + (size_t)e.strand];
+                            c.active = 1; c.score = e.score; c.q_end = e.q_end; c.rank = e.rank; c.neg_t = e.neg_t;
+                        }
+                        i = j;
+                    }
+                    for (size_t tb = 0; tb < n_tb; tb++) cut_of[x + qb * n_tb + tb] = cuts.size();
+                    cuts.push_back(std::move(cut));
+                }
+            x += n_tb * n_qb;
+        }
+        x = 0;
+        for (size_t k = 0; k < n_pairs; k++)
+            for (size_t qb = 0; qb < qblk[k].size(); qb++)
+                for (size_t tb = 0; tb < tblk[k].size(); tb++, x++) {
+                    jobs[x]->res = Result();
+                    if (cut_of[x] != (size_t)-1) { jobs[x]->res.best_cut = &cuts[cut_of[x]]; jobs[x]->res.best_cut_t_origin = tblk[k][tb].origin; }
+                }
+        p_run = p;
+        std::fill(active.begin(), active.end(), 1);
     }
-    for (int d = 0; d < n_dev; d++)
-        if (dev_rc[(size_t)d] != MIBLAST_OK) { set_error(dev_err[(size_t)d]); return dev_rc[(size_t)d]; }
+    {
+        const int rc = run_pass();
+        if (rc != MIBLAST_OK) return rc;
+    }
 
     // ---- assembly in the order of one job over the whole files ------------------------------------------------------
     paf.clear();
@@ -248,7 +347,6 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
             const size_t n_tb = tblk[k].size(), n_qb = qblk[k].size();
             if (n_tb == 1 && n_qb == 1) { paf += jobs[x0]->res.paf; x0 += 1; continue; }      // (one block pair: the job's own text)
             paf += "#name1\tzstart1\tend1\tname2\tzstart2+\tend2+\n";
-            const uint8_t *th = T.host(), *qh = Q.host();
             for (size_t qb = 0; qb < n_qb; qb++) {
                 const Block &QB = qblk[k][qb];
                 struct Ent { int32_t qc, strand, q_end, rank; int64_t neg_t; const miblast_hsp *h; int64_t t_origin; };
@@ -257,20 +355,9 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
                     const Result &r = jobs[x0 + qb * n_tb + tb]->res;
                     const Block &TB = tblk[k][tb];
                     for (const miblast_hsp &h : r.hsps) {
-                        // the word variant that made the hit (0 exact, 1 + k a transition at care position k): the 19 bases before the seed end
-                        // in the target and in the searched strand of the query -- the '-' strand read off the '+' strand's codes, contig-wise mirrored
-                        uint8_t tw[kSeedSpan], qw[kSeedSpan];
                         const int64_t t_end = TB.origin + h.seed_t_end;
-                        for (int c = 0; c < kSeedSpan; c++) tw[c] = th[t_end - kSeedSpan + c];
                         const int qc_g = QB.c0 + h.q_contig;
-                        const int64_t cst = Q.starts[(size_t)qc_g], cln = Q.lens[(size_t)qc_g];
-                        const int64_t q_in = (int64_t)h.seed_q_end - (cst - QB.origin);          // seed end inside the contig, on the searched strand
-                        for (int c = 0; c < kSeedSpan; c++) {
-                            const int64_t ps = q_in - kSeedSpan + c;
-                            if (!h.strand) qw[c] = qh[cst + ps];
-                            else { const uint8_t b = qh[cst + (cln - 1 - ps)]; qw[c] = (uint8_t)((b & 4u) ? b : (b & ~3u) | (3u - (b & 3u))); }
-                        }
-                        ents.push_back(Ent{qc_g, h.strand, h.seed_q_end, seed_variant_rank(tw, qw), -t_end, &h, TB.origin});
+                        ents.push_back(Ent{qc_g, h.strand, h.seed_q_end, variant_of(k, TB, QB, h), -t_end, &h, TB.origin});
                     }
                 }
                 std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) {

@@ -1513,6 +1513,25 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
             hs.resize(wr); anc.resize(wr);
         }
         // --queryhspbest=N per query contig and strand: N best scores, ties to the earlier found
+        if (p.queryhspbest > 0 && job.res->best_cut) {
+            // the target is one block of several (mb_multi.cpp): which HSPs the WHOLE target keeps was ranked over all blocks -- an HSP stays when
+            // it is not behind the last one kept (score first; of equal scores the earlier found, or with hspbest_ties the later found)
+            const std::vector<HspBestCut> &cuts = *job.res->best_cut;
+            size_t wr = 0;
+            for (size_t k = 0; k < hs.size(); k++) {
+                const HspBestCut &c = cuts[2 * (size_t)hs[k].q_contig + (size_t)strand];
+                bool keep = true;
+                if (c.active && hs[k].score != c.score) keep = hs[k].score > c.score;
+                else if (c.active) {
+                    const int32_t rank = variant_rank(tc_h, qc_h[strand], hs[k].seed_t_end, hs[k].seed_q_end);
+                    const int64_t neg_t = -(job.res->best_cut_t_origin + (int64_t)hs[k].seed_t_end);
+                    const int cmp = hs[k].seed_q_end != c.q_end ? (hs[k].seed_q_end < c.q_end ? -1 : 1) : rank != c.rank ? (rank < c.rank ? -1 : 1) : neg_t != c.neg_t ? (neg_t < c.neg_t ? -1 : 1) : 0;
+                    keep = p.hspbest_ties ? cmp >= 0 : cmp <= 0;
+                }
+                if (keep) { anc[wr] = anc[k]; hs[wr++] = hs[k]; }
+            }
+            hs.resize(wr); anc.resize(wr);
+        } else
         if (p.queryhspbest > 0) {
             std::vector<std::vector<size_t>> by_contig(Q.starts.size());
             for (size_t k = 0; k < hs.size(); k++) by_contig[(size_t)hs[k].q_contig].push_back(k);

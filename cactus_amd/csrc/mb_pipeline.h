@@ -30,7 +30,15 @@ struct Ctx {
 };
 void chain_cache_destroy(void *cache);  // mp_chain.cpp
 
+// --queryhspbest over a target that needs several blocks (mb_multi.cpp): the last HSP the whole target keeps for a query sequence and strand --
+// its score and its place in the order a sequential search finds HSPs (query position, word variant, whole-target position descending)
+struct HspBestCut { int32_t active = 0, score = 0, q_end = 0, rank = 0; int64_t neg_t = 0; };
+
 struct Result {
+    // set by mb_multi.cpp before the call, read by the seed stage's host half instead of ranking the block's own HSPs: cut[2 * contig + strand]
+    // for the contigs of the query block; t_origin: the target block's first base in the whole target
+    const std::vector<HspBestCut> *best_cut = nullptr;
+    int64_t best_cut_t_origin = 0;
     std::string paf;
     std::vector<miblast_hsp> hsps;
     std::vector<miblast_aln> alns;

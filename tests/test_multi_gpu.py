@@ -168,14 +168,69 @@ def test_repeat_mask_call_assembled_from_blocks_equals_one_oracle_run(olz, monke
     assert two == want["paf"]
 
 
+def _copies_of_a_unit(seed):
+    """A target whose contigs hold copies of one 600-base unit -- three of them the unit itself and nothing else (HSPs of EQUAL score in
+    different target blocks: the extension ends at the contig's ends), others mutated, one reverse-complemented -- and query sequences that
+    are the unit, its reverse complement, a mutated copy and a copy inside random sequence: every query sequence has more HSPs than a small
+    --queryhspbest keeps, spread over the blocks."""
+    from cactus_amd import gen
+    rng = np.random.default_rng(seed)
+    unit = gen.random_sequence(600, rng)
+    rnd = lambda n: gen.random_sequence(n, rng)                      # noqa: E731
+    trecs = [("id=T|a", np.concatenate([rnd(1200), gen.mutate(unit, rng, 0.04, 0.0), rnd(900)])),
+             ("id=T|u1", unit.copy()),
+             ("id=T|b", rnd(2500)),
+             ("id=T|m", gen.mutate(unit, rng, 0.03, 0.002)),
+             ("id=T|u2", unit.copy()),
+             ("id=T|c", np.concatenate([rnd(700), gen.revcomp(unit), rnd(1500), gen.mutate(unit, rng, 0.08, 0.0)])),
+             ("id=T|u3", unit.copy()),
+             ("id=T|d", np.concatenate([rnd(1000), gen.mutate(unit, rng, 0.06, 0.004), rnd(300)]))]
+    qrecs = [("id=Q|u", unit.copy()), ("id=Q|rc", gen.revcomp(unit)), ("id=Q|m", gen.mutate(unit, rng, 0.02, 0.0)),
+             ("id=Q|in", np.concatenate([rnd(500), unit, rnd(500)]))]
+    return gen.fasta_bytes(trecs), gen.fasta_bytes(qrecs)
+
+
+@pytest.mark.parametrize("best,ties", [(2, "earlier"), (2, "later"), (1, "earlier"), (5, "earlier"), (3, "later")])
+def test_queryhspbest_over_target_blocks_equals_one_oracle_run(olz, monkeypatch, best, ties):
+    """--queryhspbest=N (every option set of cactus_progressive_config.xml:131-136 passes it) on a target that needs SEVERAL blocks (round 6;
+    refused until then): the N best HSPs of a query sequence and strand are the N best over the WHOLE target -- ranked over the blocks, of
+    equal scores the earlier (or, A.9 #11, the later) found in the order one search over the whole target finds them -- and the gapped stage
+    starts from exactly those: the bytes and counters of ONE oracle run over the whole files, with one and with two logical devices."""
+    from cactus_amd import miblast
+    tf, qf = _copies_of_a_unit(500 + best)
+    args = [a for a in DEFAULT if not a.startswith("--queryhspbest")] + ["--queryhspbest=%d" % best, "--miblast-hspbest-ties=" + ties]
+    pm, want = _oracle(olz, tf, qf, args)
+    _, unlimited = _oracle(olz, tf, qf, [a for a in args if not a.startswith("--queryhspbest")])
+    assert want["counters"]["hsps"] < unlimited["counters"]["hsps"] and want["paf"] != unlimited["paf"]          # (the limit binds)
+    assert want["paf"].count(b"\n") >= 4
+    m = miblast.Multi(1)
+    try:
+        whole, _ = m.align_fasta_pairs([(tf, qf)], pm)
+        assert whole == want["paf"]
+        monkeypatch.setenv("MIBLAST_BLOCK_BASES", "3600")          # the unit's exact copies in three different target blocks
+        blocked, st = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert blocked == want["paf"]
+    for k in ("hsps", "anchors", "anchors_skipped", "dp_sides", "dp_cells", "dp_rows", "alignments"):
+        assert st[k] == want["counters"][k], k
+    monkeypatch.setenv("MIBLAST_DEVICE_MAP", "0,0")
+    m = miblast.Multi(2)
+    try:
+        two, _ = m.align_fasta_pairs([(tf, qf)], pm)
+    finally:
+        m.close()
+    assert two == want["paf"]
+
+
 def test_limits_of_the_blocked_path_are_refused_loudly(monkeypatch):
     from cactus_amd import miblast
     tf, qf = genome_like(404)
     monkeypatch.setenv("MIBLAST_BLOCK_BASES", "14000")         # every contig fits, the target needs several blocks
     m = miblast.Multi(1)
     try:
-        with pytest.raises(miblast.MiblastError, match="queryhspbest"):
-            m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(DEFAULT))
+        with pytest.raises(miblast.MiblastError, match="queryhsplimit"):
+            m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(KEG_DEFAULT + ["--queryhsplimit=keep,nowarn:5"]))
         monkeypatch.setenv("MIBLAST_BLOCK_BASES", "2000")          # smaller than a contig
         with pytest.raises(miblast.MiblastError, match="longer than"):
             m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(KEG_DEFAULT))
