@@ -22,8 +22,8 @@
 //       - --queryhspbest=N ranks a query sequence's HSPs over the whole target: when the target needs more than one block the seed
 //         stages of all its blocks run once WITHOUT the limit, the HSPs of a query sequence and strand are ranked over the blocks as one
 //         search over the whole target ranks them (score; of equal scores the earlier found), and the jobs proper are given the last
-//         HSP kept (HspBestCut) instead of ranking their own block's (round 6; refused until then).  --queryhsplimit before a gapped
-//         stage, or together with --queryhspbest, over a target in several blocks is still refused.
+//         HSP kept (HspBestCut) instead of ranking their own block's (round 6; refused until then).  --queryhsplimit=N in front of a
+//         gapped stage (or of --queryhspbest) the same way: the whole target's first N in found order, the last of them the cut.
 //
 // No data-path collective: block pairs are independent; the only exchange is this in-process gather of
 // the PAF lines.  The one-process-per-GPU form of the same sharding (torch.distributed, RCCL gather) is bench.py /
@@ -147,12 +147,7 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
             set_error("--miblast-diag=hash16 / --miblast-walls jobs are not assembled from blocks: input longer than 2^30 bases");
             return MIBLAST_ELIMIT;
         }
-        if (tblk[k].size() > 1 && p.queryhsplimit > 0 && (p.queryhspbest > 0 || !general)) {
-            set_error("--queryhsplimit before a gapped stage (or together with --queryhspbest) cuts the HSP list of the whole target in found order: not available when the "
-                      "target needs more than one block (the repeat masker's --ungapped call is; KegAlign's option sets do not pass it, cactus_progressive_config.xml:138-146)");
-            return MIBLAST_ELIMIT;
-        }
-        if (tblk[k].size() > 1 && p.queryhspbest > 0) any_cut = true;
+        if (tblk[k].size() > 1 && (p.queryhspbest > 0 || (p.queryhsplimit > 0 && !general))) any_cut = true;
         for (size_t qb = 0; qb < qblk[k].size(); qb++)
             for (size_t tb = 0; tb < tblk[k].size(); tb++) {
                 std::unique_ptr<Job> j(new Job());
@@ -269,7 +264,7 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
     std::vector<std::vector<HspBestCut>> cuts;             // per (pair, query block) in job order: 2 x contigs of the block
     std::vector<size_t> cut_of(jobs.size(), (size_t)-1);
     if (any_cut) {
-        p_run.queryhspbest = 0; p_run.gapped = 0;
+        p_run.queryhspbest = 0; p_run.gapped = 0;          // (--queryhsplimit stays: a block's own first N hold the whole target's that lie in it)
         {
             size_t x = 0;
             for (size_t k = 0; k < n_pairs; k++) {
@@ -294,21 +289,36 @@ int align_blocked(const std::vector<Ctx *> &ctxs, const SeqSet *const *Ts, const
                             ents.push_back(Ent{h.q_contig, h.strand, h.score, h.seed_q_end, variant_of(k, TB, QB, h), -(TB.origin + (int64_t)h.seed_t_end)});
                     }
                     const bool later = p.hspbest_ties != 0;
-                    std::sort(ents.begin(), ents.end(), [later](const Ent &a, const Ent &b) {
+                    auto found_before = [](const Ent &a, const Ent &b) {
+                        if (a.q_end != b.q_end) return a.q_end < b.q_end;
+                        if (a.rank != b.rank) return a.rank < b.rank;
+                        return a.neg_t < b.neg_t;
+                    };
+                    auto ranked_before = [later, found_before](const Ent &a, const Ent &b) {
+                        if (a.score != b.score) return a.score > b.score;
+                        return later ? found_before(b, a) : found_before(a, b);
+                    };
+                    std::sort(ents.begin(), ents.end(), [ranked_before](const Ent &a, const Ent &b) {
                         if (a.qc != b.qc) return a.qc < b.qc;
                         if (a.strand != b.strand) return a.strand < b.strand;
-                        if (a.score != b.score) return a.score > b.score;
-                        if (a.q_end != b.q_end) return later ? a.q_end > b.q_end : a.q_end < b.q_end;
-                        if (a.rank != b.rank) return later ? a.rank > b.rank : a.rank < b.rank;
-                        return later ? a.neg_t > b.neg_t : a.neg_t < b.neg_t;
+                        return ranked_before(a, b);
                     });
                     std::vector<HspBestCut> cut(2 * (size_t)(QB.c1 - QB.c0));
                     for (size_t i = 0; i < ents.size();) {
                         size_t j = i;
                         while (j < ents.size() && ents[j].qc == ents[i].qc && ents[j].strand == ents[i].strand) j++;
-                        if ((int64_t)(j - i) > (int64_t)p.queryhspbest) {
+                        HspBestCut &c = cut[2 * (size_t)ents[i].qc + (size_t)ents[i].strand];
+                        size_t n_in = j - i;
+                        if (p.queryhsplimit > 0 && (int64_t)n_in > (int64_t)p.queryhsplimit) {
+                            // the whole target's first N in found order (every block kept its own first N: they are among those), the rest leaves the ranking
+                            std::sort(ents.begin() + (long)i, ents.begin() + (long)j, found_before);
+                            n_in = (size_t)p.queryhsplimit;
+                            const Ent &e = ents[i + n_in - 1];
+                            c.lim_active = 1; c.lim_q_end = e.q_end; c.lim_rank = e.rank; c.lim_neg_t = e.neg_t;
+                            std::sort(ents.begin() + (long)i, ents.begin() + (long)(i + n_in), ranked_before);
+                        }
+                        if (p.queryhspbest > 0 && (int64_t)n_in > (int64_t)p.queryhspbest) {
                             const Ent &e = ents[i + (size_t)p.queryhspbest - 1];
-                            HspBestCut &c = cut[2 * (size_t)e.qc + (size_t)e.strand];
                             c.active = 1; c.score = e.score; c.q_end = e.q_end; c.rank = e.rank; c.neg_t = e.neg_t;
                         }
                         i = j;

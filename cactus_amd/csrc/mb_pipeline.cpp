@@ -1513,20 +1513,28 @@ static void seed_host(const miblast_params &p, PairJob &job, int strand) {
             hs.resize(wr); anc.resize(wr);
         }
         // --queryhspbest=N per query contig and strand: N best scores, ties to the earlier found
-        if (p.queryhspbest > 0 && job.res->best_cut) {
-            // the target is one block of several (mb_multi.cpp): which HSPs the WHOLE target keeps was ranked over all blocks -- an HSP stays when
-            // it is not behind the last one kept (score first; of equal scores the earlier found, or with hspbest_ties the later found)
+        if (job.res->best_cut && (p.queryhspbest > 0 || p.queryhsplimit > 0)) {
+            // the target is one block of several (mb_multi.cpp): which HSPs the WHOLE target keeps was decided over all blocks.  --queryhsplimit: an
+            // HSP stays when it is not behind the last of the whole target's first N in found order (the block's own first N, above, hold them);
+            // --queryhspbest: when it is not behind the last one kept (score first; of equal scores the earlier found, or with hspbest_ties
+            // the later found)
             const std::vector<HspBestCut> &cuts = *job.res->best_cut;
             size_t wr = 0;
             for (size_t k = 0; k < hs.size(); k++) {
                 const HspBestCut &c = cuts[2 * (size_t)hs[k].q_contig + (size_t)strand];
+                int32_t rank = -1;
+                const int64_t neg_t = -(job.res->best_cut_t_origin + (int64_t)hs[k].seed_t_end);
+                auto found_order = [&](int32_t q_end, int32_t c_rank, int64_t c_neg_t) -> int {      // -1: found before the cut's HSP, 0: it is that HSP, 1: after
+                    if (hs[k].seed_q_end != q_end) return hs[k].seed_q_end < q_end ? -1 : 1;
+                    if (rank < 0) rank = variant_rank(tc_h, qc_h[strand], hs[k].seed_t_end, hs[k].seed_q_end);
+                    if (rank != c_rank) return rank < c_rank ? -1 : 1;
+                    return neg_t != c_neg_t ? (neg_t < c_neg_t ? -1 : 1) : 0;
+                };
                 bool keep = true;
-                if (c.active && hs[k].score != c.score) keep = hs[k].score > c.score;
-                else if (c.active) {
-                    const int32_t rank = variant_rank(tc_h, qc_h[strand], hs[k].seed_t_end, hs[k].seed_q_end);
-                    const int64_t neg_t = -(job.res->best_cut_t_origin + (int64_t)hs[k].seed_t_end);
-                    const int cmp = hs[k].seed_q_end != c.q_end ? (hs[k].seed_q_end < c.q_end ? -1 : 1) : rank != c.rank ? (rank < c.rank ? -1 : 1) : neg_t != c.neg_t ? (neg_t < c.neg_t ? -1 : 1) : 0;
-                    keep = p.hspbest_ties ? cmp >= 0 : cmp <= 0;
+                if (c.lim_active && p.queryhsplimit > 0) keep = found_order(c.lim_q_end, c.lim_rank, c.lim_neg_t) <= 0;
+                if (keep && c.active && p.queryhspbest > 0) {
+                    if (hs[k].score != c.score) keep = hs[k].score > c.score;
+                    else { const int cmp = found_order(c.q_end, c.rank, c.neg_t); keep = p.hspbest_ties ? cmp >= 0 : cmp <= 0; }
                 }
                 if (keep) { anc[wr] = anc[k]; hs[wr++] = hs[k]; }
             }

@@ -30,9 +30,14 @@ struct Ctx {
 };
 void chain_cache_destroy(void *cache);  // mp_chain.cpp
 
-// --queryhspbest over a target that needs several blocks (mb_multi.cpp): the last HSP the whole target keeps for a query sequence and strand --
-// its score and its place in the order a sequential search finds HSPs (query position, word variant, whole-target position descending)
-struct HspBestCut { int32_t active = 0, score = 0, q_end = 0, rank = 0; int64_t neg_t = 0; };
+// --queryhspbest (and --queryhsplimit in front of a gapped stage) over a target that needs several blocks (mb_multi.cpp): the last HSP the whole
+// target keeps for a query sequence and strand -- its score and its place in the order a sequential search finds HSPs (query position, word
+// variant, whole-target position descending)
+struct HspBestCut {
+    int32_t active = 0, score = 0, q_end = 0, rank = 0; int64_t neg_t = 0;
+    // --queryhsplimit in front of it (or of a gapped stage): the last HSP of the whole target's first N in found order
+    int32_t lim_active = 0, lim_q_end = 0, lim_rank = 0; int64_t lim_neg_t = 0;
+};
 
 struct Result {
     // set by mb_multi.cpp before the call, read by the seed stage's host half instead of ranking the block's own HSPs: cut[2 * contig + strand]

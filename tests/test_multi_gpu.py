@@ -190,17 +190,27 @@ def _copies_of_a_unit(seed):
     return gen.fasta_bytes(trecs), gen.fasta_bytes(qrecs)
 
 
-@pytest.mark.parametrize("best,ties", [(2, "earlier"), (2, "later"), (1, "earlier"), (5, "earlier"), (3, "later")])
-def test_queryhspbest_over_target_blocks_equals_one_oracle_run(olz, monkeypatch, best, ties):
+@pytest.mark.parametrize("best,ties,limit", [(2, "earlier", 0), (2, "later", 0), (1, "earlier", 0), (5, "earlier", 0), (3, "later", 0),
+                                             (0, "earlier", 3), (0, "earlier", 1), (1, "later", 2), (2, "later", 3), (3, "earlier", 4)])
+def test_queryhspbest_over_target_blocks_equals_one_oracle_run(olz, monkeypatch, best, ties, limit):
     """--queryhspbest=N (every option set of cactus_progressive_config.xml:131-136 passes it) on a target that needs SEVERAL blocks (round 6;
     refused until then): the N best HSPs of a query sequence and strand are the N best over the WHOLE target -- ranked over the blocks, of
     equal scores the earlier (or, A.9 #11, the later) found in the order one search over the whole target finds them -- and the gapped stage
-    starts from exactly those: the bytes and counters of ONE oracle run over the whole files, with one and with two logical devices."""
+    starts from exactly those: the bytes and counters of ONE oracle run over the whole files, with one and with two logical devices.
+    limit: --queryhsplimit=keep,nowarn:N in front of the gapped stage (and of --queryhspbest) the same way -- the whole target's first N in
+    found order."""
     from cactus_amd import miblast
-    tf, qf = _copies_of_a_unit(500 + best)
-    args = [a for a in DEFAULT if not a.startswith("--queryhspbest")] + ["--queryhspbest=%d" % best, "--miblast-hspbest-ties=" + ties]
+    tf, qf = _copies_of_a_unit(500 + best + 10 * limit)
+    args = [a for a in DEFAULT if not a.startswith("--queryhspbest")] + ["--miblast-hspbest-ties=" + ties]
+    if best:
+        args.append("--queryhspbest=%d" % best)
+    if limit:
+        args.append("--queryhsplimit=keep,nowarn:%d" % limit)
     pm, want = _oracle(olz, tf, qf, args)
-    _, unlimited = _oracle(olz, tf, qf, [a for a in args if not a.startswith("--queryhspbest")])
+    _, unlimited = _oracle(olz, tf, qf, [a for a in args if not a.startswith("--queryhsp")])
+    if best and limit:
+        _, only_best = _oracle(olz, tf, qf, [a for a in args if not a.startswith("--queryhsplimit")])
+        assert only_best["paf"] != want["paf"]                       # (the limit in front changes what the ranking sees)
     assert want["counters"]["hsps"] < unlimited["counters"]["hsps"] and want["paf"] != unlimited["paf"]          # (the limit binds)
     assert want["paf"].count(b"\n") >= 4
     m = miblast.Multi(1)
@@ -229,8 +239,6 @@ def test_limits_of_the_blocked_path_are_refused_loudly(monkeypatch):
     monkeypatch.setenv("MIBLAST_BLOCK_BASES", "14000")         # every contig fits, the target needs several blocks
     m = miblast.Multi(1)
     try:
-        with pytest.raises(miblast.MiblastError, match="queryhsplimit"):
-            m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(KEG_DEFAULT + ["--queryhsplimit=keep,nowarn:5"]))
         monkeypatch.setenv("MIBLAST_BLOCK_BASES", "2000")          # smaller than a contig
         with pytest.raises(miblast.MiblastError, match="longer than"):
             m.align_fasta_pairs([(tf, qf)], miblast.params_from_args(KEG_DEFAULT))
