@@ -461,11 +461,15 @@ class ChunkWorkload:
                 by_unit[idx] = paf
         assert sorted(by_unit) == list(range(len(self.units))), "a work unit is missing from the gather"
         by_index = {}
+        names = self.__dict__.setdefault("_qnames", {})    # record names of a query chunk, read off its FASTA once (not once per step: 30 Mb of text)
         for u, (k, sc) in enumerate(self.units):
             if sc == 0:
                 by_index[k] = by_unit[u]
             elif sc == 1:                                   # (its '-' half is the next unit)
-                by_index[k] = merge_strand_pafs(by_unit[u], by_unit[u + 1], fasta_names(self.qfa[self.pairs[k][1]]))
+                qi = self.pairs[k][1]
+                if qi not in names:
+                    names[qi] = fasta_names(self.qfa[qi])
+                by_index[k] = merge_strand_pafs(by_unit[u], by_unit[u + 1], names[qi])
         self.by_index = by_index
         return b"".join(by_index[k] for k in range(len(self.pairs)))
 
