@@ -3982,7 +3982,7 @@ static void output_layout(const miblast_params &p, PairJob &job, OutputJob &oj) 
 // A lane's seed-stage buffers sized for the largest strand the call's context has met, at the lane's START -- before it takes a pair: a lane
 // that the others leave no pair in one step (they are taken from a queue) would otherwise make these allocations in the middle of a later
 // step, and a device allocation while other lanes keep the device busy stalls every lane (seed_phase).
-static void presize_lane(Ctx &lc, int64_t max_diags) {
+static void presize_lane(Ctx &lc, int64_t max_diags, int64_t max_q) {
     if (!lc.hits_hint) return;
     Workspace &w = *lc.ws;
     w.presize_gapped();                                    // the gapped stage's tables at the largest size any lane of the context has needed
@@ -4000,6 +4000,15 @@ static void presize_lane(Ctx &lc, int64_t max_diags) {
         (void)ux_scratch(w, nullptr, want, (int64_t)1 << diag_bits);
         w.sort_temp.ensure(sort_keys_temp_bytes((int64_t)want, 32 + diag_bits) + 16);
         w.extent.ensure(((size_t)1 << diag_bits) + 8);
+        // ... and what the two-pass search keeps per query position and per batch (the lane that had the call's small pairs so far met the large one
+        // in a later step and made these anew: hm30, 13 allocations in the first timed steps of most runs)
+        const int64_t nq = std::max<int64_t>(1, max_q);
+        w.qcnt.ensure((size_t)nq); w.hit_off.ensure((size_t)nq);
+        w.qbsum.ensure((size_t)((nq + 2047) / 2048) + 2); w.scan_scratch.ensure((size_t)((nq + 2047) / 2048) + 2);
+        if (env_long("MIBLAST_SEED_ORDERED", 1) != 0 && env_long("MIBLAST_SORT_BIN", 1) != 0) {
+            const int bin_mean = (int)std::max<long>(1, env_long("MIBLAST_BIN_MEAN", 11000));
+            w.bin_state.ensure(2 * (size_t)bin_state_words()); w.bin_matrix.ensure(2 * (size_t)bin_matrix_words_for(bin_keys_max(), diag_bits, bin_mean));
+        }
         return;
     }
     const size_t want = (size_t)(hint + hint / 8);
@@ -4100,6 +4109,8 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
         for (Ctx *l : w.lanes) { l->spans = ctx.spans; l->hits_hint = &w.hits_hint; l->ws->share_marks(w); }
         int64_t max_diags = 0;
         for (size_t k = 0; k < n; k++) max_diags = std::max<int64_t>(max_diags, Ts[k]->total + Qs[k]->total);
+        int64_t max_q = 0;
+        for (size_t k = 0; k < n; k++) max_q = std::max<int64_t>(max_q, Qs[k]->total);
         std::vector<int> lane_rc(n_lanes, MIBLAST_OK);
         std::vector<std::string> lane_err(n_lanes);
         std::vector<std::future<void>> lane_threads;
@@ -4120,7 +4131,7 @@ static int align_pairs_impl(Ctx &ctx, const SeqSet *const *Ts, const SeqSet *con
                 try {
                     MB_HIP(hipSetDevice(ctx.device));
                     Ctx &lc = *w.lanes[lane];
-                    presize_lane(lc, max_diags);
+                    presize_lane(lc, max_diags, max_q);
                     for (size_t k0 = pipeline ? next_pair.fetch_add(group) : lane; k0 < n; k0 = pipeline ? next_pair.fetch_add(group) : k0 + n_lanes) {
                         std::vector<size_t> mem;
                         for (size_t k = k0; k < std::min(n, k0 + group); k++) {
