@@ -6,7 +6,13 @@ from cactus_amd import gen, miblast
 from oracle import olz
 
 KEYS = ["seed_lookups", "seed_hits", "hits_extended", "ungapped_cols", "hsps_pre_entropy", "hsps", "anchors", "anchors_skipped", "dp_sides", "dp_cells", "dp_rows", "alignments"]
-ctx = miblast.Context(0)
+# FUZZ_WRITE_DIGESTS=<file>: no GPU -- the oracle's answer of every case (md5 of the PAF, counters, record counts) into <file> (JSON; run on the CPU box,
+# several processes side by side for chunk-scale cases); FUZZ_READ_DIGESTS=<file>: no oracle -- the GPU's answers against that file (the oracle's time
+# stays off the GPU box).  Neither: both run here, everything compared.
+import hashlib, json
+WRITE, READ = os.environ.get("FUZZ_WRITE_DIGESTS"), os.environ.get("FUZZ_READ_DIGESTS")
+ctx = None if WRITE else miblast.Context(0)
+digests = json.load(open(READ)) if READ else {}
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad = 0
@@ -59,10 +65,24 @@ for case in range(n_cases):
     else: args.append("--format=paf:wfmash")
     print('case', case, 'kind', kind, 'n', n, ' '.join(args), flush=True) if os.environ.get('FUZZ_VERBOSE') else None
     pm = miblast.params_from_args(args)
+    if WRITE:
+        want = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}))
+        digests[str(seed0 + case)] = {"args": " ".join(args), "kind": kind, "n": n, "paf_md5": hashlib.md5(want["paf"]).hexdigest(), "counters": {k: int(want["counters"][k]) for k in KEYS},
+                                      "n_hsps": len(want["hsps"]), "n_alns": len(want["alns"]), "n_ops": len(want["ops"])}
+        json.dump(digests, open(WRITE, "w"), indent=1, sort_keys=True)
+        continue
     T, Q = ctx.seqset_from_fasta_bytes(tf), ctx.seqset_from_fasta_bytes(qf)
     got = ctx.align(T, Q, pm)
-    want = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}))
     T.close(); Q.close()
+    if READ:
+        d = digests[str(seed0 + case)]
+        assert d["args"] == " ".join(args) and d["n"] == n, "the digest file was made for other cases"
+        ok = hashlib.md5(got.paf).hexdigest() == d["paf_md5"] and all(got.stats[k] == d["counters"][k] for k in KEYS) and (len(got.hsps), len(got.alns), len(got.ops)) == (d["n_hsps"], d["n_alns"], d["n_ops"])
+        if not ok:
+            bad += 1
+            print("MISMATCH case", case, "seed", seed0 + case, "kind", kind, "n", n, "args", " ".join(args), {k: (d["counters"][k], got.stats[k]) for k in KEYS if got.stats[k] != d["counters"][k]})
+        continue
+    want = olz.align(tf, qf, olz.default_params(**{f: getattr(pm, f) for f, _ in pm._fields_}))
     ok = got.paf == want["paf"] and got.hsps == want["hsps"] and got.alns == want["alns"] and got.ops == want["ops"] and all(got.stats[k] == want["counters"][k] for k in KEYS)
     if not ok:
         bad += 1

@@ -1061,3 +1061,16 @@ def test_the_cheap_a9_switches_on_the_device_equal_the_oracles(gpu_ctx, olz, mon
         T, Q = gpu_ctx.seqset_from_fasta_bytes(tf), gpu_ctx.seqset_from_fasta_bytes(qf)
         with pytest.raises(miblast.MiblastError):
             gpu_ctx.align(T, Q, pm)
+
+
+@pytest.mark.parametrize("seed", [22003, 22005, 23008, 23024])
+def test_chunk_scale_random_cases_against_committed_oracle_digests(seed):
+    """Chunk-scale cases of the randomised differential run (scripts/gpu_fuzz.py: 1.7 - 2.6 Mb pairs of every structure, random option sets) against
+    tests/golden/fuzz_chunk_r06.json -- the oracle's answers (md5 of the PAF, twelve counters, record counts), made beforehand by the same script with
+    FUZZ_WRITE_DIGESTS on the CPU box (50 cases, 40 CPU-minutes; scripts/gpu_r6_fuzz3.sh runs them all): near-identity with 20 000 alignments, N runs
+    under --ydrop=20000, 7 - 11 million seed hits under --step=1."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_NMIN="1700000", FUZZ_NMAX="2600000", FUZZ_READ_DIGESTS=os.path.join(root, "tests", "golden", "fuzz_chunk_r06.json"))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz.py"), "1", str(seed)], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "1 cases, 0 mismatches" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
