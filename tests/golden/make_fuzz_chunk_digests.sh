@@ -11,12 +11,16 @@ for i in 0 1 2 3 4 5; do FUZZ_WRITE_DIGESTS=$TMP/d_$i.json python scripts/gpu_fu
 wait
 for i in 0 1 2 3 4 5 6; do FUZZ_WRITE_DIGESTS=$TMP/e_$i.json python scripts/gpu_fuzz.py 6 $((23000 + 6 * i)) > $TMP/e_$i.log 2>&1 & done
 wait
+export FUZZ_NMIN=4000000 FUZZ_NMAX=6000000          # -> fuzz_chunk_r06_large.json (20 minutes more)
+for i in 0 1 2 3 4 5 6; do FUZZ_WRITE_DIGESTS=$TMP/L_$i.json python scripts/gpu_fuzz.py 1 $((24000 + i)) > $TMP/L_$i.log 2>&1 & done
+wait
 python - "$TMP" <<'PY'
 import glob, json, sys
-m = {}
-for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
-    m.update(json.load(open(f)))
-json.dump(m, open("tests/golden/fuzz_chunk_r06.json", "w"), indent=1, sort_keys=True)
-print(len(m), "cases")
+for pat, out in (("/[de]_*.json", "tests/golden/fuzz_chunk_r06.json"), ("/L_*.json", "tests/golden/fuzz_chunk_r06_large.json")):
+    m = {}
+    for f in sorted(glob.glob(sys.argv[1] + pat)):
+        m.update(json.load(open(f)))
+    json.dump(m, open(out, "w"), indent=1, sort_keys=True)
+    print(out, len(m), "cases")
 PY
 rm -rf "$TMP"
